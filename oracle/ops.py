@@ -1,0 +1,272 @@
+"""Oracle primitives: numpy restatements of the TF-1.x ops the reference graph uses.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Every function works in the
+dtype of its inputs (float64 for parity checks, float32 for the timed
+`cpu_baseline` leg of bench.py).  Layouts are the reference's boundary
+layouts: activations NHWC, conv weights HWIO `[kh,kw,Cin,Cout]`, FC weights
+`[in,out]`.  TF semantics follow SURVEY.md Appendix A.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# TF 'SAME' padding  (Appendix A.1; used implicitly by every layers.conv2d in
+# nets/sphere.py:41-42,57,61,65,69 -- padding is never overridden there).
+# --------------------------------------------------------------------------
+def same_pads(in_size, k, stride):
+    out = -(-in_size // stride)                      # ceil(in/stride)
+    total = max((out - 1) * stride + k - in_size, 0)
+    before = total // 2
+    return out, before, total - before
+
+
+def _pad_nhwc(x, pt, pb, pl, pr):
+    if pt == pb == pl == pr == 0:
+        return x
+    return np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+
+
+def _im2col(xp, kh, kw, stride, ho, wo):
+    """[N,Hp,Wp,C] -> [N*ho*wo, kh*kw*C] with k ordered (r, s, c) == HWIO rows."""
+    n, hp, wp, c = xp.shape
+    s0, s1, s2, s3 = xp.strides
+    view = np.lib.stride_tricks.as_strided(
+        xp, shape=(n, ho, wo, kh, kw, c),
+        strides=(s0, s1 * stride, s2 * stride, s1, s2, s3), writeable=False)
+    return np.ascontiguousarray(view).reshape(n * ho * wo, kh * kw * c)
+
+
+def conv2d_fwd(x, w, stride=1, bias=None):
+    """layers.conv2d(padding='SAME') linear part: NHWC x HWIO -> NHWC (nets/sphere.py:41,57)."""
+    n, h, wd, c = x.shape
+    kh, kw, ci, co = w.shape
+    assert ci == c
+    ho, pt, pb = same_pads(h, kh, stride)
+    wo, pl, pr = same_pads(wd, kw, stride)
+    cols = _im2col(_pad_nhwc(x, pt, pb, pl, pr), kh, kw, stride, ho, wo)
+    z = cols @ w.reshape(kh * kw * ci, co)
+    if bias is not None:
+        z = z + bias
+    return z.reshape(n, ho, wo, co)
+
+
+def conv2d_bwd(x, w, dz, stride=1, need_dx=True):
+    """Gradients of conv2d_fwd wrt x and w (what tf.gradients lowers to:
+    Conv2DBackpropInput / Conv2DBackpropFilter; data_parallel.py:33)."""
+    n, h, wd, c = x.shape
+    kh, kw, ci, co = w.shape
+    ho, pt, pb = same_pads(h, kh, stride)
+    wo, pl, pr = same_pads(wd, kw, stride)
+    xp = _pad_nhwc(x, pt, pb, pl, pr)
+    cols = _im2col(xp, kh, kw, stride, ho, wo)
+    dz2 = dz.reshape(n * ho * wo, co)
+    dw = (cols.T @ dz2).reshape(kh, kw, ci, co)
+    dx = None
+    if need_dx:
+        dcols = (dz2 @ w.reshape(kh * kw * ci, co).T).reshape(n, ho, wo, kh, kw, ci)
+        dxp = np.zeros_like(xp)
+        for r in range(kh):
+            for s in range(kw):
+                dxp[:, r:r + stride * ho:stride, s:s + stride * wo:stride, :] += dcols[:, :, :, r, s, :]
+        dx = dxp[:, pt:pt + h, pl:pl + wd, :]
+    return dx, dw
+
+
+# --------------------------------------------------------------------------
+# PReLU  (nets/sphere.py:29-36): relu(x) + alpha*(x-|x|)*0.5, alpha per channel.
+# --------------------------------------------------------------------------
+def prelu_fwd(z, alpha):
+    return np.maximum(z, 0) + alpha * (z - np.abs(z)) * z.dtype.type(0.5)
+
+
+def prelu_bwd(z, alpha, dy):
+    neg = z <= 0            # d/dz at z==0: relu' = 0 and (1 - sign(0))*0.5 = 0.5 -> alpha*0.5 in TF.
+    # TF: d relu(0) = 0, d|x|(0) = sign(0) = 0  ->  dy*(0 + alpha*(1-0)*0.5) at exactly z == 0.
+    slope = np.where(z > 0, z.dtype.type(1), alpha * np.ones_like(z))
+    slope = np.where(z == 0, alpha * z.dtype.type(0.5) * np.ones_like(z), slope)
+    dz = dy * slope
+    axes = tuple(range(z.ndim - 1))
+    dalpha = (dy * np.where(neg, z, 0)).sum(axis=axes)
+    return dz, dalpha
+
+
+# --------------------------------------------------------------------------
+# fully_connected (nets/sphere.py:73-74, 86-90)
+# --------------------------------------------------------------------------
+def fc_fwd(x, w, b=None):
+    y = x @ w
+    return y if b is None else y + b
+
+
+def fc_bwd(x, w, dy, has_bias):
+    dx = dy @ w.T
+    dw = x.T @ dy
+    db = dy.sum(axis=0) if has_bias else None
+    return dx, dw, db
+
+
+# --------------------------------------------------------------------------
+# tf.losses.sparse_softmax_cross_entropy: mean over examples (nets/sphere.py:109)
+# --------------------------------------------------------------------------
+def softmax_ce(logits, labels, grad_scale=None):
+    """Returns (loss, dlogits) with dlogits = (softmax - onehot) * grad_scale,
+    grad_scale defaulting to 1/N (mean reduction)."""
+    n = logits.shape[0]
+    m = logits.max(axis=1, keepdims=True)
+    e = np.exp(logits - m)
+    s = e.sum(axis=1, keepdims=True)
+    logp_y = (logits - m)[np.arange(n), labels] - np.log(s[:, 0])
+    loss = -logp_y.mean()
+    d = e / s
+    d[np.arange(n), labels] -= 1
+    d *= logits.dtype.type(1.0 / n if grad_scale is None else grad_scale)
+    return loss, d
+
+
+# --------------------------------------------------------------------------
+# l2_regularizer(s)(w) = s * sum(w^2)/2   (Appendix A.4, nets/net_base.py:105)
+# --------------------------------------------------------------------------
+def l2_reg(ws, wd):
+    return wd * sum(float((w.astype(np.float64) ** 2).sum()) for w in ws) / 2
+
+
+# --------------------------------------------------------------------------
+# Optimizers (data_parallel.py:65-69,191-196; Appendix A.7)
+# --------------------------------------------------------------------------
+def momentum_step(w, acc, g, lr, mom=0.9):
+    acc = mom * acc + g
+    return w - lr * acc, acc
+
+
+def adam_step(w, m, v, g, lr, t, b1=0.5, b2=0.999, eps=1e-8):
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    return w - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+# --------------------------------------------------------------------------
+# LR schedules (train.py:122-144).  step is the global step (0-based).
+# --------------------------------------------------------------------------
+def lr_step(step, init_lr, decay_rate, decay_epochs, batches_per_epoch):
+    """tf.train.piecewise_constant: value[i] for boundaries[i-1] < step <= boundaries[i]
+    (the boundary step itself still takes the EARLIER value)."""
+    bounds = [(int(e) - 1) * batches_per_epoch for e in decay_epochs]
+    vals = [init_lr] + [init_lr * decay_rate ** (p + 1) for p in range(len(bounds))]
+    k = 0
+    while k < len(bounds) and step > bounds[k]:
+        k += 1
+    return vals[k]
+
+
+def lr_exp(step, init_lr, decay_epoch, max_epoches, batches_per_epoch):
+    decay_step = int(decay_epoch) * batches_per_epoch
+    if step < decay_step:
+        return init_lr
+    decay_steps = int(max_epoches) * batches_per_epoch + 1 - decay_step
+    return init_lr * 0.001 ** ((step - decay_step) / decay_steps)
+
+
+def lr_cosine(step, init_lr, max_epoches, batches_per_epoch):
+    total = max_epoches * batches_per_epoch
+    s = min(step, total)
+    return init_lr * 0.5 * (1 + np.cos(np.pi * s / total))
+
+
+# --------------------------------------------------------------------------
+# A-softmax (SphereFace, m=4; SURVEY.md Appendix A.9 -- NOT in the reference tree)
+# --------------------------------------------------------------------------
+def asoftmax_lambda(it, lambda_base=1000.0, gamma=0.12, power=1.0, lambda_min=5.0):
+    return max(lambda_min, lambda_base * (1.0 + gamma * it) ** (-power))
+
+
+_COS_K = (np.cos(np.pi / 4), 0.0, np.cos(3 * np.pi / 4))
+
+
+def asoftmax_logits(x, w, labels, lam):
+    """x [N,D], w [D,C] -> margin logits f [N,C] plus the intermediates backward needs."""
+    n = x.shape[0]
+    xn = np.sqrt((x * x).sum(axis=1))                 # |x_i|
+    wn = np.sqrt((w * w).sum(axis=0))                 # |W_j|
+    s = x @ w
+    f = s / wn                                        # |x| cos(theta_ij)
+    sy = s[np.arange(n), labels]
+    c = sy / (xn * wn[labels])
+    k = (c <= _COS_K[0]).astype(np.int64) + (c <= _COS_K[1]) + (c <= _COS_K[2])
+    sign = np.where(k % 2 == 0, 1.0, -1.0).astype(x.dtype)
+    c2 = c * c
+    psi = sign * (8 * c2 * c2 - 8 * c2 + 1) - 2 * k
+    dpsi = sign * (32 * c2 * c - 16 * c)
+    phi = lam * c + psi
+    f = f.copy()
+    f[np.arange(n), labels] = xn * phi / (1 + lam)
+    return f, dict(xn=xn, wn=wn, s=s, c=c, phi=phi, dphi=lam + dpsi)
+
+
+def asoftmax_fwd_bwd(x, w, labels, lam, grad_scale=None):
+    """Mean softmax-CE over the margin logits and its EXACT gradient wrt x and w
+    (differentiating through both norms)."""
+    n = x.shape[0]
+    idx = np.arange(n)
+    f, t = asoftmax_logits(x, w, labels, lam)
+    loss, g = softmax_ce(f, labels, grad_scale)
+    xn, wn, s, c, phi, dphi = t['xn'], t['wn'], t['s'], t['c'], t['phi'], t['dphi']
+    G = g / wn                                        # coefficient of ds_ij, j != y
+    G[idx, labels] = g[idx, labels] * dphi / ((1 + lam) * wn[labels])
+    rowcoef = g[idx, labels] * (phi - dphi * c) / ((1 + lam) * xn)
+    colcoef = -(G * s).sum(axis=0) / (wn * wn)
+    dx = G @ w.T + rowcoef[:, None] * x
+    dw = x.T @ G + colcoef[None, :] * w
+    return loss, f, dx, dw
+
+
+# --------------------------------------------------------------------------
+# center loss (loss.py:29-45) and batch-hard triplet (loss.py:47-78)
+# --------------------------------------------------------------------------
+def center_loss(features, labels, centers, alpha=0.99):
+    """Returns (loss, dfeatures, new_centers).  Gather happens BEFORE the
+    scatter_sub (the loss uses the pre-update centers: loss.py:37,41)."""
+    cb = centers[labels]
+    diffs = (1 - alpha) * (cb - features)
+    new_centers = centers.copy()
+    np.subtract.at(new_centers, labels, diffs)        # duplicates accumulate (scatter_sub)
+    d = features - cb
+    loss = (d * d).mean()
+    dfeat = 2 * d / d.size
+    return loss, dfeat, new_centers
+
+
+def batch_hard_triplet(features, labels, margin=None):
+    """Per-sample loss vector [N] (unreduced, loss.py:78) and d(sum)/dfeatures."""
+    n = features.shape[0]
+    diff = features[:, None, :] - features[None, :, :]
+    d2 = (diff * diff).sum(-1)
+    dist = np.sqrt(d2 + 1e-12)
+    same = labels[:, None] == labels[None, :]
+    pos_mask = (same ^ np.eye(n, dtype=bool)).astype(features.dtype)
+    neg_mask = (~same).astype(features.dtype)
+    pm = dist * pos_mask
+    nm = dist * neg_mask + 1e6 * same.astype(features.dtype)
+    ip = pm.argmax(axis=1)
+    ineg = nm.argmin(axis=1)
+    hp = pm[np.arange(n), ip]
+    hn = nm[np.arange(n), ineg]
+    v = hp - hn
+    if margin is None:
+        loss = np.logaddexp(0, v)
+        dv = 1 / (1 + np.exp(-v))
+    else:
+        loss = np.maximum(0, v + margin)
+        dv = (v + margin > 0).astype(features.dtype)
+    # gradient of sum(loss) wrt features (d dist_ij / d f_i = (f_i - f_j)/dist_ij)
+    df = np.zeros_like(features)
+    for i in range(n):
+        if pos_mask[i, ip[i]] > 0:                    # hardest_pos is a real distance, not a masked 0
+            gvec = dv[i] * diff[i, ip[i]] / dist[i, ip[i]]
+            df[i] += gvec
+            df[ip[i]] -= gvec
+        if not same[i, ineg[i]]:                      # hardest_neg is a real distance, not the 1e6 filler
+            gvec = dv[i] * diff[i, ineg[i]] / dist[i, ineg[i]]
+            df[i] -= gvec
+            df[ineg[i]] += gvec
+    return loss, df
