@@ -1,0 +1,182 @@
+/*
+ * fte.h -- C ABI of libfte.so, the MI355X (gfx950) kernel library behind
+ * tf_face_toolbox_amd's data-parallel training step.
+ *
+ * The reference (medivhna/TF_Face_Toolbox) has NO native boundary of its own:
+ * its hot path is a TensorFlow-1.x graph whose arithmetic lives in stock TF
+ * ops.  Each entry point below therefore replaces one TF op
+ * (or one fused group of them) at the reference call site cited beside it.
+ * A maintainer binds them with ctypes; nothing here takes or
+ * returns a torch type.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is
+ *     allocated, freed or retained by the library; scratch comes in through
+ *     (ws, ws_bytes) and fte_*_ws_bytes() says how much a call needs;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it
+ *     and the call returns without synchronising;
+ *   - return value: 0 = ok, otherwise a negative FTE_E* code or a positive
+ *     hipError_t; no C++ exception crosses the boundary;
+ *   - activations are NHWC fp32 (the layout data.py:275-279 hands over; the
+ *     reference's NHWC->NCHW transpose, nets/sphere.py:53-54, is folded away),
+ *     conv weights are TF HWIO [3,3,Cin,Cout], dense weights are [in,out].
+ *   - TF 'SAME' padding (pad_before = pad_total/2) -- asymmetric (0,1) for
+ *     stride 2 on even sizes.
+ *   - all arithmetic is fp32 with fp32 accumulation (v_mfma_f32_32x32x2_f32
+ *     for the GEMM-shaped work), the reference's dtype (nets/sphere.py:35).
+ */
+#ifndef FTE_H_
+#define FTE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTE_OK 0
+#define FTE_EINVAL (-1)      /* unsupported shape / null pointer */
+#define FTE_EWORKSPACE (-2)  /* ws_bytes too small */
+
+/* Library / build identification: "fte <version> gfx950". */
+const char* fte_version(void);
+
+/* ---------------------------------------------------------------------------
+ * 3x3 convolution, TF-SAME, stride 1 or 2, Cin % 32 == 0, Cout % 64 == 0
+ * (every conv of nets/sphere.py:41-42,61,65,69 except the first).
+ * Implicit GEMM on fp32 MFMA: M = n*ho*wo, K = 9*cin, N = cout.
+ * ------------------------------------------------------------------------- */
+
+/* Replaces Conv2D + BiasAdd + the 6-op PReLU (nets/sphere.py:29-36) + residual
+ * Add (nets/sphere.py:43):   z = conv(x,w) + bias ;  y = prelu(z, alpha) + res.
+ * bias, alpha, res, z may be NULL (no bias / identity / no residual / do not
+ * keep the pre-activation).  z is what backward needs (sign of z, min(z,0)). */
+int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* alpha,
+                    const float* res, float* z, float* y,
+                    int n, int h, int wd, int cin, int cout, int stride, void* stream);
+
+/* Replaces Conv2DBackpropInput fused with the PReLU gradient of the PRODUCING
+ * layer (tf.gradients, data_parallel.py:33):
+ *     g      = conv_transpose(dz, w) + addin          (gradient wrt the input x of this conv)
+ *     raw    = g                                      (optional: x is also a residual shortcut)
+ *     dzprev = g * prelu'(zprev, alpha_prev)          (zprev NULL: dzprev = g)
+ *     dalpha_prev[c] = sum g*min(zprev,0) ; dbias_prev[c] = sum dzprev
+ * x has shape [n,h,wd,cin]; dz has the conv's output shape.  addin, raw,
+ * zprev, dalpha_prev, dbias_prev may be NULL. */
+int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin,
+                      const float* zprev, const float* alpha_prev,
+                      float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
+                      int n, int h, int wd, int cin, int cout, int stride,
+                      void* ws, size_t ws_bytes, void* stream);
+size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride);
+
+/* Replaces Conv2DBackpropFilter:  dw[3,3,cin,cout] = sum_pixels x (*) dz
+ * (deterministic split-K: partial slabs in ws, then an ordered reduction). */
+int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw,
+                      int n, int h, int wd, int cin, int cout, int stride,
+                      void* ws, size_t ws_bytes, void* stream);
+size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride);
+
+/* ---------------------------------------------------------------------------
+ * First conv of the net (Cin = 1 or 3, stride 2; nets/sphere.py:57): K = 9*Cin
+ * is too short for a GEMM -- HBM-bound direct convolution, fused bias+PReLU.
+ * ------------------------------------------------------------------------- */
+int fte_conv3x3_first_fwd(const float* x, const float* w, const float* bias, const float* alpha,
+                          float* z, float* y, int n, int h, int wd, int cin, int cout,
+                          int stride, void* stream);
+int fte_conv3x3_first_wgrad(const float* x, const float* dz, float* dw,
+                            int n, int h, int wd, int cin, int cout, int stride,
+                            void* ws, size_t ws_bytes, void* stream);
+size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride);
+
+/* ---------------------------------------------------------------------------
+ * Dense layers (MatMul + BiasAdd and their gradients: nets/sphere.py:73-74,
+ * 86-90).  Row-major fp32; k % 32 == 0 for nn/nt, n % 64 == 0 everywhere.
+ * ------------------------------------------------------------------------- */
+
+/* y[m,n] = x[m,k] @ w[k,n] (+ bias[n]) */
+int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y,
+                int m, int n, int k, void* ws, size_t ws_bytes, void* stream);
+/* dx[m,k] = dy[m,n] @ w[k,n]^T, with the same fused PReLU-gradient epilogue as
+ * fte_conv3x3_dgrad (zprev has dx's shape; alpha_prev has `amod` entries and
+ * column j uses alpha_prev[j % amod] -- the flattened H*W*C feature map that
+ * feeds nets/sphere.py:72-74). */
+int fte_gemm_nt(const float* dy, const float* w, const float* zprev, const float* alpha_prev,
+                int amod, float* raw, float* dx, float* dalpha_prev,
+                int m, int n, int k, void* ws, size_t ws_bytes, void* stream);
+/* dw[k,n] = x[m,k]^T @ dy[m,n] */
+int fte_gemm_tn(const float* x, const float* dy, float* dw,
+                int m, int n, int k, void* ws, size_t ws_bytes, void* stream);
+size_t fte_gemm_ws_bytes(int m, int n, int k);
+
+/* ---------------------------------------------------------------------------
+ * Loss heads
+ * ------------------------------------------------------------------------- */
+
+/* Replaces SparseSoftmaxCrossEntropyWithLogits + mean + its gradient
+ * (tf.losses.sparse_softmax_cross_entropy, nets/sphere.py:109):
+ *   loss_rows[i] = -log softmax(logits[i,:c])[labels[i]]
+ *   dlogits[i,j] = (softmax - onehot) * grad_scale   (columns c..ld-1 get 0)
+ * logits/dlogits are [n, ld] with ld >= c (padded classifier width). */
+int fte_softmax_ce_fwd_bwd(const float* logits, const int32_t* labels, float* loss_rows,
+                           float* dlogits, int n, int c, int ld, float grad_scale, void* stream);
+
+/* A-softmax (SphereFace, m = 4; README.md:14,19 claims it, the code is not in
+ * the reference tree -- SURVEY.md Appendix A.9).  s = x @ w is the raw dot
+ * product [n, ld]; xn = |x_i| (n), wn = |W_j| (c).  Produces the margin logits
+ * f (optional), the per-row loss, G = dLoss/ds (the matrix that feeds the two
+ * gradient GEMMs), rowcoef (dx += rowcoef_i * x_i) and, via
+ * fte_asoftmax_colcoef, colcoef (dw[:,j] += colcoef_j * w[:,j]). */
+int fte_asoftmax_fwd_bwd(const float* s, const float* xn, const float* wn, const int32_t* labels,
+                         float lambda, float* f, float* loss_rows, float* G, float* rowcoef,
+                         int n, int c, int ld, float grad_scale, void* stream);
+int fte_asoftmax_colcoef(const float* G, const float* s, const float* wn, float* colcoef,
+                         int n, int c, int ld, void* stream);
+/* out[i] = sqrt(sum_j a[i,j]^2) over rows of [rows, ld] (cols used) */
+int fte_row_norms(const float* a, float* out, int rows, int cols, int ld, void* stream);
+/* out[j] = sqrt(sum_i a[i,j]^2) over columns */
+int fte_col_norms(const float* a, float* out, int rows, int cols, int ld, void* stream);
+/* a[i,j] += rc[i] * b[i,j]   (rc NULL -> skip) ;  a[i,j] += cc[j] * b[i,j]  (cc NULL -> skip) */
+int fte_add_scaled_rows_cols(float* a, const float* b, const float* rc, const float* cc,
+                             int rows, int cols, int ld, void* stream);
+
+/* center loss (loss.py:29-45): loss_rows[i] = sum_j (f_ij - c_{y_i} j)^2 (caller takes the mean over n*d);
+ * dfeat = 2(f - c_y)*grad_scale; then centers[y] -= (1-alpha)(c_y - f), duplicates accumulating
+ * (scatter_sub).  Every gather is served from the centers as they were BEFORE the update
+ * (loss.py:37 before :39).  In place on `centers`; ws >= n*d floats. */
+int fte_center_loss_fwd_bwd_update(const float* feat, const int32_t* labels, float* centers,
+                                   float* loss_rows, float* dfeat, int n, int d, float alpha,
+                                   float grad_scale, void* ws, size_t ws_bytes, void* stream);
+
+/* batch-hard triplet (loss.py:47-78): per-sample loss [n] and d(sum w_i*loss_i)/dfeat.
+ * margin < 0 selects softplus (margin=None in the reference).  ws >= 3*n*n floats. */
+int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, float margin,
+                                   float loss_weight, float* loss_rows, float* dfeat,
+                                   int n, int d, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Flat-arena reductions and optimizers (ApplyMomentum / ApplyAdam per variable,
+ * data_parallel.py:65-69,191-196; L2Loss + AddN, nets/net_base.py:105).
+ * ------------------------------------------------------------------------- */
+
+/* out[j] = scale * sum_{r<rows} in[r*cols + j]  (+ bias[j % bmod] when bias != NULL).
+ * If fold > 1, column j of `out` (cols/fold of them) sums in[r, j + t*(cols/fold)] over t too. */
+int fte_reduce_rows(const float* in, float* out, const float* bias, int bmod,
+                    long rows, long cols, int fold, float scale, void* stream);
+/* out[0] = scale * sum_i a[i]^2   (ws >= 1024 floats) */
+int fte_sumsq(const float* a, long n, float scale, float* out, void* ws, size_t ws_bytes, void* stream);
+/* out[0] = scale * sum_i a[i]     (ws >= 1024 floats) */
+int fte_sum(const float* a, long n, float scale, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* acc = mom*acc + (gscale*g + wd*w) ; w -= lr*acc      (MomentumOptimizer, Appendix A.7) */
+int fte_momentum_update(float* w, float* acc, const float* g, long n,
+                        float lr, float mom, float wd, float gscale, void* stream);
+/* TF AdamOptimizer (epsilon outside the bias correction); t = 1-based step */
+int fte_adam_update(float* w, float* m, float* v, const float* g, long n,
+                    float lr, float b1, float b2, float eps, float wd, float gscale, int t, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTE_H_ */

@@ -1,0 +1,88 @@
+"""-m gpu: the whole hot path (SphereNet-20 forward / loss / backward / optimizer through the
+reference-shaped Python API and the C ABI) against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops, spherenet as osn
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from util_gpu import dev, host, check_maxabs, check_rell2
+    from tf_face_toolbox_amd import net_select, Singular
+
+
+def _setup(name, data_format, n, h, w, ch, ncls, seed=21):
+    p = osn.perturb_params(osn.init_params(seed, ch, ncls, h, w), seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    x = rng.uniform(-1, 1, (n, h, w, ch)); y = rng.integers(0, ncls, n)
+    net = net_select(name, data_format, 5e-4)
+    net.build(h, w, ch, ncls, 'cuda')
+    net.load_params(p)
+    return net, p, x, y
+
+
+@pytest.mark.parametrize('name,data_format,n,h,w,ch,ncls', [
+    ('SphereNet', 'NCHW', 4, 32, 32, 3, 10),
+    ('SphereNet', 'NHWC', 3, 48, 16, 1, 200),
+    ('SphereNet-ASoftmax', 'NCHW', 4, 32, 32, 3, 10),
+    ('SphereNet', 'NCHW', 2, 112, 112, 3, 1000),          # BASELINE geometry, small batch
+    ('SphereNet-ASoftmax', 'NCHW', 2, 112, 112, 1, 10575),  # config[0] geometry (gray, C = 10575)
+])
+def test_forward_loss_and_every_gradient(name, data_format, n, h, w, ch, ncls):
+    net, p, x, y = _setup(name, data_format, n, h, w, ch, ncls)
+    head = 'asoftmax' if 'ASoftmax' in name else 'softmax'
+    lam = ops.asoftmax_lambda(0)
+    losses_ref, g_ref, ex = osn.loss_and_grads(p, x, y, 5e-4, data_format, head, lam)
+    xd, yd = dev(x), dev(y, torch.int32)
+    net.tower_scale = 1.0
+    if net.needs_labels:
+        logits = net.forward(xd, yd, num_classes=ncls, is_training=True)
+    else:
+        logits = net.forward(xd, num_classes=ncls, is_training=True)
+    losses, names, others = net.loss_function('TOWER', yd, **logits)
+    net.backward()
+    torch.cuda.synchronize()
+    assert names == ['cross_entropy', 'reg_loss']
+    check_maxabs(host(net.emb), ex['embedding'], what='embedding')
+    check_maxabs(host(logits['logits']), ex['logits'], what='logits')
+    assert abs(float(losses[0]) - losses_ref[0]) <= 1e-5 * max(1, abs(losses_ref[0]))
+    assert abs(float(losses[1]) - losses_ref[1]) <= 1e-5 * max(1, abs(losses_ref[1]))
+    for k in p:
+        data_grad = g_ref[k] - (5e-4 * p[k] if k.endswith('/weights') else 0)     # wd*w is folded into the optimizer
+        check_rell2(host(net.get_variable(k, net.grads)), data_grad, what='grad ' + k)
+
+
+@pytest.mark.parametrize('optimizer', ['Momentum', 'Adam'])
+def test_three_training_steps_match_oracle(optimizer):
+    n, h, w, ch, ncls = 4, 32, 32, 3, 10
+    net, p, x, y = _setup('SphereNet', 'NCHW', n, h, w, ch, ncls, seed=31)
+    inputs = {'images': dev(x), 'labels': dev(y, torch.int32), 'num_classes': ncls, 'num_examples': n}
+    lr = 0.05 if optimizer == 'Momentum' else 1e-3
+    step, losses, names, others = Singular(net, lr, optimizer)(inputs)
+    slots = osn.zero_slots(p, optimizer)
+    for t in range(1, 4):
+        step()
+        p, slots, l_ref = osn.train_step(p, slots, x, y, lr, optimizer=optimizer, t=t)
+        assert abs(float(losses[0]) - l_ref[0]) <= 2e-4 * max(1, abs(l_ref[0])), (t, float(losses[0]), l_ref)
+    for k in p:
+        tol = 2e-4 if optimizer == 'Momentum' else 5e-3      # Adam's 1/sqrt(v) amplifies fp32 noise in tiny grads
+        check_maxabs(host(net.get_variable(k)), p[k], tol, what='weights after 3 steps ' + k)
+
+
+def test_eval_features_flip_average():
+    net, p, x, y = _setup('SphereNet', 'NCHW', 3, 32, 32, 3, 10, seed=41)
+    f = net.forward(dev(x), is_training=False)
+    check_maxabs(host(f), osn.eval_features(p, x, 'NCHW'), what='eval features')
+
+
+def test_variable_names_and_groups_follow_the_reference():
+    net, p, x, y = _setup('SphereNet', 'NCHW', 2, 32, 32, 3, 10)
+    assert list(sorted(net.variables)) == list(sorted(p))             # 47 TF variable names
+    groups = net.param_list(is_training=True, trainable=True)
+    assert len(groups) == 2 and [v.name for v in groups[1]] == ['classifier/fc_classifier/weights']
+    assert net.mult_lr_list() == [1.0, 1.0]
+    assert all(v.name.startswith('SphereNet/') for v in net.pretrained_param())
+    for k in p:                                                       # import/export round trip in reference layout
+        np.testing.assert_allclose(host(net.get_variable(k)), p[k].astype(np.float32), rtol=0, atol=0)

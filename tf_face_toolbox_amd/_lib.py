@@ -1,0 +1,91 @@
+"""ctypes binding of libfte.so (include/fte.h).  This is the ONLY way arithmetic of the
+training step runs: there is no CPU fallback.  If the library is missing or a call
+fails, the error is raised -- never swallowed."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfte.so')
+
+
+class FteError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_SIGS = {
+    'fte_version': (c_char_p, []),
+    'fte_conv3x3_fwd': (c_int, [_P] * 7 + [c_int] * 6 + [_P]),
+    'fte_conv3x3_dgrad': (c_int, [_P] * 9 + [c_int] * 6 + [_P, c_size_t, _P]),
+    'fte_conv3x3_dgrad_ws_bytes': (c_size_t, [c_int] * 6),
+    'fte_conv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
+    'fte_conv3x3_wgrad_ws_bytes': (c_size_t, [c_int] * 6),
+    'fte_conv3x3_first_fwd': (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
+    'fte_conv3x3_first_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
+    'fte_conv3x3_first_wgrad_ws_bytes': (c_size_t, [c_int] * 6),
+    'fte_gemm_nn': (c_int, [_P] * 4 + [c_int] * 3 + [_P, c_size_t, _P]),
+    'fte_gemm_nt': (c_int, [_P] * 4 + [c_int] + [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
+    'fte_gemm_tn': (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
+    'fte_gemm_ws_bytes': (c_size_t, [c_int] * 3),
+    'fte_softmax_ce_fwd_bwd': (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P]),
+    'fte_asoftmax_fwd_bwd': (c_int, [_P] * 4 + [c_float] + [_P] * 4 + [c_int] * 3 + [c_float, _P]),
+    'fte_asoftmax_colcoef': (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
+    'fte_row_norms': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
+    'fte_col_norms': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
+    'fte_add_scaled_rows_cols': (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
+    'fte_center_loss_fwd_bwd_update': (c_int, [_P] * 5 + [c_int] * 2 + [c_float] * 2 + [_P, c_size_t, _P]),
+    'fte_batch_hard_triplet_fwd_bwd': (c_int, [_P] * 2 + [c_float] * 2 + [_P] * 2 + [c_int] * 2 + [_P, c_size_t, _P]),
+    'fte_reduce_rows': (c_int, [_P] * 3 + [c_int, c_long, c_long, c_int, c_float, _P]),
+    'fte_sumsq': (c_int, [_P, c_long, c_float, _P, _P, c_size_t, _P]),
+    'fte_sum': (c_int, [_P, c_long, c_float, _P, _P, c_size_t, _P]),
+    'fte_momentum_update': (c_int, [_P] * 3 + [c_long] + [c_float] * 4 + [_P]),
+    'fte_adam_update': (c_int, [_P] * 4 + [c_long] + [c_float] * 6 + [c_int, _P]),
+}
+
+_lib = None
+
+
+def exported_names():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load libfte.so; raises FteError with the build command when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FteError('libfte.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(or tf_face_toolbox_amd/csrc/build.sh). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing: loud on purpose
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def call(name, *args):
+    """Call an int-returning entry point; tensors are passed as device pointers."""
+    lib = load()
+    r = getattr(lib, name)(*[_ptr(a) if (a is None or hasattr(a, 'data_ptr')) else a for a in args])
+    if r != 0:
+        raise FteError('%s failed with code %d' % (name, r))
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+def version():
+    return load().fte_version().decode()

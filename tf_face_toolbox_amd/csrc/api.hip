@@ -1,0 +1,426 @@
+// api.hip -- extern "C" entry points of libfte.so (declared in include/fte.h).
+// Host-side only: shape checks, operand-gather descriptors for the igemm kernel
+// family, tile / split-K selection, ordered reductions.  Never allocates, never
+// synchronises; every launch goes to the caller's stream.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/fte.h"
+#include "igemm.h"
+#include "kernels.h"
+
+namespace {
+
+struct Pads { int out, before; };
+inline Pads same_pads(int in, int k, int stride) {
+    const int out = (in + stride - 1) / stride;
+    int total = (out - 1) * stride + k - in;
+    if (total < 0) total = 0;
+    return {out, total / 2};
+}
+
+inline int rc(hipError_t e) { return e == hipSuccess ? FTE_OK : (int)e; }
+
+inline long tiles_of(int tile, long M, long N) {
+    int bm, bn;
+    igemm_tile_dims(tile, &bm, &bn);
+    return ((M + bm - 1) / bm) * (N / bn);
+}
+
+// Largest tile that still gives the chip >= 1.5 blocks per CU; else the smallest legal one.
+inline int pick_tile(long M, long N) {
+    const long want = 384;
+    int cands[3];
+    int nc = 0;
+    if (N % 128 == 0) { cands[nc++] = TILE_128x128; cands[nc++] = TILE_128x64; cands[nc++] = TILE_64x64; }
+    else { cands[nc++] = TILE_256x64; cands[nc++] = TILE_128x64; cands[nc++] = TILE_64x64; }
+    for (int i = 0; i < nc; ++i)
+        if (tiles_of(cands[i], M, N) >= want) return cands[i];
+    return cands[nc - 1];
+}
+
+// split-K plan: aim for ~3 blocks per CU, at least 8 K-steps (256 deep) per split
+inline void plan_splits(long tiles, int K, int* splits, int* kchunk) {
+    int s = (int)((768 + tiles - 1) / tiles);
+    const int maxs = K / 256 > 0 ? K / 256 : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    int kc = ((K + s - 1) / s + 31) / 32 * 32;
+    *kchunk = kc;
+    *splits = (K + kc - 1) / kc;
+}
+
+inline void zero_params(IgemmParams* p) { memset(p, 0, sizeof(*p)); }
+
+inline void plain_a(IgemmParams* p, const float* a, int ld, int kc) {
+    p->A = a; p->a_OH = 1; p->a_OW = 1; p->a_IH = 1; p->a_IW = 1; p->a_stride = 1;
+    p->a_ld = ld; p->a_KC = kc; p->a_NT = 1;
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+const char* fte_version(void) { return "fte 0.1 gfx950 fp32-mfma"; }
+
+// ------------------------------------------------------------------------------------------------
+int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
+                    float* z, float* y, int n, int h, int wd, int cin, int cout, int stride, void* stream) {
+    if (!x || !w || !y || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    IgemmParams p;
+    zero_params(&p);
+    p.M = n * ph.out * pw.out; p.N = cout; p.K = 9 * cin; p.kchunk = p.K;
+    p.A = x; p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
+    p.a_ld = cin; p.a_KC = cin; p.a_NT = 9;
+    for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < 3; ++s) { p.a_dh[r * 3 + s] = r - ph.before; p.a_dw[r * 3 + s] = s - pw.before; }
+    p.B = w; p.b_ld = cout;
+    p.c_ld = cout;
+    p.Y = y; p.Z = z; p.R = res; p.bias = bias; p.alpha = alpha;
+    return rc(igemm_launch(p, AL_MK, BL_KN, EPI_FWD, pick_tile(p.M, p.N), 1, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct DgradClass { int ph, pw, hq, wq, ntap, dh[9], dw[9], wt[9], tile; long mtiles; };
+int dgrad_classes(int n, int h, int wd, int cin, int stride, DgradClass* cls) {
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    int nc = 0;
+    for (int a = 0; a < stride; ++a)
+        for (int b = 0; b < stride; ++b) {
+            DgradClass& c = cls[nc];
+            c.ph = a; c.pw = b;
+            c.hq = (h - a + stride - 1) / stride;
+            c.wq = (wd - b + stride - 1) / stride;
+            c.ntap = 0;
+            if (c.hq <= 0 || c.wq <= 0) continue;
+            for (int r = 0; r < 3; ++r) {
+                if ((a + ph.before - r) % stride) continue;
+                for (int s = 0; s < 3; ++s) {
+                    if ((b + pw.before - s) % stride) continue;
+                    // hi = ho*stride + r - pt  with hi = hq*stride + a  ->  ho = hq + (a + pt - r)/stride
+                    c.dh[c.ntap] = (a + ph.before - r) / stride;
+                    c.dw[c.ntap] = (b + pw.before - s) / stride;
+                    c.wt[c.ntap] = r * 3 + s;
+                    ++c.ntap;
+                }
+            }
+            if (c.ntap == 0) continue;
+            const long M = (long)n * c.hq * c.wq;
+            c.tile = pick_tile(M, cin);
+            int bm, bn;
+            igemm_tile_dims(c.tile, &bm, &bn);
+            c.mtiles = (M + bm - 1) / bm;
+            ++nc;
+        }
+    return nc;
+}
+}  // namespace
+
+size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+    (void)cout;
+    DgradClass cls[4];
+    const int nc = dgrad_classes(n, h, wd, cin, stride, cls);
+    long rows = 0;
+    for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
+    return 2 * align_up((size_t)rows * cin * sizeof(float));
+}
+
+int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
+                      const float* alpha_prev, float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
+                      int n, int h, int wd, int cin, int cout, int stride, void* ws, size_t ws_bytes, void* stream) {
+    if (!dz || !w || !dzprev || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    if (zprev && !alpha_prev) return FTE_EINVAL;
+    const Pads pho = same_pads(h, 3, stride), pwo = same_pads(wd, 3, stride);
+    DgradClass cls[4];
+    const int nc = dgrad_classes(n, h, wd, cin, stride, cls);
+    long rows = 0;
+    for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
+    const bool want_part = zprev && (dalpha_prev || dbias_prev);
+    const size_t half = align_up((size_t)rows * cin * sizeof(float));
+    if (want_part && (!ws || ws_bytes < 2 * half)) return FTE_EWORKSPACE;
+    float* PA = want_part ? (float*)ws : nullptr;
+    float* PB = want_part ? (float*)((char*)ws + half) : nullptr;
+    long prow = 0;
+    for (int i = 0; i < nc; ++i) {
+        const DgradClass& c = cls[i];
+        IgemmParams p;
+        zero_params(&p);
+        p.M = n * c.hq * c.wq; p.N = cin; p.K = c.ntap * cout; p.kchunk = p.K;
+        p.A = dz; p.a_OH = c.hq; p.a_OW = c.wq; p.a_IH = pho.out; p.a_IW = pwo.out; p.a_stride = 1;
+        p.a_ld = cout; p.a_KC = cout; p.a_NT = c.ntap;
+        for (int t = 0; t < c.ntap; ++t) {
+            p.a_dh[t] = c.dh[t]; p.a_dw[t] = c.dw[t];
+            p.b_tapoff[t] = c.wt[t] * cin * cout;
+        }
+        p.B = w; p.b_ld = cout;
+        if (stride == 1) { p.c_OH = 0; }
+        else { p.c_OH = c.hq; p.c_OW = c.wq; p.c_FH = h; p.c_FW = wd; p.c_step = stride; p.c_ph = c.ph; p.c_pw = c.pw; }
+        p.c_ld = cin;
+        p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
+        p.PA = PA; p.PB = PB; p.prow0 = (int)prow;
+        hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_DGRAD, c.tile, 1, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        prow += c.mtiles;
+    }
+    if (want_part) {
+        if (dalpha_prev) { hipError_t e = k_reduce_rows(PA, dalpha_prev, nullptr, 1, rows, cin, 1, 1.f, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+        if (dbias_prev) { hipError_t e = k_reduce_rows(PB, dbias_prev, nullptr, 1, rows, cin, 1, 1.f, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+    }
+    return FTE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+void wgrad_plan(int n, int h, int wd, int cin, int cout, int stride, int* tile, int* splits, int* kchunk, int* K) {
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    *K = n * ph.out * pw.out;
+    const long M = 9L * cin;
+    *tile = (cout % 128 == 0) ? TILE_128x128 : TILE_128x64;
+    plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk);
+}
+}  // namespace
+
+size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+    int tile, splits, kchunk, K;
+    wgrad_plan(n, h, wd, cin, cout, stride, &tile, &splits, &kchunk, &K);
+    return splits > 1 ? (size_t)splits * 9 * cin * cout * sizeof(float) : 0;
+}
+
+int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                      void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dz || !dw || n <= 0 || cin % 4 || cout % 64 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    int tile, splits, kchunk, K;
+    wgrad_plan(n, h, wd, cin, cout, stride, &tile, &splits, &kchunk, &K);
+    const size_t need = splits > 1 ? (size_t)splits * 9 * cin * cout * sizeof(float) : 0;
+    if (need && (!ws || ws_bytes < need)) return FTE_EWORKSPACE;
+    IgemmParams p;
+    zero_params(&p);
+    p.M = 9 * cin; p.N = cout; p.K = K; p.kchunk = kchunk;
+    p.A = x; p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
+    p.a_ld = cin; p.a_KC = cin; p.a_NT = 9;
+    for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < 3; ++s) { p.a_dh[r * 3 + s] = r - ph.before; p.a_dw[r * 3 + s] = s - pw.before; }
+    p.B = dz; p.b_ld = cout;
+    p.c_ld = cout;
+    p.slab = (long)p.M * p.N;
+    p.Y = splits > 1 ? (float*)ws : dw;
+    hipError_t e = igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (splits > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+    return FTE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int fte_conv3x3_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
+                          int n, int h, int wd, int cin, int cout, int stride, void* stream) {
+    if (!x || !w || !y || cout != 64 || (cin != 1 && cin != 3)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(k_conv_first_fwd(x, w, bias, alpha, z, y, n, h, wd, cin, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+}
+
+size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return (size_t)k_conv_first_wgrad_blocks((long)n * ph.out * pw.out) * 9 * cin * cout * sizeof(float);
+}
+
+int fte_conv3x3_first_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                            void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dz || !dw || cout != 64 || (cin != 1 && cin != 3)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    const int blocks = k_conv_first_wgrad_blocks((long)n * ph.out * pw.out);
+    const size_t need = (size_t)blocks * 9 * cin * cout * sizeof(float);
+    if (!ws || ws_bytes < need) return FTE_EWORKSPACE;
+    hipError_t e = k_conv_first_wgrad(x, dz, (float*)ws, n, h, wd, cin, ph.out, pw.out, stride, ph.before, pw.before, blocks, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, blocks, 9L * cin * cout, 1, 1.f, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense
+namespace {
+// split-K plan of a dense product with `rows` x `cols` outputs and reduction length `red`
+size_t dense_slab_bytes(int tile, long rows, long cols, int red) {
+    int splits = 1, kchunk = red;
+    if (tiles_of(tile, rows, cols) < 256) plan_splits(tiles_of(tile, rows, cols), red, &splits, &kchunk);
+    return splits > 1 ? (size_t)splits * rows * cols * sizeof(float) : 0;
+}
+inline int tn_tile(long k, long n) {
+    return (n % 128 == 0) ? (tiles_of(TILE_128x128, k, n) >= 384 ? TILE_128x128 : TILE_128x64) : TILE_128x64;
+}
+}  // namespace
+
+size_t fte_gemm_ws_bytes(int m, int n, int k) {
+    // max over nn (m x n, red k), nt (m x k, red n; or its dalpha partials), tn (k x n, red m)
+    size_t need = 0, v;
+    if (n % 64 == 0) { v = dense_slab_bytes(pick_tile(m, n), m, n, k); if (v > need) need = v; }
+    if (k % 64 == 0) {
+        v = dense_slab_bytes(pick_tile(m, k), m, k, n); if (v > need) need = v;
+        v = (size_t)((m + 63) / 64) * k * sizeof(float); if (v > need) need = v;
+    }
+    if (n % 64 == 0) { v = dense_slab_bytes(tn_tile(k, n), k, n, m); if (v > need) need = v; }
+    return need;
+}
+
+int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y, int m, int n, int k,
+                void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || m <= 0 || n % 64 || k % 32) return FTE_EINVAL;
+    IgemmParams p;
+    zero_params(&p);
+    p.M = m; p.N = n; p.K = k;
+    plain_a(&p, x, k, k);
+    p.B = w; p.b_ld = n; p.c_ld = n;
+    const int tile = pick_tile(m, n);
+    int splits = 1, kchunk = k;
+    if (tiles_of(tile, m, n) < 256) plan_splits(tiles_of(tile, m, n), k, &splits, &kchunk);
+    p.kchunk = kchunk;
+    p.slab = (long)m * n;
+    if (splits > 1) {
+        if (!ws || ws_bytes < (size_t)splits * p.slab * sizeof(float)) return FTE_EWORKSPACE;
+        p.Y = (float*)ws;
+        hipError_t e = igemm_launch(p, AL_MK, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        return rc(k_reduce_rows((const float*)ws, y, bias, n, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+    }
+    p.Y = y; p.bias = bias;
+    return rc(igemm_launch(p, AL_MK, BL_KN, EPI_FWD, tile, 1, (hipStream_t)stream));
+}
+
+int fte_gemm_nt(const float* dy, const float* w, const float* zprev, const float* alpha_prev, int amod,
+                float* raw, float* dx, float* dalpha_prev, int m, int n, int k, void* ws, size_t ws_bytes, void* stream) {
+    // dx[m,k] = dy[m,n] @ w[k,n]^T : GEMM with rows m, cols k, reduction n
+    if (!dy || !w || !dx || m <= 0 || k % 64 || n % 32) return FTE_EINVAL;
+    if (zprev && (!alpha_prev || amod <= 0 || k % amod)) return FTE_EINVAL;
+    IgemmParams p;
+    zero_params(&p);
+    p.M = m; p.N = k; p.K = n;
+    plain_a(&p, dy, n, n);
+    p.B = w; p.b_ld = n; p.c_ld = k;
+    const int tile = pick_tile(m, k);
+    if (!zprev && !raw) {     // plain product, split-K allowed
+        int splits = 1, kchunk = n;
+        if (tiles_of(tile, m, k) < 256) plan_splits(tiles_of(tile, m, k), n, &splits, &kchunk);
+        p.kchunk = kchunk;
+        p.slab = (long)m * k;
+        if (splits > 1) {
+            if (!ws || ws_bytes < (size_t)splits * p.slab * sizeof(float)) return FTE_EWORKSPACE;
+            p.Y = (float*)ws;
+            hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_FWD, tile, splits, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            return rc(k_reduce_rows((const float*)ws, dx, nullptr, 1, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+        }
+        p.Y = dx;
+        return rc(igemm_launch(p, AL_MK, BL_NK, EPI_FWD, tile, 1, (hipStream_t)stream));
+    }
+    p.kchunk = n;
+    int bm, bn;
+    igemm_tile_dims(tile, &bm, &bn);
+    const long mtiles = ((long)m + bm - 1) / bm;
+    const bool want_part = zprev && dalpha_prev;
+    if (want_part && (!ws || ws_bytes < (size_t)mtiles * k * sizeof(float))) return FTE_EWORKSPACE;
+    p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = zprev ? amod : 1; p.DZ = dx;
+    p.PA = want_part ? (float*)ws : nullptr;
+    hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_DGRAD, tile, 1, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (want_part) return rc(k_reduce_rows((const float*)ws, dalpha_prev, nullptr, 1, mtiles, k, k / amod, 1.f, (hipStream_t)stream));
+    return FTE_OK;
+}
+
+int fte_gemm_tn(const float* x, const float* dy, float* dw, int m, int n, int k, void* ws, size_t ws_bytes, void* stream) {
+    // dw[k,n] = x[m,k]^T @ dy[m,n] : GEMM with rows k, cols n, reduction m
+    if (!x || !dy || !dw || m <= 0 || n % 64 || k % 4) return FTE_EINVAL;
+    IgemmParams p;
+    zero_params(&p);
+    p.M = k; p.N = n; p.K = m;
+    plain_a(&p, x, k, k);
+    p.B = dy; p.b_ld = n; p.c_ld = n;
+    const int tile = tn_tile(k, n);
+    int splits = 1, kchunk = (m + 31) / 32 * 32;
+    if (tiles_of(tile, k, n) < 256) plan_splits(tiles_of(tile, k, n), m, &splits, &kchunk);
+    p.kchunk = kchunk;
+    p.slab = (long)k * n;
+    if (splits > 1) {
+        if (!ws || ws_bytes < (size_t)splits * p.slab * sizeof(float)) return FTE_EWORKSPACE;
+        p.Y = (float*)ws;
+        hipError_t e = igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+    }
+    p.Y = dw;
+    return rc(igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, 1, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss heads
+int fte_softmax_ce_fwd_bwd(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits,
+                           int n, int c, int ld, float grad_scale, void* stream) {
+    if (!logits || !labels || !loss_rows || !dlogits || n <= 0 || c <= 0 || ld < c) return FTE_EINVAL;
+    return rc(k_softmax_ce(logits, labels, loss_rows, dlogits, n, c, ld, grad_scale, (hipStream_t)stream));
+}
+int fte_asoftmax_fwd_bwd(const float* s, const float* xn, const float* wn, const int32_t* labels, float lambda,
+                         float* f, float* loss_rows, float* G, float* rowcoef, int n, int c, int ld,
+                         float grad_scale, void* stream) {
+    if (!s || !xn || !wn || !labels || !loss_rows || !G || !rowcoef || n <= 0 || c <= 0 || ld < c) return FTE_EINVAL;
+    return rc(k_asoftmax(s, xn, wn, labels, lambda, f, loss_rows, G, rowcoef, n, c, ld, grad_scale, (hipStream_t)stream));
+}
+int fte_asoftmax_colcoef(const float* G, const float* s, const float* wn, float* colcoef, int n, int c, int ld, void* stream) {
+    if (!G || !s || !wn || !colcoef) return FTE_EINVAL;
+    return rc(k_asoftmax_colcoef(G, s, wn, colcoef, n, c, ld, (hipStream_t)stream));
+}
+int fte_row_norms(const float* a, float* out, int rows, int cols, int ld, void* stream) {
+    if (!a || !out || rows <= 0) return FTE_EINVAL;
+    return rc(k_row_norms(a, out, rows, cols, ld, (hipStream_t)stream));
+}
+int fte_col_norms(const float* a, float* out, int rows, int cols, int ld, void* stream) {
+    if (!a || !out || rows <= 0) return FTE_EINVAL;
+    return rc(k_col_norms(a, out, rows, cols, ld, (hipStream_t)stream));
+}
+int fte_add_scaled_rows_cols(float* a, const float* b, const float* rcf, const float* cc, int rows, int cols, int ld, void* stream) {
+    if (!a || !b || rows <= 0) return FTE_EINVAL;
+    return rc(k_add_scaled(a, b, rcf, cc, rows, cols, ld, (hipStream_t)stream));
+}
+int fte_center_loss_fwd_bwd_update(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
+                                   int n, int d, float alpha, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !labels || !centers || !loss_rows || !dfeat || n <= 0) return FTE_EINVAL;
+    if (!ws || ws_bytes < (size_t)n * d * sizeof(float)) return FTE_EWORKSPACE;
+    return rc(k_center_loss(feat, labels, centers, loss_rows, dfeat, n, d, alpha, grad_scale, (float*)ws, (hipStream_t)stream));
+}
+int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, float margin, float loss_weight,
+                                   float* loss_rows, float* dfeat, int n, int d, void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !labels || !loss_rows || !dfeat || n <= 0) return FTE_EINVAL;
+    if (!ws || ws_bytes < (size_t)2 * n * n * sizeof(float)) return FTE_EWORKSPACE;
+    return rc(k_triplet(feat, labels, margin, loss_weight, loss_rows, dfeat, n, d, (float*)ws, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions / optimizers
+int fte_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0 || fold <= 0 || cols % fold) return FTE_EINVAL;
+    return rc(k_reduce_rows(in, out, bias, bmod > 0 ? bmod : 1, rows, cols, fold, scale, (hipStream_t)stream));
+}
+int fte_sumsq(const float* a, long n, float scale, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!a || !out || ((uintptr_t)a & 15)) return FTE_EINVAL;
+    if (!ws || ws_bytes < 1024 * sizeof(float)) return FTE_EWORKSPACE;
+    return rc(k_sum(a, n, scale, out, (float*)ws, true, (hipStream_t)stream));
+}
+int fte_sum(const float* a, long n, float scale, float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (!a || !out || ((uintptr_t)a & 15)) return FTE_EINVAL;
+    if (!ws || ws_bytes < 1024 * sizeof(float)) return FTE_EWORKSPACE;
+    return rc(k_sum(a, n, scale, out, (float*)ws, false, (hipStream_t)stream));
+}
+int fte_momentum_update(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gscale, void* stream) {
+    if (!w || !acc || !g || n <= 0 || (((uintptr_t)w | (uintptr_t)acc | (uintptr_t)g) & 15)) return FTE_EINVAL;
+    return rc(k_momentum(w, acc, g, n, lr, mom, wd, gscale, (hipStream_t)stream));
+}
+int fte_adam_update(float* w, float* m, float* v, const float* g, long n, float lr, float b1, float b2, float eps,
+                    float wd, float gscale, int t, void* stream) {
+    if (!w || !m || !v || !g || n <= 0 || t < 1) return FTE_EINVAL;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t));
+    return rc(k_adam(w, m, v, g, n, (float)lr_t, b1, b2, eps, wd, gscale, (hipStream_t)stream));
+}
+
+}  // extern "C"

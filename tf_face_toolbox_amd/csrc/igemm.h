@@ -1,0 +1,41 @@
+// igemm.h -- parameter block and launcher of the gathered-GEMM kernel family (igemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { AL_MK = 0, AL_KM = 1 };           // A operand: k-contiguous rows (im2col) | m-contiguous (k = pixel)
+enum { BL_KN = 0, BL_NK = 1 };           // B operand: [k][n] n-contiguous | [n][k] k-contiguous (per tap)
+enum { EPI_FWD = 0, EPI_DGRAD = 1 };
+enum { TILE_128x128 = 0, TILE_256x64 = 1, TILE_128x64 = 2, TILE_64x64 = 3 };
+
+struct IgemmParams {
+    int M, N, K;          // K = NT*KC (tap modes) or number of pixels (AL_KM)
+    int kchunk;           // K range per blockIdx.y (multiple of 32)
+    // ---- A: gathered from an NHWC image -------------------------------------
+    const float* A;
+    int a_OH, a_OW;       // grid over which the GEMM row (AL_MK) / reduction index (AL_KM) decomposes
+    int a_IH, a_IW;       // source image
+    int a_stride;         // source pixels per grid step
+    int a_ld;             // floats per source pixel
+    int a_KC;             // channels per tap
+    int a_NT;             // taps
+    int a_dh[9], a_dw[9]; // source pixel = grid*stride + (dh, dw); out of range -> zero
+    // ---- B -------------------------------------------------------------------
+    const float* B;
+    int b_ld;
+    int b_tapoff[9];      // BL_NK: element offset of tap t
+    // ---- C / epilogue ----------------------------------------------------------
+    int c_OH, c_OW;       // 0,0: row m stored at m*c_ld; else m -> (n, oh, ow) on this grid ...
+    int c_FH, c_FW;       // ... placed at pixel (oh*c_step + c_ph, ow*c_step + c_pw) of a c_FH x c_FW image
+    int c_step, c_ph, c_pw;
+    int c_ld;
+    long slab;            // EPI_FWD: Y offset per blockIdx.y (split-K partial slabs)
+    // EPI_FWD:  v = acc + bias[n]; Z = v; Y = prelu(v, alpha[n]) + R
+    float* Y; float* Z; const float* R; const float* bias; const float* alpha;
+    // EPI_DGRAD: v = acc + ADD; RAW = v; DZ = v * prelu'(Zin, alpha[n % amod]);
+    //            PA[prow0 + mtile][n] = sum_rows v*min(Zin,0); PB[...] = sum_rows DZ
+    const float* ADD; float* RAW; const float* Zin; float* DZ; float* PA; float* PB;
+    int amod, prow0;
+};
+
+hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st);
+void igemm_tile_dims(int tile, int* bm, int* bn);

@@ -1,0 +1,25 @@
+// kernels.h -- host launchers of the HBM-bound kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
+                            int n, int h, int wd, int cin, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
+int k_conv_first_wgrad_blocks(long npix);
+hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int cin, int ho, int wo,
+                              int stride, int pt, int pl, int blocks, hipStream_t st);
+hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale, hipStream_t st);
+hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, bool sq, hipStream_t st);
+hipError_t k_softmax_ce(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld, float gs, hipStream_t st);
+hipError_t k_asoftmax(const float* s, const float* xn, const float* wn, const int32_t* labels, float lam, float* f, float* loss_rows,
+                      float* G, float* rowcoef, int n, int c, int ld, float gs, hipStream_t st);
+hipError_t k_asoftmax_colcoef(const float* G, const float* s, const float* wn, float* cc, int n, int c, int ld, hipStream_t st);
+hipError_t k_row_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st);
+hipError_t k_col_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st);
+hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* cc, int rows, int cols, int ld, hipStream_t st);
+hipError_t k_center_loss(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
+                         int n, int d, float alpha, float gs, float* ws, hipStream_t st);
+hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, float lw, float* loss_rows, float* dfeat,
+                     int n, int d, float* ws, hipStream_t st);
+hipError_t k_momentum(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gs, hipStream_t st);
+hipError_t k_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps, float wd, float gs, hipStream_t st);

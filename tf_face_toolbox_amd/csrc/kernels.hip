@@ -1,0 +1,546 @@
+// kernels.hip -- the HBM-bound kernels of the training step for gfx950:
+// first-layer direct conv (+wgrad), ordered reductions, softmax-CE / A-softmax /
+// center / triplet heads, flat-arena momentum and Adam.  Wave = 64 lanes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// block-wide reductions for 256-thread blocks (4 waves); result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// ------------------------------------------------------------------------------------
+// First conv (nets/sphere.py:57): Cin in {1,3}, Cout = 64, 3x3, TF-SAME.  K = 9*Cin is far
+// too short for MFMA; the layer is bound by the 2 x [N,Ho,Wo,64] fp32 writes (z and y).
+// Thread = 4 consecutive output pixels (along ow) x 4 consecutive output channels;
+// 16 threads cover one pixel's 64 channels -> 256-B coalesced row stores; weights in LDS.
+// ------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ alpha, float* __restrict__ z, float* __restrict__ y,
+    int n, int h, int wd, int ho, int wo, int stride, int pt, int pl) {
+    constexpr int COUT = 64, K = 9 * CIN;
+    __shared__ __attribute__((aligned(16))) float ws[K * COUT];
+    for (int i = threadIdx.x; i < K * COUT; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int cq = threadIdx.x & 15;                      // channel quad
+    const int wo4 = (wo + 3) >> 2;
+    const long grp = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const long ngrp = (long)n * ho * wo4;
+    if (grp >= ngrp) return;
+    const int owg = (int)(grp % wo4);
+    const long t = grp / wo4;
+    const int oh = (int)(t % ho), img = (int)(t / ho);
+    const int ow0 = owg * 4;
+    f32x4 acc[4];
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[p] = b4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int ih = oh * stride + r - pt;
+        if (ih < 0 || ih >= h) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + ((r * 3 + s) * CIN + c) * COUT + cq * 4);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int iw = (ow0 + p) * stride + s - pl;
+                    float xv = 0.f;
+                    if (iw >= 0 && iw < wd && ow0 + p < wo) xv = x[((long)(img * h + ih) * wd + iw) * CIN + c];
+                    acc[p] += xv * wv;
+                }
+            }
+        }
+    }
+    f32x4 a4 = {1.f, 1.f, 1.f, 1.f};
+    if (alpha) a4 = *reinterpret_cast<const f32x4*>(alpha + cq * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (ow0 + p >= wo) break;
+        const long o = ((long)(img * ho + oh) * wo + ow0 + p) * COUT + cq * 4;
+        f32x4 v = acc[p];
+        if (z) *reinterpret_cast<f32x4*>(z + o) = v;
+        if (alpha) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : a4[e] * v[e];
+        }
+        *reinterpret_cast<f32x4*>(y + o) = v;
+    }
+}
+
+// dW[r,s,c,co] partials: wave = one strided subset of a pixel chunk, lane = co (64 channels);
+// x taps are wave-uniform (scalar loads), dz rows are 256-B coalesced.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ part,
+    int n, int h, int wd, int ho, int wo, int stride, int pt, int pl, long pix_per_block) {
+    constexpr int COUT = 64, K = 9 * CIN;
+    __shared__ float red[4][K][COUT];
+    const int co = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long npix = (long)n * ho * wo;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = min(npix, p0 + pix_per_block);
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    for (long p = p0 + wv; p < p1; p += 4) {
+        const int ow = (int)(p % wo);
+        const long t = p / wo;
+        const int oh = (int)(t % ho), img = (int)(t / ho);
+        const float g = dz[p * COUT + co];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * stride + r - pt;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int iw = ow * stride + s - pl;
+                const bool ok = ih >= 0 && ih < h && iw >= 0 && iw < wd;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    const float xv = ok ? x[((long)(img * h + ih) * wd + iw) * CIN + c] : 0.f;
+                    acc[(r * 3 + s) * CIN + c] += xv * g;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[wv][k][co] = acc[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * COUT; i += 256) {
+        const int k = i / COUT, c = i % COUT;
+        part[(long)blockIdx.x * K * COUT + i] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Ordered (deterministic) row reduction: out[j] = scale * sum_r sum_t in[r, j + t*ocols] (+bias)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          const float* __restrict__ bias, int bmod, long rows,
+                                                          long cols, int fold, float scale) {
+    const long ocols = cols / fold;
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ocols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int t = 0; t < fold; ++t) {
+        const float* pcol = in + j + (long)t * ocols;
+        long r = 0;
+        for (; r + 3 < rows; r += 4) {
+            s0 += pcol[r * cols];
+            s1 += pcol[(r + 1) * cols];
+            s2 += pcol[(r + 2) * cols];
+            s3 += pcol[(r + 3) * cols];
+        }
+        for (; r < rows; ++r) s0 += pcol[r * cols];
+    }
+    float v = ((s0 + s1) + (s2 + s3)) * scale;
+    if (bias) v += bias[j % bmod];
+    out[j] = v;
+}
+
+// two-stage scalar reductions (sum / sum of squares): 1024 block partials, then one block
+template <bool SQ>
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ a, long n, float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = a4[i];
+        s += SQ ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = a[(n4 << 2) + threadIdx.x];
+        s += SQ ? v * v : v;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void final_sum_kernel(const float* __restrict__ part, int np, float scale, float* out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// ------------------------------------------------------------------------------------
+// Softmax cross-entropy, forward + gradient in one launch; one block per row.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                         float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                         int c, int ld, float gscale) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    const float* z = logits + (long)row * ld;
+    float* d = dlogits + (long)row * ld;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < c; j += 256) mx = fmaxf(mx, z[j]);
+    mx = block_max(mx, sh);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < c; j += 256) s += expf(z[j] - mx);
+    s = block_sum(s, sh);
+    const int y = labels[row];
+    const float inv = 1.f / s;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        float g = 0.f;
+        if (j < c) g = (expf(z[j] - mx) * inv - (j == y ? 1.f : 0.f)) * gscale;
+        d[j] = g;
+    }
+    if (threadIdx.x == 0) loss_rows[row] = logf(s) - (z[y] - mx);
+}
+
+// ------------------------------------------------------------------------------------
+// A-softmax (m = 4).  One block per row; s = raw x.W row.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void asoftmax_kernel(const float* __restrict__ s, const float* __restrict__ xn,
+                                                       const float* __restrict__ wn, const int32_t* __restrict__ labels,
+                                                       float lam, float* __restrict__ f, float* __restrict__ loss_rows,
+                                                       float* __restrict__ G, float* __restrict__ rowcoef,
+                                                       int c, int ld, float gscale) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    const float* sr = s + (long)row * ld;
+    float* gr = G + (long)row * ld;
+    const int y = labels[row];
+    const float xnorm = xn[row];
+    // target logit
+    const float cy = sr[y] / (xnorm * wn[y]);
+    const int k = (cy <= 0.70710678118654752f) + (cy <= 0.f) + (cy <= -0.70710678118654752f);
+    const float sign = (k & 1) ? -1.f : 1.f;
+    const float c2 = cy * cy;
+    const float psi = sign * (8.f * c2 * c2 - 8.f * c2 + 1.f) - 2.f * k;
+    const float dpsi = sign * (32.f * c2 * cy - 16.f * cy);
+    const float phi = lam * cy + psi, dphi = lam + dpsi;
+    const float fy = xnorm * phi / (1.f + lam);
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < c; j += 256) mx = fmaxf(mx, j == y ? fy : sr[j] / wn[j]);
+    mx = block_max(mx, sh);
+    float se = 0.f;
+    for (int j = threadIdx.x; j < c; j += 256) se += expf((j == y ? fy : sr[j] / wn[j]) - mx);
+    se = block_sum(se, sh);
+    const float inv = 1.f / se;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        float g = 0.f, fv = 0.f;
+        if (j < c) {
+            const float w_ = wn[j];
+            fv = j == y ? fy : sr[j] / w_;
+            const float sm = expf(fv - mx) * inv;
+            if (j == y) {
+                const float gy = (sm - 1.f) * gscale;
+                g = gy * dphi / ((1.f + lam) * w_);
+                rowcoef[row] = gy * (phi - dphi * cy) / ((1.f + lam) * xnorm);
+            } else {
+                g = sm * gscale / w_;
+            }
+        }
+        gr[j] = g;
+        if (f) f[(long)row * ld + j] = fv;
+    }
+    if (threadIdx.x == 0) loss_rows[row] = logf(se) - (fy - mx);
+}
+
+__global__ __launch_bounds__(256) void asoftmax_colcoef_kernel(const float* __restrict__ G, const float* __restrict__ s,
+                                                               const float* __restrict__ wn, float* __restrict__ cc,
+                                                               int n, int c, int ld) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ld) return;
+    float a = 0.f;
+    if (j < c) {
+        for (int i = 0; i < n; ++i) a += G[(long)i * ld + j] * s[(long)i * ld + j];
+        const float w_ = wn[j];
+        a = -a / (w_ * w_);
+    }
+    cc[j] = a;
+}
+
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ a, float* __restrict__ out, int cols, int ld) {
+    __shared__ float sh[4];
+    const float* r = a + (long)blockIdx.x * ld;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < cols; j += 256) s += r[j] * r[j];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrtf(s);
+}
+__global__ __launch_bounds__(256) void col_norms_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int cols, int ld) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < rows; ++i) {
+        const float v = a[(long)i * ld + j];
+        s += v * v;
+    }
+    out[j] = sqrtf(s);
+}
+__global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ rc, const float* __restrict__ cc,
+                                                         int rows, int cols, int ld) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)rows * cols) return;
+    const int i = (int)(idx / cols), j = (int)(idx % cols);
+    const long o = (long)i * ld + j;
+    float v = a[o];
+    const float bv = b[o];
+    if (rc) v += rc[i] * bv;
+    if (cc) v += cc[j] * bv;
+    a[o] = v;
+}
+
+// ------------------------------------------------------------------------------------
+// center loss (loss.py:29-45): one block per sample
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void center_loss_kernel(const float* __restrict__ feat, const int32_t* __restrict__ labels,
+                                                          const float* __restrict__ centers, float* __restrict__ diff,
+                                                          float* __restrict__ loss_rows, float* __restrict__ dfeat,
+                                                          int d, float gscale) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x, y = labels[i];
+    float s = 0.f;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const float df = feat[(long)i * d + j] - centers[(long)y * d + j];
+        s += df * df;
+        dfeat[(long)i * d + j] = 2.f * df * gscale;
+        diff[(long)i * d + j] = df;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) loss_rows[i] = s;
+}
+// scatter_sub after every gather has been served from the OLD centers (loss.py:37-39):
+// centers[y] -= (1-alpha)*(c_y - f)  ==  += (1-alpha)*(f - c_y); duplicate labels accumulate.
+__global__ __launch_bounds__(256) void center_update_kernel(const float* __restrict__ diff, const int32_t* __restrict__ labels,
+                                                            float* __restrict__ centers, int d, float alpha) {
+    const int i = blockIdx.x, y = labels[i];
+    for (int j = threadIdx.x; j < d; j += 256) atomicAdd(centers + (long)y * d + j, (1.f - alpha) * diff[(long)i * d + j]);
+}
+
+// ------------------------------------------------------------------------------------
+// batch-hard triplet (loss.py:47-78).  Gram form: D_ij^2 = |f_i|^2 + |f_j|^2 - 2 f_i.f_j
+// is NOT used for the distances themselves (cancellation would cost the fp32 tolerance):
+// one block per (i) computes D_i: directly from differences, N x N x D is tiny (N <= 256/GPU).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void triplet_dist_kernel(const float* __restrict__ feat, float* __restrict__ dist, int n, int d) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x / n, j = blockIdx.x % n;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < d; k += 256) {
+        const float df = feat[(long)i * d + k] - feat[(long)j * d + k];
+        s += df * df;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) dist[(long)i * n + j] = sqrtf(s + 1e-12f);
+}
+// one wave-sized block per anchor: hardest positive (max) / hardest negative (min), loss, and the
+// coefficient matrix coef[i][j] such that dfeat_a = sum_b (coef[a][b] + coef[b][a]) (f_a - f_b)
+__global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restrict__ dist, const int32_t* __restrict__ labels,
+                                                          float margin, float lw, float* __restrict__ loss_rows,
+                                                          float* __restrict__ coef, int n) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int yi = labels[i];
+    float bp = -1.f, bn = INFINITY;
+    int ip = -1, in_ = -1;
+    for (int j = lane; j < n; j += 64) {
+        const bool same = labels[j] == yi;
+        const float dv = dist[(long)i * n + j];
+        const float pv = (same && j != i) ? dv : 0.f;            // dists*pos_mask
+        const float nv = same ? 1e6f : dv;                        // dists*neg_mask + 1e6*intra (0*d + 1e6)
+        if (pv > bp) { bp = pv; ip = j; }
+        if (nv < bn) { bn = nv; in_ = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {       // argmax / argmin with first-index tie-break
+        const float op = __shfl_xor(bp, o); const int oip = __shfl_xor(ip, o);
+        if (op > bp || (op == bp && oip >= 0 && (ip < 0 || oip < ip))) { bp = op; ip = oip; }
+        const float on = __shfl_xor(bn, o); const int oin = __shfl_xor(in_, o);
+        if (on < bn || (on == bn && oin >= 0 && (in_ < 0 || oin < in_))) { bn = on; in_ = oin; }
+    }
+    for (int j = lane; j < n; j += 64) coef[(long)i * n + j] = 0.f;
+    __syncthreads();
+    if (lane == 0) {
+        const float v = bp - bn;
+        float loss, dv;
+        if (margin < 0.f) {
+            loss = v > 20.f ? v : log1pf(expf(v));
+            dv = 1.f / (1.f + expf(-v));
+        } else {
+            loss = fmaxf(0.f, v + margin);
+            dv = v + margin > 0.f ? 1.f : 0.f;
+        }
+        loss_rows[i] = loss;
+        dv *= lw;
+        const bool pos_real = ip >= 0 && ip != i && labels[ip] == yi;
+        const bool neg_real = in_ >= 0 && labels[in_] != yi;
+        if (pos_real) coef[(long)i * n + ip] += dv / dist[(long)i * n + ip];
+        if (neg_real) coef[(long)i * n + in_] -= dv / dist[(long)i * n + in_];
+    }
+}
+__global__ __launch_bounds__(256) void triplet_grad_kernel(const float* __restrict__ feat, const float* __restrict__ coef,
+                                                           float* __restrict__ dfeat, int n, int d) {
+    const int a = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += 256) {
+        float g = 0.f;
+        const float fa = feat[(long)a * d + k];
+        for (int b = 0; b < n; ++b) {
+            const float cf = coef[(long)a * n + b] + coef[(long)b * n + a];
+            if (cf != 0.f) g += cf * (fa - feat[(long)b * d + k]);
+        }
+        dfeat[(long)a * d + k] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Optimizers on the flat arena
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ w, float* __restrict__ acc, const float* __restrict__ g,
+                                                       long n, float lr, float mom, float wd, float gs) {
+    const long n4 = n >> 2;
+    f32x4* w4 = reinterpret_cast<f32x4*>(w);
+    f32x4* a4 = reinterpret_cast<f32x4*>(acc);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 wv = w4[i], av = a4[i];
+        const f32x4 gv = g4[i];
+        av = mom * av + (gs * gv + wd * wv);
+        wv = wv - lr * av;
+        a4[i] = av;
+        w4[i] = wv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long i = (n4 << 2) + threadIdx.x;
+        const float av = mom * acc[i] + (gs * g[i] + wd * w[i]);
+        acc[i] = av;
+        w[i] = w[i] - lr * av;
+    }
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, long n, float lr_t, float b1, float b2,
+                                                   float eps, float wd, float gs) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gv = gs * g[i] + wd * w[i];
+        const float mv = b1 * m[i] + (1.f - b1) * gv;
+        const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        w[i] = w[i] - lr_t * mv / (sqrtf(vv) + eps);
+    }
+}
+
+inline int grid_for(long n, int per) { long b = (n + per - 1) / per; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------
+hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
+                            int n, int h, int wd, int cin, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
+    const long ngrp = (long)n * ho * ((wo + 3) / 4);
+    const int blocks = (int)((ngrp + 15) / 16);
+    if (cin == 1) hipLaunchKernelGGL(conv_first_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl);
+    else if (cin == 3) hipLaunchKernelGGL(conv_first_fwd_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+int k_conv_first_wgrad_blocks(long npix) { long b = (npix + 511) / 512; return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); }
+hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int cin, int ho, int wo,
+                              int stride, int pt, int pl, int blocks, hipStream_t st) {
+    const long npix = (long)n * ho * wo;
+    const long ppb = (npix + blocks - 1) / blocks;
+    if (cin == 1) hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, x, dz, part, n, h, wd, ho, wo, stride, pt, pl, ppb);
+    else if (cin == 3) hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(blocks), dim3(256), 0, st, x, dz, part, n, h, wd, ho, wo, stride, pt, pl, ppb);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale, hipStream_t st) {
+    const long ocols = cols / fold;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ocols + 255) / 256)), dim3(256), 0, st, in, out, bias, bmod, rows, cols, fold, scale);
+    return hipGetLastError();
+}
+hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, bool sq, hipStream_t st) {
+    const int nb = grid_for(n, 256 * 4 * 8) > 1024 ? 1024 : grid_for(n, 256 * 4 * 8);
+    if (sq) hipLaunchKernelGGL(partial_sum_kernel<true>, dim3(nb), dim3(256), 0, st, a, n, ws);
+    else hipLaunchKernelGGL(partial_sum_kernel<false>, dim3(nb), dim3(256), 0, st, a, n, ws);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, ws, nb, scale, out);
+    return hipGetLastError();
+}
+hipError_t k_softmax_ce(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld, float gs, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gs);
+    return hipGetLastError();
+}
+hipError_t k_asoftmax(const float* s, const float* xn, const float* wn, const int32_t* labels, float lam, float* f, float* loss_rows,
+                      float* G, float* rowcoef, int n, int c, int ld, float gs, hipStream_t st) {
+    hipLaunchKernelGGL(asoftmax_kernel, dim3(n), dim3(256), 0, st, s, xn, wn, labels, lam, f, loss_rows, G, rowcoef, c, ld, gs);
+    return hipGetLastError();
+}
+hipError_t k_asoftmax_colcoef(const float* G, const float* s, const float* wn, float* cc, int n, int c, int ld, hipStream_t st) {
+    hipLaunchKernelGGL(asoftmax_colcoef_kernel, dim3((ld + 255) / 256), dim3(256), 0, st, G, s, wn, cc, n, c, ld);
+    return hipGetLastError();
+}
+hipError_t k_row_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st) {
+    hipLaunchKernelGGL(row_norms_kernel, dim3(rows), dim3(256), 0, st, a, out, cols, ld);
+    return hipGetLastError();
+}
+hipError_t k_col_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st) {
+    hipLaunchKernelGGL(col_norms_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, a, out, rows, cols, ld);
+    return hipGetLastError();
+}
+hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* cc, int rows, int cols, int ld, hipStream_t st) {
+    const long tot = (long)rows * cols;
+    hipLaunchKernelGGL(add_scaled_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, b, rc, cc, rows, cols, ld);
+    return hipGetLastError();
+}
+hipError_t k_center_loss(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
+                         int n, int d, float alpha, float gs, float* ws, hipStream_t st) {
+    hipLaunchKernelGGL(center_loss_kernel, dim3(n), dim3(256), 0, st, feat, labels, centers, ws, loss_rows, dfeat, d, gs);
+    hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), 0, st, ws, labels, centers, d, alpha);
+    return hipGetLastError();
+}
+hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, float lw, float* loss_rows, float* dfeat,
+                     int n, int d, float* ws, hipStream_t st) {
+    float* dist = ws;
+    float* coef = ws + (long)n * n;
+    hipLaunchKernelGGL(triplet_dist_kernel, dim3(n * n), dim3(256), 0, st, feat, dist, n, d);
+    hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(64), 0, st, dist, labels, margin, lw, loss_rows, coef, n);
+    hipLaunchKernelGGL(triplet_grad_kernel, dim3(n), dim3(256), 0, st, feat, coef, dfeat, n, d);
+    return hipGetLastError();
+}
+hipError_t k_momentum(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gs, hipStream_t st) {
+    hipLaunchKernelGGL(momentum_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, st, w, acc, g, n, lr, mom, wd, gs);
+    return hipGetLastError();
+}
+hipError_t k_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps, float wd, float gs, hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, w, m, v, g, n, lr_t, b1, b2, eps, wd, gs);
+    return hipGetLastError();
+}

@@ -1,0 +1,68 @@
+"""Net factory + Network ABC: the host-side mirror of the reference's nets/net_base.py.
+
+Same names, arguments and error behaviour as nets/net_base.py:22-63 (`net_select`) and
+:65-101 (`Network`).  What was graph construction in TF1 is eager here: `forward` /
+`loss_function` enqueue HIP kernels, and because there is no `tf.gradients`
+(data_parallel.py:33) a Network also implements `backward()`, which fills the flat
+gradient arena the parallel wrappers all-reduce.
+"""
+import abc
+
+
+def net_select(name, data_format='NCHW', weight_decay=5e-4):
+    """nets/net_base.py:22-63.  Names kept verbatim; `SphereNet-ASoftmax` is the margin net the
+    reference's `DataParallel_margin` (data_parallel.py:220) expects but whose code is missing
+    from the snapshot (README.md:14,19)."""
+    if name == 'SphereNet':
+        from .sphere import SphereNet
+        network = SphereNet(data_format=data_format, weight_decay=weight_decay)
+    elif name == 'SphereNet-ASoftmax':
+        from .sphere import SphereNetMargin
+        network = SphereNetMargin(data_format=data_format, weight_decay=weight_decay)
+    elif name in ('ResNeXt-26', 'ResNeXt-50', 'ResNet-50', 'SENet-50', 'ShuffleNet-v2-small',
+                  'ShuffleNet-v2-middle', 'ShuffleNet-v2-large'):
+        raise NotImplementedError('%s: kernels for BN / grouped / depthwise conv are the next rows of the '
+                                  'hot-path scope table (SURVEY.md 8a R1,R2,S1); not built yet.' % name)
+    elif name in ('MobileNet-v2', 'Inception-v4', 'VGG16', 'AlexNet'):
+        # nets/net_base.py:52-59 `pass` branches: the reference dies with UnboundLocalError here
+        raise UnboundLocalError("local variable 'network' referenced before assignment")
+    else:
+        raise ValueError('Unsupport network architecture.')
+    return network
+
+
+class Network(abc.ABC):
+    """nets/net_base.py:65-101."""
+
+    needs_labels = False       # True for margin nets: forward(images, labels, num_classes=...)
+
+    def __init__(self, weight_decay, data_format, name=None):
+        assert data_format in ['NCHW', 'NHWC'], 'Unknown data format.'
+        self.data_format = data_format
+        self.channel_axis = 1 if self.data_format == 'NCHW' else 3
+        self.spatial_axis = [2, 3] if self.data_format == 'NCHW' else [1, 2]
+        self.weight_decay = weight_decay
+        self.name = name
+
+    @abc.abstractmethod
+    def backbone(self, inputs, is_training, reuse):
+        pass
+
+    @abc.abstractmethod
+    def forward(self, images, num_classes, is_training):
+        pass
+
+    @abc.abstractmethod
+    def loss_function(self, scope, labels, **logits):
+        pass
+
+    @abc.abstractmethod
+    def backward(self):
+        """Replaces tf.gradients(total_loss, params): fill the gradient arena for the
+        batch that the last forward()/loss_function() saw."""
+
+    def param_list(self, is_training, trainable, scope=None):
+        raise NotImplementedError
+
+    def mult_lr_list(self, scope=None):
+        return [1.0 for _ in self.param_list(is_training=True, trainable=True, scope=scope)]

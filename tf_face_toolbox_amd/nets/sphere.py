@@ -1,0 +1,458 @@
+"""SphereNet-20 ("SphereFaceNet-20") on libfte.so -- host-side mirror of nets/sphere.py.
+
+Reference: nets/sphere.py:23-134 (class SphereNet: prelu :29-36, resBlock :38-45, backbone
+:47-76, forward :78-101, loss_function :103-118, param_list :120-126, pretrained_param
+:128-134).  Same constructor / method names and argument meaning; the bodies enqueue HIP
+kernels instead of building TF graph nodes.
+
+MI355X-first layout decisions (engine-internal; the boundary keeps the reference layouts):
+  * activations are NHWC fp32 end to end -- the NHWC->NCHW transpose of nets/sphere.py:53-54
+    disappears; with data_format='NCHW' only the ROW ORDER of the 25088x512 FC weight differs
+    (flatten order C,H,W vs H,W,C, nets/sphere.py:72) and that is permuted on import/export;
+  * all parameters live in ONE flat fp32 arena  [biases+alphas | conv W (HWIO) | FC W | classifier W],
+    gradients and optimizer slots in arenas of the same layout: one fused optimizer launch per
+    decay group and one (bucketed) RCCL all-reduce instead of 47 (data_parallel.py:179);
+  * the classifier is padded to a multiple of 128 columns (zero weights, masked in the loss);
+  * every conv keeps z (pre-activation) and y = PReLU(z) (+shortcut): backward needs sign(z)
+    and min(z,0) exactly, for any alpha.
+"""
+from collections import OrderedDict
+
+import torch
+
+from .. import _lib
+from .net_base import Network
+
+NUM_BLOCKS = (1, 2, 4, 1)     # nets/sphere.py:58,62,66,70
+EMBED = 512                   # nets/sphere.py:73
+
+
+def same_pads(in_size, k, stride):
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + k - in_size, 0)
+    return out, total // 2, total - total // 2
+
+
+class _Conv(object):
+    __slots__ = ('name', 'stage', 'stride', 'has_bias', 'second', 'cin', 'cout', 'hin', 'win', 'hout', 'wout')
+
+
+class Variable(object):
+    """A named view of the parameter arena, addressed by the reference's TF variable name."""
+
+    def __init__(self, name, kind, ref_shape, offset, size):
+        self.name, self.kind, self.ref_shape, self.offset, self.size = name, kind, tuple(ref_shape), offset, size
+
+    def __repr__(self):
+        return '<Variable %s %s>' % (self.name, self.ref_shape)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class SphereNet(Network):
+    head = 'softmax'
+
+    def __init__(self, weight_decay=0.0005, data_format='NCHW', name='SphereNet', seed=0):
+        super(SphereNet, self).__init__(weight_decay, data_format, name)
+        self.num_outputs = [64, 128, 256, 512]
+        self.seed = seed
+        self.built = False
+        self.tower_scale = 1.0        # 1/num_gpus, set by the parallel wrapper (data_parallel.py:37)
+        self.global_step = 0          # A-softmax lambda annealing reads it
+        self._act_n = None
+
+    # ------------------------------------------------------------------ construction
+    def _conv_specs(self, h, w, cin):
+        specs = []
+        for si, nb in enumerate(NUM_BLOCKS):
+            stage = '%s/conv%d' % (self.name, si + 1)
+            lst = [(stage + '/Conv', 2, True, None)]
+            for b in range(nb):
+                blk = stage + ('/resBlock' if nb == 1 else '/Repeat/resBlock_%d' % (b + 1))
+                lst += [(blk + '/Conv', 1, False, 0), (blk + '/Conv_1', 1, False, 1)]
+            for nm, stride, has_bias, second in lst:
+                c = _Conv()
+                c.name, c.stage, c.stride, c.has_bias, c.second = nm, si, stride, has_bias, second
+                c.cin, c.cout, c.hin, c.win = cin, self.num_outputs[si], h, w
+                c.hout, c.wout = same_pads(h, 3, stride)[0], same_pads(w, 3, stride)[0]
+                specs.append(c)
+                h, w, cin = c.hout, c.wout, c.cout
+        return specs
+
+    def build(self, height, width, channels, num_classes, device='cuda'):
+        """Create the variables (TF does this lazily inside the first forward())."""
+        _lib.load()
+        self.device = torch.device(device)
+        self.in_hwc = (height, width, channels)
+        self.num_classes = int(num_classes)
+        self.cpad = (self.num_classes + 127) // 128 * 128
+        self.convs = self._conv_specs(height, width, channels)
+        last = self.convs[-1]
+        self.feat_hwc = (last.hout, last.wout, last.cout)
+        self.fin = last.hout * last.wout * last.cout
+        # ---- arena layout: [small | conv W | FC W | classifier W(padded)] ----------------
+        small, big = [], []
+        for c in self.convs:
+            if c.has_bias:
+                small.append((c.name + '/biases', 'bias', (c.cout,), c.cout))
+            small.append((c.name + '/alpha', 'alpha', (c.cout,), c.cout))
+            big.append((c.name + '/weights', 'conv_w', (3, 3, c.cin, c.cout), 9 * c.cin * c.cout))
+        small.append((self.name + '/fully_connected/biases', 'fc_b', (EMBED,), EMBED))
+        big.append((self.name + '/fully_connected/weights', 'fc_w', (self.fin, EMBED), self.fin * EMBED))
+        big.append(('classifier/fc_classifier/weights', 'cls_w', (EMBED, self.num_classes), EMBED * self.cpad))
+        self.variables = OrderedDict()
+        off = 0
+        for nm, kind, shape, size in small + big:
+            self.variables[nm] = Variable(nm, kind, shape, off, size)
+            off += (size + 3) // 4 * 4
+        self.small_end = self.variables[big[0][0]].offset
+        self.cls_start = self.variables['classifier/fc_classifier/weights'].offset
+        self.fc_start = self.variables[self.name + '/fully_connected/weights'].offset
+        self.arena_size = off
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off + 4, dtype=torch.float32, device=dev)      # +4: [ce, reg, -, -] loss slots
+        self.loss_slots = self.grads[off:off + 4]
+        self._init_params()
+        self.built = True
+        return self
+
+    def view(self, name, arena=None):
+        v = self.variables[name]
+        a = self.params if arena is None else arena
+        return a[v.offset:v.offset + v.size]
+
+    def _init_params(self):
+        """Reference initialisers: nets/sphere.py:34 (alpha 0.25), :41-42 (N(0,0.01) resBlock convs),
+        :87 (N(0,1e-3) classifier); layers.conv2d / fully_connected defaults = Xavier-uniform, zero bias."""
+        g = torch.Generator().manual_seed(self.seed)
+        for c in self.convs:
+            if c.has_bias:
+                lim = (6.0 / (9 * c.cin + 9 * c.cout)) ** 0.5
+                w = (torch.rand(3, 3, c.cin, c.cout, generator=g) * 2 - 1) * lim
+            else:
+                w = torch.randn(3, 3, c.cin, c.cout, generator=g) * 0.01
+            self.view(c.name + '/weights').copy_(w.reshape(-1))
+            self.view(c.name + '/alpha').fill_(0.25)
+        lim = (6.0 / (self.fin + EMBED)) ** 0.5
+        w = (torch.rand(self.fin, EMBED, generator=g) * 2 - 1) * lim
+        self.view(self.name + '/fully_connected/weights').copy_(w.reshape(-1))
+        wc = torch.zeros(EMBED, self.cpad)
+        wc[:, :self.num_classes] = torch.randn(EMBED, self.num_classes, generator=g) * 0.001
+        self.view('classifier/fc_classifier/weights').copy_(wc.reshape(-1))
+
+    # ---- reference-layout import / export ----------------------------------------------
+    def _fc_perm(self, t, to_internal):
+        """FC weight rows: reference order is the flatten order of data_format (nets/sphere.py:72)."""
+        if self.data_format == 'NHWC':
+            return t
+        h, w, c = self.feat_hwc
+        if to_internal:
+            return t.reshape(c, h, w, EMBED).permute(1, 2, 0, 3).reshape(self.fin, EMBED)
+        return t.reshape(h, w, c, EMBED).permute(2, 0, 1, 3).reshape(self.fin, EMBED)
+
+    def get_variable(self, name, arena=None):
+        """Value of a variable (or of its gradient / slot when `arena` is given) in the REFERENCE layout."""
+        v = self.variables[name]
+        t = self.view(name, arena)
+        if v.kind == 'cls_w':
+            return t.reshape(EMBED, self.cpad)[:, :self.num_classes].clone()
+        if v.kind == 'fc_w':
+            return self._fc_perm(t.reshape(self.fin, EMBED), False).contiguous()
+        return t.reshape(v.ref_shape).clone()
+
+    def set_variable(self, name, value):
+        v = self.variables[name]
+        t = torch.as_tensor(value, dtype=torch.float32).to(self.device)
+        assert tuple(t.shape) == v.ref_shape, (name, tuple(t.shape), v.ref_shape)
+        if v.kind == 'cls_w':
+            buf = torch.zeros(EMBED, self.cpad, device=self.device)
+            buf[:, :self.num_classes] = t
+            t = buf
+        elif v.kind == 'fc_w':
+            t = self._fc_perm(t, True)
+        self.view(name).copy_(t.reshape(-1))
+
+    def load_params(self, params):
+        for k, val in params.items():
+            self.set_variable(k, val)
+
+    # ---- buffers that depend on the batch size -----------------------------------------
+    def _alloc_acts(self, n):
+        if self._act_n == n:
+            return
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.z, self.y = [], []
+        for c in self.convs:
+            self.z.append(torch.empty(n, c.hout, c.wout, c.cout, **f32))
+            self.y.append(torch.empty(n, c.hout, c.wout, c.cout, **f32))
+        self.emb = torch.empty(n, EMBED, **f32)
+        self.s_raw = torch.empty(n, self.cpad, **f32)
+        self.G = torch.empty(n, self.cpad, **f32)
+        self.logits_buf = torch.empty(n, self.cpad, **f32) if self.head == 'asoftmax' else self.s_raw
+        self.loss_rows = torch.empty(n, **f32)
+        self.xn = torch.empty(n, **f32)
+        self.wn = torch.empty(self.cpad, **f32)
+        self.rowcoef = torch.empty(n, **f32)
+        self.colcoef = torch.empty(self.cpad, **f32)
+        self.demb = torch.empty(n, EMBED, **f32)
+        self.bwd = {}
+        for si in range(4):
+            c = [q for q in self.convs if q.stage == si][0]
+            shp = (n, c.hout, c.wout, c.cout)
+            self.bwd[si] = dict(dz=[torch.empty(shp, **f32), torch.empty(shp, **f32)],
+                                raw=[torch.empty(shp, **f32), torch.empty(shp, **f32)], dzi=0, rawi=0)
+        need = 4096
+        q = _lib.query
+        for c in self.convs[1:]:
+            need = max(need, q('fte_conv3x3_wgrad_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride),
+                       q('fte_conv3x3_dgrad_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride))
+        c0 = self.convs[0]
+        need = max(need, q('fte_conv3x3_first_wgrad_ws_bytes', n, c0.hin, c0.win, c0.cin, c0.cout, c0.stride),
+                   q('fte_gemm_ws_bytes', n, EMBED, self.fin), q('fte_gemm_ws_bytes', n, self.cpad, EMBED))
+        self.ws = torch.empty((need + 3) // 4 + 1024, **f32)
+        self.ws_bytes = self.ws.numel() * 4
+        self._act_n = n
+
+    # ------------------------------------------------------------------ forward
+    def prelu(self, x, name='prelu'):
+        raise RuntimeError('PReLU is fused into the conv epilogue (fte_conv3x3_fwd); it is not a separate op here.')
+
+    def _check_images(self, images):
+        if not (isinstance(images, torch.Tensor) and images.is_cuda and images.dtype == torch.float32):
+            raise TypeError('images must be a float32 CUDA tensor in NHWC (data.py:275-279 layout)')
+        if not images.is_contiguous():
+            images = images.contiguous()
+        return images
+
+    def backbone(self, inputs, is_training=False, reuse=None):
+        """nets/sphere.py:47-76: [N,H,W,C] NHWC -> embedding [N,512] (a view of an internal buffer)."""
+        x = self._check_images(inputs)
+        n, h, w, ch = x.shape
+        if not self.built:
+            raise RuntimeError('call build() or forward(..., num_classes=) with is_training=True first')
+        assert (h, w, ch) == self.in_hwc, ((h, w, ch), self.in_hwc)
+        self._alloc_acts(n)
+        st = _stream()
+        call = _lib.call
+        keep = is_training
+        self._images = x
+        for l, c in enumerate(self.convs):
+            wv = self.view(c.name + '/weights')
+            bv = self.view(c.name + '/biases') if c.has_bias else None
+            av = self.view(c.name + '/alpha')
+            zz = self.z[l] if keep else None
+            if l == 0:
+                call('fte_conv3x3_first_fwd', x, wv, bv, av, zz, self.y[0], n, c.hin, c.win, c.cin, c.cout, c.stride, st)
+            else:
+                res = self.y[l - 2] if c.second == 1 else None
+                call('fte_conv3x3_fwd', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
+                     n, c.hin, c.win, c.cin, c.cout, c.stride, st)
+        call('fte_gemm_nn', self.y[-1], self.view(self.name + '/fully_connected/weights'),
+             self.view(self.name + '/fully_connected/biases'), self.emb, n, EMBED, self.fin, self.ws, self.ws_bytes, st)
+        return self.emb
+
+    def _classifier_raw(self, n):
+        _lib.call('fte_gemm_nn', self.emb, self.view('classifier/fc_classifier/weights'), None, self.s_raw,
+                  n, self.cpad, EMBED, self.ws, self.ws_bytes, _stream())
+
+    def _ensure_built(self, images, num_classes):
+        if not self.built:
+            n, h, w, ch = images.shape
+            self.build(h, w, ch, num_classes, images.device)
+        else:
+            assert num_classes == self.num_classes, 'num_classes changed after the variables were created'
+
+    def forward(self, images, num_classes=None, is_training=True):
+        """nets/sphere.py:78-101."""
+        if is_training:
+            assert num_classes is not None, 'num_classes must be given when is_training=True'
+            self._ensure_built(images, num_classes)
+            self.backbone(images, is_training=True)
+            self._classifier_raw(images.shape[0])
+            return {'logits': self.s_raw[:, :self.num_classes]}
+        return self._eval_features(images)
+
+    def _eval_features(self, images):
+        # nets/sphere.py:97-101: mean of the embeddings of x and of its horizontal flip (axis 2 of NHWC)
+        f1 = self.backbone(images, is_training=False).clone()
+        f2 = self.backbone(torch.flip(images, dims=[2]), is_training=False)
+        return (f1 + f2) / 2
+
+    # ------------------------------------------------------------------ loss
+    def _grad_scale(self, n):
+        # mean over the shard (tf.losses.sparse_softmax_cross_entropy) times the 1/num_gpus of
+        # data_parallel.py:37 -- applied at the head so that it propagates through backward for free.
+        return self.tower_scale / n
+
+    def _finish_losses(self, n):
+        st = _stream()
+        # slots: [ce * tower_scale, reg * tower_scale]  (sum over towers == data_parallel.py:248 mean)
+        _lib.call('fte_sum', self.loss_rows, n, self.tower_scale / n, self.loss_slots[0:1], self.ws, self.ws_bytes, st)
+        nreg = self.arena_size - self.small_end
+        _lib.call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
+                  self.loss_slots[1:2], self.ws, self.ws_bytes, st)
+
+    def loss_function(self, scope, labels, **logits):
+        """nets/sphere.py:103-118 + Network._regularize (nets/net_base.py:103-116).
+        Returns ([cross_entropy, reg_loss], names, others): the losses are 0-d device tensors
+        (views of the loss slots that ride on the gradient arena); read them after the step."""
+        n = labels.shape[0]
+        labels = self._check_labels(labels)
+        self._labels = labels
+        _lib.call('fte_softmax_ce_fwd_bwd', self.s_raw, labels, self.loss_rows, self.G, n, self.num_classes, self.cpad,
+                  self._grad_scale(n), _stream())
+        self._finish_losses(n)
+        return [self.loss_slots[0], self.loss_slots[1]], ['cross_entropy', 'reg_loss'], OrderedDict()
+
+    @staticmethod
+    def _check_labels(labels):
+        if not (isinstance(labels, torch.Tensor) and labels.is_cuda and labels.dtype == torch.int32):
+            raise TypeError('labels must be an int32 CUDA tensor (data.py:259)')
+        return labels.contiguous()
+
+    # ------------------------------------------------------------------ backward (replaces tf.gradients)
+    def _head_backward(self, n, st):
+        call = _lib.call
+        wc = self.view('classifier/fc_classifier/weights')
+        gwc = self.view('classifier/fc_classifier/weights', self.grads)
+        call('fte_gemm_tn', self.emb, self.G, gwc, n, self.cpad, EMBED, self.ws, self.ws_bytes, st)
+        call('fte_gemm_nt', self.G, wc, None, None, 0, None, self.demb, None, n, self.cpad, EMBED, self.ws, self.ws_bytes, st)
+
+    def backward_head(self):
+        """Classifier + FC gradients: the first (and largest) all-reduce bucket."""
+        n = self._act_n
+        st = _stream()
+        call = _lib.call
+        g = self.grads
+        self._head_backward(n, st)
+        fcw = self.name + '/fully_connected/weights'
+        call('fte_reduce_rows', self.demb, self.view(self.name + '/fully_connected/biases', g), None, 1, n, EMBED, 1, 1.0, st)
+        call('fte_gemm_tn', self.y[-1], self.demb, self.view(fcw, g), n, EMBED, self.fin, self.ws, self.ws_bytes, st)
+
+    def backward(self):
+        self.backward_head()
+        self.backward_body()
+
+    def backward_stages(self):
+        return [self.backward_head, self.backward_body]
+
+    def backward_body(self):
+        n = self._act_n
+        st = _stream()
+        call = _lib.call
+        g = self.grads
+        fcw = self.name + '/fully_connected/weights'
+        L = self.convs
+        last = len(L) - 1
+        b4 = self.bwd[L[last].stage]
+        d_out, dz_cur = b4['raw'][0], b4['dz'][0]
+        b4['rawi'], b4['dzi'] = 0, 0
+        call('fte_gemm_nt', self.demb, self.view(fcw), self.z[last], self.view(L[last].name + '/alpha'), L[last].cout,
+             d_out, dz_cur, self.view(L[last].name + '/alpha', g), n, EMBED, self.fin, self.ws, self.ws_bytes, st)
+        for l in range(last, -1, -1):
+            c = L[l]
+            gw = self.view(c.name + '/weights', g)
+            if l == 0:
+                call('fte_conv3x3_first_wgrad', self._images, dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
+                     self.ws, self.ws_bytes, st)
+                break
+            call('fte_conv3x3_wgrad', self.y[l - 1], dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
+                 self.ws, self.ws_bytes, st)
+            p = L[l - 1]
+            bp = self.bwd[p.stage]
+            addin = d_out if c.second == 0 else None
+            if p.stage != c.stage:
+                bp['dzi'], bp['rawi'] = 0, 0
+                dz_prev, raw_t = bp['dz'][0], bp['raw'][0]
+            else:
+                bp['dzi'] ^= 1
+                dz_prev = bp['dz'][bp['dzi']]
+                raw_t = bp['raw'][bp['rawi'] ^ 1]
+            raw = raw_t if p.second == 1 else None
+            call('fte_conv3x3_dgrad', dz_cur, self.view(c.name + '/weights'), addin, self.z[l - 1],
+                 self.view(p.name + '/alpha'), raw, dz_prev, self.view(p.name + '/alpha', g),
+                 self.view(p.name + '/biases', g) if p.has_bias else None,
+                 n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
+            if raw is not None:
+                d_out = raw
+                if p.stage == c.stage:
+                    bp['rawi'] ^= 1
+            dz_cur = dz_prev
+
+    # ------------------------------------------------------------------ bookkeeping the wrappers use
+    def param_list(self, is_training, trainable, scope=None):
+        """nets/sphere.py:120-126: [backbone vars, classifier vars] (lists of Variable)."""
+        bb = [v for k, v in self.variables.items() if k.startswith(self.name + '/')]
+        if is_training:
+            return [bb, [self.variables['classifier/fc_classifier/weights']]]
+        return [bb]
+
+    def pretrained_param(self, scope=None):
+        """nets/sphere.py:128-134: backbone variables only."""
+        return [v for grp in self.param_list(is_training=False, trainable=False, scope=scope) for v in grp
+                if self.name in v.name]
+
+    def arena_groups(self):
+        """(start, end, decayed, param_group_index) ranges of the flat arena, in arena order."""
+        return [(0, self.small_end, False, 0), (self.small_end, self.cls_start, True, 0),
+                (self.cls_start, self.arena_size, True, 1)]
+
+    def grad_buckets(self):
+        """All-reduce buckets in the order backward completes them: head (classifier + FC, produced
+        first, with the 4 loss slots that follow the arena riding along), then the conv stack."""
+        return [(self.fc_start, self.arena_size + 4), (0, self.fc_start)]
+
+
+class SphereNetMargin(SphereNet):
+    """SphereNet-20 + A-softmax (SphereFace, m = 4): the margin net DataParallel_margin drives
+    (data_parallel.py:220: forward(images, labels, num_classes=..., is_training=True)).  The head's
+    code is absent from the reference snapshot; spec = SURVEY.md Appendix A.9."""
+    head = 'asoftmax'
+    needs_labels = True
+
+    def __init__(self, weight_decay=0.0005, data_format='NCHW', name='SphereNet', seed=0,
+                 lambda_base=1000.0, gamma=0.12, power=1.0, lambda_min=5.0):
+        super(SphereNetMargin, self).__init__(weight_decay, data_format, name, seed)
+        self.lambda_base, self.gamma, self.power, self.lambda_min = lambda_base, gamma, power, lambda_min
+
+    def current_lambda(self):
+        return max(self.lambda_min, self.lambda_base * (1.0 + self.gamma * self.global_step) ** (-self.power))
+
+    def forward(self, images, labels=None, num_classes=None, is_training=True):
+        if not is_training:
+            return self._eval_features(images)
+        assert num_classes is not None, 'num_classes must be given when is_training=True'
+        assert labels is not None, 'margin nets take labels in forward (data_parallel.py:220)'
+        self._ensure_built(images, num_classes)
+        n = images.shape[0]
+        labels = self._check_labels(labels)
+        self._labels = labels
+        st = _stream()
+        self.backbone(images, is_training=True)
+        self._classifier_raw(n)
+        wc = self.view('classifier/fc_classifier/weights')
+        _lib.call('fte_row_norms', self.emb, self.xn, n, EMBED, EMBED, st)
+        _lib.call('fte_col_norms', wc, self.wn, EMBED, self.num_classes, self.cpad, st)
+        self.lam = self.current_lambda()
+        _lib.call('fte_asoftmax_fwd_bwd', self.s_raw, self.xn, self.wn, labels, self.lam, self.logits_buf, self.loss_rows,
+                  self.G, self.rowcoef, n, self.num_classes, self.cpad, self._grad_scale(n), st)
+        _lib.call('fte_asoftmax_colcoef', self.G, self.s_raw, self.wn, self.colcoef, n, self.num_classes, self.cpad, st)
+        return {'logits': self.logits_buf[:, :self.num_classes]}
+
+    def loss_function(self, scope, labels, **logits):
+        n = labels.shape[0]
+        self._finish_losses(n)
+        others = OrderedDict()
+        others['lambda'] = self.lam
+        return [self.loss_slots[0], self.loss_slots[1]], ['cross_entropy', 'reg_loss'], others
+
+    def _head_backward(self, n, st):
+        super(SphereNetMargin, self)._head_backward(n, st)
+        wc = self.view('classifier/fc_classifier/weights')
+        gwc = self.view('classifier/fc_classifier/weights', self.grads)
+        _lib.call('fte_add_scaled_rows_cols', gwc, wc, None, self.colcoef, EMBED, self.cpad, self.cpad, st)
+        _lib.call('fte_add_scaled_rows_cols', self.demb, self.emb, self.rowcoef, None, n, EMBED, EMBED, st)
