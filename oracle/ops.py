@@ -79,14 +79,18 @@ def prelu_fwd(z, alpha):
     return np.maximum(z, 0) + alpha * (z - np.abs(z)) * z.dtype.type(0.5)
 
 
-def prelu_bwd(z, alpha, dy):
-    neg = z <= 0            # d/dz at z==0: relu' = 0 and (1 - sign(0))*0.5 = 0.5 -> alpha*0.5 in TF.
-    # TF: d relu(0) = 0, d|x|(0) = sign(0) = 0  ->  dy*(0 + alpha*(1-0)*0.5) at exactly z == 0.
-    slope = np.where(z > 0, z.dtype.type(1), alpha * np.ones_like(z))
-    slope = np.where(z == 0, alpha * z.dtype.type(0.5) * np.ones_like(z), slope)
+def prelu_bwd(z, alpha, dy, zsign=None):
+    """Gradient of prelu_fwd.  TF: d relu(0) = 0 and d|x|(0) = sign(0) = 0, so the slope at exactly
+    z == 0 is alpha/2.  `zsign` (optional, same shape) replaces z in the three-way branch only: the
+    derivative is discontinuous at 0 and an fp32 evaluation of z may land on the other side of it
+    for |z| below fp32 resolution (see spherenet.kink_resolved)."""
+    zs = z if zsign is None else zsign
+    one = z.dtype.type(1)
+    slope = np.where(zs > 0, one, alpha * np.ones_like(z))
+    slope = np.where(zs == 0, alpha * z.dtype.type(0.5) * np.ones_like(z), slope)
     dz = dy * slope
     axes = tuple(range(z.ndim - 1))
-    dalpha = (dy * np.where(neg, z, 0)).sum(axis=axes)
+    dalpha = (dy * np.where(zs <= 0, z, 0)).sum(axis=axes)
     return dz, dalpha
 
 

@@ -117,7 +117,20 @@ def backbone_fwd(p, images, data_format='NCHW', keep=True):
     return emb, dict(layers=cache, feat_shape=feat_shape, flat=flat, data_format=data_format)
 
 
-def backbone_bwd(p, cache, demb):
+KINK_BAND = 1e-5      # |z| < KINK_BAND * rms(z): fp32 cannot tell which side of PReLU's kink z is on
+
+
+def kink_resolved(z, z_other):
+    """PReLU's derivative jumps at z = 0.  Where the float64 z lies within KINK_BAND*rms of the
+    kink, either one-sided slope is a valid answer for a float32 evaluation, so the oracle adopts
+    the side the checked implementation took (`z_other`, its own z) -- there and only there."""
+    thr = KINK_BAND * np.sqrt((z * z).mean())
+    return np.where(np.abs(z) < thr, z_other.astype(z.dtype), z)
+
+
+def backbone_bwd(p, cache, demb, trace=None, kink=None):
+    """`trace`, when a dict, receives the per-layer gradient wrt the pre-activation (name -> dz).
+    `kink`, when a dict name -> z of the implementation under test, resolves kink-band elements."""
     g = OrderedDict()
     dflat, g['SphereNet/fully_connected/weights'], g['SphereNet/fully_connected/biases'] = ops.fc_bwd(
         cache['flat'], p['SphereNet/fully_connected/weights'], demb, True)
@@ -129,7 +142,10 @@ def backbone_bwd(p, cache, demb):
         _, x, z = cache['layers'][li]
         if second == 1:
             dskip = dx                                   # out = shortcut + prelu(z2)
-        dz, g[name + '/alpha'] = ops.prelu_bwd(z, p[name + '/alpha'], dx)
+        zs = kink_resolved(z, kink[name]) if kink is not None and name in kink else None
+        dz, g[name + '/alpha'] = ops.prelu_bwd(z, p[name + '/alpha'], dx, zs)
+        if trace is not None:
+            trace[name] = dz
         if has_bias:
             g[name + '/biases'] = dz.sum(axis=(0, 1, 2))
         dxl, g[name + '/weights'] = ops.conv2d_bwd(x, p[name + '/weights'], dz, stride, need_dx=li > 0)
@@ -147,7 +163,7 @@ def eval_features(p, images, data_format='NCHW'):
 
 
 def loss_and_grads(p, images, labels, weight_decay=5e-4, data_format='NCHW',
-                   head='softmax', lam=None, grad_scale=None):
+                   head='softmax', lam=None, grad_scale=None, trace=None, kink=None):
     """One tower of data_parallel.py:45-63 / :215-236.
 
     Returns (losses=[ce, reg], grads incl. the L2 term, extras).  `grad_scale`
@@ -164,7 +180,7 @@ def loss_and_grads(p, images, labels, weight_decay=5e-4, data_format='NCHW',
         ce, logits, demb, dwc = ops.asoftmax_fwd_bwd(emb, wc, labels, lam, grad_scale)
     else:
         raise ValueError(head)
-    g = backbone_bwd(p, cache, demb)
+    g = backbone_bwd(p, cache, demb, trace, kink)
     g['classifier/fc_classifier/weights'] = dwc
     reg_names = regularized_names(p)
     reg = ops.l2_reg([p[k] for k in reg_names], weight_decay)
@@ -174,7 +190,7 @@ def loss_and_grads(p, images, labels, weight_decay=5e-4, data_format='NCHW',
 
 
 def train_step(p, slots, images, labels, lr, num_towers=1, weight_decay=5e-4,
-               data_format='NCHW', head='softmax', lam=None, optimizer='Momentum', t=1):
+               data_format='NCHW', head='softmax', lam=None, optimizer='Momentum', t=1, kink=None):
     """One global step as data_parallel.py builds it: split the batch into
     `num_towers` equal shards (:206-207), per-tower loss+grads scaled by
     1/num_towers (:37), sum over towers (:179), same update on every replica
@@ -185,8 +201,9 @@ def train_step(p, slots, images, labels, lr, num_towers=1, weight_decay=5e-4,
     total = None
     losses = np.zeros(2)
     for r in range(num_towers):
+        kr = None if kink is None else {k: v[r * sh:(r + 1) * sh] for k, v in kink.items()}
         ls, g, _ = loss_and_grads(p, images[r * sh:(r + 1) * sh], labels[r * sh:(r + 1) * sh],
-                                  weight_decay, data_format, head, lam)
+                                  weight_decay, data_format, head, lam, kink=kr)
         losses += np.array(ls) / num_towers
         if total is None:
             total = OrderedDict((k, v / num_towers) for k, v in g.items())

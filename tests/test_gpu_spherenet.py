@@ -9,7 +9,7 @@ from oracle import ops, spherenet as osn
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from util_gpu import dev, host, check_maxabs, check_rell2
+    from util_gpu import dev, host, check_maxabs, check_rell2, kink_of
     from tf_face_toolbox_amd import net_select, Singular
 
 
@@ -34,7 +34,6 @@ def test_forward_loss_and_every_gradient(name, data_format, n, h, w, ch, ncls):
     net, p, x, y = _setup(name, data_format, n, h, w, ch, ncls)
     head = 'asoftmax' if 'ASoftmax' in name else 'softmax'
     lam = ops.asoftmax_lambda(0)
-    losses_ref, g_ref, ex = osn.loss_and_grads(p, x, y, 5e-4, data_format, head, lam)
     xd, yd = dev(x), dev(y, torch.int32)
     net.tower_scale = 1.0
     if net.needs_labels:
@@ -44,6 +43,7 @@ def test_forward_loss_and_every_gradient(name, data_format, n, h, w, ch, ncls):
     losses, names, others = net.loss_function('TOWER', yd, **logits)
     net.backward()
     torch.cuda.synchronize()
+    losses_ref, g_ref, ex = osn.loss_and_grads(p, x, y, 5e-4, data_format, head, lam, kink=kink_of(net))
     assert names == ['cross_entropy', 'reg_loss']
     check_maxabs(host(net.emb), ex['embedding'], what='embedding')
     check_maxabs(host(logits['logits']), ex['logits'], what='logits')
@@ -64,10 +64,10 @@ def test_three_training_steps_match_oracle(optimizer):
     slots = osn.zero_slots(p, optimizer)
     for t in range(1, 4):
         step()
-        p, slots, l_ref = osn.train_step(p, slots, x, y, lr, optimizer=optimizer, t=t)
-        assert abs(float(losses[0]) - l_ref[0]) <= 2e-4 * max(1, abs(l_ref[0])), (t, float(losses[0]), l_ref)
+        p, slots, l_ref = osn.train_step(p, slots, x, y, lr, optimizer=optimizer, t=t, kink=kink_of(net))
+        assert abs(float(losses[0]) - l_ref[0]) <= 1e-5 * max(1, abs(l_ref[0])), (t, float(losses[0]), l_ref)
     for k in p:
-        tol = 2e-4 if optimizer == 'Momentum' else 5e-3      # Adam's 1/sqrt(v) amplifies fp32 noise in tiny grads
+        tol = 2e-5 if optimizer == 'Momentum' else 2e-3      # Adam's m/sqrt(v) is ~sign(g): fp32 noise in tiny grads is amplified
         check_maxabs(host(net.get_variable(k)), p[k], tol, what='weights after 3 steps ' + k)
 
 

@@ -4,11 +4,16 @@ import torch
 
 from tf_face_toolbox_amd import _lib
 
-# Stated tolerances (fp32 HIP path vs float64 oracle), SURVEY.md 8c:
-#   forward tensors  : max-abs-err <= 1e-4 * max|ref|
-#   gradients        : relative L2  <= 1e-4 per tensor
-TOL_MAXABS = 1e-4
-TOL_RELL2 = 1e-4
+# Stated tolerances (fp32 HIP path vs float64 oracle).  SURVEY.md 8c proposed 1e-4; measured on
+# MI355X the path sits at fp32's own noise floor (4e-7 .. 2e-6 relative, the same as the oracle
+# evaluated in float32), so the tests hold it 5-10x tighter than proposed:
+#   forward tensors  : max-abs-err <= 2e-5 * max|ref|
+#   gradients        : relative L2  <= 2e-5 per tensor
+# PReLU's derivative is discontinuous at z = 0: for |z| below fp32 resolution the float32 and
+# float64 evaluations may legitimately sit on different sides; whole-net tests pass the HIP
+# path's z to the oracle, which adopts its side inside the kink band only (oracle.spherenet.kink_resolved).
+TOL_MAXABS = 2e-5
+TOL_RELL2 = 2e-5
 
 
 def dev(a, dtype=torch.float32):
@@ -46,6 +51,11 @@ def check_rell2(got, ref, tol=TOL_RELL2, what=''):
 def ws(nbytes):
     t = torch.empty(max(int(nbytes), 4096) // 4 + 1024, dtype=torch.float32, device='cuda')
     return t, t.numel() * 4
+
+
+def kink_of(net):
+    """name -> z of every conv layer as the HIP path computed it (for oracle kink resolution)."""
+    return {c.name: host(net.z[i]) for i, c in enumerate(net.convs)}
 
 
 call = _lib.call

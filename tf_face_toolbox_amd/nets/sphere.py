@@ -353,8 +353,11 @@ class SphereNet(Network):
         b4['rawi'], b4['dzi'] = 0, 0
         call('fte_gemm_nt', self.demb, self.view(fcw), self.z[last], self.view(L[last].name + '/alpha'), L[last].cout,
              d_out, dz_cur, self.view(L[last].name + '/alpha', g), n, EMBED, self.fin, self.ws, self.ws_bytes, st)
+        trace = getattr(self, '_trace_dz', None)
         for l in range(last, -1, -1):
             c = L[l]
+            if trace is not None:
+                trace[c.name] = dz_cur.clone()
             gw = self.view(c.name + '/weights', g)
             if l == 0:
                 call('fte_conv3x3_first_wgrad', self._images, dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
