@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the data-parallel training step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): SphereFaceNet-20 + A-softmax, 112x112 RGB,
+GLOBAL batch 512 (train.py --batch_size is the global batch; data_parallel.py:206 splits it),
+C = 10,575 classes, fp32, Momentum 0.9, wd 5e-4, lr 1e-4 (at the reference default 0.1 this synthetic
+task -- one random-label batch fitted over and over by a BN-free net -- diverges to inf within 4-15
+steps; lr only scales the update, the work per step is identical, and the run must stay finite).  A step = forward + loss + backward +
+gradient all-reduce + optimizer (one `sess.run(train_ops)` of train.py:228) on synthetic inputs
+already resident in HBM.  Strong scaling: rank r works on rows [r*512/N, (r+1)*512/N).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel (fp32-MFMA implicit-GEMM conv forward, 128x128 tile; 14 of the
+                 16 resBlock convs, each exactly 115,605,504 MAC/image) timed with HIP events on the
+                 launch stream inside the timed steps, against the 157.3 TFLOP/s fp32 matrix peak;
+  cpu_baseline : the float32 CPU restatement of the reference graph (oracle/, kind "port") timed on
+                 this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GLOBAL_BATCH = 512
+H = W = 112
+CH = 3
+NUM_CLASSES = 10575
+MAC_PER_IMAGE_RESBLOCK_CONV = 115605504
+FP32_MFMA_PEAK_TFLOPS = 157.3                    # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+LR = 1e-4
+
+
+def cpu_baseline(sample_images, min_seconds=10.0):
+    """Times the float32 oracle (numpy + BLAS) on `sample_images` images of the same workload."""
+    import numpy as np
+    from oracle import spherenet as osn, ops as oops
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    p = {k: v.astype(np.float32) for k, v in osn.init_params(2, CH, NUM_CLASSES, H, W).items()}
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (sample_images, H, W, CH)).astype(np.float32)
+    y = np.random.default_rng(1).integers(0, NUM_CLASSES, sample_images)
+    slots = osn.zero_slots(p)
+    lam = np.float32(oops.asoftmax_lambda(0))
+    t0 = time.time()
+    reps = 0
+    while True:
+        p2, slots, _ = osn.train_step(p, slots, x, y, np.float32(0.1), head='asoftmax', lam=lam)
+        reps += 1
+        el = time.time() - t0
+        if el >= min_seconds or reps >= 8:
+            break
+    return {'value': round(sample_images * reps / el, 3), 'unit': 'images/sec', 'cores': int(threads),
+            'kind': 'port',
+            'sample': '%d training steps of %d images (same net/head/shape, float32 numpy+BLAS oracle), %.1f s on %d host cores (os.cpu_count=%s)'
+                      % (reps, sample_images, el, threads, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tf_face_toolbox_amd import net_select, Singular, DataParallel_margin
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    assert GLOBAL_BATCH % world == 0
+    shard = GLOBAL_BATCH // world
+
+    # synthetic inputs: images U[-1,1] seed 0, labels seed 1, reference initialisers seed 2
+    g = torch.Generator().manual_seed(0)
+    images = (torch.rand(GLOBAL_BATCH, H, W, CH, generator=g) * 2 - 1)[rank * shard:(rank + 1) * shard].to(dev)
+    g = torch.Generator().manual_seed(1)
+    labels = torch.randint(0, NUM_CLASSES, (GLOBAL_BATCH,), generator=g, dtype=torch.int32)[rank * shard:(rank + 1) * shard].to(dev)
+    net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+    net.seed = 2
+    inputs = {'images': images, 'labels': labels, 'num_classes': NUM_CLASSES, 'num_examples': 494414,
+              'batch_size': GLOBAL_BATCH}
+    if world > 1:
+        model = DataParallel_margin(net, LR, 'Momentum', num_gpus=world, weight_decay=5e-4)
+    else:
+        model = Singular(net, LR, 'Momentum', weight_decay=5e-4)
+    train_ops, losses, losses_name, others = model(inputs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_ops()
+    # dominant-kernel timing: HIP events on the launch stream around each 128x128-tile conv forward
+    ev = []
+    net._prof_events = ev
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_ops()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    net._prof_events = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_vals = [float(l) for l in losses]
+    import math
+    if not all(math.isfinite(v) for v in loss_vals):
+        raise SystemExit('non-finite losses %s: the timed run is invalid' % loss_vals)
+
+    if rank == 0:
+        ms = 1000.0 * elapsed / args.steps
+        kern_ms = [a.elapsed_time(b) for a, b in ev]
+        avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
+        flops = 2.0 * MAC_PER_IMAGE_RESBLOCK_CONV * shard
+        achieved = flops / (avg_ms * 1e-3) / 1e12 if kern_ms else None
+        out = {
+            'metric': 'images/sec (whole node), SphereFaceNet-20 112x112 bs512',
+            'value': round(GLOBAL_BATCH * args.steps / elapsed, 2),
+            'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3),
+            'higher_is_better': True,
+            'scaling': 'strong',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch 512, 10575 classes, Momentum, fp32',
+                       'global_batch': GLOBAL_BATCH, 'per_gpu_batch': shard, 'lr': LR, 'parallelism': 'dp%d' % world,
+                       'train_gflop_per_image': 12.2698},
+            'step_mfma_frac': round(GLOBAL_BATCH * args.steps / elapsed * 12.2698e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) / world, 4),
+            'losses': dict(zip(losses_name, [round(v, 6) for v in loss_vals])),
+            'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,2,2,MK,KN,FWD> (conv3x3 s1 forward + PReLU + residual)',
+                         'achieved': round(achieved, 2) if achieved else None, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
+                         'launches_timed': len(kern_ms), 'avg_launch_ms': round(avg_ms, 4),
+                         'flops_per_launch': flops, 'traffic': None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -6,7 +6,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfte.so')
+LIB_PATH = os.environ.get('FTE_LIB') or os.path.join(_HERE, 'libfte.so')     # FTE_LIB: A/B builds of the same ABI
 
 
 class FteError(RuntimeError):

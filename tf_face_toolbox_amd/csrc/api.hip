@@ -39,13 +39,57 @@ inline int pick_tile(long M, long N) {
     return cands[nc - 1];
 }
 
-// split-K plan: aim for ~3 blocks per CU, at least 8 K-steps (256 deep) per split
+// 256 CUs x 2 resident blocks of the big tiles (64-80 KiB of LDS each)
+constexpr long SLOTS = 512;
+
+// Row plan of an M x N output.  T big tiles on SLOTS resident blocks run in ceil(T/SLOTS) rounds, so a
+// launch of 1568 tiles pays for 4 rounds while doing 3.06 rounds of work.  The plan keeps whole rounds
+// in a big-tile MAIN launch and gives the leftover rows to a TAIL launch of 64x64 tiles (4x the blocks,
+// 1/4 the work each), which finishes in a fraction of a round.
+struct RowPlan { int main_tile; long main_rows, main_mtiles; int tail_tile; long tail_mtiles; };
+inline RowPlan plan_rows(long M, long N) {
+    RowPlan r;
+    const int big = (N % 128 == 0) ? TILE_128x128 : TILE_256x64;
+    int bm, bn;
+    igemm_tile_dims(big, &bm, &bn);
+    const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn;
+    r.tail_tile = TILE_64x64;
+    if (T < SLOTS) {                       // less than one round: smaller tiles for the whole op
+        r.main_tile = pick_tile(M, N);
+        igemm_tile_dims(r.main_tile, &bm, &bn);
+        r.main_rows = M; r.main_mtiles = (M + bm - 1) / bm; r.tail_mtiles = 0;
+        return r;
+    }
+    r.main_tile = big;
+    const long full = T / SLOTS * SLOTS;
+    if (T - full == 0 || T - full >= SLOTS * 4 / 5) {   // already (nearly) whole rounds
+        r.main_rows = M; r.main_mtiles = MT; r.tail_mtiles = 0;
+        return r;
+    }
+    r.main_mtiles = full / ntn;
+    r.main_rows = r.main_mtiles * bm;
+    r.tail_mtiles = (M - r.main_rows + 63) / 64;
+    return r;
+}
+
+// split-K plan: pick the split count whose tiles*splits fills whole rounds of SLOTS best
+// (>= 8 K-steps per split; ties go to fewer splits = less slab traffic)
 inline void plan_splits(long tiles, int K, int* splits, int* kchunk) {
-    int s = (int)((768 + tiles - 1) / tiles);
     const int maxs = K / 256 > 0 ? K / 256 : 1;
-    if (s > maxs) s = maxs;
-    if (s < 1) s = 1;
-    int kc = ((K + s - 1) / s + 31) / 32 * 32;
+    long lo = (SLOTS + tiles - 1) / tiles, hi = (3 * SLOTS + tiles - 1) / tiles;
+    if (lo < 1) lo = 1;
+    if (hi > maxs) hi = maxs;
+    if (lo > hi) lo = hi;
+    double best = -1.0;
+    int bs = 1;
+    for (long sI = lo; sI <= hi; ++sI) {
+        const int kc = (int)(((K + sI - 1) / sI + 31) / 32 * 32);
+        const long sp = (K + kc - 1) / kc;
+        const double rounds = (double)(tiles * sp) / SLOTS;
+        const double eff = rounds / (double)(long)(rounds + 0.999999);
+        if (eff > best + 0.02) { best = eff; bs = (int)sI; }
+    }
+    const int kc = ((K + bs - 1) / bs + 31) / 32 * 32;
     *kchunk = kc;
     *splits = (K + kc - 1) / kc;
 }
@@ -58,6 +102,27 @@ inline void plain_a(IgemmParams* p, const float* a, int ld, int kc) {
 }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t SCRATCH_BYTES = (size_t)REDUCE_SCRATCH_FLOATS * sizeof(float);
+
+// main (+ tail) launches of one row-tiled op; PA/PB partial rows are numbered main first, then tail
+inline hipError_t launch_rows(IgemmParams p, const RowPlan& rp, int al, int bl, int epi, long prow0, hipStream_t st) {
+    const int M = p.M;
+    p.m_base = 0; p.M = (int)rp.main_rows; p.prow0 = (int)prow0;
+    hipError_t e = igemm_launch(p, al, bl, epi, rp.main_tile, 1, st);
+    if (e != hipSuccess || rp.tail_mtiles == 0) return e;
+    p.m_base = (int)rp.main_rows; p.M = M; p.prow0 = (int)(prow0 + rp.main_mtiles);
+    return igemm_launch(p, al, bl, epi, rp.tail_tile, 1, st);
+}
+
+// operand sizes for the buffer-load range check; tensors must stay below 2 GiB (offsets are 32-bit,
+// 0x80000000 is the out-of-range marker)
+inline bool set_bytes(IgemmParams* p, size_t a_floats, size_t b_floats) {
+    const size_t lim = (size_t)1 << 31;
+    if (a_floats * 4 >= lim || b_floats * 4 >= lim) return false;
+    p->a_bytes = (unsigned)(a_floats * 4);
+    p->b_bytes = (unsigned)(b_floats * 4);
+    return true;
+}
 
 }  // namespace
 
@@ -80,12 +145,13 @@ int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const flo
     p.B = w; p.b_ld = cout;
     p.c_ld = cout;
     p.Y = y; p.Z = z; p.R = res; p.bias = bias; p.alpha = alpha;
-    return rc(igemm_launch(p, AL_MK, BL_KN, EPI_FWD, pick_tile(p.M, p.N), 1, (hipStream_t)stream));
+    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)9 * cin * cout)) return FTE_EINVAL;
+    return rc(launch_rows(p, plan_rows(p.M, p.N), AL_MK, BL_KN, EPI_FWD, 0, (hipStream_t)stream));
 }
 
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct DgradClass { int ph, pw, hq, wq, ntap, dh[9], dw[9], wt[9], tile; long mtiles; };
+struct DgradClass { int ph, pw, hq, wq, ntap, dh[9], dw[9], wt[9]; RowPlan rp; long mtiles; };
 int dgrad_classes(int n, int h, int wd, int cin, int stride, DgradClass* cls) {
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     int nc = 0;
@@ -110,10 +176,8 @@ int dgrad_classes(int n, int h, int wd, int cin, int stride, DgradClass* cls) {
             }
             if (c.ntap == 0) continue;
             const long M = (long)n * c.hq * c.wq;
-            c.tile = pick_tile(M, cin);
-            int bm, bn;
-            igemm_tile_dims(c.tile, &bm, &bn);
-            c.mtiles = (M + bm - 1) / bm;
+            c.rp = plan_rows(M, cin);
+            c.mtiles = c.rp.main_mtiles + c.rp.tail_mtiles;
             ++nc;
         }
     return nc;
@@ -126,7 +190,7 @@ size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int s
     const int nc = dgrad_classes(n, h, wd, cin, stride, cls);
     long rows = 0;
     for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
-    return 2 * align_up((size_t)rows * cin * sizeof(float));
+    return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES;
 }
 
 int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
@@ -141,7 +205,8 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
     for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
     const bool want_part = zprev && (dalpha_prev || dbias_prev);
     const size_t half = align_up((size_t)rows * cin * sizeof(float));
-    if (want_part && (!ws || ws_bytes < 2 * half)) return FTE_EWORKSPACE;
+    if (want_part && (!ws || ws_bytes < 2 * half + SCRATCH_BYTES)) return FTE_EWORKSPACE;
+    float* scratch = want_part ? (float*)((char*)ws + 2 * half) : nullptr;
     float* PA = want_part ? (float*)ws : nullptr;
     float* PB = want_part ? (float*)((char*)ws + half) : nullptr;
     long prow = 0;
@@ -161,14 +226,15 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
         else { p.c_OH = c.hq; p.c_OW = c.wq; p.c_FH = h; p.c_FW = wd; p.c_step = stride; p.c_ph = c.ph; p.c_pw = c.pw; }
         p.c_ld = cin;
         p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
-        p.PA = PA; p.PB = PB; p.prow0 = (int)prow;
-        hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_DGRAD, c.tile, 1, (hipStream_t)stream);
+        p.PA = PA; p.PB = PB;
+        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)9 * cin * cout)) return FTE_EINVAL;
+        hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
         prow += c.mtiles;
     }
     if (want_part) {
-        if (dalpha_prev) { hipError_t e = k_reduce_rows(PA, dalpha_prev, nullptr, 1, rows, cin, 1, 1.f, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
-        if (dbias_prev) { hipError_t e = k_reduce_rows(PB, dbias_prev, nullptr, 1, rows, cin, 1, 1.f, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+        if (dalpha_prev) { hipError_t e = k_reduce_rows(PA, dalpha_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+        if (dbias_prev) { hipError_t e = k_reduce_rows(PB, dbias_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
     }
     return FTE_OK;
 }
@@ -187,7 +253,7 @@ void wgrad_plan(int n, int h, int wd, int cin, int cout, int stride, int* tile, 
 size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
     int tile, splits, kchunk, K;
     wgrad_plan(n, h, wd, cin, cout, stride, &tile, &splits, &kchunk, &K);
-    return splits > 1 ? (size_t)splits * 9 * cin * cout * sizeof(float) : 0;
+    return (splits > 1 ? (size_t)splits * 9 * cin * cout * sizeof(float) : 0) + SCRATCH_BYTES;
 }
 
 int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
@@ -209,9 +275,10 @@ int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, 
     p.c_ld = cout;
     p.slab = (long)p.M * p.N;
     p.Y = splits > 1 ? (float*)ws : dw;
+    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)K * cout)) return FTE_EINVAL;
     hipError_t e = igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    if (splits > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+    if (splits > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream));
     return FTE_OK;
 }
 
@@ -225,7 +292,7 @@ int fte_conv3x3_first_fwd(const float* x, const float* w, const float* bias, con
 
 size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
-    return (size_t)k_conv_first_wgrad_blocks((long)n * ph.out * pw.out) * 9 * cin * cout * sizeof(float);
+    return align_up((size_t)k_conv_first_wgrad_blocks((long)n * ph.out * pw.out) * 9 * cin * cout * sizeof(float)) + SCRATCH_BYTES;
 }
 
 int fte_conv3x3_first_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
@@ -233,11 +300,11 @@ int fte_conv3x3_first_wgrad(const float* x, const float* dz, float* dw, int n, i
     if (!x || !dz || !dw || cout != 64 || (cin != 1 && cin != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     const int blocks = k_conv_first_wgrad_blocks((long)n * ph.out * pw.out);
-    const size_t need = (size_t)blocks * 9 * cin * cout * sizeof(float);
-    if (!ws || ws_bytes < need) return FTE_EWORKSPACE;
+    const size_t need = align_up((size_t)blocks * 9 * cin * cout * sizeof(float));
+    if (!ws || ws_bytes < need + SCRATCH_BYTES) return FTE_EWORKSPACE;
     hipError_t e = k_conv_first_wgrad(x, dz, (float*)ws, n, h, wd, cin, ph.out, pw.out, stride, ph.before, pw.before, blocks, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, blocks, 9L * cin * cout, 1, 1.f, (hipStream_t)stream));
+    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, blocks, 9L * cin * cout, 1, 1.f, (float*)((char*)ws + need), (hipStream_t)stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -260,7 +327,7 @@ size_t fte_gemm_ws_bytes(int m, int n, int k) {
     if (n % 64 == 0) { v = dense_slab_bytes(pick_tile(m, n), m, n, k); if (v > need) need = v; }
     if (k % 64 == 0) {
         v = dense_slab_bytes(pick_tile(m, k), m, k, n); if (v > need) need = v;
-        v = (size_t)((m + 63) / 64) * k * sizeof(float); if (v > need) need = v;
+        v = align_up((size_t)((m + 63) / 64) * k * sizeof(float)) + SCRATCH_BYTES; if (v > need) need = v;
     }
     if (n % 64 == 0) { v = dense_slab_bytes(tn_tile(k, n), k, n, m); if (v > need) need = v; }
     return need;
@@ -274,6 +341,7 @@ int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y, int
     p.M = m; p.N = n; p.K = k;
     plain_a(&p, x, k, k);
     p.B = w; p.b_ld = n; p.c_ld = n;
+    if (!set_bytes(&p, (size_t)m * k, (size_t)k * n)) return FTE_EINVAL;
     const int tile = pick_tile(m, n);
     int splits = 1, kchunk = k;
     if (tiles_of(tile, m, n) < 256) plan_splits(tiles_of(tile, m, n), k, &splits, &kchunk);
@@ -284,7 +352,7 @@ int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y, int
         p.Y = (float*)ws;
         hipError_t e = igemm_launch(p, AL_MK, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
-        return rc(k_reduce_rows((const float*)ws, y, bias, n, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+        return rc(k_reduce_rows((const float*)ws, y, bias, n, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream));
     }
     p.Y = y; p.bias = bias;
     return rc(igemm_launch(p, AL_MK, BL_KN, EPI_FWD, tile, 1, (hipStream_t)stream));
@@ -300,6 +368,7 @@ int fte_gemm_nt(const float* dy, const float* w, const float* zprev, const float
     p.M = m; p.N = k; p.K = n;
     plain_a(&p, dy, n, n);
     p.B = w; p.b_ld = n; p.c_ld = k;
+    if (!set_bytes(&p, (size_t)m * n, (size_t)k * n)) return FTE_EINVAL;
     const int tile = pick_tile(m, k);
     if (!zprev && !raw) {     // plain product, split-K allowed
         int splits = 1, kchunk = n;
@@ -311,7 +380,7 @@ int fte_gemm_nt(const float* dy, const float* w, const float* zprev, const float
             p.Y = (float*)ws;
             hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_FWD, tile, splits, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
-            return rc(k_reduce_rows((const float*)ws, dx, nullptr, 1, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+            return rc(k_reduce_rows((const float*)ws, dx, nullptr, 1, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream));
         }
         p.Y = dx;
         return rc(igemm_launch(p, AL_MK, BL_NK, EPI_FWD, tile, 1, (hipStream_t)stream));
@@ -321,12 +390,14 @@ int fte_gemm_nt(const float* dy, const float* w, const float* zprev, const float
     igemm_tile_dims(tile, &bm, &bn);
     const long mtiles = ((long)m + bm - 1) / bm;
     const bool want_part = zprev && dalpha_prev;
-    if (want_part && (!ws || ws_bytes < (size_t)mtiles * k * sizeof(float))) return FTE_EWORKSPACE;
+    const size_t part_bytes = align_up((size_t)mtiles * k * sizeof(float));
+    if (want_part && (!ws || ws_bytes < part_bytes + SCRATCH_BYTES)) return FTE_EWORKSPACE;
     p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = zprev ? amod : 1; p.DZ = dx;
     p.PA = want_part ? (float*)ws : nullptr;
     hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_DGRAD, tile, 1, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    if (want_part) return rc(k_reduce_rows((const float*)ws, dalpha_prev, nullptr, 1, mtiles, k, k / amod, 1.f, (hipStream_t)stream));
+    if (want_part) return rc(k_reduce_rows((const float*)ws, dalpha_prev, nullptr, 1, mtiles, k, k / amod, 1.f,
+                                           (float*)((char*)ws + part_bytes), (hipStream_t)stream));
     return FTE_OK;
 }
 
@@ -338,6 +409,7 @@ int fte_gemm_tn(const float* x, const float* dy, float* dw, int m, int n, int k,
     p.M = k; p.N = n; p.K = m;
     plain_a(&p, x, k, k);
     p.B = dy; p.b_ld = n; p.c_ld = n;
+    if (!set_bytes(&p, (size_t)m * k, (size_t)m * n)) return FTE_EINVAL;
     const int tile = tn_tile(k, n);
     int splits = 1, kchunk = (m + 31) / 32 * 32;
     if (tiles_of(tile, k, n) < 256) plan_splits(tiles_of(tile, k, n), m, &splits, &kchunk);
@@ -348,7 +420,7 @@ int fte_gemm_tn(const float* x, const float* dy, float* dw, int m, int n, int k,
         p.Y = (float*)ws;
         hipError_t e = igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
-        return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, (hipStream_t)stream));
+        return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream));
     }
     p.Y = dw;
     return rc(igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, 1, (hipStream_t)stream));
@@ -400,7 +472,7 @@ int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, flo
 // reductions / optimizers
 int fte_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0 || fold <= 0 || cols % fold) return FTE_EINVAL;
-    return rc(k_reduce_rows(in, out, bias, bmod > 0 ? bmod : 1, rows, cols, fold, scale, (hipStream_t)stream));
+    return rc(k_reduce_rows(in, out, bias, bmod > 0 ? bmod : 1, rows, cols, fold, scale, nullptr, (hipStream_t)stream));
 }
 int fte_sumsq(const float* a, long n, float scale, float* out, void* ws, size_t ws_bytes, void* stream) {
     if (!a || !out || ((uintptr_t)a & 15)) return FTE_EINVAL;

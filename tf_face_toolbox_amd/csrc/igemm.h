@@ -10,8 +10,11 @@ enum { TILE_128x128 = 0, TILE_256x64 = 1, TILE_128x64 = 2, TILE_64x64 = 3 };
 struct IgemmParams {
     int M, N, K;          // K = NT*KC (tap modes) or number of pixels (AL_KM)
     int kchunk;           // K range per blockIdx.y (multiple of 32)
+    int m_base;           // first GEMM row of this launch (rows [m_base, M) are tiled; lets one op be
+                          // split into a big-tile main launch and a small-tile tail launch)
     // ---- A: gathered from an NHWC image -------------------------------------
     const float* A;
+    unsigned a_bytes;     // size of the A tensor in bytes (< 2 GiB): buffer-load range check
     int a_OH, a_OW;       // grid over which the GEMM row (AL_MK) / reduction index (AL_KM) decomposes
     int a_IH, a_IW;       // source image
     int a_stride;         // source pixels per grid step
@@ -21,6 +24,7 @@ struct IgemmParams {
     int a_dh[9], a_dw[9]; // source pixel = grid*stride + (dh, dw); out of range -> zero
     // ---- B -------------------------------------------------------------------
     const float* B;
+    unsigned b_bytes;
     int b_ld;
     int b_tapoff[9];      // BL_NK: element offset of tap t
     // ---- C / epilogue ----------------------------------------------------------

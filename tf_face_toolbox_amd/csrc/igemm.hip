@@ -62,18 +62,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int mt = bid / ntn, nt_ = bid - mt * ntn;
-    const int m0 = mt * BM, n0 = nt_ * BN;
+    const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
     const int kbeg = blockIdx.y * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
 
     // ---- per-thread loader state ------------------------------------------------
+    // Operand tiles are fetched with raw buffer loads: a lane whose element is padding / out of
+    // range gets the byte offset OOB (>= num_records), for which the hardware returns 0.  No
+    // branches, no selects -- the whole K-step is one basic block and hipcc is free to spread the
+    // address arithmetic, the loads and the LDS writes between the 64-cycle MFMAs.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
     // A, MK layout (im2col rows): chunk column = tid&7, rows (tid>>3) + 32*i
-    int a_base[A_CH];
-    int a_mask[A_CH];
+    unsigned a_base[A_CH];   // byte offset of the row's (tap 0,0) source pixel + this thread's chunk
+    int a_mask[A_CH];        // bit t: tap t is inside the image for this row
     // A, KM layout (k = pixel): k-row = tid>>3, m-chunks (tid&7) + 8*i
-    int a_c[A_CH];        // channel offset inside the source pixel
-    int a_dhw[A_CH];      // packed (dh+8) | (dw+8)<<8 | valid<<16
+    int a_c[A_CH];           // byte offset inside the source pixel
+    int a_dhw[A_CH];         // packed (dh+8) | (dw+8)<<8 | valid<<16
     if constexpr (AL == AL_MK) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                     if (ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW) mask |= 1 << t;
                 }
             }
-            a_base[i] = base;
+            a_base[i] = (unsigned)(base + ((tid & 7) << 2)) * 4u;
             a_mask[i] = mask;
         }
     } else {
@@ -98,67 +105,68 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         for (int i = 0; i < A_CH; ++i) {
             const int m = m0 + 4 * ((tid & 7) + 8 * i);
             const int t = m / p.a_KC;
-            a_c[i] = m - t * p.a_KC;
+            a_c[i] = (m - t * p.a_KC) * 4;
             const int tt = t < p.a_NT ? t : 0;
             a_dhw[i] = (p.a_dh[tt] + 8) | ((p.a_dw[tt] + 8) << 8) | ((m < p.M ? 1 : 0) << 16);
         }
     }
+    // B: per-thread constant part of the byte offset
+    unsigned b_base[B_CH];
+    if constexpr (BL == BL_KN) {
+        constexpr int CPR = BN / 4, RPP = 256 / CPR;
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            b_base[i] = (unsigned)((tid / CPR + RPP * i) * p.b_ld + n0 + ((tid % CPR) << 2)) * 4u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            b_base[i] = (unsigned)((n0 + (tid >> 3) + 32 * i) * p.b_ld + ((tid & 7) << 2)) * 4u;
+    }
 
     f32x4 ra[A_CH], rb[B_CH];
+
+    auto ldg = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
 
     auto load_tiles = [&](int k0) {
         // ---------------- A ----------------
         if constexpr (AL == AL_MK) {
             const int tap = k0 / p.a_KC;
             const int kc0 = k0 - tap * p.a_KC;
-            const int toff = (p.a_dh[tap] * p.a_IW + p.a_dw[tap]) * p.a_ld + kc0 + ((tid & 7) << 2);
+            const unsigned toff = (unsigned)((p.a_dh[tap] * p.a_IW + p.a_dw[tap]) * p.a_ld + kc0) * 4u;   // wave-uniform
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((a_mask[i] >> tap) & 1) v = *reinterpret_cast<const f32x4*>(p.A + (long)(a_base[i] + toff));
-                ra[i] = v;
-            }
+            for (int i = 0; i < A_CH; ++i)
+                ra[i] = ldg(rsrcA, ((a_mask[i] >> tap) & 1) ? a_base[i] + toff : OOB, 0);
         } else {
             const int pix = k0 + (tid >> 3);
-            int n = 0, ih0 = 0, iw0 = 0;
             const bool kin = pix < kend;
-            if (kin) {
-                const int hw = p.a_OH * p.a_OW;
-                n = pix / hw;
-                const int rem = pix - n * hw;
-                const int oh = rem / p.a_OW;
-                ih0 = oh * p.a_stride;
-                iw0 = (rem - oh * p.a_OW) * p.a_stride;
-            }
+            const int hw = p.a_OH * p.a_OW;
+            const int n = pix / hw;
+            const int rem = pix - n * hw;
+            const int oh = rem / p.a_OW;
+            const int ih0 = oh * p.a_stride;
+            const int iw0 = (rem - oh * p.a_OW) * p.a_stride;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
                 const int ih = ih0 + (a_dhw[i] & 0xff) - 8, iw = iw0 + ((a_dhw[i] >> 8) & 0xff) - 8;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kin && (a_dhw[i] >> 16) && ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW)
-                    v = *reinterpret_cast<const f32x4*>(p.A + ((long)((n * p.a_IH + ih) * p.a_IW + iw) * p.a_ld + a_c[i]));
-                ra[i] = v;
+                const bool ok = kin && (a_dhw[i] >> 16) && ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW;
+                ra[i] = ldg(rsrcA, ok ? (unsigned)(((n * p.a_IH + ih) * p.a_IW + iw) * p.a_ld) * 4u + a_c[i] : OOB, 0);
             }
         }
         // ---------------- B ----------------
         if constexpr (BL == BL_KN) {
-            constexpr int CPR = BN / 4;               // chunks per k-row
-            constexpr int RPP = 256 / CPR;            // k-rows per pass
+            constexpr int CPR = BN / 4, RPP = 256 / CPR;
+            const unsigned koff = (unsigned)(k0 * p.b_ld) * 4u;                                         // wave-uniform
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                const int k = k0 + tid / CPR + RPP * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < kend) v = *reinterpret_cast<const f32x4*>(p.B + ((long)k * p.b_ld + n0 + ((tid % CPR) << 2)));
-                rb[i] = v;
-            }
+            for (int i = 0; i < B_CH; ++i)
+                rb[i] = ldg(rsrcB, (k0 + tid / CPR + RPP * i < kend) ? b_base[i] : OOB, koff);
         } else {
             const int tap = k0 / p.a_KC;
             const int kc0 = k0 - tap * p.a_KC;
-            const long toff = (long)p.b_tapoff[tap] + kc0 + ((tid & 7) << 2);
+            const unsigned toff = (unsigned)(p.b_tapoff[tap] + kc0) * 4u;                               // wave-uniform
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                const int nn = n0 + (tid >> 3) + 32 * i;
-                rb[i] = *reinterpret_cast<const f32x4*>(p.B + ((long)nn * p.b_ld + toff));
-            }
+            for (int i = 0; i < B_CH; ++i) rb[i] = ldg(rsrcB, b_base[i], toff);
         }
     };
 
@@ -198,43 +206,95 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Fragment reads are software-pipelined one u-step (8 k) ahead of the MFMAs that consume
+    // them: left to itself hipcc sinks each ds_read next to its consumer and every group of four
+    // 64-cycle MFMAs then starts with an exposed LDS round trip.
+    auto read_frags = [&](const float* As, const float* Bs, int u, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * (TM * 32) + i * 32 + li;
+            if constexpr (AL == AL_MK) {
+                fa[i] = *reinterpret_cast<const f32x4*>(As + row * BK + swz(row, 2 * u + lh));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[i][t] = As[(8 * u + 4 * lh + t) * BM + row];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * (TN * 32) + j * 32 + li;
+            if constexpr (BL == BL_KN) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fb[j][t] = Bs[(8 * u + 4 * lh + t) * BN + col];
+            } else {
+                fb[j] = *reinterpret_cast<const f32x4*>(Bs + col * BK + swz(col, 2 * u + lh));
+            }
+        }
+    };
+    auto mfma_block = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+    };
+#ifndef FTE_PIPE
+#define FTE_PIPE 3
+#endif
     auto compute = [&](int stage) {
         const float* As = smem + stage * STAGE;
         const float* Bs = As + BM * BK;
+#if FTE_PIPE == 0
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (TM * 32) + i * 32 + li;
-                if constexpr (AL == AL_MK) {
-                    fa[i] = *reinterpret_cast<const f32x4*>(As + row * BK + swz(row, 2 * u + lh));
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) fa[i][t] = As[(8 * u + 4 * lh + t) * BM + row];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * (TN * 32) + j * 32 + li;
-                if constexpr (BL == BL_KN) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) fb[j][t] = Bs[(8 * u + 4 * lh + t) * BN + col];
-                } else {
-                    fb[j] = *reinterpret_cast<const f32x4*>(Bs + col * BK + swz(col, 2 * u + lh));
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+            read_frags(As, Bs, u, fa, fb);
+            mfma_block(fa, fb);
         }
+#elif FTE_PIPE == 1
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        read_frags(As, Bs, 0, fa0, fb0);
+        read_frags(As, Bs, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(As, Bs, 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(As, Bs, 3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(fa1, fb1);
+#elif FTE_PIPE == 3
+        // fragments one u-step ahead, no fences: hipcc may slot loads / LDS writes between MFMAs
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        read_frags(As, Bs, 0, fa0, fb0);
+        read_frags(As, Bs, 1, fa1, fb1);
+        mfma_block(fa0, fb0);
+        read_frags(As, Bs, 2, fa0, fb0);
+        mfma_block(fa1, fb1);
+        read_frags(As, Bs, 3, fa1, fb1);
+        mfma_block(fa0, fb0);
+        mfma_block(fa1, fb1);
+#else
+        // all fragments of the K-step up front, no scheduling fences
+        f32x4 fa[4][TM], fb[4][TN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) read_frags(As, Bs, u, fa[u], fb[u]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mfma_block(fa[u], fb[u]);
+#endif
     };
 
     // ---- main loop: one barrier per K-step, loads for step s+1 in flight under step s ----
+#ifndef FTE_ABL
+#define FTE_ABL 0      // ablation builds (timing only, wrong results): 1 no global loads, 2 +no LDS stores, 3 +no barrier
+#endif
     if (nsteps > 0) {
         load_tiles(kbeg);
         store_tiles(0);
@@ -242,10 +302,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         for (int s = 0; s < nsteps; ++s) {
             const int cur = s & 1;
             const bool more = s + 1 < nsteps;
+#if FTE_ABL == 0
             if (more) load_tiles(kbeg + (s + 1) * BK);
+#endif
             compute(cur);
+#if FTE_ABL <= 1
             if (more) store_tiles(cur ^ 1);
+#endif
+#if FTE_ABL <= 2
             __syncthreads();
+#endif
         }
     }
 
@@ -353,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
 hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
-    const int mt = (p.M + BM - 1) / BM, nt = p.N / BN;
+    const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
     const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI>;
     static bool attr_done = false;

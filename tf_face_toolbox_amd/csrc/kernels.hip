@@ -146,29 +146,35 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
 }
 
 // ------------------------------------------------------------------------------------
-// Ordered (deterministic) row reduction: out[j] = scale * sum_r sum_t in[r, j + t*ocols] (+bias)
+// Ordered (deterministic) column sums of a [rows, cols] matrix:
+//   out[j] = scale * sum_r in[r, j]  (+ bias[j % bmod])
+// grid = (ceil(cols/64), row_splits); block = 64 columns x 4 row lanes.  With row_splits > 1 the
+// kernel writes partial[rs, cols] and is run a second time over those partials (fixed order).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           const float* __restrict__ bias, int bmod, long rows,
-                                                          long cols, int fold, float scale) {
-    const long ocols = cols / fold;
-    const long j = (long)blockIdx.x * 256 + threadIdx.x;
-    if (j >= ocols) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int t = 0; t < fold; ++t) {
-        const float* pcol = in + j + (long)t * ocols;
-        long r = 0;
-        for (; r + 3 < rows; r += 4) {
-            s0 += pcol[r * cols];
-            s1 += pcol[(r + 1) * cols];
-            s2 += pcol[(r + 2) * cols];
-            s3 += pcol[(r + 3) * cols];
+                                                          long cols, long rows_per_split, float scale) {
+    __shared__ float sh[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * 64 + c;
+    const long r0 = (long)blockIdx.y * rows_per_split;
+    const long r1 = min(rows, r0 + rows_per_split);
+    float s0 = 0.f, s1 = 0.f;
+    if (j < cols) {
+        long r = r0 + rl;
+        for (; r + 4 < r1; r += 8) {
+            s0 += in[r * cols + j];
+            s1 += in[(r + 4) * cols + j];
         }
-        for (; r < rows; ++r) s0 += pcol[r * cols];
+        if (r < r1) s0 += in[r * cols + j];
     }
-    float v = ((s0 + s1) + (s2 + s3)) * scale;
-    if (bias) v += bias[j % bmod];
-    out[j] = v;
+    sh[rl][c] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && j < cols) {
+        float v = ((sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c])) * scale;
+        if (bias) v += bias[j % bmod];
+        out[(long)blockIdx.y * cols + j] = v;
+    }
 }
 
 // two-stage scalar reductions (sum / sum of squares): 1024 block partials, then one block
@@ -483,9 +489,28 @@ hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int 
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale, hipStream_t st) {
-    const long ocols = cols / fold;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ocols + 255) / 256)), dim3(256), 0, st, in, out, bias, bmod, rows, cols, fold, scale);
+// scratch: REDUCE_SCRATCH_FLOATS floats, only touched when the matrix is tall and narrow
+hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale,
+                         float* scratch, hipStream_t st) {
+    // [rows, fold, cols/fold] is the same memory as [rows*fold, cols/fold]: folding is a reshape
+    rows *= fold;
+    cols /= fold;
+    const long cb = (cols + 63) / 64;
+    long rs = 1;
+    if (scratch && cb < 512 && rows >= 64) {
+        rs = 1024 / cb;
+        if (rs > rows / 16) rs = rows / 16;
+        if (rs * cols > REDUCE_SCRATCH_FLOATS) rs = REDUCE_SCRATCH_FLOATS / cols;
+        if (rs < 1) rs = 1;
+    }
+    if (rs == 1) {
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1), dim3(256), 0, st, in, out, bias, bmod, rows, cols, rows, scale);
+        return hipGetLastError();
+    }
+    const long rps = (rows + rs - 1) / rs;
+    rs = (rows + rps - 1) / rps;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, (unsigned)rs), dim3(256), 0, st, in, scratch, (const float*)nullptr, 1, rows, cols, rps, 1.f);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1), dim3(256), 0, st, (const float*)scratch, out, bias, bmod, rs, cols, rs, scale);
     return hipGetLastError();
 }
 hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, bool sq, hipStream_t st) {
