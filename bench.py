@@ -14,9 +14,13 @@ gradient all-reduce + optimizer (one `sess.run(train_ops)` of train.py:228) on s
 already resident in HBM.  Strong scaling: rank r works on rows [r*512/N, (r+1)*512/N).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel (fp32-MFMA implicit-GEMM conv forward, 128x128 tile; 14 of the
-                 16 resBlock convs, each exactly 115,605,504 MAC/image) timed with HIP events on the
-                 launch stream inside the timed steps, against the 157.3 TFLOP/s fp32 matrix peak;
+  roofline     : the dominant kernel symbol igemm_kernel<128,128,2,2,MK,KN,FWD> (fp32-MFMA implicit-GEMM
+                 conv3x3 forward, 128x128 tile: the whole-round part of 14 resBlock convs + the three
+                 stride-2 stage-entry convs).  Every launch of it inside the timed steps is bracketed by a
+                 HIP event pair on the launch stream (fte_prof_*, include/fte.h); achieved = sum of the
+                 launches' algorithmic FLOPs (2*rows*N*K each) / sum of their durations, against the
+                 157.3 TFLOP/s fp32 matrix peak.  avg_launch_ms is directly comparable with the
+                 AverageNs of the same symbol in profiles/*kernel_stats.csv;
   cpu_baseline : the float32 CPU restatement of the reference graph (oracle/, kind "port") timed on
                  this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -115,18 +119,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from tf_face_toolbox_amd import _lib
     for _ in range(args.warmup):
         train_ops()
-    # dominant-kernel timing: HIP events on the launch stream around each 128x128-tile conv forward
-    ev = []
-    net._prof_events = ev
     barrier()
+    _lib.query('fte_prof_enable', 1)        # event pairs around every MFMA-kernel launch of the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         train_ops()
     barrier()
     elapsed = time.perf_counter() - t0
-    net._prof_events = None
+    _lib.query('fte_prof_enable', 0)
+    records = _lib.prof_records() if rank == 0 else []
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -138,10 +142,26 @@ def main():
 
     if rank == 0:
         ms = 1000.0 * elapsed / args.steps
-        kern_ms = [a.elapsed_time(b) for a, b in ev]
-        avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
-        flops = 2.0 * MAC_PER_IMAGE_RESBLOCK_CONV * shard
-        achieved = flops / (avg_ms * 1e-3) / 1e12 if kern_ms else None
+        # per-symbol table: sig = (A layout, B layout, epilogue, tile)
+        table = {}
+        for sig, fl, ms_ in records:
+            t = table.setdefault(sig[:4], [0, 0.0, 0.0])
+            t[0] += 1; t[1] += fl; t[2] += ms_
+        DOM = (0, 0, 0, 0)                     # igemm_kernel<128,128,2,2,AL_MK,BL_KN,EPI_FWD>
+        if DOM not in table:                   # small shards never take the 128x128 tile: use the busiest symbol
+            DOM = max(table, key=lambda k: table[k][2])
+        cnt, dom_flops, dom_ms = table[DOM]
+        kern_ms = [1] * cnt
+        avg_ms = dom_ms / cnt
+        flops = dom_flops / cnt
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        all_ms = sum(v[2] for v in table.values())
+        all_flops = sum(v[1] for v in table.values())
+        traffic, tinfo = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+        if world == 1 and os.path.exists(tpath):
+            tinfo = json.load(open(tpath))       # PMC passes cannot run inside this process: measured by
+            traffic = tinfo['bytes_per_launch']   # rocprofv3 --pmc on this same command, kept under profiles/
         out = {
             'metric': 'images/sec (whole node), SphereFaceNet-20 112x112 bs512',
             'value': round(GLOBAL_BATCH * args.steps / elapsed, 2),
@@ -158,11 +178,17 @@ def main():
                        'train_gflop_per_image': 12.2698},
             'step_mfma_frac': round(GLOBAL_BATCH * args.steps / elapsed * 12.2698e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) / world, 4),
             'losses': dict(zip(losses_name, [round(v, 6) for v in loss_vals])),
-            'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,2,2,MK,KN,FWD> (conv3x3 s1 forward + PReLU + residual)',
-                         'achieved': round(achieved, 2) if achieved else None, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if achieved else None,
-                         'launches_timed': len(kern_ms), 'avg_launch_ms': round(avg_ms, 4),
-                         'flops_per_launch': flops, 'traffic': None},
+            'roofline': {'bound': 'mfma',
+                         'kernel': 'igemm_kernel<tile %d, A-layout %d, B-layout %d, epilogue %d> (tile 0 = 128x128; 0,0,0 = conv3x3 forward + bias/PReLU/residual)' % (DOM[3], DOM[0], DOM[1], DOM[2]),
+                         'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         'launches_timed': cnt, 'avg_launch_ms': round(avg_ms, 4),
+                         'flops_per_launch_avg': flops,
+                         'traffic': traffic, 'traffic_source': (tinfo or {}).get('summary_file'),
+                         'algorithmic_bytes_per_launch': (tinfo or {}).get('algorithmic_bytes_per_launch'),
+                         'all_mfma_kernels': {'launches': len(records), 'ms_per_step': round(all_ms / args.steps, 3),
+                                              'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+                                              'frac': round(all_flops / (all_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_sample)

@@ -42,6 +42,17 @@ extern "C" {
 /* Library / build identification: "fte <version> gfx950". */
 const char* fte_version(void);
 
+/* Measurement hook (bench.py's roofline leg; no reference counterpart).  While enabled, every
+ * launch of the MFMA kernel family is bracketed by a HIP event pair ON THE LAUNCH STREAM and its
+ * algorithmic FLOPs (2*rows*N*K of that launch) are recorded.  fte_prof_enable(1) clears and starts,
+ * fte_prof_enable(0) stops; after a device synchronise, fte_prof_get returns record i:
+ * sig = {A layout, B layout, epilogue, tile id, split count} (identifies the kernel symbol:
+ * igemm_kernel<BM,BN,WM,WN,sig[0],sig[1],sig[2]>; tile 0=128x128 1=256x64 2=128x64 3=64x64),
+ * flops, and the launch's duration in milliseconds. */
+int fte_prof_enable(int on);
+int fte_prof_count(void);
+int fte_prof_get(int i, int* sig, double* flops, float* ms);
+
 /* ---------------------------------------------------------------------------
  * 3x3 convolution, TF-SAME, stride 1 or 2, Cin % 32 == 0, Cout % 64 == 0
  * (every conv of nets/sphere.py:41-42,61,65,69 except the first).

@@ -16,6 +16,9 @@ class FteError(RuntimeError):
 _P = c_void_p
 _SIGS = {
     'fte_version': (c_char_p, []),
+    'fte_prof_enable': (c_int, [c_int]),
+    'fte_prof_count': (c_int, []),
+    'fte_prof_get': (c_int, [c_int, _P, _P, _P]),
     'fte_conv3x3_fwd': (c_int, [_P] * 7 + [c_int] * 6 + [_P]),
     'fte_conv3x3_dgrad': (c_int, [_P] * 9 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_dgrad_ws_bytes': (c_size_t, [c_int] * 6),
@@ -89,3 +92,19 @@ def query(name, *args):
 
 def version():
     return load().fte_version().decode()
+
+
+def prof_records():
+    """All launch records since fte_prof_enable(1): list of (sig tuple, flops, ms).  Synchronise first."""
+    lib = load()
+    out = []
+    sig = (ctypes.c_int * 5)()
+    fl = ctypes.c_double()
+    ms = ctypes.c_float()
+    for i in range(lib.fte_prof_count()):
+        r = lib.fte_prof_get(i, ctypes.cast(sig, c_void_p), ctypes.cast(ctypes.pointer(fl), c_void_p),
+                             ctypes.cast(ctypes.pointer(ms), c_void_p))
+        if r != 0:
+            raise FteError('fte_prof_get(%d) failed with code %d' % (i, r))
+        out.append((tuple(sig), fl.value, ms.value))
+    return out

@@ -130,6 +130,13 @@ extern "C" {
 
 const char* fte_version(void) { return "fte 0.1 gfx950 fp32-mfma"; }
 
+int fte_prof_enable(int on) { igemm_prof_enable(on != 0); return FTE_OK; }
+int fte_prof_count(void) { return igemm_prof_count(); }
+int fte_prof_get(int i, int* sig, double* flops, float* ms) {
+    if (!sig || !flops || !ms) return FTE_EINVAL;
+    return rc(igemm_prof_get(i, sig, flops, ms));
+}
+
 // ------------------------------------------------------------------------------------------------
 int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
                     float* z, float* y, int n, int h, int wd, int cin, int cout, int stride, void* stream) {

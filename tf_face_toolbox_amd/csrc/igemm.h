@@ -43,3 +43,8 @@ struct IgemmParams {
 
 hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st);
 void igemm_tile_dims(int tile, int* bm, int* bn);
+
+// launch records for the roofline measurement (see igemm.hip)
+void igemm_prof_enable(bool on);
+int igemm_prof_count();
+hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms);

@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <vector>
+
 #include "igemm.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,6 +34,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int BK = 32;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 2; }
 
@@ -123,6 +134,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
             b_base[i] = (unsigned)((n0 + (tid >> 3) + 32 * i) * p.b_ld + ((tid & 7) << 2)) * 4u;
     }
 
+    // Reduction order for tap-structured operands: K-step sigma = k0/32 covers channel chunk
+    // sigma / NT of tap sigma % NT (chunk outer, tap inner).  The NT taps of one 32-channel chunk
+    // touch ~1.3x one window of 128-B row pieces (~21 KB for a 128-row tile): they hit in the CU's L1
+    // instead of streaming the whole Cin-wide window once per tap from L2 / Infinity Cache.
+    // Weight / B rows are addressed accordingly (row tap*KC + chunk*32); sums are order-independent.
+    auto ktap = [&](int k0) -> int {
+        const int sg = k0 >> 5;
+        int t = sg % p.a_NT;
+        return t;
+    };
+    auto kchan = [&](int k0) -> int { return ((k0 >> 5) / p.a_NT) << 5; };
+    auto krow_b = [&](int k0) -> int {        // first B row ([k][n] layout) of the K-step
+        if constexpr (AL == AL_MK) return ktap(k0) * p.a_KC + kchan(k0);
+        else return k0;
+    };
+
     f32x4 ra[A_CH], rb[B_CH];
 
     auto ldg = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) -> f32x4 {
@@ -132,8 +159,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     auto load_tiles = [&](int k0) {
         // ---------------- A ----------------
         if constexpr (AL == AL_MK) {
-            const int tap = k0 / p.a_KC;
-            const int kc0 = k0 - tap * p.a_KC;
+            const int tap = ktap(k0), kc0 = kchan(k0);
             const unsigned toff = (unsigned)((p.a_dh[tap] * p.a_IW + p.a_dw[tap]) * p.a_ld + kc0) * 4u;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_CH; ++i)
@@ -157,13 +183,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         // ---------------- B ----------------
         if constexpr (BL == BL_KN) {
             constexpr int CPR = BN / 4, RPP = 256 / CPR;
-            const unsigned koff = (unsigned)(k0 * p.b_ld) * 4u;                                         // wave-uniform
+            const unsigned koff = (unsigned)(krow_b(k0) * p.b_ld) * 4u;                                 // wave-uniform
 #pragma unroll
             for (int i = 0; i < B_CH; ++i)
                 rb[i] = ldg(rsrcB, (k0 + tid / CPR + RPP * i < kend) ? b_base[i] : OOB, koff);
         } else {
-            const int tap = k0 / p.a_KC;
-            const int kc0 = k0 - tap * p.a_KC;
+            const int tap = ktap(k0), kc0 = kchan(k0);
             const unsigned toff = (unsigned)(p.b_tapoff[tap] + kc0) * 4u;                               // wave-uniform
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) rb[i] = ldg(rsrcB, b_base[i], toff);
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
     };
 #ifndef FTE_PIPE
-#define FTE_PIPE 3
+#define FTE_PIPE 4
 #endif
     auto compute = [&](int stage) {
         const float* As = smem + stage * STAGE;
@@ -291,6 +316,128 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #endif
     };
 
+#ifndef FTE_ABL
+#define FTE_ABL 0      // timing-only ablation builds (wrong results): 1 no loads, 2 no loads+stores, 5 loads re-read tile 0
+#endif
+#if FTE_PIPE == 4
+    // ---- main loop, hand-slotted --------------------------------------------------------------
+    // One K-step = NM MFMAs per wave.  Each MFMA is followed by at most one "payload" operation and a
+    // scheduling fence, so the issue order below is the order in the binary:
+    //   slots 0 .. NL-1        : the NL buffer loads of tile s+1 (address math included)
+    //   slot  Q   /  slot 2Q   : fragment reads of u-step 2 / 3 (into the set the previous u-step freed)
+    //   slots NM-NL .. NM-1    : LDS writes of tile s+1 into the other stage (loads had >= NM-2NL MFMAs to land)
+    // Everything except the two leading fragment reads and the barrier issues in the shadow of a
+    // 64-cycle MFMA.  The step after the last one loads a tile nobody uses (clamped / zero-filled).
+    {
+        constexpr int NM = 16 * TM * TN, Q = 4 * TM * TN, NL = A_CH + B_CH;
+        static_assert(NM - NL >= 2 * Q + 1, "payload slots overlap");
+        if (nsteps > 0) {
+            load_tiles(kbeg);
+            store_tiles(0);
+            __syncthreads();
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            const int cur = s & 1;
+#if FTE_ABL == 5
+            const int k0 = kbeg;                       // ablation: every step re-loads tile 0 (cache hits)
+#else
+            const int k0 = kbeg + (s + 1) * BK;
+#endif
+            const float* As = smem + cur * STAGE;
+            const float* Bs = As + BM * BK;
+            float* Asn = smem + (cur ^ 1) * STAGE;
+            float* Bsn = Asn + BM * BK;
+            // ---- per-step operand addressing (scalar / per-thread, no memory access yet) ----
+            int tap = 0, kc0 = 0;
+            if constexpr (AL == AL_MK || BL == BL_NK) {
+                tap = ktap(k0);
+                kc0 = kchan(k0);
+                if (kc0 >= p.a_KC) kc0 = 0;            // the unused tile after the last step
+            }
+            unsigned a_toff = 0, b_soff = 0;
+            bool kin = false;
+            int kn = 0, kih0 = 0, kiw0 = 0;
+            if constexpr (AL == AL_MK) {
+                a_toff = (unsigned)((p.a_dh[tap] * p.a_IW + p.a_dw[tap]) * p.a_ld + kc0) * 4u;
+            } else {
+                const int pix = k0 + (tid >> 3);
+                kin = pix < kend;
+                const int hw = p.a_OH * p.a_OW;
+                kn = pix / hw;
+                const int rem = pix - kn * hw;
+                const int oh = rem / p.a_OW;
+                kih0 = oh * p.a_stride;
+                kiw0 = (rem - oh * p.a_OW) * p.a_stride;
+            }
+            if constexpr (BL == BL_KN) b_soff = (unsigned)((AL == AL_MK ? tap * p.a_KC + kc0 : k0) * p.b_ld) * 4u;
+            else b_soff = (unsigned)(p.b_tapoff[tap] + kc0) * 4u;
+
+            auto load_slot = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < A_CH) {
+                    if constexpr (AL == AL_MK) {
+                        ra[i] = ldg(rsrcA, ((a_mask[i] >> tap) & 1) && k0 < kend ? a_base[i] + a_toff : OOB, 0);
+                    } else {
+                        const int ih = kih0 + (a_dhw[i] & 0xff) - 8, iw = kiw0 + ((a_dhw[i] >> 8) & 0xff) - 8;
+                        const bool ok = kin && (a_dhw[i] >> 16) && ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW;
+                        ra[i] = ldg(rsrcA, ok ? (unsigned)(((kn * p.a_IH + ih) * p.a_IW + iw) * p.a_ld) * 4u + a_c[i] : OOB, 0);
+                    }
+                } else {
+                    constexpr int j = i - A_CH;
+                    if constexpr (BL == BL_KN) {
+                        constexpr int CPR = BN / 4, RPP = 256 / CPR;
+                        rb[j] = ldg(rsrcB, (k0 + tid / CPR + RPP * j < kend) ? b_base[j] : OOB, b_soff);
+                    } else {
+                        rb[j] = ldg(rsrcB, k0 < kend ? b_base[j] : OOB, b_soff);
+                    }
+                }
+            };
+            auto store_slot = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < A_CH) {
+                    if constexpr (AL == AL_MK) {
+                        const int r = (tid >> 3) + 32 * i;
+                        *reinterpret_cast<f32x4*>(Asn + r * BK + swz(r, tid & 7)) = ra[i];
+                    } else {
+                        *reinterpret_cast<f32x4*>(Asn + (tid >> 3) * BM + (((tid & 7) + 8 * i) << 2)) = ra[i];
+                    }
+                } else {
+                    constexpr int j = i - A_CH;
+                    if constexpr (BL == BL_KN) {
+                        constexpr int CPR = BN / 4, RPP = 256 / CPR;
+                        *reinterpret_cast<f32x4*>(Bsn + (tid / CPR + RPP * j) * BN + ((tid % CPR) << 2)) = rb[j];
+                    } else {
+                        const int r = (tid >> 3) + 32 * j;
+                        *reinterpret_cast<f32x4*>(Bsn + r * BK + swz(r, tid & 7)) = rb[j];
+                    }
+                }
+            };
+
+            f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+            read_frags(As, Bs, 0, fa0, fb0);
+            read_frags(As, Bs, 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NM>([&](auto ic) {
+                constexpr int idx = decltype(ic)::value;
+                constexpr int u = idx / Q, w = idx % Q, t = w / (TM * TN), i = (w % (TM * TN)) / TN, j = w % TN;
+                if constexpr ((u & 1) == 0)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][t], fb0[j][t], acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][t], fb1[j][t], acc[i][j], 0, 0, 0);
+#if FTE_ABL != 1 && FTE_ABL != 2
+                if constexpr (idx < NL) load_slot(std::integral_constant<int, idx>{});
+#endif
+                if constexpr (idx == Q) read_frags(As, Bs, 2, fa0, fb0);
+                if constexpr (idx == 2 * Q) read_frags(As, Bs, 3, fa1, fb1);
+#if FTE_ABL != 2
+                if constexpr (idx >= NM - NL) store_slot(std::integral_constant<int, idx - (NM - NL)>{});
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();
+        }
+    }
+#else
     // ---- main loop: one barrier per K-step, loads for step s+1 in flight under step s ----
 #ifndef FTE_ABL
 #define FTE_ABL 0      // ablation builds (timing only, wrong results): 1 no global loads, 2 +no LDS stores, 3 +no barrier
@@ -314,6 +461,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #endif
         }
     }
+
+#endif
 
     // ---- epilogue -----------------------------------------------------------------
     int* rowoff = reinterpret_cast<int*>(smem);
@@ -446,12 +595,54 @@ hipError_t launch_tile(const IgemmParams& p, int tile, int splits, hipStream_t s
 
 }  // namespace
 
-hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st) {
+// ---- launch records (bench.py's roofline leg) -----------------------------------------------------
+// When enabled, every kernel launch of the family is bracketed by a HIP event pair on the launch
+// stream and its algorithmic FLOPs (2 * rows * N * K of THAT launch) are noted, so that a caller can
+// report FLOPs / duration per kernel symbol -- the same per-symbol average rocprofv3 --stats prints.
+namespace {
+struct ProfRec { int sig[5]; double flops; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+void prof_clear() {
+    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.clear();
+}
+hipError_t dispatch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st) {
     if (al == AL_MK && bl == BL_KN && epi == EPI_FWD) return launch_tile<AL_MK, BL_KN, EPI_FWD>(p, tile, splits, st);
     if (al == AL_MK && bl == BL_NK && epi == EPI_DGRAD) return launch_tile<AL_MK, BL_NK, EPI_DGRAD>(p, tile, splits, st);
     if (al == AL_MK && bl == BL_NK && epi == EPI_FWD) return launch_tile<AL_MK, BL_NK, EPI_FWD>(p, tile, splits, st);
     if (al == AL_KM && bl == BL_KN && epi == EPI_FWD) return launch_tile<AL_KM, BL_KN, EPI_FWD>(p, tile, splits, st);
     return hipErrorInvalidValue;
+}
+}  // namespace
+
+hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st) {
+    if (!g_prof_on) return dispatch(p, al, bl, epi, tile, splits, st);
+    ProfRec r;
+    r.sig[0] = al; r.sig[1] = bl; r.sig[2] = epi; r.sig[3] = tile; r.sig[4] = splits;
+    r.flops = 2.0 * (double)(p.M - p.m_base) * (double)p.N * (double)p.K;
+    hipError_t e = hipEventCreate(&r.e0);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&r.e1);
+    if (e != hipSuccess) return e;
+    hipEventRecord(r.e0, st);
+    e = dispatch(p, al, bl, epi, tile, splits, st);
+    hipEventRecord(r.e1, st);
+    g_prof.push_back(r);
+    return e;
+}
+
+void igemm_prof_enable(bool on) {
+    if (on) prof_clear();
+    g_prof_on = on;
+}
+int igemm_prof_count() { return (int)g_prof.size(); }
+hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms) {
+    if (i < 0 || i >= (int)g_prof.size()) return hipErrorInvalidValue;
+    const ProfRec& r = g_prof[i];
+    for (int k = 0; k < 5; ++k) sig[k] = r.sig[k];
+    *flops = r.flops;
+    return hipEventElapsedTime(ms, r.e0, r.e1);
 }
 
 void igemm_tile_dims(int tile, int* bm, int* bn) {

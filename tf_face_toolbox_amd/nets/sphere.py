@@ -249,19 +249,8 @@ class SphereNet(Network):
                 call('fte_conv3x3_first_fwd', x, wv, bv, av, zz, self.y[0], n, c.hin, c.win, c.cin, c.cout, c.stride, st)
             else:
                 res = self.y[l - 2] if c.second == 1 else None
-                # bench.py's roofline leg: HIP events on the launch stream around the launches that
-                # take the 128x128 tile (same rule as pick_tile in csrc/api.hip)
-                prof = getattr(self, '_prof_events', None)
-                timed = (prof is not None and c.stride == 1 and c.cout % 128 == 0
-                         and -(-(n * c.hout * c.wout) // 128) * (c.cout // 128) >= 384)
-                if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
                 call('fte_conv3x3_fwd', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
                      n, c.hin, c.win, c.cin, c.cout, c.stride, st)
-                if timed:
-                    e1.record()
-                    prof.append((e0, e1))
         call('fte_gemm_nn', self.y[-1], self.view(self.name + '/fully_connected/weights'),
              self.view(self.name + '/fully_connected/biases'), self.emb, n, EMBED, self.fin, self.ws, self.ws_bytes, st)
         return self.emb
