@@ -79,6 +79,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8)
+    ap.add_argument('--global-batch', type=int, default=GLOBAL_BATCH,
+                    help='exploration only (e.g. the per-rank shard sizes of N=2/4/8 on one GPU); the metric is quoted at 512')
     args = ap.parse_args()
 
     import torch
@@ -96,18 +98,19 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
-    assert GLOBAL_BATCH % world == 0
-    shard = GLOBAL_BATCH // world
+    gb = args.global_batch
+    assert gb % world == 0
+    shard = gb // world
 
     # synthetic inputs: images U[-1,1] seed 0, labels seed 1, reference initialisers seed 2
     g = torch.Generator().manual_seed(0)
-    images = (torch.rand(GLOBAL_BATCH, H, W, CH, generator=g) * 2 - 1)[rank * shard:(rank + 1) * shard].to(dev)
+    images = (torch.rand(gb, H, W, CH, generator=g) * 2 - 1)[rank * shard:(rank + 1) * shard].to(dev)
     g = torch.Generator().manual_seed(1)
-    labels = torch.randint(0, NUM_CLASSES, (GLOBAL_BATCH,), generator=g, dtype=torch.int32)[rank * shard:(rank + 1) * shard].to(dev)
+    labels = torch.randint(0, NUM_CLASSES, (gb,), generator=g, dtype=torch.int32)[rank * shard:(rank + 1) * shard].to(dev)
     net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
     net.seed = 2
     inputs = {'images': images, 'labels': labels, 'num_classes': NUM_CLASSES, 'num_examples': 494414,
-              'batch_size': GLOBAL_BATCH}
+              'batch_size': gb}
     if world > 1:
         model = DataParallel_margin(net, LR, 'Momentum', num_gpus=world, weight_decay=5e-4)
     else:
@@ -164,7 +167,7 @@ def main():
             traffic = tinfo['bytes_per_launch']   # rocprofv3 --pmc on this same command, kept under profiles/
         out = {
             'metric': 'images/sec (whole node), SphereFaceNet-20 112x112 bs512',
-            'value': round(GLOBAL_BATCH * args.steps / elapsed, 2),
+            'value': round(gb * args.steps / elapsed, 2),
             'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3),
@@ -173,10 +176,10 @@ def main():
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch 512, 10575 classes, Momentum, fp32',
-                       'global_batch': GLOBAL_BATCH, 'per_gpu_batch': shard, 'lr': LR, 'parallelism': 'dp%d' % world,
+            'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch %d, 10575 classes, Momentum, fp32' % gb,
+                       'global_batch': gb, 'per_gpu_batch': shard, 'lr': LR, 'parallelism': 'dp%d' % world,
                        'train_gflop_per_image': 12.2698},
-            'step_mfma_frac': round(GLOBAL_BATCH * args.steps / elapsed * 12.2698e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) / world, 4),
+            'step_mfma_frac': round(gb * args.steps / elapsed * 12.2698e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) / world, 4),
             'losses': dict(zip(losses_name, [round(v, 6) for v in loss_vals])),
             'roofline': {'bound': 'mfma',
                          'kernel': 'igemm_kernel<tile %d, A-layout %d, B-layout %d, epilogue %d> (tile 0 = 128x128; 0,0,0 = conv3x3 forward + bias/PReLU/residual)' % (DOM[3], DOM[0], DOM[1], DOM[2]),

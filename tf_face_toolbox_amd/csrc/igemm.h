@@ -10,6 +10,8 @@ enum { TILE_128x128 = 0, TILE_256x64 = 1, TILE_128x64 = 2, TILE_64x64 = 3 };
 struct IgemmParams {
     int M, N, K;          // K = NT*KC (tap modes) or number of pixels (AL_KM)
     int kchunk;           // K range per blockIdx.y (multiple of 32)
+    int split_major;      // > 0: 1-D grid of tiles*splits with split = id % split_major (all tiles of one K range
+                          // -- one pixel range for wgrad -- then share an XCD and its L2)
     int m_base;           // first GEMM row of this launch (rows [m_base, M) are tiled; lets one op be
                           // split into a big-tile main launch and a small-tile tail launch)
     // ---- A: gathered from an NHWC image -------------------------------------

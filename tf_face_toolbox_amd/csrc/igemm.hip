@@ -66,15 +66,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
     // ---- tile coordinates: XCD-aware bijective remap, n-tiles fastest --------
     const int ntn = p.N / BN;
-    const int ntiles = gridDim.x;
-    int bid = blockIdx.x;
-    {
+    int bid = blockIdx.x, split = blockIdx.y;
+    if (p.split_major > 0) {
+        // blocks are dealt round-robin over the 8 XCDs: with split = id % S and S % 8 == 0 every tile
+        // of one K range lands on the same XCD (placement is a speed matter only)
+        split = bid % p.split_major;
+        bid = bid / p.split_major;
+    } else {
+        const int ntiles = gridDim.x;
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int mt = bid / ntn, nt_ = bid - mt * ntn;
     const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
-    const int kbeg = blockIdx.y * p.kchunk;
+    const int kbeg = split * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
 
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     __syncthreads();
 
     if constexpr (EPI == EPI_FWD) {
-        float* Y = p.Y + (long)blockIdx.y * p.slab;
+        float* Y = p.Y + (long)split * p.slab;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (TN * 32) + j * 32 + li;
@@ -578,7 +583,8 @@ hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(256), lds, st, p);
+    if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
