@@ -1,0 +1,210 @@
+"""Input pipeline: host-side mirror of the reference's data.py (Caffe-style `path label` lists,
+random / class-balanced PxK sampling, decode -> [0,1] -> bilinear resize -> random crop -> flip or
+augmentation -> (x-0.5)/0.5, batches in NHWC).  This is the caller side of the hot path (SURVEY.md
+8f next-1): JPEG decode and augmentation stay on the host (PIL + numpy worker threads), a prefetch
+thread keeps one batch ahead and hands over float32 NHWC CUDA tensors -- exactly the `inputs` dict
+data.py:275-279 returns, with tensors replaced by callables that yield the next batch.
+
+Reference: data.py:30-56 (list parsers), :77-96 (PxK dict), :153-191 (eval_inputs),
+:195-281 (train_inputs)."""
+import copy
+import os
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from multiprocessing import cpu_count
+
+import numpy as np
+import torch
+
+from .preprocessing import data_augmentation
+
+
+# ------------------------------------------------------------------ list parsers (names kept)
+def get_image_paths(list_path):
+    """data.py:30-41: first whitespace-separated token of every line."""
+    image_paths_flat = []
+    for line in open(os.path.expanduser(list_path), 'r'):
+        part_line = line.split()
+        if part_line:
+            image_paths_flat.append(part_line[0])
+    return image_paths_flat, len(image_paths_flat)
+
+
+def get_image_paths_and_labels(list_path):
+    """data.py:44-58: `path label`, num_classes = max(label)+1."""
+    image_paths_flat, labels_flat = [], []
+    for line in open(os.path.expanduser(list_path), 'r'):
+        part_line = line.split()
+        if not part_line:
+            continue
+        image_paths_flat.append(part_line[0])
+        labels_flat.append(int(part_line[1]))
+    return image_paths_flat, labels_flat, len(labels_flat), max(labels_flat) + 1
+
+
+def get_image_paths_and_labels_dict(list_path, num_per_class):
+    """data.py:77-96: per-class path lists for the PxK sampler; classes with fewer than
+    num_per_class images are dropped and the survivors are RE-NUMBERED 0..P'-1.  (The reference
+    appends a single list when a new label shows up, so labels must first appear in increasing
+    order there -- data.py:84-86; this version grows the table as far as needed instead.)"""
+    image_path_list_tmp = []
+    for line in open(os.path.expanduser(list_path), 'r'):
+        part_line = line.split()
+        if not part_line:
+            continue
+        label_index = int(part_line[1])
+        while len(image_path_list_tmp) <= label_index:
+            image_path_list_tmp.append([])
+        image_path_list_tmp[label_index].append(part_line[0])
+    image_path_list = [lst for lst in image_path_list_tmp if len(lst) >= num_per_class]
+    return image_path_list, sum(len(lst) for lst in image_path_list), len(image_path_list)
+
+
+# ------------------------------------------------------------------ decode / preprocess (host)
+def _decode(path, num_channels, height, width):
+    from PIL import Image
+    img = Image.open(path)
+    img = img.convert('RGB' if num_channels == 3 else 'L')
+    if img.size != (width, height):
+        img = img.resize((width, height), Image.BILINEAR)          # tf.image.resize_images default
+    a = np.asarray(img, dtype=np.float32) / 255.0                   # convert_image_dtype(uint8 -> float32)
+    return a.reshape(height, width, num_channels)
+
+
+def _train_example(path, num_channels, input_height, input_width, crop_height, crop_width, augmentation, rng):
+    image = _decode(path, num_channels, input_height, input_width)
+    if crop_height != -1 and crop_width != -1:                      # tf.random_crop
+        y0 = rng.integers(0, input_height - crop_height + 1)
+        x0 = rng.integers(0, input_width - crop_width + 1)
+        image = image[y0:y0 + crop_height, x0:x0 + crop_width, :]
+    if augmentation:
+        image = data_augmentation(image, rng)
+    elif rng.random() < 0.5:                                        # tf.image.random_flip_left_right
+        image = image[:, ::-1, :]
+    return (np.ascontiguousarray(image, dtype=np.float32) - 0.5) / 0.5
+
+
+class _Prefetcher(object):
+    """One batch ahead on a background thread; `next()` returns (images, labels) on `device`."""
+
+    def __init__(self, make_batch, device, depth=2):
+        self.q = queue.Queue(maxsize=depth)
+        self.device = device
+        self.make_batch = make_batch
+        self._cur = None
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def _run(self):
+        while True:
+            x, y = self.make_batch()
+            xt = torch.from_numpy(x)
+            yt = torch.from_numpy(y) if y is not None else None
+            if self.device.type == 'cuda':
+                xt = xt.pin_memory()
+            self.q.put((xt, yt))
+
+    def advance(self):
+        xt, yt = self.q.get()
+        self._cur = (xt.to(self.device, non_blocking=True),
+                     yt.to(self.device, non_blocking=True) if yt is not None else None)
+        return self._cur
+
+
+class _BatchSource(object):
+    """images() advances to the next batch; labels() returns the labels of that same batch
+    (one `sess.run` fetches both from one dataset element in the reference)."""
+
+    def __init__(self, prefetcher):
+        self.p = prefetcher
+
+    def images(self):
+        return self.p.advance()[0]
+
+    def labels(self):
+        if self.p._cur is None:
+            self.p.advance()
+        return self.p._cur[1]
+
+
+# ------------------------------------------------------------------ public input builders
+def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop_width=-1, is_color=1,
+                 augmentation=0, batch_size=-1, num_classes=-1, num_per_class=-1, device='cuda', seed=None,
+                 rank=0, world_size=1):
+    """data.py:195-281.  Returns {'images', 'labels', 'num_classes', 'num_examples', 'batch_size'};
+    images/labels are callables (next batch / its labels).  With world_size > 1 every rank draws the
+    same global batch order (shared seed) and decodes only its own rows [r*B/n, (r+1)*B/n)."""
+    num_channels = 3 if is_color else 1
+    rng = np.random.default_rng(seed)
+    if batch_size == -1:
+        assert num_classes != -1 and num_per_class != -1
+        batch_size = num_classes * num_per_class
+        image_label_dict, num_examples_total, num_classes_total = get_image_paths_and_labels_dict(data_list_path, num_per_class)
+
+        def _gen():                                                  # data.py:230-242 (_gen_balance)
+            work = copy.deepcopy(image_label_dict)
+            for lst in work:
+                rng.shuffle(lst)
+            while True:
+                for idx in rng.choice(len(work), num_classes):
+                    if len(work[idx]) < num_per_class:
+                        work[idx] = copy.deepcopy(image_label_dict[idx])
+                        rng.shuffle(work[idx])
+                    for _ in range(num_per_class):
+                        yield work[idx].pop(), idx
+    else:
+        image_list, label_list, num_examples_total, num_classes_total = get_image_paths_and_labels(data_list_path)
+
+        def _gen():                                                  # data.py:225-228 (_gen_random) + repeat()
+            while True:
+                for idx in rng.permutation(num_examples_total):
+                    yield image_list[idx], label_list[idx]
+    print('%d images loaded, totally %d classes' % (num_examples_total, num_classes_total))
+    assert batch_size % world_size == 0
+    shard = batch_size // world_size
+    gen = _gen()
+    pool = ThreadPoolExecutor(max(1, cpu_count() // 2))
+    out_h = crop_height if crop_height != -1 and crop_width != -1 else input_height
+    out_w = crop_width if crop_height != -1 and crop_width != -1 else input_width
+
+    def make_batch():
+        items = [next(gen) for _ in range(batch_size)][rank * shard:(rank + 1) * shard]
+        seeds = rng.integers(0, 2 ** 31, size=batch_size)[rank * shard:(rank + 1) * shard]
+        imgs = list(pool.map(lambda a: _train_example(a[0][0], num_channels, input_height, input_width, crop_height,
+                                                      crop_width, augmentation, np.random.default_rng(a[1])),
+                             zip(items, seeds)))
+        x = np.stack(imgs).reshape(shard, out_h, out_w, num_channels)
+        return x, np.asarray([lab for _, lab in items], dtype=np.int32)
+
+    src = _BatchSource(_Prefetcher(make_batch, torch.device(device)))
+    return {'images': src.images, 'labels': src.labels, 'num_classes': num_classes_total,
+            'num_examples': num_examples_total, 'batch_size': batch_size}
+
+
+def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width, device='cuda'):
+    """data.py:153-191: repeating, in list order, resized, (x-0.5)/0.5.  Returns (next_batch, num_examples)."""
+    num_channels = 3 if is_color else 1
+    image_list, num_examples = get_image_paths(data_list_path)
+    print('%d images loaded' % num_examples)
+    pool = ThreadPoolExecutor(8)
+    state = {'pos': 0}
+
+    def make_batch():
+        paths = [image_list[(state['pos'] + i) % num_examples] for i in range(batch_size)]
+        state['pos'] = (state['pos'] + batch_size) % num_examples
+        imgs = list(pool.map(lambda q: (_decode(q, num_channels, input_height, input_width) - 0.5) / 0.5, paths))
+        return np.stack(imgs).astype(np.float32), None
+
+    pf = _Prefetcher(make_batch, torch.device(device))
+    return (lambda: pf.advance()[0]), num_examples
+
+
+def synthetic_inputs(batch_size, height, width, is_color, num_classes, device='cuda', rank=0, world_size=1, seed=0):
+    """Not in the reference: a resident random batch (bench.py's inputs) for runs without a list file."""
+    ch = 3 if is_color else 1
+    g = torch.Generator().manual_seed(seed)
+    shard = batch_size // world_size
+    x = (torch.rand(batch_size, height, width, ch, generator=g) * 2 - 1)[rank * shard:(rank + 1) * shard].to(device)
+    y = torch.randint(0, num_classes, (batch_size,), generator=g, dtype=torch.int32)[rank * shard:(rank + 1) * shard].to(device)
+    return {'images': x, 'labels': y, 'num_classes': num_classes, 'num_examples': batch_size * 100, 'batch_size': batch_size}

@@ -163,7 +163,8 @@ class SphereNet(Network):
             return self._fc_perm(t.reshape(self.fin, EMBED), False).contiguous()
         return t.reshape(v.ref_shape).clone()
 
-    def set_variable(self, name, value):
+    def set_variable(self, name, value, arena=None):
+        """Write a reference-layout value into the variable (or into its slot of another arena)."""
         v = self.variables[name]
         t = torch.as_tensor(value, dtype=torch.float32).to(self.device)
         assert tuple(t.shape) == v.ref_shape, (name, tuple(t.shape), v.ref_shape)
@@ -173,7 +174,7 @@ class SphereNet(Network):
             t = buf
         elif v.kind == 'fc_w':
             t = self._fc_perm(t, True)
-        self.view(name).copy_(t.reshape(-1))
+        self.view(name, arena).copy_(t.reshape(-1))
 
     def load_params(self, params):
         for k, val in params.items():

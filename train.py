@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""train.py -- the reference's training CLI (train.py:33-262) on the MI355X engine.
+
+Same flags, defaults, assertions, LR schedules, log line and checkpoint cadence as the reference
+(SURVEY.md Appendix D).  One process per GPU: with --num_gpus N > 1 launch it as
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train.py --num_gpus N ...
+(the reference drives N towers from one process; here WORLD_SIZE must equal --num_gpus).
+Extra, not in the reference: --synthetic 1 trains on a resident random batch when no list is given,
+--max_steps stops early (smoke runs)."""
+import argparse
+import math
+import os
+import sys
+import time
+from datetime import datetime
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    # Name configures
+    parser.add_argument('--net_name', type=str, help='Name of the network architecture.')
+    parser.add_argument('--model_name', type=str, help='Name of the training model.')
+    # Directory configures
+    parser.add_argument('--train_dir', type=str, default='train', help='Root directory where to write event logs.')
+    parser.add_argument('--model_dir', type=str, default='models', help='Root directory where to save checkpoints.')
+    parser.add_argument('--pretrained_path', type=str, default='', help='Path to save pretrained checkpoints.')
+    # Data configure
+    parser.add_argument('--data_format', type=str, default='NCHW', help='The format of data in the network (NCHW(default) or NHWC).')
+    parser.add_argument('--train_list_path', type=str, help='Path to the list of training data.')
+    parser.add_argument('--input_height', type=int, default=384, help='The height of input images.')
+    parser.add_argument('--input_width', type=int, default=128, help='The width of input images.')
+    parser.add_argument('--crop_height', type=int, default=-1, help='The height of input images.')
+    parser.add_argument('--crop_width', type=int, default=-1, help='The width of input images.')
+    parser.add_argument('--is_color', type=int, default=1, help='Whether to read inputs as RGB images.')
+    parser.add_argument('--augmentation', type=int, default=0, help='Whether to employ data augmentation to training set.')
+    # Hyperparameters configure
+    parser.add_argument('--batch_size', type=int, default=-1, help='Number of sampled images in a batch.')
+    parser.add_argument('--num_classes', type=int, default=-1, help='Number of sampled classesin a batch.')
+    parser.add_argument('--num_per_class', type=int, default=-1, help='Number of sampled images per class in a batch.')
+    parser.add_argument('--optimizer', type=str, default='Momentum', help='Type of optimizer.')
+    parser.add_argument('--init_lr', type=float, default=0.1, help='Initial learning rate.')
+    parser.add_argument('--lr_decay_method', type=str, default='step', help='Learning rate strategy (step/cosine/exp).')
+    parser.add_argument('--lr_decay_rate', type=float, default=0.1, help='Learning rate decay rate.')
+    parser.add_argument('--lr_decay_epoch', type=str, default='', help='Boundaries of decaying learning rate in step lr_decay')
+    parser.add_argument('--max_epoches', type=int, help='Number of batches to run.')
+    parser.add_argument('--weight_decay', type=float, default=5e-4, help='Factor for weight decaying.')
+    # Device configures
+    parser.add_argument('--num_gpus', type=int, default=4, help='Number of GPUs to use.')
+    # Interval configures
+    parser.add_argument('--display_interval', type=int, default=10, help='Internal iterations of verbose.')
+    parser.add_argument('--save_interval', type=int, default=1000, help='Internal iterations of saving models.')
+    # Not in the reference
+    parser.add_argument('--synthetic', type=int, default=0, help='1: resident random batch instead of a list file.')
+    parser.add_argument('--synthetic_classes', type=int, default=10575)
+    parser.add_argument('--max_steps', type=int, default=-1, help='Stop after this many steps (smoke runs).')
+    return parser
+
+
+def FLAGS_assertion(FLAGS):
+    """train.py:95-99."""
+    assert FLAGS.data_format in ['NCHW', 'NHWC'], 'Unknown data format.'
+    assert FLAGS.batch_size != -1 or (FLAGS.num_classes != -1 and FLAGS.num_per_class != -1)
+    assert (FLAGS.num_classes != -1 and FLAGS.num_per_class != -1 and (FLAGS.num_classes * FLAGS.num_per_class) % FLAGS.num_gpus == 0) \
+        or (FLAGS.batch_size % FLAGS.num_gpus == 0 and FLAGS.batch_size != -1)
+    assert FLAGS.optimizer in ['Momentum', 'Adam'], 'Unsupported optimizer.'
+
+
+def lr_config(FLAGS, method, batches_per_epoch):
+    """train.py:122-144 as a function of the global step (tf.train.piecewise_constant /
+    exponential_decay / cosine_decay semantics)."""
+    if method == 'step':
+        if FLAGS.lr_decay_epoch == '':
+            raise ValueError('Empty learning rate decay epoch boundaries.')
+        decay_boundary = [(int(epoch) - 1) * batches_per_epoch for epoch in FLAGS.lr_decay_epoch.split(',')]
+        decay_value = [FLAGS.init_lr] + [FLAGS.init_lr * FLAGS.lr_decay_rate ** (p + 1) for p in range(len(decay_boundary))]
+
+        def lr(step):       # value[i] for boundary[i-1] < step <= boundary[i]
+            k = 0
+            while k < len(decay_boundary) and step > decay_boundary[k]:
+                k += 1
+            return decay_value[k]
+    elif method == 'exp':
+        decay_step = int(FLAGS.lr_decay_epoch) * batches_per_epoch
+        decay_steps = int(FLAGS.max_epoches) * batches_per_epoch + 1 - decay_step
+
+        def lr(step):
+            if step < decay_step:
+                return FLAGS.init_lr
+            return FLAGS.init_lr * 0.001 ** ((step - decay_step) / float(decay_steps))
+    elif method == 'cosine':
+        total = FLAGS.max_epoches * batches_per_epoch
+
+        def lr(step):
+            return FLAGS.init_lr * 0.5 * (1 + math.cos(math.pi * min(step, total) / total))
+    else:
+        raise ValueError('Unsupported learning rate decaying method.')
+    return lr
+
+
+def format_str(losses_name):
+    """train.py:146-152, verbatim."""
+    outputs = '[%s] Epoch/Step %d/%d, lr = %g\n'
+    for loss_id, loss_name in enumerate(losses_name):
+        outputs += '[%s]    Loss #' + str(loss_id) + ': ' + loss_name + ' = %.6f\n'
+    outputs += '[%s]    batch_time = %.1fms/batch, throughput = %.1fimages/s'
+    return outputs
+
+
+def train(FLAGS):
+    import torch
+    import torch.distributed as dist
+    from tf_face_toolbox_amd import net_select, Singular, DataParallel_margin, saver
+    from tf_face_toolbox_amd.data import train_inputs, synthetic_inputs
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if FLAGS.num_gpus != world:
+        raise SystemExit('--num_gpus %d needs one process per GPU: python -m torch.distributed.run --nproc-per-node %d '
+                         '--master-addr 127.0.0.1 train.py ... (WORLD_SIZE is %d)' % (FLAGS.num_gpus, FLAGS.num_gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    batch_size = FLAGS.batch_size if FLAGS.batch_size != -1 else FLAGS.num_classes * FLAGS.num_per_class
+    # Data I/O (train.py:161-170)
+    if FLAGS.synthetic:
+        h = FLAGS.crop_height if FLAGS.crop_height != -1 else FLAGS.input_height
+        w = FLAGS.crop_width if FLAGS.crop_width != -1 else FLAGS.input_width
+        inputs = synthetic_inputs(batch_size, h, w, FLAGS.is_color, FLAGS.synthetic_classes, device, rank, world)
+    else:
+        inputs = train_inputs(FLAGS.train_list_path, input_height=FLAGS.input_height, input_width=FLAGS.input_width,
+                              crop_height=FLAGS.crop_height, crop_width=FLAGS.crop_width, is_color=FLAGS.is_color,
+                              augmentation=FLAGS.augmentation, batch_size=FLAGS.batch_size, num_classes=FLAGS.num_classes,
+                              num_per_class=FLAGS.num_per_class, device=device, seed=1234, rank=rank, world_size=world)
+    batches_per_epoch = inputs['num_examples'] // batch_size + 1                                  # train.py:172
+    network = net_select(FLAGS.net_name, FLAGS.data_format, FLAGS.weight_decay)                  # train.py:174
+    lr = lr_config(FLAGS, FLAGS.lr_decay_method, batches_per_epoch)                              # train.py:176
+    if FLAGS.num_gpus > 1:                                                                        # train.py:178-183
+        model = DataParallel_margin(network, lr, optimizer=FLAGS.optimizer, weight_decay=FLAGS.weight_decay, num_gpus=FLAGS.num_gpus)
+    else:
+        model = Singular(network, lr, optimizer=FLAGS.optimizer, weight_decay=FLAGS.weight_decay)
+    train_ops, losses, losses_name, others = model(inputs)
+
+    tag = FLAGS.net_name + '_' + FLAGS.model_name
+    ckpt_dir = os.path.join(FLAGS.model_dir, tag)
+    latest = saver.latest_checkpoint(ckpt_dir)                                                    # train.py:207-215
+    if latest:
+        model.global_step = saver.restore(network, latest, optimizer=model._opt)
+        print('Model restored from %s' % ckpt_dir)
+    elif FLAGS.pretrained_path != '':
+        saver.restore(network, FLAGS.pretrained_path, only=model.pretrained_param)
+        print('Network parameters initialized from %s' % FLAGS.pretrained_path)
+    else:
+        print('Network parameters initialized from scratch.')
+    if world > 1:
+        model.comm.broadcast(network.params, src=0)
+
+    print('%s training start...' % tag)
+    step, epoch = 0, 1
+    time_sim, image_sim = 0.0, 0.0
+    while epoch <= FLAGS.max_epoches:                                                             # train.py:223-250
+        step = model.global_step
+        epoch = step // batches_per_epoch + 1
+        start_time = time.time()
+        train_ops()
+        losses_value = [float(l) for l in losses]            # reading the losses synchronises, like sess.run
+        duration = time.time() - start_time
+        if not all(math.isfinite(v) for v in losses_value):
+            raise SystemExit('Model diverged with losses = %s' % losses_value)
+        if step % FLAGS.display_interval == 0 and rank == 0:
+            format_list = [datetime.now(), epoch, step, model.learning_rate]
+            for loss_value in losses_value:
+                format_list.extend([datetime.now(), loss_value])
+            format_list.extend([datetime.now(), duration * 1000, batch_size / duration])
+            print(format_str(losses_name) % tuple(format_list))
+            for other_name, other_value in others.items():
+                print('%s: %s' % (other_name, other_value))
+        if step > 0:
+            time_sim += duration
+            image_sim += batch_size / duration
+        last = step == FLAGS.max_epoches * batches_per_epoch or (FLAGS.max_steps > 0 and step + 1 >= FLAGS.max_steps)
+        if ((step > 0 and step % FLAGS.save_interval == 0) or last) and rank == 0:
+            path = saver.save(network, model._opt.slots, model.global_step, os.path.join(ckpt_dir, tag + '.ckpt'))
+            print('[%s]: Model has been saved in Iteration %d (%s)' % (datetime.now(), step, path))
+        if FLAGS.max_steps > 0 and step + 1 >= FLAGS.max_steps:
+            break
+    if rank == 0 and step > 0:
+        print('mean batch_time=%.2f, mean throughput=%.2f' % (time_sim / step * 1000, image_sim / step))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    FLAGS = build_parser().parse_args(argv)
+    FLAGS_assertion(FLAGS)
+    os.makedirs(os.path.join(FLAGS.train_dir, FLAGS.net_name + '_' + FLAGS.model_name), exist_ok=True)
+    os.makedirs(os.path.join(FLAGS.model_dir, FLAGS.net_name + '_' + FLAGS.model_name), exist_ok=True)
+    train(FLAGS)
+
+
+if __name__ == '__main__':
+    main()
