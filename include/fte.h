@@ -65,7 +65,11 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms);
  * keep the pre-activation).  z is what backward needs (sign of z, min(z,0)). */
 int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* alpha,
                     const float* res, float* z, float* y,
-                    int n, int h, int wd, int cin, int cout, int stride, void* stream);
+                    int n, int h, int wd, int cin, int cout, int stride,
+                    void* ws, size_t ws_bytes, void* stream);
+/* ws is optional (NULL/0 allowed): with it, leftover or too-few output tiles run as split-K big tiles
+ * plus a fused fix-up instead of small tiles (faster tails and small per-GPU shards). */
+size_t fte_conv3x3_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int stride);
 
 /* Replaces Conv2DBackpropInput fused with the PReLU gradient of the PRODUCING
  * layer (tf.gradients, data_parallel.py:33):

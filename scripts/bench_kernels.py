@@ -24,7 +24,7 @@ for hw, cin, cout, stride, count in cases:
     dz = torch.randn_like(z); zp = torch.randn_like(x); raw = torch.empty_like(x); dzp = torch.empty_like(x); add = torch.randn_like(x)
     da = torch.empty(cin, device='cuda'); db = torch.empty(cin, device='cuda'); dw = torch.empty_like(w)
     fl = 2.0 * B * ho * ho * 9 * cin * cout
-    t1 = T(lambda: _lib.call('fte_conv3x3_fwd', x, w, None, al, res if stride == 1 else None, z, y, B, hw, hw, cin, cout, stride, st))
+    t1 = T(lambda: _lib.call('fte_conv3x3_fwd', x, w, None, al, res if stride == 1 else None, z, y, B, hw, hw, cin, cout, stride, ws, wsb, st))
     t2 = T(lambda: _lib.call('fte_conv3x3_dgrad', dz, w, add, zp, alp, raw, dzp, da, db, B, hw, hw, cin, cout, stride, ws, wsb, st))
     t3 = T(lambda: _lib.call('fte_conv3x3_wgrad', x, dz, dw, B, hw, hw, cin, cout, stride, ws, wsb, st))
     tot['fwd'] += t1 * count; tot['dgrad'] += t2 * count; tot['wgrad'] += t3 * count

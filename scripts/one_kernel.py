@@ -15,7 +15,7 @@ da = torch.empty(cin, device='cuda'); db = torch.empty(cin, device='cuda'); dw =
 ws = torch.empty(256 << 20, dtype=torch.float32, device='cuda'); wsb = ws.numel() * 4
 for _ in range(reps):
     if which == 'fwd':
-        _lib.call('fte_conv3x3_fwd', x, w, None, al, res if stride == 1 else None, z, y, B, hw, hw, cin, cout, stride, st)
+        _lib.call('fte_conv3x3_fwd', x, w, None, al, res if stride == 1 else None, z, y, B, hw, hw, cin, cout, stride, ws, wsb, st)
     elif which == 'dgrad':
         _lib.call('fte_conv3x3_dgrad', dz, w, add, zp, alp, raw, dzp, da, db, B, hw, hw, cin, cout, stride, ws, wsb, st)
     else:

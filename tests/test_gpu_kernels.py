@@ -25,6 +25,9 @@ CONV_CASES = [
     (2, 6, 6, 256, 512, 2),
     (5, 7, 7, 512, 512, 1),
     (16, 28, 28, 128, 128, 1),   # enough rows for the 128x128 tile
+    (84, 28, 28, 128, 128, 1),   # 515 big tiles: one whole round + a 3-tile split-K tail
+    (40, 14, 14, 256, 256, 1),   # 124 big tiles (< one round): every tile split-K x4 + fix-up
+    (66, 28, 28, 64, 128, 2),    # stride-2 dgrad classes with split-K tails
 ]
 
 
@@ -37,11 +40,12 @@ def test_conv3x3_fwd(n, h, w, cin, cout, stride):
     res = r.standard_normal(z_ref.shape)
     y_ref = ops.prelu_fwd(z_ref, al) + res
     z = torch.empty(z_ref.shape, device='cuda'); y = torch.empty_like(z)
-    call('fte_conv3x3_fwd', dev(x), dev(wt), dev(b), dev(al), dev(res), z, y, n, h, w, cin, cout, stride, stream())
+    wsb, nb = ws(query('fte_conv3x3_fwd_ws_bytes', n, h, w, cin, cout, stride))
+    call('fte_conv3x3_fwd', dev(x), dev(wt), dev(b), dev(al), dev(res), z, y, n, h, w, cin, cout, stride, wsb, nb, stream())
     check_maxabs(host(z), z_ref, what='z'); check_maxabs(host(y), y_ref, what='y')
     # no bias / no activation / no residual / no z
     y2 = torch.empty_like(z)
-    call('fte_conv3x3_fwd', dev(x), dev(wt), None, None, None, None, y2, n, h, w, cin, cout, stride, stream())
+    call('fte_conv3x3_fwd', dev(x), dev(wt), None, None, None, None, y2, n, h, w, cin, cout, stride, None, 0, stream())   # no workspace: small-tile path
     check_maxabs(host(y2), ops.conv2d_fwd(x, wt, stride), what='plain')
 
 
@@ -227,6 +231,6 @@ def test_bad_arguments_are_rejected_not_run():
     from tf_face_toolbox_amd._lib import FteError
     y = torch.empty(4, device='cuda')
     with pytest.raises(FteError):
-        call('fte_conv3x3_fwd', y, y, None, None, None, None, y, 1, 8, 8, 48, 64, 1, stream())     # cin % 32
+        call('fte_conv3x3_fwd', y, y, None, None, None, None, y, 1, 8, 8, 48, 64, 1, None, 0, stream())     # cin % 32
     with pytest.raises(FteError):
         call('fte_conv3x3_wgrad', y, y, y, 64, 28, 28, 64, 64, 1, None, 0, stream())               # split-K needs a workspace

@@ -19,7 +19,8 @@ _SIGS = {
     'fte_prof_enable': (c_int, [c_int]),
     'fte_prof_count': (c_int, []),
     'fte_prof_get': (c_int, [c_int, _P, _P, _P]),
-    'fte_conv3x3_fwd': (c_int, [_P] * 7 + [c_int] * 6 + [_P]),
+    'fte_conv3x3_fwd': (c_int, [_P] * 7 + [c_int] * 6 + [_P, c_size_t, _P]),
+    'fte_conv3x3_fwd_ws_bytes': (c_size_t, [c_int] * 6),
     'fte_conv3x3_dgrad': (c_int, [_P] * 9 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_dgrad_ws_bytes': (c_size_t, [c_int] * 6),
     'fte_conv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),

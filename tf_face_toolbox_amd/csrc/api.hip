@@ -42,33 +42,59 @@ inline int pick_tile(long M, long N) {
 // 256 CUs x 2 resident blocks of the big tiles (64-80 KiB of LDS each)
 constexpr long SLOTS = 512;
 
-// Row plan of an M x N output.  T big tiles on SLOTS resident blocks run in ceil(T/SLOTS) rounds, so a
-// launch of 1568 tiles pays for 4 rounds while doing 3.06 rounds of work.  The plan keeps whole rounds
-// in a big-tile MAIN launch and gives the leftover rows to a TAIL launch of 64x64 tiles (4x the blocks,
-// 1/4 the work each), which finishes in a fraction of a round.
-struct RowPlan { int main_tile; long main_rows, main_mtiles; int tail_tile; long tail_mtiles; };
-inline RowPlan plan_rows(long M, long N) {
+// Row plan of an M x N output with reduction length K.  T big tiles on SLOTS resident blocks run in
+// ceil(T/SLOTS) rounds, so a launch of 1568 tiles pays for 4 rounds while doing 3.06 rounds of work.  The
+// plan keeps whole rounds in a big-tile MAIN launch (epilogue fused in the kernel) and runs the leftover
+// tiles -- or ALL tiles when there is less than one round of them (small per-GPU shards) -- as a TAIL:
+//   mode 2 (needs workspace): the same big tiles with split-K, P = SLOTS / tiles splits, raw partial
+//          tiles to the workspace, then igemm_fixup sums them and applies the epilogue;
+//   mode 1 (no workspace / P < 2): 64x64 tiles (4x the blocks, 1/4 of the work each).
+struct RowPlan {
+    int main_tile; long main_rows, main_mtiles;
+    int tail_mode, tail_tile; long tail_mtiles; int tail_splits, tail_kchunk; size_t pw_bytes;
+};
+inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
     RowPlan r;
+    memset(&r, 0, sizeof(r));
     const int big = (N % 128 == 0) ? TILE_128x128 : TILE_256x64;
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
-    const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn;
-    r.tail_tile = TILE_64x64;
-    if (T < SLOTS) {                       // less than one round: smaller tiles for the whole op
-        r.main_tile = pick_tile(M, N);
-        igemm_tile_dims(r.main_tile, &bm, &bn);
-        r.main_rows = M; r.main_mtiles = (M + bm - 1) / bm; r.tail_mtiles = 0;
-        return r;
-    }
+    const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn, ksteps = (K + 31) / 32;
     r.main_tile = big;
-    const long full = T / SLOTS * SLOTS;
-    if (T - full == 0 || T - full >= SLOTS * 4 / 5) {   // already (nearly) whole rounds
-        r.main_rows = M; r.main_mtiles = MT; r.tail_mtiles = 0;
+    long tail_rows = 0;
+    if (T >= SLOTS) {
+        const long full = T / SLOTS * SLOTS;
+        if (T - full == 0 || T - full >= SLOTS * 4 / 5) {        // already (nearly) whole rounds
+            r.main_rows = M; r.main_mtiles = MT;
+            return r;
+        }
+        r.main_mtiles = full / ntn;
+        r.main_rows = r.main_mtiles * bm;
+        tail_rows = M - r.main_rows;
+    } else {
+        tail_rows = M;                                            // less than one round in total
+    }
+    const long tmt = (tail_rows + bm - 1) / bm, R = tmt * ntn;
+    long P = (SLOTS + R / 2) / R;
+    if (P > ksteps / 4) P = ksteps / 4;
+    // Split-K pays only when there is NO whole round (small per-GPU shards): measured on MI355X at batch
+    // 512 a 32-tile tail split 16 ways is slower than the 64x64 tail (which costs ~3 % of the kernel).
+    // ... and only with few tiles and a long K (P >= 4): the fix-up moves P x the output through HBM; at
+    // P = 2-3 (batch-64 stage 3) it costs more than the better-filled MFMA launch saves.
+    if (allow_pw && P >= 4 && T < SLOTS) {
+        r.tail_mode = 2; r.tail_tile = big; r.tail_mtiles = tmt * FIXUP_CHUNKS;   // partial rows: one per (tile row, chunk)
+        r.tail_kchunk = (int)((ksteps + P - 1) / P * 32);
+        r.tail_splits = (int)((K + r.tail_kchunk - 1) / r.tail_kchunk);
+        r.pw_bytes = (size_t)r.tail_splits * R * bm * bn * sizeof(float);
         return r;
     }
-    r.main_mtiles = full / ntn;
-    r.main_rows = r.main_mtiles * bm;
-    r.tail_mtiles = (M - r.main_rows + 63) / 64;
+    if (T >= SLOTS) {
+        r.tail_mode = 1; r.tail_tile = TILE_64x64; r.tail_mtiles = (tail_rows + 63) / 64;
+        return r;
+    }
+    r.main_tile = pick_tile(M, N);                                // single launch with a smaller tile
+    igemm_tile_dims(r.main_tile, &bm, &bn);
+    r.main_rows = M; r.main_mtiles = (M + bm - 1) / bm;
     return r;
 }
 
@@ -105,16 +131,6 @@ inline void plain_a(IgemmParams* p, const float* a, int ld, int kc) {
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr size_t SCRATCH_BYTES = (size_t)REDUCE_SCRATCH_FLOATS * sizeof(float);
 
-// main (+ tail) launches of one row-tiled op; PA/PB partial rows are numbered main first, then tail
-inline hipError_t launch_rows(IgemmParams p, const RowPlan& rp, int al, int bl, int epi, long prow0, hipStream_t st) {
-    const int M = p.M;
-    p.m_base = 0; p.M = (int)rp.main_rows; p.prow0 = (int)prow0;
-    hipError_t e = igemm_launch(p, al, bl, epi, rp.main_tile, 1, st);
-    if (e != hipSuccess || rp.tail_mtiles == 0) return e;
-    p.m_base = (int)rp.main_rows; p.M = M; p.prow0 = (int)(prow0 + rp.main_mtiles);
-    return igemm_launch(p, al, bl, epi, rp.tail_tile, 1, st);
-}
-
 // operand sizes for the buffer-load range check; tensors must stay below 2 GiB (offsets are 32-bit,
 // 0x80000000 is the out-of-range marker)
 inline bool set_bytes(IgemmParams* p, size_t a_floats, size_t b_floats) {
@@ -123,6 +139,24 @@ inline bool set_bytes(IgemmParams* p, size_t a_floats, size_t b_floats) {
     p->a_bytes = (unsigned)(a_floats * 4);
     p->b_bytes = (unsigned)(b_floats * 4);
     return true;
+}
+
+// main (+ tail) launches of one row-tiled op; PA/PB partial rows are numbered main first, then tail
+inline hipError_t launch_rows(IgemmParams p, const RowPlan& rp, int al, int bl, int epi, long prow0, float* pw, hipStream_t st) {
+    const int M = p.M;
+    hipError_t e = hipSuccess;
+    if (rp.main_rows > 0) {
+        p.m_base = 0; p.M = (int)rp.main_rows; p.prow0 = (int)prow0;
+        e = igemm_launch(p, al, bl, epi, rp.main_tile, 1, st);
+        if (e != hipSuccess) return e;
+    }
+    if (rp.tail_mode == 0) return e;
+    p.m_base = (int)rp.main_rows; p.M = M; p.prow0 = (int)(prow0 + rp.main_mtiles);
+    if (rp.tail_mode == 1) return igemm_launch(p, al, bl, epi, rp.tail_tile, 1, st);
+    p.PW = pw; p.kchunk = rp.tail_kchunk;
+    e = igemm_launch(p, al, bl, epi, rp.tail_tile, rp.tail_splits, st);
+    if (e != hipSuccess) return e;
+    return igemm_fixup(p, epi, rp.tail_tile, rp.tail_splits, st);
 }
 
 }  // namespace
@@ -139,8 +173,14 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms) {
 }
 
 // ------------------------------------------------------------------------------------------------
+size_t fte_conv3x3_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return plan_rows((long)n * ph.out * pw.out, cout, 9L * cin, true).pw_bytes;
+}
+
 int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
-                    float* z, float* y, int n, int h, int wd, int cin, int cout, int stride, void* stream) {
+                    float* z, float* y, int n, int h, int wd, int cin, int cout, int stride,
+                    void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !y || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     IgemmParams p;
@@ -154,13 +194,15 @@ int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const flo
     p.c_ld = cout;
     p.Y = y; p.Z = z; p.R = res; p.bias = bias; p.alpha = alpha;
     if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)9 * cin * cout)) return FTE_EINVAL;
-    return rc(launch_rows(p, plan_rows(p.M, p.N), AL_MK, BL_KN, EPI_FWD, 0, (hipStream_t)stream));
+    RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr);
+    if (rp.tail_mode == 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
+    return rc(launch_rows(p, rp, AL_MK, BL_KN, EPI_FWD, 0, (float*)ws, (hipStream_t)stream));
 }
 
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct DgradClass { int ph, pw, hq, wq, ntap, dh[9], dw[9], wt[9]; RowPlan rp; long mtiles; };
-int dgrad_classes(int n, int h, int wd, int cin, int stride, DgradClass* cls) {
+int dgrad_classes(int n, int h, int wd, int cin, int cout, int stride, DgradClass* cls) {
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     int nc = 0;
     for (int a = 0; a < stride; ++a)
@@ -184,7 +226,7 @@ int dgrad_classes(int n, int h, int wd, int cin, int stride, DgradClass* cls) {
             }
             if (c.ntap == 0) continue;
             const long M = (long)n * c.hq * c.wq;
-            c.rp = plan_rows(M, cin);
+            c.rp = plan_rows(M, cin, (long)c.ntap * cout, true);
             c.mtiles = c.rp.main_mtiles + c.rp.tail_mtiles;
             ++nc;
         }
@@ -193,12 +235,12 @@ int dgrad_classes(int n, int h, int wd, int cin, int stride, DgradClass* cls) {
 }  // namespace
 
 size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
-    (void)cout;
     DgradClass cls[4];
-    const int nc = dgrad_classes(n, h, wd, cin, stride, cls);
+    const int nc = dgrad_classes(n, h, wd, cin, cout, stride, cls);
     long rows = 0;
-    for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
-    return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES;
+    size_t pw = 0;
+    for (int i = 0; i < nc; ++i) { rows += cls[i].mtiles; if (cls[i].rp.pw_bytes > pw) pw = cls[i].rp.pw_bytes; }
+    return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES + pw;
 }
 
 int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
@@ -208,13 +250,17 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
     if (zprev && !alpha_prev) return FTE_EINVAL;
     const Pads pho = same_pads(h, 3, stride), pwo = same_pads(wd, 3, stride);
     DgradClass cls[4];
-    const int nc = dgrad_classes(n, h, wd, cin, stride, cls);
+    const int nc = dgrad_classes(n, h, wd, cin, cout, stride, cls);
     long rows = 0;
     for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
     const bool want_part = zprev && (dalpha_prev || dbias_prev);
     const size_t half = align_up((size_t)rows * cin * sizeof(float));
-    if (want_part && (!ws || ws_bytes < 2 * half + SCRATCH_BYTES)) return FTE_EWORKSPACE;
+    size_t pw_need = 0;
+    for (int i = 0; i < nc; ++i) if (cls[i].rp.pw_bytes > pw_need) pw_need = cls[i].rp.pw_bytes;
+    const size_t fixed = 2 * half + SCRATCH_BYTES;
+    if ((want_part || pw_need) && (!ws || ws_bytes < fixed + pw_need)) return FTE_EWORKSPACE;
     float* scratch = want_part ? (float*)((char*)ws + 2 * half) : nullptr;
+    float* pwbuf = pw_need ? (float*)((char*)ws + fixed) : nullptr;
     float* PA = want_part ? (float*)ws : nullptr;
     float* PB = want_part ? (float*)((char*)ws + half) : nullptr;
     long prow = 0;
@@ -236,7 +282,7 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
         p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
         p.PA = PA; p.PB = PB;
         if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)9 * cin * cout)) return FTE_EINVAL;
-        hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, (hipStream_t)stream);
+        hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, pwbuf, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
         prow += c.mtiles;
     }

@@ -35,6 +35,8 @@ struct IgemmParams {
     int c_step, c_ph, c_pw;
     int c_ld;
     long slab;            // EPI_FWD: Y offset per blockIdx.y (split-K partial slabs)
+    float* PW;            // != NULL: store the raw accumulator tile to PW[(split*tiles + tile)*BM*BN + r*BN + c] and stop;
+                          // igemm_fixup then sums the splits and applies the epilogue (split-K for fwd / dgrad tiles)
     // EPI_FWD:  v = acc + bias[n]; Z = v; Y = prelu(v, alpha[n]) + R
     float* Y; float* Z; const float* R; const float* bias; const float* alpha;
     // EPI_DGRAD: v = acc + ADD; RAW = v; DZ = v * prelu'(Zin, alpha[n % amod]);
@@ -44,6 +46,11 @@ struct IgemmParams {
 };
 
 hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st);
+// the fix-up splits every tile into this many row chunks (one block each); a dgrad fix-up therefore writes
+// FIXUP_CHUNKS partial rows (PA/PB) per tile row, numbered prow0 + mt*FIXUP_CHUNKS + chunk
+constexpr int FIXUP_CHUNKS = 4;
+// sums `splits` partial tiles written through PW and applies the EPI_FWD / EPI_DGRAD epilogue of the same params
+hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st);
 void igemm_tile_dims(int tile, int* bm, int* bn);
 
 // launch records for the roofline measurement (see igemm.hip)

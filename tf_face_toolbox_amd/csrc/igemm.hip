@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #ifndef FTE_PIPE
 #define FTE_PIPE 4
 #endif
-    auto compute = [&](int stage) {
+    [[maybe_unused]] auto compute = [&](int stage) {
         const float* As = smem + stage * STAGE;
         const float* Bs = As + BM * BK;
 #if FTE_PIPE == 0
@@ -469,6 +469,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
 #endif
 
+    // ---- split-K partial tile: raw accumulators to the workspace, epilogue happens in igemm_fixup ----
+    if (p.PW) {
+        float* W = p.PW + ((long)split * gridDim.x + bid) * (BM * BN);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = wn * (TN * 32) + j * 32 + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    W[rl * BN + cl] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
     // ---- epilogue -----------------------------------------------------------------
     int* rowoff = reinterpret_cast<int*>(smem);
     for (int r = tid; r < BM; r += 256) {
@@ -571,6 +588,137 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     }
 }
 
+// ---- fix-up: sum the split-K partial tiles of one output tile and apply the fused epilogue -------------
+// grid = tiles of the launch that wrote PW (same tile numbering, no XCD remap needed: pure streaming);
+// thread = one column (tid % BN) and every (256/BN)-th row of the tile: 512-B coalesced rows.
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, int splits) {
+    __shared__ int rowoff[BM];
+    __shared__ float red[2][256 / BN][BN];
+    const int tid = threadIdx.x;
+    const int ntn = p.N / BN;
+    const int bid = blockIdx.x / FIXUP_CHUNKS, chunk = blockIdx.x % FIXUP_CHUNKS;   // tile, row chunk of the tile
+    constexpr int CR = BM / FIXUP_CHUNKS;
+    const int mt = bid / ntn, nt_ = bid - mt * ntn;
+    const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m0 + r;
+        int off = -1;
+        if (m < p.M) {
+            if (p.c_OH == 0) {
+                off = m * p.c_ld;
+            } else {
+                const int hw = p.c_OH * p.c_OW;
+                const int n = m / hw, rem = m - n * hw;
+                const int oh = rem / p.c_OW, ow = rem - oh * p.c_OW;
+                off = ((n * p.c_FH + oh * p.c_step + p.c_ph) * p.c_FW + ow * p.c_step + p.c_pw) * p.c_ld;
+            }
+        }
+        rowoff[r] = off;
+    }
+    __syncthreads();
+    constexpr int RG = 256 / BN;                       // row groups
+    const int cl = tid % BN, rg = tid / BN;
+    const int col = n0 + cl;
+    const long tile_stride = (long)(gridDim.x / FIXUP_CHUNKS) * (BM * BN);
+    const float* W = p.PW + (long)bid * (BM * BN) + cl;
+    float sa = 0.f, sb = 0.f;
+    // rows of this thread: chunk*CR + rg + RG*i, i < NR; all partial-tile loads of UNR rows are issued
+    // before any of them is used (the loop is latency-bound otherwise)
+    constexpr int NR = CR / RG;
+    constexpr int UNR = NR < 4 ? NR : 4;
+    static_assert(NR % UNR == 0, "row unroll");
+    if constexpr (EPI == EPI_FWD) {
+        const float bias = p.bias ? p.bias[col] : 0.f;
+        const bool act = p.alpha != nullptr;
+        const float al = act ? p.alpha[col] : 1.f;
+        for (int i0 = 0; i0 < NR; i0 += UNR) {
+            float v[UNR], rres[UNR];
+            int off[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int rl = chunk * CR + rg + RG * (i0 + u);
+                off[u] = rowoff[rl];
+                v[u] = 0.f;
+                rres[u] = 0.f;
+                if (off[u] >= 0) {
+                    for (int sidx = 0; sidx < splits; ++sidx) v[u] += W[sidx * tile_stride + rl * BN];
+                    if (p.R) rres[u] = p.R[(long)off[u] + col];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (off[u] < 0) continue;
+                const long o = (long)off[u] + col;
+                float x = v[u] + bias;
+                if (p.Z) p.Z[o] = x;
+                if (act) x = x > 0.f ? x : al * x;
+                p.Y[o] = x + rres[u];
+            }
+        }
+    } else {
+        const bool msk = p.Zin != nullptr;
+        const float al = msk ? p.alpha[col % p.amod] : 1.f;
+        for (int i0 = 0; i0 < NR; i0 += UNR) {
+            float v[UNR], zz[UNR];
+            int off[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int rl = chunk * CR + rg + RG * (i0 + u);
+                off[u] = rowoff[rl];
+                v[u] = 0.f;
+                zz[u] = 1.f;
+                if (off[u] >= 0) {
+                    for (int sidx = 0; sidx < splits; ++sidx) v[u] += W[sidx * tile_stride + rl * BN];
+                    const long o = (long)off[u] + col;
+                    if (p.ADD) v[u] += p.ADD[o];
+                    if (msk) zz[u] = p.Zin[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (off[u] < 0) continue;
+                const long o = (long)off[u] + col;
+                float x = v[u];
+                if (p.RAW) p.RAW[o] = x;
+                if (msk) {
+                    sa += x * fminf(zz[u], 0.f);
+                    x *= prelu_slope(zz[u], al);
+                    sb += x;
+                }
+                p.DZ[o] = x;
+            }
+        }
+        if (p.PA) {
+            red[0][rg][cl] = sa;
+            red[1][rg][cl] = sb;
+            __syncthreads();
+            if (rg == 0) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int g = 0; g < RG; ++g) { a += red[0][g][cl]; b += red[1][g][cl]; }
+                const long o = (long)(p.prow0 + mt * FIXUP_CHUNKS + chunk) * p.N + col;      // one partial row per (tile row, chunk)
+                p.PA[o] = a;
+                if (p.PB) p.PB[o] = b;
+            }
+        }
+    }
+}
+
+template <int EPI>
+hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st) {
+    int bm, bn;
+    igemm_tile_dims(tile, &bm, &bn);
+    const int tiles = ((p.M - p.m_base + bm - 1) / bm) * (p.N / bn) * FIXUP_CHUNKS;
+    switch (tile) {
+        case TILE_128x128: hipLaunchKernelGGL((igemm_fixup_kernel<128, 128, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
+        case TILE_256x64:  hipLaunchKernelGGL((igemm_fixup_kernel<256, 64, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
+        case TILE_128x64:  hipLaunchKernelGGL((igemm_fixup_kernel<128, 64, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
+        default:           hipLaunchKernelGGL((igemm_fixup_kernel<64, 64, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
+    }
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
 hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
@@ -610,7 +758,7 @@ struct ProfRec { int sig[5]; double flops; hipEvent_t e0, e1; };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
 void prof_clear() {
-    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
 }
 hipError_t dispatch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st) {
@@ -631,11 +779,16 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
     if (e != hipSuccess) return e;
     e = hipEventCreate(&r.e1);
     if (e != hipSuccess) return e;
-    hipEventRecord(r.e0, st);
+    (void)hipEventRecord(r.e0, st);
     e = dispatch(p, al, bl, epi, tile, splits, st);
-    hipEventRecord(r.e1, st);
+    (void)hipEventRecord(r.e1, st);
     g_prof.push_back(r);
     return e;
+}
+
+hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st) {
+    if (epi == EPI_FWD) return fixup_tile<EPI_FWD>(p, tile, splits, st);
+    return fixup_tile<EPI_DGRAD>(p, tile, splits, st);
 }
 
 void igemm_prof_enable(bool on) {

@@ -209,7 +209,8 @@ class SphereNet(Network):
         need = 4096
         q = _lib.query
         for c in self.convs[1:]:
-            need = max(need, q('fte_conv3x3_wgrad_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride),
+            need = max(need, q('fte_conv3x3_fwd_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride),
+                       q('fte_conv3x3_wgrad_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride),
                        q('fte_conv3x3_dgrad_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride))
         c0 = self.convs[0]
         need = max(need, q('fte_conv3x3_first_wgrad_ws_bytes', n, c0.hin, c0.win, c0.cin, c0.cout, c0.stride),
@@ -251,7 +252,7 @@ class SphereNet(Network):
             else:
                 res = self.y[l - 2] if c.second == 1 else None
                 call('fte_conv3x3_fwd', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
-                     n, c.hin, c.win, c.cin, c.cout, c.stride, st)
+                     n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
         call('fte_gemm_nn', self.y[-1], self.view(self.name + '/fully_connected/weights'),
              self.view(self.name + '/fully_connected/biases'), self.emb, n, EMBED, self.fin, self.ws, self.ws_bytes, st)
         return self.emb
