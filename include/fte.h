@@ -93,6 +93,65 @@ int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw,
                       void* ws, size_t ws_bytes, void* stream);
 size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride);
 
+
+/* ---------------------------------------------------------------------------
+ * Generic SAME convolution (kernel 1x1 or 3x3, stride 1 or 2, no dilation) on the same MFMA kernel
+ * family: the convs of nets/resnet.py:47-61 (`conv_bn_relu`), nets/resnext.py:56-62 and the pointwise
+ * convs of nets/shufflenet_v2.py:100-105.  Arguments as fte_conv3x3_*, plus `ksize`.
+ * ------------------------------------------------------------------------- */
+int fte_conv2d_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
+                   float* z, float* y, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                   void* ws, size_t ws_bytes, void* stream);
+size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
+                     const float* alpha_prev, float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
+                     int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                     void* ws, size_t ws_bytes, void* stream);
+size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int fte_conv2d_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout,
+                     int ksize, int stride, void* ws, size_t ws_bytes, void* stream);
+size_t fte_conv2d_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+
+/* First layer of the BN nets (7x7 stride 2, Cin = 3; nets/resnet.py:109): cols[n*ho*wo, kpad] with k ordered
+ * (r, s, c) like the HWIO weight rows and zero columns from ksize*ksize*cin to kpad (kpad % 32 == 0); the
+ * stem is then fte_gemm_nn / fte_gemm_tn on cols. */
+int fte_im2col_first(const float* x, float* cols, int n, int h, int wd, int cin, int ksize, int stride,
+                     int kpad, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * layers.batch_norm(scale=True, center=True, fused=True, decay=0.999, epsilon=1e-3) in TRAINING mode
+ * (nets/resnet.py:97-99; FusedBatchNorm / FusedBatchNormGrad).  z is [rows, c] (NHWC flattened).
+ *   fwd: mean/var over the rows of THIS shard (biased var normalises; the moving variance gets the unbiased
+ *        one), y = [relu](gamma*(z-mean)*rstd + beta [+ res]);  mean, rstd, scale, shift are kept for backward;
+ *        moving_mean / moving_var may be NULL (replicas other than tower 0, data_parallel.py:242-243).
+ *   bwd: g = dy * (ymask > 0) when ymask != NULL (the ReLU that followed), dgamma = sum g*xhat, dbeta = sum g,
+ *        dz = gamma*rstd*(g - dbeta/rows - xhat*dgamma/rows).
+ * ws >= fte_bn_ws_bytes(c).
+ * ------------------------------------------------------------------------- */
+size_t fte_bn_ws_bytes(int c);
+int fte_bn_train_fwd(const float* z, const float* gamma, const float* beta, const float* res, float* y,
+                     float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                     long rows, int c, float eps, float decay, int relu, void* ws, size_t ws_bytes, void* stream);
+int fte_bn_infer_fwd(const float* z, const float* gamma, const float* beta, const float* moving_mean,
+                     const float* moving_var, const float* res, float* y, float* scale, float* shift,
+                     long rows, int c, float eps, int relu, void* stream);
+int fte_bn_train_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
+                     const float* rstd, float* dz, float* dgamma, float* dbeta, long rows, int c,
+                     void* ws, size_t ws_bytes, void* stream);
+/* g = dy * (y > 0)  (tf.nn.relu gradient, materialised where a residual shortcut needs it) */
+int fte_relu_bwd(const float* dy, const float* y, float* g, long n, void* stream);
+
+/* layers.max_pool2d(kernel 3, stride 2, 'SAME') (nets/resnet.py:115); idx keeps the window position of
+ * the first maximum (uint8 per element) for the gradient. */
+int fte_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int wd, int c, void* stream);
+int fte_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int wd, int c, void* stream);
+/* tf.reduce_mean over the spatial axes (nets/resnet.py:142) */
+int fte_gap_fwd(const float* x, float* y, int n, int hw, int c, void* stream);
+int fte_gap_bwd(const float* dy, float* dx, int n, int hw, int c, void* stream);
+/* layers.dropout(keep_prob) (nets/resnet.py:152): mask = U(seed, i) < keep, y = x*mask/keep */
+int fte_dropout_fwd(const float* x, float* mask, float* y, long n, float keep_prob, uint64_t seed, void* stream);
+int fte_dropout_bwd(const float* dy, const float* mask, float* dx, long n, float keep_prob, void* stream);
+
 /* ---------------------------------------------------------------------------
  * First conv of the net (Cin = 1 or 3, stride 2; nets/sphere.py:57): K = 9*Cin
  * is too short for a GEMM -- HBM-bound direct convolution, fused bias+PReLU.

@@ -1,0 +1,191 @@
+"""Oracle: a tiny static-graph executor (numpy, float64) for the BN / pooling nets of the reference
+(nets/resnet.py, nets/resnext.py, nets/shufflenet_v2.py).  TEST INFRASTRUCTURE -- PARITY UNPINNED.
+
+A net is a list of ops over named tensors; forward fills an environment, backward walks the list in
+reverse accumulating gradients.  The HIP engine (tf_face_toolbox_amd/nets/graph.py) executes the same
+op lists, which is what makes the layer-by-layer parity checks line up."""
+from collections import OrderedDict
+
+import numpy as np
+
+from . import ops
+
+
+def forward(graph, params, images, labels=None, train=True, masks=None, state=None):
+    """graph: list of tuples.  Returns env (all tensors), caches."""
+    env = {'images': images}
+    cache = {}
+    new_state = {}
+    for op in graph:
+        kind, out = op[0], op[1]
+        if kind == 'conv':          # ('conv', out, inp, wname, stride)
+            _, _, inp, wname, stride = op
+            env[out] = ops.conv2d_fwd(env[inp], params[wname], stride)
+        elif kind == 'bn':          # ('bn', out, inp, prefix)
+            _, _, inp, pre = op
+            g, b = params[pre + '/gamma'], params[pre + '/beta']
+            if train:
+                env[out], cache[out] = ops.bn_train_fwd(env[inp], g, b)
+                cnt = float(np.prod(env[inp].shape[:-1]))
+                if state is not None:
+                    new_state[pre + '/moving_mean'], new_state[pre + '/moving_variance'] = ops.bn_moving_update(
+                        state[pre + '/moving_mean'], state[pre + '/moving_variance'], cache[out]['mean'], cache[out]['var'], cnt)
+            else:
+                env[out] = ops.bn_infer(env[inp], g, b, state[pre + '/moving_mean'], state[pre + '/moving_variance'])
+        elif kind == 'relu':
+            env[out] = np.maximum(env[op[2]], 0)
+        elif kind == 'add':
+            env[out] = env[op[2]] + env[op[3]]
+        elif kind == 'maxpool':
+            env[out], cache[out] = ops.maxpool3x3s2_fwd(env[op[2]])
+        elif kind == 'gap':
+            env[out] = ops.gap_fwd(env[op[2]])
+        elif kind == 'dropout':     # ('dropout', out, inp, keep_prob)
+            if train:
+                env[out] = ops.dropout_fwd(env[op[2]], masks[out], op[3])
+            else:
+                env[out] = env[op[2]]
+        elif kind == 'fc':          # ('fc', out, inp, wname, bname-or-None)
+            env[out] = ops.fc_fwd(env[op[2]], params[op[3]], params[op[4]] if op[4] else None)
+        else:
+            raise ValueError(kind)
+    return env, cache, new_state
+
+
+def backward(graph, params, env, cache, dout, masks=None):
+    """dout: {tensor name: gradient}.  Returns (param grads, tensor grads)."""
+    gt = dict(dout)
+    gp = OrderedDict()
+
+    def acc(d, k, v):
+        d[k] = v if k not in d else d[k] + v
+    for op in reversed(graph):
+        kind, out = op[0], op[1]
+        if out not in gt:
+            continue
+        dy = gt[out]
+        if kind == 'conv':
+            _, _, inp, wname, stride = op
+            dx, dw = ops.conv2d_bwd(env[inp], params[wname], dy, stride, need_dx=inp != 'images')
+            acc(gp, wname, dw)
+            if dx is not None:
+                acc(gt, inp, dx)
+        elif kind == 'bn':
+            _, _, inp, pre = op
+            dx, dg, db = ops.bn_train_bwd(dy, params[pre + '/gamma'], cache[out])
+            acc(gp, pre + '/gamma', dg)
+            acc(gp, pre + '/beta', db)
+            acc(gt, inp, dx)
+        elif kind == 'relu':
+            acc(gt, op[2], dy * (env[out] > 0))
+        elif kind == 'add':
+            acc(gt, op[2], dy)
+            acc(gt, op[3], dy)
+        elif kind == 'maxpool':
+            acc(gt, op[2], ops.maxpool3x3s2_bwd(dy, cache[out]))
+        elif kind == 'gap':
+            acc(gt, op[2], ops.gap_bwd(dy, env[op[2]].shape))
+        elif kind == 'dropout':
+            acc(gt, op[2], dy * masks[out] / op[3])
+        elif kind == 'fc':
+            dx, dw, db = ops.fc_bwd(env[op[2]], params[op[3]], dy, op[4] is not None)
+            acc(gp, op[3], dw)
+            if op[4]:
+                acc(gp, op[4], db)
+            acc(gt, op[2], dx)
+    return gp, gt
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet (nets/resnet.py:24-161): bottleneck, conv-BN-ReLU, projection shortcut, pre_act=False
+# ------------------------------------------------------------------------------------------------
+RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3], 26: [2, 2, 2, 2]}   # nets/resnet.py:35-41
+RESNET_OUTPUTS = [256, 512, 1024, 2048]                                                          # nets/resnet.py:43
+
+
+def resnet_graph(num_layers=50, in_ch=3):
+    """Returns (graph, weight specs [(name, shape, kind)], feature tensor name)."""
+    name = 'ResNet-%d' % num_layers
+    g, spec = [], []
+
+    def conv_bn(scope, out, inp, cin, cout, k, stride, relu):
+        spec.append((scope + '/weights', (k, k, cin, cout), 'conv_w'))
+        spec.append((scope + '/BatchNorm/gamma', (cout,), 'gamma'))
+        spec.append((scope + '/BatchNorm/beta', (cout,), 'beta'))
+        g.append(('conv', out + '/z', inp, scope + '/weights', stride))
+        g.append(('bn', out + '/bn', out + '/z', scope + '/BatchNorm'))
+        if relu:
+            g.append(('relu', out, out + '/bn'))
+            return out
+        return out + '/bn'
+
+    x = conv_bn(name + '/conv1/conv_7x7', 'conv1', 'images', in_ch, 64, 7, 2, True)               # nets/resnet.py:109-113
+    g.append(('maxpool', 'pool1', x))                                                            # :115
+    x, cin = 'pool1', 64
+    for si, nb in enumerate(RESNET_BLOCKS[num_layers]):
+        cout = RESNET_OUTPUTS[si]
+        for b in range(nb):
+            stride = 2 if (b == 0 and si > 0) else 1                                             # :126-139
+            sc = '%s/conv%d/resBlock_%d' % (name, si + 2, b)
+            t = 's%db%d' % (si + 2, b)
+            shortcut = x
+            if stride != 1 or cin != cout:                                                       # :72-78
+                shortcut = conv_bn(sc + '/conv_shortcut_1x1', t + '/sc', x, cin, cout, 1, stride, False)
+            y = conv_bn(sc + '/conv1_1x1', t + '/c1', x, cin, cout // 4, 1, 1, True)             # :82
+            y = conv_bn(sc + '/conv2_3x3', t + '/c2', y, cout // 4, cout // 4, 3, stride, True)  # :83
+            y = conv_bn(sc + '/conv3_1x1', t + '/c3', y, cout // 4, cout, 1, 1, False)           # :84-87
+            g.append(('add', t + '/sum', y, shortcut))                                           # :88
+            g.append(('relu', t, t + '/sum'))                                                    # :89-90
+            x, cin = t, cout
+    g.append(('gap', 'features', x))                                                             # :142
+    return g, spec, 'features', name
+
+
+def resnet_train_graph(num_layers, in_ch, num_classes):
+    g, spec, feat, name = resnet_graph(num_layers, in_ch)
+    g = g + [('dropout', 'features_drop', feat, 0.5),                                            # nets/resnet.py:152
+             ('fc', 'logits', 'features_drop', 'classifier/fc_classifier/weights', None)]        # :153-157
+    spec = spec + [('classifier/fc_classifier/weights', (RESNET_OUTPUTS[3], num_classes), 'cls_w')]
+    return g, spec
+
+
+def init_params(spec, seed, dtype=np.float64):
+    """layers.conv2d default Xavier-uniform weights; BN gamma 1 / beta 0; classifier N(0, 1e-3)."""
+    rng = np.random.default_rng(seed)
+    p, state = OrderedDict(), OrderedDict()
+    for name, shape, kind in spec:
+        if kind == 'conv_w':
+            k, _, cin, cout = shape
+            lim = np.sqrt(6.0 / (k * k * cin + k * k * cout))
+            p[name] = rng.uniform(-lim, lim, shape).astype(dtype)
+        elif kind == 'cls_w':
+            p[name] = (0.001 * rng.standard_normal(shape)).astype(dtype)
+        elif kind == 'gamma':
+            p[name] = np.ones(shape, dtype)
+            pre = name[:-len('/gamma')]
+            state[pre + '/moving_mean'] = np.zeros(shape, dtype)
+            state[pre + '/moving_variance'] = np.ones(shape, dtype)
+        elif kind == 'beta':
+            p[name] = np.zeros(shape, dtype)
+    return p, state
+
+
+def perturb(p, seed, scale=0.1):
+    rng = np.random.default_rng(seed)
+    q = OrderedDict()
+    for k, v in p.items():
+        q[k] = (v + scale * rng.standard_normal(v.shape)).astype(v.dtype) if (k.endswith('/gamma') or k.endswith('/beta')) else v
+    return q
+
+
+def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None, grad_scale=None, state=None):
+    """softmax-CE + L2 on conv / fc weights (gamma, beta are not regularised); returns
+    ([ce, reg], grads incl. wd*w, env, new moving stats)."""
+    env, cache, new_state = forward(graph, params, images, train=True, masks=masks, state=state)
+    ce, dlogits = ops.softmax_ce(env['logits'], labels, grad_scale)
+    gp, _ = backward(graph, params, env, cache, {'logits': dlogits}, masks=masks)
+    reg_names = [k for k in params if k.endswith('/weights')]
+    reg = ops.l2_reg([params[k] for k in reg_names], weight_decay)
+    for k in reg_names:
+        gp[k] = gp[k] + weight_decay * params[k]
+    return [ce, reg], gp, env, new_state

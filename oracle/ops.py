@@ -274,3 +274,87 @@ def batch_hard_triplet(features, labels, margin=None):
             df[i] -= gvec
             df[ineg[i]] += gvec
     return loss, df
+
+
+# --------------------------------------------------------------------------
+# layers.batch_norm(fused=True, scale=True, center=True, decay=0.999, epsilon=1e-3)
+# (nets/resnet.py:97-99; Appendix A.6).  Statistics over N,H,W of THIS shard.
+# --------------------------------------------------------------------------
+BN_EPS = 1e-3
+BN_DECAY = 0.999
+
+
+def bn_train_fwd(x, gamma, beta, eps=BN_EPS):
+    axes = tuple(range(x.ndim - 1))
+    mean = x.mean(axis=axes)
+    var = x.var(axis=axes)                       # biased: what normalises the batch
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = (x - mean) * rstd
+    return gamma * xhat + beta, dict(xhat=xhat, rstd=rstd, mean=mean, var=var)
+
+
+def bn_moving_update(moving_mean, moving_var, mean, var, count, decay=BN_DECAY):
+    """The fused kernel feeds the UNBIASED variance (N/(N-1)) into the moving average."""
+    unbiased = var * (count / max(count - 1.0, 1.0))
+    return decay * moving_mean + (1 - decay) * mean, decay * moving_var + (1 - decay) * unbiased
+
+
+def bn_train_bwd(dy, gamma, cache):
+    xhat, rstd = cache['xhat'], cache['rstd']
+    axes = tuple(range(dy.ndim - 1))
+    m = float(np.prod([dy.shape[a] for a in axes]))
+    dbeta = dy.sum(axis=axes)
+    dgamma = (dy * xhat).sum(axis=axes)
+    dx = gamma * rstd * (dy - dbeta / m - xhat * (dgamma / m))
+    return dx, dgamma, dbeta
+
+
+def bn_infer(x, gamma, beta, moving_mean, moving_var, eps=BN_EPS):
+    return gamma * (x - moving_mean) / np.sqrt(moving_var + eps) + beta
+
+
+# --------------------------------------------------------------------------
+# max_pool2d(kernel 3, stride 2, padding='SAME')  (nets/resnet.py:115); padded cells never win.
+# --------------------------------------------------------------------------
+def maxpool3x3s2_fwd(x):
+    n, h, w, c = x.shape
+    ho, pt, pb = same_pads(h, 3, 2)
+    wo, pl, pr = same_pads(w, 3, 2)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf)
+    s0, s1, s2, s3 = xp.strides
+    win = np.lib.stride_tricks.as_strided(xp, shape=(n, ho, wo, 3, 3, c), strides=(s0, 2 * s1, 2 * s2, s1, s2, s3), writeable=False)
+    flat = win.reshape(n, ho, wo, 9, c)
+    arg = flat.argmax(axis=3)                    # first maximum wins (row-major window order), like TF's MaxPoolGrad
+    y = np.take_along_axis(flat, arg[:, :, :, None, :], axis=3)[:, :, :, 0, :]
+    return y, dict(arg=arg, shape=x.shape, pads=(pt, pl))
+
+
+def maxpool3x3s2_bwd(dy, cache):
+    n, h, w, c = cache['shape']
+    pt, pl = cache['pads']
+    arg = cache['arg']
+    _, ho, wo, _ = dy.shape
+    dx = np.zeros((n, h + 3, w + 3, c), dy.dtype)
+    oh = np.arange(ho)[None, :, None, None]
+    ow = np.arange(wo)[None, None, :, None]
+    ih = oh * 2 + arg // 3                       # coordinates in the padded frame
+    iw = ow * 2 + arg % 3
+    ni = np.arange(n)[:, None, None, None]
+    ci = np.arange(c)[None, None, None, :]
+    np.add.at(dx, (ni, ih, iw, ci), dy)
+    return dx[:, pt:pt + h, pl:pl + w, :]
+
+
+def gap_fwd(x):
+    return x.mean(axis=(1, 2))                   # tf.reduce_mean over the spatial axes (nets/resnet.py:142)
+
+
+def gap_bwd(dy, shape):
+    n, h, w, c = shape
+    return np.broadcast_to(dy[:, None, None, :] / (h * w), shape).copy()
+
+
+def dropout_fwd(x, mask, keep_prob=0.5):
+    """layers.dropout: inverted dropout; `mask` is the 0/1 keep mask (TF's RNG stream is not reproducible,
+    so parity tests feed the implementation's mask to the oracle)."""
+    return x * mask / keep_prob

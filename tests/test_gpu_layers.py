@@ -1,0 +1,132 @@
+"""-m gpu: layer kernels of the BN / pooling nets against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from util_gpu import call, query, dev, host, stream, ws, check_maxabs, check_rell2
+
+
+def _rng(s):
+    return np.random.default_rng(s)
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,ks,stride', [
+    (3, 14, 14, 64, 256, 1, 1), (2, 14, 14, 256, 64, 1, 1), (3, 12, 12, 256, 512, 1, 2), (2, 7, 7, 512, 128, 1, 2),
+    (2, 9, 9, 64, 64, 3, 2), (40, 14, 14, 1024, 256, 1, 1),
+])
+def test_conv2d_1x1_and_3x3(n, h, w, cin, cout, ks, stride):
+    r = _rng(1)
+    x = r.standard_normal((n, h, w, cin)); wt = r.standard_normal((ks, ks, cin, cout)) * 0.05
+    z_ref = ops.conv2d_fwd(x, wt, stride)
+    z = torch.empty(z_ref.shape, device='cuda')
+    wsb, nb = ws(max(query('fte_conv2d_fwd_ws_bytes', n, h, w, cin, cout, ks, stride),
+                     query('fte_conv2d_dgrad_ws_bytes', n, h, w, cin, cout, ks, stride),
+                     query('fte_conv2d_wgrad_ws_bytes', n, h, w, cin, cout, ks, stride)))
+    call('fte_conv2d_fwd', dev(x), dev(wt), None, None, None, None, z, n, h, w, cin, cout, ks, stride, wsb, nb, stream())
+    check_maxabs(host(z), z_ref, what='fwd')
+    dz = r.standard_normal(z_ref.shape)
+    dx_ref, dw_ref = ops.conv2d_bwd(x, wt, dz, stride)
+    dx = torch.full(x.shape, 7.0, device='cuda')                 # poison: zero-gradient parity classes must be WRITTEN
+    call('fte_conv2d_dgrad', dev(dz), dev(wt), None, None, None, None, dx, None, None, n, h, w, cin, cout, ks, stride, wsb, nb, stream())
+    check_maxabs(host(dx), dx_ref, what='dgrad')
+    dw = torch.empty(ks, ks, cin, cout, device='cuda')
+    call('fte_conv2d_wgrad', dev(x), dev(dz), dw, n, h, w, cin, cout, ks, stride, wsb, nb, stream())
+    check_maxabs(host(dw), dw_ref, what='wgrad')
+
+
+@pytest.mark.parametrize('rows_shape,c', [((3, 9, 7), 64), ((16, 28, 28), 256), ((2, 4, 4), 2048), ((64, 14, 14), 1024)])
+def test_batch_norm_train_fwd_bwd(rows_shape, c):
+    r = _rng(2)
+    shape = rows_shape + (c,)
+    z = r.standard_normal(shape) * 2.0 + 3.0                      # mean well away from 0: E[x^2]-E[x]^2 would lose digits
+    gamma = 1 + 0.2 * r.standard_normal(c); beta = 0.3 * r.standard_normal(c)
+    res = r.standard_normal(shape)
+    rows = int(np.prod(rows_shape))
+    bn_ref, cache = ops.bn_train_fwd(z, gamma, beta)
+    y_ref = np.maximum(bn_ref + res, 0)
+    mm = r.standard_normal(c) * 0.1; mv = 1 + 0.1 * r.random(c)
+    mm_ref, mv_ref = ops.bn_moving_update(mm, mv, cache['mean'], cache['var'], rows)
+    y = torch.empty(shape, device='cuda')
+    mean, rstd, scale, shift = [torch.empty(c, device='cuda') for _ in range(4)]
+    mmd, mvd = dev(mm), dev(mv)
+    wsb, nb = ws(query('fte_bn_ws_bytes', c))
+    zd, gd = dev(z), dev(gamma)
+    call('fte_bn_train_fwd', zd, gd, dev(beta), dev(res), y, mean, rstd, scale, shift, mmd, mvd, rows, c, 1e-3, 0.999, 1, wsb, nb, stream())
+    check_maxabs(host(mean), cache['mean'], 1e-6, 'mean'); check_maxabs(host(rstd), cache['rstd'], 2e-6, 'rstd')
+    check_maxabs(host(y), y_ref, what='y = relu(bn + res)')
+    check_maxabs(host(mmd), mm_ref, 1e-6, 'moving mean'); check_maxabs(host(mvd), mv_ref, 1e-6, 'moving var')
+    # backward through relu(bn(z) + res): g = dy * (y > 0)
+    dy = r.standard_normal(shape)
+    g_ref = dy * (y_ref > 0)
+    dz_ref, dg_ref, db_ref = ops.bn_train_bwd(g_ref, gamma, cache)
+    dz = torch.empty(shape, device='cuda'); dg = torch.empty(c, device='cuda'); db = torch.empty(c, device='cuda')
+    call('fte_bn_train_bwd', dev(dy), y, zd, gd, mean, rstd, dz, dg, db, rows, c, wsb, nb, stream())
+    check_maxabs(host(dz), dz_ref, what='dz'); check_rell2(host(dg), dg_ref, what='dgamma'); check_rell2(host(db), db_ref, what='dbeta')
+    g = torch.empty(shape, device='cuda')
+    call('fte_relu_bwd', dev(dy), y, g, int(np.prod(shape)), stream())
+    check_maxabs(host(g), g_ref, 1e-7, 'relu bwd')
+    # no mask / no residual / no relu variant, and inference mode
+    call('fte_bn_train_fwd', zd, gd, dev(beta), None, y, mean, rstd, scale, shift, None, None, rows, c, 1e-3, 0.999, 0, wsb, nb, stream())
+    check_maxabs(host(y), bn_ref, what='bn plain')
+    call('fte_bn_train_bwd', dev(dy), None, zd, gd, mean, rstd, dz, dg, db, rows, c, wsb, nb, stream())
+    check_maxabs(host(dz), ops.bn_train_bwd(dy, gamma, cache)[0], what='dz plain')
+    call('fte_bn_infer_fwd', zd, gd, dev(beta), dev(mm), dev(mv), None, y, scale, shift, rows, c, 1e-3, 0, stream())
+    check_maxabs(host(y), ops.bn_infer(z, gamma, beta, mm, mv), what='bn infer')
+
+
+@pytest.mark.parametrize('n,h,w,c', [(2, 56, 56, 64), (3, 7, 6, 8), (2, 13, 9, 24)])
+def test_maxpool_gap_dropout(n, h, w, c):
+    r = _rng(3)
+    x = r.integers(0, 4, (n, h, w, c)).astype(np.float64) + 0.25 * r.integers(0, 2, (n, h, w, c))   # plenty of ties
+    y_ref, cache = ops.maxpool3x3s2_fwd(x)
+    y = torch.empty(y_ref.shape, device='cuda'); idx = torch.empty(y_ref.shape, dtype=torch.uint8, device='cuda')
+    call('fte_maxpool3x3s2_fwd', dev(x), y, idx, n, h, w, c, stream())
+    assert np.array_equal(host(y), y_ref)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), cache['arg'])
+    dy = r.standard_normal(y_ref.shape)
+    dx = torch.empty(x.shape, device='cuda')
+    call('fte_maxpool3x3s2_bwd', dev(dy), idx, dx, n, h, w, c, stream())
+    check_maxabs(host(dx), ops.maxpool3x3s2_bwd(dy, cache), 1e-6, 'maxpool bwd')
+    g = torch.empty(n, c, device='cuda')
+    call('fte_gap_fwd', dev(x), g, n, h * w, c, stream())
+    check_maxabs(host(g), ops.gap_fwd(x), 1e-6, 'gap')
+    dg = r.standard_normal((n, c)); dxx = torch.empty(x.shape, device='cuda')
+    call('fte_gap_bwd', dev(dg), dxx, n, h * w, c, stream())
+    check_maxabs(host(dxx), ops.gap_bwd(dg, x.shape), 1e-6, 'gap bwd')
+    f = r.standard_normal((n, 2048)); m = torch.empty(n, 2048, device='cuda'); o = torch.empty(n, 2048, device='cuda')
+    call('fte_dropout_fwd', dev(f), m, o, n * 2048, 0.5, 1234, stream())
+    mh = host(m)
+    assert set(np.unique(mh)) <= {0.0, 1.0} and 0.4 < mh.mean() < 0.6
+    check_maxabs(host(o), ops.dropout_fwd(f, mh, 0.5), 1e-7, 'dropout')
+    m2 = torch.empty_like(m)
+    call('fte_dropout_fwd', dev(f), m2, o, n * 2048, 0.5, 1235, stream())
+    assert not torch.equal(m, m2)                                   # another seed, another mask
+    call('fte_dropout_bwd', dev(f), m, o, n * 2048, 0.5, stream())
+    check_maxabs(host(o), f * mh / 0.5, 1e-7, 'dropout bwd')
+
+
+def test_first_layer_7x7_as_im2col_gemm():
+    r = _rng(4)
+    n, h, w, cin, cout, ks, stride, kpad = 3, 32, 24, 3, 64, 7, 2, 160
+    x = r.uniform(-1, 1, (n, h, w, cin)); wt = r.standard_normal((ks, ks, cin, cout)) * 0.1
+    z_ref = ops.conv2d_fwd(x, wt, stride)
+    ho, wo = z_ref.shape[1], z_ref.shape[2]
+    m = n * ho * wo
+    cols = torch.empty(m, kpad, device='cuda')
+    call('fte_im2col_first', dev(x), cols, n, h, w, cin, ks, stride, kpad, stream())
+    wp = np.zeros((kpad, cout)); wp[:ks * ks * cin] = wt.reshape(-1, cout)
+    z = torch.empty(m, cout, device='cuda')
+    wsb, nb = ws(max(query('fte_gemm_ws_bytes', m, cout, kpad), 1 << 20))
+    call('fte_gemm_nn', cols, dev(wp), None, z, m, cout, kpad, wsb, nb, stream())
+    check_maxabs(host(z).reshape(z_ref.shape), z_ref, what='stem fwd')
+    dz = r.standard_normal(z_ref.shape)
+    _, dw_ref = ops.conv2d_bwd(x, wt, dz, stride, need_dx=False)
+    dw = torch.empty(kpad, cout, device='cuda')
+    call('fte_gemm_tn', cols, dev(dz.reshape(m, cout)), dw, m, cout, kpad, wsb, nb, stream())
+    check_maxabs(host(dw)[:ks * ks * cin].reshape(wt.shape), dw_ref, what='stem wgrad')
+    assert float(dw[ks * ks * cin:].abs().max()) == 0.0

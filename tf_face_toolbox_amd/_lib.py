@@ -3,7 +3,7 @@ training step runs: there is no CPU fallback.  If the library is missing or a ca
 fails, the error is raised -- never swallowed."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FTE_LIB') or os.path.join(_HERE, 'libfte.so')     # FTE_LIB: A/B builds of the same ABI
@@ -25,6 +25,24 @@ _SIGS = {
     'fte_conv3x3_dgrad_ws_bytes': (c_size_t, [c_int] * 6),
     'fte_conv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_wgrad_ws_bytes': (c_size_t, [c_int] * 6),
+    'fte_conv2d_fwd': (c_int, [_P] * 7 + [c_int] * 7 + [_P, c_size_t, _P]),
+    'fte_conv2d_fwd_ws_bytes': (c_size_t, [c_int] * 7),
+    'fte_conv2d_dgrad': (c_int, [_P] * 9 + [c_int] * 7 + [_P, c_size_t, _P]),
+    'fte_conv2d_dgrad_ws_bytes': (c_size_t, [c_int] * 7),
+    'fte_conv2d_wgrad': (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),
+    'fte_conv2d_wgrad_ws_bytes': (c_size_t, [c_int] * 7),
+    'fte_im2col_first': (c_int, [_P] * 2 + [c_int] * 7 + [_P]),
+    'fte_bn_ws_bytes': (c_size_t, [c_int]),
+    'fte_bn_train_fwd': (c_int, [_P] * 11 + [c_long, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
+    'fte_bn_infer_fwd': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_int, _P]),
+    'fte_bn_train_bwd': (c_int, [_P] * 9 + [c_long, c_int, _P, c_size_t, _P]),
+    'fte_relu_bwd': (c_int, [_P] * 3 + [c_long, _P]),
+    'fte_maxpool3x3s2_fwd': (c_int, [_P] * 3 + [c_int] * 4 + [_P]),
+    'fte_maxpool3x3s2_bwd': (c_int, [_P] * 3 + [c_int] * 4 + [_P]),
+    'fte_gap_fwd': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
+    'fte_gap_bwd': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
+    'fte_dropout_fwd': (c_int, [_P] * 3 + [c_long, c_float, c_uint64, _P]),
+    'fte_dropout_bwd': (c_int, [_P] * 3 + [c_long, c_float, _P]),
     'fte_conv3x3_first_fwd': (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
     'fte_conv3x3_first_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_first_wgrad_ws_bytes': (c_size_t, [c_int] * 6),

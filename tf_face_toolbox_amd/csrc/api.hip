@@ -8,6 +8,7 @@
 #include "../../include/fte.h"
 #include "igemm.h"
 #include "kernels.h"
+#include "layers.h"
 
 namespace {
 
@@ -173,37 +174,47 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms) {
 }
 
 // ------------------------------------------------------------------------------------------------
-size_t fte_conv3x3_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
-    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
-    return plan_rows((long)n * ph.out * pw.out, cout, 9L * cin, true).pw_bytes;
+size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
+    return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true).pw_bytes;
 }
 
-int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
-                    float* z, float* y, int n, int h, int wd, int cin, int cout, int stride,
-                    void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !y || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2)) return FTE_EINVAL;
-    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+int fte_conv2d_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
+                   float* z, float* y, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                   void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3))
+        return FTE_EINVAL;
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     IgemmParams p;
     zero_params(&p);
-    p.M = n * ph.out * pw.out; p.N = cout; p.K = 9 * cin; p.kchunk = p.K;
+    p.M = n * ph.out * pw.out; p.N = cout; p.K = ksize * ksize * cin; p.kchunk = p.K;
     p.A = x; p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
-    p.a_ld = cin; p.a_KC = cin; p.a_NT = 9;
-    for (int r = 0; r < 3; ++r)
-        for (int s = 0; s < 3; ++s) { p.a_dh[r * 3 + s] = r - ph.before; p.a_dw[r * 3 + s] = s - pw.before; }
+    p.a_ld = cin; p.a_KC = cin; p.a_NT = ksize * ksize;
+    for (int r = 0; r < ksize; ++r)
+        for (int s = 0; s < ksize; ++s) { p.a_dh[r * ksize + s] = r - ph.before; p.a_dw[r * ksize + s] = s - pw.before; }
     p.B = w; p.b_ld = cout;
     p.c_ld = cout;
     p.Y = y; p.Z = z; p.R = res; p.bias = bias; p.alpha = alpha;
-    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)9 * cin * cout)) return FTE_EINVAL;
+    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)ksize * ksize * cin * cout)) return FTE_EINVAL;
     RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr);
     if (rp.tail_mode == 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
     return rc(launch_rows(p, rp, AL_MK, BL_KN, EPI_FWD, 0, (float*)ws, (hipStream_t)stream));
 }
 
+size_t fte_conv3x3_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+    return fte_conv2d_fwd_ws_bytes(n, h, wd, cin, cout, 3, stride);
+}
+int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
+                    float* z, float* y, int n, int h, int wd, int cin, int cout, int stride,
+                    void* ws, size_t ws_bytes, void* stream) {
+    return fte_conv2d_fwd(x, w, bias, alpha, res, z, y, n, h, wd, cin, cout, 3, stride, ws, ws_bytes, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct DgradClass { int ph, pw, hq, wq, ntap, dh[9], dw[9], wt[9]; RowPlan rp; long mtiles; };
-int dgrad_classes(int n, int h, int wd, int cin, int cout, int stride, DgradClass* cls) {
-    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+int dgrad_classes(int n, int h, int wd, int cin, int cout, int ksize, int stride, DgradClass* cls) {
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     int nc = 0;
     for (int a = 0; a < stride; ++a)
         for (int b = 0; b < stride; ++b) {
@@ -213,18 +224,17 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int stride, DgradClas
             c.wq = (wd - b + stride - 1) / stride;
             c.ntap = 0;
             if (c.hq <= 0 || c.wq <= 0) continue;
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < ksize; ++r) {
                 if ((a + ph.before - r) % stride) continue;
-                for (int s = 0; s < 3; ++s) {
+                for (int s = 0; s < ksize; ++s) {
                     if ((b + pw.before - s) % stride) continue;
                     // hi = ho*stride + r - pt  with hi = hq*stride + a  ->  ho = hq + (a + pt - r)/stride
                     c.dh[c.ntap] = (a + ph.before - r) / stride;
                     c.dw[c.ntap] = (b + pw.before - s) / stride;
-                    c.wt[c.ntap] = r * 3 + s;
+                    c.wt[c.ntap] = r * ksize + s;
                     ++c.ntap;
                 }
             }
-            if (c.ntap == 0) continue;
             const long M = (long)n * c.hq * c.wq;
             c.rp = plan_rows(M, cin, (long)c.ntap * cout, true);
             c.mtiles = c.rp.main_mtiles + c.rp.tail_mtiles;
@@ -234,23 +244,23 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int stride, DgradClas
 }
 }  // namespace
 
-size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     DgradClass cls[4];
-    const int nc = dgrad_classes(n, h, wd, cin, cout, stride, cls);
+    const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
     long rows = 0;
     size_t pw = 0;
     for (int i = 0; i < nc; ++i) { rows += cls[i].mtiles; if (cls[i].rp.pw_bytes > pw) pw = cls[i].rp.pw_bytes; }
     return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES + pw;
 }
 
-int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
-                      const float* alpha_prev, float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
-                      int n, int h, int wd, int cin, int cout, int stride, void* ws, size_t ws_bytes, void* stream) {
-    if (!dz || !w || !dzprev || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
+                     const float* alpha_prev, float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
+                     int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
+    if (!dz || !w || !dzprev || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
     if (zprev && !alpha_prev) return FTE_EINVAL;
-    const Pads pho = same_pads(h, 3, stride), pwo = same_pads(wd, 3, stride);
+    const Pads pho = same_pads(h, ksize, stride), pwo = same_pads(wd, ksize, stride);
     DgradClass cls[4];
-    const int nc = dgrad_classes(n, h, wd, cin, cout, stride, cls);
+    const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
     long rows = 0;
     for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
     const bool want_part = zprev && (dalpha_prev || dbias_prev);
@@ -281,7 +291,7 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
         p.c_ld = cin;
         p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
         p.PA = PA; p.PB = PB;
-        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)9 * cin * cout)) return FTE_EINVAL;
+        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout)) return FTE_EINVAL;
         hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, pwbuf, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
         prow += c.mtiles;
@@ -293,12 +303,22 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
     return FTE_OK;
 }
 
+size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+    return fte_conv2d_dgrad_ws_bytes(n, h, wd, cin, cout, 3, stride);
+}
+int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
+                      const float* alpha_prev, float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
+                      int n, int h, int wd, int cin, int cout, int stride, void* ws, size_t ws_bytes, void* stream) {
+    return fte_conv2d_dgrad(dz, w, addin, zprev, alpha_prev, raw, dzprev, dalpha_prev, dbias_prev,
+                            n, h, wd, cin, cout, 3, stride, ws, ws_bytes, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 namespace {
-void wgrad_plan(int n, int h, int wd, int cin, int cout, int stride, int* tile, int* splits, int* kchunk, int* K) {
-    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, int* tile, int* splits, int* kchunk, int* K) {
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     *K = n * ph.out * pw.out;
-    const long M = 9L * cin;
+    const long M = (long)ksize * ksize * cin;
     *tile = (cout % 128 == 0) ? TILE_128x128 : TILE_128x64;
     // prefer8 / split-major placement (one pixel range per XCD) cut wgrad's HBM traffic ~9x on MI355X but the
     // kernel is MFMA-bound: 18.4 -> 18.9 ms per step.  Left off.
@@ -306,27 +326,30 @@ void wgrad_plan(int n, int h, int wd, int cin, int cout, int stride, int* tile, 
 }
 }  // namespace
 
-size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+size_t fte_conv2d_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     int tile, splits, kchunk, K;
-    wgrad_plan(n, h, wd, cin, cout, stride, &tile, &splits, &kchunk, &K);
-    return (splits > 1 ? (size_t)splits * 9 * cin * cout * sizeof(float) : 0) + SCRATCH_BYTES;
+    wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
+    return (splits > 1 ? (size_t)splits * ksize * ksize * cin * cout * sizeof(float) : 0) + SCRATCH_BYTES;
+}
+size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
+    return fte_conv2d_wgrad_ws_bytes(n, h, wd, cin, cout, 3, stride);
 }
 
-int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
-                      void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dz || !dw || n <= 0 || cin % 4 || cout % 64 || (stride != 1 && stride != 2)) return FTE_EINVAL;
-    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+int fte_conv2d_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                     void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dz || !dw || n <= 0 || cin % 4 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     int tile, splits, kchunk, K;
-    wgrad_plan(n, h, wd, cin, cout, stride, &tile, &splits, &kchunk, &K);
-    const size_t need = splits > 1 ? (size_t)splits * 9 * cin * cout * sizeof(float) : 0;
+    wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
+    const size_t need = splits > 1 ? (size_t)splits * ksize * ksize * cin * cout * sizeof(float) : 0;
     if (need && (!ws || ws_bytes < need)) return FTE_EWORKSPACE;
     IgemmParams p;
     zero_params(&p);
-    p.M = 9 * cin; p.N = cout; p.K = K; p.kchunk = kchunk;
+    p.M = ksize * ksize * cin; p.N = cout; p.K = K; p.kchunk = kchunk;
     p.A = x; p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
-    p.a_ld = cin; p.a_KC = cin; p.a_NT = 9;
-    for (int r = 0; r < 3; ++r)
-        for (int s = 0; s < 3; ++s) { p.a_dh[r * 3 + s] = r - ph.before; p.a_dw[r * 3 + s] = s - pw.before; }
+    p.a_ld = cin; p.a_KC = cin; p.a_NT = ksize * ksize;
+    for (int r = 0; r < ksize; ++r)
+        for (int s = 0; s < ksize; ++s) { p.a_dh[r * ksize + s] = r - ph.before; p.a_dw[r * ksize + s] = s - pw.before; }
     p.B = dz; p.b_ld = cout;
     p.c_ld = cout;
     p.slab = (long)p.M * p.N;
@@ -337,6 +360,10 @@ int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, 
     if (e != hipSuccess) return (int)e;
     if (splits > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream));
     return FTE_OK;
+}
+int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                      void* ws, size_t ws_bytes, void* stream) {
+    return fte_conv2d_wgrad(x, dz, dw, n, h, wd, cin, cout, 3, stride, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,6 +577,70 @@ int fte_adam_update(float* w, float* m, float* v, const float* g, long n, float 
     if (!w || !m || !v || !g || n <= 0 || t < 1) return FTE_EINVAL;
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t));
     return rc(k_adam(w, m, v, g, n, (float)lr_t, b1, b2, eps, wd, gscale, (hipStream_t)stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// layers of the BN / pooling nets
+size_t fte_bn_ws_bytes(int c) { return ((size_t)BN_MAX_SPLITS * 3 * c + 3 * (size_t)c) * sizeof(float); }
+
+int fte_bn_train_fwd(const float* z, const float* gamma, const float* beta, const float* res, float* y,
+                     float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                     long rows, int c, float eps, float decay, int relu, void* ws, size_t ws_bytes, void* stream) {
+    if (!z || !gamma || !beta || !y || !mean || !rstd || !scale || !shift || rows <= 0 || c % 4) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    hipError_t e = l_bn_train_stats(z, gamma, beta, rows, c, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
+                                    (float*)ws, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return rc(l_bn_apply(z, scale, shift, res, y, rows, c, relu, (hipStream_t)stream));
+}
+int fte_bn_infer_fwd(const float* z, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                     const float* res, float* y, float* scale, float* shift, long rows, int c, float eps, int relu, void* stream) {
+    if (!z || !gamma || !beta || !moving_mean || !moving_var || !y || !scale || !shift || rows <= 0 || c % 4) return FTE_EINVAL;
+    hipError_t e = l_bn_infer_coef(gamma, beta, moving_mean, moving_var, eps, c, scale, shift, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return rc(l_bn_apply(z, scale, shift, res, y, rows, c, relu, (hipStream_t)stream));
+}
+int fte_bn_train_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
+                     const float* rstd, float* dz, float* dgamma, float* dbeta, long rows, int c,
+                     void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !z || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || rows <= 0 || c % 4) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    return rc(l_bn_bwd(dy, ymask, z, gamma, mean, rstd, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
+}
+int fte_relu_bwd(const float* dy, const float* y, float* g, long n, void* stream) {
+    if (!dy || !y || !g || n <= 0 || n % 4) return FTE_EINVAL;
+    return rc(l_relu_bwd(dy, y, g, n, (hipStream_t)stream));
+}
+int fte_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int wd, int c, void* stream) {
+    if (!x || !y || !idx || n <= 0 || c % 4) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, 2), pw = same_pads(wd, 3, 2);
+    return rc(l_maxpool_fwd(x, y, idx, n, h, wd, c, ph.out, pw.out, ph.before, pw.before, (hipStream_t)stream));
+}
+int fte_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int wd, int c, void* stream) {
+    if (!dy || !idx || !dx || n <= 0 || c % 4) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, 2), pw = same_pads(wd, 3, 2);
+    return rc(l_maxpool_bwd(dy, idx, dx, n, h, wd, c, ph.out, pw.out, ph.before, pw.before, (hipStream_t)stream));
+}
+int fte_gap_fwd(const float* x, float* y, int n, int hw, int c, void* stream) {
+    if (!x || !y || n <= 0 || hw <= 0) return FTE_EINVAL;
+    return rc(l_gap_fwd(x, y, n, hw, c, (hipStream_t)stream));
+}
+int fte_gap_bwd(const float* dy, float* dx, int n, int hw, int c, void* stream) {
+    if (!dy || !dx || n <= 0 || hw <= 0) return FTE_EINVAL;
+    return rc(l_gap_bwd(dy, dx, n, hw, c, (hipStream_t)stream));
+}
+int fte_dropout_fwd(const float* x, float* mask, float* y, long n, float keep_prob, uint64_t seed, void* stream) {
+    if (!x || !mask || !y || n <= 0 || !(keep_prob > 0.f)) return FTE_EINVAL;
+    return rc(l_dropout_fwd(x, mask, y, n, keep_prob, seed, (hipStream_t)stream));
+}
+int fte_dropout_bwd(const float* dy, const float* mask, float* dx, long n, float keep_prob, void* stream) {
+    if (!dy || !mask || !dx || n <= 0 || !(keep_prob > 0.f)) return FTE_EINVAL;
+    return rc(l_scale_mask(dy, mask, dx, n, 1.f / keep_prob, (hipStream_t)stream));
+}
+int fte_im2col_first(const float* x, float* cols, int n, int h, int wd, int cin, int ksize, int stride, int kpad, void* stream) {
+    if (!x || !cols || n <= 0 || kpad % 32 || kpad < ksize * ksize * cin) return FTE_EINVAL;
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
+    return rc(l_im2col_first(x, cols, n, h, wd, cin, ksize, stride, ph.out, pw.out, ph.before, pw.before, kpad, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,25 @@
+// layers.h -- host launchers of the layer kernels (layers.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+constexpr int BN_MAX_SPLITS = 64;      // row splits of the two-level per-channel reductions
+
+hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* beta, long rows, int C, float eps, float decay,
+                            float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var,
+                            float* part, hipStream_t st);
+hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int C,
+                           float* scale, float* shift, hipStream_t st);
+hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, const float* res, float* y, long rows, int C,
+                      int relu, hipStream_t st);
+hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st);
+hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
+                    const float* rstd, float* dz, float* dgamma, float* dbeta, long rows, int C, float* part, hipStream_t st);
+hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
+hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
+hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st);
+hipError_t l_gap_bwd(const float* dy, float* dx, int n, int hw, int c, hipStream_t st);
+hipError_t l_dropout_fwd(const float* x, float* mask, float* y, long n, float keep, uint64_t seed, hipStream_t st);
+hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, float inv_keep, hipStream_t st);
+hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
+                          int pt, int pl, int kpad, hipStream_t st);

@@ -1,0 +1,425 @@
+// layers.hip -- HBM-bound layer kernels of the BN / pooling nets (nets/resnet.py, nets/resnext.py,
+// nets/shufflenet_v2.py) for gfx950: batch-norm statistics / apply / backward, ReLU backward,
+// 3x3-s2 max-pool, global average pool, dropout, first-layer im2col.  Tensors are NHWC fp32, so the
+// channel index is the fastest one: per-channel vectors are read once per thread and rows stream
+// through 16-byte coalesced accesses.  All reductions are ordered (two-level, no float atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layers.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// Per-channel statistics of x[rows, C].  grid = (ceil(C/64), splits), block = 64 channels x 4 row lanes.
+// Each thread keeps shifted sums (shift = its first element) -> (n, mean, M2); lanes / blocks are merged
+// with Chan's parallel-variance formula, so no E[x^2]-E[x]^2 cancellation in fp32.
+// partial layout: part[(split*3 + {0:n,1:mean,2:M2}) * C + c]
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
+    if (nb == 0.f) return;
+    if (n == 0.f) { n = nb; mean = meanb; m2 = m2b; return; }
+    const float tot = n + nb, d = meanb - mean;
+    mean += d * (nb / tot);
+    m2 += m2b + d * d * (n * nb / tot);
+    n = tot;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                       long rows, int C, long rows_per_split) {
+    __shared__ float sh[3][4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + c;
+    const long r0 = (long)blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    float n = 0.f, s = 0.f, ss = 0.f, shift = 0.f;
+    if (ch < C) {
+        long r = r0 + rl;
+        if (r < r1) shift = x[r * C + ch];
+        for (; r < r1; r += 4) {
+            const float v = x[r * C + ch] - shift;
+            s += v;
+            ss += v * v;
+            n += 1.f;
+        }
+    }
+    float mean = 0.f, m2 = 0.f;
+    if (n > 0.f) { mean = shift + s / n; m2 = ss - s * s / n; }
+    sh[0][rl][c] = n; sh[1][rl][c] = mean; sh[2][rl][c] = m2;
+    __syncthreads();
+    if (rl == 0 && ch < C) {
+#pragma unroll
+        for (int l = 1; l < 4; ++l) chan_merge(n, mean, m2, sh[0][l][c], sh[1][l][c], sh[2][l][c]);
+        float* pp = part + (long)blockIdx.y * 3 * C;
+        pp[ch] = n; pp[C + ch] = mean; pp[2 * C + ch] = m2 < 0.f ? 0.f : m2;
+    }
+}
+
+// merge the splits; scale = gamma*rstd, shift = beta - mean*scale; moving statistics (decay, unbiased var)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int splits, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float decay, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, float* __restrict__ scale,
+                                                          float* __restrict__ shift, float* __restrict__ mov_mean,
+                                                          float* __restrict__ mov_var) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= C) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float* pp = part + (long)s * 3 * C;
+        chan_merge(n, mean, m2, pp[ch], pp[C + ch], pp[2 * C + ch]);
+    }
+    const float var = m2 / n;
+    const float rstd = 1.f / sqrtf(var + eps);
+    mean_out[ch] = mean;
+    rstd_out[ch] = rstd;
+    const float sc = gamma[ch] * rstd;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - mean * sc;
+    if (mov_mean) {
+        mov_mean[ch] = decay * mov_mean[ch] + (1.f - decay) * mean;
+        mov_var[ch] = decay * mov_var[ch] + (1.f - decay) * (m2 / fmaxf(n - 1.f, 1.f));
+    }
+}
+
+// inference-mode scale/shift from the moving statistics
+__global__ __launch_bounds__(256) void bn_infer_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mm, const float* __restrict__ mv,
+                                                            float eps, int C, float* __restrict__ scale, float* __restrict__ shift) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= C) return;
+    const float sc = gamma[ch] / sqrtf(mv[ch] + eps);
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - mm[ch] * sc;
+}
+
+// y = [relu]( scale[c]*z + shift[c] [+ res] )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ res,
+                                                       float* __restrict__ y, long n4, int C, int relu) {
+    const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(res);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sf = *reinterpret_cast<const f32x4*>(shift + c);
+        f32x4 v = z4[i] * sc + sf;
+        if (res) v += r4[i];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        y4[i] = v;
+    }
+}
+
+// g = dy * (y > 0)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ g, long n4) {
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+    f32x4* g4 = reinterpret_cast<f32x4*>(g);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 d = d4[i];
+        const f32x4 yy = y4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = yy[e] > 0.f ? d[e] : 0.f;
+        g4[i] = d;
+    }
+}
+
+// partial sums for the BN backward: sum g and sum g*xhat per channel, g = dy * (ymask > 0 if given)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                            const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ part,
+                                                            long rows, int C, long rows_per_split) {
+    __shared__ float sh[2][4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + c;
+    const long r0 = (long)blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    float sg = 0.f, sgx = 0.f;
+    if (ch < C) {
+        const float mu = mean[ch], rs = rstd[ch];
+        for (long r = r0 + rl; r < r1; r += 4) {
+            float g = dy[r * C + ch];
+            if (ymask && !(ymask[r * C + ch] > 0.f)) g = 0.f;
+            sg += g;
+            sgx += g * ((z[r * C + ch] - mu) * rs);
+        }
+    }
+    sh[0][rl][c] = sg; sh[1][rl][c] = sgx;
+    __syncthreads();
+    if (rl == 0 && ch < C) {
+        float* pp = part + (long)blockIdx.y * 2 * C;
+        pp[ch] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+        pp[C + ch] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+    }
+}
+
+// dgamma, dbeta and the coefficients of dz = A*g + B*z + C0
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int splits, int C, float count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= C) return;
+    float sg = 0.f, sgx = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        sg += part[(long)s * 2 * C + ch];
+        sgx += part[(long)s * 2 * C + C + ch];
+    }
+    dbeta[ch] = sg;
+    dgamma[ch] = sgx;
+    const float gr = gamma[ch] * rstd[ch];
+    const float b = -gr * rstd[ch] * sgx / count;
+    coef[ch] = gr;
+    coef[C + ch] = b;
+    coef[2 * C + ch] = -gr * sg / count - b * mean[ch];
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                           const float* __restrict__ z, const float* __restrict__ coef,
+                                                           float* __restrict__ dz, long n4, int C) {
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* m4 = reinterpret_cast<const f32x4*>(ymask);
+    const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dz);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 A = *reinterpret_cast<const f32x4*>(coef + c), B = *reinterpret_cast<const f32x4*>(coef + C + c),
+                    C0 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
+        f32x4 g = d4[i];
+        if (ymask) {
+            const f32x4 m = m4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+        }
+        o4[i] = A * g + B * z4[i] + C0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// max_pool 3x3 stride 2 SAME.  idx = window position (0..8) of the FIRST maximum; backward is a gather
+// over the <= 4 windows that cover an input pixel (ordered, no atomics).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int n, int h, int w, int c,
+                                                          int ho, int wo, int pt, int pl) {
+    const long total = (long)n * ho * wo * (c >> 2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % (c >> 2));
+        long t = i / (c >> 2);
+        const int ow = (int)(t % wo); t /= wo;
+        const int oh = (int)(t % ho);
+        const int img = (int)(t / ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 + r - pt;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int iw = ow * 2 + s - pl;
+                if (ih < 0 || ih >= h || iw < 0 || iw >= w) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)(img * h + ih) * w + iw) * c + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = best;
+        *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int n, int h, int w, int c,
+                                                          int ho, int wo, int pt, int pl) {
+    const long total = (long)n * h * w * (c >> 2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % (c >> 2));
+        long t = i / (c >> 2);
+        const int iw = (int)(t % w); t /= w;
+        const int ih = (int)(t % h);
+        const int img = (int)(t / h);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // windows oh with oh*2 - pt <= ih <= oh*2 - pt + 2
+        for (int oh = (ih + pt - 2 + 1) >> 1; oh * 2 - pt <= ih; ++oh) {
+            if (oh < 0 || oh >= ho) continue;
+            const int r = ih - (oh * 2 - pt);
+            for (int ow = (iw + pl - 2 + 1) >> 1; ow * 2 - pl <= iw; ++ow) {
+                if (ow < 0 || ow >= wo) continue;
+                const int s = iw - (ow * 2 - pl);
+                const long o = (((long)(img * ho + oh) * wo + ow) * c) + c4 * 4;
+                const uchar4 k = *reinterpret_cast<const uchar4*>(idx + o);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                const int pos = r * 3 + s;
+                if (k.x == pos) acc[0] += d[0];
+                if (k.y == pos) acc[1] += d[1];
+                if (k.z == pos) acc[2] += d[2];
+                if (k.w == pos) acc[3] += d[3];
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// global average pool: y[n,c] = mean_hw x[n,h,w,c]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int hw, int c) {
+    const int img = blockIdx.y;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    const float* px = x + (long)img * hw * c + ch;
+    float s = 0.f;
+    for (int i = 0; i < hw; ++i) s += px[(long)i * c];
+    y[(long)img * c + ch] = s / hw;
+}
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long total, int hw, int c) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const long img = i / ((long)hw * c);
+        dx[i] = dy[img * c + ch] / hw;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dropout (inverted): mask[i] = U(seed, i) < keep ; y = x * mask / keep.  The generator is a 64-bit
+// mix (splitmix64) of (seed, element index): stateless, reproducible for a given seed, different per rank
+// when the caller folds the rank into the seed.  TF's Philox stream is not reproduced (cannot be).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t v) {
+    v += 0x9E3779B97F4A7C15ull;
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+    return v ^ (v >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ mask,
+                                                          float* __restrict__ y, long n, float keep, uint64_t seed) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float u = (float)(splitmix64(seed * 0x100000001B3ull + (uint64_t)i) >> 40) * (1.0f / 16777216.0f);
+        const float m = u < keep ? 1.f : 0.f;
+        mask[i] = m;
+        y[i] = x[i] * m / keep;
+    }
+}
+__global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                         float* __restrict__ dx, long n, float inv_keep) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dx[i] = dy[i] * mask[i] * inv_keep;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// im2col of the first layer (Cin = 1 or 3, any k): cols[m, kpad], k ordered (r, s, c) like HWIO rows,
+// columns >= k*k*cin are zero.  Turns the 7x7-s2 stem of nets/resnet.py:109 into a dense MFMA GEMM.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restrict__ x, float* __restrict__ cols,
+                                                           int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
+                                                           int pt, int pl, int kpad) {
+    const int k4 = kpad >> 2;
+    const long total = (long)n * ho * wo * k4;
+    const int kreal = ks * ks * cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kc = (int)(i % k4) * 4;
+        long t = i / k4;
+        const int ow = (int)(t % wo); t /= wo;
+        const int oh = (int)(t % ho);
+        const int img = (int)(t / ho);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = kc + e;
+            if (k < kreal) {
+                const int cch = k % cin, rs = k / cin, s = rs % ks, r = rs / ks;
+                const int ih = oh * stride + r - pt, iw = ow * stride + s - pl;
+                if (ih >= 0 && ih < h && iw >= 0 && iw < w) v[e] = x[((long)(img * h + ih) * w + iw) * cin + cch];
+            }
+        }
+        *reinterpret_cast<f32x4*>(cols + i * 4) = v;
+    }
+}
+
+inline int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+inline void stat_split(long rows, int C, int* splits, long* rps) {
+    const long cb = (C + 63) / 64;
+    long rs = 2048 / cb;
+    if (rs > rows / 32) rs = rows / 32;
+    if (rs > BN_MAX_SPLITS) rs = BN_MAX_SPLITS;
+    if (rs < 1) rs = 1;
+    *rps = (rows + rs - 1) / rs;
+    *splits = (int)((rows + *rps - 1) / *rps);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* beta, long rows, int C, float eps, float decay,
+                            float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var,
+                            float* part, hipStream_t st) {
+    int splits; long rps;
+    stat_split(rows, C, &splits, &rps);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
+                       mean, rstd, scale, shift, mov_mean, mov_var);
+    return hipGetLastError();
+}
+hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int C,
+                           float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(bn_infer_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mm, mv, eps, C, scale, shift);
+    return hipGetLastError();
+}
+hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, const float* res, float* y, long rows, int C,
+                      int relu, hipStream_t st) {
+    const long n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, st, z, scale, shift, res, y, n4, C, relu);
+    return hipGetLastError();
+}
+hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, dy, y, g, n / 4);
+    return hipGetLastError();
+}
+hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
+                    const float* rstd, float* dz, float* dgamma, float* dbeta, long rows, int C, float* part, hipStream_t st) {
+    int splits; long rps;
+    stat_split(rows, C, &splits, &rps);
+    float* coef = part + (long)splits * 2 * C;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
+                       dgamma, dbeta, coef);
+    const long n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dy, ymask, z, coef, dz, n4, C);
+    return hipGetLastError();
+}
+hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)n * ho * wo * (c / 4))), dim3(256), 0, st, x, y, idx, n, h, w, c, ho, wo, pt, pl);
+    return hipGetLastError();
+}
+hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)n * h * w * (c / 4))), dim3(256), 0, st, dy, idx, dx, n, h, w, c, ho, wo, pt, pl);
+    return hipGetLastError();
+}
+hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st) {
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3((c + 255) / 256, n), dim3(256), 0, st, x, y, hw, c);
+    return hipGetLastError();
+}
+hipError_t l_gap_bwd(const float* dy, float* dx, int n, int hw, int c, hipStream_t st) {
+    const long total = (long)n * hw * c;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, dy, dx, total, hw, c);
+    return hipGetLastError();
+}
+hipError_t l_dropout_fwd(const float* x, float* mask, float* y, long n, float keep, uint64_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, mask, y, n, keep, seed);
+    return hipGetLastError();
+}
+hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, float inv_keep, hipStream_t st) {
+    hipLaunchKernelGGL(scale_mask_kernel, dim3(grid_for(n)), dim3(256), 0, st, dy, mask, dx, n, inv_keep);
+    return hipGetLastError();
+}
+hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
+                          int pt, int pl, int kpad, hipStream_t st) {
+    hipLaunchKernelGGL(im2col_first_kernel, dim3(grid_for((long)n * ho * wo * (kpad / 4))), dim3(256), 0, st, x, cols, n, h, w, cin, ks,
+                       stride, ho, wo, pt, pl, kpad);
+    return hipGetLastError();
+}
