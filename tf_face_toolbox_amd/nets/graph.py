@@ -1,0 +1,458 @@
+"""Static-graph engine for the BN / pooling nets (ResNet family) on libfte.so.
+
+A net is a list of ops over named NHWC tensors (the same description the oracle executes,
+oracle/graphnet.py).  `GraphNet` compiles it once -- shapes, one flat parameter arena
+[gamma+beta | conv W | classifier W], a state arena for the BN moving statistics, BN+add+ReLU
+fusion -- and then forward / backward are fixed sequences of kernel launches on the current stream.
+It replaces the TF graph that nets/resnet.py builds and `tf.gradients` differentiates
+(data_parallel.py:33); every FLOP runs in libfte.so.
+"""
+from collections import OrderedDict
+
+import torch
+
+from .. import _lib
+from .net_base import Network
+from .sphere import Variable, same_pads
+
+BN_EPS = 1e-3          # nets/resnet.py:97-99 via layers.batch_norm defaults
+BN_DECAY = 0.999
+STEM_KPAD = 160        # 7*7*3 = 147 rows of the stem weight, zero-padded to a multiple of 32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class GraphNet(Network):
+    """Network whose body is an op list: ('conv', out, inp, wname, stride) | ('bn', out, inp, prefix) |
+    ('relu', out, inp) | ('add', out, a, b) | ('maxpool', out, inp) | ('gap', out, inp) |
+    ('dropout', out, inp, keep) | ('fc', out, inp, wname, None)."""
+
+    head = 'softmax'
+
+    def __init__(self, weight_decay, data_format, name, seed=0):
+        super(GraphNet, self).__init__(weight_decay, data_format, name)
+        self.seed = seed
+        self.built = False
+        self.tower_scale = 1.0
+        self.global_step = 0
+        self.update_moving_stats = True      # data_parallel.py:242-243: UPDATE_OPS of tower 0 only
+        self.dropout_seed = 0
+        self._act_n = None
+
+    # ---- to be provided by the subclass ----------------------------------------------------------
+    def build_graph(self, in_ch, num_classes):
+        """-> (graph, spec) with spec = [(variable name, reference shape, kind)], kind in
+        {'conv_w', 'gamma', 'beta', 'cls_w'}."""
+        raise NotImplementedError
+
+    # ---- construction -----------------------------------------------------------------------------
+    def build(self, height, width, channels, num_classes, device='cuda'):
+        _lib.load()
+        self.device = torch.device(device)
+        self.in_hwc = (height, width, channels)
+        self.num_classes = int(num_classes)
+        self.cpad = (self.num_classes + 127) // 128 * 128
+        self.graph, spec = self.build_graph(channels, num_classes)
+        self.spec = OrderedDict((n, (s, k)) for n, s, k in spec)
+        self._infer_shapes()
+        small = [(n, s, k) for n, s, k in spec if k in ('gamma', 'beta')]
+        convs = [(n, s, k) for n, s, k in spec if k == 'conv_w']
+        cls = [(n, s, k) for n, s, k in spec if k == 'cls_w']
+        self.variables = OrderedDict()
+        off = 0
+        for n, s, k in small + convs + cls:
+            size = self._internal_size(n, s, k)
+            self.variables[n] = Variable(n, k, s, off, size)
+            off += (size + 3) // 4 * 4
+        self.small_end = self.variables[convs[0][0]].offset
+        self.cls_start = self.variables[cls[0][0]].offset
+        self.arena_size = off
+        dev = self.device
+        self.params = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(off + 4, dtype=torch.float32, device=dev)
+        self.loss_slots = self.grads[off:off + 4]
+        # BN moving statistics: non-trainable state, never all-reduced (each replica keeps its own; only
+        # tower 0's are saved: saver.py:36-40)
+        self.state = OrderedDict()
+        for n, s, k in small:
+            if k == 'gamma':
+                pre = n[:-len('/gamma')]
+                self.state[pre + '/moving_mean'] = torch.zeros(s, dtype=torch.float32, device=dev)
+                self.state[pre + '/moving_variance'] = torch.ones(s, dtype=torch.float32, device=dev)
+        self._init_params()
+        self._compile()
+        self.built = True
+        return self
+
+    def _internal_size(self, name, shape, kind):
+        if kind == 'cls_w':
+            return shape[0] * self.cpad
+        if kind == 'conv_w' and shape[2] < 32:                 # the stem: [k*k*cin -> STEM_KPAD, cout]
+            return STEM_KPAD * shape[3]
+        size = 1
+        for d in shape:
+            size *= d
+        return size
+
+    def view(self, name, arena=None):
+        v = self.variables[name]
+        a = self.params if arena is None else arena
+        return a[v.offset:v.offset + v.size]
+
+    def _init_params(self):
+        """layers.conv2d default Xavier-uniform; BN gamma 1 / beta 0; classifier N(0, 1e-3) (nets/resnet.py:153-157)."""
+        g = torch.Generator().manual_seed(self.seed)
+        for n, v in self.variables.items():
+            if v.kind == 'conv_w':
+                k, _, cin, cout = v.ref_shape
+                lim = (6.0 / (k * k * cin + k * k * cout)) ** 0.5
+                self.set_variable(n, (torch.rand(v.ref_shape, generator=g) * 2 - 1) * lim)
+            elif v.kind == 'cls_w':
+                self.set_variable(n, torch.randn(v.ref_shape, generator=g) * 0.001)
+            elif v.kind == 'gamma':
+                self.view(n).fill_(1.0)
+
+    def get_variable(self, name, arena=None):
+        if name in self.state:
+            return self.state[name].clone()
+        v = self.variables[name]
+        t = self.view(name, arena)
+        if v.kind == 'cls_w':
+            return t.reshape(v.ref_shape[0], self.cpad)[:, :self.num_classes].clone()
+        if v.kind == 'conv_w' and v.ref_shape[2] < 32:
+            k, _, cin, cout = v.ref_shape
+            return t.reshape(STEM_KPAD, cout)[:k * k * cin].reshape(v.ref_shape).clone()
+        return t.reshape(v.ref_shape).clone()
+
+    def set_variable(self, name, value, arena=None):
+        if name in self.state:
+            self.state[name].copy_(torch.as_tensor(value, dtype=torch.float32))
+            return
+        v = self.variables[name]
+        t = torch.as_tensor(value, dtype=torch.float32).to(self.device)
+        assert tuple(t.shape) == v.ref_shape, (name, tuple(t.shape), v.ref_shape)
+        if v.kind == 'cls_w':
+            buf = torch.zeros(v.ref_shape[0], self.cpad, device=self.device)
+            buf[:, :self.num_classes] = t
+            t = buf
+        elif v.kind == 'conv_w' and v.ref_shape[2] < 32:
+            k, _, cin, cout = v.ref_shape
+            buf = torch.zeros(STEM_KPAD, cout, device=self.device)
+            buf[:k * k * cin] = t.reshape(k * k * cin, cout)
+            t = buf
+        self.view(name, arena).copy_(t.reshape(-1))
+
+    def load_params(self, params):
+        for k, val in params.items():
+            self.set_variable(k, val)
+
+    # ---- static analysis ----------------------------------------------------------------------------
+    def _infer_shapes(self):
+        h, w, c = self.in_hwc
+        shp = {'images': (h, w, c)}
+        for op in self.graph:
+            kind, out = op[0], op[1]
+            if kind == 'conv':
+                ih, iw, _ = shp[op[2]]
+                k, _, _, cout = self.spec[op[3]][0]
+                shp[out] = (same_pads(ih, k, op[4])[0], same_pads(iw, k, op[4])[0], cout)
+            elif kind in ('bn', 'relu', 'dropout'):
+                shp[out] = shp[op[2]]
+            elif kind == 'add':
+                shp[out] = shp[op[2]]
+            elif kind == 'maxpool':
+                ih, iw, cc = shp[op[2]]
+                shp[out] = (same_pads(ih, 3, 2)[0], same_pads(iw, 3, 2)[0], cc)
+            elif kind == 'gap':
+                shp[out] = (shp[op[2]][2],)
+            elif kind == 'fc':
+                shp[out] = (self.cpad,)
+        self.shapes = shp
+
+    def _compile(self):
+        """Fuse bn -> relu and bn -> add -> relu into one BN-apply launch; build consumer counts."""
+        g = self.graph
+        users = {}
+        for i, op in enumerate(g):
+            for inp in self._inputs(op):
+                users.setdefault(inp, []).append(i)
+        plan, skip = [], set()
+        for i, op in enumerate(g):
+            if i in skip:
+                continue
+            if op[0] == 'bn':
+                out, res, relu, final = op[1], None, 0, op[1]
+                u = users.get(out, [])
+                if len(u) == 1 and g[u[0]][0] == 'relu':
+                    relu, final = 1, g[u[0]][1]
+                    skip.add(u[0])
+                elif len(u) == 1 and g[u[0]][0] == 'add':
+                    add = g[u[0]]
+                    other = add[3] if add[2] == out else add[2]
+                    u2 = users.get(add[1], [])
+                    if len(u2) == 1 and g[u2[0]][0] == 'relu' and self._defined_before(other, i):
+                        res, relu, final = other, 1, g[u2[0]][1]
+                        skip.update([u[0], u2[0]])
+                plan.append(('bn', final, op[2], op[3], res, relu))
+            else:
+                plan.append(op)
+        self.plan = plan
+
+    @staticmethod
+    def _inputs(op):
+        if op[0] == 'add':
+            return [op[2], op[3]]
+        return [op[2]]
+
+    def _defined_before(self, name, idx):
+        if name == 'images':
+            return True
+        for j in range(idx):
+            if self.graph[j][1] == name:
+                return True
+        return False
+
+    # ---- buffers --------------------------------------------------------------------------------------
+    def _alloc(self, n):
+        if self._act_n == n:
+            return
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.t = {}
+        self.bn = {}
+        need = 1 << 20
+        q = _lib.query
+        for op in self.plan:
+            kind, out = op[0], op[1]
+            shape = (n,) + self.shapes[out]
+            self.t[out] = torch.empty(shape, **f32)
+            if kind == 'bn':
+                c = shape[-1]
+                self.bn[out] = dict(mean=torch.empty(c, **f32), rstd=torch.empty(c, **f32), scale=torch.empty(c, **f32),
+                                    shift=torch.empty(c, **f32))
+                need = max(need, q('fte_bn_ws_bytes', c))
+            elif kind == 'conv':
+                ih, iw, cin = self.shapes[op[2]]
+                k, _, _, cout = self.spec[op[3]][0]
+                if cin >= 32:
+                    need = max(need, q('fte_conv2d_fwd_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
+                               q('fte_conv2d_dgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
+                               q('fte_conv2d_wgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]))
+                else:
+                    oh, ow, _ = self.shapes[out]
+                    self.cols = torch.empty(n * oh * ow, STEM_KPAD, **f32)
+                    need = max(need, q('fte_gemm_ws_bytes', n * oh * ow, cout, STEM_KPAD))
+            elif kind == 'maxpool':
+                self.t[out + '/idx'] = torch.empty(shape, dtype=torch.uint8, device=dev)
+            elif kind == 'dropout':
+                self.t[out + '/mask'] = torch.empty(shape, **f32)
+            elif kind == 'fc':
+                need = max(need, q('fte_gemm_ws_bytes', n, self.cpad, self.shapes[op[2]][0]))
+        self.G = torch.empty(n, self.cpad, **f32)
+        self.loss_rows = torch.empty(n, **f32)
+        self.ws = torch.empty((need + 3) // 4 + 1024, **f32)
+        self.ws_bytes = self.ws.numel() * 4
+        self._act_n = n
+
+    # ---- forward ----------------------------------------------------------------------------------------
+    def _check_images(self, images):
+        if not (isinstance(images, torch.Tensor) and images.is_cuda and images.dtype == torch.float32):
+            raise TypeError('images must be a float32 CUDA tensor in NHWC (data.py:275-279 layout)')
+        return images.contiguous()
+
+    def _run_forward(self, images, is_training):
+        x = self._check_images(images)
+        n, h, w, ch = x.shape
+        assert (h, w, ch) == self.in_hwc, ((h, w, ch), self.in_hwc)
+        self._alloc(n)
+        st = _stream()
+        call = _lib.call
+        T = self.t
+        T['images'] = x
+        for op in self.plan:
+            kind, out = op[0], op[1]
+            if kind == 'conv':
+                _, _, inp, wname, stride = op
+                ih, iw, cin = self.shapes[inp]
+                k, _, _, cout = self.spec[wname][0]
+                if cin >= 32:
+                    call('fte_conv2d_fwd', T[inp], self.view(wname), None, None, None, None, T[out],
+                         n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                else:                                          # stem: im2col + dense MFMA GEMM
+                    oh, ow, _ = self.shapes[out]
+                    call('fte_im2col_first', T[inp], self.cols, n, ih, iw, cin, k, stride, STEM_KPAD, st)
+                    call('fte_gemm_nn', self.cols, self.view(wname), None, T[out], n * oh * ow, cout, STEM_KPAD,
+                         self.ws, self.ws_bytes, st)
+            elif kind == 'bn':
+                _, _, inp, pre, res, relu = op
+                b = self.bn[out]
+                c = self.shapes[out][-1]
+                rows = T[out].numel() // c
+                resbuf = T[res] if res is not None else None
+                if is_training:
+                    upd = self.update_moving_stats
+                    call('fte_bn_train_fwd', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'), resbuf, T[out],
+                         b['mean'], b['rstd'], b['scale'], b['shift'],
+                         self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None,
+                         rows, c, BN_EPS, BN_DECAY, relu, self.ws, self.ws_bytes, st)
+                else:
+                    call('fte_bn_infer_fwd', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
+                         self.state[pre + '/moving_mean'], self.state[pre + '/moving_variance'], resbuf, T[out],
+                         b['scale'], b['shift'], rows, c, BN_EPS, relu, st)
+            elif kind == 'maxpool':
+                ih, iw, c = self.shapes[op[2]]
+                call('fte_maxpool3x3s2_fwd', T[op[2]], T[out], T[out + '/idx'], n, ih, iw, c, st)
+            elif kind == 'gap':
+                ih, iw, c = self.shapes[op[2]]
+                call('fte_gap_fwd', T[op[2]], T[out], n, ih * iw, c, st)
+            elif kind == 'dropout':
+                if is_training:
+                    seed = (self.dropout_seed * 1000003 + self.global_step) & 0x7FFFFFFFFFFFFFFF
+                    call('fte_dropout_fwd', T[op[2]], T[out + '/mask'], T[out], T[out].numel(), op[3], seed, st)
+                else:
+                    T[out].copy_(T[op[2]])
+            elif kind == 'fc':
+                k = self.shapes[op[2]][0]
+                call('fte_gemm_nn', T[op[2]], self.view(op[3]), None, T[out], n, self.cpad, k, self.ws, self.ws_bytes, st)
+            else:
+                raise RuntimeError('op %s must have been fused away' % kind)
+
+    def _ensure_built(self, images, num_classes):
+        if not self.built:
+            n, h, w, ch = images.shape
+            self.build(h, w, ch, num_classes, images.device)
+        else:
+            assert num_classes == self.num_classes, 'num_classes changed after the variables were created'
+
+    def backbone(self, inputs, is_training=False, reuse=None):
+        self._run_forward(inputs, is_training)
+        return self.t[self.feature_name]
+
+    def forward(self, images, num_classes=None, is_training=True):
+        assert num_classes is not None, 'num_classes must be given when is_training=True'   # nets/resnet.py:147
+        self._ensure_built(images, num_classes)
+        self._run_forward(images, is_training)
+        return {'logits': self.t['logits'][:, :self.num_classes]}
+
+    # ---- loss -------------------------------------------------------------------------------------------
+    def loss_function(self, scope, labels, **logits):
+        """nets/resnet.py:163-176 + Network._regularize."""
+        if not (isinstance(labels, torch.Tensor) and labels.is_cuda and labels.dtype == torch.int32):
+            raise TypeError('labels must be an int32 CUDA tensor (data.py:259)')
+        n = labels.shape[0]
+        st = _stream()
+        _lib.call('fte_softmax_ce_fwd_bwd', self.t['logits'], labels.contiguous(), self.loss_rows, self.G, n,
+                  self.num_classes, self.cpad, self.tower_scale / n, st)
+        _lib.call('fte_sum', self.loss_rows, n, self.tower_scale / n, self.loss_slots[0:1], self.ws, self.ws_bytes, st)
+        nreg = self.arena_size - self.small_end
+        _lib.call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
+                  self.loss_slots[1:2], self.ws, self.ws_bytes, st)
+        return [self.loss_slots[0], self.loss_slots[1]], ['cross_entropy', 'reg_loss'], OrderedDict()
+
+    # ---- backward ---------------------------------------------------------------------------------------
+    def backward(self):
+        self.backward_head()
+        self.backward_body()
+
+    def backward_stages(self):
+        return [self.backward_head, self.backward_body]
+
+    def backward_head(self):
+        """Classifier gradient (first all-reduce bucket) and the gradient wrt its input."""
+        n = self._act_n
+        st = _stream()
+        op = self.plan[-1]
+        assert op[0] == 'fc'
+        k = self.shapes[op[2]][0]
+        self._grad = {}
+        gin = torch.empty(n, k, dtype=torch.float32, device=self.device)
+        _lib.call('fte_gemm_tn', self.t[op[2]], self.G, self.view(op[3], self.grads), n, self.cpad, k, self.ws, self.ws_bytes, st)
+        _lib.call('fte_gemm_nt', self.G, self.view(op[3]), None, None, 0, None, gin, None, n, self.cpad, k, self.ws, self.ws_bytes, st)
+        self._grad[op[2]] = gin
+
+    def _new(self, name):
+        return torch.empty_like(self.t[name])
+
+    def backward_body(self):
+        n = self._act_n
+        st = _stream()
+        call = _lib.call
+        T, G = self.t, self._grad
+        for op in reversed(self.plan[:-1]):
+            kind, out = op[0], op[1]
+            if out not in G:
+                continue
+            dy = G.pop(out)
+            if kind == 'dropout':
+                g = self._new(op[2])
+                call('fte_dropout_bwd', dy, T[out + '/mask'], g, dy.numel(), op[3], st)
+                self._put(op[2], g)
+            elif kind == 'gap':
+                ih, iw, c = self.shapes[op[2]]
+                g = self._new(op[2])
+                call('fte_gap_bwd', dy, g, n, ih * iw, c, st)
+                self._put(op[2], g)
+            elif kind == 'maxpool':
+                ih, iw, c = self.shapes[op[2]]
+                g = self._new(op[2])
+                call('fte_maxpool3x3s2_bwd', dy, T[out + '/idx'], g, n, ih, iw, c, st)
+                self._put(op[2], g)
+            elif kind == 'bn':
+                _, _, inp, pre, res, relu = op
+                b = self.bn[out]
+                c = self.shapes[out][-1]
+                rows = dy.numel() // c
+                if res is not None:                      # the shortcut gets g = dy * (out > 0)
+                    g = self._new(out)
+                    call('fte_relu_bwd', dy, T[out], g, dy.numel(), st)
+                    self._put(res, g)
+                    dy, mask = g, None
+                else:
+                    mask = T[out] if relu else None
+                dz = self._new(inp)
+                call('fte_bn_train_bwd', dy, mask, T[inp], self.view(pre + '/gamma'), b['mean'], b['rstd'], dz,
+                     self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), rows, c,
+                     self.ws, self.ws_bytes, st)
+                self._put(inp, dz)
+            elif kind == 'conv':
+                _, _, inp, wname, stride = op
+                ih, iw, cin = self.shapes[inp]
+                k, _, _, cout = self.spec[wname][0]
+                gw = self.view(wname, self.grads)
+                if cin < 32:                             # stem: filter gradient only
+                    oh, ow, _ = self.shapes[out]
+                    call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, STEM_KPAD, self.ws, self.ws_bytes, st)
+                    continue
+                call('fte_conv2d_wgrad', T[inp], dy, gw, n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                prev = G.pop(inp, None)                  # accumulate into an existing contribution through `addin`
+                dx = self._new(inp)
+                call('fte_conv2d_dgrad', dy, self.view(wname), prev, None, None, None, dx, None, None,
+                     n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                G[inp] = dx
+            else:
+                raise RuntimeError(kind)
+        self._grad = {}
+
+    def _put(self, name, g):
+        if name in self._grad:
+            raise RuntimeError('gradient of %s already has a contribution that cannot be accumulated in place' % name)
+        self._grad[name] = g
+
+    # ---- bookkeeping the wrappers use ---------------------------------------------------------------------
+    def param_list(self, is_training, trainable, scope=None):
+        bb = [v for k, v in self.variables.items() if k.startswith(self.name + '/')]
+        if is_training:
+            return [bb, [v for k, v in self.variables.items() if k.startswith('classifier/')]]
+        return [bb]
+
+    def pretrained_param(self, scope=None):
+        return [v for grp in self.param_list(is_training=False, trainable=False, scope=scope) for v in grp if self.name in v.name]
+
+    def arena_groups(self):
+        return [(0, self.small_end, False, 0), (self.small_end, self.cls_start, True, 0),
+                (self.cls_start, self.arena_size, True, 1)]
+
+    def grad_buckets(self):
+        return [(self.cls_start, self.arena_size + 4), (0, self.cls_start)]

@@ -19,10 +19,16 @@ def net_select(name, data_format='NCHW', weight_decay=5e-4):
     elif name == 'SphereNet-ASoftmax':
         from .sphere import SphereNetMargin
         network = SphereNetMargin(data_format=data_format, weight_decay=weight_decay)
-    elif name in ('ResNeXt-26', 'ResNeXt-50', 'ResNet-50', 'SENet-50', 'ShuffleNet-v2-small',
+    elif name == 'ResNet-50':
+        from .resnet import ResNet
+        network = ResNet(num_layers=50, data_format=data_format, weight_decay=weight_decay)
+    elif name == 'ResNet-26':                    # not a reference factory name; the class accepts 26 (nets/resnet.py:39-40)
+        from .resnet import ResNet
+        network = ResNet(num_layers=26, data_format=data_format, weight_decay=weight_decay)
+    elif name in ('ResNeXt-26', 'ResNeXt-50', 'SENet-50', 'ShuffleNet-v2-small',
                   'ShuffleNet-v2-middle', 'ShuffleNet-v2-large'):
-        raise NotImplementedError('%s: kernels for BN / grouped / depthwise conv are the next rows of the '
-                                  'hot-path scope table (SURVEY.md 8a R1,R2,S1); not built yet.' % name)
+        raise NotImplementedError('%s: grouped / depthwise conv and SE kernels are the next rows of the '
+                                  'hot-path scope table (SURVEY.md 8a R2,S1); not built yet.' % name)
     elif name in ('MobileNet-v2', 'Inception-v4', 'VGG16', 'AlexNet'):
         # nets/net_base.py:52-59 `pass` branches: the reference dies with UnboundLocalError here
         raise UnboundLocalError("local variable 'network' referenced before assignment")
