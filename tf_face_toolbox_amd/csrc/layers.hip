@@ -56,6 +56,90 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
+// float4 version: Q channel quads per row segment (Q = min(C/4, 64)), RL = 256/Q row lanes; a wave reads
+// 1 KiB (C >= 256) or several whole rows per instruction, two rows in flight per lane.
+template <int Q>
+__global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                          long rows, int C, long rows_per_split) {
+    constexpr int RL = 256 / Q;
+    __shared__ f32x4 sh[3][RL][Q];
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const int ch = (blockIdx.x * Q + q) * 4;
+    const long r0 = (long)blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    f32x4 n = {0.f, 0.f, 0.f, 0.f}, s = n, ss = n, shift = n;
+    const bool ok = ch < C;
+    if (ok) {
+        long r = r0 + rl;
+        if (r < r1) shift = *reinterpret_cast<const f32x4*>(x + r * C + ch);
+        for (; r + RL < r1; r += 2 * RL) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + ch) - shift;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(x + (r + RL) * C + ch) - shift;
+            s += a + b;
+            ss += a * a + b * b;
+            n += 2.f;
+        }
+        if (r < r1) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + ch) - shift;
+            s += a;
+            ss += a * a;
+            n += 1.f;
+        }
+    }
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = mean;
+    if (n[0] > 0.f) { mean = shift + s / n; m2 = ss - s * s / n; }
+    sh[0][rl][q] = n; sh[1][rl][q] = mean; sh[2][rl][q] = m2;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float* pp = part + (long)blockIdx.y * 3 * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float nn = n[e], mm = mean[e], m22 = m2[e];
+            for (int l = 1; l < RL; ++l) chan_merge(nn, mm, m22, sh[0][l][q][e], sh[1][l][q][e], sh[2][l][q][e]);
+            pp[ch + e] = nn; pp[C + ch + e] = mm; pp[2 * C + ch + e] = m22 < 0.f ? 0.f : m22;
+        }
+    }
+}
+
+template <int Q>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                               const float* __restrict__ z, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ part,
+                                                               long rows, int C, long rows_per_split) {
+    constexpr int RL = 256 / Q;
+    __shared__ f32x4 sh[2][RL][Q];
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const int ch = (blockIdx.x * Q + q) * 4;
+    const long r0 = (long)blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg;
+    const bool ok = ch < C;
+    if (ok) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), rs = *reinterpret_cast<const f32x4*>(rstd + ch);
+        auto one = [&](long r) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + ch);
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * C + ch);
+            if (ymask) {
+                const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + r * C + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+            }
+            sg += g;
+            sgx += g * ((zz - mu) * rs);
+        };
+        long r = r0 + rl;
+        for (; r + RL < r1; r += 2 * RL) { one(r); one(r + RL); }
+        if (r < r1) one(r);
+    }
+    sh[0][rl][q] = sg; sh[1][rl][q] = sgx;
+    __syncthreads();
+    if (rl == 0 && ok) {
+        float* pp = part + (long)blockIdx.y * 2 * C;
+        f32x4 a = sg, b = sgx;
+        for (int l = 1; l < RL; ++l) { a += sh[0][l][q]; b += sh[1][l][q]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pp[ch + e] = a[e]; pp[C + ch + e] = b[e]; }
+    }
+}
+
 // merge the splits; scale = gamma*rstd, shift = beta - mean*scale; moving statistics (decay, unbiased var)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int splits, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -342,10 +426,14 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
 
 inline int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
+inline int quads_per_block(int C) { return C % 4 ? 0 : (C >= 256 ? 64 : (C >= 128 ? 32 : (C >= 64 ? 16 : 0))); }
+
 inline void stat_split(long rows, int C, int* splits, long* rps) {
-    const long cb = (C + 63) / 64;
+    const int Q = quads_per_block(C);
+    const long cb = Q ? (C / 4 + Q - 1) / Q : (C + 63) / 64;
+    const long lanes = Q ? 256 / Q : 4;
     long rs = 2048 / cb;
-    if (rs > rows / 32) rs = rows / 32;
+    if (rs > rows / (lanes * 8)) rs = rows / (lanes * 8);
     if (rs > BN_MAX_SPLITS) rs = BN_MAX_SPLITS;
     if (rs < 1) rs = 1;
     *rps = (rows + rs - 1) / rs;
@@ -360,7 +448,12 @@ hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* bet
                             float* part, hipStream_t st) {
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps);
+    switch (quads_per_block(C)) {
+        case 64: hipLaunchKernelGGL(bn_stats_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
+        case 32: hipLaunchKernelGGL(bn_stats_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
+        case 16: hipLaunchKernelGGL(bn_stats_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
+        default: hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
                        mean, rstd, scale, shift, mov_mean, mov_var);
     return hipGetLastError();
@@ -385,7 +478,12 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
     float* coef = part + (long)splits * 2 * C;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps);
+    switch (quads_per_block(C)) {
+        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps); break;
+        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps); break;
+        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps); break;
+        default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps);
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
                        dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
