@@ -153,6 +153,28 @@ int fte_dropout_fwd(const float* x, float* mask, float* y, long n, float keep_pr
 int fte_dropout_bwd(const float* dy, const float* mask, float* dx, long n, float keep_prob, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Grouped 3x3 convolution: ONE kernel for the tf.split / 32 x layers.conv2d / tf.concat of
+ * nets/resnext.py:41-51.  x [n,h,wd,c], w [groups][3][3][c/groups][c/groups] (the reference's 32 HWIO
+ * variables `conv2_3x3_group_<i>/weights` stacked), c/groups in {4,8,16,32}, TF-SAME, stride 1 or 2.
+ * ------------------------------------------------------------------------- */
+int fte_gconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups,
+                     int stride, void* stream);
+int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups,
+                       int stride, void* stream);
+int fte_gconv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups,
+                       int stride, void* ws, size_t ws_bytes, void* stream);
+size_t fte_gconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int groups, int stride);
+
+/* Squeeze-excitation gate pieces (nets/shufflenet_v2.py:79-85): activations kind 0 = ReLU, 1 = sigmoid
+ * (bwd takes the OUTPUT y), and the per-(image, channel) scale y = x * gate[n,c] with its gradients
+ * dx = dy*gate, dgate[n,c] = sum_hw dy*x.  The two 1x1 convs on the pooled vector are fte_gemm_*. */
+int fte_act_fwd(const float* x, float* y, long n, int kind, void* stream);
+int fte_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, void* stream);
+int fte_channel_scale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, void* stream);
+int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate,
+                          int n, int hw, int c, void* stream);
+
+/* ---------------------------------------------------------------------------
  * First conv of the net (Cin = 1 or 3, stride 2; nets/sphere.py:57): K = 9*Cin
  * is too short for a GEMM -- HBM-bound direct convolution, fused bias+PReLU.
  * ------------------------------------------------------------------------- */

@@ -130,3 +130,47 @@ def test_first_layer_7x7_as_im2col_gemm():
     call('fte_gemm_tn', cols, dev(dz.reshape(m, cout)), dw, m, cout, kpad, wsb, nb, stream())
     check_maxabs(host(dw)[:ks * ks * cin].reshape(wt.shape), dw_ref, what='stem wgrad')
     assert float(dw[ks * ks * cin:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('n,h,w,c,groups,stride', [(3, 14, 14, 128, 32, 1), (2, 13, 9, 256, 32, 2), (2, 8, 8, 512, 32, 1),
+                                                   (2, 7, 7, 1024, 32, 2), (4, 28, 28, 128, 32, 2)])
+def test_grouped_conv3x3(n, h, w, c, groups, stride):
+    r = _rng(5)
+    gw = c // groups
+    x = r.standard_normal((n, h, w, c)); wt = r.standard_normal((groups, 3, 3, gw, gw)) * 0.2
+    # oracle: the reference's split / conv / concat (nets/resnext.py:43-49)
+    ys = [ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], wt[g], stride) for g in range(groups)]
+    y_ref = np.concatenate(ys, axis=-1)
+    y = torch.empty(y_ref.shape, device='cuda')
+    call('fte_gconv3x3_fwd', dev(x), dev(wt), y, n, h, w, c, groups, stride, stream())
+    check_maxabs(host(y), y_ref, what='gconv fwd')
+    dz = r.standard_normal(y_ref.shape)
+    dx_ref = np.zeros_like(x); dw_ref = np.zeros_like(wt)
+    for g in range(groups):
+        dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], wt[g], dz[..., g * gw:(g + 1) * gw], stride)
+        dx_ref[..., g * gw:(g + 1) * gw] = dxg; dw_ref[g] = dwg
+    dx = torch.empty(x.shape, device='cuda')
+    call('fte_gconv3x3_dgrad', dev(dz), dev(wt), dx, n, h, w, c, groups, stride, stream())
+    check_maxabs(host(dx), dx_ref, what='gconv dgrad')
+    dw = torch.empty(wt.shape, device='cuda')
+    wsb, nb = ws(query('fte_gconv3x3_wgrad_ws_bytes', n, h, w, c, groups, stride))
+    call('fte_gconv3x3_wgrad', dev(x), dev(dz), dw, n, h, w, c, groups, stride, wsb, nb, stream())
+    check_maxabs(host(dw), dw_ref, what='gconv wgrad')
+
+
+def test_se_gate_pieces():
+    r = _rng(6)
+    n, hw, c = 5, 49, 256
+    x = r.standard_normal((n, hw, c)); gate = 1 / (1 + np.exp(-r.standard_normal((n, c))))
+    y = torch.empty(n, hw, c, device='cuda')
+    call('fte_channel_scale_fwd', dev(x), dev(gate), y, n, hw, c, stream())
+    check_maxabs(host(y), x * gate[:, None, :], 1e-6, 'scale fwd')
+    dy = r.standard_normal((n, hw, c)); dx = torch.empty(n, hw, c, device='cuda'); dg = torch.empty(n, c, device='cuda')
+    call('fte_channel_scale_bwd', dev(dy), dev(x), dev(gate), dx, dg, n, hw, c, stream())
+    check_maxabs(host(dx), dy * gate[:, None, :], 1e-6, 'scale dx'); check_maxabs(host(dg), (dy * x).sum(1), 1e-5, 'scale dgate')
+    v = r.standard_normal(1000) * 3
+    for kind, f, df in ((0, lambda a: np.maximum(a, 0), lambda o: (o > 0).astype(float)), (1, lambda a: 1 / (1 + np.exp(-a)), lambda o: o * (1 - o))):
+        o = torch.empty(1000, device='cuda'); call('fte_act_fwd', dev(v), o, 1000, kind, stream())
+        check_maxabs(host(o), f(v), 1e-6, 'act fwd')
+        d = torch.empty(1000, device='cuda'); call('fte_act_bwd', dev(v), o, d, 1000, kind, stream())
+        check_maxabs(host(d), v * df(f(v)), 1e-5, 'act bwd')

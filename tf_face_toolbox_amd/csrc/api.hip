@@ -643,4 +643,50 @@ int fte_im2col_first(const float* x, float* cols, int n, int h, int wd, int cin,
     return rc(l_im2col_first(x, cols, n, h, wd, cin, ksize, stride, ph.out, pw.out, ph.before, pw.before, kpad, (hipStream_t)stream));
 }
 
+// ------------------------------------------------------------------------------------------------
+// grouped 3x3 conv, SE-gate pieces
+int fte_gconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int stride, void* stream) {
+    if (!x || !w || !y || n <= 0 || groups <= 0 || c % groups || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_gconv_fwd(x, w, y, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+}
+int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int stride, void* stream) {
+    if (!dz || !w || !dx || n <= 0 || groups <= 0 || c % groups || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_gconv_dgrad(dz, w, dx, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+}
+size_t fte_gconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int groups, int stride) {
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    const int gw = c / groups;
+    return (size_t)l_gconv_wgrad_chunks((long)n * ph.out * pw.out) * 9 * c * gw * sizeof(float) + SCRATCH_BYTES;
+}
+int fte_gconv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups, int stride,
+                       void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dz || !dw || n <= 0 || groups <= 0 || c % groups || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    const int gw = c / groups;
+    const int chunks = l_gconv_wgrad_chunks((long)n * ph.out * pw.out);
+    const size_t need = (size_t)chunks * 9 * c * gw * sizeof(float);
+    if (!ws || ws_bytes < need) return FTE_EWORKSPACE;
+    hipError_t e = l_gconv_wgrad(x, dz, (float*)ws, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before, chunks, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, chunks, 9L * c * gw, 1, 1.f, nullptr, (hipStream_t)stream));
+}
+int fte_act_fwd(const float* x, float* y, long n, int kind, void* stream) {
+    if (!x || !y || n <= 0 || (kind != 0 && kind != 1)) return FTE_EINVAL;
+    return rc(l_act_fwd(x, y, n, kind, (hipStream_t)stream));
+}
+int fte_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, void* stream) {
+    if (!dy || !y || !dx || n <= 0 || (kind != 0 && kind != 1)) return FTE_EINVAL;
+    return rc(l_act_bwd(dy, y, dx, n, kind, (hipStream_t)stream));
+}
+int fte_channel_scale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, void* stream) {
+    if (!x || !gate || !y || n <= 0 || c % 4) return FTE_EINVAL;
+    return rc(l_chscale_fwd(x, gate, y, n, hw, c, (hipStream_t)stream));
+}
+int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c, void* stream) {
+    if (!dy || !x || !gate || !dx || !dgate || n <= 0) return FTE_EINVAL;
+    return rc(l_chscale_bwd(dy, x, gate, dx, dgate, n, hw, c, (hipStream_t)stream));
+}
+
 }  // extern "C"

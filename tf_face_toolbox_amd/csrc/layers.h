@@ -23,3 +23,14 @@ hipError_t l_dropout_fwd(const float* x, float* mask, float* y, long n, float ke
 hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, float inv_keep, hipStream_t st);
 hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
                           int pt, int pl, int kpad, hipStream_t st);
+hipError_t l_gconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int ho, int wo,
+                       int stride, int pt, int pl, hipStream_t st);
+hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int ho, int wo,
+                         int stride, int pt, int pl, hipStream_t st);
+int l_gconv_wgrad_chunks(long npix);
+hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int c, int groups, int ho, int wo,
+                         int stride, int pt, int pl, int chunks, hipStream_t st);
+hipError_t l_act_fwd(const float* x, float* y, long n, int kind, hipStream_t st);
+hipError_t l_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, hipStream_t st);
+hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st);
+hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c, hipStream_t st);

@@ -521,3 +521,237 @@ hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int 
                        stride, ho, wo, pt, pl, kpad);
     return hipGetLastError();
 }
+
+// ===================================================================================================
+// Grouped 3x3 convolution (nets/resnext.py:41-51: tf.split into 32 groups, 32 convs, tf.concat -- here one
+// kernel, no split / concat traffic).  Group width gw = C/groups is 4..32: N = gw is far too narrow for
+// a 32x32 MFMA tile (12 % utilisation at gw = 4), and the layer carries ~5 % of ResNeXt's MACs, so this is
+// a direct VALU kernel: a block owns one group, its 9*gw*gw weights sit in LDS, a thread produces 4 output
+// channels for PX consecutive pixels (weight reads are reused PX times).
+//   x [N,H,W,C], w [G][3][3][gw_in][gw_out], y [N,Ho,Wo,C]; TF-SAME; stride 1 or 2.
+// ===================================================================================================
+namespace {
+
+template <int GW, bool DGRAD>
+__global__ __launch_bounds__(256) void gconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int n, int h, int wd, int c,
+                                                       int ho, int wo, int stride, int pt, int pl) {
+    // DGRAD = false: y[n,ho,wo] = sum_taps x[n, oh*s + r - pt, ow*s + q - pl] * W[r][q][ic][oc]
+    // DGRAD = true : x is dz [n,ho,wo,C], y is dx [n,h,wd,C]: dx[ih,iw][ic] = sum dz[(ih+pt-r)/s,(iw+pl-q)/s][oc] * W[r][q][ic][oc]
+    constexpr int PX = 4, OC4 = GW / 4;
+    __shared__ __attribute__((aligned(16))) float ws[9 * GW * GW];
+    const int g = blockIdx.y;
+    const float* wg = w + (long)g * 9 * GW * GW;
+    for (int i = threadIdx.x; i < 9 * GW * GW; i += 256) {
+        if (!DGRAD) ws[i] = wg[i];
+        else {                     // store transposed: ws[tap][oc][ic] so that the inner loop reads a float4 over ic
+            const int oc = i % GW, ic = (i / GW) % GW, tap = i / (GW * GW);
+            ws[(tap * GW + oc) * GW + ic] = wg[i];
+        }
+    }
+    __syncthreads();
+    const int oq = threadIdx.x % OC4;                       // output channel quad inside the group
+    const int oh_ = DGRAD ? h : ho, ow_ = DGRAD ? wd : wo;   // grid the threads walk
+    const int owp = (ow_ + PX - 1) / PX;
+    const long nunits = (long)n * oh_ * owp;
+    for (long u = (long)blockIdx.x * (256 / OC4) + threadIdx.x / OC4; u < nunits; u += (long)gridDim.x * (256 / OC4)) {
+        const int wq = (int)(u % owp);
+        long t = u / owp;
+        const int oy = (int)(t % oh_);
+        const int img = (int)(t / oh_);
+        f32x4 acc[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int sy;
+                bool rowok;
+                if (!DGRAD) { sy = oy * stride + r - pt; rowok = sy >= 0 && sy < h; }
+                else { const int num = oy + pt - r; sy = num / stride; rowok = num >= 0 && num % stride == 0 && sy < ho; }
+                if (!rowok) continue;
+                const float* wt = ws + (r * 3 + q) * GW * GW;
+                for (int ic = 0; ic < GW; ic += 4) {
+                    f32x4 xv[PX];
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) {
+                        const int ox = wq * PX + p;
+                        int sx;
+                        bool ok;
+                        if (!DGRAD) { sx = ox * stride + q - pl; ok = sx >= 0 && sx < wd && ox < ow_; }
+                        else { const int num = ox + pl - q; sx = num / stride; ok = num >= 0 && num % stride == 0 && sx < wo && ox < ow_; }
+                        xv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (ok) {
+                            const long src = DGRAD ? ((long)(img * ho + sy) * wo + sx) : ((long)(img * h + sy) * wd + sx);
+                            xv[p] = *reinterpret_cast<const f32x4*>(x + src * c + g * GW + ic);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f32x4 wv;
+                        if (!DGRAD) wv = *reinterpret_cast<const f32x4*>(wt + (ic + e) * GW + oq * 4);     // W[ic+e][oc quad]
+                        else {                                                                             // W^T: out quad = ic quad
+                            wv = f32x4{wt[(ic + e) * GW + oq * 4], wt[(ic + e) * GW + oq * 4 + 1],
+                                       wt[(ic + e) * GW + oq * 4 + 2], wt[(ic + e) * GW + oq * 4 + 3]};
+                        }
+#pragma unroll
+                        for (int p = 0; p < PX; ++p) acc[p] += xv[p][e] * wv;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int ox = wq * PX + p;
+            if (ox < ow_) *reinterpret_cast<f32x4*>(y + ((long)(img * oh_ + oy) * ow_ + ox) * c + g * GW + oq * 4) = acc[p];
+        }
+    }
+}
+
+// filter gradient: block = (pixel chunk, group); thread = (ic, oc quad) pairs; partial [chunk][G*9*gw*gw]
+template <int GW>
+__global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                             float* __restrict__ part, int n, int h, int wd, int c,
+                                                             int ho, int wo, int stride, int pt, int pl, long pix_per_block, int groups) {
+    constexpr int OC4 = GW / 4, TPG = GW * OC4;              // threads per group
+    constexpr int GPB = 256 / TPG > 0 ? 256 / TPG : 1;       // groups per block
+    const int gl = threadIdx.x / TPG, rem = threadIdx.x % TPG;
+    const int g = blockIdx.y * GPB + gl;
+    const int ic = rem / OC4, oq = rem % OC4;
+    const long npix = (long)n * ho * wo;
+    const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g < groups && threadIdx.x < GPB * TPG) {
+        for (long p = p0; p < p1; ++p) {
+            const int ow = (int)(p % wo);
+            const long t2 = p / wo;
+            const int oh = (int)(t2 % ho), img = (int)(t2 / ho);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dz + p * c + g * GW + oq * 4);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int ih = oh * stride + r - pt;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int iw = ow * stride + q - pl;
+                    if (ih >= 0 && ih < h && iw >= 0 && iw < wd)
+                        acc[r * 3 + q] += x[((long)(img * h + ih) * wd + iw) * c + g * GW + ic] * d;
+                }
+            }
+        }
+        float* out = part + ((long)blockIdx.x * groups + g) * 9 * GW * GW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(out + (t * GW + ic) * GW + oq * 4) = acc[t];
+    }
+}
+
+// ---- activations (SE gate: ReLU on the squeeze FC, sigmoid on the excitation FC) ------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int kind) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        y[i] = kind == 0 ? fmaxf(v, 0.f) : 1.f / (1.f + expf(-v));
+    }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                      long n, int kind) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float o = y[i];
+        dx[i] = kind == 0 ? (o > 0.f ? dy[i] : 0.f) : dy[i] * o * (1.f - o);
+    }
+}
+// y[n,hw,c] = x * gate[n,c]
+__global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                          float* __restrict__ y, long n4, int hw, int c) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int ch = (int)(e % c);
+        const long img = e / ((long)hw * c);
+        y4[i] = x4[i] * *reinterpret_cast<const f32x4*>(gate + img * c + ch);
+    }
+}
+// dx = dy * gate ; dgate[n,c] = sum_hw dy * x   (block = one image x 64 channels x 4 row lanes)
+__global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ gate, float* __restrict__ dx,
+                                                          float* __restrict__ dgate, int hw, int c) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl, img = blockIdx.y;
+    float s = 0.f;
+    if (ch < c) {
+        const float gt = gate[(long)img * c + ch];
+        for (int r = rl; r < hw; r += 4) {
+            const long o = ((long)img * hw + r) * c + ch;
+            const float d = dy[o];
+            s += d * x[o];
+            dx[o] = d * gt;
+        }
+    }
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && ch < c) dgate[(long)img * c + ch] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+
+template <bool DGRAD>
+hipError_t gconv_launch(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int ho, int wo,
+                        int stride, int pt, int pl, hipStream_t st) {
+    const int gw = c / groups;
+    const int oh_ = DGRAD ? h : ho, ow_ = DGRAD ? wd : wo;
+    const long units = (long)n * oh_ * ((ow_ + 3) / 4);
+    auto blocks = [&](int oc4) { long b = (units + 256 / oc4 - 1) / (256 / oc4); return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+    switch (gw) {
+        case 4:  hipLaunchKernelGGL((gconv3x3_kernel<4, DGRAD>), dim3(blocks(1), groups), dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, stride, pt, pl); break;
+        case 8:  hipLaunchKernelGGL((gconv3x3_kernel<8, DGRAD>), dim3(blocks(2), groups), dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, stride, pt, pl); break;
+        case 16: hipLaunchKernelGGL((gconv3x3_kernel<16, DGRAD>), dim3(blocks(4), groups), dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, stride, pt, pl); break;
+        case 32: hipLaunchKernelGGL((gconv3x3_kernel<32, DGRAD>), dim3(blocks(8), groups), dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, stride, pt, pl); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t l_gconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int ho, int wo,
+                       int stride, int pt, int pl, hipStream_t st) {
+    return gconv_launch<false>(x, w, y, n, h, wd, c, groups, ho, wo, stride, pt, pl, st);
+}
+hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int ho, int wo,
+                         int stride, int pt, int pl, hipStream_t st) {
+    return gconv_launch<true>(dz, w, dx, n, h, wd, c, groups, ho, wo, stride, pt, pl, st);
+}
+int l_gconv_wgrad_chunks(long npix) { long b = (npix + 255) / 256; return (int)(b > 256 ? 256 : (b < 1 ? 1 : b)); }
+hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int c, int groups, int ho, int wo,
+                         int stride, int pt, int pl, int chunks, hipStream_t st) {
+    const int gw = c / groups;
+    const long npix = (long)n * ho * wo, ppb = (npix + chunks - 1) / chunks;
+    const int tpg = gw * (gw / 4), gpb = 256 / tpg > 0 ? 256 / tpg : 1;
+    const dim3 grid(chunks, (groups + gpb - 1) / gpb);
+    switch (gw) {
+        case 4:  hipLaunchKernelGGL(gconv3x3_wgrad_kernel<4>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        case 8:  hipLaunchKernelGGL(gconv3x3_wgrad_kernel<8>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        case 16: hipLaunchKernelGGL(gconv3x3_wgrad_kernel<16>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        case 32: hipLaunchKernelGGL(gconv3x3_wgrad_kernel<32>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t l_act_fwd(const float* x, float* y, long n, int kind, hipStream_t st) {
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, x, y, n, kind);
+    return hipGetLastError();
+}
+hipError_t l_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, hipStream_t st) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, dy, y, dx, n, kind);
+    return hipGetLastError();
+}
+hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st) {
+    const long n4 = (long)n * hw * c / 4;
+    hipLaunchKernelGGL(chscale_fwd_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)), dim3(256), 0, st, x, gate, y, n4, hw, c);
+    return hipGetLastError();
+}
+hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c, hipStream_t st) {
+    hipLaunchKernelGGL(chscale_bwd_kernel, dim3((c + 63) / 64, n), dim3(256), 0, st, dy, x, gate, dx, dgate, hw, c);
+    return hipGetLastError();
+}
