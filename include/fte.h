@@ -168,6 +168,8 @@ size_t fte_gconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int groups, int 
 /* Squeeze-excitation gate pieces (nets/shufflenet_v2.py:79-85): activations kind 0 = ReLU, 1 = sigmoid
  * (bwd takes the OUTPUT y), and the per-(image, channel) scale y = x * gate[n,c] with its gradients
  * dx = dy*gate, dgate[n,c] = sum_hw dy*x.  The two 1x1 convs on the pooled vector are fte_gemm_*. */
+/* dx[n,hw,c] += v[n,c]*scale: the squeeze (spatial mean) gradient broadcast back over the map */
+int fte_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, void* stream);
 int fte_act_fwd(const float* x, float* y, long n, int kind, void* stream);
 int fte_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, void* stream);
 int fte_channel_scale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, void* stream);

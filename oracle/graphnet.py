@@ -47,6 +47,20 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
                 env[out] = env[op[2]]
         elif kind == 'fc':          # ('fc', out, inp, wname, bname-or-None)
             env[out] = ops.fc_fwd(env[op[2]], params[op[3]], params[op[4]] if op[4] else None)
+        elif kind == 'gconv':       # ('gconv', out, inp, wname, stride, groups): nets/resnext.py:41-51 split / conv / concat
+            _, _, inp, wname, stride, groups = op
+            x = env[inp]
+            gw = x.shape[-1] // groups
+            env[out] = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], params[wname][g], stride)
+                                       for g in range(groups)], axis=-1)
+        elif kind == 'se':          # ('se', out, inp, prefix): nets/shufflenet_v2.py:79-85
+            _, _, inp, pre = op
+            x = env[inp]
+            sq = x.mean(axis=(1, 2))
+            hid = np.maximum(sq @ params[pre + '/fc1/weights'] + params[pre + '/fc1/biases'], 0)
+            gate = 1.0 / (1.0 + np.exp(-(hid @ params[pre + '/fc2/weights'] + params[pre + '/fc2/biases'])))
+            env[out] = x * gate[:, None, None, :]
+            cache[out] = dict(sq=sq, hid=hid, gate=gate)
         else:
             raise ValueError(kind)
     return env, cache, new_state
@@ -120,6 +134,32 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None):
             acc(gt, op[2], ops.gap_bwd(dy, env[op[2]].shape))
         elif kind == 'dropout':
             acc(gt, op[2], dy * masks[out] / op[3])
+        elif kind == 'gconv':
+            _, _, inp, wname, stride, groups = op
+            x = env[inp]
+            gw = x.shape[-1] // groups
+            dx = np.zeros_like(x)
+            dw = np.zeros_like(params[wname])
+            for g in range(groups):
+                dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw], stride)
+                dx[..., g * gw:(g + 1) * gw] = dxg
+                dw[g] = dwg
+            acc(gp, wname, dw)
+            acc(gt, inp, dx)
+        elif kind == 'se':
+            _, _, inp, pre = op
+            x = env[inp]
+            c = cache[out]
+            hw = x.shape[1] * x.shape[2]
+            dgate = (dy * x).sum(axis=(1, 2))
+            dpre2 = dgate * c['gate'] * (1 - c['gate'])
+            acc(gp, pre + '/fc2/weights', c['hid'].T @ dpre2)
+            acc(gp, pre + '/fc2/biases', dpre2.sum(0))
+            dpre1 = (dpre2 @ params[pre + '/fc2/weights'].T) * (c['hid'] > 0)
+            acc(gp, pre + '/fc1/weights', c['sq'].T @ dpre1)
+            acc(gp, pre + '/fc1/biases', dpre1.sum(0))
+            dsq = dpre1 @ params[pre + '/fc1/weights'].T
+            acc(gt, inp, dy * c['gate'][:, None, None, :] + dsq[:, None, None, :] / hw)
         elif kind == 'fc':
             dx, dw, db = ops.fc_bwd(env[op[2]], params[op[3]], dy, op[4] is not None)
             acc(gp, op[3], dw)
@@ -136,37 +176,62 @@ RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3], 26: [
 RESNET_OUTPUTS = [256, 512, 1024, 2048]                                                          # nets/resnet.py:43
 
 
-def resnet_graph(num_layers=50, in_ch=3):
-    """Returns (graph, weight specs [(name, shape, kind)], feature tensor name)."""
-    name = 'ResNet-%d' % num_layers
+def resnet_graph(num_layers=50, in_ch=3, variant='resnet', cardinality=32):
+    """Returns (graph, weight specs [(name, shape, kind)], feature tensor name, net name).
+    variant 'resnet'  : nets/resnet.py as written (mid = C/4, dense 3x3)
+            'resnext' : the INTENDED nets/resnext.py (mid = C/2, 3x3 grouped x`cardinality`, conv-BN-ReLU like its
+                        base class; the snapshot's override drops BN/ReLU and cannot run -- SURVEY Appendix C)
+            'senet'   : 'resnet' + the SE gate of nets/shufflenet_v2.py:79-85 on the block output before the residual
+                        add (SE-ResNet-50; the build's composition, SURVEY 8 "SENet-50")."""
+    name = {'resnet': 'ResNet', 'resnext': 'ResNeXt', 'senet': 'SENet'}[variant] + '-%d' % num_layers
     g, spec = [], []
 
-    def conv_bn(scope, out, inp, cin, cout, k, stride, relu):
-        spec.append((scope + '/weights', (k, k, cin, cout), 'conv_w'))
+    def bn_relu(scope, out, cout, relu):
         spec.append((scope + '/BatchNorm/gamma', (cout,), 'gamma'))
         spec.append((scope + '/BatchNorm/beta', (cout,), 'beta'))
-        g.append(('conv', out + '/z', inp, scope + '/weights', stride))
         g.append(('bn', out + '/bn', out + '/z', scope + '/BatchNorm'))
         if relu:
             g.append(('relu', out, out + '/bn'))
             return out
         return out + '/bn'
 
+    def conv_bn(scope, out, inp, cin, cout, k, stride, relu):
+        spec.append((scope + '/weights', (k, k, cin, cout), 'conv_w'))
+        g.append(('conv', out + '/z', inp, scope + '/weights', stride))
+        return bn_relu(scope, out, cout, relu)
+
+    def gconv_bn(scope, out, inp, c, stride, relu):
+        gw = c // cardinality
+        spec.append((scope + '/weights', (cardinality, 3, 3, gw, gw), 'gconv_w'))
+        g.append(('gconv', out + '/z', inp, scope + '/weights', stride, cardinality))
+        return bn_relu(scope, out, c, relu)
+
     x = conv_bn(name + '/conv1/conv_7x7', 'conv1', 'images', in_ch, 64, 7, 2, True)               # nets/resnet.py:109-113
     g.append(('maxpool', 'pool1', x))                                                            # :115
     x, cin = 'pool1', 64
+    sc_scope = 'conv_1x1_shortcut' if variant == 'resnext' else 'conv_shortcut_1x1'               # resnext.py:57 / resnet.py:77
     for si, nb in enumerate(RESNET_BLOCKS[num_layers]):
         cout = RESNET_OUTPUTS[si]
+        mid = cout // 2 if variant == 'resnext' else cout // 4                                    # resnext.py:60 / resnet.py:82
         for b in range(nb):
             stride = 2 if (b == 0 and si > 0) else 1                                             # :126-139
             sc = '%s/conv%d/resBlock_%d' % (name, si + 2, b)
             t = 's%db%d' % (si + 2, b)
             shortcut = x
             if stride != 1 or cin != cout:                                                       # :72-78
-                shortcut = conv_bn(sc + '/conv_shortcut_1x1', t + '/sc', x, cin, cout, 1, stride, False)
-            y = conv_bn(sc + '/conv1_1x1', t + '/c1', x, cin, cout // 4, 1, 1, True)             # :82
-            y = conv_bn(sc + '/conv2_3x3', t + '/c2', y, cout // 4, cout // 4, 3, stride, True)  # :83
-            y = conv_bn(sc + '/conv3_1x1', t + '/c3', y, cout // 4, cout, 1, 1, False)           # :84-87
+                shortcut = conv_bn(sc + '/' + sc_scope, t + '/sc', x, cin, cout, 1, stride, False)
+            y = conv_bn(sc + '/conv1_1x1', t + '/c1', x, cin, mid, 1, 1, True)                   # :82
+            if variant == 'resnext':
+                y = gconv_bn(sc + '/conv2_3x3', t + '/c2', y, mid, stride, True)                 # resnext.py:61
+            else:
+                y = conv_bn(sc + '/conv2_3x3', t + '/c2', y, mid, mid, 3, stride, True)          # :83
+            y = conv_bn(sc + '/conv3_1x1', t + '/c3', y, mid, cout, 1, 1, False)                 # :84-87
+            if variant == 'senet':
+                pre = sc + '/se'
+                spec.extend([(pre + '/fc1/weights', (cout, cout // 2), 'fc_w'), (pre + '/fc1/biases', (cout // 2,), 'bias'),
+                             (pre + '/fc2/weights', (cout // 2, cout), 'fc_w'), (pre + '/fc2/biases', (cout,), 'bias')])
+                g.append(('se', t + '/se', y, pre))
+                y = t + '/se'
             g.append(('add', t + '/sum', y, shortcut))                                           # :88
             g.append(('relu', t, t + '/sum'))                                                    # :89-90
             x, cin = t, cout
@@ -174,11 +239,12 @@ def resnet_graph(num_layers=50, in_ch=3):
     return g, spec, 'features', name
 
 
-def resnet_train_graph(num_layers, in_ch, num_classes):
-    g, spec, feat, name = resnet_graph(num_layers, in_ch)
-    g = g + [('dropout', 'features_drop', feat, 0.5),                                            # nets/resnet.py:152
-             ('fc', 'logits', 'features_drop', 'classifier/fc_classifier/weights', None)]        # :153-157
-    spec = spec + [('classifier/fc_classifier/weights', (RESNET_OUTPUTS[3], num_classes), 'cls_w')]
+def resnet_train_graph(num_layers, in_ch, num_classes, variant='resnet', classifier=True):
+    g, spec, feat, name = resnet_graph(num_layers, in_ch, variant)
+    if classifier:
+        g = g + [('dropout', 'features_drop', feat, 0.5),                                        # nets/resnet.py:152
+                 ('fc', 'logits', 'features_drop', 'classifier/fc_classifier/weights', None)]    # :153-157
+        spec = spec + [('classifier/fc_classifier/weights', (RESNET_OUTPUTS[3], num_classes), 'cls_w')]
     return g, spec
 
 
@@ -191,6 +257,15 @@ def init_params(spec, seed, dtype=np.float64):
             k, _, cin, cout = shape
             lim = np.sqrt(6.0 / (k * k * cin + k * k * cout))
             p[name] = rng.uniform(-lim, lim, shape).astype(dtype)
+        elif kind == 'gconv_w':
+            gw = shape[3]
+            lim = np.sqrt(6.0 / (9 * gw + 9 * gw))
+            p[name] = rng.uniform(-lim, lim, shape).astype(dtype)
+        elif kind == 'fc_w':
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            p[name] = rng.uniform(-lim, lim, shape).astype(dtype)
+        elif kind == 'bias':
+            p[name] = np.zeros(shape, dtype)
         elif kind == 'cls_w':
             p[name] = (0.001 * rng.standard_normal(shape)).astype(dtype)
         elif kind == 'gamma':
@@ -207,18 +282,40 @@ def perturb(p, seed, scale=0.1):
     rng = np.random.default_rng(seed)
     q = OrderedDict()
     for k, v in p.items():
-        q[k] = (v + scale * rng.standard_normal(v.shape)).astype(v.dtype) if (k.endswith('/gamma') or k.endswith('/beta')) else v
+        q[k] = (v + scale * rng.standard_normal(v.shape)).astype(v.dtype) if (k.endswith('/gamma') or k.endswith('/beta') or k.endswith('/biases')) else v
     return q
 
 
-def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None, grad_scale=None, state=None, kink=None):
-    """softmax-CE + L2 on conv / fc weights (gamma, beta are not regularised); returns
-    ([ce, reg], grads incl. wd*w, env, new moving stats)."""
+def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None, grad_scale=None, state=None, kink=None,
+                   center=None, triplet_margin='off'):
+    """softmax-CE (+ center loss) or batch-hard triplet, + L2 on conv / fc weights (gamma, beta, biases are not
+    regularised).  center = dict(centers=[C,D], alpha=, weight=): loss.py:29-45 on the pooled features, added to the
+    total loss with `weight` (the reference leaves the wiring to the caller, loss.py:43).  triplet_margin != 'off':
+    the net has no classifier; the loss is the MEAN of loss.py:47-78's per-sample vector.
+    Returns (losses, grads incl. wd*w, env, new moving stats [, new centers])."""
     env, cache, new_state = forward(graph, params, images, train=True, masks=masks, state=state)
-    ce, dlogits = ops.softmax_ce(env['logits'], labels, grad_scale)
-    gp, _ = backward(graph, params, env, cache, {'logits': dlogits}, masks=masks, kink=kink)
+    n = images.shape[0]
+    dout, losses, extra = {}, [], {}
+    if triplet_margin != 'off':
+        per, df = ops.batch_hard_triplet(env['features'], labels, triplet_margin)
+        losses.append(per.mean())
+        dout['features'] = df * (1.0 / n if grad_scale is None else grad_scale)
+    else:
+        ce, dlogits = ops.softmax_ce(env['logits'], labels, grad_scale)
+        losses.append(ce)
+        dout['logits'] = dlogits
+        if center is not None:
+            cl, dfe, newc = ops.center_loss(env['features'], labels, center['centers'], center['alpha'])
+            losses.append(cl)
+            scale = center['weight'] * (1.0 if grad_scale is None else grad_scale * n)
+            dout['features'] = dfe * scale
+            extra['centers'] = newc
+    gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink)
     reg_names = [k for k in params if k.endswith('/weights')]
     reg = ops.l2_reg([params[k] for k in reg_names], weight_decay)
     for k in reg_names:
         gp[k] = gp[k] + weight_decay * params[k]
-    return [ce, reg], gp, env, new_state
+    losses.append(reg)
+    if extra:
+        return losses, gp, env, new_state, extra
+    return losses, gp, env, new_state

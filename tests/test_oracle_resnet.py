@@ -100,3 +100,40 @@ def test_maxpool_matches_torch_with_ties():
     dy = np.random.default_rng(1).standard_normal(y.shape)
     ty.backward(torch.tensor(dy).permute(0, 3, 1, 2))
     np.testing.assert_allclose(ops.maxpool3x3s2_bwd(dy, c), tx.grad.permute(0, 2, 3, 1).numpy(), atol=1e-14)
+
+
+def test_gconv_and_se_ops_match_torch_autograd():
+    """Oracle 'gconv' (split / conv / concat) and 'se' (squeeze-excitation) ops vs torch (groups=, autograd)."""
+    rng = np.random.default_rng(3)
+    n, h, w, c, groups = 2, 7, 6, 64, 8
+    gw = c // groups
+    x = rng.standard_normal((n, h, w, c)); wt = rng.standard_normal((groups, 3, 3, gw, gw)) * 0.3
+    p = {'w': wt, 'se/fc1/weights': rng.standard_normal((c, c // 2)) * 0.2, 'se/fc1/biases': rng.standard_normal(c // 2) * 0.1,
+         'se/fc2/weights': rng.standard_normal((c // 2, c)) * 0.2, 'se/fc2/biases': rng.standard_normal(c) * 0.1}
+    graph = [('gconv', 'a', 'images', 'w', 2, groups), ('se', 'b', 'a', 'se')]
+    env, cache, _ = og.forward(graph, p, x)
+    dy = rng.standard_normal(env['b'].shape)
+    gp, gt = og.backward(graph + [], p, env, cache, {'b': dy})
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+    tx = torch.tensor(x, requires_grad=True)
+    xin = tx.permute(0, 3, 1, 2)
+    xp, _ = _same_pad(xin, 3, 2)
+    w_t = tp['w'].permute(0, 4, 3, 1, 2).reshape(c, gw, 3, 3)          # [G,3,3,in,out] -> [G*out, in, 3, 3]
+    a = F.conv2d(xp, w_t, None, stride=2, groups=groups)
+    sq = a.mean(dim=(2, 3))
+    gate = torch.sigmoid(torch.relu(sq @ tp['se/fc1/weights'] + tp['se/fc1/biases']) @ tp['se/fc2/weights'] + tp['se/fc2/biases'])
+    b = a * gate[:, :, None, None]
+    np.testing.assert_allclose(env['b'], b.detach().permute(0, 2, 3, 1).numpy(), atol=1e-12)
+    b.backward(torch.tensor(dy).permute(0, 3, 1, 2))
+    for k in tp:
+        np.testing.assert_allclose(gp[k], tp[k].grad.numpy(), atol=1e-11, err_msg=k)
+    # 'images' never receives a gradient from a conv in the oracle (need_dx is off for the stem); check through a proxy
+    graph2 = [('relu', 'r', 'images')] + [('gconv', 'a', 'r', 'w', 2, groups), ('se', 'b', 'a', 'se')]
+    env2, cache2, _ = og.forward(graph2, p, np.abs(x) + 0.1)
+    _, gt2 = og.backward(graph2, p, env2, cache2, {'b': dy})
+    tx2 = torch.tensor(np.abs(x) + 0.1, requires_grad=True)
+    xp2, _ = _same_pad(tx2.permute(0, 3, 1, 2), 3, 2)
+    a2 = F.conv2d(xp2, w_t.detach(), None, stride=2, groups=groups)
+    g2 = torch.sigmoid(torch.relu(a2.mean(dim=(2, 3)) @ tp['se/fc1/weights'].detach() + tp['se/fc1/biases'].detach()) @ tp['se/fc2/weights'].detach() + tp['se/fc2/biases'].detach())
+    (a2 * g2[:, :, None, None]).backward(torch.tensor(dy).permute(0, 3, 1, 2))
+    np.testing.assert_allclose(gt2['images'], tx2.grad.numpy(), atol=1e-11)

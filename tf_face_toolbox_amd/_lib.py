@@ -47,6 +47,7 @@ _SIGS = {
     'fte_gconv3x3_dgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
     'fte_gconv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_gconv3x3_wgrad_ws_bytes': (c_size_t, [c_int] * 6),
+    'fte_bcast_add': (c_int, [_P] * 2 + [c_int] * 3 + [c_float, _P]),
     'fte_act_fwd': (c_int, [_P] * 2 + [c_long, c_int, _P]),
     'fte_act_bwd': (c_int, [_P] * 3 + [c_long, c_int, _P]),
     'fte_channel_scale_fwd': (c_int, [_P] * 3 + [c_int] * 3 + [_P]),

@@ -672,6 +672,10 @@ int fte_gconv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h,
     if (e != hipSuccess) return (int)e;
     return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, chunks, 9L * c * gw, 1, 1.f, nullptr, (hipStream_t)stream));
 }
+int fte_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, void* stream) {
+    if (!dx || !v || n <= 0 || c % 4) return FTE_EINVAL;
+    return rc(l_bcast_add(dx, v, n, hw, c, scale, (hipStream_t)stream));
+}
 int fte_act_fwd(const float* x, float* y, long n, int kind, void* stream) {
     if (!x || !y || n <= 0 || (kind != 0 && kind != 1)) return FTE_EINVAL;
     return rc(l_act_fwd(x, y, n, kind, (hipStream_t)stream));

@@ -755,3 +755,21 @@ hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, flo
     hipLaunchKernelGGL(chscale_bwd_kernel, dim3((c + 63) / 64, n), dim3(256), 0, st, dy, x, gate, dx, dgate, hw, c);
     return hipGetLastError();
 }
+
+// dx[n,hw,c] += v[n,c] * scale   (gradient of the SE squeeze: d(mean over hw) broadcast back)
+namespace {
+__global__ __launch_bounds__(256) void bcast_add_kernel(float* __restrict__ dx, const float* __restrict__ v, long n4, int hw, int c, float scale) {
+    f32x4* d4 = reinterpret_cast<f32x4*>(dx);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int ch = (int)(e % c);
+        const long img = e / ((long)hw * c);
+        d4[i] += *reinterpret_cast<const f32x4*>(v + img * c + ch) * scale;
+    }
+}
+}  // namespace
+hipError_t l_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, hipStream_t st) {
+    const long n4 = (long)n * hw * c / 4;
+    hipLaunchKernelGGL(bcast_add_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)), dim3(256), 0, st, dx, v, n4, hw, c, scale);
+    return hipGetLastError();
+}

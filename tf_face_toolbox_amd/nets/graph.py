@@ -27,7 +27,10 @@ def _stream():
 class GraphNet(Network):
     """Network whose body is an op list: ('conv', out, inp, wname, stride) | ('bn', out, inp, prefix) |
     ('relu', out, inp) | ('add', out, a, b) | ('maxpool', out, inp) | ('gap', out, inp) |
-    ('dropout', out, inp, keep) | ('fc', out, inp, wname, None)."""
+    ('dropout', out, inp, keep) | ('fc', out, inp, wname, None) | ('gconv', out, inp, wname, stride, groups) |
+    ('se', out, inp, prefix).  Heads: 'softmax' (CE on the classifier), 'softmax+center' (CE + weight * center loss
+    on the pooled features, loss.py:29-45) and 'triplet' (batch-hard triplet on the pooled features, loss.py:47-78, no
+    classifier)."""
 
     head = 'softmax'
 
@@ -40,6 +43,9 @@ class GraphNet(Network):
         self.update_moving_stats = True      # data_parallel.py:242-243: UPDATE_OPS of tower 0 only
         self.dropout_seed = 0
         self._act_n = None
+        self.center_weight = 0.0          # 'softmax+center': total loss = CE + center_weight * center_loss
+        self.center_alpha = 0.99          # loss.py:29 default
+        self.triplet_margin = None        # 'triplet': None = soft-margin (softplus), loss.py:47
 
     # ---- to be provided by the subclass ----------------------------------------------------------
     def build_graph(self, in_ch, num_classes):
@@ -57,8 +63,8 @@ class GraphNet(Network):
         self.graph, spec = self.build_graph(channels, num_classes)
         self.spec = OrderedDict((n, (s, k)) for n, s, k in spec)
         self._infer_shapes()
-        small = [(n, s, k) for n, s, k in spec if k in ('gamma', 'beta')]
-        convs = [(n, s, k) for n, s, k in spec if k == 'conv_w']
+        small = [(n, s, k) for n, s, k in spec if k in ('gamma', 'beta', 'bias')]
+        convs = [(n, s, k) for n, s, k in spec if k in ('conv_w', 'gconv_w', 'fc_w')]
         cls = [(n, s, k) for n, s, k in spec if k == 'cls_w']
         self.variables = OrderedDict()
         off = 0
@@ -67,7 +73,7 @@ class GraphNet(Network):
             self.variables[n] = Variable(n, k, s, off, size)
             off += (size + 3) // 4 * 4
         self.small_end = self.variables[convs[0][0]].offset
-        self.cls_start = self.variables[cls[0][0]].offset
+        self.cls_start = self.variables[cls[0][0]].offset if cls else off
         self.arena_size = off
         dev = self.device
         self.params = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -108,6 +114,13 @@ class GraphNet(Network):
             if v.kind == 'conv_w':
                 k, _, cin, cout = v.ref_shape
                 lim = (6.0 / (k * k * cin + k * k * cout)) ** 0.5
+                self.set_variable(n, (torch.rand(v.ref_shape, generator=g) * 2 - 1) * lim)
+            elif v.kind == 'gconv_w':
+                gw = v.ref_shape[3]
+                lim = (6.0 / (18 * gw)) ** 0.5
+                self.set_variable(n, (torch.rand(v.ref_shape, generator=g) * 2 - 1) * lim)
+            elif v.kind == 'fc_w':
+                lim = (6.0 / (v.ref_shape[0] + v.ref_shape[1])) ** 0.5
                 self.set_variable(n, (torch.rand(v.ref_shape, generator=g) * 2 - 1) * lim)
             elif v.kind == 'cls_w':
                 self.set_variable(n, torch.randn(v.ref_shape, generator=g) * 0.001)
@@ -158,7 +171,10 @@ class GraphNet(Network):
                 ih, iw, _ = shp[op[2]]
                 k, _, _, cout = self.spec[op[3]][0]
                 shp[out] = (same_pads(ih, k, op[4])[0], same_pads(iw, k, op[4])[0], cout)
-            elif kind in ('bn', 'relu', 'dropout'):
+            elif kind == 'gconv':
+                ih, iw, cc = shp[op[2]]
+                shp[out] = (same_pads(ih, 3, op[4])[0], same_pads(iw, 3, op[4])[0], cc)
+            elif kind in ('bn', 'relu', 'dropout', 'se'):
                 shp[out] = shp[op[2]]
             elif kind == 'add':
                 shp[out] = shp[op[2]]
@@ -196,9 +212,15 @@ class GraphNet(Network):
                         res, relu, final = other, 1, g[u2[0]][1]
                         skip.update([u[0], u2[0]])
                 plan.append(('bn', final, op[2], op[3], res, relu))
+            elif op[0] == 'add':
+                u = users.get(op[1], [])
+                assert len(u) == 1 and g[u[0]][0] == 'relu', 'a bare add is always followed by a ReLU in these nets'
+                skip.add(u[0])
+                plan.append(('addrelu', g[u[0]][1], op[2], op[3]))
             else:
                 plan.append(op)
         self.plan = plan
+        self.has_classifier = plan[-1][0] == 'fc'
 
     @staticmethod
     def _inputs(op):
@@ -222,6 +244,7 @@ class GraphNet(Network):
         f32 = dict(dtype=torch.float32, device=dev)
         self.t = {}
         self.bn = {}
+        self.ident = {}
         need = 1 << 20
         q = _lib.query
         for op in self.plan:
@@ -244,6 +267,19 @@ class GraphNet(Network):
                     oh, ow, _ = self.shapes[out]
                     self.cols = torch.empty(n * oh * ow, STEM_KPAD, **f32)
                     need = max(need, q('fte_gemm_ws_bytes', n * oh * ow, cout, STEM_KPAD))
+            elif kind == 'gconv':
+                ih, iw, cc = self.shapes[op[2]]
+                need = max(need, q('fte_gconv3x3_wgrad_ws_bytes', n, ih, iw, cc, op[5], op[4]))
+            elif kind == 'se':
+                cc = shape[-1]
+                self.t[out + '/sq'] = torch.empty(n, cc, **f32)
+                self.t[out + '/hid'] = torch.empty(n, cc // 2, **f32)
+                self.t[out + '/gate'] = torch.empty(n, cc, **f32)
+                need = max(need, q('fte_gemm_ws_bytes', n, cc, cc // 2), q('fte_gemm_ws_bytes', n, cc // 2, cc))
+            elif kind == 'addrelu':
+                cc = shape[-1]
+                if cc not in self.ident:
+                    self.ident[cc] = (torch.ones(cc, **f32), torch.zeros(cc, **f32))
             elif kind == 'maxpool':
                 self.t[out + '/idx'] = torch.empty(shape, dtype=torch.uint8, device=dev)
             elif kind == 'dropout':
@@ -252,6 +288,10 @@ class GraphNet(Network):
                 need = max(need, q('fte_gemm_ws_bytes', n, self.cpad, self.shapes[op[2]][0]))
         self.G = torch.empty(n, self.cpad, **f32)
         self.loss_rows = torch.empty(n, **f32)
+        fdim = self.shapes[self.feature_name][0]
+        self.dfeat = torch.empty(n, fdim, **f32)
+        self.ones_n = torch.ones(n, **f32)
+        need = max(need, 4 * n * fdim, 12 * n * n)
         self.ws = torch.empty((need + 3) // 4 + 1024, **f32)
         self.ws_bytes = self.ws.numel() * 4
         self._act_n = n
@@ -301,6 +341,24 @@ class GraphNet(Network):
                     call('fte_bn_infer_fwd', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
                          self.state[pre + '/moving_mean'], self.state[pre + '/moving_variance'], resbuf, T[out],
                          b['scale'], b['shift'], rows, c, BN_EPS, relu, st)
+            elif kind == 'gconv':
+                ih, iw, c = self.shapes[op[2]]
+                call('fte_gconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[5], op[4], st)
+            elif kind == 'se':
+                _, _, inp, pre = op
+                ih, iw, c = self.shapes[inp]
+                sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
+                call('fte_gap_fwd', T[inp], sq, n, ih * iw, c, st)
+                call('fte_gemm_nn', sq, self.view(pre + '/fc1/weights'), self.view(pre + '/fc1/biases'), hid, n, c // 2, c, self.ws, self.ws_bytes, st)
+                call('fte_act_fwd', hid, hid, hid.numel(), 0, st)
+                call('fte_gemm_nn', hid, self.view(pre + '/fc2/weights'), self.view(pre + '/fc2/biases'), gate, n, c, c // 2, self.ws, self.ws_bytes, st)
+                call('fte_act_fwd', gate, gate, gate.numel(), 1, st)
+                call('fte_channel_scale_fwd', T[inp], gate, T[out], n, ih * iw, c, st)
+            elif kind == 'addrelu':
+                c = self.shapes[out][-1]
+                one, zero = self.ident[c]
+                call('fte_bn_infer_fwd', T[op[2]], one, zero, zero, one, T[op[3]], T[out], self._scr(c, 0), self._scr(c, 1),
+                     T[out].numel() // c, c, 0.0, 1, st)
             elif kind == 'maxpool':
                 ih, iw, c = self.shapes[op[2]]
                 call('fte_maxpool3x3s2_fwd', T[op[2]], T[out], T[out + '/idx'], n, ih, iw, c, st)
@@ -319,6 +377,12 @@ class GraphNet(Network):
             else:
                 raise RuntimeError('op %s must have been fused away' % kind)
 
+    def _scr(self, c, i):
+        key = ('scr', c, i)
+        if key not in self.ident:
+            self.ident[key] = torch.empty(c, dtype=torch.float32, device=self.device)
+        return self.ident[key]
+
     def _ensure_built(self, images, num_classes):
         if not self.built:
             n, h, w, ch = images.shape
@@ -334,37 +398,71 @@ class GraphNet(Network):
         assert num_classes is not None, 'num_classes must be given when is_training=True'   # nets/resnet.py:147
         self._ensure_built(images, num_classes)
         self._run_forward(images, is_training)
-        return {'logits': self.t['logits'][:, :self.num_classes]}
+        out = {'features': self.t[self.feature_name]}
+        if self.has_classifier:
+            out['logits'] = self.t['logits'][:, :self.num_classes]
+        return out
 
     # ---- loss -------------------------------------------------------------------------------------------
+    def _centers(self):
+        if 'centers' not in self.state:          # loss.py:34-35: zeros, non-trainable
+            d = self.shapes[self.feature_name][0]
+            self.state['centers'] = torch.zeros(self.num_classes, d, dtype=torch.float32, device=self.device)
+        return self.state['centers']
+
     def loss_function(self, scope, labels, **logits):
-        """nets/resnet.py:163-176 + Network._regularize."""
+        """nets/resnet.py:163-176 + Network._regularize; the center / triplet terms are loss.py's functions wired to
+        the pooled features (the reference leaves that wiring to the caller)."""
         if not (isinstance(labels, torch.Tensor) and labels.is_cuda and labels.dtype == torch.int32):
             raise TypeError('labels must be an int32 CUDA tensor (data.py:259)')
+        labels = labels.contiguous()
         n = labels.shape[0]
         st = _stream()
-        _lib.call('fte_softmax_ce_fwd_bwd', self.t['logits'], labels.contiguous(), self.loss_rows, self.G, n,
-                  self.num_classes, self.cpad, self.tower_scale / n, st)
-        _lib.call('fte_sum', self.loss_rows, n, self.tower_scale / n, self.loss_slots[0:1], self.ws, self.ws_bytes, st)
+        call = _lib.call
+        slots = self.loss_slots
+        feat = self.t[self.feature_name]
+        d = feat.shape[1]
+        losses, names = [], []
+        self._dfeat = None
+        if self.head == 'triplet':
+            margin = -1.0 if self.triplet_margin is None else float(self.triplet_margin)
+            call('fte_batch_hard_triplet_fwd_bwd', feat, labels, margin, self.tower_scale / n, self.loss_rows, self.dfeat,
+                 n, d, self.ws, self.ws_bytes, st)
+            call('fte_sum', self.loss_rows, n, self.tower_scale / n, slots[0:1], self.ws, self.ws_bytes, st)
+            self._dfeat = self.dfeat
+            losses.append(slots[0]); names.append('triplet_loss')
+        else:
+            call('fte_softmax_ce_fwd_bwd', self.t['logits'], labels, self.loss_rows, self.G, n,
+                 self.num_classes, self.cpad, self.tower_scale / n, st)
+            call('fte_sum', self.loss_rows, n, self.tower_scale / n, slots[0:1], self.ws, self.ws_bytes, st)
+            losses.append(slots[0]); names.append('cross_entropy')
+            if self.head == 'softmax+center':
+                call('fte_center_loss_fwd_bwd_update', feat, labels, self._centers(), self.loss_rows, self.dfeat, n, d,
+                     self.center_alpha, self.center_weight * self.tower_scale / (n * d), self.ws, self.ws_bytes, st)
+                call('fte_sum', self.loss_rows, n, self.tower_scale / (n * d), slots[2:3], self.ws, self.ws_bytes, st)
+                self._dfeat = self.dfeat
+                losses.append(slots[2]); names.append('center_loss')
         nreg = self.arena_size - self.small_end
-        _lib.call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
-                  self.loss_slots[1:2], self.ws, self.ws_bytes, st)
-        return [self.loss_slots[0], self.loss_slots[1]], ['cross_entropy', 'reg_loss'], OrderedDict()
+        call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
+             slots[1:2], self.ws, self.ws_bytes, st)
+        losses.append(slots[1]); names.append('reg_loss')
+        return losses, names, OrderedDict()
 
     # ---- backward ---------------------------------------------------------------------------------------
     def backward(self):
-        self.backward_head()
-        self.backward_body()
+        for stage in self.backward_stages():
+            stage()
 
     def backward_stages(self):
-        return [self.backward_head, self.backward_body]
+        if self.has_classifier:
+            return [self.backward_head, self.backward_body]
+        return [self.backward_body]
 
     def backward_head(self):
         """Classifier gradient (first all-reduce bucket) and the gradient wrt its input."""
         n = self._act_n
         st = _stream()
         op = self.plan[-1]
-        assert op[0] == 'fc'
         k = self.shapes[op[2]][0]
         self._grad = {}
         gin = torch.empty(n, k, dtype=torch.float32, device=self.device)
@@ -379,9 +477,19 @@ class GraphNet(Network):
         n = self._act_n
         st = _stream()
         call = _lib.call
-        T, G = self.t, self._grad
-        for op in reversed(self.plan[:-1]):
+        T = self.t
+        if not self.has_classifier:
+            self._grad = {self.feature_name: self._dfeat}
+            self._dfeat = None
+        G = self._grad
+        ops = self.plan[:-1] if self.has_classifier else self.plan
+        for op in reversed(ops):
             kind, out = op[0], op[1]
+            if out == self.feature_name and self._dfeat is not None and out in G:
+                # the pooled features also feed the center loss: add its gradient to the classifier path's
+                d = G[out].shape[1]
+                call('fte_add_scaled_rows_cols', G[out], self._dfeat, self.ones_n, None, n, d, d, st)
+                self._dfeat = None
             if out not in G:
                 continue
             dy = G.pop(out)
@@ -399,6 +507,39 @@ class GraphNet(Network):
                 g = self._new(op[2])
                 call('fte_maxpool3x3s2_bwd', dy, T[out + '/idx'], g, n, ih, iw, c, st)
                 self._put(op[2], g)
+            elif kind == 'addrelu':
+                g = self._new(out)
+                call('fte_relu_bwd', dy, T[out], g, dy.numel(), st)
+                self._put(op[2], g)
+                self._put(op[3], g)                      # both addends see the same (read-only) gradient
+            elif kind == 'se':
+                _, _, inp, pre = op
+                ih, iw, c = self.shapes[inp]
+                hw = ih * iw
+                sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
+                f32 = dict(dtype=torch.float32, device=self.device)
+                dx = self._new(inp)
+                dgate = torch.empty(n, c, **f32)
+                call('fte_channel_scale_bwd', dy, T[inp], gate, dx, dgate, n, hw, c, st)
+                call('fte_act_bwd', dgate, gate, dgate, dgate.numel(), 1, st)                       # -> d(pre-sigmoid)
+                call('fte_gemm_tn', hid, dgate, self.view(pre + '/fc2/weights', self.grads), n, c, c // 2, self.ws, self.ws_bytes, st)
+                call('fte_reduce_rows', dgate, self.view(pre + '/fc2/biases', self.grads), None, 1, n, c, 1, 1.0, st)
+                dhid = torch.empty(n, c // 2, **f32)
+                call('fte_gemm_nt', dgate, self.view(pre + '/fc2/weights'), None, None, 0, None, dhid, None, n, c, c // 2, self.ws, self.ws_bytes, st)
+                call('fte_act_bwd', dhid, hid, dhid, dhid.numel(), 0, st)                            # -> d(pre-ReLU)
+                call('fte_gemm_tn', sq, dhid, self.view(pre + '/fc1/weights', self.grads), n, c // 2, c, self.ws, self.ws_bytes, st)
+                call('fte_reduce_rows', dhid, self.view(pre + '/fc1/biases', self.grads), None, 1, n, c // 2, 1, 1.0, st)
+                dsq = torch.empty(n, c, **f32)
+                call('fte_gemm_nt', dhid, self.view(pre + '/fc1/weights'), None, None, 0, None, dsq, None, n, c // 2, c, self.ws, self.ws_bytes, st)
+                call('fte_bcast_add', dx, dsq, n, hw, c, 1.0 / hw, st)
+                self._put(inp, dx)
+            elif kind == 'gconv':
+                _, _, inp, wname, stride, groups = op
+                ih, iw, c = self.shapes[inp]
+                call('fte_gconv3x3_wgrad', T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, self.ws, self.ws_bytes, st)
+                dx = self._new(inp)
+                call('fte_gconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, groups, stride, st)
+                self._put(inp, dx)
             elif kind == 'bn':
                 _, _, inp, pre, res, relu = op
                 b = self.bn[out]
@@ -451,8 +592,12 @@ class GraphNet(Network):
         return [v for grp in self.param_list(is_training=False, trainable=False, scope=scope) for v in grp if self.name in v.name]
 
     def arena_groups(self):
-        return [(0, self.small_end, False, 0), (self.small_end, self.cls_start, True, 0),
-                (self.cls_start, self.arena_size, True, 1)]
+        groups = [(0, self.small_end, False, 0), (self.small_end, self.cls_start, True, 0)]
+        if self.has_classifier:
+            groups.append((self.cls_start, self.arena_size, True, 1))
+        return groups
 
     def grad_buckets(self):
-        return [(self.cls_start, self.arena_size + 4), (0, self.cls_start)]
+        if self.has_classifier:
+            return [(self.cls_start, self.arena_size + 4), (0, self.cls_start)]
+        return [(0, self.arena_size + 4)]

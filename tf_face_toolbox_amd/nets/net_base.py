@@ -25,10 +25,22 @@ def net_select(name, data_format='NCHW', weight_decay=5e-4):
     elif name == 'ResNet-26':                    # not a reference factory name; the class accepts 26 (nets/resnet.py:39-40)
         from .resnet import ResNet
         network = ResNet(num_layers=26, data_format=data_format, weight_decay=weight_decay)
-    elif name in ('ResNeXt-26', 'ResNeXt-50', 'SENet-50', 'ShuffleNet-v2-small',
-                  'ShuffleNet-v2-middle', 'ShuffleNet-v2-large'):
-        raise NotImplementedError('%s: grouped / depthwise conv and SE kernels are the next rows of the '
-                                  'hot-path scope table (SURVEY.md 8a R2,S1); not built yet.' % name)
+    elif name in ('ResNeXt-26', 'ResNeXt-50'):   # nets/net_base.py:27-31 exposes -26; -50 is BASELINE config 3
+        from .resnet import ResNeXt
+        network = ResNeXt(num_layers=int(name.split('-')[1]), num_card=32, data_format=data_format, weight_decay=weight_decay)
+    elif name == 'ResNeXt-50-center':            # config 3: + center loss on the pooled features (loss.py:29-45)
+        from .resnet import ResNeXt
+        network = ResNeXt(num_layers=50, num_card=32, data_format=data_format, weight_decay=weight_decay,
+                          head='softmax+center', center_weight=0.008)
+    elif name == 'SENet-50':
+        from .resnet import SENet
+        network = SENet(num_layers=50, data_format=data_format, weight_decay=weight_decay)
+    elif name == 'SENet-50-triplet':             # config 4: batch-hard triplet (loss.py:47-78), no classifier
+        from .resnet import SENet
+        network = SENet(num_layers=50, data_format=data_format, weight_decay=weight_decay, head='triplet')
+    elif name in ('ShuffleNet-v2-small', 'ShuffleNet-v2-middle', 'ShuffleNet-v2-large'):
+        raise NotImplementedError('%s: depthwise conv + channel split / shuffle are the next row of the hot-path scope table '
+                                  '(SURVEY.md 8a S1); not built yet.' % name)
     elif name in ('MobileNet-v2', 'Inception-v4', 'VGG16', 'AlexNet'):
         # nets/net_base.py:52-59 `pass` branches: the reference dies with UnboundLocalError here
         raise UnboundLocalError("local variable 'network' referenced before assignment")

@@ -64,7 +64,72 @@ class ResNet(GraphNet):
                                   x, cin, self.num_outputs[si], stride)
                 cin = self.num_outputs[si]
         g.append(('gap', 'features', x))                                                                    # :142
+        if getattr(self, 'head', 'softmax') == 'triplet':      # metric-learning head on the pooled features: no classifier
+            return g, spec
         g.append(('dropout', 'features_drop', 'features', 0.5))                                             # :152
         g.append(('fc', 'logits', 'features_drop', 'classifier/fc_classifier/weights', None))               # :153-157
         spec.append(('classifier/fc_classifier/weights', (self.num_outputs[3], num_classes), 'cls_w'))
         return g, spec
+
+
+class ResNeXt(ResNet):
+    """nets/resnext.py:21-67 as INTENDED: bottleneck with mid = C/2 channels, the 3x3 conv grouped x num_card (one
+    grouped-conv kernel instead of tf.split + 32 convs + tf.concat), conv-BN-ReLU like its base class.  The snapshot's
+    override passes a kwarg its helper does not take and drops BN/ReLU; that cannot run, so the
+    parity target is the build's own oracle.  The 32 per-group variables `conv2_3x3_group_<i>/weights` are one stacked
+    variable `conv2_3x3/weights` of shape [32,3,3,gw,gw]."""
+
+    def __init__(self, num_layers, num_card=32, weight_decay=0.0005, data_format='NCHW', name='ResNeXt', seed=0,
+                 head='softmax', center_weight=0.0):
+        self.num_card = num_card
+        super(ResNeXt, self).__init__(num_layers, weight_decay=weight_decay, data_format=data_format, name=name, seed=seed)
+        self.head = head
+        self.center_weight = center_weight
+
+    def resBlock(self, g, spec, scope, t, x, cin, num_outputs, stride=1):
+        assert num_outputs % 2 == 0, "num_outputs must be divided by 2."                   # nets/resnext.py:53
+        shortcut = x
+        if stride != 1 or cin != num_outputs:
+            shortcut = self.conv_bn_relu(g, spec, scope + '/conv_1x1_shortcut', t + '/sc', x, cin, num_outputs, 1, stride, relu=False)
+        mid = num_outputs // 2
+        y = self.conv_bn_relu(g, spec, scope + '/conv1_1x1', t + '/c1', x, cin, mid, 1, 1)
+        gw = mid // self.num_card
+        sc2 = scope + '/conv2_3x3'
+        spec.append((sc2 + '/weights', (self.num_card, 3, 3, gw, gw), 'gconv_w'))
+        spec.append((sc2 + '/BatchNorm/gamma', (mid,), 'gamma'))
+        spec.append((sc2 + '/BatchNorm/beta', (mid,), 'beta'))
+        g.append(('gconv', t + '/c2/z', y, sc2 + '/weights', stride, self.num_card))
+        g.append(('bn', t + '/c2/bn', t + '/c2/z', sc2 + '/BatchNorm'))
+        g.append(('relu', t + '/c2', t + '/c2/bn'))
+        y = self.conv_bn_relu(g, spec, scope + '/conv3_1x1', t + '/c3', t + '/c2', mid, num_outputs, 1, 1, relu=False)
+        g.append(('add', t + '/sum', y, shortcut))
+        g.append(('relu', t, t + '/sum'))
+        return t
+
+
+class SENet(ResNet):
+    """SE-ResNet ("SENet-50", BASELINE.json config 4): the ResNet bottleneck of nets/resnet.py:63-92 with the
+    squeeze-excitation gate of nets/shufflenet_v2.py:79-85 (GAP -> 1x1 to C/2 + ReLU -> 1x1 to C + sigmoid ->
+    channel scale, both with biases, no BN) applied to the block output before the residual add.  The reference has
+    no such class: the composition and its oracle are the build's."""
+
+    def __init__(self, num_layers, weight_decay=0.0005, data_format='NCHW', name='SENet', seed=0, head='softmax',
+                 triplet_margin=None):
+        super(SENet, self).__init__(num_layers, weight_decay=weight_decay, data_format=data_format, name=name, seed=seed)
+        self.head = head
+        self.triplet_margin = triplet_margin
+
+    def resBlock(self, g, spec, scope, t, x, cin, num_outputs, stride=1):
+        shortcut = x
+        if stride != 1 or cin != num_outputs:
+            shortcut = self.conv_bn_relu(g, spec, scope + '/conv_shortcut_1x1', t + '/sc', x, cin, num_outputs, 1, stride, relu=False)
+        y = self.conv_bn_relu(g, spec, scope + '/conv1_1x1', t + '/c1', x, cin, num_outputs // 4, 1, 1)
+        y = self.conv_bn_relu(g, spec, scope + '/conv2_3x3', t + '/c2', y, num_outputs // 4, num_outputs // 4, 3, stride)
+        y = self.conv_bn_relu(g, spec, scope + '/conv3_1x1', t + '/c3', y, num_outputs // 4, num_outputs, 1, 1, relu=False)
+        pre = scope + '/se'
+        spec.extend([(pre + '/fc1/weights', (num_outputs, num_outputs // 2), 'fc_w'), (pre + '/fc1/biases', (num_outputs // 2,), 'bias'),
+                     (pre + '/fc2/weights', (num_outputs // 2, num_outputs), 'fc_w'), (pre + '/fc2/biases', (num_outputs,), 'bias')])
+        g.append(('se', t + '/se', y, pre))
+        g.append(('add', t + '/sum', t + '/se', shortcut))
+        g.append(('relu', t, t + '/sum'))
+        return t
