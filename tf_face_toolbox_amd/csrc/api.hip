@@ -3,6 +3,7 @@
 // family, tile / split-K selection, ordered reductions.  Never allocates, never
 // synchronises; every launch goes to the caller's stream.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/fte.h"
@@ -40,8 +41,8 @@ inline int pick_tile(long M, long N) {
     return cands[nc - 1];
 }
 
-// 256 CUs x 2 resident blocks of the big tiles (64-80 KiB of LDS each)
-constexpr long SLOTS = 512;
+// 256 CUs x 3 resident blocks of the 128x128 tile (32 KiB of LDS, <= 168 VGPRs each)
+constexpr long SLOTS = 768;
 
 // Row plan of an M x N output with reduction length K.  T big tiles on SLOTS resident blocks run in
 // ceil(T/SLOTS) rounds, so a launch of 1568 tiles pays for 4 rounds while doing 3.06 rounds of work.  The
@@ -57,7 +58,10 @@ struct RowPlan {
 inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
     RowPlan r;
     memset(&r, 0, sizeof(r));
-    const int big = (N % 128 == 0) ? TILE_128x128 : TILE_256x64;
+    static const int narrow_tile = getenv("FTE_NARROW_TILE") ? atoi(getenv("FTE_NARROW_TILE")) : TILE_64x64;   // N = 64: measured on MI355X
+    // 64x64 beats 128x64 beats 256x64 (fwd 83 / 82 / 75 TF, dgrad 80 / 76 / 65): with only 18 K-steps per tile the
+    // layer lives on co-resident blocks hiding each other's prologue / epilogue, not on operand reuse.
+    const int big = (N % 128 == 0) ? TILE_128x128 : narrow_tile;
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
     const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn, ksteps = (K + 31) / 32;

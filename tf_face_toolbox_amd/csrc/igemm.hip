@@ -31,6 +31,13 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDS staging: 1 = ONE stage (32 KiB for the 128x128 tile) with a second barrier in the middle of the K-step,
+// 3 blocks per CU; 0 = two stages (64 KiB), one barrier per K-step, 2 blocks per CU.  Measured on MI355X at batch
+// 512: the extra co-resident block is worth more than the saved barrier (conv time per step 60.7 -> 56.3 ms).
+#ifndef FTE_SINGLE
+#define FTE_SINGLE 1
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -51,7 +58,7 @@ __device__ __forceinline__ float prelu_slope(float z, float a) {
 }
 
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
     constexpr int A_CH = BM / 32;                 // 16-byte chunks each thread stages for A per K-step
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #ifndef FTE_PIPE
 #define FTE_PIPE 4
 #endif
+
     [[maybe_unused]] auto compute = [&](int stage) {
         const float* As = smem + stage * STAGE;
         const float* Bs = As + BM * BK;
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
             __syncthreads();
         }
         for (int s = 0; s < nsteps; ++s) {
-            const int cur = s & 1;
+            const int cur = FTE_SINGLE ? 0 : (s & 1);
 #if FTE_ABL == 5
             const int k0 = kbeg;                       // ablation: every step re-loads tile 0 (cache hits)
 #else
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #endif
             const float* As = smem + cur * STAGE;
             const float* Bs = As + BM * BK;
-            float* Asn = smem + (cur ^ 1) * STAGE;
+            float* Asn = smem + (FTE_SINGLE ? 0 : (cur ^ 1)) * STAGE;
             float* Bsn = Asn + BM * BK;
             // ---- per-step operand addressing (scalar / per-thread, no memory access yet) ----
             int tap = 0, kc0 = 0;
@@ -434,6 +442,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #endif
                 if constexpr (idx == Q) read_frags(As, Bs, 2, fa0, fb0);
                 if constexpr (idx == 2 * Q) read_frags(As, Bs, 3, fa1, fb1);
+#if FTE_SINGLE
+                if constexpr (idx == 3 * Q) __syncthreads();       // every wave has fetched its last fragments of this tile
+#endif
 #if FTE_ABL != 2
                 if constexpr (idx >= NM - NL) store_slot(std::integral_constant<int, idx - (NM - NL)>{});
 #endif
@@ -722,7 +733,7 @@ hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
 hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
-    const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+    const size_t lds = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
