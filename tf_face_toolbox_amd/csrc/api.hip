@@ -41,8 +41,11 @@ inline int pick_tile(long M, long N) {
     return cands[nc - 1];
 }
 
-// 256 CUs x 3 resident blocks of the 128x128 tile (32 KiB of LDS, <= 168 VGPRs each)
-constexpr long SLOTS = 768;
+// Resident blocks the planner assumes: 256 CUs x 6 blocks of the 64x64 tile (16 KiB of LDS, <= 80 VGPRs).
+// fp32 MFMAs are 64 cycles each, so operand reuse is not what limits these kernels -- latency hiding is: on
+// MI355X at batch 512 the conv time per step is 60.7 ms with 128x128 tiles at 2 blocks/CU, 56.2 ms at 3 blocks/CU
+// (single LDS stage) and 53.4 ms with 64x64 tiles at 6 blocks/CU.
+constexpr long SLOTS = 1536;
 
 // Row plan of an M x N output with reduction length K.  T big tiles on SLOTS resident blocks run in
 // ceil(T/SLOTS) rounds, so a launch of 1568 tiles pays for 4 rounds while doing 3.06 rounds of work.  The
@@ -61,7 +64,8 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
     static const int narrow_tile = getenv("FTE_NARROW_TILE") ? atoi(getenv("FTE_NARROW_TILE")) : TILE_64x64;   // N = 64: measured on MI355X
     // 64x64 beats 128x64 beats 256x64 (fwd 83 / 82 / 75 TF, dgrad 80 / 76 / 65): with only 18 K-steps per tile the
     // layer lives on co-resident blocks hiding each other's prologue / epilogue, not on operand reuse.
-    const int big = (N % 128 == 0) ? TILE_128x128 : narrow_tile;
+    static const int wide_tile = getenv("FTE_WIDE_TILE") ? atoi(getenv("FTE_WIDE_TILE")) : TILE_64x64;         // measured: see below
+    const int big = (N % 128 == 0) ? wide_tile : narrow_tile;
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
     const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn, ksteps = (K + 31) / 32;
@@ -69,7 +73,7 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
     long tail_rows = 0;
     if (T >= SLOTS) {
         const long full = T / SLOTS * SLOTS;
-        if (T - full == 0 || T - full >= SLOTS * 4 / 5) {        // already (nearly) whole rounds
+        if (big == TILE_64x64 || T - full == 0 || T - full >= SLOTS * 4 / 5) {        // smallest tile, or (nearly) whole rounds
             r.main_rows = M; r.main_mtiles = MT;
             return r;
         }
@@ -105,8 +109,10 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
 
 // split-K plan: pick the split count whose tiles*splits fills whole rounds of SLOTS best
 // (>= 8 K-steps per split; ties go to fewer splits = less slab traffic)
+constexpr long SLOTS_BIG = 768;       // 128x128 / 128x64 tiles (wgrad, dense split-K): 3 blocks per CU
 inline void plan_splits(long tiles, int K, int* splits, int* kchunk, bool prefer8 = false) {
     const int maxs = K / 256 > 0 ? K / 256 : 1;
+    const long SLOTS = SLOTS_BIG;
     long lo = (SLOTS + tiles - 1) / tiles, hi = (3 * SLOTS + tiles - 1) / tiles;
     if (lo < 1) lo = 1;
     if (hi > maxs) hi = maxs;
@@ -323,7 +329,8 @@ void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, 
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     *K = n * ph.out * pw.out;
     const long M = (long)ksize * ksize * cin;
-    *tile = (cout % 128 == 0) ? TILE_128x128 : TILE_128x64;
+    static const int wg_tile = getenv("FTE_WGRAD_TILE") ? atoi(getenv("FTE_WGRAD_TILE")) : -1;      // tuning hook
+    *tile = wg_tile >= 0 ? wg_tile : ((cout % 128 == 0) ? TILE_128x128 : TILE_128x64);
     // prefer8 / split-major placement (one pixel range per XCD) cut wgrad's HBM traffic ~9x on MI355X but the
     // kernel is MFMA-bound: 18.4 -> 18.9 ms per step.  Left off.
     plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk, false);
