@@ -9,10 +9,12 @@
 // It replaces the cuDNN/cuBLAS calls behind layers.conv2d / fully_connected and
 // tf.gradients in the reference (nets/sphere.py:41-42,57-74; data_parallel.py:33).
 //
-// Design (CDNA4): 256 threads = 4 waves; each wave owns a (TM*32)x(TN*32) block
-// of v_mfma_f32_32x32x2_f32 accumulators; BK = 32 floats per K-step; operand
-// tiles are staged global -> VGPR -> LDS (double buffered, one barrier per
-// K-step) so that HBM/L2 latency hides under the 64-cycle fp32 MFMAs.
+// Design (CDNA4): 256 threads = 4 waves; each wave owns a (TM*32)x(TN*32) block of
+// v_mfma_f32_32x32x2_f32 accumulators; BK = 32 floats per K-step; operand tiles are staged
+// global -> VGPR -> LDS by raw buffer loads (out-of-range lanes read 0: no branches) into ONE LDS
+// stage (16 KiB for the 64x64 tile) with two barriers per K-step, so that up to 6 blocks share a CU:
+// fp32 MFMAs are 64 cycles each and what these kernels live on is co-resident blocks hiding each
+// other's prologue / epilogue / barrier stalls, not operand reuse (measurements: DESIGN.md 4.1).
 // LDS images:
 //   "MK" (k-contiguous operands): [row][32 floats] with the 16-byte chunk index
 //        XOR-swizzled by (row>>1)&7 -> ds_read_b128 fragment reads are
@@ -20,6 +22,8 @@
 //   "KM" (m/n-contiguous operands): [k][BM floats], fragments by ds_read_b32.
 // The reduction index inside a K-step is permuted (k = 8u + 4*half + t) so that
 // one b128 read feeds four consecutive MFMAs; A and B use the same permutation.
+// The K-step is hand-slotted: every MFMA is followed by at most one payload operation (a buffer
+// load of the next tile, a fragment-read group, an LDS write) and a scheduling fence.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -268,71 +272,6 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             }
         }
     };
-    auto mfma_block = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
-    };
-#ifndef FTE_PIPE
-#define FTE_PIPE 4
-#endif
-
-    [[maybe_unused]] auto compute = [&](int stage) {
-        const float* As = smem + stage * STAGE;
-        const float* Bs = As + BM * BK;
-#if FTE_PIPE == 0
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            f32x4 fa[TM], fb[TN];
-            read_frags(As, Bs, u, fa, fb);
-            mfma_block(fa, fb);
-        }
-#elif FTE_PIPE == 1
-        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-        read_frags(As, Bs, 0, fa0, fb0);
-        read_frags(As, Bs, 1, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(As, Bs, 2, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(As, Bs, 3, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block(fa1, fb1);
-#elif FTE_PIPE == 3
-        // fragments one u-step ahead, no fences: hipcc may slot loads / LDS writes between MFMAs
-        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-        read_frags(As, Bs, 0, fa0, fb0);
-        read_frags(As, Bs, 1, fa1, fb1);
-        mfma_block(fa0, fb0);
-        read_frags(As, Bs, 2, fa0, fb0);
-        mfma_block(fa1, fb1);
-        read_frags(As, Bs, 3, fa1, fb1);
-        mfma_block(fa0, fb0);
-        mfma_block(fa1, fb1);
-#else
-        // all fragments of the K-step up front, no scheduling fences
-        f32x4 fa[4][TM], fb[4][TN];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) read_frags(As, Bs, u, fa[u], fb[u]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) mfma_block(fa[u], fb[u]);
-#endif
-    };
-
-#ifndef FTE_ABL
-#define FTE_ABL 0      // timing-only ablation builds (wrong results): 1 no loads, 2 no loads+stores, 5 loads re-read tile 0
-#endif
-#if FTE_PIPE == 4
     // ---- main loop, hand-slotted --------------------------------------------------------------
     // One K-step = NM MFMAs per wave.  Each MFMA is followed by at most one "payload" operation and a
     // scheduling fence, so the issue order below is the order in the binary:
@@ -351,11 +290,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         }
         for (int s = 0; s < nsteps; ++s) {
             const int cur = FTE_SINGLE ? 0 : (s & 1);
-#if FTE_ABL == 5
-            const int k0 = kbeg;                       // ablation: every step re-loads tile 0 (cache hits)
-#else
             const int k0 = kbeg + (s + 1) * BK;
-#endif
             const float* As = smem + cur * STAGE;
             const float* Bs = As + BM * BK;
             float* Asn = smem + (FTE_SINGLE ? 0 : (cur ^ 1)) * STAGE;
@@ -437,48 +372,18 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[i][t], fb0[j][t], acc[i][j], 0, 0, 0);
                 else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[i][t], fb1[j][t], acc[i][j], 0, 0, 0);
-#if FTE_ABL != 1 && FTE_ABL != 2
                 if constexpr (idx < NL) load_slot(std::integral_constant<int, idx>{});
-#endif
                 if constexpr (idx == Q) read_frags(As, Bs, 2, fa0, fb0);
                 if constexpr (idx == 2 * Q) read_frags(As, Bs, 3, fa1, fb1);
 #if FTE_SINGLE
                 if constexpr (idx == 3 * Q) __syncthreads();       // every wave has fetched its last fragments of this tile
 #endif
-#if FTE_ABL != 2
                 if constexpr (idx >= NM - NL) store_slot(std::integral_constant<int, idx - (NM - NL)>{});
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
             __syncthreads();
         }
     }
-#else
-    // ---- main loop: one barrier per K-step, loads for step s+1 in flight under step s ----
-#ifndef FTE_ABL
-#define FTE_ABL 0      // ablation builds (timing only, wrong results): 1 no global loads, 2 +no LDS stores, 3 +no barrier
-#endif
-    if (nsteps > 0) {
-        load_tiles(kbeg);
-        store_tiles(0);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const int cur = s & 1;
-            const bool more = s + 1 < nsteps;
-#if FTE_ABL == 0
-            if (more) load_tiles(kbeg + (s + 1) * BK);
-#endif
-            compute(cur);
-#if FTE_ABL <= 1
-            if (more) store_tiles(cur ^ 1);
-#endif
-#if FTE_ABL <= 2
-            __syncthreads();
-#endif
-        }
-    }
-
-#endif
 
     // ---- split-K partial tile: raw accumulators to the workspace, epilogue happens in igemm_fixup ----
     if (p.PW) {
