@@ -177,6 +177,22 @@ int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, fl
                           int n, int hw, int c, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * ShuffleNet-v2 (nets/shufflenet_v2.py).  Depthwise 3x3, TF-SAME, stride 1 or 2: the DepthwiseConv2dNative half of
+ * layers.separable_conv2d (:98,104; the pointwise half is fte_conv2d_* with ksize 1).  x [n,h,wd,c], w [3,3,c].
+ * HBM-bound (9 MAC per element).
+ * fte_channel_gather: out[row,k] = table[k] < 0 ? 0 : (table[k]>>16 ? b : a)[row, table[k] & 0xffff] -- one kernel
+ * for _channel_split (:60-64), tf.concat + _channel_shuffle (:66-77,112-113) and their gradients; the
+ * concatenated tensor is never materialised.  table is a device int32[co].
+ * ------------------------------------------------------------------------- */
+int fte_dwconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int stride, void* stream);
+int fte_dwconv3x3_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int stride, void* stream);
+int fte_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int c, int stride,
+                        void* ws, size_t ws_bytes, void* stream);
+size_t fte_dwconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int stride);
+int fte_channel_gather(const float* a, const float* b, float* out, const int32_t* table, long rows,
+                       int ca, int cb, int co, void* stream);
+
+/* ---------------------------------------------------------------------------
  * First conv of the net (Cin = 1 or 3, stride 2; nets/sphere.py:57): K = 9*Cin
  * is too short for a GEMM -- HBM-bound direct convolution, fused bias+PReLU.
  * ------------------------------------------------------------------------- */

@@ -53,14 +53,25 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
             gw = x.shape[-1] // groups
             env[out] = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], params[wname][g], stride)
                                        for g in range(groups)], axis=-1)
-        elif kind == 'se':          # ('se', out, inp, prefix): nets/shufflenet_v2.py:79-85
-            _, _, inp, pre = op
+        elif kind == 'se':          # ('se', out, inp, prefix[, scope1, scope2]): nets/shufflenet_v2.py:79-85
+            inp, pre = op[2], op[3]
+            s1, s2 = (op[4], op[5]) if len(op) > 4 else ('fc1', 'fc2')
             x = env[inp]
             sq = x.mean(axis=(1, 2))
-            hid = np.maximum(sq @ params[pre + '/fc1/weights'] + params[pre + '/fc1/biases'], 0)
-            gate = 1.0 / (1.0 + np.exp(-(hid @ params[pre + '/fc2/weights'] + params[pre + '/fc2/biases'])))
+            w1 = params[pre + '/%s/weights' % s1].reshape(params[pre + '/%s/weights' % s1].shape[-2:])
+            w2 = params[pre + '/%s/weights' % s2].reshape(params[pre + '/%s/weights' % s2].shape[-2:])
+            hid = np.maximum(sq @ w1 + params[pre + '/%s/biases' % s1], 0)
+            gate = 1.0 / (1.0 + np.exp(-(hid @ w2 + params[pre + '/%s/biases' % s2])))
             env[out] = x * gate[:, None, None, :]
             cache[out] = dict(sq=sq, hid=hid, gate=gate)
+        elif kind == 'dwconv':      # ('dwconv', out, inp, wname, stride)
+            env[out] = ops.dwconv3x3_fwd(env[op[2]], params[op[3]], op[4])
+        elif kind == 'split':       # ('split', out_a, inp, out_b): nets/shufflenet_v2.py:60-64
+            env[out], env[op[3]] = ops.channel_split(env[op[2]])
+        elif kind == 'shufsplit':   # ('shufsplit', out_s, a, b, out_x, fmt): concat + shuffle (:112-113), then the NEXT block's split (:93)
+            env[out], env[op[4]] = ops.channel_split(ops.channel_shuffle(np.concatenate([env[op[2]], env[op[3]]], axis=-1), op[5]))
+        elif kind == 'shufcat':     # ('shufcat', out, a, b, fmt): concat + shuffle feeding a conv (the last block)
+            env[out] = ops.channel_shuffle(np.concatenate([env[op[2]], env[op[3]]], axis=-1), op[4])
         else:
             raise ValueError(kind)
     return env, cache, new_state
@@ -86,6 +97,9 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None):
         if out not in gt:
             continue
         dy = gt[out]
+        if kind in ('split', 'shufsplit', 'shufcat', 'dwconv'):
+            _backward_shuffle_ops(op, params, env, gt, gp, acc)
+            continue
         if kind == 'conv':
             _, _, inp, wname, stride = op
             dx, dw = ops.conv2d_bwd(env[inp], params[wname], dy, stride, need_dx=inp != 'images')
@@ -147,18 +161,21 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None):
             acc(gp, wname, dw)
             acc(gt, inp, dx)
         elif kind == 'se':
-            _, _, inp, pre = op
+            inp, pre = op[2], op[3]
+            s1, s2 = (op[4], op[5]) if len(op) > 4 else ('fc1', 'fc2')
+            n1, n2 = pre + '/%s/weights' % s1, pre + '/%s/weights' % s2
+            w1, w2 = params[n1].reshape(params[n1].shape[-2:]), params[n2].reshape(params[n2].shape[-2:])
             x = env[inp]
             c = cache[out]
             hw = x.shape[1] * x.shape[2]
             dgate = (dy * x).sum(axis=(1, 2))
             dpre2 = dgate * c['gate'] * (1 - c['gate'])
-            acc(gp, pre + '/fc2/weights', c['hid'].T @ dpre2)
-            acc(gp, pre + '/fc2/biases', dpre2.sum(0))
-            dpre1 = (dpre2 @ params[pre + '/fc2/weights'].T) * (c['hid'] > 0)
-            acc(gp, pre + '/fc1/weights', c['sq'].T @ dpre1)
-            acc(gp, pre + '/fc1/biases', dpre1.sum(0))
-            dsq = dpre1 @ params[pre + '/fc1/weights'].T
+            acc(gp, n2, (c['hid'].T @ dpre2).reshape(params[n2].shape))
+            acc(gp, pre + '/%s/biases' % s2, dpre2.sum(0))
+            dpre1 = (dpre2 @ w2.T) * (c['hid'] > 0)
+            acc(gp, n1, (c['sq'].T @ dpre1).reshape(params[n1].shape))
+            acc(gp, pre + '/%s/biases' % s1, dpre1.sum(0))
+            dsq = dpre1 @ w1.T
             acc(gt, inp, dy * c['gate'][:, None, None, :] + dsq[:, None, None, :] / hw)
         elif kind == 'fc':
             dx, dw, db = ops.fc_bwd(env[op[2]], params[op[3]], dy, op[4] is not None)
@@ -167,6 +184,137 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None):
                 acc(gp, op[4], db)
             acc(gt, op[2], dx)
     return gp, gt
+
+
+def _unshuffle(d, fmt):
+    """gradient of channel_shuffle = the inverse permutation"""
+    c = d.shape[-1]
+    idx = ops.channel_shuffle(np.arange(c), fmt)
+    out = np.empty_like(d)
+    out[..., idx] = d
+    return out
+
+
+def _backward_shuffle_ops(op, params, env, gt, gp, acc):
+    kind, out = op[0], op[1]
+    dy = gt[out]
+    if kind == 'dwconv':
+        dx, dw = ops.dwconv3x3_bwd(env[op[2]], params[op[3]], dy, op[4])
+        acc(gp, op[3], dw)
+        acc(gt, op[2], dx)
+    elif kind == 'split':
+        acc(gt, op[2], np.concatenate([dy, gt[op[3]]], axis=-1))
+    elif kind == 'shufsplit':
+        dcat = _unshuffle(np.concatenate([dy, gt[op[4]]], axis=-1), op[5])
+        ca = env[op[2]].shape[-1]
+        acc(gt, op[2], dcat[..., :ca])
+        acc(gt, op[3], dcat[..., ca:])
+    elif kind == 'shufcat':
+        dcat = _unshuffle(dy, op[4])
+        ca = env[op[2]].shape[-1]
+        acc(gt, op[2], dcat[..., :ca])
+        acc(gt, op[3], dcat[..., ca:])
+
+
+# ------------------------------------------------------------------------------------------------
+# ShuffleNet-v2 (nets/shufflenet_v2.py:32-420)
+# ------------------------------------------------------------------------------------------------
+SHUFFLENET = {   # variant -> (name, stem ops, [(scope, blocks, width)], final width)
+    'small_x0_5': ('ShuffleNet_v2_small_x0_5', 24, [('conv2', 4, 24), ('conv3', 8, 48), ('conv4', 4, 96)], 1024),      # :40-42
+    'small_x1': ('ShuffleNet_v2_small', 24, [('conv2', 4, 58), ('conv3', 8, 116), ('conv4', 4, 232)], 1024),            # :43-44
+    'small_x1_5': ('ShuffleNet_v2_small_x1_5', 24, [('conv2', 4, 88), ('conv3', 8, 176), ('conv4', 4, 352)], 1024),     # :45-47
+    'small': ('ShuffleNet_v2_small_x2', 24, [('conv2', 4, 122), ('conv3', 8, 244), ('conv4', 4, 488)], 2048),           # :48-50, net_base.py:37-42 (alpha=2.0)
+    'middle': ('ShuffleNet_v2_middle', 64, [('conv2', 3, 244), ('conv3', 4, 488), ('conv4', 6, 976), ('conv5', 3, 1952)], 2048),   # :234,264-290
+    'large': ('ShuffleNet_v2_large_se_res', 128, [('conv2', 10, 340), ('conv3', 10, 680), ('conv4', 23, 1360), ('conv5', 10, 2720)], 2048),  # :305,345-371
+}
+
+
+def shufflenet_graph(variant='small', in_ch=3, data_format='NCHW', blocks_override=None):
+    """Returns (graph, spec, feature tensor, net name).  `data_format` only selects WHICH channel permutation
+    _channel_shuffle applies (the reference's two branches differ, see ops.channel_shuffle); tensors are NHWC.
+    The 'large' variant is built with se=True, residual=True (:305): the SE gate is applied; the residual flag can
+    never fire because :91 compares num_outputs with the channel count BEFORE the split (always 2x for stride 1).
+    Its stem applies conv1_3x3, conv2_3x3 and conv3_3x3 all to `inputs` (:336-340), so only conv3_3x3 (stride 1,
+    128 channels) reaches the max-pool; the other two exist as variables that only see weight decay."""
+    name, stem_c, stages, final_c = SHUFFLENET[variant]
+    if blocks_override is not None:
+        stages = [(s, nb, c) for (s, _, c), nb in zip(stages, blocks_override)]
+    se = variant == 'large'
+    g, spec = [], []
+
+    def bn(scope, out, cout, relu):
+        spec.append((scope + '/BatchNorm/gamma', (cout,), 'gamma'))
+        spec.append((scope + '/BatchNorm/beta', (cout,), 'beta'))
+        g.append(('bn', out + '/bn', out + '/z', scope + '/BatchNorm'))
+        if relu:
+            g.append(('relu', out, out + '/bn'))
+            return out
+        return out + '/bn'
+
+    def conv_bn(scope, out, inp, cin, cout, k, stride):                       # layers.conv2d arg_scope :130-135: BN + ReLU
+        spec.append((scope + '/weights', (k, k, cin, cout), 'conv_w'))
+        g.append(('conv', out + '/z', inp, scope + '/weights', stride))
+        return bn(scope, out, cout, True)
+
+    def sep_bn(scope, out, inp, cin, cout, stride):                           # layers.separable_conv2d arg_scope :136-143: BN, no activation
+        spec.append((scope + '/depthwise_weights', (3, 3, cin, 1), 'dw_w'))
+        spec.append((scope + '/pointwise_weights', (1, 1, cin, cout), 'conv_w'))
+        g.append(('dwconv', out + '/dw', inp, scope + '/depthwise_weights', stride))
+        g.append(('conv', out + '/z', out + '/dw', scope + '/pointwise_weights', 1))
+        return bn(scope, out, cout, False)
+
+    if variant == 'large':
+        spec.append((name + '/conv1/conv1_3x3/weights', (3, 3, in_ch, 64), 'conv_w'))     # dead: :336-339
+        spec.extend([(name + '/conv1/conv1_3x3/BatchNorm/gamma', (64,), 'gamma'), (name + '/conv1/conv1_3x3/BatchNorm/beta', (64,), 'beta')])
+        spec.append((name + '/conv1/conv2_3x3/weights', (3, 3, in_ch, 64), 'conv_w'))
+        spec.extend([(name + '/conv1/conv2_3x3/BatchNorm/gamma', (64,), 'gamma'), (name + '/conv1/conv2_3x3/BatchNorm/beta', (64,), 'beta')])
+        x = conv_bn(name + '/conv1/conv3_3x3', 'conv1', 'images', in_ch, stem_c, 3, 1)    # :340
+    else:
+        x = conv_bn(name + '/conv1/conv_3x3', 'conv1', 'images', in_ch, stem_c, 3, 2)      # :149 / :260
+    g.append(('maxpool', 'pool1', x))                                                      # :151
+    g.append(('split', 'pool1/s', 'pool1', 'pool1/x'))                                     # first block's _channel_split (:93)
+    s_in, x_in, half = 'pool1/s', 'pool1/x', (int(0.5 * stem_c), stem_c - int(0.5 * stem_c))
+    nstage = len(stages)
+    for si, (scope, nb, c) in enumerate(stages):
+        for b in range(nb):
+            stride = 2 if b == 0 else 1                                                    # :157-158
+            sc = '%s/%s/resBlock_%d' % (name, scope, b)
+            t = '%sb%d' % (scope, b)
+            shortcut = s_in
+            if stride != 1:                                                                # :94-98
+                shortcut = sep_bn(sc + '/separable_conv_shortcut_3x3', t + '/ss', s_in, half[0], c, stride)
+                shortcut = conv_bn(sc + '/conv_shortcut_1x1', t + '/sc', shortcut, c, c, 1, 1)
+            y = conv_bn(sc + '/conv1_1x1', t + '/c1', x_in, half[1], c, 1, 1)              # :101
+            y = sep_bn(sc + '/separable_conv2_3x3', t + '/c2', y, c, c, stride)            # :102
+            y = conv_bn(sc + '/conv3_1x1', t + '/c3', y, c, c, 1, 1)                       # :103
+            if se:                                                                         # :104-105, :79-85 (1x1 convs with biases == FCs on the squeezed map)
+                pre = sc
+                spec.extend([(pre + '/Conv/weights', (1, 1, c, c // 2), 'fc_w'), (pre + '/Conv/biases', (c // 2,), 'bias'),
+                             (pre + '/Conv_1/weights', (1, 1, c // 2, c), 'fc_w'), (pre + '/Conv_1/biases', (c,), 'bias')])
+                g.append(('se', t + '/se', y, pre, 'Conv', 'Conv_1'))
+                y = t + '/se'
+            last = si == nstage - 1 and b == nb - 1
+            if last:
+                g.append(('shufcat', t, shortcut, y, data_format))                         # :112-113 feeding conv5/conv_1x1
+                x = t
+            else:
+                g.append(('shufsplit', t + '/s', shortcut, y, t + '/x', data_format))      # :112-113 + next block's :93
+                s_in, x_in = t + '/s', t + '/x'
+            # after a block the tensor has 2c channels; every later block of the stage splits it c / c
+            half = (c, c)
+    c_last = 2 * stages[-1][2]
+    x = conv_bn(name + '/conv5/conv_1x1', 'conv_last', x, c_last, final_c, 1, 1)            # :175-177 (the middle / large nets reuse scope 'conv5', :288,369)
+    g.append(('gap', 'features', x))                                                       # :180
+    return g, spec, 'features', name
+
+
+def shufflenet_train_graph(variant, in_ch, num_classes, data_format='NCHW', blocks_override=None):
+    g, spec, feat, name = shufflenet_graph(variant, in_ch, data_format, blocks_override)
+    final_c = SHUFFLENET[variant][3]
+    g = g + [('dropout', 'features_drop', feat, 0.5),                                      # :191
+             ('fc', 'logits', 'features_drop', 'classifier/fc_classifier/weights', None)]  # :192-196
+    spec = spec + [('classifier/fc_classifier/weights', (final_c, num_classes), 'cls_w')]
+    return g, spec
 
 
 # ------------------------------------------------------------------------------------------------
@@ -262,7 +410,10 @@ def init_params(spec, seed, dtype=np.float64):
             lim = np.sqrt(6.0 / (9 * gw + 9 * gw))
             p[name] = rng.uniform(-lim, lim, shape).astype(dtype)
         elif kind == 'fc_w':
-            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            lim = np.sqrt(6.0 / (shape[-2] + shape[-1]))
+            p[name] = rng.uniform(-lim, lim, shape).astype(dtype)
+        elif kind == 'dw_w':
+            lim = np.sqrt(6.0 / (9 * shape[2] + 9))        # Xavier-uniform: fan_in 9*C, fan_out 9*1 (TF's fan rule on [3,3,C,1])
             p[name] = rng.uniform(-lim, lim, shape).astype(dtype)
         elif kind == 'bias':
             p[name] = np.zeros(shape, dtype)
@@ -311,10 +462,10 @@ def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None,
             dout['features'] = dfe * scale
             extra['centers'] = newc
     gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink)
-    reg_names = [k for k in params if k.endswith('/weights')]
+    reg_names = [k for k in params if k.endswith('weights')]      # weights, depthwise_weights, pointwise_weights
     reg = ops.l2_reg([params[k] for k in reg_names], weight_decay)
     for k in reg_names:
-        gp[k] = gp[k] + weight_decay * params[k]
+        gp[k] = gp.get(k, 0.0) + weight_decay * params[k]      # variables no op reads (ShuffleNet-large's dead stem convs) see only decay
     losses.append(reg)
     if extra:
         return losses, gp, env, new_state, extra

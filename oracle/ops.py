@@ -358,3 +358,53 @@ def dropout_fwd(x, mask, keep_prob=0.5):
     """layers.dropout: inverted dropout; `mask` is the 0/1 keep mask (TF's RNG stream is not reproducible,
     so parity tests feed the implementation's mask to the oracle)."""
     return x * mask / keep_prob
+
+
+# ------------------------------------------------------------------------------------------------
+# ShuffleNet-v2 pieces (nets/shufflenet_v2.py)
+# ------------------------------------------------------------------------------------------------
+def dwconv3x3_fwd(x, w, stride=1):
+    """Depthwise half of layers.separable_conv2d (nets/shufflenet_v2.py:98,104; depth_multiplier=1, :139).
+    x [N,H,W,C], w [3,3,C,1], TF-SAME."""
+    n, h, wd, c = x.shape
+    ho, pt, pb = same_pads(h, 3, stride)
+    wo, pl, pr = same_pads(wd, 3, stride)
+    xp = _pad_nhwc(x, pt, pb, pl, pr)
+    y = np.zeros((n, ho, wo, c), x.dtype)
+    for r in range(3):
+        for q in range(3):
+            y += xp[:, r:r + (ho - 1) * stride + 1:stride, q:q + (wo - 1) * stride + 1:stride, :] * w[r, q, :, 0]
+    return y
+
+
+def dwconv3x3_bwd(x, w, dy, stride=1):
+    n, h, wd, c = x.shape
+    ho, pt, pb = same_pads(h, 3, stride)
+    wo, pl, pr = same_pads(wd, 3, stride)
+    xp = _pad_nhwc(x, pt, pb, pl, pr)
+    dxp = np.zeros_like(xp)
+    dw = np.zeros_like(w)
+    for r in range(3):
+        for q in range(3):
+            sl = (slice(None), slice(r, r + (ho - 1) * stride + 1, stride), slice(q, q + (wo - 1) * stride + 1, stride), slice(None))
+            dw[r, q, :, 0] = (xp[sl] * dy).sum(axis=(0, 1, 2))
+            dxp[sl] += dy * w[r, q, :, 0]
+    return dxp[:, pt:pt + h, pl:pl + wd, :], dw
+
+
+def channel_split(x):
+    """_channel_split (nets/shufflenet_v2.py:60-64): sizes [int(0.5*C), C - int(0.5*C)] on the channel axis."""
+    c = x.shape[-1]
+    h = int(0.5 * c)
+    return x[..., :h], x[..., h:]
+
+
+def channel_shuffle(x, data_format='NCHW'):
+    """_channel_shuffle (nets/shufflenet_v2.py:66-77) restated on an NHWC array.  The two layouts of the reference
+    do NOT compute the same permutation: NCHW (the default, :37) views channels as [2, C/2] and transposes --
+    out[2i+j] = in[j*C/2+i]; its NHWC branch views them as [C/2, 2] -- out[j*C/2+i] = in[2i+j]."""
+    c = x.shape[-1]
+    lead = x.shape[:-1]
+    if data_format == 'NCHW':
+        return x.reshape(lead + (2, c // 2)).swapaxes(-1, -2).reshape(lead + (c,))
+    return x.reshape(lead + (c // 2, 2)).swapaxes(-1, -2).reshape(lead + (c,))

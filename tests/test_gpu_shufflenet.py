@@ -1,0 +1,186 @@
+"""-m gpu: ShuffleNet-v2 (depthwise 3x3, channel split / concat / shuffle, 64-padded channel storage) through the
+reference-shaped API and the C ABI against the float64 graph oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphnet as og, ops
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from util_gpu import dev, host, stream, ws, check_maxabs, check_rell2
+    from tf_face_toolbox_amd import net_select, Singular, _lib
+    from tf_face_toolbox_amd.nets.shufflenet_v2 import ShuffleNet_v2_small, ShuffleNet_v2_middle, ShuffleNet_v2_large
+    from test_gpu_resnet import _kink
+
+
+@pytest.mark.parametrize('n,h,w,c,stride', [(3, 14, 14, 128, 1), (2, 28, 28, 64, 2), (2, 7, 9, 256, 2), (1, 4, 4, 512, 1),
+                                            (5, 13, 8, 192, 1), (64, 14, 14, 128, 2)])
+def test_depthwise_conv_kernels(n, h, w, c, stride):
+    rng = np.random.default_rng(n * 100 + c + stride)
+    x = rng.standard_normal((n, h, w, c)); wt = rng.standard_normal((3, 3, c, 1)) * 0.3
+    y = ops.dwconv3x3_fwd(x, wt, stride)
+    dy = rng.standard_normal(y.shape)
+    dx, dw = ops.dwconv3x3_bwd(x, wt, dy, stride)
+    xd, wd_, dyd = dev(x), dev(wt.reshape(3, 3, c)), dev(dy)
+    yd = torch.empty(y.shape, device='cuda'); dxd = torch.empty(x.shape, device='cuda'); dwd = torch.empty(3, 3, c, device='cuda')
+    _lib.call('fte_dwconv3x3_fwd', xd, wd_, yd, n, h, w, c, stride, stream())
+    _lib.call('fte_dwconv3x3_dgrad', dyd, wd_, dxd, n, h, w, c, stride, stream())
+    buf, nb = ws(_lib.query('fte_dwconv3x3_wgrad_ws_bytes', n, h, w, c, stride))
+    _lib.call('fte_dwconv3x3_wgrad', xd, dyd, dwd, n, h, w, c, stride, buf, nb, stream())
+    check_maxabs(host(yd), y, 2e-6, 'dw fwd')
+    check_maxabs(host(dxd), dx, 2e-6, 'dw dgrad')
+    check_rell2(host(dwd), dw.reshape(3, 3, c), 2e-6, 'dw wgrad')
+
+
+@pytest.mark.parametrize('fmt', ['NCHW', 'NHWC'])
+@pytest.mark.parametrize('ca', [12, 122, 58])
+def test_channel_gather_is_concat_shuffle_split(ca, fmt):
+    """The engine's tables against the literal reference sequence: bit-exact (pure data movement)."""
+    net = ShuffleNet_v2_small(alpha=2.0, data_format=fmt)
+    net.device = torch.device('cuda')
+    pc = net._pc
+    n, h, w = 3, 5, 4
+    rng = np.random.default_rng(ca)
+    a, b = rng.standard_normal((n, h, w, ca)).astype(np.float32), rng.standard_normal((n, h, w, ca)).astype(np.float32)
+    s_ref, x_ref = ops.channel_split(ops.channel_shuffle(np.concatenate([a, b], -1), fmt))
+    net.real_c = {'a': ca, 'b': ca}
+    net.shapes = {k: (h, w, pc(ca)) for k in ('a', 'b', 's', 'x')}
+    net.shapes['cat'] = (h, w, pc(2 * ca))
+    net.real_c['cat'] = 2 * ca
+
+    def padded(v):
+        out = np.zeros(v.shape[:-1] + (pc(v.shape[-1]),), np.float32)
+        out[..., :v.shape[-1]] = v
+        return dev(out)
+    ad, bd = padded(a), padded(b)
+    rows = n * h * w
+
+    def run(table, s0, s1, co):
+        out = torch.full((n, h, w, co), 7.0, device='cuda')
+        _lib.call('fte_channel_gather', s0, s1, out, table, rows, s0.shape[-1], s1.shape[-1] if s1 is not None else 0, co, stream())
+        return out
+    tb = net._gather_tables(('shufsplit', 's', 'a', 'b', 'x', fmt))
+    sd = run(tb['outs'][0][1], ad, bd, pc(ca)); xd = run(tb['outs'][1][1], ad, bd, pc(ca))
+    np.testing.assert_array_equal(sd.cpu().numpy()[..., :ca], s_ref); np.testing.assert_array_equal(xd.cpu().numpy()[..., :ca], x_ref)
+    assert float(sd[..., ca:].abs().max()) == 0 and float(xd[..., ca:].abs().max()) == 0          # padding stays zero
+    # backward tables = the inverse permutation: gather(s, x) must give back a and b
+    a2 = run(tb['bwd'][0][1], sd, xd, pc(ca)); b2 = run(tb['bwd'][1][1], sd, xd, pc(ca))
+    assert torch.equal(a2, ad) and torch.equal(b2, bd)
+    tc = net._gather_tables(('shufcat', 'cat', 'a', 'b', fmt))
+    cd = run(tc['outs'][0][1], ad, bd, pc(2 * ca))
+    np.testing.assert_array_equal(cd.cpu().numpy()[..., :2 * ca], ops.channel_shuffle(np.concatenate([a, b], -1), fmt))
+    assert torch.equal(run(tc['bwd'][0][1], cd, None, pc(ca)), ad) and torch.equal(run(tc['bwd'][1][1], cd, None, pc(ca)), bd)
+    net.real_c['in'] = 2 * ca; net.shapes['in'] = (h, w, pc(2 * ca))
+    ts = net._gather_tables(('split', 's', 'in', 'x'))
+    h0 = run(ts['outs'][0][1], cd, None, pc(ca)); h1 = run(ts['outs'][1][1], cd, None, pc(ca))
+    r0, r1 = ops.channel_split(cd.cpu().numpy()[..., :2 * ca])
+    np.testing.assert_array_equal(h0.cpu().numpy()[..., :ca], r0); np.testing.assert_array_equal(h1.cpu().numpy()[..., :ca], r1)
+    assert torch.equal(run(ts['bwd'][0][1], h0, h1, pc(2 * ca)), cd)
+
+
+def _check_net(net, variant, blocks, fmt, n, h, w, ncls, seed):
+    graph, spec = og.shufflenet_train_graph(variant, 3, ncls, fmt, blocks_override=blocks)
+    p, state = og.init_params(spec, seed)
+    p = og.perturb(p, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    x = rng.uniform(-1, 1, (n, h, w, 3)); y = rng.integers(0, ncls, n)
+    if blocks is not None:
+        net.num_block = list(blocks)
+    net.build(h, w, 3, ncls, 'cuda')
+    assert net.graph == graph and sorted(net.variables) == sorted(p)          # same op list, same variable names and shapes
+    assert all(tuple(net.variables[k].ref_shape) == p[k].shape for k in p)
+    net.load_params(p)
+    net.dropout_seed = 5
+    xd, yd = dev(x), dev(y, torch.int32)
+    logits = net.forward(xd, num_classes=ncls, is_training=True)
+    losses, names, _ = net.loss_function('TOWER', yd, **logits)
+    net.backward()
+    torch.cuda.synchronize()
+    mask = host(net.t['features_drop/mask'])
+    kink = {}
+    for op in net.graph:                                      # the HIP path's ReLU outputs / pool arg-max, unpadded
+        if op[0] == 'relu':
+            kink[op[1]] = host(net.t[op[1]])[..., :net.real_c[op[1]]]
+        elif op[0] == 'maxpool':
+            kink[op[1] + '/idx'] = net.t[op[1] + '/idx'].cpu().numpy()[..., :net.real_c[op[1]]]
+            kink[op[1]] = host(net.t[op[1]])[..., :net.real_c[op[1]]]
+    l_ref, g_ref, env, new_state = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink)
+    p32 = {k: v.astype(np.float32) for k, v in p.items()}
+    s32 = {k: v.astype(np.float32) for k, v in state.items()}
+    _, g32, env32, _ = og.loss_and_grads(graph, p32, x.astype(np.float32), y, np.float32(5e-4),
+                                         masks={'features_drop': mask.astype(np.float32)}, state=s32, kink=kink)
+
+    def rel(a, b):
+        return float(np.sqrt(((np.asarray(a, np.float64) - b) ** 2).sum()) / max(np.sqrt((b * b).sum()), 1e-30))
+    # every activation the engine stores: real channels match the oracle, padding channels are exactly zero
+    worst = 0.0
+    for name, t in net.t.items():
+        if name in env and name != 'images' and t.dtype == torch.float32:
+            rc = net.real_c[name]
+            got = host(t)
+            if name != 'logits':
+                assert np.abs(got[..., rc:]).max(initial=0.0) == 0.0, 'padding of %s is not zero' % name
+            e = rel(got[..., :rc], env[name])
+            assert e <= max(2e-5, 2 * rel(env32[name], env[name])), (name, e, rel(env32[name], env[name]))
+            worst = max(worst, e)
+    assert abs(float(losses[0]) - l_ref[0]) <= 1e-4 * max(1, l_ref[0]) and abs(float(losses[1]) - l_ref[1]) <= 1e-5 * max(1, l_ref[1])
+    for k in p:
+        got = host(net.get_variable(k, net.grads)) + (5e-4 * p[k] if k.endswith('weights') else 0)     # + wd*w (folded into the optimizer)
+        ref = g_ref.get(k, np.zeros_like(p[k]))               # large net: the dead stem BN variables get no gradient
+        if not np.any(ref):
+            assert not np.any(got), k
+            continue
+        # a BN beta (or a bias) that feeds conv -> BN has a true gradient of exactly zero (the next BN removes any
+        # per-channel constant); the oracle gives 1e-18, fp32 gives 1e-9: judge those against an absolute noise floor
+        err = np.sqrt(((got - ref) ** 2).sum())
+        floor = 1e-7 * np.sqrt(ref.size)
+        assert err <= max(1e-4 * np.sqrt((ref * ref).sum()), 2 * np.sqrt(((g32[k] - ref) ** 2).sum()), floor), ('grad ' + k, err, floor)
+    # gradient arena outside the real entries (the padding rows / columns) must be exactly zero
+    real = torch.zeros_like(net.grads[:net.arena_size])
+    ones = {k: np.ones(p[k].shape) for k in p}
+    for k in p:
+        net.set_variable(k, ones[k], arena=real)
+    assert float(net.grads[:net.arena_size][real == 0].abs().max()) == 0.0
+    for k in new_state:
+        got = host(net.get_variable(k))
+        assert np.abs(got - new_state[k]).max() <= 3e-5 * np.abs(new_state[k]).max() + 1e-9, k
+    return worst
+
+
+@pytest.mark.parametrize('n,h,w,fmt', [(8, 64, 64, 'NCHW'), (4, 112, 112, 'NCHW'), (6, 64, 48, 'NHWC')])
+def test_shufflenet_small_x2_forward_loss_and_every_gradient(n, h, w, fmt):
+    """net_base.py:37-42's net: alpha = 2.0 (122 / 244 / 488 / 2048), all 16 blocks."""
+    _check_net(ShuffleNet_v2_small(alpha=2.0, data_format=fmt), 'small', None, fmt, n, h, w, 10, 31)
+
+
+def test_shufflenet_other_widths_and_variants():
+    _check_net(ShuffleNet_v2_small(alpha=1.0), 'small_x1', [2, 2, 2], 'NCHW', 6, 64, 64, 7, 41)
+    _check_net(ShuffleNet_v2_middle(), 'middle', [2, 2, 2, 2], 'NCHW', 6, 64, 64, 7, 51)
+    _check_net(ShuffleNet_v2_large(), 'large', [2, 1, 1, 2], 'NCHW', 4, 32, 32, 7, 61)          # SE gate + stride-1 stem + dead stem convs
+
+
+def test_shufflenet_training_steps_and_eval_mode():
+    ncls, n, h, w = 10, 16, 64, 64
+    net = net_select('ShuffleNet-v2-small', 'NCHW', 5e-4)
+    assert net.name == 'ShuffleNet_v2_small_x2'
+    rng = np.random.default_rng(1)
+    x = dev(rng.uniform(-1, 1, (n, h, w, 3))); y = dev(rng.integers(0, ncls, n), torch.int32)
+    step, losses, names, _ = Singular(net, 0.05, 'Momentum')({'images': x, 'labels': y, 'num_classes': ncls, 'num_examples': n})
+    w0 = net.params.clone()
+    real = torch.zeros_like(net.params)
+    for k, v in net.variables.items():
+        net.set_variable(k, torch.ones(v.ref_shape), arena=real)
+    hist = []
+    for i in range(40):
+        step()
+        hist.append(float(losses[0]))
+    assert all(np.isfinite(hist)) and not torch.equal(w0, net.params)
+    assert np.mean(hist[-8:]) < np.mean(hist[:8])
+    assert float(net.params[real == 0].abs().max()) == 0.0          # 40 optimizer steps later the padding is still exactly zero
+    assert names == ['cross_entropy', 'reg_loss']
+    out = net.forward(x, num_classes=ncls, is_training=False)['logits']
+    assert out.shape == (n, ncls) and torch.isfinite(out).all()
+    assert net.get_variable('ShuffleNet_v2_small_x2/conv2/resBlock_1/conv1_1x1/BatchNorm/moving_mean').shape == (122,)
+    assert net.get_variable('ShuffleNet_v2_small_x2/conv2/resBlock_0/separable_conv_shortcut_3x3/depthwise_weights').shape == (3, 3, 12, 1)

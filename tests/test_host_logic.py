@@ -15,8 +15,15 @@ def test_net_select_names_and_errors_follow_the_reference():
         net_select('LeNet')
     with pytest.raises(UnboundLocalError):                             # nets/net_base.py:52-59 `pass` branches
         net_select('MobileNet-v2')
-    with pytest.raises(NotImplementedError):
-        net_select('ShuffleNet-v2-small')
+    s = net_select('ShuffleNet-v2-small')                               # nets/net_base.py:37-42: alpha = 2.0
+    assert s.name == 'ShuffleNet_v2_small_x2' and s.num_outputs == [122, 244, 488, 2048] and not s.se and not s.residual
+    m, l = net_select('ShuffleNet-v2-middle'), net_select('ShuffleNet-v2-large')
+    assert m.name == 'ShuffleNet_v2_middle' and m.num_outputs == [244, 488, 976, 1952, 2048]           # shufflenet_v2.py:233-234
+    assert l.name == 'ShuffleNet_v2_large_se_res' and l.num_outputs == [340, 680, 1360, 2720, 2048]    # :305-306
+    g, spec = s.build_graph(3, 10)
+    shapes = dict((n_, s_) for n_, s_, _ in spec)
+    assert shapes['ShuffleNet_v2_small_x2/conv3/resBlock_0/separable_conv2_3x3/depthwise_weights'] == (3, 3, 244, 1)
+    assert sum(1 for op in g if op[0] in ('shufsplit', 'shufcat')) == 16 and g[-1][0] == 'fc'
     r = net_select('ResNet-50', 'NHWC', 1e-4)                          # nets/net_base.py:32-36
     assert r.name == 'ResNet-50' and r.num_block == [3, 4, 6, 3] and r.weight_decay == 1e-4
     with pytest.raises(AssertionError, match='Unknown data format.'):   # nets/net_base.py:72

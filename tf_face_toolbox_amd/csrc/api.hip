@@ -704,4 +704,35 @@ int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, fl
     return rc(l_chscale_bwd(dy, x, gate, dx, dgate, n, hw, c, (hipStream_t)stream));
 }
 
+// ------------------------------------------------------------------------------------------------
+// ShuffleNet-v2: depthwise 3x3, channel gather
+int fte_dwconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int stride, void* stream) {
+    if (!x || !w || !y || n <= 0 || c % 4 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_dwconv_fwd(x, w, y, n, h, wd, c, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+}
+int fte_dwconv3x3_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int stride, void* stream) {
+    if (!dy || !w || !dx || n <= 0 || c % 4 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_dwconv_dgrad(dy, w, dx, n, h, wd, c, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+}
+size_t fte_dwconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int stride) {
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return (size_t)l_dwconv_wgrad_splits((long)n * ph.out * pw.out, c) * 9 * c * sizeof(float) + SCRATCH_BYTES;
+}
+int fte_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int c, int stride,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw || n <= 0 || c % 4 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    const int splits = l_dwconv_wgrad_splits((long)n * ph.out * pw.out, c);
+    if (!ws || ws_bytes < (size_t)splits * 9 * c * sizeof(float)) return FTE_EWORKSPACE;
+    hipError_t e = l_dwconv_wgrad(x, dy, (float*)ws, n, h, wd, c, ph.out, pw.out, stride, ph.before, pw.before, splits, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, 9L * c, 1, 1.f, nullptr, (hipStream_t)stream));
+}
+int fte_channel_gather(const float* a, const float* b, float* out, const int32_t* table, long rows, int ca, int cb, int co, void* stream) {
+    if (!a || !out || !table || rows <= 0 || co <= 0) return FTE_EINVAL;
+    return rc(l_channel_gather(a, b ? b : a, out, table, rows, ca, cb, co, (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -35,3 +35,9 @@ hipError_t l_act_bwd(const float* dy, const float* y, float* dx, long n, int kin
 hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st);
 hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c, hipStream_t st);
 hipError_t l_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, hipStream_t st);
+hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
+hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
+int l_dwconv_wgrad_splits(long npix, int c);
+hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, int h, int wd, int c, int ho, int wo, int stride,
+                          int pt, int pl, int splits, hipStream_t st);
+hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st);

@@ -773,3 +773,137 @@ hipError_t l_bcast_add(float* dx, const float* v, int n, int hw, int c, float sc
     hipLaunchKernelGGL(bcast_add_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)), dim3(256), 0, st, dx, v, n4, hw, c, scale);
     return hipGetLastError();
 }
+
+// ===================================================================================================
+// ShuffleNet-v2 pieces (nets/shufflenet_v2.py): depthwise 3x3 (the DepthwiseConv2dNative half of
+// layers.separable_conv2d, :98,104) and a table-driven channel gather that implements _channel_split
+// (:60-64), tf.concat + _channel_shuffle (:66-77, :112-113) and their gradients without ever
+// materialising the concatenated tensor.  All HBM-bound: ~9 MAC per element.
+// ===================================================================================================
+namespace {
+
+// y[n,oh,ow,c] = sum_{r,q} x[n, oh*s + r - pt, ow*s + q - pl, c] * w[r,q,c]        (DGRAD: the transposed gather)
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, int n, int h, int wd, int c,
+                                                        int ho, int wo, int stride, int pt, int pl) {
+    const int c4n = c >> 2;
+    const int oh_ = DGRAD ? h : ho, ow_ = DGRAD ? wd : wo;
+    const long total = (long)n * oh_ * ow_ * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % c4n);
+        long t = i / c4n;
+        const int ox = (int)(t % ow_); t /= ow_;
+        const int oy = (int)(t % oh_);
+        const int img = (int)(t / oh_);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int sy; bool rok;
+            if (!DGRAD) { sy = oy * stride + r - pt; rok = sy >= 0 && sy < h; }
+            else { const int num = oy + pt - r; sy = num / stride; rok = num >= 0 && num % stride == 0 && sy < ho; }
+            if (!rok) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int sx; bool ok;
+                if (!DGRAD) { sx = ox * stride + q - pl; ok = sx >= 0 && sx < wd; }
+                else { const int num = ox + pl - q; sx = num / stride; ok = num >= 0 && num % stride == 0 && sx < wo; }
+                if (!ok) continue;
+                const long src = DGRAD ? ((long)(img * ho + sy) * wo + sx) : ((long)(img * h + sy) * wd + sx);
+                acc += *reinterpret_cast<const f32x4*>(x + src * c + c4 * 4) * *reinterpret_cast<const f32x4*>(w + (r * 3 + q) * c + c4 * 4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = acc;
+    }
+}
+
+// dw[r,q,c] partials: block = 64 channel quads... thread = (channel quad, row lane) over a chunk of output pixels
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ part, int n, int h, int wd, int c,
+                                                              int ho, int wo, int stride, int pt, int pl, long pix_per_split) {
+    __shared__ f32x4 sh[4][64];
+    const int q4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ch = (blockIdx.x * 64 + q4) * 4;
+    const long npix = (long)n * ho * wo;
+    const long p0 = (long)blockIdx.y * pix_per_split, p1 = min(npix, p0 + pix_per_split);
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ch < c) {
+        for (long p = p0 + rl; p < p1; p += 4) {
+            const int ow = (int)(p % wo);
+            const long t2 = p / wo;
+            const int oh = (int)(t2 % ho), img = (int)(t2 / ho);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + p * c + ch);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int ih = oh * stride + r - pt;
+                if (ih < 0 || ih >= h) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int iw = ow * stride + q - pl;
+                    if (iw < 0 || iw >= wd) continue;
+                    acc[r * 3 + q] += *reinterpret_cast<const f32x4*>(x + ((long)(img * h + ih) * wd + iw) * c + ch) * d;
+                }
+            }
+        }
+    }
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        sh[rl][q4] = acc[t];
+        __syncthreads();
+        if (rl == 0 && ch < c) {
+            const f32x4 s = (sh[0][q4] + sh[1][q4]) + (sh[2][q4] + sh[3][q4]);
+            *reinterpret_cast<f32x4*>(part + ((long)blockIdx.y * 9 + t) * c + ch) = s;
+        }
+    }
+}
+
+// out[row, k] = (table[k] < 0) ? 0 : src[table[k] >> 16][row, table[k] & 0xffff]      (src 0 = a, 1 = b)
+__global__ __launch_bounds__(256) void channel_gather_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ out, const int* __restrict__ table,
+                                                             long rows, int ca, int cb, int co) {
+    const long total = rows * co;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % co);
+        const long row = i / co;
+        const int t = table[k];
+        float v = 0.f;
+        if (t >= 0) {
+            const int ch = t & 0xffff;
+            v = (t >> 16) ? b[row * cb + ch] : a[row * ca + ch];
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace
+
+hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
+    const long total = (long)n * ho * wo * (c / 4);
+    hipLaunchKernelGGL(dwconv3x3_kernel<false>, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, stride, pt, pl);
+    return hipGetLastError();
+}
+hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
+    const long total = (long)n * h * wd * (c / 4);
+    hipLaunchKernelGGL(dwconv3x3_kernel<true>, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, stride, pt, pl);
+    return hipGetLastError();
+}
+int l_dwconv_wgrad_splits(long npix, int c) {
+    const long cb = (c / 4 + 63) / 64;
+    long s = 2048 / cb;
+    if (s > npix / 32) s = npix / 32;
+    if (s > 256) s = 256;
+    return (int)(s < 1 ? 1 : s);
+}
+hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, int h, int wd, int c, int ho, int wo, int stride,
+                          int pt, int pl, int splits, hipStream_t st) {
+    const long npix = (long)n * ho * wo, pps = (npix + splits - 1) / splits;
+    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((c / 4 + 63) / 64, splits), dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps);
+    return hipGetLastError();
+}
+hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st) {
+    const long total = rows * co;
+    hipLaunchKernelGGL(channel_gather_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, a, b, out, table, rows, ca, cb, co);
+    return hipGetLastError();
+}

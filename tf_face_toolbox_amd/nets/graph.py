@@ -17,7 +17,23 @@ from .sphere import Variable, same_pads
 
 BN_EPS = 1e-3          # nets/resnet.py:97-99 via layers.batch_norm defaults
 BN_DECAY = 0.999
-STEM_KPAD = 160        # 7*7*3 = 147 rows of the stem weight, zero-padded to a multiple of 32
+
+
+def stem_kpad(k, cin):
+    """rows of the im2col'ed stem weight, zero-padded to a multiple of 32 (7*7*3 = 147 -> 160, 3*3*3 = 27 -> 32)"""
+    return (k * k * cin + 31) // 32 * 32
+
+
+STEM_KPAD = stem_kpad(7, 3)
+
+
+def shuffle_perm(c, data_format):
+    """_channel_shuffle (nets/shufflenet_v2.py:66-77) as an index vector: out[k] = in[perm[k]].  The reference's NCHW
+    branch views channels as [2, C/2] and transposes; its NHWC branch views them as [C/2, 2] -- a different permutation."""
+    idx = torch.arange(c)
+    if data_format == 'NCHW':
+        return idx.reshape(2, c // 2).t().reshape(-1).tolist()
+    return idx.reshape(c // 2, 2).t().reshape(-1).tolist()
 
 
 def _stream():
@@ -28,11 +44,21 @@ class GraphNet(Network):
     """Network whose body is an op list: ('conv', out, inp, wname, stride) | ('bn', out, inp, prefix) |
     ('relu', out, inp) | ('add', out, a, b) | ('maxpool', out, inp) | ('gap', out, inp) |
     ('dropout', out, inp, keep) | ('fc', out, inp, wname, None) | ('gconv', out, inp, wname, stride, groups) |
-    ('se', out, inp, prefix).  Heads: 'softmax' (CE on the classifier), 'softmax+center' (CE + weight * center loss
+    ('se', out, inp, prefix[, scope1, scope2]) | ('dwconv', out, inp, wname, stride) | ('split', out_a, inp, out_b) |
+    ('shufsplit', out_s, a, b, out_x, fmt) | ('shufcat', out, a, b, fmt).
+    `channel_pad` > 1 (ShuffleNet: 64) stores every activation and weight with its channel count rounded up to that
+    multiple; the padding channels are exactly zero in the forward and backward pass (zero weight rows / columns, BN of
+    a constant-zero channel with beta 0 stays 0, and every gradient flowing into them is 0), so results equal the
+    unpadded net's while all kernels keep their float4 / MFMA-tile granularity.  Heads: 'softmax' (CE on the classifier), 'softmax+center' (CE + weight * center loss
     on the pooled features, loss.py:29-45) and 'triplet' (batch-hard triplet on the pooled features, loss.py:47-78, no
     classifier)."""
 
     head = 'softmax'
+    channel_pad = 1
+
+    def _pc(self, c):
+        p = self.channel_pad
+        return (c + p - 1) // p * p
 
     def __init__(self, weight_decay, data_format, name, seed=0):
         super(GraphNet, self).__init__(weight_decay, data_format, name)
@@ -64,12 +90,16 @@ class GraphNet(Network):
         self.spec = OrderedDict((n, (s, k)) for n, s, k in spec)
         self._infer_shapes()
         small = [(n, s, k) for n, s, k in spec if k in ('gamma', 'beta', 'bias')]
-        convs = [(n, s, k) for n, s, k in spec if k in ('conv_w', 'gconv_w', 'fc_w')]
+        convs = [(n, s, k) for n, s, k in spec if k in ('conv_w', 'gconv_w', 'fc_w', 'dw_w')]
         cls = [(n, s, k) for n, s, k in spec if k == 'cls_w']
         self.variables = OrderedDict()
         off = 0
+        self.ishape = {}
         for n, s, k in small + convs + cls:
-            size = self._internal_size(n, s, k)
+            self.ishape[n] = self._internal_shape(s, k)
+            size = 1
+            for d in self.ishape[n]:
+                size *= d
             self.variables[n] = Variable(n, k, s, off, size)
             off += (size + 3) // 4 * 4
         self.small_end = self.variables[convs[0][0]].offset
@@ -82,25 +112,37 @@ class GraphNet(Network):
         # BN moving statistics: non-trainable state, never all-reduced (each replica keeps its own; only
         # tower 0's are saved: saver.py:36-40)
         self.state = OrderedDict()
+        self.state_ref = {}
         for n, s, k in small:
             if k == 'gamma':
                 pre = n[:-len('/gamma')]
-                self.state[pre + '/moving_mean'] = torch.zeros(s, dtype=torch.float32, device=dev)
-                self.state[pre + '/moving_variance'] = torch.ones(s, dtype=torch.float32, device=dev)
+                self.state[pre + '/moving_mean'] = torch.zeros(self._pc(s[0]), dtype=torch.float32, device=dev)
+                self.state[pre + '/moving_variance'] = torch.ones(self._pc(s[0]), dtype=torch.float32, device=dev)
+                self.state_ref[pre + '/moving_mean'] = self.state_ref[pre + '/moving_variance'] = s[0]
         self._init_params()
         self._compile()
         self.built = True
         return self
 
-    def _internal_size(self, name, shape, kind):
+    def _internal_shape(self, shape, kind):
+        """arena layout of a variable whose reference shape is `shape`"""
+        pc = self._pc
         if kind == 'cls_w':
-            return shape[0] * self.cpad
-        if kind == 'conv_w' and shape[2] < 32:                 # the stem: [k*k*cin -> STEM_KPAD, cout]
-            return STEM_KPAD * shape[3]
-        size = 1
-        for d in shape:
-            size *= d
-        return size
+            assert pc(shape[0]) == shape[0]
+            return (shape[0], self.cpad)
+        if kind == 'conv_w':
+            k, _, cin, cout = shape
+            if cin <= 4:                                       # the stem (image channels): [k*k*cin -> kpad, cout]
+                return (stem_kpad(k, cin), pc(cout))
+            return (k, k, pc(cin), pc(cout))
+        if kind == 'dw_w':
+            return (3, 3, pc(shape[2]))
+        if kind == 'fc_w':
+            return (pc(shape[-2]), pc(shape[-1]))
+        if kind in ('gamma', 'beta', 'bias'):
+            return (pc(shape[0]),)
+        assert self.channel_pad == 1 or kind != 'gconv_w'
+        return tuple(shape)
 
     def view(self, name, arena=None):
         v = self.variables[name]
@@ -120,42 +162,68 @@ class GraphNet(Network):
                 lim = (6.0 / (18 * gw)) ** 0.5
                 self.set_variable(n, (torch.rand(v.ref_shape, generator=g) * 2 - 1) * lim)
             elif v.kind == 'fc_w':
-                lim = (6.0 / (v.ref_shape[0] + v.ref_shape[1])) ** 0.5
+                lim = (6.0 / (v.ref_shape[-2] + v.ref_shape[-1])) ** 0.5
+                self.set_variable(n, (torch.rand(v.ref_shape, generator=g) * 2 - 1) * lim)
+            elif v.kind == 'dw_w':
+                lim = (6.0 / (9 * v.ref_shape[2] + 9)) ** 0.5          # Xavier on [3,3,C,1]: fan_in 9C, fan_out 9
                 self.set_variable(n, (torch.rand(v.ref_shape, generator=g) * 2 - 1) * lim)
             elif v.kind == 'cls_w':
                 self.set_variable(n, torch.randn(v.ref_shape, generator=g) * 0.001)
             elif v.kind == 'gamma':
-                self.view(n).fill_(1.0)
+                self.set_variable(n, torch.ones(v.ref_shape))
 
     def get_variable(self, name, arena=None):
         if name in self.state:
-            return self.state[name].clone()
+            t = self.state[name]
+            return t[:self.state_ref[name]].clone() if name in self.state_ref else t.clone()
         v = self.variables[name]
-        t = self.view(name, arena)
+        t = self.view(name, arena).reshape(self.ishape[name])
+        ref = v.ref_shape
         if v.kind == 'cls_w':
-            return t.reshape(v.ref_shape[0], self.cpad)[:, :self.num_classes].clone()
-        if v.kind == 'conv_w' and v.ref_shape[2] < 32:
-            k, _, cin, cout = v.ref_shape
-            return t.reshape(STEM_KPAD, cout)[:k * k * cin].reshape(v.ref_shape).clone()
-        return t.reshape(v.ref_shape).clone()
+            return t[:, :self.num_classes].clone()
+        if v.kind == 'conv_w':
+            k, _, cin, cout = ref
+            if cin <= 4:
+                return t[:k * k * cin, :cout].reshape(ref).clone()
+            return t[:, :, :cin, :cout].clone()
+        if v.kind == 'dw_w':
+            return t[:, :, :ref[2]].reshape(ref).clone()
+        if v.kind == 'fc_w':
+            return t[:ref[-2], :ref[-1]].reshape(ref).clone()
+        if v.kind in ('gamma', 'beta', 'bias'):
+            return t[:ref[0]].clone()
+        return t.reshape(ref).clone()
 
     def set_variable(self, name, value, arena=None):
         if name in self.state:
-            self.state[name].copy_(torch.as_tensor(value, dtype=torch.float32))
+            t = torch.as_tensor(value, dtype=torch.float32)
+            if name in self.state_ref:
+                self.state[name][:self.state_ref[name]].copy_(t)
+            else:
+                self.state[name].copy_(t)
             return
         v = self.variables[name]
         t = torch.as_tensor(value, dtype=torch.float32).to(self.device)
-        assert tuple(t.shape) == v.ref_shape, (name, tuple(t.shape), v.ref_shape)
+        ref = v.ref_shape
+        assert tuple(t.shape) == ref, (name, tuple(t.shape), ref)
+        buf = torch.zeros(self.ishape[name], device=self.device)
         if v.kind == 'cls_w':
-            buf = torch.zeros(v.ref_shape[0], self.cpad, device=self.device)
             buf[:, :self.num_classes] = t
-            t = buf
-        elif v.kind == 'conv_w' and v.ref_shape[2] < 32:
-            k, _, cin, cout = v.ref_shape
-            buf = torch.zeros(STEM_KPAD, cout, device=self.device)
-            buf[:k * k * cin] = t.reshape(k * k * cin, cout)
-            t = buf
-        self.view(name, arena).copy_(t.reshape(-1))
+        elif v.kind == 'conv_w':
+            k, _, cin, cout = ref
+            if cin <= 4:
+                buf[:k * k * cin, :cout] = t.reshape(k * k * cin, cout)
+            else:
+                buf[:, :, :cin, :cout] = t
+        elif v.kind == 'dw_w':
+            buf[:, :, :ref[2]] = t.reshape(3, 3, ref[2])
+        elif v.kind == 'fc_w':
+            buf[:ref[-2], :ref[-1]] = t.reshape(ref[-2], ref[-1])
+        elif v.kind in ('gamma', 'beta', 'bias'):
+            buf[:ref[0]] = t
+        else:
+            buf = t
+        self.view(name, arena).copy_(buf.reshape(-1))
 
     def load_params(self, params):
         for k, val in params.items():
@@ -163,29 +231,94 @@ class GraphNet(Network):
 
     # ---- static analysis ----------------------------------------------------------------------------
     def _infer_shapes(self):
+        """self.shapes: stored (channel-padded) shape of every tensor; self.real_c: its true channel count."""
         h, w, c = self.in_hwc
         shp = {'images': (h, w, c)}
+        real = {'images': c}
+        pc = self._pc
+
+        def put(name, hh, ww, cc):
+            real[name] = cc
+            shp[name] = (hh, ww, pc(cc))
         for op in self.graph:
             kind, out = op[0], op[1]
             if kind == 'conv':
                 ih, iw, _ = shp[op[2]]
-                k, _, _, cout = self.spec[op[3]][0]
-                shp[out] = (same_pads(ih, k, op[4])[0], same_pads(iw, k, op[4])[0], cout)
-            elif kind == 'gconv':
-                ih, iw, cc = shp[op[2]]
-                shp[out] = (same_pads(ih, 3, op[4])[0], same_pads(iw, 3, op[4])[0], cc)
-            elif kind in ('bn', 'relu', 'dropout', 'se'):
+                k, _, cin, cout = self.spec[op[3]][0]
+                assert cin == real[op[2]], (op, cin, real[op[2]])
+                put(out, same_pads(ih, k, op[4])[0], same_pads(iw, k, op[4])[0], cout)
+            elif kind in ('gconv', 'dwconv'):
+                ih, iw, _ = shp[op[2]]
+                put(out, same_pads(ih, 3, op[4])[0], same_pads(iw, 3, op[4])[0], real[op[2]])
+            elif kind in ('bn', 'relu', 'dropout', 'se', 'add'):
                 shp[out] = shp[op[2]]
-            elif kind == 'add':
-                shp[out] = shp[op[2]]
+                real[out] = real[op[2]]
             elif kind == 'maxpool':
-                ih, iw, cc = shp[op[2]]
-                shp[out] = (same_pads(ih, 3, 2)[0], same_pads(iw, 3, 2)[0], cc)
+                ih, iw, _ = shp[op[2]]
+                put(out, same_pads(ih, 3, 2)[0], same_pads(iw, 3, 2)[0], real[op[2]])
             elif kind == 'gap':
                 shp[out] = (shp[op[2]][2],)
+                real[out] = real[op[2]]
             elif kind == 'fc':
                 shp[out] = (self.cpad,)
+                real[out] = self.num_classes
+            elif kind == 'split':
+                ih, iw, _ = shp[op[2]]
+                cc = real[op[2]]
+                put(out, ih, iw, int(0.5 * cc))
+                put(op[3], ih, iw, cc - int(0.5 * cc))
+            elif kind == 'shufsplit':
+                ih, iw, _ = shp[op[2]]
+                cc = real[op[2]] + real[op[3]]
+                put(out, ih, iw, int(0.5 * cc))
+                put(op[4], ih, iw, cc - int(0.5 * cc))
+            elif kind == 'shufcat':
+                ih, iw, _ = shp[op[2]]
+                put(out, ih, iw, real[op[2]] + real[op[3]])
+            else:
+                raise ValueError(kind)
         self.shapes = shp
+        self.real_c = real
+
+    def _table(self, entries, width):
+        """device int32 gather table of `width` slots from [(src, channel) or None]"""
+        t = [-1] * width
+        for k, e in enumerate(entries):
+            if e is not None:
+                t[k] = (e[0] << 16) | e[1]
+        return torch.tensor(t, dtype=torch.int32, device=self.device)
+
+    def _gather_tables(self, op):
+        """Forward and backward channel-gather tables of a split / shufsplit / shufcat op (fte_channel_gather)."""
+        kind = op[0]
+        real, shp = self.real_c, self.shapes
+        if kind == 'split':                                   # nets/shufflenet_v2.py:60-64
+            cc = real[op[2]]
+            h = int(0.5 * cc)
+            fwd = [(op[1], self._table([(0, k) for k in range(h)], shp[op[1]][2])),
+                   (op[3], self._table([(0, h + k) for k in range(cc - h)], shp[op[3]][2]))]
+            bwd = [(op[2], self._table([(0, k) if k < h else (1, k - h) for k in range(cc)], shp[op[2]][2]))]
+            return dict(ins=(op[2], None), outs=fwd, gouts=(op[1], op[3]), bwd=bwd)
+        a, b = op[2], op[3]
+        ca, cb = real[a], real[b]
+        cc = ca + cb
+        fmt = op[5] if kind == 'shufsplit' else op[4]
+        perm = shuffle_perm(cc, fmt)                          # shuffled[k] = cat[perm[k]]
+        src = [(0, j) if j < ca else (1, j - ca) for j in perm]
+        if kind == 'shufsplit':
+            h = int(0.5 * cc)
+            fwd = [(op[1], self._table(src[:h], shp[op[1]][2])), (op[4], self._table(src[h:], shp[op[4]][2]))]
+            gouts = (op[1], op[4])
+            where = lambda k: (0, k) if k < h else (1, k - h)
+        else:
+            fwd = [(op[1], self._table(src, shp[op[1]][2]))]
+            gouts = (op[1], None)
+            where = lambda k: (0, k)
+        inv = [None] * cc
+        for k, j in enumerate(perm):
+            inv[j] = where(k)
+        bwd = [(a, self._table(inv[:ca], shp[a][2])), (b, self._table(inv[ca:], shp[b][2]))]
+        return dict(ins=(a, b), outs=fwd, gouts=gouts, bwd=bwd)
 
     def _compile(self):
         """Fuse bn -> relu and bn -> add -> relu into one BN-apply launch; build consumer counts."""
@@ -217,6 +350,8 @@ class GraphNet(Network):
                 assert len(u) == 1 and g[u[0]][0] == 'relu', 'a bare add is always followed by a ReLU in these nets'
                 skip.add(u[0])
                 plan.append(('addrelu', g[u[0]][1], op[2], op[3]))
+            elif op[0] in ('split', 'shufsplit', 'shufcat'):
+                plan.append(('gather', op[1], self._gather_tables(op)))
             else:
                 plan.append(op)
         self.plan = plan
@@ -224,7 +359,7 @@ class GraphNet(Network):
 
     @staticmethod
     def _inputs(op):
-        if op[0] == 'add':
+        if op[0] in ('add', 'shufsplit', 'shufcat'):
             return [op[2], op[3]]
         return [op[2]]
 
@@ -232,7 +367,8 @@ class GraphNet(Network):
         if name == 'images':
             return True
         for j in range(idx):
-            if self.graph[j][1] == name:
+            o = self.graph[j]
+            if o[1] == name or (o[0] == 'split' and o[3] == name) or (o[0] == 'shufsplit' and o[4] == name):
                 return True
         return False
 
@@ -249,6 +385,10 @@ class GraphNet(Network):
         q = _lib.query
         for op in self.plan:
             kind, out = op[0], op[1]
+            if kind == 'gather':
+                for name, _ in op[2]['outs']:
+                    self.t[name] = torch.empty((n,) + self.shapes[name], **f32)
+                continue
             shape = (n,) + self.shapes[out]
             self.t[out] = torch.empty(shape, **f32)
             if kind == 'bn':
@@ -258,24 +398,30 @@ class GraphNet(Network):
                 need = max(need, q('fte_bn_ws_bytes', c))
             elif kind == 'conv':
                 ih, iw, cin = self.shapes[op[2]]
-                k, _, _, cout = self.spec[op[3]][0]
+                k = self.spec[op[3]][0][0]
+                cout = shape[-1]
                 if cin >= 32:
                     need = max(need, q('fte_conv2d_fwd_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_dgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_wgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]))
                 else:
                     oh, ow, _ = self.shapes[out]
-                    self.cols = torch.empty(n * oh * ow, STEM_KPAD, **f32)
-                    need = max(need, q('fte_gemm_ws_bytes', n * oh * ow, cout, STEM_KPAD))
+                    kpad = stem_kpad(k, cin)
+                    self.cols = torch.empty(n * oh * ow, kpad, **f32)
+                    need = max(need, q('fte_gemm_ws_bytes', n * oh * ow, cout, kpad))
+            elif kind == 'dwconv':
+                ih, iw, cc = self.shapes[op[2]]
+                need = max(need, q('fte_dwconv3x3_wgrad_ws_bytes', n, ih, iw, cc, op[4]))
             elif kind == 'gconv':
                 ih, iw, cc = self.shapes[op[2]]
                 need = max(need, q('fte_gconv3x3_wgrad_ws_bytes', n, ih, iw, cc, op[5], op[4]))
             elif kind == 'se':
                 cc = shape[-1]
+                hd = self._se_names(op)[4]
                 self.t[out + '/sq'] = torch.empty(n, cc, **f32)
-                self.t[out + '/hid'] = torch.empty(n, cc // 2, **f32)
+                self.t[out + '/hid'] = torch.empty(n, hd, **f32)
                 self.t[out + '/gate'] = torch.empty(n, cc, **f32)
-                need = max(need, q('fte_gemm_ws_bytes', n, cc, cc // 2), q('fte_gemm_ws_bytes', n, cc // 2, cc))
+                need = max(need, q('fte_gemm_ws_bytes', n, cc, hd), q('fte_gemm_ws_bytes', n, hd, cc))
             elif kind == 'addrelu':
                 cc = shape[-1]
                 if cc not in self.ident:
@@ -316,15 +462,26 @@ class GraphNet(Network):
             if kind == 'conv':
                 _, _, inp, wname, stride = op
                 ih, iw, cin = self.shapes[inp]
-                k, _, _, cout = self.spec[wname][0]
+                k = self.spec[wname][0][0]
+                cout = self.shapes[out][-1]
                 if cin >= 32:
                     call('fte_conv2d_fwd', T[inp], self.view(wname), None, None, None, None, T[out],
                          n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 else:                                          # stem: im2col + dense MFMA GEMM
                     oh, ow, _ = self.shapes[out]
-                    call('fte_im2col_first', T[inp], self.cols, n, ih, iw, cin, k, stride, STEM_KPAD, st)
-                    call('fte_gemm_nn', self.cols, self.view(wname), None, T[out], n * oh * ow, cout, STEM_KPAD,
+                    kpad = stem_kpad(k, cin)
+                    call('fte_im2col_first', T[inp], self.cols, n, ih, iw, cin, k, stride, kpad, st)
+                    call('fte_gemm_nn', self.cols, self.view(wname), None, T[out], n * oh * ow, cout, kpad,
                          self.ws, self.ws_bytes, st)
+            elif kind == 'dwconv':
+                ih, iw, c = self.shapes[op[2]]
+                call('fte_dwconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[4], st)
+            elif kind == 'gather':
+                a, b = op[2]['ins']
+                for name, table in op[2]['outs']:
+                    co = self.shapes[name][-1]
+                    call('fte_channel_gather', T[a], T[b] if b else None, T[name], table, T[name].numel() // co,
+                         self.shapes[a][-1], self.shapes[b][-1] if b else 0, co, st)
             elif kind == 'bn':
                 _, _, inp, pre, res, relu = op
                 b = self.bn[out]
@@ -345,13 +502,14 @@ class GraphNet(Network):
                 ih, iw, c = self.shapes[op[2]]
                 call('fte_gconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[5], op[4], st)
             elif kind == 'se':
-                _, _, inp, pre = op
+                inp = op[2]
+                w1, b1, w2, b2, hd = self._se_names(op)
                 ih, iw, c = self.shapes[inp]
                 sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
                 call('fte_gap_fwd', T[inp], sq, n, ih * iw, c, st)
-                call('fte_gemm_nn', sq, self.view(pre + '/fc1/weights'), self.view(pre + '/fc1/biases'), hid, n, c // 2, c, self.ws, self.ws_bytes, st)
+                call('fte_gemm_nn', sq, self.view(w1), self.view(b1), hid, n, hd, c, self.ws, self.ws_bytes, st)
                 call('fte_act_fwd', hid, hid, hid.numel(), 0, st)
-                call('fte_gemm_nn', hid, self.view(pre + '/fc2/weights'), self.view(pre + '/fc2/biases'), gate, n, c, c // 2, self.ws, self.ws_bytes, st)
+                call('fte_gemm_nn', hid, self.view(w2), self.view(b2), gate, n, c, hd, self.ws, self.ws_bytes, st)
                 call('fte_act_fwd', gate, gate, gate.numel(), 1, st)
                 call('fte_channel_scale_fwd', T[inp], gate, T[out], n, ih * iw, c, st)
             elif kind == 'addrelu':
@@ -376,6 +534,13 @@ class GraphNet(Network):
                 call('fte_gemm_nn', T[op[2]], self.view(op[3]), None, T[out], n, self.cpad, k, self.ws, self.ws_bytes, st)
             else:
                 raise RuntimeError('op %s must have been fused away' % kind)
+
+    def _se_names(self, op):
+        """('se', out, inp, prefix[, scope1, scope2]) -> weight / bias names of the two FCs and the (padded) hidden width"""
+        pre = op[3]
+        s1, s2 = (op[4], op[5]) if len(op) > 4 else ('fc1', 'fc2')
+        w1 = pre + '/%s/weights' % s1
+        return w1, pre + '/%s/biases' % s1, pre + '/%s/weights' % s2, pre + '/%s/biases' % s2, self.ishape[w1][1]
 
     def _scr(self, c, i):
         key = ('scr', c, i)
@@ -490,10 +655,30 @@ class GraphNet(Network):
                 d = G[out].shape[1]
                 call('fte_add_scaled_rows_cols', G[out], self._dfeat, self.ones_n, None, n, d, d, st)
                 self._dfeat = None
+            if kind == 'gather':
+                ga, gb = op[2]['gouts']
+                if ga not in G:
+                    continue
+                da = G.pop(ga)
+                db = G.pop(gb) if gb else None
+                for name, table in op[2]['bwd']:
+                    g = self._new(name)
+                    co = self.shapes[name][-1]
+                    call('fte_channel_gather', da, db, g, table, g.numel() // co, da.shape[-1],
+                         db.shape[-1] if db is not None else 0, co, st)
+                    self._put(name, g)
+                continue
             if out not in G:
                 continue
             dy = G.pop(out)
-            if kind == 'dropout':
+            if kind == 'dwconv':
+                _, _, inp, wname, stride = op
+                ih, iw, c = self.shapes[inp]
+                call('fte_dwconv3x3_wgrad', T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, stride, self.ws, self.ws_bytes, st)
+                dx = self._new(inp)
+                call('fte_dwconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, stride, st)
+                self._put(inp, dx)
+            elif kind == 'dropout':
                 g = self._new(op[2])
                 call('fte_dropout_bwd', dy, T[out + '/mask'], g, dy.numel(), op[3], st)
                 self._put(op[2], g)
@@ -513,7 +698,8 @@ class GraphNet(Network):
                 self._put(op[2], g)
                 self._put(op[3], g)                      # both addends see the same (read-only) gradient
             elif kind == 'se':
-                _, _, inp, pre = op
+                inp = op[2]
+                w1, b1, w2, b2, hd = self._se_names(op)
                 ih, iw, c = self.shapes[inp]
                 hw = ih * iw
                 sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
@@ -522,15 +708,15 @@ class GraphNet(Network):
                 dgate = torch.empty(n, c, **f32)
                 call('fte_channel_scale_bwd', dy, T[inp], gate, dx, dgate, n, hw, c, st)
                 call('fte_act_bwd', dgate, gate, dgate, dgate.numel(), 1, st)                       # -> d(pre-sigmoid)
-                call('fte_gemm_tn', hid, dgate, self.view(pre + '/fc2/weights', self.grads), n, c, c // 2, self.ws, self.ws_bytes, st)
-                call('fte_reduce_rows', dgate, self.view(pre + '/fc2/biases', self.grads), None, 1, n, c, 1, 1.0, st)
-                dhid = torch.empty(n, c // 2, **f32)
-                call('fte_gemm_nt', dgate, self.view(pre + '/fc2/weights'), None, None, 0, None, dhid, None, n, c, c // 2, self.ws, self.ws_bytes, st)
+                call('fte_gemm_tn', hid, dgate, self.view(w2, self.grads), n, c, hd, self.ws, self.ws_bytes, st)
+                call('fte_reduce_rows', dgate, self.view(b2, self.grads), None, 1, n, c, 1, 1.0, st)
+                dhid = torch.empty(n, hd, **f32)
+                call('fte_gemm_nt', dgate, self.view(w2), None, None, 0, None, dhid, None, n, c, hd, self.ws, self.ws_bytes, st)
                 call('fte_act_bwd', dhid, hid, dhid, dhid.numel(), 0, st)                            # -> d(pre-ReLU)
-                call('fte_gemm_tn', sq, dhid, self.view(pre + '/fc1/weights', self.grads), n, c // 2, c, self.ws, self.ws_bytes, st)
-                call('fte_reduce_rows', dhid, self.view(pre + '/fc1/biases', self.grads), None, 1, n, c // 2, 1, 1.0, st)
+                call('fte_gemm_tn', sq, dhid, self.view(w1, self.grads), n, hd, c, self.ws, self.ws_bytes, st)
+                call('fte_reduce_rows', dhid, self.view(b1, self.grads), None, 1, n, hd, 1, 1.0, st)
                 dsq = torch.empty(n, c, **f32)
-                call('fte_gemm_nt', dhid, self.view(pre + '/fc1/weights'), None, None, 0, None, dsq, None, n, c // 2, c, self.ws, self.ws_bytes, st)
+                call('fte_gemm_nt', dhid, self.view(w1), None, None, 0, None, dsq, None, n, hd, c, self.ws, self.ws_bytes, st)
                 call('fte_bcast_add', dx, dsq, n, hw, c, 1.0 / hw, st)
                 self._put(inp, dx)
             elif kind == 'gconv':
@@ -560,11 +746,12 @@ class GraphNet(Network):
             elif kind == 'conv':
                 _, _, inp, wname, stride = op
                 ih, iw, cin = self.shapes[inp]
-                k, _, _, cout = self.spec[wname][0]
+                k = self.spec[wname][0][0]
+                cout = self.shapes[out][-1]
                 gw = self.view(wname, self.grads)
                 if cin < 32:                             # stem: filter gradient only
                     oh, ow, _ = self.shapes[out]
-                    call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, STEM_KPAD, self.ws, self.ws_bytes, st)
+                    call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, stem_kpad(k, cin), self.ws, self.ws_bytes, st)
                     continue
                 call('fte_conv2d_wgrad', T[inp], dy, gw, n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 prev = G.pop(inp, None)                  # accumulate into an existing contribution through `addin`

@@ -38,9 +38,15 @@ def net_select(name, data_format='NCHW', weight_decay=5e-4):
     elif name == 'SENet-50-triplet':             # config 4: batch-hard triplet (loss.py:47-78), no classifier
         from .resnet import SENet
         network = SENet(num_layers=50, data_format=data_format, weight_decay=weight_decay, head='triplet')
-    elif name in ('ShuffleNet-v2-small', 'ShuffleNet-v2-middle', 'ShuffleNet-v2-large'):
-        raise NotImplementedError('%s: depthwise conv + channel split / shuffle are the next row of the hot-path scope table '
-                                  '(SURVEY.md 8a S1); not built yet.' % name)
+    elif name == 'ShuffleNet-v2-small':                                  # nets/net_base.py:37-42
+        from .shufflenet_v2 import ShuffleNet_v2_small
+        network = ShuffleNet_v2_small(alpha=2.0, se=False, residual=False, data_format=data_format, weight_decay=weight_decay)
+    elif name == 'ShuffleNet-v2-middle':                                 # :43-47
+        from .shufflenet_v2 import ShuffleNet_v2_middle
+        network = ShuffleNet_v2_middle(se=False, residual=False, data_format=data_format, weight_decay=weight_decay)
+    elif name == 'ShuffleNet-v2-large':                                  # :48-51
+        from .shufflenet_v2 import ShuffleNet_v2_large
+        network = ShuffleNet_v2_large(data_format=data_format, weight_decay=weight_decay)
     elif name in ('MobileNet-v2', 'Inception-v4', 'VGG16', 'AlexNet'):
         # nets/net_base.py:52-59 `pass` branches: the reference dies with UnboundLocalError here
         raise UnboundLocalError("local variable 'network' referenced before assignment")
