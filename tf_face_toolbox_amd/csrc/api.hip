@@ -718,17 +718,18 @@ int fte_dwconv3x3_dgrad(const float* dy, const float* w, float* dx, int n, int h
 }
 size_t fte_dwconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int stride) {
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
-    return (size_t)l_dwconv_wgrad_splits((long)n * ph.out * pw.out, c) * 9 * c * sizeof(float) + SCRATCH_BYTES;
+    return align_up((size_t)l_dwconv_wgrad_splits((long)n * ph.out * pw.out, c) * 9 * c * sizeof(float)) + SCRATCH_BYTES;
 }
 int fte_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int n, int h, int wd, int c, int stride,
                         void* ws, size_t ws_bytes, void* stream) {
     if (!x || !dy || !dw || n <= 0 || c % 4 || (stride != 1 && stride != 2)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     const int splits = l_dwconv_wgrad_splits((long)n * ph.out * pw.out, c);
-    if (!ws || ws_bytes < (size_t)splits * 9 * c * sizeof(float)) return FTE_EWORKSPACE;
+    const size_t need = align_up((size_t)splits * 9 * c * sizeof(float));
+    if (!ws || ws_bytes < need + SCRATCH_BYTES) return FTE_EWORKSPACE;
     hipError_t e = l_dwconv_wgrad(x, dy, (float*)ws, n, h, wd, c, ph.out, pw.out, stride, ph.before, pw.before, splits, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, 9L * c, 1, 1.f, nullptr, (hipStream_t)stream));
+    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, 9L * c, 1, 1.f, (float*)((char*)ws + need), (hipStream_t)stream));
 }
 int fte_channel_gather(const float* a, const float* b, float* out, const int32_t* table, long rows, int ca, int cb, int co, void* stream) {
     if (!a || !out || !table || rows <= 0 || co <= 0) return FTE_EINVAL;

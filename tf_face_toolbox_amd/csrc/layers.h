@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-constexpr int BN_MAX_SPLITS = 64;      // row splits of the two-level per-channel reductions
+constexpr int BN_MAX_SPLITS = 512;     // row splits of the two-level per-channel reductions
 
 hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* beta, long rows, int C, float eps, float decay,
                             float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var,

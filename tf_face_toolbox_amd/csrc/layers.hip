@@ -140,20 +140,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
     }
 }
 
-// merge the splits; scale = gamma*rstd, shift = beta - mean*scale; moving statistics (decay, unbiased var)
+// merge the splits; scale = gamma*rstd, shift = beta - mean*scale; moving statistics (decay, unbiased var).
+// Block = 16 channels x 16 split lanes: a lane merges splits lane, lane+16, ..., the 16 lanes merge through LDS
+// (a single thread walking 64 dependent Chan merges took 38 us -- as long as the statistics pass itself).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int splits, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float decay, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out, float* __restrict__ scale,
                                                           float* __restrict__ shift, float* __restrict__ mov_mean,
                                                           float* __restrict__ mov_var) {
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= C) return;
+    __shared__ float sh[3][16][16];
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int s = 0; s < splits; ++s) {
-        const float* pp = part + (long)s * 3 * C;
-        chan_merge(n, mean, m2, pp[ch], pp[C + ch], pp[2 * C + ch]);
-    }
+    if (ch < C)
+        for (int s = lane; s < splits; s += 16) {
+            const float* pp = part + (long)s * 3 * C;
+            chan_merge(n, mean, m2, pp[ch], pp[C + ch], pp[2 * C + ch]);
+        }
+    sh[0][lane][cl] = n; sh[1][lane][cl] = mean; sh[2][lane][cl] = m2;
+    __syncthreads();
+    if (lane != 0 || ch >= C) return;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) chan_merge(n, mean, m2, sh[0][l][cl], sh[1][l][cl], sh[2][l][cl]);
     const float var = m2 / n;
     const float rstd = 1.f / sqrtf(var + eps);
     mean_out[ch] = mean;
@@ -246,13 +255,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
-    const int ch = blockIdx.x * 256 + threadIdx.x;
-    if (ch >= C) return;
+    __shared__ float sh[2][16][16];                          // 16 channels x 16 split lanes, as bn_finalize_kernel
+    const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
     float sg = 0.f, sgx = 0.f;
-    for (int s = 0; s < splits; ++s) {
-        sg += part[(long)s * 2 * C + ch];
-        sgx += part[(long)s * 2 * C + C + ch];
-    }
+    if (ch < C)
+        for (int s = lane; s < splits; s += 16) {
+            sg += part[(long)s * 2 * C + ch];
+            sgx += part[(long)s * 2 * C + C + ch];
+        }
+    sh[0][lane][cl] = sg; sh[1][lane][cl] = sgx;
+    __syncthreads();
+    if (lane != 0 || ch >= C) return;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { sg += sh[0][l][cl]; sgx += sh[1][l][cl]; }
     dbeta[ch] = sg;
     dgamma[ch] = sgx;
     const float gr = gamma[ch] * rstd[ch];
@@ -454,7 +470,7 @@ hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* bet
         case 16: hipLaunchKernelGGL(bn_stats_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
         default: hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
                        mean, rstd, scale, shift, mov_mean, mov_var);
     return hipGetLastError();
 }
@@ -484,7 +500,7 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
         case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps); break;
         default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps);
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
                        dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dy, ymask, z, coef, dz, n4, C);
@@ -817,20 +833,22 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
     }
 }
 
-// dw[r,q,c] partials: block = 64 channel quads... thread = (channel quad, row lane) over a chunk of output pixels
+// dw[r,q,c] partials: block = Q channel quads x (256/Q) pixel lanes over one chunk of output pixels
+template <int Q>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ part, int n, int h, int wd, int c,
                                                               int ho, int wo, int stride, int pt, int pl, long pix_per_split) {
-    __shared__ f32x4 sh[4][64];
-    const int q4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int ch = (blockIdx.x * 64 + q4) * 4;
+    constexpr int RL = 256 / Q;
+    __shared__ f32x4 sh[RL][Q];
+    const int q4 = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const int ch = (blockIdx.x * Q + q4) * 4;
     const long npix = (long)n * ho * wo;
     const long p0 = (long)blockIdx.y * pix_per_split, p1 = min(npix, p0 + pix_per_split);
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ch < c) {
-        for (long p = p0 + rl; p < p1; p += 4) {
+        for (long p = p0 + rl; p < p1; p += RL) {
             const int ow = (int)(p % wo);
             const long t2 = p / wo;
             const int oh = (int)(t2 % ho), img = (int)(t2 / ho);
@@ -853,7 +871,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
         sh[rl][q4] = acc[t];
         __syncthreads();
         if (rl == 0 && ch < c) {
-            const f32x4 s = (sh[0][q4] + sh[1][q4]) + (sh[2][q4] + sh[3][q4]);
+            f32x4 s = sh[0][q4];
+            for (int l = 1; l < RL; ++l) s += sh[l][q4];
             *reinterpret_cast<f32x4*>(part + ((long)blockIdx.y * 9 + t) * c + ch) = s;
         }
     }
@@ -889,17 +908,25 @@ hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int
     hipLaunchKernelGGL(dwconv3x3_kernel<true>, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, stride, pt, pl);
     return hipGetLastError();
 }
+static int dw_quads(int c) { return c >= 256 ? 64 : (c >= 128 ? 32 : 16); }
 int l_dwconv_wgrad_splits(long npix, int c) {
-    const long cb = (c / 4 + 63) / 64;
+    const int Q = dw_quads(c);
+    const long cb = (c / 4 + Q - 1) / Q;
     long s = 2048 / cb;
-    if (s > npix / 32) s = npix / 32;
-    if (s > 256) s = 256;
+    if (s > npix / (256 / Q * 4)) s = npix / (256 / Q * 4);
+    if (s > 1024) s = 1024;
     return (int)(s < 1 ? 1 : s);
 }
 hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, int h, int wd, int c, int ho, int wo, int stride,
                           int pt, int pl, int splits, hipStream_t st) {
     const long npix = (long)n * ho * wo, pps = (npix + splits - 1) / splits;
-    hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((c / 4 + 63) / 64, splits), dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps);
+    const int Q = dw_quads(c);
+    const dim3 grid((c / 4 + Q - 1) / Q, splits);
+    switch (Q) {
+        case 64: hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<64>, grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps); break;
+        case 32: hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<32>, grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps); break;
+        default: hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<16>, grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps);
+    }
     return hipGetLastError();
 }
 hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st) {
