@@ -252,6 +252,28 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int ksize, int stride
         }
     return nc;
 }
+// stride-2 3x3 with even image sides: the four classes have identical row grids and 4 / 2 / 2 / 1 taps
+bool dgrad_mergeable(const DgradClass* cls, int nc) {
+    static const bool off = getenv("FTE_DGRAD_SPLIT_CLASSES") != nullptr;      // tuning hook: the per-class launches
+    if (off || nc != 4) return false;
+    for (int i = 0; i < nc; ++i)
+        if (cls[i].hq != cls[0].hq || cls[i].wq != cls[0].wq || cls[i].ntap < 1) return false;
+    return true;
+}
+// partial rows (one per tile row and class) the merged launch writes for dalpha / dbias
+long dgrad_merged_rows(const DgradClass* cls, int nc, int n) {
+    if (!dgrad_mergeable(cls, nc)) return 0;
+    return (long)nc * (((long)n * cls[0].hq * cls[0].wq + 63) / 64);
+}
+// tile of the merged launch and the class order (most taps first)
+int dgrad_merged_plan(const DgradClass* cls, int nc, int n, int cin, int* order) {
+    for (int i = 0; i < nc; ++i) order[i] = i;
+    for (int i = 0; i < nc; ++i)
+        for (int j = i + 1; j < nc; ++j)
+            if (cls[order[j]].ntap > cls[order[i]].ntap) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    (void)n; (void)cin;
+    return TILE_64x64;
+}
 }  // namespace
 
 size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
@@ -260,6 +282,8 @@ size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
     long rows = 0;
     size_t pw = 0;
     for (int i = 0; i < nc; ++i) { rows += cls[i].mtiles; if (cls[i].rp.pw_bytes > pw) pw = cls[i].rp.pw_bytes; }
+    const long merged_rows = dgrad_merged_rows(cls, nc, n);
+    if (merged_rows > rows) rows = merged_rows;
     return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES + pw;
 }
 
@@ -271,18 +295,47 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
     const Pads pho = same_pads(h, ksize, stride), pwo = same_pads(wd, ksize, stride);
     DgradClass cls[4];
     const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
+    const bool merged = dgrad_mergeable(cls, nc);
     long rows = 0;
     for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
+    if (merged) rows = dgrad_merged_rows(cls, nc, n);
     const bool want_part = zprev && (dalpha_prev || dbias_prev);
     const size_t half = align_up((size_t)rows * cin * sizeof(float));
     size_t pw_need = 0;
-    for (int i = 0; i < nc; ++i) if (cls[i].rp.pw_bytes > pw_need) pw_need = cls[i].rp.pw_bytes;
+    for (int i = 0; i < nc && !merged; ++i) if (cls[i].rp.pw_bytes > pw_need) pw_need = cls[i].rp.pw_bytes;
     const size_t fixed = 2 * half + SCRATCH_BYTES;
     if ((want_part || pw_need) && (!ws || ws_bytes < fixed + pw_need)) return FTE_EWORKSPACE;
     float* scratch = want_part ? (float*)((char*)ws + 2 * half) : nullptr;
     float* pwbuf = pw_need ? (float*)((char*)ws + fixed) : nullptr;
     float* PA = want_part ? (float*)ws : nullptr;
     float* PB = want_part ? (float*)((char*)ws + half) : nullptr;
+    if (merged) {
+        // one launch for all parity classes (each had its own until now: at 36-60 % of the rate of a stride-1 layer,
+        // the 1-tap class being a K = cout GEMM that cannot fill the chip on its own)
+        int order[4];
+        const int tile = dgrad_merged_plan(cls, nc, n, cin, order);
+        IgemmParams p;
+        zero_params(&p);
+        const DgradClass& c0 = cls[0];
+        p.M = n * c0.hq * c0.wq; p.N = cin; p.a_KC = cout;
+        p.A = dz; p.a_OH = c0.hq; p.a_OW = c0.wq; p.a_IH = pho.out; p.a_IW = pwo.out; p.a_stride = 1; p.a_ld = cout;
+        p.ncls = nc;
+        int t = 0;
+        for (int k = 0; k < nc; ++k) {
+            const DgradClass& c = cls[order[k]];
+            p.cls_tap0[k] = t; p.cls_ph[k] = c.ph; p.cls_pw[k] = c.pw;
+            for (int j = 0; j < c.ntap; ++j, ++t) { p.a_dh[t] = c.dh[j]; p.a_dw[t] = c.dw[j]; p.b_tapoff[t] = c.wt[j] * cin * cout; }
+        }
+        p.cls_tap0[nc] = t;
+        p.a_NT = t; p.K = t * cout; p.kchunk = p.K;
+        p.B = w; p.b_ld = cout;
+        p.c_OH = c0.hq; p.c_OW = c0.wq; p.c_FH = h; p.c_FW = wd; p.c_step = stride; p.c_ld = cin;
+        p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
+        p.PA = PA; p.PB = PB; p.prow0 = 0;
+        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout)) return FTE_EINVAL;
+        hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_DGRAD, tile, 1, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    } else {
     long prow = 0;
     for (int i = 0; i < nc; ++i) {
         const DgradClass& c = cls[i];
@@ -305,6 +358,7 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
         hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, pwbuf, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
         prow += c.mtiles;
+    }
     }
     if (want_part) {
         if (dalpha_prev) { hipError_t e = k_reduce_rows(PA, dalpha_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }

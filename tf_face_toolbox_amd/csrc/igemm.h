@@ -43,6 +43,9 @@ struct IgemmParams {
     //            PA[prow0 + mtile][n] = sum_rows v*min(Zin,0); PB[...] = sum_rows DZ
     const float* ADD; float* RAW; const float* Zin; float* DZ; float* PA; float* PB;
     int amod, prow0;
+    // EPI_DGRAD, stride 2: ncls > 1 merges the output-parity classes into one launch (see igemm_kernel)
+    int ncls, cls_tiles, cls_mtiles;
+    int cls_tap0[5], cls_ph[4], cls_pw[4];
 };
 
 hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st);

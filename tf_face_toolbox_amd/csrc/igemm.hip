@@ -88,10 +88,25 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    // stride-2 dgrad: the (up to) four output-parity classes share one launch.  Class c owns tiles
+    // [c*cls_tiles, (c+1)*cls_tiles), taps [cls_tap0[c], cls_tap0[c+1]) of the concatenated tap tables and its own
+    // K = taps * KC; classes are ordered longest-first so the short ones fill the tail of the launch.
+    int tap0 = 0, NT = p.a_NT, Kc = p.K, c_ph = p.c_ph, c_pw = p.c_pw, prow = p.prow0;
+    if constexpr (EPI == EPI_DGRAD) {
+        if (p.ncls > 1) {
+            const int cls = bid / p.cls_tiles;
+            bid -= cls * p.cls_tiles;
+            tap0 = p.cls_tap0[cls];
+            NT = p.cls_tap0[cls + 1] - tap0;
+            Kc = NT * p.a_KC;
+            c_ph = p.cls_ph[cls]; c_pw = p.cls_pw[cls];
+            prow += cls * p.cls_mtiles;
+        }
+    }
     const int mt = bid / ntn, nt_ = bid - mt * ntn;
     const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
     const int kbeg = split * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
+    const int kend = min(Kc, kbeg + p.kchunk);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
 
     // ---- per-thread loader state ------------------------------------------------
@@ -119,8 +134,8 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 const int oh = rem / p.a_OW, ow = rem - oh * p.a_OW;
                 const int ih0 = oh * p.a_stride, iw0 = ow * p.a_stride;
                 base = ((n * p.a_IH + ih0) * p.a_IW + iw0) * p.a_ld;
-                for (int t = 0; t < p.a_NT; ++t) {
-                    const int ih = ih0 + p.a_dh[t], iw = iw0 + p.a_dw[t];
+                for (int t = 0; t < NT; ++t) {
+                    const int ih = ih0 + p.a_dh[tap0 + t], iw = iw0 + p.a_dw[tap0 + t];
                     if (ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW) mask |= 1 << t;
                 }
             }
@@ -157,10 +172,10 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     // Weight / B rows are addressed accordingly (row tap*KC + chunk*32); sums are order-independent.
     auto ktap = [&](int k0) -> int {
         const int sg = k0 >> 5;
-        int t = sg % p.a_NT;
+        int t = sg % NT;
         return t;
     };
-    auto kchan = [&](int k0) -> int { return ((k0 >> 5) / p.a_NT) << 5; };
+    auto kchan = [&](int k0) -> int { return ((k0 >> 5) / NT) << 5; };
     auto krow_b = [&](int k0) -> int {        // first B row ([k][n] layout) of the K-step
         if constexpr (AL == AL_MK) return ktap(k0) * p.a_KC + kchan(k0);
         else return k0;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         // ---------------- A ----------------
         if constexpr (AL == AL_MK) {
             const int tap = ktap(k0), kc0 = kchan(k0);
-            const unsigned toff = (unsigned)((p.a_dh[tap] * p.a_IW + p.a_dw[tap]) * p.a_ld + kc0) * 4u;   // wave-uniform
+            const unsigned toff = (unsigned)((p.a_dh[tap0 + tap] * p.a_IW + p.a_dw[tap0 + tap]) * p.a_ld + kc0) * 4u;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_CH; ++i)
                 ra[i] = ldg(rsrcA, ((a_mask[i] >> tap) & 1) ? a_base[i] + toff : OOB, 0);
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 rb[i] = ldg(rsrcB, (k0 + tid / CPR + RPP * i < kend) ? b_base[i] : OOB, koff);
         } else {
             const int tap = ktap(k0), kc0 = kchan(k0);
-            const unsigned toff = (unsigned)(p.b_tapoff[tap] + kc0) * 4u;                               // wave-uniform
+            const unsigned toff = (unsigned)(p.b_tapoff[tap0 + tap] + kc0) * 4u;                        // wave-uniform
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) rb[i] = ldg(rsrcB, b_base[i], toff);
         }
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             bool kin = false;
             int kn = 0, kih0 = 0, kiw0 = 0;
             if constexpr (AL == AL_MK) {
-                a_toff = (unsigned)((p.a_dh[tap] * p.a_IW + p.a_dw[tap]) * p.a_ld + kc0) * 4u;
+                a_toff = (unsigned)((p.a_dh[tap0 + tap] * p.a_IW + p.a_dw[tap0 + tap]) * p.a_ld + kc0) * 4u;
             } else {
                 const int pix = k0 + (tid >> 3);
                 kin = pix < kend;
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 kiw0 = (rem - oh * p.a_OW) * p.a_stride;
             }
             if constexpr (BL == BL_KN) b_soff = (unsigned)((AL == AL_MK ? tap * p.a_KC + kc0 : k0) * p.b_ld) * 4u;
-            else b_soff = (unsigned)(p.b_tapoff[tap] + kc0) * 4u;
+            else b_soff = (unsigned)(p.b_tapoff[tap0 + tap] + kc0) * 4u;
 
             auto load_slot = [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 const int hw = p.c_OH * p.c_OW;
                 const int n = m / hw, rem = m - n * hw;
                 const int oh = rem / p.c_OW, ow = rem - oh * p.c_OW;
-                off = ((n * p.c_FH + oh * p.c_step + p.c_ph) * p.c_FW + ow * p.c_step + p.c_pw) * p.c_ld;
+                off = ((n * p.c_FH + oh * p.c_step + c_ph) * p.c_FW + ow * p.c_step + c_pw) * p.c_ld;
             }
         }
         rowoff[r] = off;
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                     a += red[w * BN + c];
                     b += red[(WM + w) * BN + c];
                 }
-                const long o = (long)(p.prow0 + mt) * p.N + n0 + c;
+                const long o = (long)(prow + mt) * p.N + n0 + c;
                 p.PA[o] = a;
                 if (p.PB) p.PB[o] = b;
             }
@@ -647,7 +662,11 @@ hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(256), lds, st, p);
+    if (p.ncls > 1) {                       // merged parity classes: every class has the same M x N tile grid
+        IgemmParams q = p;
+        q.cls_tiles = mt * nt; q.cls_mtiles = mt;
+        hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(256), lds, st, q);
+    } else if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(256), lds, st, p);
     return hipGetLastError();
 }
@@ -690,7 +709,7 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
     if (!g_prof_on) return dispatch(p, al, bl, epi, tile, splits, st);
     ProfRec r;
     r.sig[0] = al; r.sig[1] = bl; r.sig[2] = epi; r.sig[3] = tile; r.sig[4] = splits;
-    r.flops = 2.0 * (double)(p.M - p.m_base) * (double)p.N * (double)p.K;
+    r.flops = 2.0 * (double)(p.M - p.m_base) * (double)p.N * (double)(p.ncls > 1 ? p.cls_tap0[p.ncls] * p.a_KC : p.K);
     hipError_t e = hipEventCreate(&r.e0);
     if (e != hipSuccess) return e;
     e = hipEventCreate(&r.e1);
