@@ -42,6 +42,20 @@ extern "C" {
 /* Library / build identification: "fte <version> gfx950". */
 const char* fte_version(void);
 
+/* ---------------------------------------------------------------------------
+ * Operand precision of every MFMA product of the library (convolutions and dense GEMMs; process-wide, not per stream).
+ *   FTE_MFMA_F32  (default): v_mfma_f32_32x32x2_f32, exact fp32 -- the reference's arithmetic (dtype=tf.float32,
+ *                 nets/sphere.py:35).
+ *   FTE_MFMA_BF16: operand tiles are rounded to bf16 (round-to-nearest-even) on their way into LDS and multiplied by
+ *                 v_mfma_f32_32x32x16_bf16 with fp32 accumulation (16x the fp32 MFMA rate).  Tensors in HBM, epilogues,
+ *                 reductions, losses and the optimizer stay fp32 -- mixed precision as in BASELINE.json config 3.
+ * Returns FTE_EINVAL for any other value.
+ * ------------------------------------------------------------------------- */
+#define FTE_MFMA_F32 0
+#define FTE_MFMA_BF16 1
+int fte_set_mfma_dtype(int dtype);
+int fte_get_mfma_dtype(void);
+
 /* Measurement hook (bench.py's roofline leg; no reference counterpart).  While enabled, every
  * launch of the MFMA kernel family is bracketed by a HIP event pair ON THE LAUNCH STREAM and its
  * algorithmic FLOPs (2*rows*N*K of that launch) are recorded.  fte_prof_enable(1) clears and starts,

@@ -1,0 +1,87 @@
+"""-m gpu: the bf16-operand MFMA mode (fte_set_mfma_dtype(FTE_MFMA_BF16)).  The kernels round operand tiles to bf16
+(RNE) and accumulate in fp32, so against the float64 oracle evaluated on the SAME bf16-rounded operands they must
+agree to fp32 accumulation error; against the unrounded oracle the stated mixed-precision tolerance is rel-L2 <= 1e-2
+(SURVEY 8c)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from util_gpu import dev, host, stream, ws, check_maxabs, check_rell2
+    from tf_face_toolbox_amd import _lib
+
+
+def rb(a):
+    """fp32 -> bf16 (round to nearest even) -> float64, as the kernel's v_cvt_pk_bf16_f32 does"""
+    return torch.tensor(np.asarray(a, np.float32)).bfloat16().double().numpy()
+
+
+@pytest.fixture
+def bf16_mode():
+    _lib.set_mfma_dtype('bf16')
+    assert _lib.get_mfma_dtype() == 'bf16'
+    yield
+    _lib.set_mfma_dtype('f32')
+
+
+def test_dtype_switch_validates():
+    with pytest.raises(_lib.FteError):
+        _lib.call('fte_set_mfma_dtype', 7)
+    with pytest.raises(ValueError):
+        _lib.set_mfma_dtype('fp8')
+    assert _lib.get_mfma_dtype() == 'f32'
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,stride', [(4, 14, 14, 64, 64, 3, 1), (3, 15, 9, 64, 128, 3, 2), (2, 28, 28, 128, 64, 3, 1),
+                                                     (5, 8, 8, 256, 128, 1, 1), (2, 12, 12, 32, 64, 3, 1), (64, 14, 14, 128, 128, 3, 2),
+                                                     (2, 7, 7, 512, 512, 3, 1), (3, 16, 16, 96, 192, 1, 2)])
+def test_conv_fwd_dgrad_wgrad_bf16_operands(bf16_mode, n, h, w, cin, cout, k, stride):
+    rng = np.random.default_rng(n * 1000 + cin + cout + k + stride)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32); wt = (rng.standard_normal((k, k, cin, cout)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32) * 0.1
+    alpha = rng.uniform(0.1, 0.4, cout).astype(np.float32)
+    z_ref = ops.conv2d_fwd(rb(x), rb(wt), stride, bias.astype(np.float64))
+    y_ref = ops.prelu_fwd(z_ref, alpha.astype(np.float64))
+    dz = rng.standard_normal(z_ref.shape).astype(np.float32)
+    dx_ref, _ = ops.conv2d_bwd(x.astype(np.float64), rb(wt), rb(dz), stride)            # dgrad: operands dz, w
+    _, dw_ref = ops.conv2d_bwd(rb(x), wt.astype(np.float64), rb(dz), stride, need_dx=False)   # wgrad: operands x, dz
+    xd, wd_, dzd = dev(x), dev(wt), dev(dz)
+    zd = torch.empty(z_ref.shape, device='cuda'); yd = torch.empty_like(zd)
+    q = _lib.query
+    buf, nb = ws(max(q('fte_conv2d_fwd_ws_bytes', n, h, w, cin, cout, k, stride), q('fte_conv2d_dgrad_ws_bytes', n, h, w, cin, cout, k, stride),
+                     q('fte_conv2d_wgrad_ws_bytes', n, h, w, cin, cout, k, stride)))
+    _lib.call('fte_conv2d_fwd', xd, wd_, dev(bias), dev(alpha), None, zd, yd, n, h, w, cin, cout, k, stride, buf, nb, stream())
+    check_maxabs(host(zd), z_ref, 2e-5, 'z (bf16 operands)')
+    check_maxabs(host(yd), y_ref, 2e-5, 'y')
+    z_exact = ops.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), stride, bias.astype(np.float64))
+    check_rell2(host(zd), z_exact, 1e-2, 'z vs the unrounded oracle')               # the stated mixed-precision tolerance
+    assert np.sqrt(((host(zd) - z_exact) ** 2).sum()) > 1e-4 * np.sqrt((z_exact ** 2).sum())   # ... and it IS the bf16 path
+    if cin % 64 == 0:
+        dxd = torch.empty(x.shape, device='cuda')
+        _lib.call('fte_conv2d_dgrad', dzd, wd_, None, None, None, None, dxd, None, None, n, h, w, cin, cout, k, stride, buf, nb, stream())
+        check_maxabs(host(dxd), dx_ref, 2e-5, 'dgrad')
+    dwd = torch.empty(wt.shape, device='cuda')
+    _lib.call('fte_conv2d_wgrad', xd, dzd, dwd, n, h, w, cin, cout, k, stride, buf, nb, stream())
+    check_rell2(host(dwd), dw_ref, 2e-5, 'wgrad')
+
+
+@pytest.mark.parametrize('m,n,k', [(64, 128, 512), (37, 10624, 512), (512, 512, 25088), (8, 128, 2048)])
+def test_dense_gemms_bf16_operands(bf16_mode, m, n, k):
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((m, k)).astype(np.float32); b = (rng.standard_normal((k, n)) * 0.05).astype(np.float32)
+    g = rng.standard_normal((m, n)).astype(np.float32)
+    ad, bd, gd = dev(a), dev(b), dev(g)
+    buf, nb = ws(_lib.query('fte_gemm_ws_bytes', m, n, k))
+    c = torch.empty(m, n, device='cuda')
+    _lib.call('fte_gemm_nn', ad, bd, None, c, m, n, k, buf, nb, stream())
+    check_rell2(host(c), rb(a) @ rb(b), 2e-5, 'nn')
+    da = torch.empty(m, k, device='cuda')
+    _lib.call('fte_gemm_nt', gd, bd, None, None, 0, None, da, None, m, n, k, buf, nb, stream())
+    check_rell2(host(da), rb(g) @ rb(b).T, 2e-5, 'nt')
+    db = torch.empty(k, n, device='cuda')
+    _lib.call('fte_gemm_tn', ad, gd, db, m, n, k, buf, nb, stream())
+    check_rell2(host(db), rb(a).T @ rb(g), 2e-5, 'tn')

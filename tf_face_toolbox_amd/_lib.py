@@ -52,6 +52,8 @@ _SIGS = {
     'fte_act_bwd': (c_int, [_P] * 3 + [c_long, c_int, _P]),
     'fte_channel_scale_fwd': (c_int, [_P] * 3 + [c_int] * 3 + [_P]),
     'fte_channel_scale_bwd': (c_int, [_P] * 5 + [c_int] * 3 + [_P]),
+    'fte_set_mfma_dtype': (c_int, [c_int]),
+    'fte_get_mfma_dtype': (c_int, []),
     'fte_dwconv3x3_fwd': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_dgrad': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),
@@ -86,6 +88,9 @@ def exported_names():
     return sorted(_SIGS)
 
 
+MFMA_DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+
+
 def load():
     """Load libfte.so; raises FteError with the build command when it is absent."""
     global _lib
@@ -100,6 +105,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    env = os.environ.get('FTE_MFMA_DTYPE')          # process-wide default of fte_set_mfma_dtype: f32 | bf16
+    if env:
+        if env not in MFMA_DTYPES:
+            raise FteError('FTE_MFMA_DTYPE=%r: expected f32 or bf16' % env)
+        lib.fte_set_mfma_dtype(MFMA_DTYPES[env])
     return lib
 
 
@@ -125,6 +135,17 @@ def query(name, *args):
 
 def version():
     return load().fte_version().decode()
+
+
+def set_mfma_dtype(name):
+    """'f32' (default, the reference's arithmetic) or 'bf16' (bf16 operands, fp32 accumulate and storage): fte.h."""
+    if name not in MFMA_DTYPES:
+        raise ValueError('unknown MFMA dtype %r (f32 | bf16)' % (name,))
+    call('fte_set_mfma_dtype', MFMA_DTYPES[name])
+
+
+def get_mfma_dtype():
+    return 'bf16' if query('fte_get_mfma_dtype') == 1 else 'f32'
 
 
 def prof_records():

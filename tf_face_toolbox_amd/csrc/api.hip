@@ -176,6 +176,13 @@ extern "C" {
 
 const char* fte_version(void) { return "fte 0.1 gfx950 fp32-mfma"; }
 
+int fte_set_mfma_dtype(int dtype) {
+    if (dtype != FTE_MFMA_F32 && dtype != FTE_MFMA_BF16) return FTE_EINVAL;
+    igemm_set_bf16(dtype == FTE_MFMA_BF16);
+    return FTE_OK;
+}
+int fte_get_mfma_dtype(void) { return igemm_get_bf16() ? FTE_MFMA_BF16 : FTE_MFMA_F32; }
+
 int fte_prof_enable(int on) { igemm_prof_enable(on != 0); return FTE_OK; }
 int fte_prof_count(void) { return igemm_prof_count(); }
 int fte_prof_get(int i, int* sig, double* flops, float* ms) {
@@ -185,6 +192,7 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms) {
 
 // ------------------------------------------------------------------------------------------------
 size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+    if (n <= 0 || cin <= 0 || cin % 32 || cout <= 0 || cout % 64) return 0;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true).pw_bytes;
 }
@@ -277,6 +285,7 @@ int dgrad_merged_plan(const DgradClass* cls, int nc, int n, int cin, int* order)
 }  // namespace
 
 size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+    if (n <= 0 || cin <= 0 || cin % 64 || cout % 32) return 0;      // shapes fte_conv2d_dgrad rejects need no workspace
     DgradClass cls[4];
     const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
     long rows = 0;
@@ -392,6 +401,7 @@ void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, 
 }  // namespace
 
 size_t fte_conv2d_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+    if (n <= 0 || cin <= 0 || cin % 4 || cout <= 0 || cout % 64) return 0;
     int tile, splits, kchunk, K;
     wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
     return (splits > 1 ? (size_t)splits * ksize * ksize * cin * cout * sizeof(float) : 0) + SCRATCH_BYTES;

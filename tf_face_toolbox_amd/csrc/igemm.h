@@ -56,6 +56,11 @@ constexpr int FIXUP_CHUNKS = 4;
 hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st);
 void igemm_tile_dims(int tile, int* bm, int* bn);
 
+// operand precision of the MFMA products: false = fp32 (v_mfma_f32_32x32x2_f32, exact), true = operands rounded to bf16
+// inside the kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate); storage in HBM is fp32 either way
+void igemm_set_bf16(bool on);
+bool igemm_get_bf16();
+
 // launch records for the roofline measurement (see igemm.hip)
 void igemm_prof_enable(bool on);
 int igemm_prof_count();

@@ -34,6 +34,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS staging: 1 = ONE stage (32 KiB for the 128x128 tile) with a second barrier in the middle of the K-step,
 // 3 blocks per CU; 0 = two stages (64 KiB), one barrier per K-step, 2 blocks per CU.  Measured on MI355X at batch
@@ -61,7 +66,10 @@ __device__ __forceinline__ float prelu_slope(float z, float a) {
     return z > 0.f ? 1.f : (z == 0.f ? 0.5f * a : a);
 }
 
-template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
+// BF = 1: the same gathers, epilogues and fp32 accumulators, but the operand tiles are rounded to bf16 (RNE) on their way
+// into LDS and multiplied by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): storage stays fp32 in HBM, the kernel
+// turns from MFMA-bound into staging / HBM-bound.  See the BF branch of the main loop.
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF = 0>
 __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
@@ -145,7 +153,9 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     } else {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            const int m = m0 + 4 * ((tid & 7) + 8 * i);
+            // fp32: k-row = tid>>3, m-chunks (tid&7) + 8i.  bf16: k-PAIR = tid>>4, m-chunks (tid&15) + 16i (i < A_CH/2),
+            // so that a thread holds rows k and k+1 of the same 4 m and packs them into 32-bit LDS words.
+            const int m = BF ? m0 + 4 * ((tid & 15) + 16 * i) : m0 + 4 * ((tid & 7) + 8 * i);
             const int t = m / p.a_KC;
             a_c[i] = (m - t * p.a_KC) * 4;
             const int tt = t < p.a_NT ? t : 0;
@@ -157,8 +167,12 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     if constexpr (BL == BL_KN) {
         constexpr int CPR = BN / 4, RPP = 256 / CPR;
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i)
-            b_base[i] = (unsigned)((tid / CPR + RPP * i) * p.b_ld + n0 + ((tid % CPR) << 2)) * 4u;
+        for (int i = 0; i < B_CH; ++i) {
+            if constexpr (BF)      // entry 2j + e: row 2*(tid>>4) + e, n-chunk (tid&15) + 16j
+                b_base[i] = (unsigned)((2 * (tid >> 4) + (i & 1)) * p.b_ld + n0 + (((tid & 15) + 16 * (i >> 1)) << 2)) * 4u;
+            else
+                b_base[i] = (unsigned)((tid / CPR + RPP * i) * p.b_ld + n0 + ((tid % CPR) << 2)) * 4u;
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < B_CH; ++i)
@@ -195,6 +209,24 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
 #pragma unroll
             for (int i = 0; i < A_CH; ++i)
                 ra[i] = ldg(rsrcA, ((a_mask[i] >> tap) & 1) ? a_base[i] + toff : OOB, 0);
+        } else if constexpr (BF) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                  // ra[2j + e]: pixel k0 + 2*(tid>>4) + e, m-chunk j
+                const int pix = k0 + 2 * (tid >> 4) + e;
+                const bool kin = pix < kend;
+                const int hw = p.a_OH * p.a_OW;
+                const int n = pix / hw;
+                const int rem = pix - n * hw;
+                const int oh = rem / p.a_OW;
+                const int ih0 = oh * p.a_stride;
+                const int iw0 = (rem - oh * p.a_OW) * p.a_stride;
+#pragma unroll
+                for (int j = 0; j < A_CH / 2; ++j) {
+                    const int ih = ih0 + (a_dhw[j] & 0xff) - 8, iw = iw0 + ((a_dhw[j] >> 8) & 0xff) - 8;
+                    const bool ok = kin && (a_dhw[j] >> 16) && ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW;
+                    ra[2 * j + e] = ldg(rsrcA, ok ? (unsigned)(((n * p.a_IH + ih) * p.a_IW + iw) * p.a_ld) * 4u + a_c[j] : OOB, 0);
+                }
+            }
         } else {
             const int pix = k0 + (tid >> 3);
             const bool kin = pix < kend;
@@ -216,8 +248,10 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             constexpr int CPR = BN / 4, RPP = 256 / CPR;
             const unsigned koff = (unsigned)(krow_b(k0) * p.b_ld) * 4u;                                 // wave-uniform
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i)
-                rb[i] = ldg(rsrcB, (k0 + tid / CPR + RPP * i < kend) ? b_base[i] : OOB, koff);
+            for (int i = 0; i < B_CH; ++i) {
+                if constexpr (BF) rb[i] = ldg(rsrcB, (k0 + 2 * (tid >> 4) + (i & 1) < kend) ? b_base[i] : OOB, koff);
+                else rb[i] = ldg(rsrcB, (k0 + tid / CPR + RPP * i < kend) ? b_base[i] : OOB, koff);
+            }
         } else {
             const int tap = ktap(k0), kc0 = kchan(k0);
             const unsigned toff = (unsigned)(p.b_tapoff[tap0 + tap] + kc0) * 4u;                        // wave-uniform
@@ -287,6 +321,81 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             }
         }
     };
+    // ---- bf16-operand main loop ------------------------------------------------------------------
+    // LDS image of BOTH operands: [row][32 bf16] (64-byte rows), 16-byte chunk c stored at c ^ ((row>>2)&3): the
+    // ds_read_b128 fragment reads (lane -> row li, chunk 2s + lh = k 16s + 8lh .. +7, exactly the 32x32x16 operand
+    // map) are conflict-free.  k-contiguous sources (MK / NK) convert 4 floats and write 8 bytes; row-contiguous
+    // sources (KM / KN) hold rows k, k+1 of 4 consecutive m (n) and write four 32-bit words -- the transpose
+    // happens in the write pass.  Two stages, one barrier per K-step; the next tile's buffer loads are in flight
+    // under the MFMAs.  No k permutation.
+    if constexpr (BF) {
+        constexpr int STAGE_B = (BM + BN) * 64;                       // bytes per stage
+        char* lds = reinterpret_cast<char*>(smem);
+        auto off16 = [](int row, int chunk) -> int { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); };
+        auto pk = [](float a, float b) -> unsigned {
+            return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+        };
+        auto store_bf = [&](int stage) {
+            char* As = lds + stage * STAGE_B;
+            char* Bs = As + BM * 64;
+            if constexpr (AL == AL_MK) {
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    const int r = (tid >> 3) + 32 * i, c8 = tid & 7;
+                    *reinterpret_cast<u32x2*>(As + off16(r, c8 >> 1) + (c8 & 1) * 8) = u32x2{pk(ra[i][0], ra[i][1]), pk(ra[i][2], ra[i][3])};
+                }
+            } else {
+                const int kp = tid >> 4;
+#pragma unroll
+                for (int j = 0; j < A_CH / 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r = 4 * ((tid & 15) + 16 * j) + t;
+                        *reinterpret_cast<unsigned*>(As + off16(r, kp >> 2) + (kp & 3) * 4) = pk(ra[2 * j][t], ra[2 * j + 1][t]);
+                    }
+            }
+            if constexpr (BL == BL_NK) {
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i) {
+                    const int r = (tid >> 3) + 32 * i, c8 = tid & 7;
+                    *reinterpret_cast<u32x2*>(Bs + off16(r, c8 >> 1) + (c8 & 1) * 8) = u32x2{pk(rb[i][0], rb[i][1]), pk(rb[i][2], rb[i][3])};
+                }
+            } else {
+                const int kp = tid >> 4;
+#pragma unroll
+                for (int j = 0; j < B_CH / 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r = 4 * ((tid & 15) + 16 * j) + t;
+                        *reinterpret_cast<unsigned*>(Bs + off16(r, kp >> 2) + (kp & 3) * 4) = pk(rb[2 * j][t], rb[2 * j + 1][t]);
+                    }
+            }
+        };
+        if (nsteps > 0) load_tiles(kbeg);
+        for (int s = 0; s < nsteps; ++s) {
+            store_bf(s & 1);
+            __syncthreads();
+            if (s + 1 < nsteps) load_tiles(kbeg + (s + 1) * BK);
+            const char* As = lds + (s & 1) * STAGE_B;
+            const char* Bs = As + BM * 64;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(As + off16(wm * (TM * 32) + i * 32 + li, 2 * h + lh));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const bf16x8*>(Bs + off16(wn * (TN * 32) + j * 32 + li, 2 * h + lh));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();           // the epilogue reuses the LDS image
+    } else
     // ---- main loop, hand-slotted --------------------------------------------------------------
     // One K-step = NM MFMAs per wave.  Each MFMA is followed by at most one "payload" operation and a
     // scheduling fence, so the issue order below is the order in the binary:
@@ -650,11 +759,13 @@ hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
-hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF>
+hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
-    const size_t lds = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
-    auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI>;
+    // fp32: one stage of (BM+BN) x 32 floats; bf16: two stages of (BM+BN) x 64 bytes -- the same size, and at least the
+    // BM ints the epilogue's row-offset table needs
+    const size_t lds = BF ? 2 * (size_t)(BM + BN) * 64 : (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
+    auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -669,6 +780,13 @@ hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
     } else if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(256), lds, st, p);
     else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(256), lds, st, p);
     return hipGetLastError();
+}
+
+bool g_bf16 = false;      // igemm_set_bf16(): operand precision of every launch of the family
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
+hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
+    if (g_bf16) return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 1>(p, splits, st);
+    return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 0>(p, splits, st);
 }
 
 template <int AL, int BL, int EPI>
@@ -725,6 +843,9 @@ hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipS
     if (epi == EPI_FWD) return fixup_tile<EPI_FWD>(p, tile, splits, st);
     return fixup_tile<EPI_DGRAD>(p, tile, splits, st);
 }
+
+void igemm_set_bf16(bool on) { g_bf16 = on; }
+bool igemm_get_bf16() { return g_bf16; }
 
 void igemm_prof_enable(bool on) {
     if (on) prof_clear();
