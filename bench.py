@@ -39,6 +39,7 @@ CH = 3
 NUM_CLASSES = 10575
 MAC_PER_IMAGE_RESBLOCK_CONV = 115605504
 FP32_MFMA_PEAK_TFLOPS = 157.3                    # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0                   # same table, "Peak BF16/FP16 MFMA" (dense)
 LR = 1e-4
 
 
@@ -80,6 +81,9 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=8)
     ap.add_argument('--global-batch', type=int, default=GLOBAL_BATCH,
                     help='exploration only (e.g. the per-rank shard sizes of N=2/4/8 on one GPU); the metric is quoted at 512')
+    ap.add_argument('--mfma-dtype', choices=['f32', 'bf16'], default='f32',
+                    help="operand precision of the MFMA products (fte_set_mfma_dtype).  The metric (BASELINE.json configs[1]) is "
+                         "fp32 = the default; bf16 = bf16 operands, fp32 accumulate, fp32 storage (exploration, configs[2]'s precision)")
     args = ap.parse_args()
 
     import torch
@@ -122,6 +126,8 @@ def main():
         torch.cuda.synchronize()
 
     from tf_face_toolbox_amd import _lib
+    _lib.set_mfma_dtype(args.mfma_dtype)
+    peak = FP32_MFMA_PEAK_TFLOPS if args.mfma_dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
     for _ in range(args.warmup):
         train_ops()
     barrier()
@@ -162,7 +168,7 @@ def main():
         all_flops = sum(v[1] for v in table.values())
         traffic, tinfo = None, None
         tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
-        if world == 1 and os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath) and args.mfma_dtype == 'f32':
             tinfo = json.load(open(tpath))       # PMC passes cannot run inside this process: measured by
             traffic = tinfo['bytes_per_launch']   # rocprofv3 --pmc on this same command, kept under profiles/
         out = {
@@ -174,24 +180,24 @@ def main():
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': args.mfma_dtype,
             'data': 'synthetic',
-            'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch %d, 10575 classes, Momentum, fp32' % gb,
+            'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch %d, 10575 classes, Momentum, %s' % (gb, 'fp32' if args.mfma_dtype == 'f32' else 'bf16 MFMA operands / fp32 accumulate + storage'),
                        'global_batch': gb, 'per_gpu_batch': shard, 'lr': LR, 'parallelism': 'dp%d' % world,
                        'train_gflop_per_image': 12.2698},
-            'step_mfma_frac': round(gb * args.steps / elapsed * 12.2698e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) / world, 4),
+            'step_mfma_frac': round(gb * args.steps / elapsed * 12.2698e9 / (peak * 1e12) / world, 4),
             'losses': dict(zip(losses_name, [round(v, 6) for v in loss_vals])),
             'roofline': {'bound': 'mfma',
                          'kernel': 'igemm_kernel<%s,2,2,%d,%d,%d> = conv3x3 forward + bias/PReLU/residual (fp32 MFMA implicit GEMM)' % ({0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64'}[DOM[3]], DOM[0], DOM[1], DOM[2]),
-                         'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'launches_timed': cnt, 'avg_launch_ms': round(avg_ms, 4),
                          'flops_per_launch_avg': flops,
                          'traffic': traffic, 'traffic_source': (tinfo or {}).get('summary_file'),
                          'algorithmic_bytes_per_launch': (tinfo or {}).get('algorithmic_bytes_per_launch'),
                          'all_mfma_kernels': {'launches': len(records), 'ms_per_step': round(all_ms / args.steps, 3),
                                               'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 2),
-                                              'frac': round(all_flops / (all_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}},
+                                              'frac': round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_sample)

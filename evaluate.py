@@ -72,3 +72,8 @@ def evaluate(FLAGS):
 
 if __name__ == '__main__':
     evaluate(build_parser().parse_args())
+    # leave without running interpreter / HIP runtime teardown: on ROCm 7 an exit-time race between torch's helper
+    # threads and the runtime's static destructors occasionally ends a finished run with std::terminate (exit code -6)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)

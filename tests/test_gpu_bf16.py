@@ -11,7 +11,7 @@ from oracle import ops
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from util_gpu import dev, host, stream, ws, check_maxabs, check_rell2
+    from util_gpu import dev, host, stream, ws, check_maxabs, check_rell2, kink_of
     from tf_face_toolbox_amd import _lib
 
 
@@ -85,3 +85,35 @@ def test_dense_gemms_bf16_operands(bf16_mode, m, n, k):
     db = torch.empty(k, n, device='cuda')
     _lib.call('fte_gemm_tn', ad, gd, db, m, n, k, buf, nb, stream())
     check_rell2(host(db), rb(a).T @ rb(g), 2e-5, 'tn')
+
+
+def test_spherenet_step_bf16_vs_oracle_and_training(bf16_mode):
+    """Whole SphereNet-ASoftmax step in the bf16-operand mode against the UNROUNDED float64 oracle at the stated
+    mixed-precision tolerance (rel-L2 1e-2 on embeddings / logits, 2e-2 on gradients), then a few optimizer steps."""
+    from oracle import spherenet as osn
+    from tf_face_toolbox_amd import net_select, Singular
+    n, h, w, ch, ncls = 8, 64, 64, 3, 40
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (n, h, w, ch)); y = rng.integers(0, ncls, n)
+    net = net_select('SphereNet', 'NHWC', 5e-4)
+    net.build(h, w, ch, ncls, 'cuda')
+    p = {k: host(net.get_variable(k)) for k in net.variables}
+    out = net.forward(dev(x), num_classes=ncls, is_training=True)
+    losses, names, _ = net.loss_function('T', dev(y, torch.int32), **out)
+    net.backward()
+    torch.cuda.synchronize()
+    l_ref, g_ref, cache = osn.loss_and_grads(p, x, y, data_format='NHWC', weight_decay=5e-4, kink=kink_of(net))
+    check_rell2(host(out['logits']), cache['logits'], 1e-2, 'logits (bf16 operands)')
+    assert abs(float(losses[0]) - l_ref[0]) <= 1e-2 * l_ref[0]
+    worst = 0.0
+    for k in net.variables:
+        got = host(net.get_variable(k, net.grads)) + (5e-4 * p[k] if k.endswith('/weights') else 0)
+        worst = max(worst, check_rell2(got, g_ref[k], 3e-2, 'grad ' + k))
+    assert worst > 1e-5                                     # it is the bf16 path, not fp32
+    step, ls, names, _ = Singular(net_select('SphereNet-ASoftmax', 'NCHW', 5e-4), 0.01, 'Momentum')(
+        {'images': dev(x), 'labels': dev(y, torch.int32), 'num_classes': ncls, 'num_examples': n})
+    hist = []
+    for _ in range(30):
+        step()
+        hist.append(float(ls[0]))
+    assert np.isfinite(hist).all() and hist[-1] < hist[0]

@@ -24,6 +24,11 @@
 // one b128 read feeds four consecutive MFMAs; A and B use the same permutation.
 // The K-step is hand-slotted: every MFMA is followed by at most one payload operation (a buffer
 // load of the next tile, a fragment-read group, an LDS write) and a scheduling fence.
+// Epilogue: every wave transposes its 32x32 accumulator blocks through a private LDS patch so that all global
+// accesses of the epilogue are 16 bytes per lane (8 rows x 128 B per wave instruction).
+// BF = 1 (fte_set_mfma_dtype(FTE_MFMA_BF16)): same gathers / epilogues / fp32 accumulators, operand tiles rounded to
+// bf16 on the way into LDS ([row][32 bf16] images for BOTH operands, row-contiguous sources transposed in the write
+// pass) and multiplied by v_mfma_f32_32x32x16_bf16.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,6 +51,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef FTE_SINGLE
 #define FTE_SINGLE 1
 #endif
+
 
 namespace {
 
@@ -195,13 +201,13 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         else return k0;
     };
 
-    f32x4 ra[A_CH], rb[B_CH];
+    f32x4 ra0[A_CH], rb0[B_CH];
 
     auto ldg = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) -> f32x4 {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int k0, f32x4 (&ra)[A_CH], f32x4 (&rb)[B_CH]) {
         // ---------------- A ----------------
         if constexpr (AL == AL_MK) {
             const int tap = ktap(k0), kc0 = kchan(k0);
@@ -260,6 +266,8 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         }
     };
 
+    f32x4 (&ra)[A_CH] = ra0;
+    f32x4 (&rb)[B_CH] = rb0;
     auto store_tiles = [&](int stage) {
         float* As = smem + stage * STAGE;
         float* Bs = As + BM * BK;
@@ -326,23 +334,42 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     // ds_read_b128 fragment reads (lane -> row li, chunk 2s + lh = k 16s + 8lh .. +7, exactly the 32x32x16 operand
     // map) are conflict-free.  k-contiguous sources (MK / NK) convert 4 floats and write 8 bytes; row-contiguous
     // sources (KM / KN) hold rows k, k+1 of 4 consecutive m (n) and write four 32-bit words -- the transpose
-    // happens in the write pass.  Two stages, one barrier per K-step; the next tile's buffer loads are in flight
-    // under the MFMAs.  No k permutation.
+    // happens in the write pass.  One LDS image per macro step (two barriers); the next macro step's buffer loads are in
+    // flight under the MFMAs.  No k permutation.
     if constexpr (BF) {
-        constexpr int STAGE_B = (BM + BN) * 64;                       // bytes per stage
         char* lds = reinterpret_cast<char*>(smem);
         auto off16 = [](int row, int chunk) -> int { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); };
         auto pk = [](float a, float b) -> unsigned {
             return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
         };
-        auto store_bf = [&](int stage) {
-            char* As = lds + stage * STAGE_B;
+        // KS sub-steps of 32 k form one macro step: all of its buffer loads are issued together and stay in flight
+        // under the previous macro step's MFMAs -- with 2 MFMAs per wave and sub-step the loop is latency-bound, and
+        // measured on MI355X KS = 1 / 2 / 4 are within 1 % of each other (the loop is bound by the L1 / texture-address
+        // path, not by latency); kept because it halves the barrier count.
+        constexpr int KS = (BM + BN) <= 128 ? 4 : ((BM + BN) <= 256 ? 2 : 1);
+        constexpr int SUB_B = (BM + BN) * 64;                          // bytes per sub-step image
+        f32x4 qa[KS][A_CH], qb[KS][B_CH];
+        auto load_macro = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                if (k0 + u * BK < kend) {
+                    load_tiles(k0 + u * BK, qa[u], qb[u]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < A_CH; ++i) qa[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < B_CH; ++i) qb[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        auto store_bf = [&](int u) {
+            char* As = lds + u * SUB_B;
             char* Bs = As + BM * 64;
             if constexpr (AL == AL_MK) {
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     const int r = (tid >> 3) + 32 * i, c8 = tid & 7;
-                    *reinterpret_cast<u32x2*>(As + off16(r, c8 >> 1) + (c8 & 1) * 8) = u32x2{pk(ra[i][0], ra[i][1]), pk(ra[i][2], ra[i][3])};
+                    *reinterpret_cast<u32x2*>(As + off16(r, c8 >> 1) + (c8 & 1) * 8) = u32x2{pk(qa[u][i][0], qa[u][i][1]), pk(qa[u][i][2], qa[u][i][3])};
                 }
             } else {
                 const int kp = tid >> 4;
@@ -351,14 +378,14 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int r = 4 * ((tid & 15) + 16 * j) + t;
-                        *reinterpret_cast<unsigned*>(As + off16(r, kp >> 2) + (kp & 3) * 4) = pk(ra[2 * j][t], ra[2 * j + 1][t]);
+                        *reinterpret_cast<unsigned*>(As + off16(r, kp >> 2) + (kp & 3) * 4) = pk(qa[u][2 * j][t], qa[u][2 * j + 1][t]);
                     }
             }
             if constexpr (BL == BL_NK) {
 #pragma unroll
                 for (int i = 0; i < B_CH; ++i) {
                     const int r = (tid >> 3) + 32 * i, c8 = tid & 7;
-                    *reinterpret_cast<u32x2*>(Bs + off16(r, c8 >> 1) + (c8 & 1) * 8) = u32x2{pk(rb[i][0], rb[i][1]), pk(rb[i][2], rb[i][3])};
+                    *reinterpret_cast<u32x2*>(Bs + off16(r, c8 >> 1) + (c8 & 1) * 8) = u32x2{pk(qb[u][i][0], qb[u][i][1]), pk(qb[u][i][2], qb[u][i][3])};
                 }
             } else {
                 const int kp = tid >> 4;
@@ -367,34 +394,39 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int r = 4 * ((tid & 15) + 16 * j) + t;
-                        *reinterpret_cast<unsigned*>(Bs + off16(r, kp >> 2) + (kp & 3) * 4) = pk(rb[2 * j][t], rb[2 * j + 1][t]);
+                        *reinterpret_cast<unsigned*>(Bs + off16(r, kp >> 2) + (kp & 3) * 4) = pk(qb[u][2 * j][t], qb[u][2 * j + 1][t]);
                     }
             }
         };
-        if (nsteps > 0) load_tiles(kbeg);
-        for (int s = 0; s < nsteps; ++s) {
-            store_bf(s & 1);
+        const int nmacro = (nsteps + KS - 1) / KS;
+        if (nmacro > 0) load_macro(kbeg);
+        for (int ms = 0; ms < nmacro; ++ms) {
+#pragma unroll
+            for (int u = 0; u < KS; ++u) store_bf(u);
             __syncthreads();
-            if (s + 1 < nsteps) load_tiles(kbeg + (s + 1) * BK);
-            const char* As = lds + (s & 1) * STAGE_B;
-            const char* Bs = As + BM * 64;
+            if (ms + 1 < nmacro) load_macro(kbeg + (ms + 1) * KS * BK);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                bf16x8 fa[TM], fb[TN];
+            for (int u = 0; u < KS; ++u) {
+                const char* As = lds + u * SUB_B;
+                const char* Bs = As + BM * 64;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[i] = *reinterpret_cast<const bf16x8*>(As + off16(wm * (TM * 32) + i * 32 + li, 2 * h + lh));
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8 fa[TM], fb[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[j] = *reinterpret_cast<const bf16x8*>(Bs + off16(wn * (TN * 32) + j * 32 + li, 2 * h + lh));
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
+                        fa[i] = *reinterpret_cast<const bf16x8*>(As + off16(wm * (TM * 32) + i * 32 + li, 2 * h + lh));
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        fb[j] = *reinterpret_cast<const bf16x8*>(Bs + off16(wn * (TN * 32) + j * 32 + li, 2 * h + lh));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
             }
+            __syncthreads();       // every wave has read this image; also: the epilogue reuses the LDS
         }
-        __syncthreads();           // the epilogue reuses the LDS image
     } else
     // ---- main loop, hand-slotted --------------------------------------------------------------
     // One K-step = NM MFMAs per wave.  Each MFMA is followed by at most one "payload" operation and a
@@ -408,7 +440,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         constexpr int NM = 16 * TM * TN, Q = 4 * TM * TN, NL = A_CH + B_CH;
         static_assert(NM - NL >= 2 * Q + 1, "payload slots overlap");
         if (nsteps > 0) {
-            load_tiles(kbeg);
+            load_tiles(kbeg, ra0, rb0);
             store_tiles(0);
             __syncthreads();
         }
@@ -545,84 +577,107 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     }
     __syncthreads();
 
-    if constexpr (EPI == EPI_FWD) {
-        float* Y = p.Y + (long)split * p.slab;
+    {
+        // ---- LDS-staged epilogue, 16 bytes per lane --------------------------------------------------------------
+        // The accumulator layout (lane = column) gives 4-byte global accesses, 256 B per wave instruction -- a quarter
+        // of what the texture-address path moves per clock.  Each wave transposes its 32x32 blocks through a private
+        // 32 x 36 float LDS patch and then touches global memory as 8 rows x 128 B per instruction.  With bf16 MFMAs the
+        // epilogue is no longer hidden under other blocks' matrix work (56x56x64 layer 0.87 -> 0.65 ms); the fp32
+        // kernels gain 1-3 %.
+        float* patch = smem + BM + wid * (32 * 36);              // after the BM row offsets
+        const int prw = lane >> 3, pc4 = lane & 7;
+        f32x4 sa4[TN], sb4[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { sa4[j] = f32x4{0.f, 0.f, 0.f, 0.f}; sb4[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        float* Y = nullptr;
+        if constexpr (EPI == EPI_FWD) Y = p.Y + (long)split * p.slab;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (TN * 32) + j * 32 + li;
-            const float bias = p.bias ? p.bias[col] : 0.f;
-            const bool act = p.alpha != nullptr;
-            const float al = act ? p.alpha[col] : 1.f;
+            const int col = n0 + wn * (TN * 32) + j * 32 + 4 * pc4;
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f};
+            bool act = false;
+            if constexpr (EPI == EPI_FWD) {
+                if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+                act = p.alpha != nullptr;
+                if (act) al4 = *reinterpret_cast<const f32x4*>(p.alpha + col);
+            } else {
+                act = p.Zin != nullptr;
+                if (act) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int off = rowoff[rl];
-                    if (off < 0) continue;
-                    const long o = (long)off + col;
-                    float v = acc[i][j][r] + bias;
-                    if (p.Z) p.Z[o] = v;
-                    if (act) v = v > 0.f ? v : al * v;
-                    if (p.R) v += p.R[o];
-                    Y[o] = v;
+                    for (int e = 0; e < 4; ++e) al4[e] = p.alpha[(col + e) % p.amod];
                 }
             }
-        }
-    } else {   // EPI_DGRAD
-        float sa[TN], sb[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            sa[j] = 0.f;
-            sb[j] = 0.f;
-            const int col = n0 + wn * (TN * 32) + j * 32 + li;
-            const bool msk = p.Zin != nullptr;
-            const float al = msk ? p.alpha[col % p.amod] : 1.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int off = rowoff[rl];
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rr = prw + 8 * ps;
+                    const int off = rowoff[wm * (TM * 32) + i * 32 + rr];
+                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + rr * 36 + 4 * pc4);
                     if (off < 0) continue;
                     const long o = (long)off + col;
-                    float v = acc[i][j][r];
-                    if (p.ADD) v += p.ADD[o];
-                    if (p.RAW) p.RAW[o] = v;
-                    if (msk) {
-                        const float z = p.Zin[o];
-                        sa[j] += v * fminf(z, 0.f);
-                        v *= prelu_slope(z, al);
-                        sb[j] += v;
+                    if constexpr (EPI == EPI_FWD) {
+                        v += bias4;
+                        if (p.Z) *reinterpret_cast<f32x4*>(p.Z + o) = v;
+                        if (act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : al4[e] * v[e];
+                        }
+                        if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + o);
+                        *reinterpret_cast<f32x4*>(Y + o) = v;
+                    } else {
+                        if (p.ADD) v += *reinterpret_cast<const f32x4*>(p.ADD + o);
+                        if (p.RAW) *reinterpret_cast<f32x4*>(p.RAW + o) = v;
+                        if (act) {
+                            const f32x4 z = *reinterpret_cast<const f32x4*>(p.Zin + o);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                sa4[j][e] += v[e] * fminf(z[e], 0.f);
+                                v[e] *= prelu_slope(z[e], al4[e]);
+                                sb4[j][e] += v[e];
+                            }
+                        }
+                        *reinterpret_cast<f32x4*>(p.DZ + o) = v;
                     }
-                    p.DZ[o] = v;
                 }
             }
         }
-        if (p.PA) {        // per-block column partials (dalpha, dbias), reduced later in a fixed order
-            __syncthreads();
-            float* red = smem + 256;                      // [2][WM][BN], past rowoff
+        if constexpr (EPI == EPI_DGRAD) {
+            if (p.PA) {    // per-block column partials (dalpha, dbias), reduced later in a fixed order
+                __syncthreads();
+                float* red = smem + BM + 4 * (32 * 36);              // [2][WM][BN], past the patches
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                sa[j] += __shfl_xor(sa[j], 32);
-                sb[j] += __shfl_xor(sb[j], 32);
-                if (lh == 0) {
-                    const int c = wn * (TN * 32) + j * 32 + li;
-                    red[wm * BN + c] = sa[j];
-                    red[(WM + wm) * BN + c] = sb[j];
-                }
-            }
-            __syncthreads();
-            for (int c = tid; c < BN; c += 256) {
-                float a = 0.f, b = 0.f;
+                for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                for (int w = 0; w < WM; ++w) {
-                    a += red[w * BN + c];
-                    b += red[(WM + w) * BN + c];
+                    for (int e = 0; e < 4; ++e) {
+                        float a = sa4[j][e], b = sb4[j][e];
+                        a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
+                        a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+                        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+                        if (prw == 0) {
+                            const int c = wn * (TN * 32) + j * 32 + 4 * pc4 + e;
+                            red[wm * BN + c] = a;
+                            red[(WM + wm) * BN + c] = b;
+                        }
+                    }
                 }
-                const long o = (long)(prow + mt) * p.N + n0 + c;
-                p.PA[o] = a;
-                if (p.PB) p.PB[o] = b;
+                __syncthreads();
+                for (int c = tid; c < BN; c += 256) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) {
+                        a += red[w * BN + c];
+                        b += red[(WM + w) * BN + c];
+                    }
+                    const long o = (long)(prow + mt) * p.N + n0 + c;
+                    p.PA[o] = a;
+                    if (p.PB) p.PB[o] = b;
+                }
             }
         }
     }
@@ -762,9 +817,13 @@ hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF>
 hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
-    // fp32: one stage of (BM+BN) x 32 floats; bf16: two stages of (BM+BN) x 64 bytes -- the same size, and at least the
-    // BM ints the epilogue's row-offset table needs
-    const size_t lds = BF ? 2 * (size_t)(BM + BN) * 64 : (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
+    // fp32: one stage of (BM+BN) x 32 floats; bf16: KS sub-step images of (BM+BN) x 64 bytes (one macro step); both hold
+    // at least the BM ints of the epilogue's row-offset table
+    constexpr int KSL = (BM + BN) <= 128 ? 4 : ((BM + BN) <= 256 ? 2 : 1);
+    const size_t epi = (size_t)(BM + 4 * 32 * 36 + 2 * WM * BN) * sizeof(float);      // row offsets + 4 transpose patches + column partials
+    const size_t loop = (size_t)KSL * (BM + BN) * 64;
+    const size_t loop32 = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
+    const size_t lds = BF ? (loop > epi ? loop : epi) : (epi > loop32 ? epi : loop32);
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>;
     static bool attr_done = false;
     if (!attr_done) {

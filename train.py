@@ -57,6 +57,8 @@ def build_parser():
     parser.add_argument('--synthetic', type=int, default=0, help='1: resident random batch instead of a list file.')
     parser.add_argument('--synthetic_classes', type=int, default=10575)
     parser.add_argument('--max_steps', type=int, default=-1, help='Stop after this many steps (smoke runs).')
+    parser.add_argument('--mfma_dtype', type=str, default='f32',
+                        help='f32 (the reference arithmetic) or bf16 (bf16 MFMA operands, fp32 accumulate and storage).')
     return parser
 
 
@@ -127,6 +129,8 @@ def train(FLAGS):
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
+    from tf_face_toolbox_amd import _lib
+    _lib.set_mfma_dtype(FLAGS.mfma_dtype)
 
     batch_size = FLAGS.batch_size if FLAGS.batch_size != -1 else FLAGS.num_classes * FLAGS.num_per_class
     # Data I/O (train.py:161-170)
@@ -208,3 +212,8 @@ def main(argv=None):
 
 if __name__ == '__main__':
     main()
+    # leave without running interpreter / HIP runtime teardown: on ROCm 7 an exit-time race between torch's helper
+    # threads and the runtime's static destructors occasionally ends a finished run with std::terminate (exit code -6)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
