@@ -733,19 +733,19 @@ int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h,
 size_t fte_gconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int groups, int stride) {
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     const int gw = c / groups;
-    return (size_t)l_gconv_wgrad_chunks((long)n * ph.out * pw.out) * 9 * c * gw * sizeof(float) + SCRATCH_BYTES;
+    return align_up((size_t)l_gconv_wgrad_chunks((long)n * ph.out * pw.out, c, gw) * 9 * c * gw * sizeof(float)) + SCRATCH_BYTES;
 }
 int fte_gconv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups, int stride,
                        void* ws, size_t ws_bytes, void* stream) {
     if (!x || !dz || !dw || n <= 0 || groups <= 0 || c % groups || (stride != 1 && stride != 2)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     const int gw = c / groups;
-    const int chunks = l_gconv_wgrad_chunks((long)n * ph.out * pw.out);
-    const size_t need = (size_t)chunks * 9 * c * gw * sizeof(float);
-    if (!ws || ws_bytes < need) return FTE_EWORKSPACE;
+    const int chunks = l_gconv_wgrad_chunks((long)n * ph.out * pw.out, c, gw);
+    const size_t need = align_up((size_t)chunks * 9 * c * gw * sizeof(float));
+    if (!ws || ws_bytes < need + SCRATCH_BYTES) return FTE_EWORKSPACE;
     hipError_t e = l_gconv_wgrad(x, dz, (float*)ws, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before, chunks, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, chunks, 9L * c * gw, 1, 1.f, nullptr, (hipStream_t)stream));
+    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, chunks, 9L * c * gw, 1, 1.f, (float*)((char*)ws + need), (hipStream_t)stream));
 }
 int fte_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, void* stream) {
     if (!dx || !v || n <= 0 || c % 4) return FTE_EINVAL;

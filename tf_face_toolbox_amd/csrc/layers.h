@@ -27,7 +27,7 @@ hipError_t l_gconv_fwd(const float* x, const float* w, float* y, int n, int h, i
                        int stride, int pt, int pl, hipStream_t st);
 hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int ho, int wo,
                          int stride, int pt, int pl, hipStream_t st);
-int l_gconv_wgrad_chunks(long npix);
+int l_gconv_wgrad_chunks(long npix, int c, int gw);
 hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int c, int groups, int ho, int wo,
                          int stride, int pt, int pl, int chunks, hipStream_t st);
 hipError_t l_act_fwd(const float* x, float* y, long n, int kind, hipStream_t st);
