@@ -154,9 +154,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int ch = blockIdx.x * 16 + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (ch < C)
-        for (int s = lane; s < splits; s += 16) {
-            const float* pp = part + (long)s * 3 * C;
-            chan_merge(n, mean, m2, pp[ch], pp[C + ch], pp[2 * C + ch]);
+        for (int s0 = lane; s0 < splits; s0 += 64) {        // 4 splits per trip: 12 independent loads, then the merges
+            float nb[4], mb[4], qb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + 16 * u;
+                const bool ok = s < splits;
+                const float* pp = part + (long)(ok ? s : 0) * 3 * C;
+                nb[u] = ok ? pp[ch] : 0.f; mb[u] = pp[C + ch]; qb[u] = pp[2 * C + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) chan_merge(n, mean, m2, nb[u], mb[u], qb[u]);
         }
     sh[0][lane][cl] = n; sh[1][lane][cl] = mean; sh[2][lane][cl] = m2;
     __syncthreads();
@@ -259,11 +267,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cl;
     float sg = 0.f, sgx = 0.f;
-    if (ch < C)
+    if (ch < C) {
+#pragma unroll 4
         for (int s = lane; s < splits; s += 16) {
             sg += part[(long)s * 2 * C + ch];
             sgx += part[(long)s * 2 * C + C + ch];
         }
+    }
     sh[0][lane][cl] = sg; sh[1][lane][cl] = sgx;
     __syncthreads();
     if (lane != 0 || ch >= C) return;
@@ -646,21 +656,38 @@ __global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __rest
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (g < groups && threadIdx.x < GPB * TPG) {
-        for (long p = p0; p < p1; ++p) {
-            const int ow = (int)(p % wo);
-            const long t2 = p / wo;
-            const int oh = (int)(t2 % ho), img = (int)(t2 / ho);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dz + p * c + g * GW + oq * 4);
+        // 4 pixels per trip: their 40 loads are independent and issued together (branch-free: clamped address, zero
+        // factor) -- one pixel per trip left the loop waiting on one memory round trip per pixel
+        constexpr int UP = 4;
+        for (long pb = p0; pb < p1; pb += UP) {
+            f32x4 d[UP];
+            float xs[UP][9];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int ih = oh * stride + r - pt;
+            for (int u = 0; u < UP; ++u) {
+                const long p = pb + u;
+                const bool pok = p < p1;
+                const long pp = pok ? p : p0;
+                const int ow = (int)(pp % wo);
+                const long t2 = pp / wo;
+                const int oh = (int)(t2 % ho), img = (int)(t2 / ho);
+                d[u] = *reinterpret_cast<const f32x4*>(dz + pp * c + g * GW + oq * 4);
+                if (!pok) d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int iw = ow * stride + q - pl;
-                    if (ih >= 0 && ih < h && iw >= 0 && iw < wd)
-                        acc[r * 3 + q] += x[((long)(img * h + ih) * wd + iw) * c + g * GW + ic] * d;
+                for (int r = 0; r < 3; ++r) {
+                    const int ih = oh * stride + r - pt;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int iw = ow * stride + q - pl;
+                        const bool ok = ih >= 0 && ih < h && iw >= 0 && iw < wd;
+                        const float v = x[((long)(img * h + (ok ? ih : 0)) * wd + (ok ? iw : 0)) * c + g * GW + ic];
+                        xs[u][r * 3 + q] = ok ? v : 0.f;
+                    }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < UP; ++u)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] += xs[u][t] * d[u];
         }
         float* out = part + ((long)blockIdx.x * groups + g) * 9 * GW * GW;
 #pragma unroll
