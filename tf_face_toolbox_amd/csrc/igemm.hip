@@ -196,10 +196,6 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         return t;
     };
     auto kchan = [&](int k0) -> int { return ((k0 >> 5) / NT) << 5; };
-    auto krow_b = [&](int k0) -> int {        // first B row ([k][n] layout) of the K-step
-        if constexpr (AL == AL_MK) return ktap(k0) * p.a_KC + kchan(k0);
-        else return k0;
-    };
 
     f32x4 ra0[A_CH], rb0[B_CH];
 
@@ -207,10 +203,11 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
 
-    auto load_tiles = [&](int k0, f32x4 (&ra)[A_CH], f32x4 (&rb)[B_CH]) {
+    // (tap, kc0) = (ktap(k0), kchan(k0)): the bf16 loop keeps them incrementally -- the two integer divisions cost ~40
+    // scalar instructions per K-step, invisible next to sixteen 64-cycle fp32 MFMAs but not next to two 32-cycle bf16 ones
+    auto load_tiles = [&](int k0, int tap, int kc0, f32x4 (&ra)[A_CH], f32x4 (&rb)[B_CH]) {
         // ---------------- A ----------------
         if constexpr (AL == AL_MK) {
-            const int tap = ktap(k0), kc0 = kchan(k0);
             const unsigned toff = (unsigned)((p.a_dh[tap0 + tap] * p.a_IW + p.a_dw[tap0 + tap]) * p.a_ld + kc0) * 4u;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_CH; ++i)
@@ -252,14 +249,13 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         // ---------------- B ----------------
         if constexpr (BL == BL_KN) {
             constexpr int CPR = BN / 4, RPP = 256 / CPR;
-            const unsigned koff = (unsigned)(krow_b(k0) * p.b_ld) * 4u;                                 // wave-uniform
+            const unsigned koff = (unsigned)((AL == AL_MK ? tap * p.a_KC + kc0 : k0) * p.b_ld) * 4u;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
                 if constexpr (BF) rb[i] = ldg(rsrcB, (k0 + 2 * (tid >> 4) + (i & 1) < kend) ? b_base[i] : OOB, koff);
                 else rb[i] = ldg(rsrcB, (k0 + tid / CPR + RPP * i < kend) ? b_base[i] : OOB, koff);
             }
         } else {
-            const int tap = ktap(k0), kc0 = kchan(k0);
             const unsigned toff = (unsigned)(p.b_tapoff[tap0 + tap] + kc0) * 4u;                        // wave-uniform
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) rb[i] = ldg(rsrcB, b_base[i], toff);
@@ -343,17 +339,26 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
         };
         // KS sub-steps of 32 k form one macro step: all of its buffer loads are issued together and stay in flight
-        // under the previous macro step's MFMAs -- with 2 MFMAs per wave and sub-step the loop is latency-bound, and
-        // measured on MI355X KS = 1 / 2 / 4 are within 1 % of each other (the loop is bound by the L1 / texture-address
-        // path, not by latency); kept because it halves the barrier count.
-        constexpr int KS = (BM + BN) <= 128 ? 4 : ((BM + BN) <= 256 ? 2 : 1);
+        // under the previous macro step's MFMAs.  PMC on the 14x14x256 forward layer: 17 VALU + 20 SALU + 3.6 LDS + 2
+        // VMEM instructions per MFMA, MFMA pipe 14 % busy -- the loop is instruction-issue bound, not latency bound
+        // (KS = 1 / 2 / 4 run within 1 % of each other on the 64x64 tile).
+        // 64x64 tiles: KS = 4 sub-steps per macro step in ONE LDS image (two barriers per macro step).  Bigger tiles:
+        // KS = 1 with TWO images and one barrier per step -- with KS = 2 the 128x128 wgrad kernel spills and ran the
+        // 14x14x256 filter gradient at 0.53 ms instead of 0.31.
+        constexpr int KS = (BM + BN) <= 128 ? 4 : 1;
+        constexpr int NST = KS == 1 ? 2 : 1;
         constexpr int SUB_B = (BM + BN) * 64;                          // bytes per sub-step image
         f32x4 qa[KS][A_CH], qb[KS][B_CH];
+        int ptap = 0, pkc = 0;                                         // (tap, channel chunk) of the next sub-step to load
+        if constexpr (AL == AL_MK || BL == BL_NK) { ptap = ktap(kbeg); pkc = kchan(kbeg); }
         auto load_macro = [&](int k0) {
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
                 if (k0 + u * BK < kend) {
-                    load_tiles(k0 + u * BK, qa[u], qb[u]);
+                    load_tiles(k0 + u * BK, ptap, pkc, qa[u], qb[u]);
+                    if constexpr (AL == AL_MK || BL == BL_NK) {
+                        if (++ptap == NT) { ptap = 0; pkc += BK; }
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < A_CH; ++i) qa[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -362,8 +367,8 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 }
             }
         };
-        auto store_bf = [&](int u) {
-            char* As = lds + u * SUB_B;
+        auto store_bf = [&](int u, int stage) {
+            char* As = lds + (stage * KS + u) * SUB_B;
             char* Bs = As + BM * 64;
             if constexpr (AL == AL_MK) {
 #pragma unroll
@@ -401,13 +406,14 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         const int nmacro = (nsteps + KS - 1) / KS;
         if (nmacro > 0) load_macro(kbeg);
         for (int ms = 0; ms < nmacro; ++ms) {
+            const int stage = NST == 2 ? (ms & 1) : 0;
 #pragma unroll
-            for (int u = 0; u < KS; ++u) store_bf(u);
+            for (int u = 0; u < KS; ++u) store_bf(u, stage);
             __syncthreads();
             if (ms + 1 < nmacro) load_macro(kbeg + (ms + 1) * KS * BK);
 #pragma unroll
             for (int u = 0; u < KS; ++u) {
-                const char* As = lds + u * SUB_B;
+                const char* As = lds + (stage * KS + u) * SUB_B;
                 const char* Bs = As + BM * 64;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -425,8 +431,9 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                 }
             }
-            __syncthreads();       // every wave has read this image; also: the epilogue reuses the LDS
+            if constexpr (NST == 1) __syncthreads();       // every wave has read this image before it is overwritten
         }
+        __syncthreads();           // the epilogue reuses the LDS
     } else
     // ---- main loop, hand-slotted --------------------------------------------------------------
     // One K-step = NM MFMAs per wave.  Each MFMA is followed by at most one "payload" operation and a
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         constexpr int NM = 16 * TM * TN, Q = 4 * TM * TN, NL = A_CH + B_CH;
         static_assert(NM - NL >= 2 * Q + 1, "payload slots overlap");
         if (nsteps > 0) {
-            load_tiles(kbeg, ra0, rb0);
+            load_tiles(kbeg, ktap(kbeg), kchan(kbeg), ra0, rb0);
             store_tiles(0);
             __syncthreads();
         }
@@ -819,7 +826,7 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
     // fp32: one stage of (BM+BN) x 32 floats; bf16: KS sub-step images of (BM+BN) x 64 bytes (one macro step); both hold
     // at least the BM ints of the epilogue's row-offset table
-    constexpr int KSL = (BM + BN) <= 128 ? 4 : ((BM + BN) <= 256 ? 2 : 1);
+    constexpr int KSL = (BM + BN) <= 128 ? 4 : 2;               // sub-step images: KS = 4 x 1 stage, or KS = 1 x 2 stages
     const size_t epi = (size_t)(BM + 4 * 32 * 36 + 2 * WM * BN) * sizeof(float);      // row offsets + 4 transpose patches + column partials
     const size_t loop = (size_t)KSL * (BM + BN) * 64;
     const size_t loop32 = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
