@@ -1,0 +1,51 @@
+"""Worker of tests/test_gpu_dp_two_ranks.py: one rank of a 2-process DataParallel run.  Both ranks share the test box's
+single GPU and talk over gloo (RCCL refuses two ranks on one device); everything else is the production path: real HIP
+kernels, per-rank shard, bucketed async all-reduce of the gradient arena, broadcast of rank 0's parameters."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tf_face_toolbox_amd import net_select, DataParallel, DataParallel_margin   # noqa: E402
+
+
+def main():
+    fix, out, name, steps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo')
+    d = np.load(fix)
+    x, y = d['x'], d['y']
+    n, h, w, ch = x.shape
+    ncls = int(d['ncls'])
+    sh = n // world
+    xs = torch.tensor(x[rank * sh:(rank + 1) * sh], dtype=torch.float32, device='cuda')
+    ys = torch.tensor(y[rank * sh:(rank + 1) * sh], dtype=torch.int32, device='cuda')
+    net = net_select(name, 'NCHW', 5e-4)
+    net.seed = 100 + rank                       # replicas start DIFFERENT: the wrapper's broadcast must make them equal
+    net.build(h, w, ch, ncls, 'cuda')
+    if rank == 0:
+        net.load_params({k[2:]: d[k] for k in d.files if k.startswith('p:')})
+    wrapper = DataParallel_margin if net.needs_labels else DataParallel
+    model = wrapper(net, 0.05, 'Momentum', num_gpus=world)
+    step, losses, names, _ = model({'images': xs, 'labels': ys, 'num_classes': ncls, 'num_examples': n, 'batch_size': n})
+    hist = []
+    for _ in range(steps):
+        step()
+        hist.append([float(v) for v in losses])
+    torch.cuda.synchronize()
+    res = {'w:' + k: net.get_variable(k).cpu().numpy() for k in net.variables}
+    res['losses'] = np.array(hist)
+    np.savez(out + '.rank%d.npz' % rank, **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
+    sys.stdout.flush()
+    os._exit(0)

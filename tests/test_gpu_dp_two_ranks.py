@@ -1,0 +1,60 @@
+"""-m gpu: a real 2-rank data-parallel run on the test box's one GPU (two processes launched the way the driver launches
+bench.py, gloo as the transport).  Checks SURVEY 8c's N-rank pins with the HIP kernels in the loop: replicas identical
+after the initial broadcast and after every step, and the result equal to the oracle's 2-tower step
+(data_parallel.py:203-256: shard, 1/n pre-scale, SUM, same update everywhere)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spherenet as osn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('name,head', [('SphereNet', 'softmax'), ('SphereNet-ASoftmax', 'asoftmax')])
+def test_two_ranks_equal_the_oracle_two_tower_step(tmp_path, name, head):
+    n, h, w, ch, ncls, steps = 8, 32, 32, 3, 20, 2
+    p = osn.perturb_params(osn.init_params(71, ch, ncls, h, w), 72)
+    rng = np.random.default_rng(73)
+    x = rng.uniform(-1, 1, (n, h, w, ch)); y = rng.integers(0, ncls, n)
+    fix = str(tmp_path / 'fix.npz')
+    np.savez(fix, x=x, y=y, ncls=ncls, **{'p:' + k: v for k, v in p.items()})
+    out = str(tmp_path / 'out')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(ROOT, 'tests', 'dp_worker.py'), fix, out, name, str(steps)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    r0, r1 = np.load(out + '.rank0.npz'), np.load(out + '.rank1.npz')
+    for k in r0.files:                                     # replicas bit-identical (weights AND displayed losses)
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    # oracle: the same two steps with 2 towers
+    ref = dict(p)
+    slots = {k: np.zeros_like(v) for k, v in p.items()}
+    ref_losses = []
+    for t in range(steps):
+        lam = None
+        if head == 'asoftmax':
+            from oracle import ops
+            lam = ops.asoftmax_lambda(t)
+        ref, slots, ls = osn.train_step(ref, slots, x, y, 0.05, num_towers=2, weight_decay=5e-4, data_format='NCHW', head=head, lam=lam)
+        ref_losses.append(ls)
+    np.testing.assert_allclose(r0['losses'], np.array(ref_losses), rtol=2e-5)
+    for k in p:
+        a, b = r0['w:' + k].astype(np.float64), ref[k]
+        assert np.sqrt(((a - b) ** 2).sum()) <= 2e-5 * max(np.sqrt((b * b).sum()), 1e-30), k
