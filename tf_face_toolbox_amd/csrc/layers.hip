@@ -843,10 +843,11 @@ hipError_t l_bcast_add(float* dx, const float* v, int n, int hw, int c, float sc
 namespace {
 
 // y[n,oh,ow,c] = sum_{r,q} x[n, oh*s + r - pt, ow*s + q - pl, c] * w[r,q,c]        (DGRAD: the transposed gather)
-template <bool DGRAD>
+template <bool DGRAD, int S>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ y, int n, int h, int wd, int c,
-                                                        int ho, int wo, int stride, int pt, int pl) {
+                                                        int ho, int wo, int pt, int pl) {
+    constexpr int stride = S;                 // compile-time: the dgrad gather divides by it
     const int c4n = c >> 2;
     const int oh_ = DGRAD ? h : ho, ow_ = DGRAD ? wd : wo;
     const long total = (long)n * oh_ * ow_ * c4n;
@@ -944,12 +945,16 @@ __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __rest
 
 hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
     const long total = (long)n * ho * wo * (c / 4);
-    hipLaunchKernelGGL(dwconv3x3_kernel<false>, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, stride, pt, pl);
+    const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+    if (stride == 1) hipLaunchKernelGGL((dwconv3x3_kernel<false, 1>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
+    else hipLaunchKernelGGL((dwconv3x3_kernel<false, 2>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
 hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
     const long total = (long)n * h * wd * (c / 4);
-    hipLaunchKernelGGL(dwconv3x3_kernel<true>, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, stride, pt, pl);
+    const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+    if (stride == 1) hipLaunchKernelGGL((dwconv3x3_kernel<true, 1>), grid, dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
+    else hipLaunchKernelGGL((dwconv3x3_kernel<true, 2>), grid, dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
 static int dw_quads(int c) { return c >= 256 ? 64 : (c >= 128 ? 32 : 16); }
