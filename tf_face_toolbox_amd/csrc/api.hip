@@ -261,16 +261,21 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int ksize, int stride
     return nc;
 }
 // stride-2 3x3 with even image sides: the four classes have identical row grids and 4 / 2 / 2 / 1 taps
-bool dgrad_mergeable(const DgradClass* cls, int nc) {
-    static const bool off = getenv("FTE_DGRAD_SPLIT_CLASSES") != nullptr;      // tuning hook: the per-class launches
-    if (off || nc != 4) return false;
+// ... and only while one class alone cannot fill the chip (fewer 64x64 tiles than resident slots: the small per-GPU
+// shards).  Measured on MI355X, 28x28x128 <- 256 at batch 512: four launches 0.55 ms, the merged one 0.75 ms with the SAME
+// instruction counts but half the resident waves (PMC); at batch 64 the merged launch is the faster one (36 -> 50 TFLOP/s).
+bool dgrad_mergeable(const DgradClass* cls, int nc, int n, int cin) {
+    static const char* mode = getenv("FTE_DGRAD_CLASSES");      // tuning hook: "split" | "merged"
+    if (nc != 4 || (mode && mode[0] == 's')) return false;
     for (int i = 0; i < nc; ++i)
         if (cls[i].hq != cls[0].hq || cls[i].wq != cls[0].wq || cls[i].ntap < 1) return false;
-    return true;
+    if (mode && mode[0] == 'm') return true;
+    const long tiles = (((long)n * cls[0].hq * cls[0].wq + 63) / 64) * (cin / 64);
+    return tiles < SLOTS;
 }
 // partial rows (one per tile row and class) the merged launch writes for dalpha / dbias
-long dgrad_merged_rows(const DgradClass* cls, int nc, int n) {
-    if (!dgrad_mergeable(cls, nc)) return 0;
+long dgrad_merged_rows(const DgradClass* cls, int nc, int n, int cin) {
+    if (!dgrad_mergeable(cls, nc, n, cin)) return 0;
     return (long)nc * (((long)n * cls[0].hq * cls[0].wq + 63) / 64);
 }
 // tile of the merged launch and the class order (most taps first)
@@ -291,7 +296,7 @@ size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
     long rows = 0;
     size_t pw = 0;
     for (int i = 0; i < nc; ++i) { rows += cls[i].mtiles; if (cls[i].rp.pw_bytes > pw) pw = cls[i].rp.pw_bytes; }
-    const long merged_rows = dgrad_merged_rows(cls, nc, n);
+    const long merged_rows = dgrad_merged_rows(cls, nc, n, cin);
     if (merged_rows > rows) rows = merged_rows;
     return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES + pw;
 }
@@ -304,10 +309,10 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
     const Pads pho = same_pads(h, ksize, stride), pwo = same_pads(wd, ksize, stride);
     DgradClass cls[4];
     const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
-    const bool merged = dgrad_mergeable(cls, nc);
+    const bool merged = dgrad_mergeable(cls, nc, n, cin);
     long rows = 0;
     for (int i = 0; i < nc; ++i) rows += cls[i].mtiles;
-    if (merged) rows = dgrad_merged_rows(cls, nc, n);
+    if (merged) rows = dgrad_merged_rows(cls, nc, n, cin);
     const bool want_part = zprev && (dalpha_prev || dbias_prev);
     const size_t half = align_up((size_t)rows * cin * sizeof(float));
     size_t pw_need = 0;

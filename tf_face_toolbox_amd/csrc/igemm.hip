@@ -102,14 +102,16 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    // stride-2 dgrad: the (up to) four output-parity classes share one launch.  Class c owns tiles
-    // [c*cls_tiles, (c+1)*cls_tiles), taps [cls_tap0[c], cls_tap0[c+1]) of the concatenated tap tables and its own
-    // K = taps * KC; classes are ordered longest-first so the short ones fill the tail of the launch.
+    // stride-2 dgrad: the (up to) four output-parity classes share one launch.  Class c owns taps
+    // [cls_tap0[c], cls_tap0[c+1]) of the concatenated tap tables and its own K = taps * KC.
     int tap0 = 0, NT = p.a_NT, Kc = p.K, c_ph = p.c_ph, c_pw = p.c_pw, prow = p.prow0;
     if constexpr (EPI == EPI_DGRAD) {
         if (p.ncls > 1) {
-            const int cls = bid / p.cls_tiles;
-            bid -= cls * p.cls_tiles;
+            // class = fastest index of the remapped id: the XCD remap hands each XCD a CONTIGUOUS range of ids, so
+            // "class c owns ids [c*T, (c+1)*T)" put the whole 4-tap class on two XCDs and the 1-tap class on two others
+            // (merged launch 25 % slower than four separate ones); interleaved, every XCD gets 1/8 of every class
+            const int cls = bid % p.ncls;
+            bid /= p.ncls;
             tap0 = p.cls_tap0[cls];
             NT = p.cls_tap0[cls + 1] - tap0;
             Kc = NT * p.a_KC;
