@@ -88,9 +88,10 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
     if (P > ksteps / 4) P = ksteps / 4;
     // Split-K pays only when there is NO whole round (small per-GPU shards): measured on MI355X at batch
     // 512 a 32-tile tail split 16 ways is slower than the 64x64 tail (which costs ~3 % of the kernel).
-    // ... and only with few tiles and a long K (P >= 4): the fix-up moves P x the output through HBM; at
-    // P = 2-3 (batch-64 stage 3) it costs more than the better-filled MFMA launch saves.
-    if (allow_pw && P >= 4 && T < SLOTS) {
+    // With the 16-byte fix-up epilogue P = 2 already pays (batch 64, 14x14x256: 96 -> 101 TFLOP/s forward, 89 -> 95
+    // dgrad; batch 128, 7x7x512: 100 -> 111); P = 1 means the tiles fill the chip on their own.
+    static const int min_p = getenv("FTE_MIN_SPLITP") ? atoi(getenv("FTE_MIN_SPLITP")) : 2;     // tuning hook
+    if (allow_pw && P >= min_p && T < SLOTS) {
         r.tail_mode = 2; r.tail_tile = big; r.tail_mtiles = tmt * FIXUP_CHUNKS;   // partial rows: one per (tile row, chunk)
         r.tail_kchunk = (int)((ksteps + P - 1) / P * 32);
         r.tail_splits = (int)((K + r.tail_kchunk - 1) / r.tail_kchunk);
