@@ -88,7 +88,7 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
     if (P > ksteps / 4) P = ksteps / 4;
     // Split-K pays only when there is NO whole round (small per-GPU shards): measured on MI355X at batch
     // 512 a 32-tile tail split 16 ways is slower than the 64x64 tail (which costs ~3 % of the kernel).
-    // With the 16-byte fix-up epilogue P = 2 already pays (batch 64, 14x14x256: 96 -> 101 TFLOP/s forward, 89 -> 95
+    // P = 2 already pays (batch 64, 14x14x256: 96 -> 101 TFLOP/s forward, 89 -> 95
     // dgrad; batch 128, 7x7x512: 100 -> 111); P = 1 means the tiles fill the chip on their own.
     static const int min_p = getenv("FTE_MIN_SPLITP") ? atoi(getenv("FTE_MIN_SPLITP")) : 2;     // tuning hook
     if (allow_pw && P >= min_p && T < SLOTS) {
@@ -376,8 +376,13 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
     }
     }
     if (want_part) {
-        if (dalpha_prev) { hipError_t e = k_reduce_rows(PA, dalpha_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
-        if (dbias_prev) { hipError_t e = k_reduce_rows(PB, dbias_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+        if (dalpha_prev && dbias_prev) {
+            hipError_t e = k_reduce_rows2(PA, dalpha_prev, PB, dbias_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        } else {
+            if (dalpha_prev) { hipError_t e = k_reduce_rows(PA, dalpha_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+            if (dbias_prev) { hipError_t e = k_reduce_rows(PB, dbias_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream); if (e != hipSuccess) return (int)e; }
+        }
     }
     return FTE_OK;
 }

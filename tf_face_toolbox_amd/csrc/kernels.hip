@@ -173,10 +173,13 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
 // grid = (ceil(cols/64), row_splits); block = 64 columns x 4 row lanes.  With row_splits > 1 the
 // kernel writes partial[rs, cols] and is run a second time over those partials (fixed order).
 // ------------------------------------------------------------------------------------
+// blockIdx.z = 1 reduces a second matrix of the same shape (in2 -> out2): dalpha and dbias partials in one launch
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           const float* __restrict__ bias, int bmod, long rows,
-                                                          long cols, long rows_per_split, float scale) {
+                                                          long cols, long rows_per_split, float scale,
+                                                          const float* __restrict__ in2, float* __restrict__ out2) {
     __shared__ float sh[4][64];
+    if (blockIdx.z == 1) { in = in2; out = out2; }
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * 64 + c;
     const long r0 = (long)blockIdx.y * rows_per_split;
@@ -323,15 +326,24 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
     s = block_sum(s, sh);
     if (threadIdx.x == 0) out[blockIdx.x] = sqrtf(s);
 }
+// block = 64 columns x 4 row lanes, 4 independent loads per trip (one thread per column walking all rows serially took
+// 121 us for the 512 x 10575 classifier)
 __global__ __launch_bounds__(256) void col_norms_kernel(const float* __restrict__ a, float* __restrict__ out, int rows, int cols, int ld) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
-    float s = 0.f;
-    for (int i = 0; i < rows; ++i) {
-        const float v = a[(long)i * ld + j];
-        s += v * v;
+    __shared__ float sh[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < cols) {
+        int i = rl;
+        for (; i + 12 < rows; i += 16) {
+            const float v0 = a[(long)i * ld + j], v1 = a[(long)(i + 4) * ld + j], v2 = a[(long)(i + 8) * ld + j], v3 = a[(long)(i + 12) * ld + j];
+            s0 += v0 * v0; s1 += v1 * v1; s2 += v2 * v2; s3 += v3 * v3;
+        }
+        for (; i < rows; i += 4) { const float v = a[(long)i * ld + j]; s0 += v * v; }
     }
-    out[j] = sqrtf(s);
+    sh[rl][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && j < cols) out[j] = sqrtf((sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]));
 }
 __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ a, const float* __restrict__ b,
                                                          const float* __restrict__ rc, const float* __restrict__ cc,
@@ -512,28 +524,37 @@ hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int 
     return hipGetLastError();
 }
 // scratch: REDUCE_SCRATCH_FLOATS floats, only touched when the matrix is tall and narrow
-hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale,
-                         float* scratch, hipStream_t st) {
+hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* out2, const float* bias, int bmod, long rows, long cols,
+                          int fold, float scale, float* scratch, hipStream_t st) {
     // [rows, fold, cols/fold] is the same memory as [rows*fold, cols/fold]: folding is a reshape
     rows *= fold;
     cols /= fold;
+    const unsigned nz = in2 ? 2 : 1;
     const long cb = (cols + 63) / 64;
     long rs = 1;
     if (scratch && cb < 512 && rows >= 64) {
         rs = 1024 / cb;
         if (rs > rows / 16) rs = rows / 16;
-        if (rs * cols > REDUCE_SCRATCH_FLOATS) rs = REDUCE_SCRATCH_FLOATS / cols;
+        if (rs * cols * nz > REDUCE_SCRATCH_FLOATS) rs = REDUCE_SCRATCH_FLOATS / (cols * nz);
         if (rs < 1) rs = 1;
     }
     if (rs == 1) {
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1), dim3(256), 0, st, in, out, bias, bmod, rows, cols, rows, scale);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1, nz), dim3(256), 0, st, in, out, bias, bmod, rows, cols, rows, scale, in2, out2);
         return hipGetLastError();
     }
     const long rps = (rows + rs - 1) / rs;
     rs = (rows + rps - 1) / rps;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, (unsigned)rs), dim3(256), 0, st, in, scratch, (const float*)nullptr, 1, rows, cols, rps, 1.f);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1), dim3(256), 0, st, (const float*)scratch, out, bias, bmod, rs, cols, rs, scale);
+    float* scratch2 = scratch + rs * cols;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, (unsigned)rs, nz), dim3(256), 0, st, in, scratch, (const float*)nullptr, 1, rows, cols, rps, 1.f,
+                       in2, scratch2);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1, nz), dim3(256), 0, st, (const float*)scratch, out, bias, bmod, rs, cols, rs, scale,
+                       (const float*)scratch2, out2);
     return hipGetLastError();
+}
+// scratch: REDUCE_SCRATCH_FLOATS floats, only touched when the matrix is tall and narrow
+hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale,
+                         float* scratch, hipStream_t st) {
+    return k_reduce_rows2(in, out, nullptr, nullptr, bias, bmod, rows, cols, fold, scale, scratch, st);
 }
 hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, bool sq, hipStream_t st) {
     const int nb = grid_for(n, 256 * 4 * 8) > 1024 ? 1024 : grid_for(n, 256 * 4 * 8);
@@ -560,7 +581,7 @@ hipError_t k_row_norms(const float* a, float* out, int rows, int cols, int ld, h
     return hipGetLastError();
 }
 hipError_t k_col_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st) {
-    hipLaunchKernelGGL(col_norms_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, a, out, rows, cols, ld);
+    hipLaunchKernelGGL(col_norms_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, a, out, rows, cols, ld);
     return hipGetLastError();
 }
 hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* cc, int rows, int cols, int ld, hipStream_t st) {
