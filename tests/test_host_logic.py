@@ -51,7 +51,14 @@ def test_arena_layout_variables_and_reference_layout_round_trip(data_format):
     groups = net.arena_groups()
     assert groups[0][:3] == (0, net.small_end, False) and groups[-1][1] == net.arena_size
     assert net.cpad == 128 and net.view('classifier/fc_classifier/weights').numel() == 512 * 128
-    assert net.grad_buckets() == [(net.fc_start, net.arena_size + 4), (0, net.fc_start)]
+    # buckets in completion order: head (FC + classifier + the 4 loss slots), stages 4, 3, 2, then [biases/alphas + stage 1];
+    # together they tile the arena exactly once and line up with the backward stages
+    b = net.grad_buckets()
+    assert b[0] == (net.fc_start, net.arena_size + 4) and len(b) == 5 == len(net.backward_stages())
+    assert b[-1][0] == 0 and [x[1] for x in b[1:]] == [net.fc_start] + [x[0] for x in b[1:-1]]
+    assert sum(e - a for a, e in b) == net.arena_size + 4
+    w4 = net.variables['SphereNet/conv4/Conv/weights']
+    assert b[1] == (w4.offset, net.fc_start)                              # stage 4 = conv4 + its residual block
     kinds = {v.kind for v in net.variables.values() if v.offset < net.small_end}
     assert kinds == {'bias', 'alpha', 'fc_b'}
     net.load_params(p)
