@@ -250,6 +250,12 @@ size_t fte_gemm_ws_bytes(int m, int n, int k);
 int fte_softmax_ce_fwd_bwd(const float* logits, const int32_t* labels, float* loss_rows,
                            float* dlogits, int n, int c, int ld, float grad_scale, void* stream);
 
+/* focal_loss (loss.py:18-27; note the reference's swapped-looking defaults gamma = 1.0, alpha = 2.0 are kept as named):
+ * loss_rows[i] = gamma * (1 - p_y)^alpha * CE_i, dlogits = grad_scale * d(loss_rows[i])/dlogits (through BOTH the
+ * cross-entropy and the softmax-score factor, as tf.gradients does).  alpha >= 1.  Same layout rules as above. */
+int fte_focal_loss_fwd_bwd(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits,
+                           int n, int c, int ld, float gamma, float alpha, float grad_scale, void* stream);
+
 /* A-softmax (SphereFace, m = 4; README.md:14,19 claims it, the code is not in
  * the reference tree -- SURVEY.md Appendix A.9).  s = x @ w is the raw dot
  * product [n, ld]; xn = |x_i| (n), wn = |W_j| (c).  Produces the margin logits

@@ -438,7 +438,7 @@ def perturb(p, seed, scale=0.1):
 
 
 def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None, grad_scale=None, state=None, kink=None,
-                   center=None, triplet_margin='off'):
+                   center=None, triplet_margin='off', focal=None):
     """softmax-CE (+ center loss) or batch-hard triplet, + L2 on conv / fc weights (gamma, beta, biases are not
     regularised).  center = dict(centers=[C,D], alpha=, weight=): loss.py:29-45 on the pooled features, added to the
     total loss with `weight` (the reference leaves the wiring to the caller, loss.py:43).  triplet_margin != 'off':
@@ -452,7 +452,10 @@ def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None,
         losses.append(per.mean())
         dout['features'] = df * (1.0 / n if grad_scale is None else grad_scale)
     else:
-        ce, dlogits = ops.softmax_ce(env['logits'], labels, grad_scale)
+        if focal is not None:                             # (gamma, alpha): loss.py:18-27 in place of the cross-entropy
+            ce, dlogits = ops.focal_loss(env['logits'], labels, focal[0], focal[1], grad_scale)
+        else:
+            ce, dlogits = ops.softmax_ce(env['logits'], labels, grad_scale)
         losses.append(ce)
         dout['logits'] = dlogits
         if center is not None:

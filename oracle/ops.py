@@ -127,6 +127,24 @@ def softmax_ce(logits, labels, grad_scale=None):
     return loss, d
 
 
+def focal_loss(logits, labels, gamma=1.0, alpha=2.0, grad_scale=None):
+    """loss.py:18-27: mean_i gamma * (1 - p_y)^alpha * CE_i (the reference's parameter names kept as written).
+    Returns (loss, dlogits) with dlogits scaled by grad_scale (default 1/N: the reduce_mean)."""
+    n = logits.shape[0]
+    m = logits.max(axis=1, keepdims=True)
+    e = np.exp(logits - m)
+    s = e.sum(axis=1, keepdims=True)
+    p = e / s
+    logq = (logits - m)[np.arange(n), labels] - np.log(s[:, 0])
+    q = np.exp(logq)
+    per = gamma * (1 - q) ** alpha * (-logq)
+    coef = gamma * ((1 - q) ** alpha - alpha * q * (1 - q) ** (alpha - 1) * logq)
+    d = p.copy()
+    d[np.arange(n), labels] -= 1
+    d *= coef[:, None] * (1.0 / n if grad_scale is None else grad_scale)
+    return per.mean(), d
+
+
 # --------------------------------------------------------------------------
 # l2_regularizer(s)(w) = s * sum(w^2)/2   (Appendix A.4, nets/net_base.py:105)
 # --------------------------------------------------------------------------

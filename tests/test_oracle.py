@@ -258,3 +258,21 @@ def test_triplet_matches_torch_restatement(margin):
     tl.sum().backward()
     np.testing.assert_allclose(loss, tl.detach().numpy(), atol=1e-12)
     np.testing.assert_allclose(df, tf_.grad.numpy(), atol=1e-10)
+
+
+def test_focal_loss_matches_torch_autograd():
+    """loss.py:18-27 restated in oracle.ops.focal_loss vs the literal formula under torch autograd (the gradient flows
+    through BOTH the cross-entropy and the softmax-score factor)."""
+    import torch
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((6, 11)) * 2
+    y = rng.integers(0, 11, 6)
+    for g, a in ((1.0, 2.0), (0.5, 1.0), (2.0, 3.5)):
+        loss, d = ops.focal_loss(z, y, g, a)
+        t = torch.tensor(z, requires_grad=True)
+        ce = torch.nn.functional.cross_entropy(t, torch.tensor(y), reduction='none')
+        sc = torch.softmax(t, 1)[torch.arange(6), torch.tensor(y)]
+        ref = (g * (1 - sc) ** a * ce).mean()
+        ref.backward()
+        assert abs(loss - ref.item()) < 1e-12
+        np.testing.assert_allclose(d, t.grad.numpy(), atol=1e-14)

@@ -67,6 +67,7 @@ _SIGS = {
     'fte_gemm_tn': (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     'fte_gemm_ws_bytes': (c_size_t, [c_int] * 3),
     'fte_softmax_ce_fwd_bwd': (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P]),
+    'fte_focal_loss_fwd_bwd': (c_int, [_P] * 4 + [c_int] * 3 + [c_float] * 3 + [_P]),
     'fte_asoftmax_fwd_bwd': (c_int, [_P] * 4 + [c_float] + [_P] * 4 + [c_int] * 3 + [c_float, _P]),
     'fte_asoftmax_colcoef': (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
     'fte_row_norms': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),

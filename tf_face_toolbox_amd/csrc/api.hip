@@ -603,6 +603,11 @@ int fte_softmax_ce_fwd_bwd(const float* logits, const int32_t* labels, float* lo
     if (!logits || !labels || !loss_rows || !dlogits || n <= 0 || c <= 0 || ld < c) return FTE_EINVAL;
     return rc(k_softmax_ce(logits, labels, loss_rows, dlogits, n, c, ld, grad_scale, (hipStream_t)stream));
 }
+int fte_focal_loss_fwd_bwd(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits,
+                           int n, int c, int ld, float gamma, float alpha, float grad_scale, void* stream) {
+    if (!logits || !labels || !loss_rows || !dlogits || n <= 0 || c <= 0 || ld < c || alpha < 1.f) return FTE_EINVAL;
+    return rc(k_focal_loss(logits, labels, loss_rows, dlogits, n, c, ld, gamma, alpha, grad_scale, (hipStream_t)stream));
+}
 int fte_asoftmax_fwd_bwd(const float* s, const float* xn, const float* wn, const int32_t* labels, float lambda,
                          float* f, float* loss_rows, float* G, float* rowcoef, int n, int c, int ld,
                          float grad_scale, void* stream) {

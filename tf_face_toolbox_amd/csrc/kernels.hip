@@ -254,6 +254,37 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     if (threadIdx.x == 0) loss_rows[row] = logf(s) - (z[y] - mx);
 }
 
+// Focal loss (loss.py:18-27): F_i = gamma * (1 - p_y)^alpha * CE_i.  With q = p_y, dF/dz_j = coef * (p_j - [j = y]),
+// coef = gamma * ((1-q)^alpha - alpha * q * (1-q)^(alpha-1) * log q): the softmax-CE gradient rescaled per row.
+__global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                         float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                         int c, int ld, float gamma, float alpha, float gscale) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    const float* z = logits + (long)row * ld;
+    float* d = dlogits + (long)row * ld;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < c; j += 256) mx = fmaxf(mx, z[j]);
+    mx = block_max(mx, sh);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < c; j += 256) s += expf(z[j] - mx);
+    s = block_sum(s, sh);
+    const int y = labels[row];
+    const float inv = 1.f / s;
+    const float logq = (z[y] - mx) - logf(s);                  // log p_y <= 0
+    const float q = expf(logq);
+    const float omq = fmaxf(1.f - q, 0.f);
+    const float pw = powf(omq, alpha);                          // (1-q)^alpha
+    const float pw1 = alpha == 1.f ? 1.f : powf(omq, alpha - 1.f);
+    const float coef = gamma * (pw - alpha * q * pw1 * logq) * gscale;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        float g = 0.f;
+        if (j < c) g = (expf(z[j] - mx) * inv - (j == y ? 1.f : 0.f)) * coef;
+        d[j] = g;
+    }
+    if (threadIdx.x == 0) loss_rows[row] = -gamma * pw * logq;
+}
+
 // ------------------------------------------------------------------------------------
 // A-softmax (m = 4).  One block per row; s = raw x.W row.
 // ------------------------------------------------------------------------------------
@@ -565,6 +596,11 @@ hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, boo
 }
 hipError_t k_softmax_ce(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld, float gs, hipStream_t st) {
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gs);
+    return hipGetLastError();
+}
+hipError_t k_focal_loss(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld,
+                        float gamma, float alpha, float gs, hipStream_t st) {
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gamma, alpha, gs);
     return hipGetLastError();
 }
 hipError_t k_asoftmax(const float* s, const float* xn, const float* wn, const int32_t* labels, float lam, float* f, float* loss_rows,

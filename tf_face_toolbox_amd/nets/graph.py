@@ -49,7 +49,7 @@ class GraphNet(Network):
     `channel_pad` > 1 (ShuffleNet: 64) stores every activation and weight with its channel count rounded up to that
     multiple; the padding channels are exactly zero in the forward and backward pass (zero weight rows / columns, BN of
     a constant-zero channel with beta 0 stays 0, and every gradient flowing into them is 0), so results equal the
-    unpadded net's while all kernels keep their float4 / MFMA-tile granularity.  Heads: 'softmax' (CE on the classifier), 'softmax+center' (CE + weight * center loss
+    unpadded net's while all kernels keep their float4 / MFMA-tile granularity.  Heads: 'softmax' (CE on the classifier), 'focal' (loss.py:18-27 instead of CE), 'softmax+center' (CE + weight * center loss
     on the pooled features, loss.py:29-45) and 'triplet' (batch-hard triplet on the pooled features, loss.py:47-78, no
     classifier)."""
 
@@ -72,6 +72,7 @@ class GraphNet(Network):
         self.center_weight = 0.0          # 'softmax+center': total loss = CE + center_weight * center_loss
         self.center_alpha = 0.99          # loss.py:29 default
         self.triplet_margin = None        # 'triplet': None = soft-margin (softplus), loss.py:47
+        self.focal_gamma, self.focal_alpha = 1.0, 2.0     # 'focal': loss.py:18 defaults (names as in the reference)
 
     # ---- to be provided by the subclass ----------------------------------------------------------
     def build_graph(self, in_ch, num_classes):
@@ -597,10 +598,14 @@ class GraphNet(Network):
             self._dfeat = self.dfeat
             losses.append(slots[0]); names.append('triplet_loss')
         else:
-            call('fte_softmax_ce_fwd_bwd', self.t['logits'], labels, self.loss_rows, self.G, n,
-                 self.num_classes, self.cpad, self.tower_scale / n, st)
+            if self.head == 'focal':                         # loss.py:18-27 on the classifier logits
+                call('fte_focal_loss_fwd_bwd', self.t['logits'], labels, self.loss_rows, self.G, n,
+                     self.num_classes, self.cpad, self.focal_gamma, self.focal_alpha, self.tower_scale / n, st)
+            else:
+                call('fte_softmax_ce_fwd_bwd', self.t['logits'], labels, self.loss_rows, self.G, n,
+                     self.num_classes, self.cpad, self.tower_scale / n, st)
             call('fte_sum', self.loss_rows, n, self.tower_scale / n, slots[0:1], self.ws, self.ws_bytes, st)
-            losses.append(slots[0]); names.append('cross_entropy')
+            losses.append(slots[0]); names.append('focal_entropy' if self.head == 'focal' else 'cross_entropy')
             if self.head == 'softmax+center':
                 call('fte_center_loss_fwd_bwd_update', feat, labels, self._centers(), self.loss_rows, self.dfeat, n, d,
                      self.center_alpha, self.center_weight * self.tower_scale / (n * d), self.ws, self.ws_bytes, st)
