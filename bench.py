@@ -96,11 +96,19 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
+    # FTE_BENCH_SHARED_GPU=1 (tests only): all ranks on the GPUs that exist, gloo as the transport -- RCCL refuses two
+    # ranks on one device, and the test boxes have one GPU; everything else of the N > 1 path is what the driver runs
+    shared = os.environ.get('FTE_BENCH_SHARED_GPU') == '1'
+    if shared:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if shared:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     gb = args.global_batch
     assert gb % world == 0
     shard = gb // world

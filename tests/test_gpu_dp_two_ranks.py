@@ -58,3 +58,23 @@ def test_two_ranks_equal_the_oracle_two_tower_step(tmp_path, name, head):
     for k in p:
         a, b = r0['w:' + k].astype(np.float64), ref[k]
         assert np.sqrt(((a - b) ** 2).sum()) <= 2e-5 * max(np.sqrt((b * b).sum()), 1e-30), k
+
+
+def test_bench_py_runs_with_two_ranks(tmp_path):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one JSON line from rank 0), with the
+    two ranks sharing the box's GPU over gloo (FTE_BENCH_SHARED_GPU=1)."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, FTE_BENCH_SHARED_GPU='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--global-batch', '16'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout                       # exactly ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['scaling'] == 'strong'
+    assert out['config']['global_batch'] == 16 and out['config']['per_gpu_batch'] == 8 and out['config']['parallelism'] == 'dp2'
+    assert out['value'] > 0 and abs(out['value'] - 16 / (out['ms_per_step'] * 1e-3)) <= 0.01 * out['value']
+    assert out['cpu_baseline'] is None and out['roofline']['frac'] > 0
+    assert all(np.isfinite(v) for v in out['losses'].values())
