@@ -45,6 +45,7 @@ inline int pick_tile(long M, long N) {
 // fp32 MFMAs are 64 cycles each, so operand reuse is not what limits these kernels -- latency hiding is: on
 // MI355X at batch 512 the conv time per step is 60.7 ms with 128x128 tiles at 2 blocks/CU, 56.2 ms at 3 blocks/CU
 // (single LDS stage) and 53.4 ms with 64x64 tiles at 6 blocks/CU.
+constexpr long SLOTS_BIG = 768;       // 128x128 / 128x64 tiles (wgrad, dense split-K): 3 blocks per CU
 constexpr long SLOTS = 1536;
 
 // Row plan of an M x N output with reduction length K.  T big tiles on SLOTS resident blocks run in
@@ -58,14 +59,21 @@ struct RowPlan {
     int main_tile; long main_rows, main_mtiles;
     int tail_mode, tail_tile; long tail_mtiles; int tail_splits, tail_kchunk; size_t pw_bytes;
 };
-inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
+inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only = false) {
     RowPlan r;
     memset(&r, 0, sizeof(r));
     static const int narrow_tile = getenv("FTE_NARROW_TILE") ? atoi(getenv("FTE_NARROW_TILE")) : TILE_64x64;   // N = 64: measured on MI355X
     // 64x64 beats 128x64 beats 256x64 (fwd 83 / 82 / 75 TF, dgrad 80 / 76 / 65): with only 18 K-steps per tile the
     // layer lives on co-resident blocks hiding each other's prologue / epilogue, not on operand reuse.
     static const int wide_tile = getenv("FTE_WIDE_TILE") ? atoi(getenv("FTE_WIDE_TILE")) : TILE_64x64;         // measured: see below
-    const int big = (N % 128 == 0) ? wide_tile : narrow_tile;
+    // bf16-operand mode: the loop is instruction-issue bound (17 VALU + 20 SALU per MFMA on the 64x64 tile), so the tile
+    // with 4x the MFMAs per staged operand wins where N allows it and the launch still fills the chip (batch 512: forward
+    // 6.8 -> 5.8 ms, dgrad 8.1 -> 7.5 ms per step; at batch 64 the big tile loses: 3.7 -> 4.7 ms);
+    // the short-K stride-2 dgrad classes stay on 64x64 (`small_only`)
+    static const bool wide_env = getenv("FTE_WIDE_TILE") != nullptr;
+    const bool fills = ((M + 127) / 128) * (N / 128) >= SLOTS_BIG;      // at least one round of the big tile's slots
+    const int wide = (!wide_env && igemm_get_bf16() && !small_only && fills) ? TILE_128x128 : wide_tile;
+    const int big = (N % 128 == 0) ? wide : narrow_tile;
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
     const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn, ksteps = (K + 31) / 32;
@@ -110,7 +118,6 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw) {
 
 // split-K plan: pick the split count whose tiles*splits fills whole rounds of SLOTS best
 // (>= 8 K-steps per split; ties go to fewer splits = less slab traffic)
-constexpr long SLOTS_BIG = 768;       // 128x128 / 128x64 tiles (wgrad, dense split-K): 3 blocks per CU
 inline void plan_splits(long tiles, int K, int* splits, int* kchunk, bool prefer8 = false) {
     const int maxs = K / 256 > 0 ? K / 256 : 1;
     const long SLOTS = SLOTS_BIG;
@@ -171,6 +178,18 @@ inline hipError_t launch_rows(IgemmParams p, const RowPlan& rp, int al, int bl, 
     return igemm_fixup(p, epi, rp.tail_tile, rp.tail_splits, st);
 }
 
+// the tile plan depends on the MFMA dtype (fte_set_mfma_dtype): workspace queries answer for BOTH modes, so that a buffer
+// sized once stays valid when the mode is switched
+template <class F>
+size_t both_modes(F f) {
+    const bool cur = igemm_get_bf16();
+    igemm_set_bf16(false);
+    const size_t a = f();
+    igemm_set_bf16(true);
+    const size_t b = f();
+    igemm_set_bf16(cur);
+    return a > b ? a : b;
+}
 }  // namespace
 
 extern "C" {
@@ -195,7 +214,7 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms) {
 size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     if (n <= 0 || cin <= 0 || cin % 32 || cout <= 0 || cout % 64) return 0;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
-    return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true).pw_bytes;
+    return both_modes([&] { return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true).pw_bytes; });
 }
 
 int fte_conv2d_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
@@ -255,7 +274,7 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int ksize, int stride
                 }
             }
             const long M = (long)n * c.hq * c.wq;
-            c.rp = plan_rows(M, cin, (long)c.ntap * cout, true);
+            c.rp = plan_rows(M, cin, (long)c.ntap * cout, true, stride != 1);
             c.mtiles = c.rp.main_mtiles + c.rp.tail_mtiles;
             ++nc;
         }
@@ -292,14 +311,18 @@ int dgrad_merged_plan(const DgradClass* cls, int nc, int n, int cin, int* order)
 
 size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     if (n <= 0 || cin <= 0 || cin % 64 || cout % 32) return 0;      // shapes fte_conv2d_dgrad rejects need no workspace
-    DgradClass cls[4];
-    const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
-    long rows = 0;
-    size_t pw = 0;
-    for (int i = 0; i < nc; ++i) { rows += cls[i].mtiles; if (cls[i].rp.pw_bytes > pw) pw = cls[i].rp.pw_bytes; }
-    const long merged_rows = dgrad_merged_rows(cls, nc, n, cin);
-    if (merged_rows > rows) rows = merged_rows;
-    return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES + pw;
+    return both_modes([&] {
+        DgradClass cls[4];
+        const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
+        long rows = 0;
+        size_t pw = 0;
+        for (int i = 0; i < nc; ++i) { rows += cls[i].mtiles; if (cls[i].rp.pw_bytes > pw) pw = cls[i].rp.pw_bytes; }
+        const long merged_rows = dgrad_merged_rows(cls, nc, n, cin);
+        if (merged_rows > rows) rows = merged_rows;
+        // 64-row tiles give the most partial rows; the layout below (two halves, then scratch, then split-K tiles) is
+        // sized for the larger of the two modes in each part
+        return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES + pw;
+    });
 }
 
 int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
