@@ -73,7 +73,10 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     static const bool wide_env = getenv("FTE_WIDE_TILE") != nullptr;
     const bool fills = ((M + 127) / 128) * (N / 128) >= SLOTS_BIG;      // at least one round of the big tile's slots
     const int wide = (!wide_env && igemm_get_bf16() && !small_only && fills) ? TILE_128x128 : wide_tile;
-    const int big = (N % 128 == 0) ? wide : narrow_tile;
+    static const bool narrow_env = getenv("FTE_NARROW_TILE") != nullptr;
+    const bool fills_n = ((M + 127) / 128) * (N / 64) >= SLOTS_BIG;
+    const int narrow = (!narrow_env && igemm_get_bf16() && !small_only && fills_n) ? TILE_128x64 : narrow_tile;   // N = 64 layers: +3 %
+    const int big = (N % 128 == 0) ? wide : narrow;
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
     const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn, ksteps = (K + 31) / 32;
