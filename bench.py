@@ -140,11 +140,15 @@ def main():
         train_ops()
     barrier()
     _lib.query('fte_prof_enable', 1)        # event pairs around every MFMA-kernel launch of the timed steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step device times (no host sync)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         train_ops()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     _lib.query('fte_prof_enable', 0)
     records = _lib.prof_records() if rank == 0 else []
     if world > 1:
@@ -185,6 +189,7 @@ def main():
             'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3),
+            'step_ms': {'min': round(step_ms[0], 3), 'median': round(step_ms[len(step_ms) // 2], 3), 'max': round(step_ms[-1], 3)},
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,

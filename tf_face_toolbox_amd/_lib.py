@@ -89,6 +89,10 @@ def exported_names():
     return sorted(_SIGS)
 
 
+_CODES = {-1: 'FTE_EINVAL -- a null pointer, a shape the kernel family does not tile (channel multiples, stride, '
+              'ksize) or a tensor of 2 GiB or more (buffer-load range)',
+          -2: 'FTE_EWORKSPACE -- workspace missing or smaller than the matching *_ws_bytes() query'}
+
 MFMA_DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
 
 
@@ -127,7 +131,8 @@ def call(name, *args):
     lib = load()
     r = getattr(lib, name)(*[_ptr(a) if (a is None or hasattr(a, 'data_ptr')) else a for a in args])
     if r != 0:
-        raise FteError('%s failed with code %d' % (name, r))
+        what = _CODES.get(r, 'hipError_t %d (see hip_runtime_api.h)' % r if r > 0 else 'unknown')
+        raise FteError('%s failed with code %d: %s' % (name, r, what))
 
 
 def query(name, *args):
