@@ -1,0 +1,55 @@
+"""-m gpu: the metric's FULL size (SphereFaceNet-20 + A-softmax, 512 x 112 x 112 x 3, 10575 classes), checked through
+size-independent properties -- the float64 oracle needs minutes per image batch at this size:
+  * batch independence (no BN in SphereNet): the embeddings of images 0..3 inside the 512-batch equal those of the same
+    images run alone, and THOSE are compared with the oracle;
+  * tower-split additivity (data_parallel.py:37,179): gradient(512) == gradient(first 256) + gradient(last 256) with the
+    1/2 pre-scale -- the identity the multi-GPU path rests on, here across different tile plans / split-K factors;
+  * determinism: the same step twice gives bit-identical gradients (ordered reductions, no float atomics)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spherenet as osn
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from util_gpu import host, check_maxabs, check_rell2
+    from tf_face_toolbox_amd import net_select
+
+B, H, W, CH, NCLS = 512, 112, 112, 3, 10575
+
+
+def _step(net, x, y, scale):
+    net.tower_scale = scale
+    net.global_step = 0
+    out = net.forward(x, y, num_classes=NCLS, is_training=True)
+    losses, _, _ = net.loss_function('T', y, **out)
+    net.backward()
+    torch.cuda.synchronize()
+    return [float(v) for v in losses], net.grads[:net.arena_size].clone(), net.emb.clone()
+
+
+def test_full_size_step_properties():
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(B, H, W, CH, generator=g) * 2 - 1).cuda()
+    y = torch.randint(0, NCLS, (B,), generator=g, dtype=torch.int32).cuda()
+    net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+    net.seed = 2
+    net.build(H, W, CH, NCLS, 'cuda')
+    l_full, g_full, e_full = _step(net, x, y, 1.0)
+    l_again, g_again, _ = _step(net, x, y, 1.0)
+    assert l_again == l_full and torch.equal(g_again, g_full)                       # determinism
+    l_a, g_a, _ = _step(net, x[:B // 2], y[:B // 2], 0.5)
+    l_b, g_b, _ = _step(net, x[B // 2:], y[B // 2:], 0.5)
+    assert abs((l_a[0] + l_b[0]) - l_full[0]) <= 1e-5 * l_full[0]                    # displayed CE: mean of the shard means
+    assert abs((l_a[1] + l_b[1]) - l_full[1]) <= 1e-6 * l_full[1]                    # reg loss: wd*|w|^2/2 scaled 1/2 per tower
+    gs, gf = host(g_a + g_b), host(g_full)
+    for name, v in net.variables.items():                                           # tower-split additivity, per variable
+        a, b = gs[v.offset:v.offset + v.size], gf[v.offset:v.offset + v.size]
+        check_rell2(a, b, 2e-5, 'split-sum gradient of ' + name)
+    _, _, e_small = _step(net, x[:4], y[:4], 1.0)                                    # batch independence
+    check_maxabs(host(e_small), host(e_full[:4]), 2e-5, 'embeddings of images 0..3: alone vs inside the 512-batch')
+    p = {k: host(net.get_variable(k)) for k in net.variables}
+    emb_ref, _ = osn.backbone_fwd(p, host(x[:2]), 'NCHW')                            # ... and the oracle on two of them
+    check_maxabs(host(e_small[:2]), emb_ref, 2e-5, 'embeddings vs the float64 oracle')
