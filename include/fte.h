@@ -59,7 +59,8 @@ int fte_get_mfma_dtype(void);
 /* Measurement hook (bench.py's roofline leg; no reference counterpart).  While enabled, every
  * launch of the MFMA kernel family is bracketed by a HIP event pair ON THE LAUNCH STREAM and its
  * algorithmic FLOPs (2*rows*N*K of that launch) are recorded.  fte_prof_enable(1) clears and starts,
- * fte_prof_enable(0) stops; after a device synchronise, fte_prof_get returns record i:
+ * fte_prof_enable(0) pauses, fte_prof_enable(2) resumes without clearing (sampled recording: the event pair costs a
+ * queue barrier per launch, ~5 % of a step at 64 images per GPU); after a device synchronise, fte_prof_get returns record i:
  * sig = {A layout, B layout, epilogue, tile id, split count} (identifies the kernel symbol:
  * igemm_kernel<BM,BN,WM,WN,sig[0],sig[1],sig[2]>; tile 0=128x128 1=256x64 2=128x64 3=64x64),
  * flops, and the launch's duration in milliseconds. */

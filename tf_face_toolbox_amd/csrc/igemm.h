@@ -62,6 +62,6 @@ void igemm_set_bf16(bool on);
 bool igemm_get_bf16();
 
 // launch records for the roofline measurement (see igemm.hip)
-void igemm_prof_enable(bool on);
+void igemm_prof_enable(bool on, bool clear);
 int igemm_prof_count();
 hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms);

@@ -915,8 +915,8 @@ hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipS
 void igemm_set_bf16(bool on) { g_bf16 = on; }
 bool igemm_get_bf16() { return g_bf16; }
 
-void igemm_prof_enable(bool on) {
-    if (on) prof_clear();
+void igemm_prof_enable(bool on, bool clear) {
+    if (on && clear) prof_clear();
     g_prof_on = on;
 }
 int igemm_prof_count() { return (int)g_prof.size(); }
