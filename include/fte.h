@@ -17,6 +17,8 @@
  *     and the call returns without synchronising;
  *   - return value: 0 = ok, otherwise a negative FTE_E* code or a positive
  *     hipError_t; no C++ exception crosses the boundary;
+ *   - every tensor pointer is 16-byte aligned and every tensor smaller than 2 GiB (the kernels move 16 bytes per lane
+ *     through range-checked buffer loads); a violation is an error code, never an out-of-bounds access;
  *   - activations are NHWC fp32 (the layout data.py:275-279 hands over; the
  *     reference's NHWC->NCHW transpose, nets/sphere.py:53-54, is folded away),
  *     conv weights are TF HWIO [3,3,Cin,Cout], dense weights are [in,out].

@@ -234,3 +234,18 @@ def test_bad_arguments_are_rejected_not_run():
         call('fte_conv3x3_fwd', y, y, None, None, None, None, y, 1, 8, 8, 48, 64, 1, None, 0, stream())     # cin % 32
     with pytest.raises(FteError):
         call('fte_conv3x3_wgrad', y, y, y, 64, 28, 28, 64, 64, 1, None, 0, stream())               # split-K needs a workspace
+
+
+def test_unaligned_pointers_are_rejected_not_executed():
+    """16 bytes per lane everywhere: a pointer or pitch that is not 16-byte aligned must come back as an error code."""
+    from tf_face_toolbox_amd._lib import FteError
+    n, h, w, cin, cout = 2, 8, 8, 64, 64
+    x = torch.randn(n * h * w * cin + 4, device='cuda'); wt = torch.randn(9 * cin * cout, device='cuda')
+    y = torch.empty(n * h * w * cout + 4, device='cuda')
+    buf, nb = ws(query('fte_conv3x3_fwd_ws_bytes', n, h, w, cin, cout, 1))
+    call('fte_conv3x3_fwd', x, wt, None, None, None, None, y, n, h, w, cin, cout, 1, buf, nb, stream())       # aligned: fine
+    with pytest.raises(FteError):
+        call('fte_conv3x3_fwd', x[1:], wt, None, None, None, None, y, n, h, w, cin, cout, 1, buf, nb, stream())
+    with pytest.raises(FteError):
+        call('fte_conv3x3_fwd', x, wt, None, None, None, None, y[1:], n, h, w, cin, cout, 1, buf, nb, stream())
+    torch.cuda.synchronize()

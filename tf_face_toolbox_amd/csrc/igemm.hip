@@ -892,6 +892,12 @@ hipError_t dispatch(const IgemmParams& p, int al, int bl, int epi, int tile, int
 }  // namespace
 
 hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st) {
+    // the loaders and the epilogue move 16 bytes per lane: every tensor the kernel touches must be 16-byte aligned and
+    // its row pitch a multiple of 4 floats (torch allocations and the arenas' views are)
+    const uintptr_t ptrs = (uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.Y | (uintptr_t)p.Z | (uintptr_t)p.R | (uintptr_t)p.ADD |
+                           (uintptr_t)p.RAW | (uintptr_t)p.Zin | (uintptr_t)p.DZ | (uintptr_t)p.PW | (uintptr_t)p.bias;
+    const uintptr_t al_ptr = epi == EPI_FWD ? (uintptr_t)p.alpha : 0;      // read as float4 by the forward epilogue only
+    if (((ptrs | al_ptr) & 15) || (p.c_ld & 3) || (p.a_ld & 3) || (p.b_ld & 3)) return hipErrorInvalidValue;
     if (!g_prof_on) return dispatch(p, al, bl, epi, tile, splits, st);
     ProfRec r;
     r.sig[0] = al; r.sig[1] = bl; r.sig[2] = epi; r.sig[3] = tile; r.sig[4] = splits;

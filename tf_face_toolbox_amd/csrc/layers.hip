@@ -620,12 +620,9 @@ __global__ __launch_bounds__(256) void gconv3x3_kernel(const float* __restrict__
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        f32x4 wv;
-                        if (!DGRAD) wv = *reinterpret_cast<const f32x4*>(wt + (ic + e) * GW + oq * 4);     // W[ic+e][oc quad]
-                        else {                                                                             // W^T: out quad = ic quad
-                            wv = f32x4{wt[(ic + e) * GW + oq * 4], wt[(ic + e) * GW + oq * 4 + 1],
-                                       wt[(ic + e) * GW + oq * 4 + 2], wt[(ic + e) * GW + oq * 4 + 3]};
-                        }
+                        // forward: W[ic+e][oc quad]; dgrad: the LDS image is transposed ([tap][oc][ic]), so the same address
+                        // is W^T[oc = ic+e][ic quad] -- one 16-byte read either way
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + (ic + e) * GW + oq * 4);
 #pragma unroll
                         for (int p = 0; p < PX; ++p) acc[p] += xv[p][e] * wv;
                     }
