@@ -1,0 +1,57 @@
+"""-m gpu: the engine LEARNS -- an end-to-end check no single-step parity test gives.  Ten synthetic identities (a fixed
+random template each, fresh Gaussian noise per sample) are fitted by SphereNet-20 + A-softmax through Singular with the
+reference optimizer; afterwards the flip-averaged evaluation embeddings (nets/sphere.py:97-101, the evaluate.py path)
+of unseen samples are classified by the nearest class centroid in cosine distance.  Run in both MFMA dtypes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from tf_face_toolbox_amd import net_select, Singular, _lib
+
+
+def _samples(templates, labels, rng, sigma=0.6):
+    x = templates[labels] + sigma * rng.standard_normal((len(labels),) + templates.shape[1:])
+    return torch.tensor(np.clip(x, -1, 1), dtype=torch.float32, device='cuda')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_identities_become_separable(dtype):
+    _lib.set_mfma_dtype(dtype)
+    try:
+        rng = np.random.default_rng(0)
+        ncls, h, w, bs = 10, 32, 32, 64
+        templates = rng.uniform(-0.7, 0.7, (ncls, h, w, 3))
+        net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+        state = {}
+
+        def images():
+            state['y'] = rng.integers(0, ncls, bs)
+            return _samples(templates, state['y'], rng)
+
+        def labels():
+            return torch.tensor(state['y'], dtype=torch.int32, device='cuda')
+        step, losses, names, _ = Singular(net, 0.01, 'Momentum')({'images': images, 'labels': labels, 'num_classes': ncls, 'num_examples': 10000})
+        first = None
+        for i in range(120):
+            step()
+            if i == 4:
+                first = float(losses[0])
+        last = float(losses[0])
+        assert np.isfinite(last) and last < 0.5 * first, (first, last)
+
+        def embed(y):
+            e = net.forward(_samples(templates, y, rng), is_training=False)
+            e = e / e.norm(dim=1, keepdim=True)
+            return e
+        ya = np.repeat(np.arange(ncls), 20)
+        cent = torch.stack([embed(ya)[torch.tensor(ya, device='cuda') == c].mean(0) for c in range(ncls)])
+        cent = cent / cent.norm(dim=1, keepdim=True)
+        yt = rng.integers(0, ncls, 200)
+        pred = (embed(yt) @ cent.t()).argmax(1).cpu().numpy()
+        acc = float((pred == yt).mean())
+        assert acc >= 0.95, acc
+    finally:
+        _lib.set_mfma_dtype('f32')
