@@ -194,6 +194,32 @@ int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, fl
                           int n, int hw, int c, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * bf16 OPERAND COPIES (mixed precision with bf16 storage of what the MFMAs read; BASELINE.json config 3).
+ * The *16 convolutions read bf16 copies of their two operands -- half the bytes per K-step through the load path, no
+ * conversion in the loop -- and can write a bf16 copy of their result for the next consumer; everything else (fp32
+ * accumulation, bias / PReLU / residual / PReLU-gradient epilogues, the fp32 result tensors, reductions) is unchanged.
+ * Results are bit-identical to the FTE_MFMA_BF16 mode of the fp32-source entry points (same rounding, same order).
+ *   fte_to_bf16            y16[i] = bf16(x[i]) (round to nearest even), n % 4 == 0
+ *   fte_pack_weights_bf16  w [k*k][cin][cout] (HWIO) -> w16 (same layout: dgrad's operand) and / or w16t [k*k][cout][cin]
+ *                          (forward's operand); once per optimizer step
+ *   fte_conv2d_fwd16       = fte_conv2d_fwd with x16, w16t; y16 (optional) receives bf16(y)
+ *   fte_conv2d_dgrad16     = fte_conv2d_dgrad with dz16, w16; dzprev16 (optional) receives bf16(dzprev)
+ *   fte_conv2d_wgrad16     = fte_conv2d_wgrad with x16, dz16 (cin % 8 == 0)
+ * Workspace sizes are those of the fp32-source functions.
+ * ------------------------------------------------------------------------- */
+int fte_to_bf16(const float* x, uint16_t* y16, long n, void* stream);
+int fte_pack_weights_bf16(const float* w, uint16_t* w16, uint16_t* w16t, int ksize, int cin, int cout, void* stream);
+int fte_conv2d_fwd16(const uint16_t* x16, const uint16_t* w16t, const float* bias, const float* alpha, const float* res,
+                     float* z, float* y, uint16_t* y16, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                     void* ws, size_t ws_bytes, void* stream);
+int fte_conv2d_dgrad16(const uint16_t* dz16, const uint16_t* w16, const float* addin, const float* zprev,
+                       const float* alpha_prev, float* raw, float* dzprev, uint16_t* dzprev16, float* dalpha_prev,
+                       float* dbias_prev, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                       void* ws, size_t ws_bytes, void* stream);
+int fte_conv2d_wgrad16(const uint16_t* x16, const uint16_t* dz16, float* dw, int n, int h, int wd, int cin, int cout,
+                       int ksize, int stride, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * ShuffleNet-v2 (nets/shufflenet_v2.py).  Depthwise 3x3, TF-SAME, stride 1 or 2: the DepthwiseConv2dNative half of
  * layers.separable_conv2d (:98,104; the pointwise half is fte_conv2d_* with ksize 1).  x [n,h,wd,c], w [3,3,c].
  * HBM-bound (9 MAC per element).

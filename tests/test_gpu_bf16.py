@@ -117,3 +117,54 @@ def test_spherenet_step_bf16_vs_oracle_and_training(bf16_mode):
         step()
         hist.append(float(ls[0]))
     assert np.isfinite(hist).all() and hist[-1] < hist[0]
+
+
+def _bf16_bits(t):
+    """torch float32 -> uint16 bit pattern of its bf16 rounding (RNE), as a torch int16 tensor on the same device"""
+    return t.bfloat16().view(torch.int16)
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,stride', [(4, 14, 14, 64, 64, 3, 1), (3, 15, 9, 64, 128, 3, 2), (2, 28, 28, 128, 64, 3, 1),
+                                                     (5, 8, 8, 256, 128, 1, 1), (64, 14, 14, 128, 128, 3, 2), (2, 7, 7, 512, 512, 3, 1),
+                                                     (512, 14, 14, 128, 128, 3, 1)])
+def test_bf16_source_entry_points_equal_the_operand_mode_bit_for_bit(bf16_mode, n, h, w, cin, cout, k, stride):
+    """fte_conv2d_{fwd,dgrad,wgrad}16 read bf16 COPIES of the operands; the FTE_MFMA_BF16 mode rounds the fp32 operands
+    inside the kernel.  Same rounding, same K order, same tile plan -> identical bits.  The bf16 result copies (y16,
+    dzprev16) must be the RNE rounding of the fp32 results."""
+    g = torch.Generator(device='cuda').manual_seed(n + cin + cout + k)
+    x = torch.randn(n, h, w, cin, device='cuda', generator=g); wt = torch.randn(k, k, cin, cout, device='cuda', generator=g) * 0.1
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    bias = torch.randn(cout, device='cuda', generator=g) * 0.1; alpha = torch.rand(cout, device='cuda', generator=g) * 0.3 + 0.1
+    alp = torch.rand(cin, device='cuda', generator=g) * 0.3 + 0.1
+    res = torch.randn(n, ho, wo, cout, device='cuda', generator=g)
+    dz = torch.randn(n, ho, wo, cout, device='cuda', generator=g); zp = torch.randn(n, h, w, cin, device='cuda', generator=g)
+    add = torch.randn(n, h, w, cin, device='cuda', generator=g)
+    q = _lib.query
+    buf, nb = ws(max(q('fte_conv2d_fwd_ws_bytes', n, h, w, cin, cout, k, stride), q('fte_conv2d_dgrad_ws_bytes', n, h, w, cin, cout, k, stride),
+                     q('fte_conv2d_wgrad_ws_bytes', n, h, w, cin, cout, k, stride)))
+    st = stream()
+    # operand mode (fp32 sources, rounded in the kernel)
+    z0 = torch.empty_like(res); y0 = torch.empty_like(res)
+    _lib.call('fte_conv2d_fwd', x, wt, bias, alpha, res, z0, y0, n, h, w, cin, cout, k, stride, buf, nb, st)
+    raw0 = torch.empty_like(x); dx0 = torch.empty_like(x); da0 = torch.empty(cin, device='cuda'); db0 = torch.empty(cin, device='cuda')
+    _lib.call('fte_conv2d_dgrad', dz, wt, add, zp, alp, raw0, dx0, da0, db0, n, h, w, cin, cout, k, stride, buf, nb, st)
+    dw0 = torch.empty_like(wt)
+    _lib.call('fte_conv2d_wgrad', x, dz, dw0, n, h, w, cin, cout, k, stride, buf, nb, st)
+    # bf16 copies
+    x16 = torch.empty(x.shape, dtype=torch.int16, device='cuda'); dz16 = torch.empty(dz.shape, dtype=torch.int16, device='cuda')
+    w16 = torch.empty(wt.shape, dtype=torch.int16, device='cuda'); w16t = torch.empty(k, k, cout, cin, dtype=torch.int16, device='cuda')
+    _lib.call('fte_to_bf16', x, x16, x.numel(), st); _lib.call('fte_to_bf16', dz, dz16, dz.numel(), st)
+    _lib.call('fte_pack_weights_bf16', wt, w16, w16t, k, cin, cout, st)
+    assert torch.equal(x16, _bf16_bits(x)) and torch.equal(w16, _bf16_bits(wt))
+    assert torch.equal(w16t, _bf16_bits(wt).permute(0, 1, 3, 2).contiguous())
+    z1 = torch.empty_like(res); y1 = torch.empty_like(res); y16 = torch.empty(res.shape, dtype=torch.int16, device='cuda')
+    _lib.call('fte_conv2d_fwd16', x16, w16t, bias, alpha, res, z1, y1, y16, n, h, w, cin, cout, k, stride, buf, nb, st)
+    assert torch.equal(z1, z0) and torch.equal(y1, y0) and torch.equal(y16, _bf16_bits(y1))
+    raw1 = torch.empty_like(x); dx1 = torch.empty_like(x); dx16 = torch.empty(x.shape, dtype=torch.int16, device='cuda')
+    da1 = torch.empty(cin, device='cuda'); db1 = torch.empty(cin, device='cuda')
+    _lib.call('fte_conv2d_dgrad16', dz16, w16, add, zp, alp, raw1, dx1, dx16, da1, db1, n, h, w, cin, cout, k, stride, buf, nb, st)
+    assert torch.equal(raw1, raw0) and torch.equal(dx1, dx0) and torch.equal(da1, da0) and torch.equal(db1, db0)
+    assert torch.equal(dx16, _bf16_bits(dx1))
+    dw1 = torch.empty_like(wt)
+    _lib.call('fte_conv2d_wgrad16', x16, dz16, dw1, n, h, w, cin, cout, k, stride, buf, nb, st)
+    assert torch.equal(dw1, dw0)

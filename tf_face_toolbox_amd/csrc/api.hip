@@ -59,6 +59,11 @@ struct RowPlan {
     int main_tile; long main_rows, main_mtiles;
     int tail_mode, tail_tile; long tail_mtiles; int tail_splits, tail_kchunk; size_t pw_bytes;
 };
+// the bf16 tile preferences apply in the bf16-operand mode and inside the bf16-source (fte_*16) entry points
+bool g_plan16 = false;
+struct Plan16 { bool prev; Plan16() : prev(g_plan16) { g_plan16 = true; } ~Plan16() { g_plan16 = prev; } };
+inline bool plan_bf16() { return g_plan16 || igemm_get_bf16(); }
+
 inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only = false) {
     RowPlan r;
     memset(&r, 0, sizeof(r));
@@ -72,10 +77,10 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     // the short-K stride-2 dgrad classes stay on 64x64 (`small_only`)
     static const bool wide_env = getenv("FTE_WIDE_TILE") != nullptr;
     const bool fills = ((M + 127) / 128) * (N / 128) >= SLOTS_BIG;      // at least one round of the big tile's slots
-    const int wide = (!wide_env && igemm_get_bf16() && !small_only && fills) ? TILE_128x128 : wide_tile;
+    const int wide = (!wide_env && plan_bf16() && !small_only && fills) ? TILE_128x128 : wide_tile;
     static const bool narrow_env = getenv("FTE_NARROW_TILE") != nullptr;
     const bool fills_n = ((M + 127) / 128) * (N / 64) >= SLOTS_BIG;
-    const int narrow = (!narrow_env && igemm_get_bf16() && !small_only && fills_n) ? TILE_128x64 : narrow_tile;   // N = 64 layers: +3 %
+    const int narrow = (!narrow_env && plan_bf16() && !small_only && fills_n) ? TILE_128x64 : narrow_tile;   // N = 64 layers: +3 %
     const int big = (N % 128 == 0) ? wide : narrow;
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
@@ -155,11 +160,11 @@ constexpr size_t SCRATCH_BYTES = (size_t)REDUCE_SCRATCH_FLOATS * sizeof(float);
 
 // operand sizes for the buffer-load range check; tensors must stay below 2 GiB (offsets are 32-bit,
 // 0x80000000 is the out-of-range marker)
-inline bool set_bytes(IgemmParams* p, size_t a_floats, size_t b_floats) {
+inline bool set_bytes(IgemmParams* p, size_t a_elems, size_t b_elems, size_t esize = 4) {
     const size_t lim = (size_t)1 << 31;
-    if (a_floats * 4 >= lim || b_floats * 4 >= lim) return false;
-    p->a_bytes = (unsigned)(a_floats * 4);
-    p->b_bytes = (unsigned)(b_floats * 4);
+    if (a_elems * esize >= lim || b_elems * esize >= lim) return false;
+    p->a_bytes = (unsigned)(a_elems * esize);
+    p->b_bytes = (unsigned)(b_elems * esize);
     return true;
 }
 
@@ -199,6 +204,15 @@ extern "C" {
 
 const char* fte_version(void) { return "fte 0.1 gfx950 fp32-mfma"; }
 
+int fte_to_bf16(const float* x, uint16_t* y, long n, void* stream) {
+    if (!x || !y || n <= 0 || n % 4) return FTE_EINVAL;
+    return rc(k_to_bf16(x, y, n, (hipStream_t)stream));
+}
+int fte_pack_weights_bf16(const float* w, uint16_t* w16, uint16_t* w16t, int ksize, int cin, int cout, void* stream) {
+    if (!w || (!w16 && !w16t) || ksize <= 0 || cin <= 0 || cout <= 0) return FTE_EINVAL;
+    return rc(k_pack_weights_bf16(w, w16, w16t, ksize * ksize, cin, cout, (hipStream_t)stream));
+}
+
 int fte_set_mfma_dtype(int dtype) {
     if (dtype != FTE_MFMA_F32 && dtype != FTE_MFMA_BF16) return FTE_EINVAL;
     igemm_set_bf16(dtype == FTE_MFMA_BF16);
@@ -220,26 +234,46 @@ size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksiz
     return both_modes([&] { return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true).pw_bytes; });
 }
 
-int fte_conv2d_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
-                   float* z, float* y, int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                   void* ws, size_t ws_bytes, void* stream) {
+// x / w are bf16 copies (x16 [n,h,wd,cin]; w16t [k*k][cout][cin], fte_pack_weights_bf16) when `src16`
+static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float* bias, const float* alpha, const float* res,
+                           float* z, float* y, uint16_t* y16, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                           void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !y || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3))
         return FTE_EINVAL;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     IgemmParams p;
     zero_params(&p);
     p.M = n * ph.out * pw.out; p.N = cout; p.K = ksize * ksize * cin; p.kchunk = p.K;
-    p.A = x; p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
+    p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
     p.a_ld = cin; p.a_KC = cin; p.a_NT = ksize * ksize;
     for (int r = 0; r < ksize; ++r)
         for (int s = 0; s < ksize; ++s) { p.a_dh[r * ksize + s] = r - ph.before; p.a_dw[r * ksize + s] = s - pw.before; }
-    p.B = w; p.b_ld = cout;
+    p.A = (const float*)x;
+    p.B = (const float*)w;
     p.c_ld = cout;
-    p.Y = y; p.Z = z; p.R = res; p.bias = bias; p.alpha = alpha;
-    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)ksize * ksize * cin * cout)) return FTE_EINVAL;
+    p.Y = y; p.Z = z; p.R = res; p.bias = bias; p.alpha = alpha; p.Y16 = y16;
+    int bl = BL_KN;
+    if (src16) {                                     // transposed pack: rows = output channels, k-contiguous per tap
+        p.src16 = 1; p.b_ld = cin; bl = BL_NK;
+        for (int t = 0; t < ksize * ksize; ++t) p.b_tapoff[t] = t * cout * cin;
+    } else {
+        p.b_ld = cout;
+    }
+    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
     RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr);
     if (rp.tail_mode == 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
-    return rc(launch_rows(p, rp, AL_MK, BL_KN, EPI_FWD, 0, (float*)ws, (hipStream_t)stream));
+    return rc(launch_rows(p, rp, AL_MK, bl, EPI_FWD, 0, (float*)ws, (hipStream_t)stream));
+}
+int fte_conv2d_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
+                   float* z, float* y, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                   void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_fwd_impl(x, w, false, bias, alpha, res, z, y, nullptr, n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
+}
+int fte_conv2d_fwd16(const uint16_t* x16, const uint16_t* w16t, const float* bias, const float* alpha, const float* res,
+                     float* z, float* y, uint16_t* y16, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                     void* ws, size_t ws_bytes, void* stream) {
+    Plan16 guard;
+    return conv2d_fwd_impl(x16, w16t, true, bias, alpha, res, z, y, y16, n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
 }
 
 size_t fte_conv3x3_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -328,9 +362,10 @@ size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
     });
 }
 
-int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
-                     const float* alpha_prev, float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
-                     int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
+// dz / w are bf16 copies (dz16 [n,ho,wo,cout]; w16 [k*k][cin][cout], the HWIO layout) when `src16`
+static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const float* addin, const float* zprev,
+                             const float* alpha_prev, float* raw, float* dzprev, uint16_t* dzprev16, float* dalpha_prev, float* dbias_prev,
+                             int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
     if (!dz || !w || !dzprev || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
     if (zprev && !alpha_prev) return FTE_EINVAL;
     const Pads pho = same_pads(h, ksize, stride), pwo = same_pads(wd, ksize, stride);
@@ -359,7 +394,7 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
         zero_params(&p);
         const DgradClass& c0 = cls[0];
         p.M = n * c0.hq * c0.wq; p.N = cin; p.a_KC = cout;
-        p.A = dz; p.a_OH = c0.hq; p.a_OW = c0.wq; p.a_IH = pho.out; p.a_IW = pwo.out; p.a_stride = 1; p.a_ld = cout;
+        p.A = (const float*)dz; p.a_OH = c0.hq; p.a_OW = c0.wq; p.a_IH = pho.out; p.a_IW = pwo.out; p.a_stride = 1; p.a_ld = cout;
         p.ncls = nc;
         int t = 0;
         for (int k = 0; k < nc; ++k) {
@@ -369,11 +404,12 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
         }
         p.cls_tap0[nc] = t;
         p.a_NT = t; p.K = t * cout; p.kchunk = p.K;
-        p.B = w; p.b_ld = cout;
+        p.B = (const float*)w; p.b_ld = cout;
         p.c_OH = c0.hq; p.c_OW = c0.wq; p.c_FH = h; p.c_FW = wd; p.c_step = stride; p.c_ld = cin;
         p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
         p.PA = PA; p.PB = PB; p.prow0 = 0;
-        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout)) return FTE_EINVAL;
+        p.src16 = src16 ? 1 : 0; p.DZ16 = dzprev16;
+        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
         hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_DGRAD, tile, 1, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     } else {
@@ -383,19 +419,20 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
         IgemmParams p;
         zero_params(&p);
         p.M = n * c.hq * c.wq; p.N = cin; p.K = c.ntap * cout; p.kchunk = p.K;
-        p.A = dz; p.a_OH = c.hq; p.a_OW = c.wq; p.a_IH = pho.out; p.a_IW = pwo.out; p.a_stride = 1;
+        p.A = (const float*)dz; p.a_OH = c.hq; p.a_OW = c.wq; p.a_IH = pho.out; p.a_IW = pwo.out; p.a_stride = 1;
         p.a_ld = cout; p.a_KC = cout; p.a_NT = c.ntap;
         for (int t = 0; t < c.ntap; ++t) {
             p.a_dh[t] = c.dh[t]; p.a_dw[t] = c.dw[t];
             p.b_tapoff[t] = c.wt[t] * cin * cout;
         }
-        p.B = w; p.b_ld = cout;
+        p.B = (const float*)w; p.b_ld = cout;
+        p.src16 = src16 ? 1 : 0; p.DZ16 = dzprev16;
         if (stride == 1) { p.c_OH = 0; }
         else { p.c_OH = c.hq; p.c_OW = c.wq; p.c_FH = h; p.c_FW = wd; p.c_step = stride; p.c_ph = c.ph; p.c_pw = c.pw; }
         p.c_ld = cin;
         p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
         p.PA = PA; p.PB = PB;
-        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout)) return FTE_EINVAL;
+        if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
         hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, pwbuf, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
         prow += c.mtiles;
@@ -411,6 +448,20 @@ int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const 
         }
     }
     return FTE_OK;
+}
+
+int fte_conv2d_dgrad(const float* dz, const float* w, const float* addin, const float* zprev,
+                     const float* alpha_prev, float* raw, float* dzprev, float* dalpha_prev, float* dbias_prev,
+                     int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_dgrad_impl(dz, w, false, addin, zprev, alpha_prev, raw, dzprev, nullptr, dalpha_prev, dbias_prev,
+                             n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
+}
+int fte_conv2d_dgrad16(const uint16_t* dz16, const uint16_t* w16, const float* addin, const float* zprev,
+                       const float* alpha_prev, float* raw, float* dzprev, uint16_t* dzprev16, float* dalpha_prev, float* dbias_prev,
+                       int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
+    Plan16 guard;
+    return conv2d_dgrad_impl(dz16, w16, true, addin, zprev, alpha_prev, raw, dzprev, dzprev16, dalpha_prev, dbias_prev,
+                             n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
 }
 
 size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -447,8 +498,9 @@ size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int s
     return fte_conv2d_wgrad_ws_bytes(n, h, wd, cin, cout, 3, stride);
 }
 
-int fte_conv2d_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                     void* ws, size_t ws_bytes, void* stream) {
+static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* dw, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (src16 && (cin % 8 || cout % 8)) return FTE_EINVAL;
     if (!x || !dz || !dw || n <= 0 || cin % 4 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     int tile, splits, kchunk, K;
@@ -458,20 +510,29 @@ int fte_conv2d_wgrad(const float* x, const float* dz, float* dw, int n, int h, i
     IgemmParams p;
     zero_params(&p);
     p.M = ksize * ksize * cin; p.N = cout; p.K = K; p.kchunk = kchunk;
-    p.A = x; p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
+    p.A = (const float*)x; p.a_OH = ph.out; p.a_OW = pw.out; p.a_IH = h; p.a_IW = wd; p.a_stride = stride;
     p.a_ld = cin; p.a_KC = cin; p.a_NT = ksize * ksize;
     for (int r = 0; r < ksize; ++r)
         for (int s = 0; s < ksize; ++s) { p.a_dh[r * ksize + s] = r - ph.before; p.a_dw[r * ksize + s] = s - pw.before; }
-    p.B = dz; p.b_ld = cout;
+    p.B = (const float*)dz; p.b_ld = cout;
     p.c_ld = cout;
     p.slab = (long)p.M * p.N;
     p.Y = splits > 1 ? (float*)ws : dw;
     p.split_major = 0;
-    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)K * cout)) return FTE_EINVAL;
+    p.src16 = src16 ? 1 : 0;
+    if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)K * cout, src16 ? 2 : 4)) return FTE_EINVAL;
     hipError_t e = igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     if (splits > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream));
     return FTE_OK;
+}
+int fte_conv2d_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                     void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_wgrad_impl(x, dz, false, dw, n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
+}
+int fte_conv2d_wgrad16(const uint16_t* x16, const uint16_t* dz16, float* dw, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                       void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_wgrad_impl(x16, dz16, true, dw, n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
 }
 int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
                       void* ws, size_t ws_bytes, void* stream) {

@@ -46,6 +46,10 @@ struct IgemmParams {
     // EPI_DGRAD, stride 2: ncls > 1 merges the output-parity classes into one launch (see igemm_kernel)
     int ncls, cls_tiles, cls_mtiles;
     int cls_tap0[5], cls_ph[4], cls_pw[4];
+    // bf16 operand copies: src16 != 0 -> A and B point at bf16 data (a_bytes / b_bytes count 2-byte elements' bytes) and the
+    // BF = 2 kernels run; Y16 / DZ16 != NULL -> the epilogue also writes a bf16 copy of Y / DZ for the next consumer
+    int src16;
+    unsigned short* Y16; unsigned short* DZ16;
 };
 
 hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st);

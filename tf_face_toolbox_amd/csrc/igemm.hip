@@ -67,6 +67,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 2; }
 
+__device__ __forceinline__ unsigned pkbf(float a, float b) {      // two floats -> packed bf16 pair, round to nearest even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ unsigned short tobf(float a) {
+    return __builtin_bit_cast(unsigned short, (__bf16)a);
+}
+
 __device__ __forceinline__ float prelu_slope(float z, float a) {
     // d/dz [relu(z) + a*(z-|z|)/2]; TF's grad of relu(0) and sign(0) are 0 -> a/2 at exactly 0.
     return z > 0.f ? 1.f : (z == 0.f ? 0.5f * a : a);
@@ -334,7 +341,163 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     // sources (KM / KN) hold rows k, k+1 of 4 consecutive m (n) and write four 32-bit words -- the transpose
     // happens in the write pass.  One LDS image per macro step (two barriers); the next macro step's buffer loads are in
     // flight under the MFMAs.  No k permutation.
-    if constexpr (BF) {
+    if constexpr (BF == 2) {
+        // ---- bf16 SOURCES (fte_*16 entry points): the operands already live in HBM as bf16 copies -- activations written
+        // by the producing epilogue (Y16 / DZ16), weights packed once per step -- so a K-step moves half the bytes through
+        // the texture-address path, needs no conversion and writes 16 bytes per lane into the same LDS image as BF = 1:
+        //   k-contiguous sources (MK / NK): lane = (row = tid>>2 + 64 i, 16-byte chunk = tid&3 = 8 k values) -> ds_write_b128
+        //   row-contiguous sources (KM / KN): lane = (k pair = tid>>4, 8 consecutive m / n) loads rows k and k+1 and writes
+        //   eight packed 32-bit words (v_perm_b32) -- the transpose happens in the write pass, as in BF = 1.
+        // Two LDS images, one barrier per K-step.
+        static_assert(!(AL == AL_MK && BL == BL_KN), "forward with bf16 sources takes the transposed weight pack (NK)");
+        char* lds = reinterpret_cast<char*>(smem);
+        auto off16 = [](int row, int chunk) -> int { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); };
+        constexpr int SUB_B = (BM + BN) * 64;
+        constexpr int AR = (BM + 63) / 64, BR = (BN + 63) / 64;          // 16-byte loads per thread, k-contiguous sources
+        constexpr int AP = (BM + 127) / 128, BP = (BN + 127) / 128;      // k-pair loads per thread, row-contiguous sources
+        const int r4 = tid >> 2, c4 = tid & 3, kp = tid >> 4, c16 = tid & 15;
+        auto ldg16 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) -> u32x4 {
+            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+        };
+        unsigned a16_base[AR]; int a16_mask[AR];        // MK
+        int a16_c[AP], a16_dhw[AP];                     // KM
+        if constexpr (AL == AL_MK) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int m = m0 + r4 + 64 * i;
+                int base = 0, mask = 0;
+                if (m < p.M && r4 + 64 * i < BM) {
+                    const int hw = p.a_OH * p.a_OW;
+                    const int n = m / hw, rem = m - n * hw;
+                    const int oh = rem / p.a_OW, ow = rem - oh * p.a_OW;
+                    const int ih0 = oh * p.a_stride, iw0 = ow * p.a_stride;
+                    base = ((n * p.a_IH + ih0) * p.a_IW + iw0) * p.a_ld;
+                    for (int t = 0; t < NT; ++t) {
+                        const int ih = ih0 + p.a_dh[tap0 + t], iw = iw0 + p.a_dw[tap0 + t];
+                        if (ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW) mask |= 1 << t;
+                    }
+                }
+                a16_base[i] = (unsigned)(base + (c4 << 3)) * 2u;
+                a16_mask[i] = mask;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < AP; ++j) {
+                const int ml = 8 * (c16 + 16 * j);
+                const int m = m0 + ml;
+                const int t = m / p.a_KC;
+                a16_c[j] = (m - t * p.a_KC) * 2;
+                const int tt = t < p.a_NT ? t : 0;
+                a16_dhw[j] = (p.a_dh[tt] + 8) | ((p.a_dw[tt] + 8) << 8) | ((m < p.M && ml < BM ? 1 : 0) << 16);
+            }
+        }
+        unsigned b16_base[BL == BL_NK ? BR : 2 * BP];
+        if constexpr (BL == BL_NK) {
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                b16_base[i] = (r4 + 64 * i < BN) ? (unsigned)((n0 + r4 + 64 * i) * p.b_ld + (c4 << 3)) * 2u : OOB;
+        } else {
+#pragma unroll
+            for (int j = 0; j < BP; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    b16_base[2 * j + e] = (8 * (c16 + 16 * j) < BN) ? (unsigned)((2 * kp + e) * p.b_ld + n0 + 8 * (c16 + 16 * j)) * 2u : OOB;
+        }
+        u32x4 ga[AL == AL_MK ? AR : 2 * AP], gb[BL == BL_NK ? BR : 2 * BP];
+        int ptap = 0, pkc = 0;
+        if constexpr (AL == AL_MK || BL == BL_NK) { ptap = ktap(kbeg); pkc = kchan(kbeg); }
+        auto load16 = [&](int k0) {
+            if constexpr (AL == AL_MK) {
+                const unsigned toff = (unsigned)((p.a_dh[tap0 + ptap] * p.a_IW + p.a_dw[tap0 + ptap]) * p.a_ld + pkc) * 2u;
+#pragma unroll
+                for (int i = 0; i < AR; ++i) ga[i] = ldg16(rsrcA, ((a16_mask[i] >> ptap) & 1) ? a16_base[i] + toff : OOB, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int pix = k0 + 2 * kp + e;
+                    const bool kin = pix < kend;
+                    const int hw = p.a_OH * p.a_OW;
+                    const int n = pix / hw;
+                    const int rem = pix - n * hw;
+                    const int oh = rem / p.a_OW;
+                    const int ih0 = oh * p.a_stride;
+                    const int iw0 = (rem - oh * p.a_OW) * p.a_stride;
+#pragma unroll
+                    for (int j = 0; j < AP; ++j) {
+                        const int ih = ih0 + (a16_dhw[j] & 0xff) - 8, iw = iw0 + ((a16_dhw[j] >> 8) & 0xff) - 8;
+                        const bool ok = kin && (a16_dhw[j] >> 16) && ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW;
+                        ga[2 * j + e] = ldg16(rsrcA, ok ? (unsigned)(((n * p.a_IH + ih) * p.a_IW + iw) * p.a_ld) * 2u + a16_c[j] : OOB, 0);
+                    }
+                }
+            }
+            if constexpr (BL == BL_NK) {
+                const unsigned toff = (unsigned)(p.b_tapoff[tap0 + ptap] + pkc) * 2u;
+#pragma unroll
+                for (int i = 0; i < BR; ++i) gb[i] = ldg16(rsrcB, b16_base[i], toff);
+            } else {
+                const unsigned koff = (unsigned)(k0 * p.b_ld) * 2u;
+#pragma unroll
+                for (int i = 0; i < 2 * BP; ++i) gb[i] = ldg16(rsrcB, (k0 + 2 * kp + (i & 1) < kend) ? b16_base[i] : OOB, koff);
+            }
+            if constexpr (AL == AL_MK || BL == BL_NK) {
+                if (++ptap == NT) { ptap = 0; pkc += BK; }
+            }
+        };
+        auto store_pairs = [&](char* T, int rows, const u32x4& v0, const u32x4& v1, int j) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int r = 8 * (c16 + 16 * j) + 2 * w;
+                if (r < rows) {
+                    *reinterpret_cast<unsigned*>(T + off16(r, kp >> 2) + (kp & 3) * 4) = __builtin_amdgcn_perm(v1[w], v0[w], 0x05040100u);
+                    *reinterpret_cast<unsigned*>(T + off16(r + 1, kp >> 2) + (kp & 3) * 4) = __builtin_amdgcn_perm(v1[w], v0[w], 0x07060302u);
+                }
+            }
+        };
+        auto store16 = [&](int stage) {
+            char* As = lds + stage * SUB_B;
+            char* Bs = As + BM * 64;
+            if constexpr (AL == AL_MK) {
+#pragma unroll
+                for (int i = 0; i < AR; ++i)
+                    if (r4 + 64 * i < BM) *reinterpret_cast<u32x4*>(As + off16(r4 + 64 * i, c4)) = ga[i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < AP; ++j) store_pairs(As, BM, ga[2 * j], ga[2 * j + 1], j);
+            }
+            if constexpr (BL == BL_NK) {
+#pragma unroll
+                for (int i = 0; i < BR; ++i)
+                    if (r4 + 64 * i < BN) *reinterpret_cast<u32x4*>(Bs + off16(r4 + 64 * i, c4)) = gb[i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < BP; ++j) store_pairs(Bs, BN, gb[2 * j], gb[2 * j + 1], j);
+            }
+        };
+        if (nsteps > 0) load16(kbeg);
+        for (int st = 0; st < nsteps; ++st) {
+            store16(st & 1);
+            __syncthreads();
+            if (st + 1 < nsteps) load16(kbeg + (st + 1) * BK);
+            const char* As = lds + (st & 1) * SUB_B;
+            const char* Bs = As + BM * 64;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8*>(As + off16(wm * (TM * 32) + i * 32 + li, 2 * h + lh));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j] = *reinterpret_cast<const bf16x8*>(Bs + off16(wn * (TN * 32) + j * 32 + li, 2 * h + lh));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();           // the epilogue reuses the LDS
+    } else if constexpr (BF) {
         char* lds = reinterpret_cast<char*>(smem);
         auto off16 = [](int row, int chunk) -> int { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); };
         auto pk = [](float a, float b) -> unsigned {
@@ -639,6 +802,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                         }
                         if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + o);
                         *reinterpret_cast<f32x4*>(Y + o) = v;
+                        if (p.Y16) *reinterpret_cast<u32x2*>(p.Y16 + o) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
                     } else {
                         if (p.ADD) v += *reinterpret_cast<const f32x4*>(p.ADD + o);
                         if (p.RAW) *reinterpret_cast<f32x4*>(p.RAW + o) = v;
@@ -652,6 +816,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                             }
                         }
                         *reinterpret_cast<f32x4*>(p.DZ + o) = v;
+                        if (p.DZ16) *reinterpret_cast<u32x2*>(p.DZ16 + o) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
                     }
                 }
             }
@@ -758,6 +923,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, i
                 if (p.Z) p.Z[o] = x;
                 if (act) x = x > 0.f ? x : al * x;
                 p.Y[o] = x + rres[u];
+                if (p.Y16) p.Y16[o] = tobf(x + rres[u]);
             }
         }
     } else {
@@ -791,6 +957,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, i
                     sb += x;
                 }
                 p.DZ[o] = x;
+                if (p.DZ16) p.DZ16[o] = tobf(x);
             }
         }
         if (p.PA) {
@@ -832,7 +999,8 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     const size_t epi = (size_t)(BM + 4 * 32 * 36 + 2 * WM * BN) * sizeof(float);      // row offsets + 4 transpose patches + column partials
     const size_t loop = (size_t)KSL * (BM + BN) * 64;
     const size_t loop32 = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
-    const size_t lds = BF ? (loop > epi ? loop : epi) : (epi > loop32 ? epi : loop32);
+    const size_t loop16 = 2 * (size_t)(BM + BN) * 64;
+    const size_t lds = BF == 2 ? (loop16 > epi ? loop16 : epi) : (BF ? (loop > epi ? loop : epi) : (epi > loop32 ? epi : loop32));
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -853,6 +1021,10 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
 bool g_bf16 = false;      // igemm_set_bf16(): operand precision of every launch of the family
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
 hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
+    if (p.src16) {                           // bf16 sources: forward / dgrad take NK weight packs, wgrad KM x KN
+        if constexpr (!(AL == AL_MK && BL == BL_KN)) return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 2>(p, splits, st);
+        else return hipErrorInvalidValue;
+    }
     if (g_bf16) return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 1>(p, splits, st);
     return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 0>(p, splits, st);
 }

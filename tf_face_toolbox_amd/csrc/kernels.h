@@ -16,6 +16,8 @@ hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* 
                           int fold, float scale, float* scratch, hipStream_t st);
 hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, bool sq, hipStream_t st);
 hipError_t k_softmax_ce(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld, float gs, hipStream_t st);
+hipError_t k_to_bf16(const float* x, unsigned short* y, long n, hipStream_t st);
+hipError_t k_pack_weights_bf16(const float* w, unsigned short* w16, unsigned short* w16t, int taps, int cin, int cout, hipStream_t st);
 hipError_t k_focal_loss(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld,
                         float gamma, float alpha, float gs, hipStream_t st);
 hipError_t k_asoftmax(const float* s, const float* xn, const float* wn, const int32_t* labels, float lam, float* f, float* loss_rows,

@@ -598,6 +598,42 @@ hipError_t k_softmax_ce(const float* logits, const int32_t* labels, float* loss_
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gs);
     return hipGetLastError();
 }
+namespace {
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        unsigned short o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
+        *reinterpret_cast<uint2*>(y + i * 4) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+    }
+}
+// w [taps][cin][cout] fp32 -> w16 (same layout) and w16t [taps][cout][cin]
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ w16,
+                                                           unsigned short* __restrict__ w16t, int taps, int cin, int cout) {
+    const long total = (long)taps * cin * cout;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const unsigned short v = __builtin_bit_cast(unsigned short, (__bf16)w[i]);
+        if (w16) w16[i] = v;
+        if (w16t) {
+            const int co = (int)(i % cout);
+            const long t2 = i / cout;
+            const int ci = (int)(t2 % cin), tap = (int)(t2 / cin);
+            w16t[((long)tap * cout + co) * cin + ci] = v;
+        }
+    }
+}
+}  // namespace
+hipError_t k_to_bf16(const float* x, unsigned short* y, long n, hipStream_t st) {
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)), dim3(256), 0, st, x, y, n4);
+    return hipGetLastError();
+}
+hipError_t k_pack_weights_bf16(const float* w, unsigned short* w16, unsigned short* w16t, int taps, int cin, int cout, hipStream_t st) {
+    const long total = (long)taps * cin * cout;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, st, w, w16, w16t, taps, cin, cout);
+    return hipGetLastError();
+}
 hipError_t k_focal_loss(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld,
                         float gamma, float alpha, float gs, hipStream_t st) {
     hipLaunchKernelGGL(focal_loss_kernel, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gamma, alpha, gs);
