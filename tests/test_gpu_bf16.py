@@ -168,3 +168,28 @@ def test_bf16_source_entry_points_equal_the_operand_mode_bit_for_bit(bf16_mode, 
     dw1 = torch.empty_like(wt)
     _lib.call('fte_conv2d_wgrad16', x16, dz16, dw1, n, h, w, cin, cout, k, stride, buf, nb, st)
     assert torch.equal(dw1, dw0)
+
+
+def test_spherenet_step_with_bf16_copies_equals_operand_mode_bit_for_bit(bf16_mode):
+    """SphereNet routes its convolutions through the bf16-copy entry points in the bf16 mode (y16 / dz16 written by the
+    producing epilogues, weights packed per step).  Same arithmetic -> every gradient bit-identical to the operand mode."""
+    from tf_face_toolbox_amd import net_select
+    n, h, w, ncls = 6, 64, 64, 30
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).cuda(); y = torch.randint(0, ncls, (n,), generator=g, dtype=torch.int32).cuda()
+    outs = []
+    for copies in (False, True):
+        net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+        net.seed = 9
+        net.bf16_copies = copies
+        net.build(h, w, 3, ncls, 'cuda')
+        o = net.forward(x, y, num_classes=ncls, is_training=True)
+        losses, _, _ = net.loss_function('T', y, **o)
+        net.backward()
+        torch.cuda.synchronize()
+        assert (net.y16 is not None) == copies
+        outs.append(([float(v) for v in losses], net.grads.clone(), net.emb.clone()))
+        e_eval = net.forward(x, is_training=False).clone()          # flip-averaged eval path through the same kernels
+        outs[-1] += (e_eval,)
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])

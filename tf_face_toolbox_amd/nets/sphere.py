@@ -16,6 +16,7 @@ MI355X-first layout decisions (engine-internal; the boundary keeps the reference
   * every conv keeps z (pre-activation) and y = PReLU(z) (+shortcut): backward needs sign(z)
     and min(z,0) exactly, for any alpha.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -59,6 +60,9 @@ class SphereNet(Network):
         self.num_outputs = [64, 128, 256, 512]
         self.seed = seed
         self.built = False
+        # in the bf16 MFMA mode the convs read bf16 COPIES of their operands (written by the producing epilogue / packed
+        # once per step) through fte_conv2d_*16: bit-identical to the operand mode, half the bytes through the load path
+        self.bf16_copies = os.environ.get('FTE_BF16_COPIES', '1') != '0'
         self.tower_scale = 1.0        # 1/num_gpus, set by the parallel wrapper (data_parallel.py:37)
         self.global_step = 0          # A-softmax lambda annealing reads it
         self._act_n = None
@@ -220,6 +224,28 @@ class SphereNet(Network):
         self.ws = torch.empty((need + 3) // 4 + 1024, **f32)
         self.ws_bytes = self.ws.numel() * 4
         self._act_n = n
+        self.y16 = None                                   # allocated on first use (_alloc_copies)
+
+    def _use_copies(self):
+        return self.bf16_copies and _lib.get_mfma_dtype() == 'bf16'
+
+    def _alloc_copies(self):
+        """bf16 copies of what the conv MFMAs read: y16[l] (written by layer l's forward epilogue), dz16 per stage
+        (written by the dgrad epilogue), the weight packs w16 (HWIO, dgrad) and w16t ([tap][cout][cin], forward)."""
+        if self.y16 is not None and self.y16[0].shape[0] == self._act_n:
+            return
+        i16 = dict(dtype=torch.int16, device=self.device)
+        self.y16 = [torch.empty(t.shape, **i16) for t in self.y]
+        for si in range(4):
+            b = self.bwd[si]
+            b['dz16'] = [torch.empty(b['dz'][0].shape, **i16), torch.empty(b['dz'][0].shape, **i16)]
+        if getattr(self, 'w16', None) is None:
+            self.w16 = {c.name: torch.empty(3, 3, c.cin, c.cout, **i16) for c in self.convs[1:]}
+            self.w16t = {c.name: torch.empty(3, 3, c.cout, c.cin, **i16) for c in self.convs[1:]}
+
+    def _pack_weights(self, st):
+        for c in self.convs[1:]:
+            _lib.call('fte_pack_weights_bf16', self.view(c.name + '/weights'), self.w16[c.name], self.w16t[c.name], 3, c.cin, c.cout, st)
 
     # ------------------------------------------------------------------ forward
     def prelu(self, x, name='prelu'):
@@ -244,6 +270,11 @@ class SphereNet(Network):
         call = _lib.call
         keep = is_training
         self._images = x
+        copies = self._use_copies()
+        self._copies_live = copies and keep              # backward of THIS forward may use the bf16 copies
+        if copies:
+            self._alloc_copies()
+            self._pack_weights(st)
         for l, c in enumerate(self.convs):
             wv = self.view(c.name + '/weights')
             bv = self.view(c.name + '/biases') if c.has_bias else None
@@ -251,10 +282,16 @@ class SphereNet(Network):
             zz = self.z[l] if keep else None
             if l == 0:
                 call('fte_conv3x3_first_fwd', x, wv, bv, av, zz, self.y[0], n, c.hin, c.win, c.cin, c.cout, c.stride, st)
+                if copies:
+                    call('fte_to_bf16', self.y[0], self.y16[0], self.y[0].numel(), st)
             else:
                 res = self.y[l - 2] if c.second == 1 else None
-                call('fte_conv3x3_fwd', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
-                     n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
+                if copies:
+                    call('fte_conv2d_fwd16', self.y16[l - 1], self.w16t[c.name], bv, av, res, zz, self.y[l], self.y16[l],
+                         n, c.hin, c.win, c.cin, c.cout, 3, c.stride, self.ws, self.ws_bytes, st)
+                else:
+                    call('fte_conv3x3_fwd', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
+                         n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
         call('fte_gemm_nn', self.y[-1], self.view(self.name + '/fully_connected/weights'),
              self.view(self.name + '/fully_connected/biases'), self.emb, n, EMBED, self.fin, self.ws, self.ws_bytes, st)
         return self.emb
@@ -367,6 +404,11 @@ class SphereNet(Network):
         b4['rawi'], b4['dzi'] = 0, 0
         call('fte_gemm_nt', self.demb, self.view(fcw), self.z[last], self.view(L[last].name + '/alpha'), L[last].cout,
              d_out, dz_cur, self.view(L[last].name + '/alpha', g), n, EMBED, self.fin, self.ws, self.ws_bytes, st)
+        copies = getattr(self, '_copies_live', False) and self._use_copies()
+        dz16_cur = None
+        if copies:
+            dz16_cur = b4['dz16'][0]
+            call('fte_to_bf16', dz_cur, dz16_cur, dz_cur.numel(), st)
         trace = getattr(self, '_trace_dz', None)
         for l in range(last, -1, -1):
             c = L[l]
@@ -377,8 +419,12 @@ class SphereNet(Network):
                 call('fte_conv3x3_first_wgrad', self._images, dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
                      self.ws, self.ws_bytes, st)
                 break
-            call('fte_conv3x3_wgrad', self.y[l - 1], dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
-                 self.ws, self.ws_bytes, st)
+            if copies:
+                call('fte_conv2d_wgrad16', self.y16[l - 1], dz16_cur, gw, n, c.hin, c.win, c.cin, c.cout, 3, c.stride,
+                     self.ws, self.ws_bytes, st)
+            else:
+                call('fte_conv3x3_wgrad', self.y[l - 1], dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
+                     self.ws, self.ws_bytes, st)
             p = L[l - 1]
             bp = self.bwd[p.stage]
             addin = d_out if c.second == 0 else None
@@ -390,10 +436,18 @@ class SphereNet(Network):
                 dz_prev = bp['dz'][bp['dzi']]
                 raw_t = bp['raw'][bp['rawi'] ^ 1]
             raw = raw_t if p.second == 1 else None
-            call('fte_conv3x3_dgrad', dz_cur, self.view(c.name + '/weights'), addin, self.z[l - 1],
-                 self.view(p.name + '/alpha'), raw, dz_prev, self.view(p.name + '/alpha', g),
-                 self.view(p.name + '/biases', g) if p.has_bias else None,
-                 n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
+            if copies:
+                dz16_prev = bp['dz16'][bp['dzi']]
+                call('fte_conv2d_dgrad16', dz16_cur, self.w16[c.name], addin, self.z[l - 1],
+                     self.view(p.name + '/alpha'), raw, dz_prev, dz16_prev, self.view(p.name + '/alpha', g),
+                     self.view(p.name + '/biases', g) if p.has_bias else None,
+                     n, c.hin, c.win, c.cin, c.cout, 3, c.stride, self.ws, self.ws_bytes, st)
+                dz16_cur = dz16_prev
+            else:
+                call('fte_conv3x3_dgrad', dz_cur, self.view(c.name + '/weights'), addin, self.z[l - 1],
+                     self.view(p.name + '/alpha'), raw, dz_prev, self.view(p.name + '/alpha', g),
+                     self.view(p.name + '/biases', g) if p.has_bias else None,
+                     n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
             if raw is not None:
                 d_out = raw
                 if p.stage == c.stage:
