@@ -16,7 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle import ops, spherenet as osn      # noqa: E402
+from oracle import ops, spherenet as osn, graphnet as og      # noqa: E402
 
 
 def sample_idx(shape, k=24, seed=0):
@@ -75,8 +75,51 @@ def heads_case():
     print('heads ok')
 
 
+def graphnet_cases():
+    """Small graph-net steps (BN nets): ResNet-26, ResNeXt-26 + center loss, SE-ResNet-26 + triplet, ShuffleNet-v2 x2 with one
+    block per stage and the focal head.  Parameters are regenerated from the seed (oracle.graphnet.init_params)."""
+    out = {}
+    cases = [('resnet26', lambda ncls: og.resnet_train_graph(26, 3, ncls), dict()),
+             ('resnext26_center', lambda ncls: og.resnet_train_graph(26, 3, ncls, 'resnext'), dict(center=True)),
+             ('senet26_triplet', lambda ncls: og.resnet_train_graph(26, 3, ncls, 'senet', classifier=False), dict(triplet=True)),
+             ('shufflenet_small_focal', lambda ncls: og.shufflenet_train_graph('small', 3, ncls, 'NCHW', blocks_override=[1, 1, 1]), dict(focal=(1.0, 2.0)))]
+    for ci, (tag, build, opt) in enumerate(cases):
+        n, h, w, ncls = 8, 32, 32, 6
+        seed = 500 + 10 * ci
+        graph, spec = build(ncls)
+        p, state = og.init_params(spec, seed)
+        p = og.perturb(p, seed + 1)
+        rng = np.random.default_rng(seed + 2)
+        x = rng.uniform(-1, 1, (n, h, w, 3)).astype(np.float32).astype(np.float64)      # stored (and fed to the GPU) as float32
+        y = np.repeat(np.arange(4), 2) if opt.get('triplet') else rng.integers(0, ncls, n)
+        fdim = 2048
+        masks = None if opt.get('triplet') else {'features_drop': (rng.random((n, fdim)) < 0.5).astype(np.float64)}
+        kw = {}
+        if opt.get('center'):
+            kw['center'] = dict(centers=rng.standard_normal((ncls, fdim)) * 0.1, alpha=0.99, weight=0.05)
+            out[tag + '/centers'] = kw['center']['centers']
+        if opt.get('triplet'):
+            kw['triplet_margin'] = None
+        if opt.get('focal'):
+            kw['focal'] = opt['focal']
+        res = og.loss_and_grads(graph, p, x, y, 5e-4, masks=masks, state=state, **kw)
+        losses, g, env, new_state = res[0], res[1], res[2], res[3]
+        out[tag + '/meta'] = np.array([seed, n, h, w, ncls])
+        out[tag + '/images'] = x.astype(np.float32); out[tag + '/labels'] = y.astype(np.int32)
+        if masks:
+            out[tag + '/mask'] = masks['features_drop'].astype(np.uint8)
+        out[tag + '/losses'] = np.array(losses); out[tag + '/features'] = env['features']
+        names = sorted(g)
+        out[tag + '/gl2'] = np.array([np.sqrt((g[k] ** 2).sum()) for k in names])
+        k0 = [k for k in sorted(new_state) if k.endswith('moving_variance')][0]
+        out[tag + '/mv0'] = new_state[k0]
+        print(tag, 'losses', losses, len(names), 'gradients')
+    np.savez_compressed(os.path.join(HERE, 'graphnets.npz'), **out)
+
+
 if __name__ == '__main__':
     spherenet_case('sphere_softmax_nchw_32', 101, 4, 32, 32, 3, 10, 'NCHW', 'softmax')
     spherenet_case('sphere_asoftmax_nhwc_gray_48x16', 202, 3, 48, 16, 1, 33, 'NHWC', 'asoftmax')
     spherenet_case('sphere_asoftmax_nchw_112_gray', 303, 2, 112, 112, 1, 200, 'NCHW', 'asoftmax')
     heads_case()
+    graphnet_cases()

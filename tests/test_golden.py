@@ -50,3 +50,38 @@ def test_oracle_reproduces_head_goldens():
     np.testing.assert_allclose([ops.lr_step(s, 0.1, 0.1, ['3', '5', '9'], 100) for s in steps], g['lr_step'], rtol=1e-15)
     np.testing.assert_allclose([ops.lr_exp(s, 0.1, 2, 12, 100) for s in steps], g['lr_exp'], rtol=1e-15)
     np.testing.assert_allclose([ops.lr_cosine(s, 0.1, 12, 100) for s in steps], g['lr_cos'], rtol=1e-15, atol=1e-18)
+
+
+GRAPH_CASES = ['resnet26', 'resnext26_center', 'senet26_triplet', 'shufflenet_small_focal']
+
+
+def graph_case_setup(g, tag):
+    """Shared with tests/test_gpu_golden.py: rebuilds graph / params / inputs of one graphnets.npz case from its seed."""
+    from oracle import graphnet as og
+    seed, n, h, w, ncls = [int(v) for v in g[tag + '/meta']]
+    graph, spec = {'resnet26': lambda: og.resnet_train_graph(26, 3, ncls),
+                   'resnext26_center': lambda: og.resnet_train_graph(26, 3, ncls, 'resnext'),
+                   'senet26_triplet': lambda: og.resnet_train_graph(26, 3, ncls, 'senet', classifier=False),
+                   'shufflenet_small_focal': lambda: og.shufflenet_train_graph('small', 3, ncls, 'NCHW', blocks_override=[1, 1, 1])}[tag]()
+    p, state = og.init_params(spec, seed)
+    p = og.perturb(p, seed + 1)
+    kw = {}
+    if tag == 'resnext26_center':
+        kw['center'] = dict(centers=g[tag + '/centers'], alpha=0.99, weight=0.05)
+    if tag == 'senet26_triplet':
+        kw['triplet_margin'] = None
+    if tag == 'shufflenet_small_focal':
+        kw['focal'] = (1.0, 2.0)
+    masks = {'features_drop': g[tag + '/mask'].astype(np.float64)} if tag + '/mask' in g.files else None
+    return graph, spec, p, state, g[tag + '/images'].astype(np.float64), g[tag + '/labels'].astype(np.int64), masks, kw
+
+
+@pytest.mark.parametrize('tag', GRAPH_CASES)
+def test_oracle_reproduces_graphnet_goldens(tag):
+    from oracle import graphnet as og
+    g = np.load(os.path.join(GOLD, 'graphnets.npz'))
+    graph, spec, p, state, x, y, masks, kw = graph_case_setup(g, tag)
+    res = og.loss_and_grads(graph, p, x, y, 5e-4, masks=masks, state=state, **kw)
+    np.testing.assert_allclose(np.array(res[0]), g[tag + '/losses'], rtol=1e-9)        # images were stored as float32
+    np.testing.assert_allclose(res[2]['features'], g[tag + '/features'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose([np.sqrt((res[1][k] ** 2).sum()) for k in sorted(res[1])], g[tag + '/gl2'], rtol=1e-6, atol=1e-12)   # atol: exact-zero gradients (a BN beta in front of conv -> BN) are 1e-18 noise

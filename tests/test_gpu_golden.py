@@ -78,3 +78,49 @@ def test_head_goldens():
         call('fte_batch_hard_triplet_fwd_bwd', dev(x), dev(g['tri_labels'], torch.int32), -1.0 if m is None else m, 1.0,
              tl, tg, n, d, wsb, nb, stream())
         check_maxabs(host(tl), g['tri_loss_%s' % m], what='triplet loss'); check_maxabs(host(tg), g['tri_grad_%s' % m], what='triplet grad')
+
+
+@pytest.mark.parametrize('tag', ['resnet26', 'resnext26_center', 'senet26_triplet', 'shufflenet_small_focal'])
+def test_graphnet_goldens(tag):
+    """The BN nets against the committed known-answer cases (tests/golden/graphnets.npz): losses, pooled features, the
+    L2 norm of every gradient tensor (the per-element comparison with kink resolution lives in test_gpu_resnet /
+    test_gpu_shufflenet; a golden file cannot know which side of a ReLU kink the fp32 run takes) and a moving variance."""
+    from test_golden import graph_case_setup
+    from tf_face_toolbox_amd.nets.resnet import ResNet, ResNeXt, SENet
+    from tf_face_toolbox_amd.nets.shufflenet_v2 import ShuffleNet_v2_small
+    g = np.load(os.path.join(GOLD, 'graphnets.npz'))
+    graph, spec, p, state, x, y, masks, kw = graph_case_setup(g, tag)
+    seed, n, h, w, ncls = [int(v) for v in g[tag + '/meta']]
+    if tag == 'resnet26':
+        net = ResNet(26)
+    elif tag == 'resnext26_center':
+        net = ResNeXt(26, head='softmax+center', center_weight=0.05)
+    elif tag == 'senet26_triplet':
+        net = SENet(26, head='triplet')
+    else:
+        net = ShuffleNet_v2_small(alpha=2.0); net.num_block = [1, 1, 1]; net.head = 'focal'
+    net.build(h, w, 3, ncls, 'cuda')
+    assert net.graph == graph
+    net.load_params(p)
+    if 'center' in kw:
+        net._centers().copy_(torch.tensor(kw['center']['centers'], dtype=torch.float32))
+    out = net.forward(dev(x), num_classes=ncls, is_training=True)
+    if masks is not None:                                   # replay the fixture's dropout mask instead of the RNG's
+        net.t['features_drop/mask'].copy_(dev(masks['features_drop']))
+        net.t['features_drop'].copy_(net.t['features'] * net.t['features_drop/mask'] / 0.5)
+        plan_fc = net.plan[-1]
+        call('fte_gemm_nn', net.t[plan_fc[2]], net.view(plan_fc[3]), None, net.t['logits'], n, net.cpad, 2048, net.ws, net.ws_bytes, stream())
+    losses, names, _ = net.loss_function('T', dev(y, torch.int32), **out)
+    net.backward()
+    torch.cuda.synchronize()
+    check_maxabs(host(net.t['features'])[..., :2048], g[tag + '/features'], 5e-5, 'pooled features')
+    got = [float(v) for v in losses]
+    for a, b in zip(got, g[tag + '/losses']):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (names, got, g[tag + '/losses'])
+    gl2 = [float(torch.linalg.vector_norm(net.get_variable(k, net.grads).double() + (5e-4 * torch.tensor(p[k], device='cuda') if k.endswith('weights') else 0)))
+           for k in sorted(p) if k in net.variables]
+    ref = g[tag + '/gl2']
+    assert len(gl2) == len(ref)
+    for k, a, b in zip(sorted(p), gl2, ref):
+        # 1 %: at 8 x 32 x 32 a handful of ReLU / max-pool decisions inside fp32's noise band move a norm by a few 1e-3
+        assert abs(a - b) <= 1e-2 * max(b, 1e-5 * ref.max()), (k, a, b)
