@@ -78,3 +78,28 @@ def test_bench_py_runs_with_two_ranks(tmp_path):
     assert out['value'] > 0 and abs(out['value'] - 16 / (out['ms_per_step'] * 1e-3)) <= 0.01 * out['value']
     assert out['cpu_baseline'] is None and out['roofline']['frac'] > 0
     assert all(np.isfinite(v) for v in out['losses'].values())
+
+
+@pytest.mark.parametrize('name', ['ResNeXt-26', 'ShuffleNet-v2-small'])
+def test_two_ranks_bn_nets_stay_identical(tmp_path, name):
+    """The graph-engine nets under the same 2-rank run: per-shard BN statistics and per-rank dropout masks differ by design
+    (data_parallel.py:242-243), the all-reduced gradients and therefore every trainable variable must not."""
+    n, h, w, ch, ncls, steps = 8, 32, 32, 3, 10, 3
+    rng = np.random.default_rng(5)
+    fix = str(tmp_path / 'fix.npz')
+    np.savez(fix, x=rng.uniform(-1, 1, (n, h, w, ch)), y=rng.integers(0, ncls, n), ncls=ncls)
+    out = str(tmp_path / 'out')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(ROOT, 'tests', 'dp_worker.py'), fix, out, name, str(steps)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    r0, r1 = np.load(out + '.rank0.npz'), np.load(out + '.rank1.npz')
+    moved = 0
+    for k in r0.files:
+        if k.startswith('w:'):
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+            moved += int(np.abs(r0[k]).sum() > 0)
+    assert moved > 10 and np.isfinite(r0['losses']).all()
+    np.testing.assert_array_equal(r0['losses'], r1['losses'])        # displayed losses are all-reduced means
