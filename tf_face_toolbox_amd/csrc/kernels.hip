@@ -38,66 +38,75 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 }
 
 // ------------------------------------------------------------------------------------
-// First conv (nets/sphere.py:57): Cin in {1,3}, Cout = 64, 3x3, TF-SAME.  K = 9*Cin is far
-// too short for MFMA; the layer is bound by the 2 x [N,Ho,Wo,64] fp32 writes (z and y).
-// Thread = 4 consecutive output pixels (along ow) x 4 consecutive output channels;
-// 16 threads cover one pixel's 64 channels -> 256-B coalesced row stores; weights in LDS.
+// First conv (nets/sphere.py:57): Cin in {1,3}, Cout = 64, 3x3, TF-SAME; bound by the 2 x [N,Ho,Wo,64] fp32 writes (z, y).
+// out[pixel][co] = sum_k patch(pixel)[k] * W[k][co] with K = 9*Cin <= 27 on v_mfma_f32_32x32x2_f32: 32 pixels on the rows,
+// k pairs on the reduction axis, two 32-column halves.  Lane (li, lh) gathers x[patch position 2s + lh] of pixel li for the
+// 14 k-steps (14 loads per lane and 32 pixels; a thread-per-(pixels x channel quad) loop re-loaded every x value from 16
+// lanes and ran at 31 % of HBM speed) and keeps its 28 weight values W[2s + lh][li], W[2s + lh][32 + li] in registers.
+// A wave walks 32-pixel groups of whole output rows.
 // ------------------------------------------------------------------------------------
+typedef float f32x16f __attribute__((ext_vector_type(16)));
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ alpha, float* __restrict__ z, float* __restrict__ y,
     int n, int h, int wd, int ho, int wo, int stride, int pt, int pl) {
-    constexpr int COUT = 64, K = 9 * CIN;
-    __shared__ __attribute__((aligned(16))) float ws[K * COUT];
-    for (int i = threadIdx.x; i < K * COUT; i += 256) ws[i] = w[i];
-    __syncthreads();
-    const int cq = threadIdx.x & 15;                      // channel quad
-    const int wo4 = (wo + 3) >> 2;
-    const long grp = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const long ngrp = (long)n * ho * wo4;
-    if (grp >= ngrp) return;
-    const int owg = (int)(grp % wo4);
-    const long t = grp / wo4;
-    const int oh = (int)(t % ho), img = (int)(t / ho);
-    const int ow0 = owg * 4;
-    f32x4 acc[4];
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+    constexpr int COUT = 64, K = 9 * CIN, KS = (K + 1) / 2;
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    float wb0[KS], wb1[KS];
+    int kr[KS], kq[KS], kc[KS];                 // (row tap, column tap, channel) of this lane's k index in every k-step
+    bool kv[KS];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) acc[p] = b4;
+    for (int s = 0; s < KS; ++s) {
+        const int k = 2 * s + lh;
+        kv[s] = k < K;
+        const int kk = kv[s] ? k : 0;
+        const int tap = kk / CIN;
+        kc[s] = kk - tap * CIN; kr[s] = tap / 3; kq[s] = tap - 3 * (tap / 3);
+        wb0[s] = kv[s] ? w[kk * COUT + li] : 0.f;
+        wb1[s] = kv[s] ? w[kk * COUT + 32 + li] : 0.f;
+    }
+    const float b0 = bias ? bias[li] : 0.f, b1 = bias ? bias[32 + li] : 0.f;
+    const float a0 = alpha ? alpha[li] : 1.f, a1 = alpha ? alpha[32 + li] : 1.f;
+    const int gpr = (wo + 31) / 32;                                  // 32-pixel groups per output row
+    const long ngrp = (long)n * ho * gpr;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long grp = wave; grp < ngrp; grp += nwaves) {
+        const int g = (int)(grp % gpr);
+        const long row = grp / gpr;
+        const int oh = (int)(row % ho), img = (int)(row / ho);
+        const int ow = g * 32 + li;
+        const bool pok = ow < wo;
+        f32x16f acc0, acc1;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int ih = oh * stride + r - pt;
-        if (ih < 0 || ih >= h) continue;
+        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        float av[KS];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < KS; ++s) {
+            const int ih = oh * stride + kr[s] - pt, iw = ow * stride + kq[s] - pl;
+            const bool ok = pok && kv[s] && ih >= 0 && ih < h && iw >= 0 && iw < wd;
+            const float v = x[((long)(img * h + (ok ? ih : 0)) * wd + (ok ? iw : 0)) * CIN + kc[s]];
+            av[s] = ok ? v : 0.f;
+        }
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + ((r * 3 + s) * CIN + c) * COUT + cq * 4);
+        for (int s = 0; s < KS; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb1[s], acc1, 0, 0, 0);
+        }
+        // C layout: column (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        const long obase = ((long)(img * ho + oh) * wo + g * 32) * COUT;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int iw = (ow0 + p) * stride + s - pl;
-                    float xv = 0.f;
-                    if (iw >= 0 && iw < wd && ow0 + p < wo) xv = x[((long)(img * h + ih) * wd + iw) * CIN + c];
-                    acc[p] += xv * wv;
-                }
+        for (int i = 0; i < 16; ++i) {
+            const int pr = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (g * 32 + pr < wo) {
+                const long o = obase + (long)pr * COUT + li;
+                float v0 = acc0[i] + b0, v1 = acc1[i] + b1;
+                if (z) { z[o] = v0; z[o + 32] = v1; }
+                if (alpha) { v0 = v0 > 0.f ? v0 : a0 * v0; v1 = v1 > 0.f ? v1 : a1 * v1; }
+                y[o] = v0; y[o + 32] = v1;
             }
         }
-    }
-    f32x4 a4 = {1.f, 1.f, 1.f, 1.f};
-    if (alpha) a4 = *reinterpret_cast<const f32x4*>(alpha + cq * 4);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (ow0 + p >= wo) break;
-        const long o = ((long)(img * ho + oh) * wo + ow0 + p) * COUT + cq * 4;
-        f32x4 v = acc[p];
-        if (z) *reinterpret_cast<f32x4*>(z + o) = v;
-        if (alpha) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : a4[e] * v[e];
-        }
-        *reinterpret_cast<f32x4*>(y + o) = v;
     }
 }
 
@@ -537,8 +546,10 @@ inline int grid_for(long n, int per) { long b = (n + per - 1) / per; return (int
 // ---------------------------------------------------------------------------------------------------
 hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
                             int n, int h, int wd, int cin, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
-    const long ngrp = (long)n * ho * ((wo + 3) / 4);
-    const int blocks = (int)((ngrp + 15) / 16);
+    const long ngrp = (long)n * ho * ((wo + 31) / 32);
+    long nb = (ngrp + 3) / 4;
+    if (nb > 4096) nb = 4096;
+    const int blocks = (int)nb;
     if (cin == 1) hipLaunchKernelGGL(conv_first_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl);
     else if (cin == 3) hipLaunchKernelGGL(conv_first_fwd_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl);
     else return hipErrorInvalidValue;
