@@ -899,7 +899,7 @@ int fte_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int n, int h
     return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, 9L * c, 1, 1.f, (float*)((char*)ws + need), (hipStream_t)stream));
 }
 int fte_channel_gather(const float* a, const float* b, float* out, const int32_t* table, long rows, int ca, int cb, int co, void* stream) {
-    if (!a || !out || !table || rows <= 0 || co <= 0) return FTE_EINVAL;
+    if (!a || !out || !table || rows <= 0 || co <= 0 || co % 4) return FTE_EINVAL;      // the table is read 4 entries at a time
     return rc(l_channel_gather(a, b ? b : a, out, table, rows, ca, cb, co, (hipStream_t)stream));
 }
 

@@ -921,20 +921,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
 }
 
 // out[row, k] = (table[k] < 0) ? 0 : src[table[k] >> 16][row, table[k] & 0xffff]      (src 0 = a, 1 = b)
+// thread = 4 consecutive output channels: four 4-byte gathers (neighbouring lanes read neighbouring source channels), one
+// 16-byte store
 __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              float* __restrict__ out, const int* __restrict__ table,
                                                              long rows, int ca, int cb, int co) {
-    const long total = rows * co;
+    const int q = co >> 2;
+    const long total = rows * q;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int k = (int)(i % co);
-        const long row = i / co;
-        const int t = table[k];
-        float v = 0.f;
-        if (t >= 0) {
-            const int ch = t & 0xffff;
-            v = (t >> 16) ? b[row * cb + ch] : a[row * ca + ch];
+        const int k4 = (int)(i % q);
+        const long row = i / q;
+        const int4 t = *reinterpret_cast<const int4*>(table + 4 * k4);
+        const int tt[4] = {t.x, t.y, t.z, t.w};
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = 0.f;
+            if (tt[e] >= 0) {
+                const int ch = tt[e] & 0xffff;
+                x = (tt[e] >> 16) ? b[row * cb + ch] : a[row * ca + ch];
+            }
+            v[e] = x;
         }
-        out[i] = v;
+        *reinterpret_cast<f32x4*>(out + row * co + 4 * k4) = v;
     }
 }
 
@@ -976,7 +985,7 @@ hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, i
     return hipGetLastError();
 }
 hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st) {
-    const long total = rows * co;
-    hipLaunchKernelGGL(channel_gather_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, a, b, out, table, rows, ca, cb, co);
+    const long total = rows * (co / 4);
+    hipLaunchKernelGGL(channel_gather_kernel, dim3((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0, st, a, b, out, table, rows, ca, cb, co);
     return hipGetLastError();
 }
