@@ -930,36 +930,50 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
     }
 }
 
-// dw[r,q,c] partials: block = Q channel quads x (256/Q) pixel lanes over one chunk of output pixels
-template <int Q>
+// dw[r,q,c] partials: block = Q channel quads x (256/Q) lanes over one chunk of 4-pixel groups (4 consecutive outputs of
+// one row): a lane loads the group's 4 dy vectors and each source column of the 3-row window once (3*(3*S+3) + 4 loads
+// per 4 pixels instead of 40)
+template <int Q, int S>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ part, int n, int h, int wd, int c,
-                                                              int ho, int wo, int stride, int pt, int pl, long pix_per_split) {
-    constexpr int RL = 256 / Q;
+                                                              int ho, int wo, int pt, int pl, long grp_per_split) {
+    constexpr int RL = 256 / Q, PX = 4, NC = (PX - 1) * S + 3;
     __shared__ f32x4 sh[RL][Q];
     const int q4 = threadIdx.x % Q, rl = threadIdx.x / Q;
     const int ch = (blockIdx.x * Q + q4) * 4;
-    const long npix = (long)n * ho * wo;
-    const long p0 = (long)blockIdx.y * pix_per_split, p1 = min(npix, p0 + pix_per_split);
+    const int wq = (wo + PX - 1) / PX;
+    const long ngrp = (long)n * ho * wq;
+    const long g0 = (long)blockIdx.y * grp_per_split, g1 = min(ngrp, g0 + grp_per_split);
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ch < c) {
-        for (long p = p0 + rl; p < p1; p += RL) {
-            const int ow = (int)(p % wo);
-            const long t2 = p / wo;
+        for (long gi = g0 + rl; gi < g1; gi += RL) {
+            const int xq = (int)(gi % wq);
+            const long t2 = gi / wq;
             const int oh = (int)(t2 % ho), img = (int)(t2 / ho);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + p * c + ch);
+            const int ow0 = xq * PX;
+            f32x4 d[PX];
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
+                d[p] = (ow0 + p < wo) ? *reinterpret_cast<const f32x4*>(dy + (((long)(img * ho + oh) * wo + ow0 + p) * c) + ch)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int sx0 = ow0 * S - pl;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const int ih = oh * stride + r - pt;
+                const int ih = oh * S + r - pt;
                 if (ih < 0 || ih >= h) continue;
+                const float* rowp = x + ((long)(img * h + ih) * wd) * c + ch;
+                f32x4 v[NC];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int iw = ow * stride + q - pl;
-                    if (iw < 0 || iw >= wd) continue;
-                    acc[r * 3 + q] += *reinterpret_cast<const f32x4*>(x + ((long)(img * h + ih) * wd + iw) * c + ch) * d;
+                for (int j = 0; j < NC; ++j) {
+                    const int sx = sx0 + j;
+                    v[j] = (sx >= 0 && sx < wd) ? *reinterpret_cast<const f32x4*>(rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) acc[r * 3 + q] += v[p * S + q] * d[p];
             }
         }
     }
@@ -1034,14 +1048,13 @@ int l_dwconv_wgrad_splits(long npix, int c) {
 }
 hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, int h, int wd, int c, int ho, int wo, int stride,
                           int pt, int pl, int splits, hipStream_t st) {
-    const long npix = (long)n * ho * wo, pps = (npix + splits - 1) / splits;
+    const long ngrp = (long)n * ho * ((wo + 3) / 4), gps = (ngrp + splits - 1) / splits;
     const int Q = dw_quads(c);
     const dim3 grid((c / 4 + Q - 1) / Q, splits);
-    switch (Q) {
-        case 64: hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<64>, grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps); break;
-        case 32: hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<32>, grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps); break;
-        default: hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<16>, grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, stride, pt, pl, pps);
-    }
+#define FTE_DWW(Q_, S_) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<Q_, S_>), grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, pt, pl, gps)
+    if (stride == 1) { switch (Q) { case 64: FTE_DWW(64, 1); break; case 32: FTE_DWW(32, 1); break; default: FTE_DWW(16, 1); } }
+    else { switch (Q) { case 64: FTE_DWW(64, 2); break; case 32: FTE_DWW(32, 2); break; default: FTE_DWW(16, 2); } }
+#undef FTE_DWW
     return hipGetLastError();
 }
 hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st) {
