@@ -127,7 +127,8 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
 // split-K plan: pick the split count whose tiles*splits fills whole rounds of SLOTS best
 // (>= 8 K-steps per split; ties go to fewer splits = less slab traffic)
 inline void plan_splits(long tiles, int K, int* splits, int* kchunk, bool prefer8 = false) {
-    const int maxs = K / 256 > 0 ? K / 256 : 1;
+    static const int mink = getenv("FTE_SPLIT_MINK") ? atoi(getenv("FTE_SPLIT_MINK")) : 256;      // tuning hook: shortest K range per split
+    const int maxs = K / mink > 0 ? K / mink : 1;
     const long SLOTS = SLOTS_BIG;
     long lo = (SLOTS + tiles - 1) / tiles, hi = (3 * SLOTS + tiles - 1) / tiles;
     if (lo < 1) lo = 1;
