@@ -1001,20 +1001,22 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     const size_t loop32 = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
     const size_t loop16 = 2 * (size_t)(BM + BN) * 64;
     const size_t lds = BF == 2 ? (loop16 > epi ? loop16 : epi) : (BF ? (loop > epi ? loop : epi) : (epi > loop32 ? epi : loop32));
+    static const size_t lds_pad = getenv("FTE_LDS_PAD") ? (size_t)atoi(getenv("FTE_LDS_PAD")) : 0;      // tuning hook: fewer blocks per CU
+    const size_t lds_x = lds + lds_pad;
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 65536 > 160 * 1024 ? lds : lds + 65536));
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (p.ncls > 1) {                       // merged parity classes: every class has the same M x N tile grid
         IgemmParams q = p;
         q.cls_tiles = mt * nt; q.cls_mtiles = mt;
-        hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(256), lds, st, q);
-    } else if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(256), lds, st, p);
+        hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(256), lds_x, st, q);
+    } else if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(256), lds_x, st, p);
+    else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(256), lds_x, st, p);
     return hipGetLastError();
 }
 
