@@ -74,6 +74,16 @@ __device__ __forceinline__ unsigned short tobf(float a) {
     return __builtin_bit_cast(unsigned short, (__bf16)a);
 }
 
+// a / d for 0 <= a < 2^24 and d > 0 with rd = 1.f / d: float multiply, truncate, one-step fix-up (the compiler's exact
+// 32-bit division is ~35 VALU instructions; the wgrad loaders decompose a pixel index on EVERY K-step)
+__device__ __forceinline__ int fdiv(int a, int d, float rd) {
+    int q = (int)((float)a * rd);
+    const int r = a - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
 __device__ __forceinline__ float prelu_slope(float z, float a) {
     // d/dz [relu(z) + a*(z-|z|)/2]; TF's grad of relu(0) and sign(0) are 0 -> a/2 at exactly 0.
     return z > 0.f ? 1.f : (z == 0.f ? 0.5f * a : a);
@@ -131,6 +141,10 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     const int kbeg = split * p.kchunk;
     const int kend = min(Kc, kbeg + p.kchunk);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
+    // index decompositions use fdiv(): every decomposed index (GEMM row m < M, pixel < K) is below 2^24 for the tensors
+    // the 2-GiB buffer range admits with >= 32 channels; the launcher checks it (igemm_launch)
+    const int a_hw = p.a_OH * p.a_OW;
+    const float r_ahw = 1.f / (float)a_hw, r_aow = 1.f / (float)p.a_OW;
 
     // ---- per-thread loader state ------------------------------------------------
     // Operand tiles are fetched with raw buffer loads: a lane whose element is padding / out of
@@ -152,9 +166,8 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             const int m = m0 + (tid >> 3) + 32 * i;
             int base = 0, mask = 0;
             if (m < p.M) {
-                const int hw = p.a_OH * p.a_OW;
-                const int n = m / hw, rem = m - n * hw;
-                const int oh = rem / p.a_OW, ow = rem - oh * p.a_OW;
+                const int n = fdiv(m, a_hw, r_ahw), rem = m - n * a_hw;
+                const int oh = fdiv(rem, p.a_OW, r_aow), ow = rem - oh * p.a_OW;
                 const int ih0 = oh * p.a_stride, iw0 = ow * p.a_stride;
                 base = ((n * p.a_IH + ih0) * p.a_IW + iw0) * p.a_ld;
                 for (int t = 0; t < NT; ++t) {
@@ -226,10 +239,9 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             for (int e = 0; e < 2; ++e) {                  // ra[2j + e]: pixel k0 + 2*(tid>>4) + e, m-chunk j
                 const int pix = k0 + 2 * (tid >> 4) + e;
                 const bool kin = pix < kend;
-                const int hw = p.a_OH * p.a_OW;
-                const int n = pix / hw;
-                const int rem = pix - n * hw;
-                const int oh = rem / p.a_OW;
+                const int n = fdiv(pix, a_hw, r_ahw);
+                const int rem = pix - n * a_hw;
+                const int oh = fdiv(rem, p.a_OW, r_aow);
                 const int ih0 = oh * p.a_stride;
                 const int iw0 = (rem - oh * p.a_OW) * p.a_stride;
 #pragma unroll
@@ -242,10 +254,9 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         } else {
             const int pix = k0 + (tid >> 3);
             const bool kin = pix < kend;
-            const int hw = p.a_OH * p.a_OW;
-            const int n = pix / hw;
-            const int rem = pix - n * hw;
-            const int oh = rem / p.a_OW;
+            const int n = fdiv(pix, a_hw, r_ahw);
+            const int rem = pix - n * a_hw;
+            const int oh = fdiv(rem, p.a_OW, r_aow);
             const int ih0 = oh * p.a_stride;
             const int iw0 = (rem - oh * p.a_OW) * p.a_stride;
 #pragma unroll
@@ -367,9 +378,8 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 const int m = m0 + r4 + 64 * i;
                 int base = 0, mask = 0;
                 if (m < p.M && r4 + 64 * i < BM) {
-                    const int hw = p.a_OH * p.a_OW;
-                    const int n = m / hw, rem = m - n * hw;
-                    const int oh = rem / p.a_OW, ow = rem - oh * p.a_OW;
+                    const int n = fdiv(m, a_hw, r_ahw), rem = m - n * a_hw;
+                    const int oh = fdiv(rem, p.a_OW, r_aow), ow = rem - oh * p.a_OW;
                     const int ih0 = oh * p.a_stride, iw0 = ow * p.a_stride;
                     base = ((n * p.a_IH + ih0) * p.a_IW + iw0) * p.a_ld;
                     for (int t = 0; t < NT; ++t) {
@@ -416,10 +426,9 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 for (int e = 0; e < 2; ++e) {
                     const int pix = k0 + 2 * kp + e;
                     const bool kin = pix < kend;
-                    const int hw = p.a_OH * p.a_OW;
-                    const int n = pix / hw;
-                    const int rem = pix - n * hw;
-                    const int oh = rem / p.a_OW;
+                    const int n = fdiv(pix, a_hw, r_ahw);
+                    const int rem = pix - n * a_hw;
+                    const int oh = fdiv(rem, p.a_OW, r_aow);
                     const int ih0 = oh * p.a_stride;
                     const int iw0 = (rem - oh * p.a_OW) * p.a_stride;
 #pragma unroll
@@ -638,10 +647,9 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             } else {
                 const int pix = k0 + (tid >> 3);
                 kin = pix < kend;
-                const int hw = p.a_OH * p.a_OW;
-                kn = pix / hw;
-                const int rem = pix - kn * hw;
-                const int oh = rem / p.a_OW;
+                kn = fdiv(pix, a_hw, r_ahw);
+                const int rem = pix - kn * a_hw;
+                const int oh = fdiv(rem, p.a_OW, r_aow);
                 kih0 = oh * p.a_stride;
                 kiw0 = (rem - oh * p.a_OW) * p.a_stride;
             }
@@ -740,8 +748,8 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 off = m * p.c_ld;
             } else {
                 const int hw = p.c_OH * p.c_OW;
-                const int n = m / hw, rem = m - n * hw;
-                const int oh = rem / p.c_OW, ow = rem - oh * p.c_OW;
+                const int n = fdiv(m, hw, 1.f / (float)hw), rem = m - n * hw;
+                const int oh = fdiv(rem, p.c_OW, 1.f / (float)p.c_OW), ow = rem - oh * p.c_OW;
                 off = ((n * p.c_FH + oh * p.c_step + c_ph) * p.c_FW + ow * p.c_step + c_pw) * p.c_ld;
             }
         }
@@ -1072,6 +1080,7 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
                            (uintptr_t)p.RAW | (uintptr_t)p.Zin | (uintptr_t)p.DZ | (uintptr_t)p.PW | (uintptr_t)p.bias;
     const uintptr_t al_ptr = epi == EPI_FWD ? (uintptr_t)p.alpha : 0;      // read as float4 by the forward epilogue only
     if (((ptrs | al_ptr) & 15) || (p.c_ld & 3) || (p.a_ld & 3) || (p.b_ld & 3)) return hipErrorInvalidValue;
+    if (p.M >= (1 << 24) || (al == AL_KM && p.K >= (1 << 24))) return hipErrorInvalidValue;      // fdiv() range (see the kernel)
     if (!g_prof_on) return dispatch(p, al, bl, epi, tile, splits, st);
     ProfRec r;
     r.sig[0] = al; r.sig[1] = bl; r.sig[2] = epi; r.sig[3] = tile; r.sig[4] = splits;
