@@ -625,6 +625,8 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             store_tiles(0);
             __syncthreads();
         }
+        int stap = 0, skc = 0;                                      // position of the tile in LDS (step s): advanced to s + 1 below
+        if constexpr (AL == AL_MK || BL == BL_NK) { stap = ktap(kbeg); skc = kchan(kbeg); }
         for (int s = 0; s < nsteps; ++s) {
             const int cur = FTE_SINGLE ? 0 : (s & 1);
             const int k0 = kbeg + (s + 1) * BK;
@@ -635,9 +637,9 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             // ---- per-step operand addressing (scalar / per-thread, no memory access yet) ----
             int tap = 0, kc0 = 0;
             if constexpr (AL == AL_MK || BL == BL_NK) {
-                tap = ktap(k0);
-                kc0 = kchan(k0);
-                if (kc0 >= p.a_KC) kc0 = 0;            // the unused tile after the last step
+                if (++stap == NT) { stap = 0; skc += BK; }      // (ktap, kchan) of k0, kept incrementally: no division
+                tap = stap;
+                kc0 = skc < p.a_KC ? skc : 0;                   // the unused tile after the last step
             }
             unsigned a_toff = 0, b_soff = 0;
             bool kin = false;
