@@ -791,6 +791,23 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                // the global inputs of the four passes (shortcut / skip gradient / z) are fetched BEFORE the transpose: one
+                // memory round trip per 32x32 block instead of one per pass
+                int offs[4];
+                f32x4 in0[4], in1[4];
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    offs[ps] = rowoff[wm * (TM * 32) + i * 32 + prw + 8 * ps];
+                    const long o = (long)(offs[ps] < 0 ? 0 : offs[ps]) + col;
+                    in0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    in1[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (EPI == EPI_FWD) {
+                        if (p.R && offs[ps] >= 0) in0[ps] = *reinterpret_cast<const f32x4*>(p.R + o);
+                    } else {
+                        if (p.ADD && offs[ps] >= 0) in0[ps] = *reinterpret_cast<const f32x4*>(p.ADD + o);
+                        if (act && offs[ps] >= 0) in1[ps] = *reinterpret_cast<const f32x4*>(p.Zin + o);
+                    }
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
@@ -799,7 +816,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     const int rr = prw + 8 * ps;
-                    const int off = rowoff[wm * (TM * 32) + i * 32 + rr];
+                    const int off = offs[ps];
                     f32x4 v = *reinterpret_cast<const f32x4*>(patch + rr * 36 + 4 * pc4);
                     if (off < 0) continue;
                     const long o = (long)off + col;
@@ -810,14 +827,14 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : al4[e] * v[e];
                         }
-                        if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + o);
+                        v += in0[ps];
                         *reinterpret_cast<f32x4*>(Y + o) = v;
                         if (p.Y16) *reinterpret_cast<u32x2*>(p.Y16 + o) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
                     } else {
-                        if (p.ADD) v += *reinterpret_cast<const f32x4*>(p.ADD + o);
+                        v += in0[ps];
                         if (p.RAW) *reinterpret_cast<f32x4*>(p.RAW + o) = v;
                         if (act) {
-                            const f32x4 z = *reinterpret_cast<const f32x4*>(p.Zin + o);
+                            const f32x4 z = in1[ps];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 sa4[j][e] += v[e] * fminf(z[e], 0.f);
