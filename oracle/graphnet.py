@@ -80,13 +80,43 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
 KINK_BAND = 1e-5
 
 
-def backward(graph, params, env, cache, dout, masks=None, kink=None):
+NOISE_MULT = 16      # band = NOISE_MULT x the oracle's OWN float32-vs-float64 forward noise on that tensor (noise_bands)
+
+
+def noise_bands(graph, params, images, masks=None, state=None):
+    """rms(float32 oracle - float64 oracle) of every ReLU / max-pool output on THIS input: the float32 noise floor of
+    the decision tensors, computed from the oracle alone (batch norm over few samples amplifies rounding noise layer
+    after layer, so a fixed 1e-5*rms band is too narrow deep inside ResNet-50 -- but the band must not depend on the
+    implementation under test, or a kernel bug would widen its own acceptance band)."""
+    f64 = lambda d: None if d is None else {k: np.asarray(v, np.float64) for k, v in d.items()}
+    f32 = lambda d: None if d is None else {k: np.asarray(v, np.float32) for k, v in d.items()}
+    e64, _, _ = forward(graph, f64(params), np.asarray(images, np.float64), train=True, masks=f64(masks), state=f64(state))
+    e32, _, _ = forward(graph, f32(params), np.asarray(images, np.float32), train=True, masks=f32(masks), state=f32(state))
+    out = {}
+    for op in graph:
+        if op[0] in ('relu', 'maxpool'):
+            out[op[1]] = float(np.sqrt(((e32[op[1]].astype(np.float64) - e64[op[1]]) ** 2).mean()))
+    return out
+
+
+def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='fp32', bands=None):
     """dout: {tensor name: gradient}.  Returns (param grads, tensor grads).
     `kink` (optional): tensors of the implementation under test.  ReLU's derivative jumps at 0 and a
     max-pool routes its gradient to ONE of several near-equal candidates; where the float64 values are
-    closer than the band (KINK_BAND*rms, or 4x the observed forward discrepancy of that tensor if larger) to such a decision boundary either choice is valid for a float32
+    closer than the band to such a decision boundary either choice is valid for a float32
     evaluation, and the oracle adopts the choice the checked implementation made (there and only there):
-    kink[relu_out] = its ReLU output, kink[pool_out + '/idx'] = its arg-max window positions."""
+    kink[relu_out] = its ReLU output, kink[pool_out + '/idx'] = its arg-max window positions.
+    The band: kink_mode 'fp32' -> max(KINK_BAND*rms, NOISE_MULT*bands[out]) with `bands` = noise_bands() of the
+    ORACLE (never a function of the implementation's tensors); kink_mode 'bf16' (mixed-precision checks only) ->
+    max(KINK_BAND*rms, 4x the forward discrepancy observed on that tensor)."""
+    if kink_mode not in ('fp32', 'bf16'):
+        raise ValueError(kink_mode)
+
+    def band_of(out, ref_rms, observed):
+        thr = KINK_BAND * ref_rms
+        if kink_mode == 'bf16':
+            return max(thr, 4 * observed())
+        return max(thr, NOISE_MULT * (bands or {}).get(out, 0.0))
     gt = dict(dout)
     gp = OrderedDict()
 
@@ -116,10 +146,8 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None):
             pre = env[op[2]]
             on = pre > 0
             if kink is not None and out in kink:
-                # band = the larger of KINK_BAND*rms and 4x the forward discrepancy actually observed on this
-                # tensor (fp32 noise grows through deep BN stacks; a fixed band would be too narrow there)
-                disc = np.sqrt(((kink[out] - np.maximum(pre, 0)) ** 2).mean())
-                band = np.abs(pre) < max(KINK_BAND * np.sqrt((pre * pre).mean()), 4 * disc)
+                thr = band_of(out, np.sqrt((pre * pre).mean()), lambda: np.sqrt(((kink[out] - np.maximum(pre, 0)) ** 2).mean()))
+                band = np.abs(pre) < thr
                 on = np.where(band, kink[out] > 0, on)
             acc(gt, op[2], dy * on)
         elif kind == 'add':
@@ -140,7 +168,7 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None):
                     ok = (ih >= 0) & (ih < x.shape[1]) & (iw >= 0) & (iw < x.shape[2])
                     assert ok.all(), 'arg-max outside the image'
                     gap = env[out][diff] - x[ii[:, 0], ih, iw, ii[:, 3]]
-                    tie = max(KINK_BAND * np.sqrt((x * x).mean()), 4 * np.sqrt(((kink.get(out, env[out]) - env[out]) ** 2).mean()))
+                    tie = band_of(out, np.sqrt((x * x).mean()), lambda: np.sqrt(((kink.get(out, env[out]) - env[out]) ** 2).mean()))
                     assert (np.abs(gap) <= tie).all(), 'arg-max differs beyond the tie band'
                     c = dict(c, arg=their)
             acc(gt, op[2], ops.maxpool3x3s2_bwd(dy, c))
@@ -438,7 +466,7 @@ def perturb(p, seed, scale=0.1):
 
 
 def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None, grad_scale=None, state=None, kink=None,
-                   center=None, triplet_margin='off', focal=None):
+                   center=None, triplet_margin='off', focal=None, kink_mode='fp32', bands=None):
     """softmax-CE (+ center loss) or batch-hard triplet, + L2 on conv / fc weights (gamma, beta, biases are not
     regularised).  center = dict(centers=[C,D], alpha=, weight=): loss.py:29-45 on the pooled features, added to the
     total loss with `weight` (the reference leaves the wiring to the caller, loss.py:43).  triplet_margin != 'off':
@@ -464,7 +492,7 @@ def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None,
             scale = center['weight'] * (1.0 if grad_scale is None else grad_scale * n)
             dout['features'] = dfe * scale
             extra['centers'] = newc
-    gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink)
+    gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink, kink_mode=kink_mode, bands=bands)
     reg_names = [k for k in params if k.endswith('weights')]      # weights, depthwise_weights, pointwise_weights
     reg = ops.l2_reg([params[k] for k in reg_names], weight_decay)
     for k in reg_names:

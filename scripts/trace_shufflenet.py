@@ -25,7 +25,7 @@ for op in net.graph:
     elif op[0] == 'maxpool':
         kink[op[1] + '/idx'] = net.t[op[1] + '/idx'].cpu().numpy()[..., :net.real_c[op[1]]]
         kink[op[1]] = host(net.t[op[1]])[..., :net.real_c[op[1]]]
-l, g, env, ns = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink)
+l, g, env, ns = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink, bands=og.noise_bands(graph, p, x, {'features_drop': mask}, state))
 for k in p:
     got = host(net.get_variable(k, net.grads)) + (5e-4 * p[k] if k.endswith('weights') else 0)
     ref = g[k]

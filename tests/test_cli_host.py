@@ -150,3 +150,61 @@ def test_checkpoint_round_trip_and_finetune(tmp_path):
         saver.save(net, None, s, prefix)
     kept = [l for l in open(os.path.join(os.path.dirname(prefix), 'checkpoint')).read().split() if l]
     assert len(kept) == saver.MAX_TO_KEEP and not os.path.exists(p1)          # max_to_keep=20 (train.py:188)
+
+
+def test_checkpoint_keeps_bn_moving_statistics_and_centers(tmp_path):
+    """tf.global_variables() is what train.py:188 saves: BatchNorm moving statistics and the center loss's `centers`
+    travel with the weights (reference names), are restored on resume, and the moving statistics are part of the
+    fine-tune set (param_list(trainable=False), nets/resnet.py:178-193); `centers` is not (it lives outside the scope)."""
+    net = net_select('ResNeXt-50-center', 'NCHW'); net.seed = 3
+    net.build(32, 32, 3, 11, 'cpu')
+    assert len(net.state) == 106 and all(k.endswith(('/moving_mean', '/moving_variance')) for k in net.state)
+    g = torch.Generator().manual_seed(1)
+    for t in net.state.values():
+        t.copy_(torch.rand(t.shape, generator=g) + 0.5)
+    net._centers().copy_(torch.randn(net._centers().shape, generator=g))
+    prefix = str(tmp_path / 'r' / 'r.ckpt')
+    path = saver.save(net, None, 7, prefix)
+    saved = torch.load(path, map_location='cpu')['variables']
+    assert 'centers' in saved and 'ResNeXt-50/conv1/conv_7x7/BatchNorm/moving_mean' in saved
+    other = net_select('ResNeXt-50-center', 'NHWC'); other.seed = 4
+    other.build(32, 32, 3, 11, 'cpu')
+    assert saver.restore(other, path) == 7
+    for k in list(net.variables) + list(net.state):
+        assert torch.equal(other.get_variable(k), net.get_variable(k)), k
+    assert torch.equal(other._centers(), net._centers())
+    # fine-tune: backbone weights AND its moving statistics, neither the classifier nor the centers
+    ft = net_select('ResNeXt-50-center', 'NCHW'); ft.seed = 5
+    ft.build(32, 32, 3, 11, 'cpu')
+    names = [v.name for v in ft.pretrained_param()]
+    assert sum('moving_' in n for n in names) == 106 and 'centers' not in names and not any(n.startswith('classifier/') for n in names)
+    cls_before = ft.get_variable('classifier/fc_classifier/weights').clone()
+    saver.restore(ft, path, only=ft.pretrained_param())
+    assert torch.equal(ft.get_variable('classifier/fc_classifier/weights'), cls_before)
+    k = 'ResNeXt-50/conv1/conv_7x7/BatchNorm/moving_variance'
+    assert torch.equal(ft.get_variable(k), net.get_variable(k))
+    assert float(ft._centers().abs().max()) == 0.0
+    # the trainable groups are unchanged (data_parallel.py:232 iterates param_list(trainable=True))
+    assert [len(g_) for g_ in ft.param_list(True, True)] == [159, 1]
+
+
+def test_loader_errors_reach_the_training_thread(tmp_path):
+    """a corrupt image / bad label must raise from the step (tf.data surfaces it to sess.run), not kill the
+    producer thread silently and leave advance() blocked forever (and the other ranks hanging in the all-reduce)."""
+    from PIL import Image
+    good = str(tmp_path / 'a.png')
+    Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(good)
+    bad = str(tmp_path / 'broken.png')
+    open(bad, 'wb').write(b'not a png')
+    (tmp_path / 'l.txt').write_text('%s 0\n%s 1\n' % (good, bad))
+    inp = data.train_inputs(str(tmp_path / 'l.txt'), 8, 8, batch_size=2, device='cpu', seed=0)
+    with pytest.raises(RuntimeError, match='input pipeline failed'):
+        inp['images']()
+    with pytest.raises(RuntimeError, match='input pipeline failed'):       # and it stays failed: no hang on the next call
+        inp['images']()
+    # out-of-range labels are caught where the batch is built
+    pf = data._Prefetcher(lambda: (np.zeros((2, 4, 4, 1), np.float32), np.array([0, 7], np.int32)), torch.device('cpu'), num_classes=7)
+    with pytest.raises(RuntimeError, match='label out of range'):
+        pf.advance()
+    pf = data._Prefetcher(lambda: (np.zeros((2, 4, 4, 1), np.float32), np.array([0, 6], np.int32)), torch.device('cpu'), num_classes=7)
+    assert pf.advance()[1].tolist() == [0, 6]

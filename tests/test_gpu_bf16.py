@@ -102,7 +102,7 @@ def test_spherenet_step_bf16_vs_oracle_and_training(bf16_mode):
     losses, names, _ = net.loss_function('T', dev(y, torch.int32), **out)
     net.backward()
     torch.cuda.synchronize()
-    l_ref, g_ref, cache = osn.loss_and_grads(p, x, y, data_format='NHWC', weight_decay=5e-4, kink=kink_of(net))
+    l_ref, g_ref, cache = osn.loss_and_grads(p, x, y, data_format='NHWC', weight_decay=5e-4, kink=kink_of(net), kink_mode='bf16')
     check_rell2(host(out['logits']), cache['logits'], 1e-2, 'logits (bf16 operands)')
     assert abs(float(losses[0]) - l_ref[0]) <= 1e-2 * l_ref[0]
     worst = 0.0

@@ -61,9 +61,10 @@ def test_focal_head_on_a_graph_net():
     assert names == ['focal_entropy', 'reg_loss']
     mask = host(net.t['features_drop/mask'])
     kink = _kink(net)
-    ref = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink, focal=(1.5, 2.0))
+    bands = og.noise_bands(graph, p, x, {'features_drop': mask}, state)
+    ref = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink, focal=(1.5, 2.0), bands=bands)
     p32 = {k: v.astype(np.float32) for k, v in p.items()}; s32 = {k: v.astype(np.float32) for k, v in state.items()}
-    r32 = og.loss_and_grads(graph, p32, x.astype(np.float32), y, np.float32(5e-4), masks={'features_drop': mask.astype(np.float32)}, state=s32, kink=kink, focal=(1.5, 2.0))
+    r32 = og.loss_and_grads(graph, p32, x.astype(np.float32), y, np.float32(5e-4), masks={'features_drop': mask.astype(np.float32)}, state=s32, kink=kink, focal=(1.5, 2.0), bands=bands)
     assert abs(float(losses[0]) - ref[0][0]) <= 1e-4 * max(1.0, ref[0][0])
 
     def rel(a, b):

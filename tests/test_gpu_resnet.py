@@ -44,14 +44,15 @@ def test_resnet_forward_loss_and_every_gradient(num_layers, n, h, w, ncls):
     torch.cuda.synchronize()
     mask = host(net.t['features_drop/mask'])
     kink = _kink(net)
-    l_ref, g_ref, env, new_state = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink)
+    bands = og.noise_bands(graph, p, x, {'features_drop': mask}, state)      # the oracle's own fp32 noise: decision bands
+    l_ref, g_ref, env, new_state = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink, bands=bands)
     # fp32's own noise floor on THIS input: the same oracle evaluated in float32.  Batch norm over few samples
     # amplifies rounding noise layer after layer (ResNet-50 at 6x64x48 ends with 24 samples per channel and the
     # float32 oracle is off by 7e-5 at the features), so each tensor is held to max(base, 2 x that floor).
     p32 = {k: v.astype(np.float32) for k, v in p.items()}
     s32 = {k: v.astype(np.float32) for k, v in state.items()}
     _, g32, env32, _ = og.loss_and_grads(graph, p32, x.astype(np.float32), y, np.float32(5e-4),
-                                         masks={'features_drop': mask.astype(np.float32)}, state=s32, kink=kink)
+                                         masks={'features_drop': mask.astype(np.float32)}, state=s32, kink=kink, bands=bands)
 
     def rel(a, b):
         return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / max(np.sqrt((b * b).sum()), 1e-30))
@@ -107,12 +108,13 @@ def _run_variant(net, graph, spec, n, h, w, ncls, labels, seed, center=None, tri
     torch.cuda.synchronize()
     masks = {'features_drop': host(net.t['features_drop/mask'])} if net.has_classifier else None
     kink = _kink(net)
-    ref = og.loss_and_grads(graph, p, x, labels, 5e-4, masks=masks, state=state, kink=kink, center=center, triplet_margin=triplet)
+    bands = og.noise_bands(graph, p, x, masks, state)
+    ref = og.loss_and_grads(graph, p, x, labels, 5e-4, masks=masks, state=state, kink=kink, center=center, triplet_margin=triplet, bands=bands)
     p32 = {k: v.astype(np.float32) for k, v in p.items()}
     s32 = {k: v.astype(np.float32) for k, v in state.items()}
     c32 = None if center is None else dict(center, centers=center['centers'].astype(np.float32))
     m32 = None if masks is None else {k: v.astype(np.float32) for k, v in masks.items()}
-    r32 = og.loss_and_grads(graph, p32, x.astype(np.float32), labels, np.float32(5e-4), masks=m32, state=s32, kink=kink, center=c32, triplet_margin=triplet)
+    r32 = og.loss_and_grads(graph, p32, x.astype(np.float32), labels, np.float32(5e-4), masks=m32, state=s32, kink=kink, center=c32, triplet_margin=triplet, bands=bands)
 
     def rel(a, b):
         return float(np.sqrt(((np.asarray(a, np.float64) - b) ** 2).sum()) / max(np.sqrt((b * b).sum()), 1e-30))

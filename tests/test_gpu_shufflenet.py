@@ -106,11 +106,12 @@ def _check_net(net, variant, blocks, fmt, n, h, w, ncls, seed):
         elif op[0] == 'maxpool':
             kink[op[1] + '/idx'] = net.t[op[1] + '/idx'].cpu().numpy()[..., :net.real_c[op[1]]]
             kink[op[1]] = host(net.t[op[1]])[..., :net.real_c[op[1]]]
-    l_ref, g_ref, env, new_state = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink)
+    bands = og.noise_bands(graph, p, x, {'features_drop': mask}, state)
+    l_ref, g_ref, env, new_state = og.loss_and_grads(graph, p, x, y, 5e-4, masks={'features_drop': mask}, state=state, kink=kink, bands=bands)
     p32 = {k: v.astype(np.float32) for k, v in p.items()}
     s32 = {k: v.astype(np.float32) for k, v in state.items()}
     _, g32, env32, _ = og.loss_and_grads(graph, p32, x.astype(np.float32), y, np.float32(5e-4),
-                                         masks={'features_drop': mask.astype(np.float32)}, state=s32, kink=kink)
+                                         masks={'features_drop': mask.astype(np.float32)}, state=s32, kink=kink, bands=bands)
 
     def rel(a, b):
         return float(np.sqrt(((np.asarray(a, np.float64) - b) ** 2).sum()) / max(np.sqrt((b * b).sum()), 1e-30))

@@ -145,3 +145,40 @@ def test_resnet_graph_on_cpu_matches_the_oracle_graph():
         ResNet(50, pre_act=True)
     with pytest.raises(ValueError, match='Unsupported num_layers.'):
         ResNet(38)
+
+
+def test_labels_outside_num_classes_fail_at_setup():
+    """the loss kernels index by label; the boundary validates resident label tensors once."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_net import FakeOracleNet
+    net = FakeOracleNet(3, 16, 16, 1, 6)
+    x = torch.zeros(4, 16, 16, 1)
+    for bad in ([0, 1, 6, 2], [0, -1, 2, 3]):
+        with pytest.raises(ValueError, match=r'labels must lie in \[0, num_classes\)'):
+            Singular(net, 0.1, 'Momentum')({'images': x, 'labels': torch.tensor(bad, dtype=torch.int32), 'num_classes': 6, 'num_examples': 4})
+    Singular(net, 0.1, 'Momentum')({'images': x, 'labels': torch.tensor([0, 5, 2, 3], dtype=torch.int32), 'num_classes': 6, 'num_examples': 4})
+
+
+def test_data_parallel_gives_every_rank_its_own_dropout_seed():
+    """The reference's towers draw independent dropout masks; a replica-shared seed would repeat one mask per shard."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_net import FakeOracleNet
+
+    class Comm(object):
+        def __init__(self, r): self.r = r
+        def world_size(self): return 2
+        def rank(self): return self.r
+        def broadcast(self, t, src=0): pass
+        def all_reduce_async(self, t): raise AssertionError('no step is run here')
+    seeds = []
+    for r in range(2):
+        net = FakeOracleNet(3, 16, 16, 1, 6)
+        net.dropout_seed = 5
+        dp = DataParallel(net, 0.1, 'Momentum', num_gpus=2, comm=Comm(r))
+        inputs = {'images': torch.zeros(4, 16, 16, 1), 'labels': torch.tensor([0, 1, 2, 3], dtype=torch.int32), 'num_classes': 6, 'num_examples': 4}
+        dp(inputs)
+        dp(inputs)                                    # building twice does not compound the seed
+        seeds.append(net.dropout_seed)
+    assert seeds == [10, 11]

@@ -9,7 +9,8 @@ mkdir -p "$HERE/obj"
 pids=()
 for f in igemm kernels layers api; do
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/igemm.h" -nt "$HERE/obj/$f.o" ] \
-     || [ "$HERE/kernels.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/fte.h" -nt "$HERE/obj/$f.o" ]; then
+     || [ "$HERE/kernels.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/layers.h" -nt "$HERE/obj/$f.o" ] \
+     || [ "$HERE/../../include/fte.h" -nt "$HERE/obj/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi

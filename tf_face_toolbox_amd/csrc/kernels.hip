@@ -253,14 +253,18 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     float s = 0.f;
     for (int j = threadIdx.x; j < c; j += 256) s += expf(z[j] - mx);
     s = block_sum(s, sh);
-    const int y = labels[row];
+    // a label outside [0, c) (list / num_classes mismatch) must not become an out-of-bounds read: the row's loss is NaN
+    // (TF's sparse_softmax_cross_entropy gives NaN loss rows on GPU), so the caller's non-finite-loss check trips
+    const int yl = labels[row];
+    const bool bad = (unsigned)yl >= (unsigned)c;
+    const int y = bad ? 0 : yl;
     const float inv = 1.f / s;
     for (int j = threadIdx.x; j < ld; j += 256) {
         float g = 0.f;
         if (j < c) g = (expf(z[j] - mx) * inv - (j == y ? 1.f : 0.f)) * gscale;
-        d[j] = g;
+        d[j] = bad ? NAN : g;
     }
-    if (threadIdx.x == 0) loss_rows[row] = logf(s) - (z[y] - mx);
+    if (threadIdx.x == 0) loss_rows[row] = bad ? NAN : logf(s) - (z[y] - mx);
 }
 
 // Focal loss (loss.py:18-27): F_i = gamma * (1 - p_y)^alpha * CE_i.  With q = p_y, dF/dz_j = coef * (p_j - [j = y]),
@@ -278,9 +282,11 @@ __global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict
     float s = 0.f;
     for (int j = threadIdx.x; j < c; j += 256) s += expf(z[j] - mx);
     s = block_sum(s, sh);
-    const int y = labels[row];
+    const int yl = labels[row];
+    const bool bad = (unsigned)yl >= (unsigned)c;              // out-of-range label: NaN row, no out-of-bounds access
+    const int y = bad ? 0 : yl;
     const float inv = 1.f / s;
-    const float logq = (z[y] - mx) - logf(s);                  // log p_y <= 0
+    const float logq = bad ? NAN : (z[y] - mx) - logf(s);      // log p_y <= 0
     const float q = expf(logq);
     const float omq = fmaxf(1.f - q, 0.f);
     const float pw = powf(omq, alpha);                          // (1-q)^alpha
@@ -306,8 +312,10 @@ __global__ __launch_bounds__(256) void asoftmax_kernel(const float* __restrict__
     const int row = blockIdx.x;
     const float* sr = s + (long)row * ld;
     float* gr = G + (long)row * ld;
-    const int y = labels[row];
-    const float xnorm = xn[row];
+    const int yl = labels[row];
+    const bool bad = (unsigned)yl >= (unsigned)c;              // out-of-range label: NaN row, no out-of-bounds access
+    const int y = bad ? 0 : yl;
+    const float xnorm = bad ? NAN : xn[row];
     // target logit
     const float cy = sr[y] / (xnorm * wn[y]);
     const int k = (cy <= 0.70710678118654752f) + (cy <= 0.f) + (cy <= -0.70710678118654752f);

@@ -86,27 +86,55 @@ def _train_example(path, num_channels, input_height, input_width, crop_height, c
 
 
 class _Prefetcher(object):
-    """One batch ahead on a background thread; `next()` returns (images, labels) on `device`."""
+    """One batch ahead on a background thread; `advance()` returns (images, labels) on `device`.
+    A failure inside the producer (unreadable or corrupt image, malformed list line, label out of range) is caught,
+    handed over through the queue and RE-RAISED from advance() in the training thread -- the reference's tf.data
+    pipeline surfaces such errors to sess.run; a silently dead producer would leave this rank blocked on q.get() and
+    the other ranks hanging in the all-reduce."""
 
-    def __init__(self, make_batch, device, depth=2):
+    POLL_SECONDS = 5.0
+
+    def __init__(self, make_batch, device, depth=2, num_classes=None):
         self.q = queue.Queue(maxsize=depth)
         self.device = device
         self.make_batch = make_batch
+        self.num_classes = num_classes
         self._cur = None
-        t = threading.Thread(target=self._run, daemon=True)
-        t.start()
+        self._dead = None
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
 
     def _run(self):
-        while True:
-            x, y = self.make_batch()
-            xt = torch.from_numpy(x)
-            yt = torch.from_numpy(y) if y is not None else None
-            if self.device.type == 'cuda':
-                xt = xt.pin_memory()
-            self.q.put((xt, yt))
+        try:
+            while True:
+                x, y = self.make_batch()
+                if y is not None and self.num_classes is not None and y.size:
+                    lo, hi = int(y.min()), int(y.max())
+                    if lo < 0 or hi >= self.num_classes:      # the loss kernels index rows / columns by label
+                        raise ValueError('label out of range: batch has labels in [%d, %d], num_classes = %d' % (lo, hi, self.num_classes))
+                xt = torch.from_numpy(x)
+                yt = torch.from_numpy(y) if y is not None else None
+                if self.device.type == 'cuda':
+                    xt = xt.pin_memory()
+                self.q.put((xt, yt))
+        except BaseException as e:                            # noqa: B902 -- everything goes to the consumer
+            self.q.put(e)
 
     def advance(self):
-        xt, yt = self.q.get()
+        if self._dead is not None:
+            raise self._dead
+        while True:
+            try:
+                item = self.q.get(timeout=self.POLL_SECONDS)
+                break
+            except queue.Empty:
+                if not self._t.is_alive():
+                    self._dead = RuntimeError('input pipeline thread died without reporting an error')
+                    raise self._dead
+        if isinstance(item, BaseException):
+            self._dead = RuntimeError('input pipeline failed: %s: %s' % (type(item).__name__, item))
+            raise self._dead from item
+        xt, yt = item
         self._cur = (xt.to(self.device, non_blocking=True),
                      yt.to(self.device, non_blocking=True) if yt is not None else None)
         return self._cur
@@ -177,7 +205,7 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
         x = np.stack(imgs).reshape(shard, out_h, out_w, num_channels)
         return x, np.asarray([lab for _, lab in items], dtype=np.int32)
 
-    src = _BatchSource(_Prefetcher(make_batch, torch.device(device)))
+    src = _BatchSource(_Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total))
     return {'images': src.images, 'labels': src.labels, 'num_classes': num_classes_total,
             'num_examples': num_examples_total, 'batch_size': batch_size}
 

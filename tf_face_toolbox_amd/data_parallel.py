@@ -111,6 +111,20 @@ class Singular(object):
             labels = labels()
         return images, labels
 
+    @staticmethod
+    def _validate_labels(inputs):
+        """Labels index rows of the centers table and columns of the logits inside the loss kernels: a label outside
+        [0, num_classes) (list / num_classes mismatch, a hand-built inputs dict) must fail HERE, at graph-construction
+        time, like TF's range error -- not as an out-of-bounds device access.  Resident label tensors are checked once
+        (one host sync at setup); batches from data.train_inputs are checked per batch in the loader thread."""
+        labels = inputs.get('labels')
+        if callable(labels) or not isinstance(labels, torch.Tensor) or labels.numel() == 0 or 'num_classes' not in inputs:
+            return
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= int(inputs['num_classes']):
+            raise ValueError('labels must lie in [0, num_classes): got [%d, %d] with num_classes = %d'
+                             % (lo, hi, int(inputs['num_classes'])))
+
     def _lr_value(self):
         return float(self.lr(self.global_step)) if callable(self.lr) else float(self.lr)
 
@@ -126,6 +140,7 @@ class Singular(object):
 
     def _setup(self, inputs):
         m = self.model
+        self._validate_labels(inputs)
         m.weight_decay = self.weight_decay
         make = getattr(m, 'make_optimizer', None)
         self._opt = make(self.optimizer) if make is not None else _DeviceOptimizer(m, self.optimizer)
@@ -201,6 +216,13 @@ class DataParallel(Singular):
         num_classes = inputs['num_classes']
         self._global_batch = inputs.get('batch_size')
         scope = 'TOWER_%d' % self.comm.rank()
+        # the reference's towers draw independent dropout masks (one layers.dropout op per tower); a shared seed would
+        # give every replica the same mask for its shard
+        if hasattr(self.model, 'dropout_seed'):
+            base = getattr(self.model, '_dropout_seed_base', None)
+            if base is None:
+                base = self.model._dropout_seed_base = int(self.model.dropout_seed)
+            self.model.dropout_seed = base * self.num_gpus + self.comm.rank()
 
         def tower():
             images, labels = self._fetch(inputs)

@@ -775,7 +775,13 @@ class GraphNet(Network):
 
     # ---- bookkeeping the wrappers use ---------------------------------------------------------------------
     def param_list(self, is_training, trainable, scope=None):
+        """nets/resnet.py:178-184: trainable=True -> tf.trainable_variables(scope), trainable=False ->
+        tf.global_variables(scope), which also holds the scope's BatchNorm moving statistics (what the fine-tune
+        saver of train.py:191-193 restores through pretrained_param)."""
         bb = [v for k, v in self.variables.items() if k.startswith(self.name + '/')]
+        if not trainable:
+            bb = bb + [Variable(k, 'state', (self.state_ref.get(k, t.shape[0]),), -1, self.state_ref.get(k, t.shape[0]))
+                       for k, t in self.state.items() if k.startswith(self.name + '/')]
         if is_training:
             return [bb, [v for k, v in self.variables.items() if k.startswith('classifier/')]]
         return [bb]

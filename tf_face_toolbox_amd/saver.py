@@ -4,6 +4,10 @@ What is kept:
   * only ONE copy of the variables is written -- replica 0's, under the un-prefixed reference names
     (DataParallelSaverBuilder strips `replicated_0/`, saver.py:30-57); here every rank holds the same
     arena, so rank 0 writes it and nobody else does;
+  * the checkpoint holds tf.global_variables() (train.py:188), not just the trainable ones: the BN nets'
+    `.../BatchNorm/moving_mean` / `moving_variance` and the center loss's `centers` (loss.py:34-35) are written
+    under their reference names next to the weights (replica 0's copies: saver.py:36-40,63-65) and restored
+    with them -- an inference or fine-tune from a checkpoint normalises with the trained statistics;
   * optimizer slots and `global_step` are saved too, so the LR schedule resumes (train.py:157,207-210);
   * files are `model_dir/<net>_<model>/<net>_<model>.ckpt-<step>` plus a `checkpoint` index naming the
     latest one (tf.train.get_checkpoint_state, train.py:207); at most 20 are kept (train.py:188);
@@ -22,6 +26,14 @@ def _index_path(ckpt_dir):
     return os.path.join(ckpt_dir, 'checkpoint')
 
 
+def _state_names(model):
+    """Names of the model's non-trainable variables (GraphNet.state: `<scope>/BatchNorm/moving_mean`,
+    `moving_variance`, `centers`); SphereNet has none."""
+    if getattr(model, 'head', None) == 'softmax+center' and hasattr(model, '_centers') and getattr(model, 'built', True):
+        model._centers()                             # created lazily by the first loss_function(): make it exist
+    return list(getattr(model, 'state', None) or {})
+
+
 def save(model, optimizer_slots, global_step, path_prefix):
     """path_prefix like models/<net>_<model>/<net>_<model>.ckpt ; writes <prefix>-<step>."""
     ckpt_dir = os.path.dirname(path_prefix)
@@ -29,6 +41,8 @@ def save(model, optimizer_slots, global_step, path_prefix):
     path = '%s-%d' % (path_prefix, global_step)
     state = {'global_step': int(global_step), 'variables': {}, 'slots': []}
     for name in model.variables:
+        state['variables'][name] = model.get_variable(name).cpu()
+    for name in _state_names(model):                 # non-trainable global variables: BN moving statistics, centers
         state['variables'][name] = model.get_variable(name).cpu()
     for slot in optimizer_slots or []:
         state['slots'].append({name: model.get_variable(name, slot).cpu() for name in model.variables})
@@ -63,7 +77,7 @@ def restore(model, path, optimizer=None, only=None):
     """Load variables (all, or the names in `only`) and, when given, the optimizer slots.
     Returns the saved global_step."""
     state = torch.load(path, map_location='cpu')
-    names = list(model.variables) if only is None else [v if isinstance(v, str) else v.name for v in only]
+    names = list(model.variables) + _state_names(model) if only is None else [v if isinstance(v, str) else v.name for v in only]
     for name in names:
         if name not in state['variables']:
             raise KeyError('%s not found in checkpoint %s' % (name, path))
