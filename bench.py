@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work: started WITHOUT a torch.distributed environment and with --gpus N > 1, the script launches its own N
+ranks (child processes through torch.distributed.run, before anything in this process touches the GPU), relays rank
+0's JSON line and exits with the children's status.
+
 Workload (BASELINE.json configs[1]): SphereFaceNet-20 + A-softmax, 112x112 RGB,
 GLOBAL batch 512 (train.py --batch_size is the global batch; data_parallel.py:206 splits it),
 C = 10,575 classes, fp32, Momentum 0.9, wd 5e-4, lr 1e-4 (at the reference default 0.1 this synthetic
@@ -14,18 +18,27 @@ gradient all-reduce + optimizer (one `sess.run(train_ops)` of train.py:228) on s
 already resident in HBM.  Strong scaling: rank r works on rows [r*512/N, (r+1)*512/N).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel symbol igemm_kernel<64,64,2,2,MK,KN,FWD> (fp32-MFMA implicit-GEMM
-                 conv3x3 forward, 64x64 tile: the 16 resBlock convs + the three stride-2 stage-entry convs).  Its launches inside every 4th timed step are bracketed by a
-                 HIP event pair on the launch stream (fte_prof_*, include/fte.h; every step would cost 5 % at 64 images per GPU); achieved = sum of the
-                 launches' algorithmic FLOPs (2*rows*N*K each) / sum of their durations, against the
-                 157.3 TFLOP/s fp32 matrix peak.  avg_launch_ms is directly comparable with the
-                 AverageNs of the same symbol in profiles/*kernel_stats.csv;
-  cpu_baseline : the float32 CPU restatement of the reference graph (oracle/, kind "port") timed on
-                 this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline     : the dominant kernel symbol (most device time among the MFMA launches; for this workload the fp32-MFMA
+                 implicit-GEMM conv3x3 forward igemm_kernel<64,64,2,2,MK,KN,FWD>).  Its launches inside every 4th timed step
+                 are bracketed by a HIP event pair on the launch stream (fte_prof_*, include/fte.h); achieved = sum of the
+                 launches' algorithmic FLOPs (2*rows*N*K each) / sum of their durations, against the 157.3 TFLOP/s fp32
+                 matrix peak.  avg_launch_ms is directly comparable with the AverageNs of the same symbol in
+                 profiles/*kernel_stats.csv.  `per_shape` lists every (op, GEMM shape) of the step: fwd / dgrad / wgrad of
+                 the four stages, the stride-2 entries, FC and classifier -- ms, TFLOP/s, fraction of peak, and the
+                 algorithmic bytes / s of that launch (every operand and result tensor once);
+  cpu_baseline : BASELINE.md section 3: the float32 torch-CPU restatement of the reference graph (oracle/torch_ref.py,
+                 kind "port") timed on this host's cores at configs[0] -- 64 gray 112x112 images, Singular path, whole
+                 training steps -- with CPU model + thread count, and `parity`: max-abs / rel-L2 of the HIP path's
+                 embeddings and logits against it on those same 64 images (rank 0, N=1 only);
+  allreduce    : N > 1: RCCL world size, bucket sizes, each bucket's all-reduce timed alone after the run, and the step
+                 time with the all-reduce switched off (what the collective costs after overlap).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,39 +50,152 @@ GLOBAL_BATCH = 512
 H = W = 112
 CH = 3
 NUM_CLASSES = 10575
-MAC_PER_IMAGE_RESBLOCK_CONV = 115605504
 FP32_MFMA_PEAK_TFLOPS = 157.3                    # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0                   # same table, "Peak BF16/FP16 MFMA" (dense)
+HBM_PEAK_GBPS = 8000.0                           # same table, HBM3E peak (spec)
 LR = 1e-4
+TILES = {0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64', 4: '192,64', 5: '192,128'}
 
 
-def cpu_baseline(sample_images, min_seconds=10.0):
-    """Times the float32 oracle (numpy + BLAS) on `sample_images` images of the same workload."""
-    import numpy as np
-    from oracle import spherenet as osn, ops as oops
+def kernel_src_sha():
+    """Identity of the kernel sources: the committed PMC traffic figures are only valid for the kernels they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'tf_face_toolbox_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    p = {k: v.astype(np.float32) for k, v in osn.init_params(2, CH, NUM_CLASSES, H, W).items()}
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline_and_parity(dev, min_seconds=10.0, max_steps=12):
+    """configs[0] = SphereFaceNet-20 + A-softmax, 112x112 GRAY, batch 64, one replica.
+    Times whole training steps of the float32 torch-CPU restatement (oracle/torch_ref.py) on the host cores, then
+    runs the HIP path on the same 64 images / same weights and reports the parity of embeddings and logits."""
+    import numpy as np
+    import torch
+    from oracle import torch_ref, spherenet as osn, ops as oops
+    from tf_face_toolbox_amd import net_select
+    n, ch = 64, 1
+    p = osn.init_params(2, ch, NUM_CLASSES, H, W, dtype=np.float32)
     rng = np.random.default_rng(0)
-    x = rng.uniform(-1, 1, (sample_images, H, W, CH)).astype(np.float32)
-    y = np.random.default_rng(1).integers(0, NUM_CLASSES, sample_images)
-    slots = osn.zero_slots(p)
-    lam = np.float32(oops.asoftmax_lambda(0))
+    x = rng.uniform(-1, 1, (n, H, W, ch)).astype(np.float32)
+    y = np.random.default_rng(1).integers(0, NUM_CLASSES, n)
+    lam = float(oops.asoftmax_lambda(0))
+    threads = torch.get_num_threads()
+    # ---- parity first (weights untouched): CPU forward vs HIP forward on the same inputs ----
+    tp = torch_ref.to_torch(p, torch.float32, requires_grad=False)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    with torch.no_grad():
+        _, _, emb_c, log_c = torch_ref.spherenet_loss(tp, xt, yt, 5e-4, 'NCHW', 'asoftmax', lam)
+    net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+    net.build(H, W, ch, NUM_CLASSES, dev)
+    net.load_params(p)
+    net.global_step = 0
+    out = net.forward(xt.to(dev), yt.to(dev, torch.int32), num_classes=NUM_CLASSES, is_training=True)
+    emb_g = net.emb.float().cpu()
+    log_g = out['logits'].float().cpu()
+    torch.cuda.synchronize()
+
+    def maxabs(a, b):
+        return float((a - b).abs().max())
+
+    def rell2(a, b):
+        return float(((a - b).double().pow(2).sum() / b.double().pow(2).sum().clamp_min(1e-300)).sqrt())
+    tol = 1e-4
+    parity = {'config': 'configs[0]: 64 gray 112x112 images, SphereFaceNet-20 + A-softmax (lambda %.0f), same weights' % lam,
+              'embedding_maxabs': maxabs(emb_g, emb_c), 'embedding_max_ref': float(emb_c.abs().max()),
+              'embedding_rell2': rell2(emb_g, emb_c),
+              'logits_maxabs': maxabs(log_g, log_c), 'logits_max_ref': float(log_c.abs().max()),
+              'logits_rell2': rell2(log_g, log_c),
+              'tolerance': 'max-abs <= %g * max|ref| (fp32 HIP path vs fp32 CPU path)' % tol}
+    parity['ok'] = bool(parity['embedding_maxabs'] <= tol * parity['embedding_max_ref'] and
+                        parity['logits_maxabs'] <= tol * parity['logits_max_ref'])
+    del net
+    # ---- timing: whole training steps on the host cores ----
+    tp = torch_ref.to_torch(p, torch.float32, requires_grad=True)
+    slots = {k: torch.zeros_like(v) for k, v in tp.items()}
+    torch_ref.train_step(tp, slots, xt, yt, LR, 5e-4, 'NCHW', 'asoftmax', lam)          # untimed: thread pools, oneDNN primitives
     t0 = time.time()
     reps = 0
     while True:
-        p2, slots, _ = osn.train_step(p, slots, x, y, np.float32(0.1), head='asoftmax', lam=lam)
+        torch_ref.train_step(tp, slots, xt, yt, LR, 5e-4, 'NCHW', 'asoftmax', lam)
         reps += 1
         el = time.time() - t0
-        if el >= min_seconds or reps >= 8:
+        if el >= min_seconds or reps >= max_steps:
             break
-    return {'value': round(sample_images * reps / el, 3), 'unit': 'images/sec', 'cores': int(threads),
-            'kind': 'port',
-            'sample': '%d training steps of %d images (same net/head/shape, float32 numpy+BLAS oracle), %.1f s on %d host cores (os.cpu_count=%s)'
-                      % (reps, sample_images, el, threads, os.cpu_count())}
+    base = {'value': round(n * reps / el, 3), 'unit': 'images/sec', 'cores': int(threads), 'kind': 'port',
+            'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(),
+            'sample': '%d training steps (fwd + A-softmax loss + bwd + Momentum) of BASELINE configs[0] = 64 gray 112x112 images, '
+                      'float32 torch-CPU restatement of the reference graph (oracle/torch_ref.py: F.conv2d + autograd), %.1f s on %d threads'
+                      % (reps, el, threads)}
+    return base, parity
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks as FRESH child processes (nothing in
+    this process has touched the GPU -- it never will), relay rank 0's JSON line, exit non-zero if any rank failed."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + '\n')
+    if r.returncode != 0 or line is None:
+        sys.stderr.write('bench.py: the %d-rank run failed (exit code %d)\n' % (n, r.returncode))
+        raise SystemExit(r.returncode or 1)
+    print(line)
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
+def latest_traffic_file():
+    d = os.path.join(ROOT, 'profiles')
+    best = None
+    for f in os.listdir(d) if os.path.isdir(d) else []:
+        if f.startswith('r') and f.endswith('_traffic.json'):
+            try:
+                rnd = int(f[1:f.index('_')])
+            except ValueError:
+                continue
+            if best is None or rnd > best[0]:
+                best = (rnd, os.path.join(d, f))
+    return best[1] if best else None
+
+
+def symbol_name(key, bf):
+    al, bl, epi, tile = key
+    return 'igemm_kernel<%s,%s,%d,%d,%d,%d>' % (TILES.get(tile, '?'), '2,2' if tile != 1 else '4,1', al, bl, epi, bf)
+
+
+def op_kind(key):
+    al, bl, epi, _ = key
+    if al == 1:
+        return 'wgrad'                           # A = x^T (k = pixel): filter gradient / dense tn
+    return 'dgrad' if epi == 1 or bl == 1 else 'fwd'
 
 
 def main():
@@ -78,13 +204,15 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=8)
     ap.add_argument('--global-batch', type=int, default=GLOBAL_BATCH,
                     help='exploration only (e.g. the per-rank shard sizes of N=2/4/8 on one GPU); the metric is quoted at 512')
     ap.add_argument('--mfma-dtype', choices=['f32', 'bf16'], default='f32',
                     help="operand precision of the MFMA products (fte_set_mfma_dtype).  The metric (BASELINE.json configs[1]) is "
                          "fp32 = the default; bf16 = bf16 operands, fp32 accumulate, fp32 storage (exploration, configs[2]'s precision)")
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args.gpus, sys.argv[1:])     # does not return
 
     import torch
     import torch.distributed as dist
@@ -103,8 +231,10 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = 'gloo' if shared else 'nccl'
         if shared:
             dist.init_process_group('gloo')
         else:
@@ -135,6 +265,7 @@ def main():
 
     from tf_face_toolbox_amd import _lib
     _lib.set_mfma_dtype(args.mfma_dtype)
+    bf = 0 if args.mfma_dtype == 'f32' else (2 if getattr(net, 'bf16_copies', False) else 1)
     peak = FP32_MFMA_PEAK_TFLOPS if args.mfma_dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
     for _ in range(args.warmup):
         train_ops()
@@ -160,7 +291,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     _lib.query('fte_prof_enable', 0)
-    records = _lib.prof_records() if rank == 0 else []
+    records = _lib.prof_records(shapes=True) if rank == 0 else []
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -170,32 +301,95 @@ def main():
     if not all(math.isfinite(v) for v in loss_vals):
         raise SystemExit('non-finite losses %s: the timed run is invalid' % loss_vals)
 
+    # ---- N > 1: what the collective costs (outside the timed region) ----
+    allreduce = None
+    if world > 1:
+        buckets = net.grad_buckets()
+        alone = []
+        for a, b in buckets:
+            buf = torch.zeros(b - a, dtype=torch.float32, device=dev)
+            for _ in range(2):
+                dist.all_reduce(buf)
+            barrier()
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                dist.all_reduce(buf)
+            barrier()
+            alone.append(1000.0 * (time.perf_counter() - t1) / reps)
+            del buf
+
+        class _NoComm(object):                   # same wrapper, collective switched off: the step's compute-only time
+            def __init__(self, c): self.c = c
+            def world_size(self): return self.c.world_size()
+            def rank(self): return self.c.rank()
+            def broadcast(self, t, src=0): pass
+
+            def all_reduce_async(self, t):
+                class _W(object):
+                    def wait(self): return True
+                return _W()
+        real = model.comm
+        model.comm = _NoComm(real)
+        ksteps = max(2, args.steps // 2)
+        for _ in range(2):
+            train_ops()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(ksteps):
+            train_ops()
+        barrier()
+        nocomm = torch.tensor([1000.0 * (time.perf_counter() - t1) / ksteps], dtype=torch.float64, device=dev)
+        dist.all_reduce(nocomm, op=dist.ReduceOp.MAX)
+        model.comm = real
+        allreduce = {'backend': backend + (' (RCCL over xGMI)' if backend == 'nccl' else ' (test transport)'),
+                     'rccl_ranks': dist.get_world_size() if backend == 'nccl' else 0,
+                     'bucket_bytes': [4 * (b - a) for a, b in buckets],
+                     'bucket_alone_ms': [round(v, 3) for v in alone],
+                     'bucket_busbw_GBps': [round(4 * (b - a) * 2 * (world - 1) / world / (ms_ * 1e-3) / 1e9, 1)
+                                           for (a, b), ms_ in zip(buckets, alone)],
+                     'ms_per_step_without_allreduce': round(float(nocomm.item()), 3)}
+
     if rank == 0:
         ms = 1000.0 * elapsed / args.steps
-        # per-symbol table: sig = (A layout, B layout, epilogue, tile)
-        table = {}
-        for sig, fl, ms_ in records:
-            t = table.setdefault(sig[:4], [0, 0.0, 0.0])
-            t[0] += 1; t[1] += fl; t[2] += ms_
-        if not table:                       # FTE_BENCH_NO_PROF=1: throughput only
+        if not records:                      # FTE_BENCH_NO_PROF=1: throughput only
             print(json.dumps({'value': round(gb * args.steps / elapsed, 2), 'ms_per_step': round(ms, 3), 'n_gpus': world, 'note': 'launch records off'}))
             return
-        # dominant kernel = the conv-forward symbol (A = im2col rows, B = [K][N], forward epilogue) with the most time:
-        # igemm_kernel<64,64,2,2,AL_MK,BL_KN,EPI_FWD> for this workload (tile id 3)
-        fwd = [k for k in table if k[:3] == (0, 0, 0)]
-        DOM = max(fwd or list(table), key=lambda k: table[k][2])
-        cnt, dom_flops, dom_ms = table[DOM]
-        kern_ms = [1] * cnt
+        sampled = (args.steps + PROF_EVERY - 1) // PROF_EVERY
+        # per-symbol table: key = (A layout, B layout, epilogue, tile) -> [launches, flops, ms, alg bytes]
+        table, shapes = {}, {}
+        for sig, fl, ms_, mnk, by in records:
+            t = table.setdefault(sig[:4], [0, 0.0, 0.0, 0.0])
+            t[0] += 1; t[1] += fl; t[2] += ms_; t[3] += by
+            s = shapes.setdefault((op_kind(sig[:4]),) + tuple(mnk) + (sig[3], sig[4]), [0, 0.0, 0.0, 0.0])
+            s[0] += 1; s[1] += fl; s[2] += ms_; s[3] += by
+        DOM = max(table, key=lambda k: table[k][2])              # the symbol with the most device time
+        cnt, dom_flops, dom_ms, dom_bytes = table[DOM]
         avg_ms = dom_ms / cnt
-        flops = dom_flops / cnt
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         all_ms = sum(v[2] for v in table.values())
         all_flops = sum(v[1] for v in table.values())
-        traffic, tinfo = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
-        if world == 1 and os.path.exists(tpath) and args.mfma_dtype == 'f32':
-            tinfo = json.load(open(tpath))       # PMC passes cannot run inside this process: measured by
-            traffic = tinfo['bytes_per_launch']   # rocprofv3 --pmc on this same command, kept under profiles/
+        # PMC traffic: cannot be collected inside this process; measured by rocprofv3 --pmc on this same command and kept
+        # under profiles/, stamped with the kernel sources it was measured on (stale figures are nulled, not reported)
+        traffic, tsrc, tnote = None, None, None
+        tpath = latest_traffic_file()
+        if world == 1 and tpath and gb == GLOBAL_BATCH:
+            tinfo = json.load(open(tpath))
+            ent = (tinfo.get('symbols') or {}).get(symbol_name(DOM, bf))
+            if tinfo.get('kernel_src_sha') != kernel_src_sha():
+                tnote = 'profiles/%s was measured on other kernel sources (%s != %s): traffic nulled' % (
+                    os.path.basename(tpath), tinfo.get('kernel_src_sha'), kernel_src_sha())
+            elif ent and tinfo.get('mfma_dtype', 'f32') == args.mfma_dtype:
+                traffic = ent['hbm_bytes_per_launch']
+                tsrc = 'profiles/' + os.path.basename(tpath)
+        per_shape = []
+        for key in sorted(shapes, key=lambda k: -shapes[k][2]):
+            c_, fl_, ms_, by_ = shapes[key]
+            tf_ = fl_ / (ms_ * 1e-3) / 1e12
+            per_shape.append({'op': key[0], 'rows': key[1], 'N': key[2], 'K': key[3], 'tile': TILES.get(key[4], '?'), 'splits': key[5],
+                              'launches_per_step': round(c_ / sampled, 2), 'ms': round(ms_ / c_, 4),
+                              'tflops': round(tf_, 1), 'frac': round(tf_ / peak, 3),
+                              'alg_GBps': round(by_ / (ms_ * 1e-3) / 1e9, 0)})
         out = {
             'metric': 'images/sec (whole node), SphereFaceNet-20 112x112 bs512',
             'value': round(gb * args.steps / elapsed, 2),
@@ -214,20 +408,31 @@ def main():
             'step_mfma_frac': round(gb * args.steps / elapsed * 12.2698e9 / (peak * 1e12) / world, 4),
             'losses': dict(zip(losses_name, [round(v, 6) for v in loss_vals])),
             'roofline': {'bound': 'mfma',
-                         'kernel': 'igemm_kernel<%s,2,2,%d,%d,%d> = conv3x3 forward + bias/PReLU/residual (fp32 MFMA implicit GEMM)' % ({0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64'}[DOM[3]], DOM[0], DOM[1], DOM[2]),
+                         'kernel': '%s = %s (MFMA implicit GEMM)' % (symbol_name(DOM, bf), {'fwd': 'conv3x3 forward + bias/PReLU/residual', 'dgrad': 'conv3x3 data gradient + PReLU gradient', 'wgrad': 'conv3x3 filter gradient'}[op_kind(DOM)]),
                          'achieved': round(achieved, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'launches_timed': cnt, 'avg_launch_ms': round(avg_ms, 4),
-                         'flops_per_launch_avg': flops,
-                         'traffic': traffic, 'traffic_source': (tinfo or {}).get('summary_file'),
-                         'algorithmic_bytes_per_launch': (tinfo or {}).get('algorithmic_bytes_per_launch'),
-                         'all_mfma_kernels': {'launches': len(records), 'steps_sampled': (args.steps + PROF_EVERY - 1) // PROF_EVERY,
-                                              'ms_per_step': round(all_ms / ((args.steps + PROF_EVERY - 1) // PROF_EVERY), 3),
+                         'flops_per_launch_avg': dom_flops / cnt,
+                         'traffic': traffic, 'traffic_source': tsrc, 'traffic_note': tnote,
+                         'algorithmic_bytes_per_launch': round(dom_bytes / cnt),
+                         'algorithmic_GBps': round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1),
+                         'all_mfma_kernels': {'launches': len(records), 'steps_sampled': sampled,
+                                              'ms_per_step': round(all_ms / sampled, 3),
                                               'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 2),
-                                              'frac': round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4)}},
+                                              'frac': round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4)},
+                         'per_symbol': {symbol_name(k, bf): {'launches_per_step': round(v[0] / sampled, 2), 'ms_per_step': round(v[2] / sampled, 3),
+                                                             'tflops': round(v[1] / (v[2] * 1e-3) / 1e12, 1),
+                                                             'frac': round(v[1] / (v[2] * 1e-3) / 1e12 / peak, 3),
+                                                             'algorithmic_bytes_per_launch': round(v[3] / v[0])}
+                                        for k, v in sorted(table.items(), key=lambda kv: -kv[1][2])},
+                         'per_shape': per_shape},
+            'kernel_src_sha': kernel_src_sha(),
         }
+        if allreduce is not None:
+            out['allreduce'] = allreduce
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+            del train_ops, model
+            out['cpu_baseline'], out['parity'] = cpu_baseline_and_parity(dev)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

@@ -69,6 +69,9 @@ int fte_get_mfma_dtype(void);
 int fte_prof_enable(int on);
 int fte_prof_count(void);
 int fte_prof_get(int i, int* sig, double* flops, float* ms);
+/* the GEMM shape of record i, mnk = {rows, N, K} (conv forward: rows = n*ho*wo, N = cout, K = 9*cin), and its ALGORITHMIC
+ * bytes: every operand and result tensor of that launch once -- what bench.py's per-shape roofline divides by. */
+int fte_prof_get_shape(int i, int* mnk, double* bytes);
 
 /* ---------------------------------------------------------------------------
  * 3x3 convolution, TF-SAME, stride 1 or 2, Cin % 32 == 0, Cout % 64 == 0

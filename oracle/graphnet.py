@@ -51,8 +51,9 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
             _, _, inp, wname, stride, groups = op
             x = env[inp]
             gw = x.shape[-1] // groups
-            env[out] = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], params[wname][g], stride)
-                                       for g in range(groups)], axis=-1)
+            with ops.operand_rounding(None):          # the engine's grouped 3x3 kernel is plain fp32 in every mode
+                env[out] = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], params[wname][g], stride)
+                                           for g in range(groups)], axis=-1)
         elif kind == 'se':          # ('se', out, inp, prefix[, scope1, scope2]): nets/shufflenet_v2.py:79-85
             inp, pre = op[2], op[3]
             s1, s2 = (op[4], op[5]) if len(op) > 4 else ('fc1', 'fc2')
@@ -60,8 +61,8 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
             sq = x.mean(axis=(1, 2))
             w1 = params[pre + '/%s/weights' % s1].reshape(params[pre + '/%s/weights' % s1].shape[-2:])
             w2 = params[pre + '/%s/weights' % s2].reshape(params[pre + '/%s/weights' % s2].shape[-2:])
-            hid = np.maximum(sq @ w1 + params[pre + '/%s/biases' % s1], 0)
-            gate = 1.0 / (1.0 + np.exp(-(hid @ w2 + params[pre + '/%s/biases' % s2])))
+            hid = np.maximum(ops.mfma_matmul(sq, w1) + params[pre + '/%s/biases' % s1], 0)
+            gate = 1.0 / (1.0 + np.exp(-(ops.mfma_matmul(hid, w2) + params[pre + '/%s/biases' % s2])))
             env[out] = x * gate[:, None, None, :]
             cache[out] = dict(sq=sq, hid=hid, gate=gate)
         elif kind == 'dwconv':      # ('dwconv', out, inp, wname, stride)
@@ -182,10 +183,11 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
             gw = x.shape[-1] // groups
             dx = np.zeros_like(x)
             dw = np.zeros_like(params[wname])
-            for g in range(groups):
-                dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw], stride)
-                dx[..., g * gw:(g + 1) * gw] = dxg
-                dw[g] = dwg
+            with ops.operand_rounding(None):
+                for g in range(groups):
+                    dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw], stride)
+                    dx[..., g * gw:(g + 1) * gw] = dxg
+                    dw[g] = dwg
             acc(gp, wname, dw)
             acc(gt, inp, dx)
         elif kind == 'se':
@@ -198,12 +200,12 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
             hw = x.shape[1] * x.shape[2]
             dgate = (dy * x).sum(axis=(1, 2))
             dpre2 = dgate * c['gate'] * (1 - c['gate'])
-            acc(gp, n2, (c['hid'].T @ dpre2).reshape(params[n2].shape))
+            acc(gp, n2, ops.mfma_matmul(c['hid'].T, dpre2).reshape(params[n2].shape))
             acc(gp, pre + '/%s/biases' % s2, dpre2.sum(0))
-            dpre1 = (dpre2 @ w2.T) * (c['hid'] > 0)
-            acc(gp, n1, (c['sq'].T @ dpre1).reshape(params[n1].shape))
+            dpre1 = ops.mfma_matmul(dpre2, w2.T) * (c['hid'] > 0)
+            acc(gp, n1, ops.mfma_matmul(c['sq'].T, dpre1).reshape(params[n1].shape))
             acc(gp, pre + '/%s/biases' % s1, dpre1.sum(0))
-            dsq = dpre1 @ w1.T
+            dsq = ops.mfma_matmul(dpre1, w1.T)
             acc(gt, inp, dy * c['gate'][:, None, None, :] + dsq[:, None, None, :] / hw)
         elif kind == 'fc':
             dx, dw, db = ops.fc_bwd(env[op[2]], params[op[3]], dy, op[4] is not None)

@@ -6,7 +6,50 @@ dtype of its inputs (float64 for parity checks, float32 for the timed
 layouts: activations NHWC, conv weights HWIO `[kh,kw,Cin,Cout]`, FC weights
 `[in,out]`.  TF semantics follow SURVEY.md Appendix A.
 """
+import contextlib
+
 import numpy as np
+
+
+# --------------------------------------------------------------------------
+# MFMA operand precision (the build's bf16 mode, BASELINE.json configs[2]: "bf16").  The reference computes in fp32
+# (dtype=tf.float32 throughout); the engine's bf16 mode rounds the two OPERANDS of every matrix product that runs on
+# the MFMA kernel family (convolutions and dense products, forward and both gradients) to bfloat16 -- round to nearest
+# even -- and keeps products, accumulation, storage and everything else in fp32.  `operand_rounding('bf16')` makes the
+# oracle's products do exactly that, so the bf16 mode has an EXACT counterpart to be checked against instead of a loose
+# mixed-precision tolerance.  Default: no rounding.
+# --------------------------------------------------------------------------
+_OPERAND_ROUND = None
+
+
+def bf16_round(a):
+    """Nearest-even rounding of the float32 value of `a` to bfloat16, returned in a's dtype."""
+    a = np.asarray(a)
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(a.dtype) if a.dtype != np.float32 else r
+
+
+@contextlib.contextmanager
+def operand_rounding(mode):
+    """mode None | 'bf16': precision of the operands of conv2d_* / fc_* / mfma_matmul products inside the block."""
+    global _OPERAND_ROUND
+    assert mode in (None, 'bf16'), mode
+    prev = _OPERAND_ROUND
+    _OPERAND_ROUND = bf16_round if mode == 'bf16' else None
+    try:
+        yield
+    finally:
+        _OPERAND_ROUND = prev
+
+
+def _r(a):
+    return a if _OPERAND_ROUND is None else _OPERAND_ROUND(a)
+
+
+def mfma_matmul(a, b):
+    """a @ b as the engine's MFMA kernels compute it: operands rounded per operand_rounding(), fp32/64 accumulate."""
+    return _r(a) @ _r(b)
 
 
 # --------------------------------------------------------------------------
@@ -44,7 +87,7 @@ def conv2d_fwd(x, w, stride=1, bias=None):
     ho, pt, pb = same_pads(h, kh, stride)
     wo, pl, pr = same_pads(wd, kw, stride)
     cols = _im2col(_pad_nhwc(x, pt, pb, pl, pr), kh, kw, stride, ho, wo)
-    z = cols @ w.reshape(kh * kw * ci, co)
+    z = mfma_matmul(cols, w.reshape(kh * kw * ci, co))
     if bias is not None:
         z = z + bias
     return z.reshape(n, ho, wo, co)
@@ -60,10 +103,10 @@ def conv2d_bwd(x, w, dz, stride=1, need_dx=True):
     xp = _pad_nhwc(x, pt, pb, pl, pr)
     cols = _im2col(xp, kh, kw, stride, ho, wo)
     dz2 = dz.reshape(n * ho * wo, co)
-    dw = (cols.T @ dz2).reshape(kh, kw, ci, co)
+    dw = mfma_matmul(cols.T, dz2).reshape(kh, kw, ci, co)
     dx = None
     if need_dx:
-        dcols = (dz2 @ w.reshape(kh * kw * ci, co).T).reshape(n, ho, wo, kh, kw, ci)
+        dcols = mfma_matmul(dz2, w.reshape(kh * kw * ci, co).T).reshape(n, ho, wo, kh, kw, ci)
         dxp = np.zeros_like(xp)
         for r in range(kh):
             for s in range(kw):
@@ -98,13 +141,13 @@ def prelu_bwd(z, alpha, dy, zsign=None):
 # fully_connected (nets/sphere.py:73-74, 86-90)
 # --------------------------------------------------------------------------
 def fc_fwd(x, w, b=None):
-    y = x @ w
+    y = mfma_matmul(x, w)
     return y if b is None else y + b
 
 
 def fc_bwd(x, w, dy, has_bias):
-    dx = dy @ w.T
-    dw = x.T @ dy
+    dx = mfma_matmul(dy, w.T)
+    dw = mfma_matmul(x.T, dy)
     db = dy.sum(axis=0) if has_bias else None
     return dx, dw, db
 
@@ -210,7 +253,7 @@ def asoftmax_logits(x, w, labels, lam):
     n = x.shape[0]
     xn = np.sqrt((x * x).sum(axis=1))                 # |x_i|
     wn = np.sqrt((w * w).sum(axis=0))                 # |W_j|
-    s = x @ w
+    s = mfma_matmul(x, w)
     f = s / wn                                        # |x| cos(theta_ij)
     sy = s[np.arange(n), labels]
     c = sy / (xn * wn[labels])
@@ -237,8 +280,8 @@ def asoftmax_fwd_bwd(x, w, labels, lam, grad_scale=None):
     G[idx, labels] = g[idx, labels] * dphi / ((1 + lam) * wn[labels])
     rowcoef = g[idx, labels] * (phi - dphi * c) / ((1 + lam) * xn)
     colcoef = -(G * s).sum(axis=0) / (wn * wn)
-    dx = G @ w.T + rowcoef[:, None] * x
-    dw = x.T @ G + colcoef[None, :] * w
+    dx = mfma_matmul(G, w.T) + rowcoef[:, None] * x
+    dw = mfma_matmul(x.T, G) + colcoef[None, :] * w
     return loss, f, dx, dw
 
 

@@ -1,0 +1,56 @@
+"""Throughput of the host input pipeline (tf_face_toolbox_amd/data.py: list reader -> JPEG decode -> TF-1.x bilinear resize ->
+crop / flip -> normalise -> NHWC float32 batch) in images/s at 112x112, on this host's cores -- to be read against the
+rate the GPU step consumes (~10 k images/s per MI355X in fp32, ~30 k in the bf16 mode).
+
+    python scripts/bench_loader.py [--images 2048] [--batch 512] [--batches 8] [--src 250] [--device cpu|cuda]
+
+Writes N synthetic JPEGs of src x src pixels (CASIA-WebFace crops are 250 x 250) to a temporary directory, then times
+`data.train_inputs(...)` batches (resize to 128 x 128, random crop 112 x 112, flip): the same call train.py makes."""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np          # noqa: E402
+from PIL import Image       # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--images', type=int, default=2048)
+    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--batches', type=int, default=8)
+    ap.add_argument('--src', type=int, default=250)
+    ap.add_argument('--device', default='cpu')
+    args = ap.parse_args()
+    from tf_face_toolbox_amd import data
+    rng = np.random.default_rng(0)
+    with tempfile.TemporaryDirectory() as d:
+        lines = []
+        base = rng.integers(0, 255, (args.src, args.src, 3), dtype=np.uint8)
+        for i in range(args.images):
+            p = os.path.join(d, '%06d.jpg' % i)
+            Image.fromarray(np.roll(base, i * 7, axis=1)).save(p, quality=90)
+            lines.append('%s %d' % (p, i % 100))
+        lst = os.path.join(d, 'list.txt')
+        open(lst, 'w').write('\n'.join(lines) + '\n')
+        inp = data.train_inputs(lst, 128, 128, 112, 112, is_color=1, batch_size=args.batch, device=args.device, seed=0)
+        inp['images']()                                  # warm-up: thread pool, page cache
+        t0 = time.time()
+        for _ in range(args.batches):
+            x = inp['images']()
+            inp['labels']()
+        if args.device != 'cpu':
+            import torch
+            torch.cuda.synchronize()
+        el = time.time() - t0
+        print('loader: %.0f images/s (%d batches of %d, %dx%d JPEG -> 128x128 -> crop 112x112, %d worker threads, os.cpu_count=%d, device %s), batch %s %s'
+              % (args.batches * args.batch / el, args.batches, args.batch, args.src, args.src,
+                 max(1, os.cpu_count() // 2), os.cpu_count(), args.device, tuple(x.shape), x.dtype))
+
+
+if __name__ == '__main__':
+    main()

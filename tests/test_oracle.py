@@ -14,52 +14,8 @@ from oracle import ops, spherenet as sn
 
 
 # ---------------------------------------------------------------- independent torch model
-def _tf_same_pad(x, k, stride):
-    h, w = x.shape[2], x.shape[3]
-    def pads(n):
-        out = (n + stride - 1) // stride
-        tot = max((out - 1) * stride + k - n, 0)
-        return tot // 2, tot - tot // 2
-    pt, pb = pads(h)
-    pl, pr = pads(w)
-    return F.pad(x, (pl, pr, pt, pb))
-
-
-def _torch_prelu(x, alpha):
-    a = alpha.view(1, -1, 1, 1)
-    return torch.relu(x) + a * (x - torch.abs(x)) * 0.5          # nets/sphere.py:36 verbatim formula
-
-
-def _torch_conv(x, w_hwio, stride, bias):
-    w = w_hwio.permute(3, 2, 0, 1)                                # HWIO -> OIHW
-    return F.conv2d(_tf_same_pad(x, 3, stride), w, bias, stride=stride)
-
-
-def torch_spherenet_loss(tp, images_nhwc, labels, wd, data_format):
-    x = images_nhwc.permute(0, 3, 1, 2)                           # sphere.py:53-54
-    def conv(name, x, stride):
-        z = _torch_conv(x, tp[name + '/weights'], stride, tp.get(name + '/biases'))
-        return _torch_prelu(z, tp[name + '/alpha'])
-    def block(scope, x):
-        return x + conv(scope + '/Conv_1', conv(scope + '/Conv', x, 1), 1)
-    x = conv('SphereNet/conv1/Conv', x, 2)
-    x = block('SphereNet/conv1/resBlock', x)
-    x = conv('SphereNet/conv2/Conv', x, 2)
-    for i in (1, 2):
-        x = block('SphereNet/conv2/Repeat/resBlock_%d' % i, x)
-    x = conv('SphereNet/conv3/Conv', x, 2)
-    for i in (1, 2, 3, 4):
-        x = block('SphereNet/conv3/Repeat/resBlock_%d' % i, x)
-    x = conv('SphereNet/conv4/Conv', x, 2)
-    x = block('SphereNet/conv4/resBlock', x)
-    if data_format == 'NHWC':
-        x = x.permute(0, 2, 3, 1)
-    flat = x.reshape(x.shape[0], -1)
-    emb = flat @ tp['SphereNet/fully_connected/weights'] + tp['SphereNet/fully_connected/biases']
-    logits = emb @ tp['classifier/fc_classifier/weights']
-    ce = F.cross_entropy(logits, labels)
-    reg = sum(wd * (v ** 2).sum() / 2 for k, v in tp.items() if k.endswith('/weights'))
-    return ce, reg, emb, logits
+# oracle/torch_ref.py: written in NCHW from the reference's layer list, shares no code with the numpy oracle
+from oracle.torch_ref import spherenet_loss as torch_spherenet_loss, train_step as torch_train_step, to_torch      # noqa: E402
 
 
 @pytest.mark.parametrize('in_ch,hw,data_format', [(3, (32, 32), 'NCHW'), (1, (48, 16), 'NHWC')])
@@ -84,6 +40,35 @@ def test_spherenet_grads_match_torch_autograd(in_ch, hw, data_format):
         ref = tp[k].grad.numpy()
         err = np.abs(g[k] - ref).max()
         assert err <= 1e-11 * max(1.0, np.abs(ref).max()), (k, err)
+
+
+@pytest.mark.parametrize('lam', [1000.0, 5.0, 0.0])
+def test_asoftmax_step_matches_torch_autograd(lam):
+    """The A-softmax head (hand-derived gradient through both norms, oracle/ops.py) and one Momentum step against
+    torch autograd on oracle/torch_ref.py's independent restatement of SURVEY App. A.9."""
+    h = w = 16
+    ncls = 9
+    p = sn.perturb_params(sn.init_params(15, 1, ncls, h, w), 16)
+    p['classifier/fc_classifier/weights'] = p['classifier/fc_classifier/weights'] * 300      # cos(theta) spread over the k branches
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, (6, h, w, 1))
+    y = rng.integers(0, ncls, 6)
+    losses, g, ex = sn.loss_and_grads(p, x, y, 5e-4, 'NCHW', 'asoftmax', lam)
+    tp = to_torch(p, torch.float64)
+    ce, reg, emb, logits = torch_spherenet_loss(tp, torch.tensor(x), torch.tensor(y), 5e-4, 'NCHW', 'asoftmax', lam)
+    (ce + reg).backward()
+    assert abs(losses[0] - ce.item()) < 1e-11 and abs(losses[1] - reg.item()) < 1e-11 * max(1, reg.item())
+    np.testing.assert_allclose(ex['logits'], logits.detach().numpy(), rtol=0, atol=1e-11 * max(1, np.abs(ex['logits']).max()))
+    for k in tp:
+        ref = tp[k].grad.numpy()
+        assert np.abs(g[k] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), k
+    # one full step (data_parallel.py:45-79): same new weights
+    p2, s2, _ = sn.train_step(p, sn.zero_slots(p), x, y, 0.05, head='asoftmax', lam=lam)
+    tp = to_torch(p, torch.float64)
+    slots = {k: torch.zeros_like(v) for k, v in tp.items()}
+    torch_train_step(tp, slots, torch.tensor(x), torch.tensor(y), 0.05, 5e-4, 'NCHW', 'asoftmax', lam)
+    for k in p2:
+        assert np.abs(tp[k].detach().numpy() - p2[k]).max() <= 1e-11 * max(1.0, np.abs(p2[k]).max()), k
 
 
 def test_same_padding_is_asymmetric_for_stride2():

@@ -19,6 +19,7 @@ _SIGS = {
     'fte_prof_enable': (c_int, [c_int]),
     'fte_prof_count': (c_int, []),
     'fte_prof_get': (c_int, [c_int, _P, _P, _P]),
+    'fte_prof_get_shape': (c_int, [c_int, _P, _P]),
     'fte_conv3x3_fwd': (c_int, [_P] * 7 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_fwd_ws_bytes': (c_size_t, [c_int] * 6),
     'fte_conv3x3_dgrad': (c_int, [_P] * 9 + [c_int] * 6 + [_P, c_size_t, _P]),
@@ -159,17 +160,26 @@ def get_mfma_dtype():
     return 'bf16' if query('fte_get_mfma_dtype') == 1 else 'f32'
 
 
-def prof_records():
-    """All launch records since fte_prof_enable(1): list of (sig tuple, flops, ms).  Synchronise first."""
+def prof_records(shapes=False):
+    """All launch records since fte_prof_enable(1): list of (sig tuple, flops, ms) -- with `shapes`, of
+    (sig tuple, flops, ms, (rows, N, K), algorithmic bytes).  Synchronise first."""
     lib = load()
     out = []
     sig = (ctypes.c_int * 5)()
+    mnk = (ctypes.c_int * 3)()
     fl = ctypes.c_double()
+    by = ctypes.c_double()
     ms = ctypes.c_float()
     for i in range(lib.fte_prof_count()):
         r = lib.fte_prof_get(i, ctypes.cast(sig, c_void_p), ctypes.cast(ctypes.pointer(fl), c_void_p),
                              ctypes.cast(ctypes.pointer(ms), c_void_p))
         if r != 0:
             raise FteError('fte_prof_get(%d) failed with code %d' % (i, r))
-        out.append((tuple(sig), fl.value, ms.value))
+        if shapes:
+            r = lib.fte_prof_get_shape(i, ctypes.cast(mnk, c_void_p), ctypes.cast(ctypes.pointer(by), c_void_p))
+            if r != 0:
+                raise FteError('fte_prof_get_shape(%d) failed with code %d' % (i, r))
+            out.append((tuple(sig), fl.value, ms.value, tuple(mnk), by.value))
+        else:
+            out.append((tuple(sig), fl.value, ms.value))
     return out

@@ -223,6 +223,10 @@ int fte_get_mfma_dtype(void) { return igemm_get_bf16() ? FTE_MFMA_BF16 : FTE_MFM
 
 int fte_prof_enable(int on) { igemm_prof_enable(on != 0, on == 1); return FTE_OK; }
 int fte_prof_count(void) { return igemm_prof_count(); }
+int fte_prof_get_shape(int i, int* mnk, double* bytes) {
+    if (!mnk || !bytes) return FTE_EINVAL;
+    return rc(igemm_prof_get_shape(i, mnk, bytes));
+}
 int fte_prof_get(int i, int* sig, double* flops, float* ms) {
     if (!sig || !flops || !ms) return FTE_EINVAL;
     return rc(igemm_prof_get(i, sig, flops, ms));

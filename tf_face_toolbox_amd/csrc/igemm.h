@@ -69,3 +69,4 @@ bool igemm_get_bf16();
 void igemm_prof_enable(bool on, bool clear);
 int igemm_prof_count();
 hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms);
+hipError_t igemm_prof_get_shape(int i, int* mnk, double* bytes);      // GEMM shape {rows, N, K} and algorithmic bytes of record i

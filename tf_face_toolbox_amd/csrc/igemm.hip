@@ -1076,7 +1076,7 @@ hipError_t launch_tile(const IgemmParams& p, int tile, int splits, hipStream_t s
 // stream and its algorithmic FLOPs (2 * rows * N * K of THAT launch) are noted, so that a caller can
 // report FLOPs / duration per kernel symbol -- the same per-symbol average rocprofv3 --stats prints.
 namespace {
-struct ProfRec { int sig[5]; double flops; hipEvent_t e0, e1; };
+struct ProfRec { int sig[5]; int mnk[3]; double flops, bytes; hipEvent_t e0, e1; };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
 void prof_clear() {
@@ -1103,7 +1103,32 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
     if (!g_prof_on) return dispatch(p, al, bl, epi, tile, splits, st);
     ProfRec r;
     r.sig[0] = al; r.sig[1] = bl; r.sig[2] = epi; r.sig[3] = tile; r.sig[4] = splits;
-    r.flops = 2.0 * (double)(p.M - p.m_base) * (double)p.N * (double)(p.ncls > 1 ? p.cls_tap0[p.ncls] * p.a_KC : p.K);
+    const double rows = (double)(p.M - p.m_base) * (p.ncls > 1 ? p.ncls : 1);      // merged parity classes: M rows per class
+    const double keff = p.ncls > 1 ? (double)(p.cls_tap0[p.ncls] * p.a_KC) / p.ncls : (double)p.K;
+    r.flops = 2.0 * rows * (double)p.N * keff;
+    r.mnk[0] = (int)rows; r.mnk[1] = p.N; r.mnk[2] = (int)keff;
+    // ALGORITHMIC bytes of this launch: every operand tensor once, every result tensor once.  The A tensor is
+    // counted on the launch that starts at row 0 (a big-tile main + small-tile tail pair reads it once between them).
+    {
+        const double esz = p.src16 ? 2.0 : 4.0;
+        (void)esz;
+        double b = (p.m_base == 0 ? (double)p.a_bytes : 0.0) + (double)p.b_bytes;
+        const double tile = rows * (double)p.N * 4.0;
+        if (p.PW) b += tile * splits;
+        else if (epi == EPI_FWD) {
+            b += tile * splits;                               // Y (split-K: one slab per split)
+            if (p.Z) b += tile;
+            if (p.R) b += tile;
+            if (p.Y16) b += tile / 2;
+        } else {
+            b += tile;                                        // DZ
+            if (p.ADD) b += tile;
+            if (p.Zin) b += tile;
+            if (p.RAW) b += tile;
+            if (p.DZ16) b += tile / 2;
+        }
+        r.bytes = b;
+    }
     hipError_t e = hipEventCreate(&r.e0);
     if (e != hipSuccess) return e;
     e = hipEventCreate(&r.e1);
@@ -1128,6 +1153,12 @@ void igemm_prof_enable(bool on, bool clear) {
     g_prof_on = on;
 }
 int igemm_prof_count() { return (int)g_prof.size(); }
+hipError_t igemm_prof_get_shape(int i, int* mnk, double* bytes) {
+    if (i < 0 || i >= (int)g_prof.size()) return hipErrorInvalidValue;
+    for (int k = 0; k < 3; ++k) mnk[k] = g_prof[i].mnk[k];
+    *bytes = g_prof[i].bytes;
+    return hipSuccess;
+}
 hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms) {
     if (i < 0 || i >= (int)g_prof.size()) return hipErrorInvalidValue;
     const ProfRec& r = g_prof[i];

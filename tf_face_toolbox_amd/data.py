@@ -17,7 +17,7 @@ from multiprocessing import cpu_count
 import numpy as np
 import torch
 
-from .preprocessing import data_augmentation
+from .preprocessing import data_augmentation  # noqa: F401
 
 
 # ------------------------------------------------------------------ list parsers (names kept)
@@ -62,27 +62,7 @@ def get_image_paths_and_labels_dict(list_path, num_per_class):
 
 
 # ------------------------------------------------------------------ decode / preprocess (host)
-def _decode(path, num_channels, height, width):
-    from PIL import Image
-    img = Image.open(path)
-    img = img.convert('RGB' if num_channels == 3 else 'L')
-    if img.size != (width, height):
-        img = img.resize((width, height), Image.BILINEAR)          # tf.image.resize_images default
-    a = np.asarray(img, dtype=np.float32) / 255.0                   # convert_image_dtype(uint8 -> float32)
-    return a.reshape(height, width, num_channels)
-
-
-def _train_example(path, num_channels, input_height, input_width, crop_height, crop_width, augmentation, rng):
-    image = _decode(path, num_channels, input_height, input_width)
-    if crop_height != -1 and crop_width != -1:                      # tf.random_crop
-        y0 = rng.integers(0, input_height - crop_height + 1)
-        x0 = rng.integers(0, input_width - crop_width + 1)
-        image = image[y0:y0 + crop_height, x0:x0 + crop_width, :]
-    if augmentation:
-        image = data_augmentation(image, rng)
-    elif rng.random() < 0.5:                                        # tf.image.random_flip_left_right
-        image = image[:, ::-1, :]
-    return (np.ascontiguousarray(image, dtype=np.float32) - 0.5) / 0.5
+from ._decode_worker import resize_bilinear_tf1, decode as _decode, train_example as _train_example, fill_rows as _fill_rows   # noqa: E402,F401
 
 
 class _Prefetcher(object):
@@ -115,7 +95,9 @@ class _Prefetcher(object):
                 xt = torch.from_numpy(x)
                 yt = torch.from_numpy(y) if y is not None else None
                 if self.device.type == 'cuda':
-                    xt = xt.pin_memory()
+                    xt = xt.pin_memory()                      # a copy: the workers' shared batch buffer is free again
+                elif isinstance(x, np.memmap):
+                    xt = xt.clone()
                 self.q.put((xt, yt))
         except BaseException as e:                            # noqa: B902 -- everything goes to the consumer
             self.q.put(e)
@@ -140,6 +122,80 @@ class _Prefetcher(object):
         return self._cur
 
 
+class _WorkerPool(object):
+    """Decode workers as separate PROCESSES (`python -m tf_face_toolbox_amd._decode_worker`: numpy + PIL only, no torch, no GPU)
+    that write their rows straight into a float32 batch buffer under /dev/shm mapped by everybody.  Threads top out at a
+    few hundred images/s (the numpy part of decode/resize holds the GIL); the GPU step consumes 10-30 k images/s."""
+
+    RING = 3                                     # batch buffers in rotation: prefetch depth 2 + the one being filled
+
+    def __init__(self, workers, shape):
+        import atexit
+        import subprocess
+        import sys
+        self.shape = tuple(shape)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1',
+                   OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        self.procs = [subprocess.Popen([sys.executable, '-m', 'tf_face_toolbox_amd._decode_worker'], stdin=subprocess.PIPE,
+                                       stdout=subprocess.PIPE, env=env) for _ in range(workers)]
+        base = '/dev/shm' if os.path.isdir('/dev/shm') else None
+        import tempfile
+        self.files, self.maps = [], []
+        for k in range(self.RING):
+            fd, path = tempfile.mkstemp(prefix='fte_batch_%d_%d_' % (os.getpid(), k), dir=base)
+            os.close(fd)
+            self.files.append(path)
+            self.maps.append(np.memmap(path, dtype=np.float32, mode='w+', shape=self.shape))
+        self.turn = 0
+        atexit.register(self.close)
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=2)
+            except Exception:
+                p.kill()
+        self.procs = []
+        self.maps = []
+        for f in self.files:
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        self.files = []
+
+    def fill(self, rows, params):
+        """rows: [(row, path, seed)]; returns the filled batch array (valid until RING - 1 further calls)."""
+        import pickle
+        import struct
+        k = self.turn
+        self.turn = (k + 1) % self.RING
+        n = len(self.procs)
+        chunks = [rows[i::n] for i in range(n)]
+        used = []
+        for p, ch in zip(self.procs, chunks):
+            if not ch:
+                continue
+            b = pickle.dumps((self.files[k], self.shape, ch) + tuple(params))
+            p.stdin.write(struct.pack('<I', len(b)) + b)
+            p.stdin.flush()
+            used.append(p)
+        for p in used:
+            hdr = p.stdout.read(4)
+            if len(hdr) < 4:
+                raise RuntimeError('a decode worker died (exit code %s)' % p.poll())
+            kind, val = pickle.loads(p.stdout.read(struct.unpack('<I', hdr)[0]))
+            if kind != 'ok':
+                raise RuntimeError('decode worker: %s' % val)
+        return self.maps[k]
+
+
 class _BatchSource(object):
     """images() advances to the next batch; labels() returns the labels of that same batch
     (one `sess.run` fetches both from one dataset element in the reference)."""
@@ -159,7 +215,7 @@ class _BatchSource(object):
 # ------------------------------------------------------------------ public input builders
 def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop_width=-1, is_color=1,
                  augmentation=0, batch_size=-1, num_classes=-1, num_per_class=-1, device='cuda', seed=None,
-                 rank=0, world_size=1):
+                 rank=0, world_size=1, num_workers=None):
     """data.py:195-281.  Returns {'images', 'labels', 'num_classes', 'num_examples', 'batch_size'};
     images/labels are callables (next batch / its labels).  With world_size > 1 every rank draws the
     same global batch order (shared seed) and decodes only its own rows [r*B/n, (r+1)*B/n)."""
@@ -192,18 +248,30 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
     assert batch_size % world_size == 0
     shard = batch_size // world_size
     gen = _gen()
-    pool = ThreadPoolExecutor(max(1, cpu_count() // 2))
     out_h = crop_height if crop_height != -1 and crop_width != -1 else input_height
     out_w = crop_width if crop_height != -1 and crop_width != -1 else input_width
+    # num_workers: decode PROCESSES (data.py:260 maps with cpu_count()/2 parallel calls); 0 = threads in this process
+    # (small batches, tests).  Default: processes once a rank's shard is big enough to pay for starting them.
+    if num_workers is None:
+        num_workers = int(os.environ.get('FTE_LOADER_WORKERS', '-1'))
+        if num_workers < 0:
+            num_workers = min(max(1, cpu_count() // 2 // max(1, world_size)), shard // 4) if shard >= 64 else 0
+    procs = _WorkerPool(num_workers, (shard, out_h, out_w, num_channels)) if num_workers > 0 else None
+    pool = None if procs else ThreadPoolExecutor(max(1, cpu_count() // 2))
+    params = (num_channels, input_height, input_width, crop_height, crop_width, augmentation)
 
     def make_batch():
         items = [next(gen) for _ in range(batch_size)][rank * shard:(rank + 1) * shard]
         seeds = rng.integers(0, 2 ** 31, size=batch_size)[rank * shard:(rank + 1) * shard]
+        labels = np.asarray([lab for _, lab in items], dtype=np.int32)
+        if procs is not None:
+            x = procs.fill([(i, it[0], int(sd)) for i, (it, sd) in enumerate(zip(items, seeds))], params)
+            return x, labels
         imgs = list(pool.map(lambda a: _train_example(a[0][0], num_channels, input_height, input_width, crop_height,
                                                       crop_width, augmentation, np.random.default_rng(a[1])),
                              zip(items, seeds)))
         x = np.stack(imgs).reshape(shard, out_h, out_w, num_channels)
-        return x, np.asarray([lab for _, lab in items], dtype=np.int32)
+        return x, labels
 
     src = _BatchSource(_Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total))
     return {'images': src.images, 'labels': src.labels, 'num_classes': num_classes_total,

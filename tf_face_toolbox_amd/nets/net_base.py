@@ -28,9 +28,9 @@ def net_select(name, data_format='NCHW', weight_decay=5e-4):
     elif name in ('ResNeXt-26', 'ResNeXt-50'):   # nets/net_base.py:27-31 exposes -26; -50 is BASELINE config 3
         from .resnet import ResNeXt
         network = ResNeXt(num_layers=int(name.split('-')[1]), num_card=32, data_format=data_format, weight_decay=weight_decay)
-    elif name == 'ResNeXt-50-center':            # config 3: + center loss on the pooled features (loss.py:29-45)
+    elif name in ('ResNeXt-50-center', 'ResNeXt-26-center'):      # config 3: + center loss on the pooled features (loss.py:29-45)
         from .resnet import ResNeXt
-        network = ResNeXt(num_layers=50, num_card=32, data_format=data_format, weight_decay=weight_decay,
+        network = ResNeXt(num_layers=int(name.split('-')[1]), num_card=32, data_format=data_format, weight_decay=weight_decay,
                           head='softmax+center', center_weight=0.008)
     elif name == 'SENet-50':
         from .resnet import SENet
