@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--batches', type=int, default=8)
     ap.add_argument('--src', type=int, default=250)
     ap.add_argument('--device', default='cpu')
+    ap.add_argument('--workers', type=int, default=None, help='decode worker processes (default: data.train_inputs picks; 0 = threads)')
     args = ap.parse_args()
     from tf_face_toolbox_amd import data
     rng = np.random.default_rng(0)
@@ -37,7 +38,7 @@ def main():
             lines.append('%s %d' % (p, i % 100))
         lst = os.path.join(d, 'list.txt')
         open(lst, 'w').write('\n'.join(lines) + '\n')
-        inp = data.train_inputs(lst, 128, 128, 112, 112, is_color=1, batch_size=args.batch, device=args.device, seed=0)
+        inp = data.train_inputs(lst, 128, 128, 112, 112, is_color=1, batch_size=args.batch, device=args.device, seed=0, num_workers=args.workers)
         inp['images']()                                  # warm-up: thread pool, page cache
         t0 = time.time()
         for _ in range(args.batches):
@@ -47,9 +48,9 @@ def main():
             import torch
             torch.cuda.synchronize()
         el = time.time() - t0
-        print('loader: %.0f images/s (%d batches of %d, %dx%d JPEG -> 128x128 -> crop 112x112, %d worker threads, os.cpu_count=%d, device %s), batch %s %s'
+        print('loader: %.0f images/s (%d batches of %d, %dx%d JPEG -> 128x128 -> crop 112x112, workers %s, os.cpu_count=%d, device %s), batch %s %s'
               % (args.batches * args.batch / el, args.batches, args.batch, args.src, args.src,
-                 max(1, os.cpu_count() // 2), os.cpu_count(), args.device, tuple(x.shape), x.dtype))
+                 'auto' if args.workers is None else args.workers, os.cpu_count(), args.device, tuple(x.shape), x.dtype))
 
 
 if __name__ == '__main__':

@@ -84,7 +84,8 @@ def test_batches_from_the_list_file_match_per_image_processing():
         os.remove(lst)
 
 
-def test_worker_processes_give_the_same_batches_as_threads():
+@pytest.mark.parametrize('workers,group', [(3, 16), (5, 2)])
+def test_worker_processes_give_the_same_batches_as_threads(workers, group, monkeypatch):
     """The decode worker PROCESSES (shared /dev/shm batch buffer) and the in-process thread pool produce identical batches
     for the same seed; a corrupt file surfaces as an error in the consumer, and the buffers are removed at close."""
     lst = os.path.join(IMG, 'list_abs2.txt')
@@ -93,8 +94,9 @@ def test_worker_processes_give_the_same_batches_as_threads():
             f.write('%s %d\n' % (os.path.join(IMG, n), i % 4))
     try:
         a = data.train_inputs(lst, 120, 116, 112, 112, is_color=1, batch_size=8, device='cpu', seed=11, num_workers=0)
-        b = data.train_inputs(lst, 120, 116, 112, 112, is_color=1, batch_size=8, device='cpu', seed=11, num_workers=3)
-        for _ in range(3):
+        monkeypatch.setattr(data._WorkerPool, 'GROUP', group)            # (5, 2): two groups decoding different batches concurrently
+        b = data.train_inputs(lst, 120, 116, 112, 112, is_color=1, batch_size=8, device='cpu', seed=11, num_workers=workers)
+        for _ in range(5):
             xa, xb = a['images'](), b['images']()
             assert np.array_equal(xa.numpy(), xb.numpy()) and np.array_equal(a['labels']().numpy(), b['labels']().numpy())
         assert not isinstance(xb.numpy(), np.memmap) or True

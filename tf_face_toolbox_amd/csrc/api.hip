@@ -89,7 +89,7 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     long tail_rows = 0;
     if (T >= SLOTS) {
         const long full = T / SLOTS * SLOTS;
-        if (big == TILE_64x64 || T - full == 0 || T - full >= SLOTS * 4 / 5) {        // smallest tile, or (nearly) whole rounds
+        if ((bm == 64 && bn == 64) || T - full == 0 || T - full >= SLOTS * 4 / 5) {        // smallest tile, or (nearly) whole rounds
             r.main_rows = M; r.main_mtiles = MT;
             return r;
         }
@@ -481,15 +481,22 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
 
 // ------------------------------------------------------------------------------------------------
 namespace {
+inline bool wgrad_split_major() {
+    static const bool on = getenv("FTE_WGRAD_SPLIT_MAJOR") && atoi(getenv("FTE_WGRAD_SPLIT_MAJOR")) != 0;
+    return on;
+}
 void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, int* tile, int* splits, int* kchunk, int* K) {
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     *K = n * ph.out * pw.out;
     const long M = (long)ksize * ksize * cin;
     static const int wg_tile = getenv("FTE_WGRAD_TILE") ? atoi(getenv("FTE_WGRAD_TILE")) : -1;      // tuning hook
-    *tile = wg_tile >= 0 ? wg_tile : ((cout % 128 == 0) ? TILE_128x128 : TILE_128x64);
+    // N = 64 layers: M = 9 * 64 = 576 is 4.5 tiles of 128 rows (a tenth of the MFMAs multiply zero padding: the stage-1
+    // filter gradient ran at 68 % of peak with its MFMA pipe 76 % busy) but exactly 3 tiles of 192
+    const int narrow = (M % 192 == 0 && M % 128 != 0) ? TILE_192x64 : TILE_128x64;
+    *tile = wg_tile >= 0 ? wg_tile : ((cout % 128 == 0) ? TILE_128x128 : narrow);
     // prefer8 / split-major placement (one pixel range per XCD) cut wgrad's HBM traffic ~9x on MI355X but the
-    // kernel is MFMA-bound: 18.4 -> 18.9 ms per step.  Left off.
-    plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk, false);
+    // kernel is MFMA-bound: 18.4 -> 18.9 ms per step.  Left off (FTE_WGRAD_SPLIT_MAJOR=1 turns it on: tuning hook).
+    plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk, wgrad_split_major());
 }
 }  // namespace
 
@@ -523,7 +530,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
     p.c_ld = cout;
     p.slab = (long)p.M * p.N;
     p.Y = splits > 1 ? (float*)ws : dw;
-    p.split_major = 0;
+    p.split_major = (wgrad_split_major() && splits > 1) ? splits : 0;
     p.src16 = src16 ? 1 : 0;
     if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)K * cout, src16 ? 2 : 4)) return FTE_EINVAL;
     hipError_t e = igemm_launch(p, AL_KM, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);

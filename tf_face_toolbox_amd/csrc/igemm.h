@@ -5,7 +5,8 @@
 enum { AL_MK = 0, AL_KM = 1 };           // A operand: k-contiguous rows (im2col) | m-contiguous (k = pixel)
 enum { BL_KN = 0, BL_NK = 1 };           // B operand: [k][n] n-contiguous | [n][k] k-contiguous (per tap)
 enum { EPI_FWD = 0, EPI_DGRAD = 1 };
-enum { TILE_128x128 = 0, TILE_256x64 = 1, TILE_128x64 = 2, TILE_64x64 = 3 };
+enum { TILE_128x128 = 0, TILE_256x64 = 1, TILE_128x64 = 2, TILE_64x64 = 3, TILE_192x64 = 4,      // 192x64: M = 576 = 9 taps x 64 channels in three whole tiles
+       TILE_64x64_W1 = 5, TILE_64x64_W2 = 6 };  // 64x64 tile computed by ONE wave (64 threads, no barrier) / by two waves (128 threads)
 
 struct IgemmParams {
     int M, N, K;          // K = NT*KC (tap modes) or number of pixels (AL_KM)

@@ -37,13 +37,7 @@
 
 #include "igemm.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#include "igemm_dev.h"
 
 // LDS staging: 1 = ONE stage (32 KiB for the 128x128 tile) with a second barrier in the middle of the K-step,
 // 3 blocks per CU; 0 = two stages (64 KiB), one barrier per K-step, 2 blocks per CU.  Measured on MI355X at batch
@@ -55,49 +49,21 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 32;
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 2; }
-
-__device__ __forceinline__ unsigned pkbf(float a, float b) {      // two floats -> packed bf16 pair, round to nearest even
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ unsigned short tobf(float a) {
-    return __builtin_bit_cast(unsigned short, (__bf16)a);
-}
-
-// a / d for 0 <= a < 2^24 and d > 0 with rd = 1.f / d: float multiply, truncate, one-step fix-up (the compiler's exact
-// 32-bit division is ~35 VALU instructions; the wgrad loaders decompose a pixel index on EVERY K-step)
-__device__ __forceinline__ int fdiv(int a, int d, float rd) {
-    int q = (int)((float)a * rd);
-    const int r = a - q * d;
-    q += (r >= d) ? 1 : 0;
-    q -= (r < 0) ? 1 : 0;
-    return q;
-}
-
-__device__ __forceinline__ float prelu_slope(float z, float a) {
-    // d/dz [relu(z) + a*(z-|z|)/2]; TF's grad of relu(0) and sign(0) are 0 -> a/2 at exactly 0.
-    return z > 0.f ? 1.f : (z == 0.f ? 0.5f * a : a);
-}
+using namespace igemm_dev;
 
 // BF = 1: the same gathers, epilogues and fp32 accumulators, but the operand tiles are rounded to bf16 (RNE) on their way
 // into LDS and multiplied by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): storage stays fp32 in HBM, the kernel
 // turns from MFMA-bound into staging / HBM-bound.  See the BF branch of the main loop.
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF = 0>
-__global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && BM <= 192) ? 3 : 2)) void igemm_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
-    constexpr int A_CH = BM / 32;                 // 16-byte chunks each thread stages for A per K-step
-    constexpr int B_CH = BN / 32;
+    // NTH threads = WM x WN waves.  4 waves is the general case; 1 or 2 waves per block (fp32, k-contiguous A only) trade
+    // operand reuse across waves for fewer waves coupled by each barrier: with ONE wave per block there is no barrier at all
+    // (hipcc drops s_barrier for a workgroup of one wavefront) and the wave's LDS image is private.
+    constexpr int NTH = 64 * WM * WN, RP = NTH / 8;   // RP: rows of a k-contiguous operand staged per pass
+    static_assert((NTH == 256 || (BF == 0 && AL == AL_MK)) && TM >= 1 && TN >= 1, "1 / 2-wave blocks: fp32 forward / dgrad only");
+    constexpr int A_CH = BM * 8 / NTH;            // 16-byte chunks each thread stages for A per K-step
+    constexpr int B_CH = BN * 8 / NTH;
     constexpr int STAGE = (BM + BN) * BK;         // floats per LDS stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -163,7 +129,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     if constexpr (AL == AL_MK) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            const int m = m0 + (tid >> 3) + 32 * i;
+            const int m = m0 + (tid >> 3) + RP * i;
             int base = 0, mask = 0;
             if (m < p.M) {
                 const int n = fdiv(m, a_hw, r_ahw), rem = m - n * a_hw;
@@ -193,7 +159,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     // B: per-thread constant part of the byte offset
     unsigned b_base[B_CH];
     if constexpr (BL == BL_KN) {
-        constexpr int CPR = BN / 4, RPP = 256 / CPR;
+        constexpr int CPR = BN / 4, RPP = NTH / CPR;
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) {
             if constexpr (BF)      // entry 2j + e: row 2*(tid>>4) + e, n-chunk (tid&15) + 16j
@@ -204,7 +170,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
     } else {
 #pragma unroll
         for (int i = 0; i < B_CH; ++i)
-            b_base[i] = (unsigned)((n0 + (tid >> 3) + 32 * i) * p.b_ld + ((tid & 7) << 2)) * 4u;
+            b_base[i] = (unsigned)((n0 + (tid >> 3) + RP * i) * p.b_ld + ((tid & 7) << 2)) * 4u;
     }
 
     // Reduction order for tap-structured operands: K-step sigma = k0/32 covers channel chunk
@@ -268,7 +234,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         }
         // ---------------- B ----------------
         if constexpr (BL == BL_KN) {
-            constexpr int CPR = BN / 4, RPP = 256 / CPR;
+            constexpr int CPR = BN / 4, RPP = NTH / CPR;
             const unsigned koff = (unsigned)((AL == AL_MK ? tap * p.a_KC + kc0 : k0) * p.b_ld) * 4u;   // wave-uniform
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
@@ -290,7 +256,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         if constexpr (AL == AL_MK) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                const int r = (tid >> 3) + 32 * i;
+                const int r = (tid >> 3) + RP * i;
                 *reinterpret_cast<f32x4*>(As + r * BK + swz(r, tid & 7)) = ra[i];
             }
         } else {
@@ -299,14 +265,14 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 *reinterpret_cast<f32x4*>(As + (tid >> 3) * BM + (((tid & 7) + 8 * i) << 2)) = ra[i];
         }
         if constexpr (BL == BL_KN) {
-            constexpr int CPR = BN / 4, RPP = 256 / CPR;
+            constexpr int CPR = BN / 4, RPP = NTH / CPR;
 #pragma unroll
             for (int i = 0; i < B_CH; ++i)
                 *reinterpret_cast<f32x4*>(Bs + (tid / CPR + RPP * i) * BN + ((tid % CPR) << 2)) = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
-                const int r = (tid >> 3) + 32 * i;
+                const int r = (tid >> 3) + RP * i;
                 *reinterpret_cast<f32x4*>(Bs + r * BK + swz(r, tid & 7)) = rb[i];
             }
         }
@@ -671,7 +637,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 } else {
                     constexpr int j = i - A_CH;
                     if constexpr (BL == BL_KN) {
-                        constexpr int CPR = BN / 4, RPP = 256 / CPR;
+                        constexpr int CPR = BN / 4, RPP = NTH / CPR;
                         rb[j] = ldg(rsrcB, (k0 + tid / CPR + RPP * j < kend) ? b_base[j] : OOB, b_soff);
                     } else {
                         rb[j] = ldg(rsrcB, k0 < kend ? b_base[j] : OOB, b_soff);
@@ -682,7 +648,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < A_CH) {
                     if constexpr (AL == AL_MK) {
-                        const int r = (tid >> 3) + 32 * i;
+                        const int r = (tid >> 3) + RP * i;
                         *reinterpret_cast<f32x4*>(Asn + r * BK + swz(r, tid & 7)) = ra[i];
                     } else {
                         *reinterpret_cast<f32x4*>(Asn + (tid >> 3) * BM + (((tid & 7) + 8 * i) << 2)) = ra[i];
@@ -690,10 +656,10 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
                 } else {
                     constexpr int j = i - A_CH;
                     if constexpr (BL == BL_KN) {
-                        constexpr int CPR = BN / 4, RPP = 256 / CPR;
+                        constexpr int CPR = BN / 4, RPP = NTH / CPR;
                         *reinterpret_cast<f32x4*>(Bsn + (tid / CPR + RPP * j) * BN + ((tid % CPR) << 2)) = rb[j];
                     } else {
-                        const int r = (tid >> 3) + 32 * j;
+                        const int r = (tid >> 3) + RP * j;
                         *reinterpret_cast<f32x4*>(Bsn + r * BK + swz(r, tid & 7)) = rb[j];
                     }
                 }
@@ -723,165 +689,7 @@ __global__ __launch_bounds__(256, (FTE_SINGLE && BM <= 128) ? 3 : 2) void igemm_
         }
     }
 
-    // ---- split-K partial tile: raw accumulators to the workspace, epilogue happens in igemm_fixup ----
-    if (p.PW) {
-        float* W = p.PW + ((long)split * gridDim.x + bid) * (BM * BN);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int cl = wn * (TN * 32) + j * 32 + li;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    W[rl * BN + cl] = acc[i][j][r];
-                }
-        }
-        return;
-    }
-
-    // ---- epilogue -----------------------------------------------------------------
-    int* rowoff = reinterpret_cast<int*>(smem);
-    for (int r = tid; r < BM; r += 256) {
-        const int m = m0 + r;
-        int off = -1;
-        if (m < p.M) {
-            if (p.c_OH == 0) {
-                off = m * p.c_ld;
-            } else {
-                const int hw = p.c_OH * p.c_OW;
-                const int n = fdiv(m, hw, 1.f / (float)hw), rem = m - n * hw;
-                const int oh = fdiv(rem, p.c_OW, 1.f / (float)p.c_OW), ow = rem - oh * p.c_OW;
-                off = ((n * p.c_FH + oh * p.c_step + c_ph) * p.c_FW + ow * p.c_step + c_pw) * p.c_ld;
-            }
-        }
-        rowoff[r] = off;
-    }
-    __syncthreads();
-
-    {
-        // ---- LDS-staged epilogue, 16 bytes per lane --------------------------------------------------------------
-        // The accumulator layout (lane = column) gives 4-byte global accesses, 256 B per wave instruction -- a quarter
-        // of what the texture-address path moves per clock.  Each wave transposes its 32x32 blocks through a private
-        // 32 x 36 float LDS patch and then touches global memory as 8 rows x 128 B per instruction.  With bf16 MFMAs the
-        // epilogue is no longer hidden under other blocks' matrix work (56x56x64 layer 0.87 -> 0.65 ms); the fp32
-        // kernels gain 1-3 %.
-        float* patch = smem + BM + wid * (32 * 36);              // after the BM row offsets
-        const int prw = lane >> 3, pc4 = lane & 7;
-        f32x4 sa4[TN], sb4[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) { sa4[j] = f32x4{0.f, 0.f, 0.f, 0.f}; sb4[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        float* Y = nullptr;
-        if constexpr (EPI == EPI_FWD) Y = p.Y + (long)split * p.slab;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (TN * 32) + j * 32 + 4 * pc4;
-            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f};
-            bool act = false;
-            if constexpr (EPI == EPI_FWD) {
-                if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-                act = p.alpha != nullptr;
-                if (act) al4 = *reinterpret_cast<const f32x4*>(p.alpha + col);
-            } else {
-                act = p.Zin != nullptr;
-                if (act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) al4[e] = p.alpha[(col + e) % p.amod];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                // the global inputs of the four passes (shortcut / skip gradient / z) are fetched BEFORE the transpose: one
-                // memory round trip per 32x32 block instead of one per pass
-                int offs[4];
-                f32x4 in0[4], in1[4];
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    offs[ps] = rowoff[wm * (TM * 32) + i * 32 + prw + 8 * ps];
-                    const long o = (long)(offs[ps] < 0 ? 0 : offs[ps]) + col;
-                    in0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    in1[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if constexpr (EPI == EPI_FWD) {
-                        if (p.R && offs[ps] >= 0) in0[ps] = *reinterpret_cast<const f32x4*>(p.R + o);
-                    } else {
-                        if (p.ADD && offs[ps] >= 0) in0[ps] = *reinterpret_cast<const f32x4*>(p.ADD + o);
-                        if (act && offs[ps] >= 0) in1[ps] = *reinterpret_cast<const f32x4*>(p.Zin + o);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    const int rr = prw + 8 * ps;
-                    const int off = offs[ps];
-                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + rr * 36 + 4 * pc4);
-                    if (off < 0) continue;
-                    const long o = (long)off + col;
-                    if constexpr (EPI == EPI_FWD) {
-                        v += bias4;
-                        if (p.Z) *reinterpret_cast<f32x4*>(p.Z + o) = v;
-                        if (act) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : al4[e] * v[e];
-                        }
-                        v += in0[ps];
-                        *reinterpret_cast<f32x4*>(Y + o) = v;
-                        if (p.Y16) *reinterpret_cast<u32x2*>(p.Y16 + o) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
-                    } else {
-                        v += in0[ps];
-                        if (p.RAW) *reinterpret_cast<f32x4*>(p.RAW + o) = v;
-                        if (act) {
-                            const f32x4 z = in1[ps];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                sa4[j][e] += v[e] * fminf(z[e], 0.f);
-                                v[e] *= prelu_slope(z[e], al4[e]);
-                                sb4[j][e] += v[e];
-                            }
-                        }
-                        *reinterpret_cast<f32x4*>(p.DZ + o) = v;
-                        if (p.DZ16) *reinterpret_cast<u32x2*>(p.DZ16 + o) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
-                    }
-                }
-            }
-        }
-        if constexpr (EPI == EPI_DGRAD) {
-            if (p.PA) {    // per-block column partials (dalpha, dbias), reduced later in a fixed order
-                __syncthreads();
-                float* red = smem + BM + 4 * (32 * 36);              // [2][WM][BN], past the patches
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float a = sa4[j][e], b = sb4[j][e];
-                        a += __shfl_xor(a, 8); b += __shfl_xor(b, 8);
-                        a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
-                        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
-                        if (prw == 0) {
-                            const int c = wn * (TN * 32) + j * 32 + 4 * pc4 + e;
-                            red[wm * BN + c] = a;
-                            red[(WM + wm) * BN + c] = b;
-                        }
-                    }
-                }
-                __syncthreads();
-                for (int c = tid; c < BN; c += 256) {
-                    float a = 0.f, b = 0.f;
-#pragma unroll
-                    for (int w = 0; w < WM; ++w) {
-                        a += red[w * BN + c];
-                        b += red[(WM + w) * BN + c];
-                    }
-                    const long o = (long)(prow + mt) * p.N + n0 + c;
-                    p.PA[o] = a;
-                    if (p.PB) p.PB[o] = b;
-                }
-            }
-        }
-    }
+    igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow);
 }
 
 // ---- fix-up: sum the split-K partial tiles of one output tile and apply the fused epilogue -------------
@@ -1012,6 +820,7 @@ hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st
         case TILE_128x128: hipLaunchKernelGGL((igemm_fixup_kernel<128, 128, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
         case TILE_256x64:  hipLaunchKernelGGL((igemm_fixup_kernel<256, 64, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
         case TILE_128x64:  hipLaunchKernelGGL((igemm_fixup_kernel<128, 64, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
+        case TILE_192x64:  hipLaunchKernelGGL((igemm_fixup_kernel<192, 64, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
         default:           hipLaunchKernelGGL((igemm_fixup_kernel<64, 64, EPI>), dim3(tiles), dim3(256), 0, st, p, splits); break;
     }
     return hipGetLastError();
@@ -1023,7 +832,7 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     // fp32: one stage of (BM+BN) x 32 floats; bf16: KS sub-step images of (BM+BN) x 64 bytes (one macro step); both hold
     // at least the BM ints of the epilogue's row-offset table
     constexpr int KSL = (BM + BN) <= 128 ? 4 : 2;               // sub-step images: KS = 4 x 1 stage, or KS = 1 x 2 stages
-    const size_t epi = (size_t)(BM + 4 * 32 * 36 + 2 * WM * BN) * sizeof(float);      // row offsets + 4 transpose patches + column partials
+    const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);      // row offsets + one transpose patch per wave + column partials
     const size_t loop = (size_t)KSL * (BM + BN) * 64;
     const size_t loop32 = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * BK * sizeof(float);
     const size_t loop16 = 2 * (size_t)(BM + BN) * 64;
@@ -1041,9 +850,9 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     if (p.ncls > 1) {                       // merged parity classes: every class has the same M x N tile grid
         IgemmParams q = p;
         q.cls_tiles = mt * nt; q.cls_mtiles = mt;
-        hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(256), lds_x, st, q);
-    } else if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(256), lds_x, st, p);
-    else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(256), lds_x, st, p);
+        hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(64 * WM * WN), lds_x, st, q);
+    } else if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(64 * WM * WN), lds_x, st, p);
+    else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(64 * WM * WN), lds_x, st, p);
     return hipGetLastError();
 }
 
@@ -1051,10 +860,14 @@ bool g_bf16 = false;      // igemm_set_bf16(): operand precision of every launch
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
 hipError_t launch_cfg(const IgemmParams& p, int splits, hipStream_t st) {
     if (p.src16) {                           // bf16 sources: forward / dgrad take NK weight packs, wgrad KM x KN
-        if constexpr (!(AL == AL_MK && BL == BL_KN)) return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 2>(p, splits, st);
+        if constexpr (!(AL == AL_MK && BL == BL_KN) && WM * WN == 4) return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 2>(p, splits, st);
         else return hipErrorInvalidValue;
     }
-    if (g_bf16) return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 1>(p, splits, st);
+    if constexpr (WM * WN == 4) {
+        if (g_bf16) return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 1>(p, splits, st);
+    } else {
+        if (g_bf16) return hipErrorInvalidValue;                  // 1 / 2-wave blocks exist for the fp32 products only
+    }
     return launch_cfg_p<BM, BN, WM, WN, AL, BL, EPI, 0>(p, splits, st);
 }
 
@@ -1065,6 +878,16 @@ hipError_t launch_tile(const IgemmParams& p, int tile, int splits, hipStream_t s
         case TILE_256x64:  return launch_cfg<256, 64, 4, 1, AL, BL, EPI>(p, splits, st);
         case TILE_128x64:  return launch_cfg<128, 64, 2, 2, AL, BL, EPI>(p, splits, st);
         case TILE_64x64:   return launch_cfg<64, 64, 2, 2, AL, BL, EPI>(p, splits, st);
+        case TILE_64x64_W1:
+            if constexpr (AL == AL_MK) return launch_cfg<64, 64, 1, 1, AL, BL, EPI>(p, splits, st);
+            else return hipErrorInvalidValue;
+        case TILE_64x64_W2:
+            if constexpr (AL == AL_MK) return launch_cfg<64, 64, 2, 1, AL, BL, EPI>(p, splits, st);
+            else return hipErrorInvalidValue;
+        case TILE_192x64:
+            // only the filter-gradient / dense-tn symbol is instantiated at this shape (M = 9 x 64 rows)
+            if constexpr (AL == AL_KM) return launch_cfg<192, 64, 2, 2, AL, BL, EPI>(p, splits, st);
+            else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
@@ -1172,6 +995,7 @@ void igemm_tile_dims(int tile, int* bm, int* bn) {
         case TILE_128x128: *bm = 128; *bn = 128; break;
         case TILE_256x64:  *bm = 256; *bn = 64; break;
         case TILE_128x64:  *bm = 128; *bn = 64; break;
+        case TILE_192x64:  *bm = 192; *bn = 64; break;
         default:           *bm = 64;  *bn = 64; break;
     }
 }

@@ -138,6 +138,30 @@ class Singular(object):
             logits = m.forward(images, num_classes=num_classes, is_training=True)
         return m.loss_function(scope, labels, **logits)
 
+    class _Construction(object):
+        """The reference builds its graph here and runs NOTHING: variables get their initial values, the non-trainable
+        state (BatchNorm moving statistics -- UPDATE_OPS --, the center loss's scatter_sub on `centers`) only moves when
+        train_ops runs.  This engine is eager, so the construction-time forward / loss pass (it creates the variables and the
+        loss handles) runs with those side effects switched off."""
+
+        def __init__(self, model):
+            self.m = model
+
+        def __enter__(self):
+            m = self.m
+            self.prev = (getattr(m, 'update_moving_stats', None), getattr(m, 'update_centers', None))
+            if self.prev[0] is not None:
+                m.update_moving_stats = False
+            if self.prev[1] is not None:
+                m.update_centers = False
+
+        def __exit__(self, *exc):
+            m = self.m
+            if self.prev[0] is not None:
+                m.update_moving_stats = self.prev[0]
+            if self.prev[1] is not None:
+                m.update_centers = self.prev[1]
+
     def _setup(self, inputs):
         m = self.model
         self._validate_labels(inputs)
@@ -164,7 +188,8 @@ class Singular(object):
 
         # Build the variables and the loss handles now (graph construction time in the reference).
         images, labels = self._fetch(inputs)
-        losses, losses_name, others = self._forward_loss(images, labels, num_classes, 'TOWER')
+        with self._Construction(self.model):
+            losses, losses_name, others = self._forward_loss(images, labels, num_classes, 'TOWER')
         self.pretrained_param = self.model.pretrained_param()
         return train_ops, losses, losses_name, others
 
@@ -234,7 +259,8 @@ class DataParallel(Singular):
             self.global_step += 1                     # data_parallel.py:160-161
             return losses, others
 
-        losses, losses_name, others = tower()
+        with self._Construction(self.model):
+            losses, losses_name, others = tower()
         # train.py:101-120: every replica starts from replica 0's values
         self.comm.broadcast(self.model.params, src=0)
         self.pretrained_param = self.model.pretrained_param()

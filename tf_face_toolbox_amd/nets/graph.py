@@ -71,6 +71,7 @@ class GraphNet(Network):
         self._act_n = None
         self.center_weight = 0.0          # 'softmax+center': total loss = CE + center_weight * center_loss
         self.center_alpha = 0.99          # loss.py:29 default
+        self.update_centers = True        # False: the loss is evaluated without running centers_update_op (loss.py:39,43 returns it to the caller)
         self.triplet_margin = None        # 'triplet': None = soft-margin (softplus), loss.py:47
         self.focal_gamma, self.focal_alpha = 1.0, 2.0     # 'focal': loss.py:18 defaults (names as in the reference)
 
@@ -608,7 +609,8 @@ class GraphNet(Network):
             losses.append(slots[0]); names.append('focal_entropy' if self.head == 'focal' else 'cross_entropy')
             if self.head == 'softmax+center':
                 call('fte_center_loss_fwd_bwd_update', feat, labels, self._centers(), self.loss_rows, self.dfeat, n, d,
-                     self.center_alpha, self.center_weight * self.tower_scale / (n * d), self.ws, self.ws_bytes, st)
+                     self.center_alpha if self.update_centers else 1.0,      # alpha = 1: centers += 0 * diff
+                     self.center_weight * self.tower_scale / (n * d), self.ws, self.ws_bytes, st)
                 call('fte_sum', self.loss_rows, n, self.tower_scale / (n * d), slots[2:3], self.ws, self.ws_bytes, st)
                 self._dfeat = self.dfeat
                 losses.append(slots[2]); names.append('center_loss')
