@@ -126,11 +126,14 @@ def _bf16_bits(t):
 
 @pytest.mark.parametrize('n,h,w,cin,cout,k,stride', [(4, 14, 14, 64, 64, 3, 1), (3, 15, 9, 64, 128, 3, 2), (2, 28, 28, 128, 64, 3, 1),
                                                      (5, 8, 8, 256, 128, 1, 1), (64, 14, 14, 128, 128, 3, 2), (2, 7, 7, 512, 512, 3, 1),
-                                                     (512, 14, 14, 128, 128, 3, 1)])
-def test_bf16_source_entry_points_equal_the_operand_mode_bit_for_bit(bf16_mode, n, h, w, cin, cout, k, stride):
+                                                     (512, 14, 14, 128, 128, 3, 1), (32, 56, 56, 64, 64, 3, 1), (500, 14, 14, 256, 256, 3, 1),
+                                                     (130, 28, 28, 128, 128, 1, 1)])
+def test_bf16_source_entry_points_equal_the_operand_mode(bf16_mode, n, h, w, cin, cout, k, stride):
     """fte_conv2d_{fwd,dgrad,wgrad}16 read bf16 COPIES of the operands; the FTE_MFMA_BF16 mode rounds the fp32 operands
-    inside the kernel.  Same rounding, same K order, same tile plan -> identical bits.  The bf16 result copies (y16,
-    dzprev16) must be the RNE rounding of the fp32 results."""
+    inside the kernel.  Same rounded operands, fp32 accumulation: the results agree to fp32 summation order (the LDS-DMA
+    kernel of igemm16.hip walks K in 64-deep steps, the register-staged one in 32-deep steps; where both run the same
+    kernel the bits are identical, which 2e-6 still pins).  The bf16 result copies (y16, dzprev16) must be the RNE
+    rounding of the fp32 results, exactly."""
     g = torch.Generator(device='cuda').manual_seed(n + cin + cout + k)
     x = torch.randn(n, h, w, cin, device='cuda', generator=g); wt = torch.randn(k, k, cin, cout, device='cuda', generator=g) * 0.1
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
@@ -159,20 +162,25 @@ def test_bf16_source_entry_points_equal_the_operand_mode_bit_for_bit(bf16_mode, 
     assert torch.equal(w16t, _bf16_bits(wt).permute(0, 1, 3, 2).contiguous())
     z1 = torch.empty_like(res); y1 = torch.empty_like(res); y16 = torch.empty(res.shape, dtype=torch.int16, device='cuda')
     _lib.call('fte_conv2d_fwd16', x16, w16t, bias, alpha, res, z1, y1, y16, n, h, w, cin, cout, k, stride, buf, nb, st)
-    assert torch.equal(z1, z0) and torch.equal(y1, y0) and torch.equal(y16, _bf16_bits(y1))
+    _close(z1, z0, 'z'); _close(y1, y0, 'y')
+    assert torch.equal(y16, _bf16_bits(y1))
     raw1 = torch.empty_like(x); dx1 = torch.empty_like(x); dx16 = torch.empty(x.shape, dtype=torch.int16, device='cuda')
     da1 = torch.empty(cin, device='cuda'); db1 = torch.empty(cin, device='cuda')
     _lib.call('fte_conv2d_dgrad16', dz16, w16, add, zp, alp, raw1, dx1, dx16, da1, db1, n, h, w, cin, cout, k, stride, buf, nb, st)
-    assert torch.equal(raw1, raw0) and torch.equal(dx1, dx0) and torch.equal(da1, da0) and torch.equal(db1, db0)
+    _close(raw1, raw0, 'raw'); _close(dx1, dx0, 'dx'); _close(da1, da0, 'dalpha', 2e-5); _close(db1, db0, 'dbias', 2e-5)
     assert torch.equal(dx16, _bf16_bits(dx1))
     dw1 = torch.empty_like(wt)
     _lib.call('fte_conv2d_wgrad16', x16, dz16, dw1, n, h, w, cin, cout, k, stride, buf, nb, st)
     assert torch.equal(dw1, dw0)
 
 
-def test_spherenet_step_with_bf16_copies_equals_operand_mode_bit_for_bit(bf16_mode):
+def _close(a, b, what, tol=2e-6):
+    check_rell2(host(a), host(b), tol, what + ': bf16-copy entry point vs operand mode')
+
+
+def test_spherenet_step_with_bf16_copies_equals_operand_mode(bf16_mode):
     """SphereNet routes its convolutions through the bf16-copy entry points in the bf16 mode (y16 / dz16 written by the
-    producing epilogues, weights packed per step).  Same arithmetic -> every gradient bit-identical to the operand mode."""
+    producing epilogues, weights packed per step).  Same arithmetic -> every gradient equal to the operand mode up to fp32 summation order."""
     from tf_face_toolbox_amd import net_select
     n, h, w, ncls = 6, 64, 64, 30
     g = torch.Generator().manual_seed(3)
@@ -191,5 +199,5 @@ def test_spherenet_step_with_bf16_copies_equals_operand_mode_bit_for_bit(bf16_mo
         outs.append(([float(v) for v in losses], net.grads.clone(), net.emb.clone()))
         e_eval = net.forward(x, is_training=False).clone()          # flip-averaged eval path through the same kernels
         outs[-1] += (e_eval,)
-    assert outs[0][0] == outs[1][0]
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+    _close(outs[1][1], outs[0][1], 'gradient arena', 1e-4); _close(outs[1][2], outs[0][2], 'embedding', 2e-5); _close(outs[1][3], outs[0][3], 'eval embedding', 2e-5)

@@ -61,6 +61,11 @@ constexpr int FIXUP_CHUNKS = 4;
 hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st);
 void igemm_tile_dims(int tile, int* bm, int* bn);
 
+// igemm16.hip: the bf16 LDS-DMA kernel (k-contiguous bf16 A and B: conv forward / dgrad on the bf16 operand copies).  igemm_launch
+// routes a launch there when igemm16_handles() says so; everything else runs on igemm.hip's kernels.
+bool igemm16_handles(const IgemmParams& p, int al, int bl, int tile);
+hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st);
+
 // operand precision of the MFMA products: false = fp32 (v_mfma_f32_32x32x2_f32, exact), true = operands rounded to bf16
 // inside the kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate); storage in HBM is fp32 either way
 void igemm_set_bf16(bool on);

@@ -31,6 +31,7 @@
 // pass) and multiplied by v_mfma_f32_32x32x16_bf16.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 #include <vector>
@@ -907,6 +908,8 @@ void prof_clear() {
     g_prof.clear();
 }
 hipError_t dispatch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st) {
+    static const bool no16 = getenv("FTE_NO_IGEMM16") != nullptr;      // A/B hook: keep the register-staged BF = 2 kernels
+    if (!no16 && igemm16_handles(p, al, bl, tile)) return igemm16_launch(p, epi, tile, splits, st);
     if (al == AL_MK && bl == BL_KN && epi == EPI_FWD) return launch_tile<AL_MK, BL_KN, EPI_FWD>(p, tile, splits, st);
     if (al == AL_MK && bl == BL_NK && epi == EPI_DGRAD) return launch_tile<AL_MK, BL_NK, EPI_DGRAD>(p, tile, splits, st);
     if (al == AL_MK && bl == BL_NK && epi == EPI_FWD) return launch_tile<AL_MK, BL_NK, EPI_FWD>(p, tile, splits, st);

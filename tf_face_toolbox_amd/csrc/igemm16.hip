@@ -1,0 +1,305 @@
+// igemm16.hip -- bf16 gathered-GEMM kernel with LDS-DMA operand staging for gfx950 (MI355X).
+//
+//   C[M,N] = sum_k A(m,k) * B(n,k),  A and B bf16 with k CONTIGUOUS, fp32 accumulate on v_mfma_f32_32x32x16_bf16:
+//   conv forward : A = im2col rows of the bf16 activation copy (NHWC: k = channels of one tap), B = weights packed
+//                  [tap][cout][cin]  (fte_pack_weights_bf16's transposed pack)
+//   conv dgrad   : A = im2col rows of the bf16 dz copy, B = weights [tap][cin][cout] (the HWIO layout itself)
+// i.e. the AL_MK x BL_NK cases of the igemm family with bf16 SOURCES (fte_conv2d_fwd16 / _dgrad16); filter gradients
+// (both operands pixel-major: transposed reads) stay on igemm.hip's BF = 2 kernel.
+//
+// Why a second kernel: at the bf16 MFMA rate a 32-deep K-step is 2 MFMAs per accumulator block -- the register-staged loop of
+// igemm.hip (global -> VGPR -> ds_write -> barrier per K-step) runs its load, LDS-write, MFMA and epilogue phases back to back
+// ("a plain SUM").  Here, as the CDNA4 GEMM playbook prescribes for an MFMA-dense loop at ~1 block per CU:
+//   * operands go global -> LDS directly (`buffer_load_dwordx4 ... offen lds`: no staging VGPRs, no ds_write pass);
+//     out-of-image taps / rows beyond M use an offset beyond num_records, for which the DMA writes ZEROS (probe:
+//     scripts/probes/lds_dma_oob.hip) -- padding costs nothing and needs no branch;
+//   * BK = 64 bf16 = 128-byte operand rows; a ring of NST stages, NST - 1 K-steps in flight; ONE raw s_barrier per K-step
+//     and a COUNTED s_waitcnt vmcnt (never 0 in the steady state), so the loads of the next stages stay in flight across
+//     the barrier;
+//   * the LDS image is lane-linear per DMA instruction (8 rows x 128 B per wave instruction), so the bank-conflict swizzle
+//     is applied to the SOURCE address (which 16-byte k-chunk a lane fetches) and again on the fragment read:
+//     chunk c of row r lives in slot c ^ ((r >> 1) & 7) -- conflict-free ds_read_b128 for the 32x32x16 operand map.
+// The epilogue (bias / PReLU / residual, or the PReLU-gradient epilogue with column partials, LDS-transposed 16-byte stores,
+// bf16 result copies) is igemm_dev.h's, shared with igemm.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "igemm_dev.h"
+
+namespace {
+
+using namespace igemm_dev;
+
+constexpr int BK16 = 64;                 // bf16 elements per K-step
+constexpr int ROWB = BK16 * 2;           // bytes per operand row in LDS
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// one LDS-DMA instruction: 16 bytes per lane from the buffer (offset voff + soff; beyond num_records -> zeros) to
+// lds + 16 * lane.  (A named __device__ function: hipcc's host pass drops the enclosing kernel's stub when the builtin sits
+// directly inside a lambda of the kernel.)
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
+}
+
+template <class T>
+__device__ __forceinline__ void keep_alive(const T& v) {      // ablation builds: the value stays computed without being used
+    asm volatile("" ::"v"(v));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ABL (diagnostic builds only, FTE_IGEMM16_ABL): 0 = the kernel; 1 = no MFMAs, 2 = no DMA (stale LDS), 3 = no epilogue
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const IgemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && NST >= 2, "4 or 8 waves");
+    constexpr int NW = WM * WN, RP = 8 * NW;          // a pass of the block's DMA instructions covers RP rows x 128 B
+    constexpr int A_P = BM / RP, B_P = BN / RP;       // DMA instructions per thread and stage
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile rows per DMA pass");
+    constexpr int L = A_P + B_P;
+    constexpr int STAGE = (BM + BN) * ROWB;           // bytes per ring stage
+    static_assert((NST - 2) * L <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- tile coordinates (as igemm_kernel: XCD-aware bijective remap, n-tiles fastest, merged stride-2 dgrad classes) ----
+    const int ntn = p.N / BN;
+    int bid = blockIdx.x;
+    const int split = blockIdx.y;
+    {
+        const int ntiles = gridDim.x;
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int tap0 = 0, NT = p.a_NT, Kc = p.K, c_ph = p.c_ph, c_pw = p.c_pw, prow = p.prow0;
+    if constexpr (EPI == EPI_DGRAD) {
+        if (p.ncls > 1) {
+            const int cls = bid % p.ncls;
+            bid /= p.ncls;
+            tap0 = p.cls_tap0[cls];
+            NT = p.cls_tap0[cls + 1] - tap0;
+            Kc = NT * p.a_KC;
+            c_ph = p.cls_ph[cls]; c_pw = p.cls_pw[cls];
+            prow += cls * p.cls_mtiles;
+        }
+    }
+    const int mt = bid / ntn, nt_ = bid - mt * ntn;
+    const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(Kc, kbeg + p.kchunk);
+    const int nk = (kend - kbeg) / BK16;                   // the launcher guarantees whole 64-deep steps
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    // ---- per-thread loader state: row (tid >> 3) + 32 i of the tile, LDS slot tid & 7 = source chunk slot ^ ((row >> 1) & 7) ----
+    const int a_hw = p.a_OH * p.a_OW;
+    const float r_ahw = 1.f / (float)a_hw, r_aow = 1.f / (float)p.a_OW;
+    unsigned a_base[A_P];
+    int a_mask[A_P];
+#pragma unroll
+    for (int i = 0; i < A_P; ++i) {
+        const int r = (tid >> 3) + RP * i;
+        const int m = m0 + r;
+        int base = 0, mask = 0;
+        if (m < p.M) {
+            const int n = fdiv(m, a_hw, r_ahw), rem = m - n * a_hw;
+            const int oh = fdiv(rem, p.a_OW, r_aow), ow = rem - oh * p.a_OW;
+            const int ih0 = oh * p.a_stride, iw0 = ow * p.a_stride;
+            base = ((n * p.a_IH + ih0) * p.a_IW + iw0) * p.a_ld;
+            for (int t = 0; t < NT; ++t) {
+                const int ih = ih0 + p.a_dh[tap0 + t], iw = iw0 + p.a_dw[tap0 + t];
+                if (ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW) mask |= 1 << t;
+            }
+        }
+        const int chunk = (tid & 7) ^ ((r >> 1) & 7);
+        a_base[i] = (unsigned)(base + (chunk << 3)) * 2u;
+        a_mask[i] = mask;
+    }
+    unsigned b_base[B_P];
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+        const int r = (tid >> 3) + RP * i;
+        const int chunk = (tid & 7) ^ ((r >> 1) & 7);
+        b_base[i] = (unsigned)((n0 + r) * p.b_ld + (chunk << 3)) * 2u;
+    }
+
+    // K-step sigma covers channel chunk sigma / NT of tap sigma % NT (chunk outer, tap inner: the taps of one 64-channel
+    // chunk re-read nearly the same 128-byte row pieces -- L1 / L2 hits); kept incrementally for the step being ISSUED
+    int itap = (kbeg / BK16) % NT, ikc = ((kbeg / BK16) / NT) * BK16;
+    auto issue = [&](int stage) {
+        char* As = smem16 + stage * STAGE + wid * 1024;
+        char* Bs = As + BM * ROWB;
+        const unsigned toff = (unsigned)((p.a_dh[tap0 + itap] * p.a_IW + p.a_dw[tap0 + itap]) * p.a_ld + ikc) * 2u;    // wave-uniform
+        const unsigned boff = (unsigned)(p.b_tapoff[tap0 + itap] + ikc) * 2u;
+#pragma unroll
+        for (int i = 0; i < A_P; ++i)
+            if constexpr (ABL != 2) dma16(rsrcA, As + i * (RP * ROWB), ((a_mask[i] >> itap) & 1) ? a_base[i] + toff : OOB, 0);
+#pragma unroll
+        for (int i = 0; i < B_P; ++i)
+            if constexpr (ABL != 2) dma16(rsrcB, Bs + i * (RP * ROWB), b_base[i], boff);
+        if (++itap == NT) { itap = 0; ikc += BK16; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: lane -> (row li of its 32-row block, k-half lh); chunk q = 2 ks + lh of the row sits in slot q ^ ((row >> 1) & 7)
+    int a_row[TM], b_row[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_row[i] = wm * (TM * 32) + i * 32 + li;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_row[j] = wn * (TN * 32) + j * 32 + li;
+
+    // One K-step: the 4 k16 sub-steps of the tile in `stage`, each = fragment reads + a quarter of the NEXT ring tile's DMA
+    // instructions (into `fill`; an LDS-DMA piece costs the issuing wave ~100-150 cycles, so they are spread between the
+    // MFMA groups instead of being issued in one burst ahead of them) + TM x TN MFMAs.
+    auto kstep = [&](int stage, int fill, bool fillnext) {
+        const char* As = smem16 + stage * STAGE;
+        const char* Bs = As + BM * ROWB;
+        char* Ad = smem16 + fill * STAGE + wid * 1024;
+        char* Bd = Ad + BM * ROWB;
+        unsigned toff = 0, boff = 0;
+        if (fillnext) {
+            toff = (unsigned)((p.a_dh[tap0 + itap] * p.a_IW + p.a_dw[tap0 + itap]) * p.a_ld + ikc) * 2u;    // wave-uniform
+            boff = (unsigned)(p.b_tapoff[tap0 + itap] + ikc) * 2u;
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(As + a_row[i] * ROWB + (((2 * ks + lh) ^ ((a_row[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+            if (fillnext) {
+#pragma unroll
+                for (int idx = 0; idx < L; ++idx) {
+                    if (idx * 4 / L != ks) continue;
+                    if constexpr (ABL != 2) {
+                        if (idx < A_P) dma16(rsrcA, Ad + idx * (RP * ROWB), ((a_mask[idx < A_P ? idx : 0] >> itap) & 1) ? a_base[idx < A_P ? idx : 0] + toff : OOB, 0);
+                        else dma16(rsrcB, Bd + (idx - A_P) * (RP * ROWB), b_base[idx >= A_P ? idx - A_P : 0], boff);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if constexpr (ABL != 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    else { keep_alive(fa[i]); keep_alive(fb[j]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (fillnext) {
+            if (++itap == NT) { itap = 0; ikc += BK16; }
+        }
+    };
+
+    // ---- ring: NST - 1 K-steps in flight; step t: wait for (this wave's part of) tile t, barrier (everybody's part has landed
+    // AND everybody has finished reading tile t - 1, whose stage is the one refilled during this step), compute tile t while
+    // issuing tile t + NST - 1 ----
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) issue(s);
+    int stage = 0, fill = NST - 1;
+    for (int t = 0; t < nk; ++t) {
+        if (t + NST - 1 <= nk) wait_vmcnt<(NST - 2) * L>();          // steady state: the NST - 2 younger tiles stay in flight
+        else wait_vmcnt<0>();                                        // last steps: fewer tiles are outstanding
+        __builtin_amdgcn_s_barrier();
+        kstep(stage, fill, t + NST - 1 < nk);
+        stage = stage + 1 == NST ? 0 : stage + 1;
+        fill = fill + 1 == NST ? 0 : fill + 1;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                       // the epilogue reuses the LDS
+    if constexpr (ABL == 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) keep_alive(acc[i][j]);
+        return;
+    }
+    igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, c_ph, c_pw, prow);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0>
+hipError_t launch16(const IgemmParams& p, int splits, hipStream_t st) {
+    const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
+    const size_t ring = (size_t)NST * (BM + BN) * ROWB;
+    const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    auto kern = igemm16_kernel<BM, BN, WM, WN, EPI, NST, MINW, ABL>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (p.ncls > 1) {
+        IgemmParams q = p;
+        q.cls_tiles = mt * nt; q.cls_mtiles = mt;
+        hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(64 * WM * WN), lds, st, q);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(64 * WM * WN), lds, st, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool igemm16_handles(const IgemmParams& p, int al, int bl, int tile) {
+    if (!p.src16 || al != AL_MK || bl != BL_NK) return false;
+    if (p.a_KC % BK16 || p.kchunk % BK16 || p.split_major > 0) return false;
+    // N = 64 layers (TILE_128x64) stay on the register-staged kernel: measured 0.49 vs 0.51 ms (forward) and 0.65 vs 0.69 ms (dgrad)
+    // on the 56x56x64 layer at batch 512 -- those launches are bound by their epilogue's HBM traffic, not by operand staging
+    static const bool narrow = getenv("FTE_IGEMM16_NARROW") != nullptr;
+    return tile == TILE_128x128 || (narrow && tile == TILE_128x64);
+}
+
+hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st) {
+    static const int abl = getenv("FTE_IGEMM16_ABL") ? atoi(getenv("FTE_IGEMM16_ABL")) : 0;      // diagnostic: see the kernel's ABL
+    if (abl && tile == TILE_128x128 && epi == EPI_FWD) {
+        if (abl == 1) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1, 1>(p, splits, st);
+        if (abl == 2) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1, 2>(p, splits, st);
+        if (abl == 3) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1, 3>(p, splits, st);
+    }
+    // Measured on MI355X at batch 512 (forward, ms: 14x14x256 / 28x28x128 / 7x7x512): 4-stage ring at one block per CU 0.30 / 0.41 /
+    // 0.29; 2-stage ring at two blocks per CU 0.24 / 0.30 / 0.23 (default); 256x128 tile, 8 waves, 3 stages 0.24 / 0.31 / 0.28;
+    // the register-staged BF = 2 kernel 0.25 / 0.32 / 0.26.  Two co-resident blocks hide each other's prologue, epilogue and
+    // DMA latency better than a deeper ring of one block does.
+    static const int cfg = getenv("FTE_IGEMM16_CFG") ? atoi(getenv("FTE_IGEMM16_CFG")) : 1;      // tuning hook
+    if (cfg == 1 && tile == TILE_128x128) {          // 2-stage ring, two blocks per CU
+        if (epi == EPI_FWD) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2>(p, splits, st);
+        return launch16<128, 128, 2, 2, EPI_DGRAD, 2, 2>(p, splits, st);
+    }
+    if (cfg == 2 && tile == TILE_128x128 && epi == EPI_FWD && !p.PW && (p.M - p.m_base) >= 256) {          // 256x128, eight waves (two per SIMD), one block per CU
+        // forward only: the dgrad epilogue's column partials are numbered by the PLANNED tile's rows (api.hip)
+        if (epi == EPI_FWD) return launch16<256, 128, 4, 2, EPI_FWD, 3, 2>(p, splits, st);
+    }
+    if (tile == TILE_128x128) {
+        if (epi == EPI_FWD) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1>(p, splits, st);
+        return launch16<128, 128, 2, 2, EPI_DGRAD, 4, 1>(p, splits, st);
+    }
+    if (tile == TILE_128x64) {
+        if (epi == EPI_FWD) return launch16<128, 64, 2, 2, EPI_FWD, 3, 2>(p, splits, st);
+        return launch16<128, 64, 2, 2, EPI_DGRAD, 3, 2>(p, splits, st);
+    }
+    return hipErrorInvalidValue;
+}
