@@ -46,7 +46,29 @@
 #ifndef FTE_SINGLE
 #define FTE_SINGLE 1
 #endif
+// wave priority outside the K loop (s_setprio; 0 = leave it alone): see the kernel's prologue
+#ifndef FTE_PRIO_PROLOGUE
+#define FTE_PRIO_PROLOGUE 3
+#endif
+#ifndef FTE_PRIO_EPILOGUE
+#define FTE_PRIO_EPILOGUE 2
+#endif
+// K order of the fp32 forward / dgrad kernels: 1 = tap outer, channel chunk inner (no VALU addressing in the K loop)
+#ifndef FTE_TAP_OUTER
+#define FTE_TAP_OUTER 1
+#endif
 
+
+#ifdef FTE_STAMP
+// DIAGNOSTIC BUILD ONLY (scripts/build_stamp_variant.sh -> variants/libfte_stamp.so; never the product library): every block of
+// the fp32 main loop stamps s_memtime (shader clock) and s_memrealtime (100 MHz) around its K loop into a buffer of its own,
+// from which scripts/clock_probe.py derives the clock the chip holds under this kernel and the cycles per K-step
+// (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The stamps go to memory nothing else reads; no output depends on them.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+extern "C" int fte_debug_set_stamp(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf));
+}
+#endif
 
 namespace {
 
@@ -67,11 +89,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
     constexpr int B_CH = BN * 8 / NTH;
     constexpr int STAGE = (BM + BN) * BK;         // floats per LDS stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef FTE_STAMP
+    const unsigned long long st_entry = g_stamp_buf ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, lh = lane >> 5;
+    // The prologue (index decomposition, tap masks, first tile) is a few hundred VALU / SALU instructions.  A new block's waves
+    // are the YOUNGEST on their SIMDs and lose every issue arbitration to the older blocks' MFMA streams: measured with in-kernel
+    // stamps at batch 512, a block spent 23 us (56x56x64) to 69 us (7x7x512) between entry and its first K-step -- as long as a
+    // quarter of its K loop -- with only 2.5 - 4 of the 6 resident blocks inside their loops.  Raised priority gets the block to
+    // its MFMAs at once; it drops back to 0 for the loop (FTE_PRIO tuning hook: 0 = off).
+    if (FTE_PRIO_PROLOGUE) __builtin_amdgcn_s_setprio(FTE_PRIO_PROLOGUE);
 
     // ---- tile coordinates: XCD-aware bijective remap, n-tiles fastest --------
     const int ntn = p.N / BN;
@@ -179,12 +210,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
     // touch ~1.3x one window of 128-B row pieces (~21 KB for a 128-row tile): they hit in the CU's L1
     // instead of streaming the whole Cin-wide window once per tap from L2 / Infinity Cache.
     // Weight / B rows are addressed accordingly (row tap*KC + chunk*32); sums are order-independent.
+    // fp32, k-contiguous A (TAPO): K-step sigma covers tap sigma / (KC/32), channel chunk sigma % (KC/32) -- TAP OUTER.  Inside a
+    // tap the per-thread source offsets do not change (the wave-uniform channel offset rides in the buffer load's scalar offset),
+    // so the K loop issues NO vector ALU instruction for addressing: every VALU instruction between two dependent MFMAs holds
+    // the SIMD's issue port and idles the matrix pipe ~3 cycles (scripts/probes/mfma_f32_waves.hip: 2 VALU per MFMA -> 90 % of the
+    // bare-loop rate, 6 -> 79 %, at every occupancy); the chunk-outer order needed ~1.5 per MFMA for the tap mask / offset selects.
+    constexpr bool TAPO = FTE_TAP_OUTER && BF == 0 && AL == AL_MK;
     auto ktap = [&](int k0) -> int {
+        if constexpr (TAPO) return k0 / p.a_KC;
         const int sg = k0 >> 5;
         int t = sg % NT;
         return t;
     };
-    auto kchan = [&](int k0) -> int { return ((k0 >> 5) / NT) << 5; };
+    auto kchan = [&](int k0) -> int {
+        if constexpr (TAPO) return k0 % p.a_KC;
+        return ((k0 >> 5) / NT) << 5;
+    };
 
     f32x4 ra0[A_CH], rb0[B_CH];
 
@@ -319,6 +360,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
     // sources (KM / KN) hold rows k, k+1 of 4 consecutive m (n) and write four 32-bit words -- the transpose
     // happens in the write pass.  One LDS image per macro step (two barriers); the next macro step's buffer loads are in
     // flight under the MFMAs.  No k permutation.
+    if constexpr (BF != 0) {
+        if (FTE_PRIO_PROLOGUE) __builtin_amdgcn_s_setprio(0);      // the bf16 loops keep the default priority throughout
+    }
     if constexpr (BF == 2) {
         // ---- bf16 SOURCES (fte_*16 entry points): the operands already live in HBM as bf16 copies -- activations written
         // by the producing epilogue (Y16 / DZ16), weights packed once per step -- so a K-step moves half the bytes through
@@ -592,8 +636,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
             store_tiles(0);
             __syncthreads();
         }
+        if (FTE_PRIO_PROLOGUE) __builtin_amdgcn_s_setprio(0);
         int stap = 0, skc = 0;                                      // position of the tile in LDS (step s): advanced to s + 1 below
         if constexpr (AL == AL_MK || BL == BL_NK) { stap = ktap(kbeg); skc = kchan(kbeg); }
+        unsigned va[A_CH];                                          // TAPO: per-thread source offsets of the current tap
+        if constexpr (TAPO) {
+            const unsigned toff = (unsigned)((p.a_dh[tap0 + stap] * p.a_IW + p.a_dw[tap0 + stap]) * p.a_ld) * 4u;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) va[i] = ((a_mask[i] >> stap) & 1) ? a_base[i] + toff : OOB;
+        }
+#ifdef FTE_STAMP
+        unsigned long long st_t0 = 0, st_r0 = 0;
+        if (g_stamp_buf) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+#endif
         for (int s = 0; s < nsteps; ++s) {
             const int cur = FTE_SINGLE ? 0 : (s & 1);
             const int k0 = kbeg + (s + 1) * BK;
@@ -603,15 +658,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
             float* Bsn = Asn + BM * BK;
             // ---- per-step operand addressing (scalar / per-thread, no memory access yet) ----
             int tap = 0, kc0 = 0;
-            if constexpr (AL == AL_MK || BL == BL_NK) {
+            unsigned a_toff = 0, b_soff = 0, a_soff = 0;
+            if constexpr (TAPO) {
+                // tile of step s + 1; the step after the last one re-stages the last tile (nobody reads it): no selects needed
+                if (k0 < kend) {
+                    skc += BK;
+                    if (skc == p.a_KC) {                        // next tap: the only vector instructions of the K loop's addressing
+                        skc = 0; ++stap;
+                        const unsigned toff = (unsigned)((p.a_dh[tap0 + stap] * p.a_IW + p.a_dw[tap0 + stap]) * p.a_ld) * 4u;
+#pragma unroll
+                        for (int i = 0; i < A_CH; ++i) va[i] = ((a_mask[i] >> stap) & 1) ? a_base[i] + toff : OOB;
+                    }
+                }
+                tap = stap; kc0 = skc;
+                a_soff = (unsigned)skc * 4u;
+            } else if constexpr (AL == AL_MK || BL == BL_NK) {
                 if (++stap == NT) { stap = 0; skc += BK; }      // (ktap, kchan) of k0, kept incrementally: no division
                 tap = stap;
                 kc0 = skc < p.a_KC ? skc : 0;                   // the unused tile after the last step
             }
-            unsigned a_toff = 0, b_soff = 0;
             bool kin = false;
             int kn = 0, kih0 = 0, kiw0 = 0;
-            if constexpr (AL == AL_MK) {
+            if constexpr (TAPO) {
+            } else if constexpr (AL == AL_MK) {
                 a_toff = (unsigned)((p.a_dh[tap0 + tap] * p.a_IW + p.a_dw[tap0 + tap]) * p.a_ld + kc0) * 4u;
             } else {
                 const int pix = k0 + (tid >> 3);
@@ -628,7 +697,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
             auto load_slot = [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < A_CH) {
-                    if constexpr (AL == AL_MK) {
+                    if constexpr (TAPO) {
+                        ra[i] = ldg(rsrcA, va[i], a_soff);
+                    } else if constexpr (AL == AL_MK) {
                         ra[i] = ldg(rsrcA, ((a_mask[i] >> tap) & 1) && k0 < kend ? a_base[i] + a_toff : OOB, 0);
                     } else {
                         const int ih = kih0 + (a_dhw[i] & 0xff) - 8, iw = kiw0 + ((a_dhw[i] >> 8) & 0xff) - 8;
@@ -637,7 +708,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                     }
                 } else {
                     constexpr int j = i - A_CH;
-                    if constexpr (BL == BL_KN) {
+                    if constexpr (TAPO) {
+                        rb[j] = ldg(rsrcB, b_base[j], b_soff);      // K ranges are whole 32-deep steps (the launcher checks): no row test
+                    } else if constexpr (BL == BL_KN) {
                         constexpr int CPR = BN / 4, RPP = NTH / CPR;
                         rb[j] = ldg(rsrcB, (k0 + tid / CPR + RPP * j < kend) ? b_base[j] : OOB, b_soff);
                     } else {
@@ -688,9 +761,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
             });
             __syncthreads();
         }
+#ifdef FTE_STAMP
+        if (g_stamp_buf && tid == 0) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* o = g_stamp_buf + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = t1 - st_t0; o[1] = r1 - st_r0; o[2] = (unsigned long long)nsteps; o[3] = st_r0;
+            o[4] = st_t0 - st_entry;            // prologue: entry -> first K-step
+            o[5] = t1;                          // loop end (the epilogue's duration is taken against the stamp below)
+        }
+#endif
     }
 
+    if (FTE_PRIO_EPILOGUE && BF == 0) __builtin_amdgcn_s_setprio(FTE_PRIO_EPILOGUE);      // drain quickly, free the slot
     igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow);
+#ifdef FTE_STAMP
+    if constexpr (BF == 0) {
+        __syncthreads();
+        if (g_stamp_buf && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* o = g_stamp_buf + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[6] = __builtin_amdgcn_s_memtime() - o[5];      // epilogue incl. its stores' completion
+            o[7] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 // ---- fix-up: sum the split-K partial tiles of one output tile and apply the fused epilogue -------------
@@ -926,6 +1020,8 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
     const uintptr_t al_ptr = epi == EPI_FWD ? (uintptr_t)p.alpha : 0;      // read as float4 by the forward epilogue only
     if (((ptrs | al_ptr) & 15) || (p.c_ld & 3) || (p.a_ld & 3) || (p.b_ld & 3)) return hipErrorInvalidValue;
     if (p.M >= (1 << 24) || (al == AL_KM && p.K >= (1 << 24))) return hipErrorInvalidValue;      // fdiv() range (see the kernel)
+    // k-contiguous A: the K loop walks whole 32-deep steps inside one tap (no partial-step row tests in the loop)
+    if (al == AL_MK && ((p.a_KC % 32) || (p.kchunk % 32) || (p.K % 32))) return hipErrorInvalidValue;
     if (!g_prof_on) return dispatch(p, al, bl, epi, tile, splits, st);
     ProfRec r;
     r.sig[0] = al; r.sig[1] = bl; r.sig[2] = epi; r.sig[3] = tile; r.sig[4] = splits;
