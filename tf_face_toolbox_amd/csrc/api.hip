@@ -482,7 +482,7 @@ int fte_conv3x3_dgrad(const float* dz, const float* w, const float* addin, const
 // ------------------------------------------------------------------------------------------------
 namespace {
 inline bool wgrad_split_major() {
-    static const bool on = getenv("FTE_WGRAD_SPLIT_MAJOR") && atoi(getenv("FTE_WGRAD_SPLIT_MAJOR")) != 0;
+    static const bool on = !getenv("FTE_WGRAD_SPLIT_MAJOR") || atoi(getenv("FTE_WGRAD_SPLIT_MAJOR")) != 0;      // tuning hook: 0 = 2-D grid
     return on;
 }
 void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, int* tile, int* splits, int* kchunk, int* K) {
@@ -496,7 +496,7 @@ void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, 
     *tile = wg_tile >= 0 ? wg_tile : ((cout % 128 == 0) ? TILE_128x128 : narrow);
     // prefer8 / split-major placement (one pixel range per XCD) cut wgrad's HBM traffic ~9x on MI355X but the
     // kernel is MFMA-bound: 18.4 -> 18.9 ms per step.  Left off (FTE_WGRAD_SPLIT_MAJOR=1 turns it on: tuning hook).
-    plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk, wgrad_split_major());
+    plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk, false);
 }
 }  // namespace
 

@@ -57,6 +57,9 @@
 #ifndef FTE_TAP_OUTER
 #define FTE_TAP_OUTER 1
 #endif
+#ifndef FTE_SUPER_CHUNK
+#define FTE_SUPER_CHUNK 128
+#endif
 
 
 #ifdef FTE_STAMP
@@ -108,10 +111,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
     const int ntn = p.N / BN;
     int bid = blockIdx.x, split = blockIdx.y;
     if (p.split_major > 0) {
-        // blocks are dealt round-robin over the 8 XCDs: with split = id % S and S % 8 == 0 every tile
-        // of one K range lands on the same XCD (placement is a speed matter only)
-        split = bid % p.split_major;
-        bid = bid / p.split_major;
+        // Split-K filter gradients: every tile of one K range (pixel range) reads the SAME x and dz rows.  Blocks are dealt
+        // round-robin over the 8 XCDs, each with its own L2: ids are laid out in groups of 8 splits x all tiles, the split
+        // fastest, so that the tiles of one split are 8 ids apart -- same XCD, dispatched together -- and x / dz leave HBM
+        // once per split instead of once per tile (placement is a speed / traffic matter only, never correctness).
+        const int S = p.split_major, T = gridDim.x / S;
+        const int g = bid / (8 * T), rem = bid - g * (8 * T);
+        const int w = min(8, S - 8 * g);                      // splits in this group (the last group may be narrower)
+        const int tile = rem / w;
+        split = 8 * g + (rem - tile * w);
+        bid = tile;
     } else {
         const int ntiles = gridDim.x;
         const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
@@ -216,14 +225,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
     // the SIMD's issue port and idles the matrix pipe ~3 cycles (scripts/probes/mfma_f32_waves.hip: 2 VALU per MFMA -> 90 % of the
     // bare-loop rate, 6 -> 79 %, at every occupancy); the chunk-outer order needed ~1.5 per MFMA for the tap mask / offset selects.
     constexpr bool TAPO = FTE_TAP_OUTER && BF == 0 && AL == AL_MK;
+    // ... in SUPER-CHUNKS of SC channels: (super-chunk outer, tap, 32-channel step inner).  With the taps of ALL channels outermost a
+    // block re-reads its rows at a distance of rows x KC x 4 bytes (the co-resident blocks of an XCD then cycle 12 MB through a
+    // 4 MB L2: 897 MB per launch left L2 on the 64x64 forward symbol against 530 MB algorithmic); SC = 128 channels keeps the nine
+    // taps of a super-chunk within L2 and costs one address recomputation (~10 VALU) per 4 K-steps.
+    const int SC = TAPO ? ((p.a_KC % FTE_SUPER_CHUNK == 0) ? FTE_SUPER_CHUNK : p.a_KC) : BK;
+    const int SCS = SC / BK;                                    // K-steps per (super-chunk, tap) visit
     auto ktap = [&](int k0) -> int {
-        if constexpr (TAPO) return k0 / p.a_KC;
+        if constexpr (TAPO) return ((k0 / BK) % (NT * SCS)) / SCS;
         const int sg = k0 >> 5;
         int t = sg % NT;
         return t;
     };
     auto kchan = [&](int k0) -> int {
-        if constexpr (TAPO) return k0 % p.a_KC;
+        if constexpr (TAPO) return ((k0 / BK) / (NT * SCS)) * SC + ((k0 / BK) % SCS) * BK;
         return ((k0 >> 5) / NT) << 5;
     };
 
@@ -640,7 +655,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
         int stap = 0, skc = 0;                                      // position of the tile in LDS (step s): advanced to s + 1 below
         if constexpr (AL == AL_MK || BL == BL_NK) { stap = ktap(kbeg); skc = kchan(kbeg); }
         unsigned va[A_CH];                                          // TAPO: per-thread source offsets of the current tap
+        int sstep = 0, scbase = 0;                                  // TAPO: step inside the (super-chunk, tap) visit; first channel of the super-chunk
         if constexpr (TAPO) {
+            sstep = (kbeg / BK) % SCS;
+            scbase = skc - sstep * BK;
             const unsigned toff = (unsigned)((p.a_dh[tap0 + stap] * p.a_IW + p.a_dw[tap0 + stap]) * p.a_ld) * 4u;
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) va[i] = ((a_mask[i] >> stap) & 1) ? a_base[i] + toff : OOB;
@@ -663,8 +681,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                 // tile of step s + 1; the step after the last one re-stages the last tile (nobody reads it): no selects needed
                 if (k0 < kend) {
                     skc += BK;
-                    if (skc == p.a_KC) {                        // next tap: the only vector instructions of the K loop's addressing
-                        skc = 0; ++stap;
+                    if (++sstep == SCS) {                       // next tap (of this super-chunk, or the first of the next one):
+                        sstep = 0;                              // the only vector instructions of the K loop's addressing
+                        if (++stap == NT) { stap = 0; scbase += SC; }
+                        skc = scbase;
                         const unsigned toff = (unsigned)((p.a_dh[tap0 + stap] * p.a_IW + p.a_dw[tap0 + stap]) * p.a_ld) * 4u;
 #pragma unroll
                         for (int i = 0; i < A_CH; ++i) va[i] = ((a_mask[i] >> stap) & 1) ? a_base[i] + toff : OOB;
