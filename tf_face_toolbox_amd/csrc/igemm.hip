@@ -60,6 +60,10 @@
 #ifndef FTE_SUPER_CHUNK
 #define FTE_SUPER_CHUNK 128
 #endif
+// filter-gradient addressing: 1 = incremental pixel tracking with wave-uniform taps where the shape allows (see the K loop)
+#ifndef FTE_KM_FAST
+#define FTE_KM_FAST 1
+#endif
 
 
 #ifdef FTE_STAMP
@@ -667,6 +671,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
         unsigned long long st_t0 = 0, st_r0 = 0;
         if (g_stamp_buf) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 #endif
+        // AL_KM (filter gradient / dense tn), KMF = true: the fast addressing path, taken when every 32-wide m group of the
+        // tile lies inside ONE tap (KC % 32 == 0: the i-th load of a wave is then a single tap -- its (dh, dw) are scalars), the K
+        // range is whole 32-pixel steps, and the image is at least 32 / OW + 1 rows high (or 1 x 1: dense).  The thread's pixel
+        // (n, oh, ow) is advanced by 32 with two carries instead of being re-derived by two divisions per step, and its tap
+        // shifts are scalar adds: ~40 instead of ~110 vector-ALU instructions per K-step (each costs the matrix pipe 3-4 cycles).
+        int kn_ = 0, koh_ = 0, kow_ = 0;                            // KMF: (n, oh, ow) of pixel k0 + (tid >> 3)
+        bool kmf = false;
+        if constexpr (AL == AL_KM && BF == 0) {
+            const bool dense = p.a_OH * p.a_OW == 1;
+            kmf = FTE_KM_FAST && (p.a_KC % 32 == 0) && (p.M % 32 == 0) && ((kend - kbeg) % BK == 0) && nsteps > 0 &&
+                  (dense || (BK / p.a_OW + 1 <= p.a_OH));
+            if (kmf) {
+                const int pix = kbeg + (tid >> 3);                  // pixel of the tile in LDS; the loop advances it to step s + 1
+                kn_ = fdiv(pix, a_hw, r_ahw);
+                const int rem = pix - kn_ * a_hw;
+                koh_ = fdiv(rem, p.a_OW, r_aow);
+                kow_ = rem - koh_ * p.a_OW;
+            }
+        }
+        auto run_loop = [&](auto KMF_) {
+        constexpr bool KMF = decltype(KMF_)::value;
         for (int s = 0; s < nsteps; ++s) {
             const int cur = FTE_SINGLE ? 0 : (s & 1);
             const int k0 = kbeg + (s + 1) * BK;
@@ -699,9 +724,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
             }
             bool kin = false;
             int kn = 0, kih0 = 0, kiw0 = 0;
+            unsigned vk[A_CH];                                  // KMF: this step's source offsets
             if constexpr (TAPO) {
             } else if constexpr (AL == AL_MK) {
                 a_toff = (unsigned)((p.a_dh[tap0 + tap] * p.a_IW + p.a_dw[tap0 + tap]) * p.a_ld + kc0) * 4u;
+            } else if constexpr (KMF) {
+                // advance the thread's pixel by one K-step (the step after the last one re-stages the last tile: no selects)
+                const bool adv = k0 < kend;
+                if (adv && !(p.a_OH * p.a_OW == 1)) {
+                    const int q32 = BK / p.a_OW, r32 = BK - q32 * p.a_OW;              // scalars
+                    kow_ += r32;
+                    const int c1 = kow_ >= p.a_OW ? 1 : 0;
+                    kow_ -= c1 ? p.a_OW : 0;
+                    koh_ += q32 + c1;
+                    const int c2 = koh_ >= p.a_OH ? 1 : 0;
+                    koh_ -= c2 ? p.a_OH : 0;
+                    kn_ += c2;
+                } else if (adv) {
+                    kn_ += BK;                                                          // 1 x 1 image: the pixel index IS n
+                }
+                kih0 = koh_ * p.a_stride;
+                kiw0 = kow_ * p.a_stride;
+                const unsigned base = (unsigned)(((kn_ * p.a_IH + kih0) * p.a_IW + kiw0) * p.a_ld + ((tid & 7) << 2)) * 4u;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    const int mg = m0 + 32 * i;                                         // wave-uniform: first m of this load's 32-wide group
+                    const int t = mg / p.a_KC, c0 = mg - t * p.a_KC;
+                    const int tt = t < p.a_NT ? t : 0;
+                    const int dh = p.a_dh[tt], dw = p.a_dw[tt];                         // scalars
+                    const bool ok = mg < p.M && (unsigned)(kih0 + dh) < (unsigned)p.a_IH && (unsigned)(kiw0 + dw) < (unsigned)p.a_IW;
+                    vk[i] = ok ? base + (unsigned)(((dh * p.a_IW + dw) * p.a_ld + c0) * 4) : OOB;
+                }
             } else {
                 const int pix = k0 + (tid >> 3);
                 kin = pix < kend;
@@ -721,6 +774,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                         ra[i] = ldg(rsrcA, va[i], a_soff);
                     } else if constexpr (AL == AL_MK) {
                         ra[i] = ldg(rsrcA, ((a_mask[i] >> tap) & 1) && k0 < kend ? a_base[i] + a_toff : OOB, 0);
+                    } else if constexpr (KMF) {
+                        ra[i] = ldg(rsrcA, vk[i], 0);
                     } else {
                         const int ih = kih0 + (a_dhw[i] & 0xff) - 8, iw = kiw0 + ((a_dhw[i] >> 8) & 0xff) - 8;
                         const bool ok = kin && (a_dhw[i] >> 16) && ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW;
@@ -728,8 +783,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                     }
                 } else {
                     constexpr int j = i - A_CH;
-                    if constexpr (TAPO) {
-                        rb[j] = ldg(rsrcB, b_base[j], b_soff);      // K ranges are whole 32-deep steps (the launcher checks): no row test
+                    if constexpr (TAPO || KMF) {
+                        rb[j] = ldg(rsrcB, b_base[j], b_soff);      // K ranges are whole 32-deep steps (the launcher / kmf check): no row test
                     } else if constexpr (BL == BL_KN) {
                         constexpr int CPR = BN / 4, RPP = NTH / CPR;
                         rb[j] = ldg(rsrcB, (k0 + tid / CPR + RPP * j < kend) ? b_base[j] : OOB, b_soff);
@@ -780,6 +835,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                 __builtin_amdgcn_sched_barrier(0);
             });
             __syncthreads();
+        }
+        };
+        if constexpr (AL == AL_KM && BF == 0) {
+            if (kmf) run_loop(std::true_type{});
+            else run_loop(std::false_type{});
+        } else {
+            run_loop(std::false_type{});
         }
 #ifdef FTE_STAMP
         if (g_stamp_buf && tid == 0) {
