@@ -15,9 +15,15 @@ class CpuMomentum(object):
         self.m = model
         self.acc = torch.zeros(model.arena_size, dtype=torch.float64)
 
-    def apply(self, lr, step_1based, mult_lr_list):
+    supports_ranges = True                      # DataParallel updates bucket by bucket as the all-reduces complete
+
+    def apply(self, lr, step_1based, mult_lr_list, lo=None, hi=None):
         m = self.m
         for a, b, decayed, grp in m.arena_groups():
+            if lo is not None:
+                a, b = max(a, lo), min(b, hi)
+                if a >= b:
+                    continue
             gs = float(mult_lr_list[grp])
             wd = m.weight_decay if decayed else 0.0
             g = gs * m.grads[a:b] + wd * gs * m.params[a:b]

@@ -51,11 +51,18 @@ class _DeviceOptimizer(object):
             self.slots = [torch.zeros(n, dtype=torch.float32, device=dev)
                           for _ in range(1 if self.kind == 'Momentum' else 2)]
 
-    def apply(self, lr, step_1based, mult_lr_list):
+    supports_ranges = True
+
+    def apply(self, lr, step_1based, mult_lr_list, lo=None, hi=None):
+        """Update the arena (or only its [lo, hi) part: one all-reduce bucket at a time)."""
         self._ensure()
         m = self.model
         st = _stream()
         for a, b, decayed, grp in m.arena_groups():
+            if lo is not None:
+                a, b = max(a, lo), min(b, hi)
+                if a >= b:
+                    continue
             wd = m.weight_decay if decayed else 0.0
             gs = float(mult_lr_list[grp])
             if self.kind == 'Momentum':
@@ -224,13 +231,21 @@ class DataParallel(Singular):
         replica applies the same summed gradient to its own copy with its own slots."""
         m = self.model
         works = []
-        for stage, (a, b) in zip(m.backward_stages(), m.grad_buckets()):
+        buckets = m.grad_buckets()
+        for stage, (a, b) in zip(m.backward_stages(), buckets):
             stage()
             works.append(self.comm.all_reduce_async(m.grads[a:b]))
-        for w in works:
-            w.wait()
         self.learning_rate = self._lr_value()
-        self._opt.apply(self.learning_rate, self.global_step + 1, m.mult_lr_list())
+        if getattr(self._opt, 'supports_ranges', False):
+            # bucket by bucket, in completion order: the head bucket (73 of the 120 MB) is updated while the later, smaller
+            # all-reduces are still crossing xGMI -- the kernel stream only ever waits for the bucket it is about to update
+            for w, (a, b) in zip(works, buckets):
+                w.wait()
+                self._opt.apply(self.learning_rate, self.global_step + 1, m.mult_lr_list(), a, min(b, m.arena_size))
+        else:
+            for w in works:
+                w.wait()
+            self._opt.apply(self.learning_rate, self.global_step + 1, m.mult_lr_list())
 
     def __call__(self, inputs):
         if self.comm is None:
