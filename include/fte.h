@@ -158,6 +158,20 @@ int fte_bn_infer_fwd(const float* z, const float* gamma, const float* beta, cons
 int fte_bn_train_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
                      const float* rstd, float* dz, float* dgamma, float* dbeta, long rows, int c,
                      void* ws, size_t ws_bytes, void* stream);
+/* The same backward pass with the ReLU mask recomputed from z: g = dy * (fma(z, scale, shift) > 0) with the scale / shift
+ * the forward pass kept -- the expression the forward kernels evaluate, so the mask is the forward's bit for bit and
+ * the normalised activation is not read (nor need it exist: fte_channel_gather_affine). */
+int fte_bn_train_bwd_zmask(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, float* dz, float* dgamma, float* dbeta, long rows, int c,
+                           void* ws, size_t ws_bytes, void* stream);
+/* The two halves of fte_bn_train_fwd / fte_bn_infer_fwd without the apply pass: batch statistics -> mean, rstd,
+ * scale = gamma*rstd, shift = beta - mean*scale (+ the moving statistics), and the inference coefficients from the
+ * moving statistics.  For consumers that apply scale / shift themselves (fte_channel_gather_affine). */
+int fte_bn_train_stats(const float* z, const float* gamma, const float* beta, float* mean, float* rstd, float* scale, float* shift,
+                       float* moving_mean, float* moving_var, long rows, int c, float eps, float decay,
+                       void* ws, size_t ws_bytes, void* stream);
+int fte_bn_infer_coef(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                      float* scale, float* shift, int c, float eps, void* stream);
 /* g = dy * (y > 0)  (tf.nn.relu gradient, materialised where a residual shortcut needs it) */
 int fte_relu_bwd(const float* dy, const float* y, float* g, long n, void* stream);
 
@@ -237,6 +251,12 @@ int fte_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int n, int h
 size_t fte_dwconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int stride);
 int fte_channel_gather(const float* a, const float* b, float* out, const int32_t* table, long rows,
                        int ca, int cb, int co, void* stream);
+/* The gather with batch norm applied to a source on the way: a source whose scale is not NULL contributes
+ * [relu](fma(src[row,ch], scale[ch], shift[ch])).  conv3_1x1's BN + ReLU output (:110) and the stride-2 shortcut's (:96-101)
+ * feed only the concat / shuffle / split: they are normalised inside the gather and never written to HBM. */
+int fte_channel_gather_affine(const float* a, const float* b, float* out, const int32_t* table, long rows,
+                              int ca, int cb, int co, const float* scale_a, const float* shift_a, int relu_a,
+                              const float* scale_b, const float* shift_b, int relu_b, void* stream);
 
 /* ---------------------------------------------------------------------------
  * First conv of the net (Cin = 1 or 3, stride 2; nets/sphere.py:57): K = 9*Cin

@@ -80,6 +80,65 @@ def test_channel_gather_is_concat_shuffle_split(ca, fmt):
     assert torch.equal(run(ts['bwd'][0][1], h0, h1, pc(2 * ca)), cd)
 
 
+@pytest.mark.parametrize('rows,c', [(3 * 14 * 14, 128), (512 * 7 * 7, 256), (40, 64)])
+def test_bn_folded_into_the_gather_is_the_unfused_sequence_bit_for_bit(rows, c):
+    """fte_bn_train_stats + fte_channel_gather_affine == fte_bn_train_fwd + fte_channel_gather, and the backward pass with
+    the mask recomputed from z == the one reading the stored output: both bit-exact (same fma, same reduction order)."""
+    g = torch.Generator(device='cuda').manual_seed(rows + c)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    z, s_in, dy = rnd(rows, c), rnd(rows, c), rnd(rows, c)
+    gamma, beta = rnd(c) * 0.5 + 1.0, rnd(c) * 0.3
+    buf, nb = ws(_lib.query('fte_bn_ws_bytes', c))
+    new = lambda: [torch.empty(c, device='cuda') for _ in range(4)]
+    y = torch.empty_like(z)
+    m0 = new(); m1 = new()
+    _lib.call('fte_bn_train_fwd', z, gamma, beta, None, y, m0[0], m0[1], m0[2], m0[3], None, None, rows, c, 1e-5, 0.9, 1, buf, nb, stream())
+    _lib.call('fte_bn_train_stats', z, gamma, beta, m1[0], m1[1], m1[2], m1[3], None, None, rows, c, 1e-5, 0.9, buf, nb, stream())
+    for a, b in zip(m0, m1):
+        assert torch.equal(a, b)
+    perm = torch.randperm(2 * c, generator=torch.Generator().manual_seed(c)).tolist()
+    table = torch.tensor([((j // c) << 16) | (j % c) for j in perm[:c]], dtype=torch.int32, device='cuda')
+    o0 = torch.empty(rows, c, device='cuda'); o1 = torch.empty(rows, c, device='cuda'); o2 = torch.empty(rows, c, device='cuda')
+    _lib.call('fte_channel_gather', s_in, y, o0, table, rows, c, c, c, stream())
+    _lib.call('fte_channel_gather_affine', s_in, z, o1, table, rows, c, c, c, None, None, 0, m1[2], m1[3], 1, stream())
+    assert torch.equal(o0, o1)
+    _lib.call('fte_channel_gather', y, s_in, o0, table, rows, c, c, c, stream())
+    _lib.call('fte_channel_gather_affine', z, s_in, o2, table, rows, c, c, c, m1[2], m1[3], 1, None, None, 0, stream())
+    assert torch.equal(o0, o2)
+    outs = []
+    for zmask in (False, True):
+        dz = torch.empty_like(z); dg = torch.empty(c, device='cuda'); db = torch.empty(c, device='cuda')
+        if zmask:
+            _lib.call('fte_bn_train_bwd_zmask', dy, z, gamma, m1[0], m1[1], m1[2], m1[3], dz, dg, db, rows, c, buf, nb, stream())
+        else:
+            _lib.call('fte_bn_train_bwd', dy, y, z, gamma, m0[0], m0[1], dz, dg, db, rows, c, buf, nb, stream())
+        outs.append((dz, dg, db))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # inference coefficients: the ones fte_bn_infer_fwd derives
+    mm, mv = rnd(c) * 0.1, rnd(c).abs() + 0.5
+    sc0, sf0, sc1, sf1 = new()
+    _lib.call('fte_bn_infer_fwd', z, gamma, beta, mm, mv, None, y, sc0, sf0, rows, c, 1e-5, 1, stream())
+    _lib.call('fte_bn_infer_coef', gamma, beta, mm, mv, sc1, sf1, c, 1e-5, stream())
+    assert torch.equal(sc0, sc1) and torch.equal(sf0, sf1)
+
+
+def test_shufflenet_folds_every_gather_only_bn():
+    """conv3_1x1's and the stride-2 shortcut's BN + ReLU outputs feed only the concat / shuffle / split: 16 + 3 folded BNs in the
+    x2 net, none of them stored; asking for one recomputes it."""
+    net = ShuffleNet_v2_small(alpha=2.0)
+    net.build(64, 64, 3, 10, 'cuda')
+    kinds = [op[0] for op in net.plan]
+    assert kinds.count('bnstats') == 19 and len(net.folded) == 19
+    x = torch.rand(4, 64, 64, 3, device='cuda') * 2 - 1
+    net.forward(x, num_classes=10, is_training=True)
+    name = 'conv3b1/c3'
+    assert name in net.folded and name not in dict.keys(net.t)
+    y = net.t[name]
+    zname, relu = net.folded[name]
+    assert relu == 1 and y.shape == net.t[zname].shape and float(y.min()) == 0.0
+
+
 def _check_net(net, variant, blocks, fmt, n, h, w, ncls, seed):
     graph, spec = og.shufflenet_train_graph(variant, 3, ncls, fmt, blocks_override=blocks)
     p, state = og.init_params(spec, seed)

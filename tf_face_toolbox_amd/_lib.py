@@ -37,6 +37,9 @@ _SIGS = {
     'fte_bn_train_fwd': (c_int, [_P] * 11 + [c_long, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
     'fte_bn_infer_fwd': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_int, _P]),
     'fte_bn_train_bwd': (c_int, [_P] * 9 + [c_long, c_int, _P, c_size_t, _P]),
+    'fte_bn_train_bwd_zmask': (c_int, [_P] * 10 + [c_long, c_int, _P, c_size_t, _P]),
+    'fte_bn_train_stats': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_float, _P, c_size_t, _P]),
+    'fte_bn_infer_coef': (c_int, [_P] * 6 + [c_int, c_float, _P]),
     'fte_relu_bwd': (c_int, [_P] * 3 + [c_long, _P]),
     'fte_maxpool3x3s2_fwd': (c_int, [_P] * 3 + [c_int] * 4 + [_P]),
     'fte_maxpool3x3s2_bwd': (c_int, [_P] * 3 + [c_int] * 4 + [_P]),
@@ -65,6 +68,7 @@ _SIGS = {
     'fte_dwconv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),
     'fte_dwconv3x3_wgrad_ws_bytes': (c_size_t, [c_int] * 5),
     'fte_channel_gather': (c_int, [_P] * 4 + [c_long] + [c_int] * 3 + [_P]),
+    'fte_channel_gather_affine': (c_int, [_P] * 4 + [c_long] + [c_int] * 3 + [_P, _P, c_int, _P, _P, c_int, _P]),
     'fte_conv3x3_first_fwd': (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
     'fte_conv3x3_first_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_first_wgrad_ws_bytes': (c_size_t, [c_int] * 6),

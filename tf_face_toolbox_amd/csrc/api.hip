@@ -493,7 +493,11 @@ void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, 
     // N = 64 layers: M = 9 * 64 = 576 is 4.5 tiles of 128 rows (a tenth of the MFMAs multiply zero padding: the stage-1
     // filter gradient ran at 68 % of peak with its MFMA pipe 76 % busy) but exactly 3 tiles of 192
     const int narrow = (M % 192 == 0 && M % 128 != 0) ? TILE_192x64 : TILE_128x64;
-    *tile = wg_tile >= 0 ? wg_tile : ((cout % 128 == 0) ? TILE_128x128 : narrow);
+    // a filter gradient of at most 256 x 256 (the 1x1 convs of the ShuffleNet stages) is 1-4 tiles of 128 x 128: every block is
+    // then one of ~400 K ranges of 256 pixels -- 64 x 64 tiles give 4x the blocks over K ranges 4x as long for the same
+    // slab bytes (14x14x128->128 at batch 512: 65 -> 51 us, 7x7x256->256: 52 -> 44 us with the slab reduction)
+    const bool tiny = ksize == 1 && M * cout <= 256L * 256;
+    *tile = wg_tile >= 0 ? wg_tile : (tiny ? TILE_64x64 : (cout % 128 == 0) ? TILE_128x128 : narrow);
     // prefer8 / split-major placement (one pixel range per XCD) cut wgrad's HBM traffic ~9x on MI355X but the
     // kernel is MFMA-bound: 18.4 -> 18.9 ms per step.  Left off (FTE_WGRAD_SPLIT_MAJOR=1 turns it on: tuning hook).
     plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk, false);
@@ -795,7 +799,27 @@ int fte_bn_train_bwd(const float* dy, const float* ymask, const float* z, const 
                      void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !z || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || rows <= 0 || c % 4) return FTE_EINVAL;
     if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
-    return rc(l_bn_bwd(dy, ymask, z, gamma, mean, rstd, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
+    return rc(l_bn_bwd(dy, ymask, z, gamma, mean, rstd, nullptr, nullptr, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
+}
+int fte_bn_train_bwd_zmask(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
+                           const float* scale, const float* shift, float* dz, float* dgamma, float* dbeta, long rows, int c,
+                           void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !z || !gamma || !mean || !rstd || !scale || !shift || !dz || !dgamma || !dbeta || rows <= 0 || c % 4) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    return rc(l_bn_bwd(dy, nullptr, z, gamma, mean, rstd, scale, shift, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
+}
+int fte_bn_train_stats(const float* z, const float* gamma, const float* beta, float* mean, float* rstd, float* scale, float* shift,
+                       float* moving_mean, float* moving_var, long rows, int c, float eps, float decay,
+                       void* ws, size_t ws_bytes, void* stream) {
+    if (!z || !gamma || !beta || !mean || !rstd || !scale || !shift || rows <= 0 || c % 4) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    return rc(l_bn_train_stats(z, gamma, beta, rows, c, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
+                               (float*)ws, (hipStream_t)stream));
+}
+int fte_bn_infer_coef(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                      float* scale, float* shift, int c, float eps, void* stream) {
+    if (!gamma || !beta || !moving_mean || !moving_var || !scale || !shift || c <= 0) return FTE_EINVAL;
+    return rc(l_bn_infer_coef(gamma, beta, moving_mean, moving_var, eps, c, scale, shift, (hipStream_t)stream));
 }
 int fte_relu_bwd(const float* dy, const float* y, float* g, long n, void* stream) {
     if (!dy || !y || !g || n <= 0 || n % 4) return FTE_EINVAL;
@@ -913,6 +937,13 @@ int fte_dwconv3x3_wgrad(const float* x, const float* dy, float* dw, int n, int h
 int fte_channel_gather(const float* a, const float* b, float* out, const int32_t* table, long rows, int ca, int cb, int co, void* stream) {
     if (!a || !out || !table || rows <= 0 || co <= 0 || co % 4) return FTE_EINVAL;      // the table is read 4 entries at a time
     return rc(l_channel_gather(a, b ? b : a, out, table, rows, ca, cb, co, (hipStream_t)stream));
+}
+int fte_channel_gather_affine(const float* a, const float* b, float* out, const int32_t* table, long rows, int ca, int cb, int co,
+                              const float* scale_a, const float* shift_a, int relu_a,
+                              const float* scale_b, const float* shift_b, int relu_b, void* stream) {
+    if (!a || !out || !table || rows <= 0 || co <= 0 || co % 4 || (scale_a && !shift_a) || (scale_b && (!shift_b || !b))) return FTE_EINVAL;
+    return rc(l_channel_gather_affine(a, b ? b : a, out, table, rows, ca, cb, co, scale_a, shift_a, relu_a, scale_b, shift_b, relu_b,
+                                      (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -14,7 +14,8 @@ hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, co
                       int relu, hipStream_t st);
 hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st);
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
-                    const float* rstd, float* dz, float* dgamma, float* dbeta, long rows, int C, float* part, hipStream_t st);
+                    const float* rstd, const float* zsc, const float* zsf, float* dz, float* dgamma, float* dbeta, long rows, int C,
+                    float* part, hipStream_t st);
 hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
 hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
 hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st);
@@ -41,3 +42,5 @@ int l_dwconv_wgrad_splits(long npix, int c);
 hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, int h, int wd, int c, int ho, int wo, int stride,
                           int pt, int pl, int splits, hipStream_t st);
 hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st);
+hipError_t l_channel_gather_affine(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co,
+                                   const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st);

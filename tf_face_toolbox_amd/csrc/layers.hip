@@ -27,6 +27,15 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
     n = tot;
 }
 
+// scale*z + shift as ONE fused multiply-add per element: the backward pass recomputes the ReLU mask from z with this same
+// expression (the normalised activation need not be kept, or even stored: bn_gather), so both must round identically
+__device__ __forceinline__ f32x4 bn_affine(const f32x4 z, const f32x4 sc, const f32x4 sf) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(z[e], sc[e], sf[e]);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                        long rows, int C, long rows_per_split) {
     __shared__ float sh[3][4][64];
@@ -103,7 +112,8 @@ __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restric
 template <int Q>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                                const float* __restrict__ z, const float* __restrict__ mean,
-                                                               const float* __restrict__ rstd, float* __restrict__ part,
+                                                               const float* __restrict__ rstd, const float* __restrict__ zsc,
+                                                               const float* __restrict__ zsf, float* __restrict__ part,
                                                                long rows, int C, long rows_per_split) {
     constexpr int RL = 256 / Q;
     __shared__ f32x4 sh[2][RL][Q];
@@ -114,10 +124,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
     const bool ok = ch < C;
     if (ok) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), rs = *reinterpret_cast<const f32x4*>(rstd + ch);
+        f32x4 sc = mu, sf = mu;
+        if (zsc) { sc = *reinterpret_cast<const f32x4*>(zsc + ch); sf = *reinterpret_cast<const f32x4*>(zsf + ch); }
         auto one = [&](long r) {
             f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + ch);
             const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * C + ch);
-            if (ymask) {
+            if (zsc) {                                   // ReLU mask recomputed from z (the output is not read)
+                const f32x4 m = bn_affine(zz, sc, sf);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+            } else if (ymask) {
                 const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + r * C + ch);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
@@ -205,7 +221,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int c = (int)((i * 4) % C);
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sf = *reinterpret_cast<const f32x4*>(shift + c);
-        f32x4 v = z4[i] * sc + sf;
+        f32x4 v = bn_affine(z4[i], sc, sf);
         if (res) v += r4[i];
         if (relu) {
 #pragma unroll
@@ -233,7 +249,8 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 // partial sums for the BN backward: sum g and sum g*xhat per channel, g = dy * (ymask > 0 if given)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                             const float* __restrict__ z, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ part,
+                                                            const float* __restrict__ rstd, const float* __restrict__ zsc,
+                                                            const float* __restrict__ zsf, float* __restrict__ part,
                                                             long rows, int C, long rows_per_split) {
     __shared__ float sh[2][4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -242,11 +259,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     float sg = 0.f, sgx = 0.f;
     if (ch < C) {
         const float mu = mean[ch], rs = rstd[ch];
+        const float sc = zsc ? zsc[ch] : 0.f, sf = zsc ? zsf[ch] : 0.f;
         for (long r = r0 + rl; r < r1; r += 4) {
             float g = dy[r * C + ch];
-            if (ymask && !(ymask[r * C + ch] > 0.f)) g = 0.f;
+            const float zz = z[r * C + ch];
+            if (zsc ? !(__builtin_fmaf(zz, sc, sf) > 0.f) : (ymask && !(ymask[r * C + ch] > 0.f))) g = 0.f;
             sg += g;
-            sgx += g * ((z[r * C + ch] - mu) * rs);
+            sgx += g * ((zz - mu) * rs);
         }
     }
     sh[0][rl][c] = sg; sh[1][rl][c] = sgx;
@@ -290,6 +309,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                            const float* __restrict__ z, const float* __restrict__ coef,
+                                                           const float* __restrict__ zsc, const float* __restrict__ zsf,
                                                            float* __restrict__ dz, long n4, int C) {
     const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* m4 = reinterpret_cast<const f32x4*>(ymask);
@@ -300,12 +320,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 A = *reinterpret_cast<const f32x4*>(coef + c), B = *reinterpret_cast<const f32x4*>(coef + C + c),
                     C0 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
         f32x4 g = d4[i];
-        if (ymask) {
+        const f32x4 zz = z4[i];
+        if (zsc) {
+            const f32x4 m = bn_affine(zz, *reinterpret_cast<const f32x4*>(zsc + c), *reinterpret_cast<const f32x4*>(zsf + c));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+        } else if (ymask) {
             const f32x4 m = m4[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
         }
-        o4[i] = A * g + B * z4[i] + C0;
+        o4[i] = A * g + B * zz + C0;
     }
 }
 
@@ -500,20 +525,21 @@ hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStre
     return hipGetLastError();
 }
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
-                    const float* rstd, float* dz, float* dgamma, float* dbeta, long rows, int C, float* part, hipStream_t st) {
+                    const float* rstd, const float* zsc, const float* zsf, float* dz, float* dgamma, float* dbeta, long rows, int C,
+                    float* part, hipStream_t st) {
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
     float* coef = part + (long)splits * 2 * C;
     switch (quads_per_block(C)) {
-        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps); break;
-        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps); break;
-        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps); break;
-        default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, part, rows, C, rps);
+        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
+        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
+        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
+        default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
                        dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dy, ymask, z, coef, dz, n4, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C);
     return hipGetLastError();
 }
 hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {
@@ -1016,6 +1042,41 @@ __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __rest
     }
 }
 
+// the same gather with batch norm (+ ReLU) applied to a source on the way: v = [relu](fma(src, scale[ch], shift[ch])) for a
+// source whose scale is given.  conv3_1x1's BN+ReLU output (and the stride-2 shortcut's) is consumed only by the concat /
+// shuffle / split that follows (nets/shufflenet_v2.py:110-113): it is never written to HBM.
+__global__ __launch_bounds__(256) void channel_gather_affine_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                    float* __restrict__ out, const int* __restrict__ table,
+                                                                    long rows, int ca, int cb, int co,
+                                                                    const float* __restrict__ sca, const float* __restrict__ sfa, int relu_a,
+                                                                    const float* __restrict__ scb, const float* __restrict__ sfb, int relu_b) {
+    const int q = co >> 2;
+    const long total = rows * q;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k4 = (int)(i % q);
+        const long row = i / q;
+        const int4 t = *reinterpret_cast<const int4*>(table + 4 * k4);
+        const int tt[4] = {t.x, t.y, t.z, t.w};
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = 0.f;
+            if (tt[e] >= 0) {
+                const int ch = tt[e] & 0xffff;
+                if (tt[e] >> 16) {
+                    x = b[row * cb + ch];
+                    if (scb) { x = __builtin_fmaf(x, scb[ch], sfb[ch]); if (relu_b) x = fmaxf(x, 0.f); }
+                } else {
+                    x = a[row * ca + ch];
+                    if (sca) { x = __builtin_fmaf(x, sca[ch], sfa[ch]); if (relu_a) x = fmaxf(x, 0.f); }
+                }
+            }
+            v[e] = x;
+        }
+        *reinterpret_cast<f32x4*>(out + row * co + 4 * k4) = v;
+    }
+}
+
 }  // namespace
 
 hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
@@ -1055,6 +1116,13 @@ hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, i
     if (stride == 1) { switch (Q) { case 64: FTE_DWW(64, 1); break; case 32: FTE_DWW(32, 1); break; default: FTE_DWW(16, 1); } }
     else { switch (Q) { case 64: FTE_DWW(64, 2); break; case 32: FTE_DWW(32, 2); break; default: FTE_DWW(16, 2); } }
 #undef FTE_DWW
+    return hipGetLastError();
+}
+hipError_t l_channel_gather_affine(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co,
+                                   const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st) {
+    const long total = rows * (co / 4);
+    hipLaunchKernelGGL(channel_gather_affine_kernel, dim3((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0, st,
+                       a, b, out, table, rows, ca, cb, co, sca, sfa, relu_a, scb, sfb, relu_b);
     return hipGetLastError();
 }
 hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st) {

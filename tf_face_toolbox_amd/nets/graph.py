@@ -7,6 +7,7 @@ fusion -- and then forward / backward are fixed sequences of kernel launches on 
 It replaces the TF graph that nets/resnet.py builds and `tf.gradients` differentiates
 (data_parallel.py:33); every FLOP runs in libfte.so.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -38,6 +39,24 @@ def shuffle_perm(c, data_format):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+class _Activations(dict):
+    """name -> stored activation.  A BN output that was folded into the channel gather that consumes it is never stored;
+    asking for it (tests, debugging) recomputes it from z and the kept scale / shift."""
+
+    def __init__(self, net):
+        super(_Activations, self).__init__()
+        self.net = net
+
+    def __missing__(self, name):
+        net = self.net
+        if name not in net.folded:
+            raise KeyError(name)
+        z, relu = net.folded[name]
+        b = net.bn[name]
+        y = torch.addcmul(b['shift'], self[z], b['scale'])
+        return torch.relu(y) if relu else y
 
 
 class GraphNet(Network):
@@ -356,6 +375,28 @@ class GraphNet(Network):
                 plan.append(('gather', op[1], self._gather_tables(op)))
             else:
                 plan.append(op)
+        # A BN(+ReLU) output whose only consumer is a channel gather (conv3_1x1 and the stride-2 shortcut's 1x1 of a
+        # ShuffleNet block, nets/shufflenet_v2.py:96-113) is normalised INSIDE the gather: the BN op keeps its statistics
+        # pass only ('bnstats'), the gather applies scale / shift / ReLU to that source on the way
+        # (fte_channel_gather_affine), and the normalised tensor is never written (FTE_BN_GATHER=0: off, A/B hook).
+        self.folded = {}
+        if os.environ.get('FTE_BN_GATHER', '1') != '0':
+            pusers = {}
+            for j, op in enumerate(plan):
+                if op[0] == 'gather':
+                    ins = [x for x in op[2]['ins'] if x is not None]
+                elif op[0] in ('bn', 'addrelu'):
+                    ins = [op[2]] + ([op[4]] if op[0] == 'bn' and op[4] is not None else []) + ([op[3]] if op[0] == 'addrelu' else [])
+                else:
+                    ins = self._inputs(op)
+                for x in ins:
+                    pusers.setdefault(x, []).append(j)
+            for j, op in enumerate(plan):
+                if op[0] == 'bn' and op[4] is None:
+                    u = pusers.get(op[1], [])
+                    if len(u) == 1 and plan[u[0]][0] == 'gather' and op[1] != self.feature_name:
+                        plan[j] = ('bnstats',) + op[1:]
+                        self.folded[op[1]] = (op[2], op[5])          # name -> (z, relu)
         self.plan = plan
         self.has_classifier = plan[-1][0] == 'fc'
 
@@ -380,7 +421,7 @@ class GraphNet(Network):
             return
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
-        self.t = {}
+        self.t = _Activations(self)
         self.bn = {}
         self.ident = {}
         need = 1 << 20
@@ -392,8 +433,9 @@ class GraphNet(Network):
                     self.t[name] = torch.empty((n,) + self.shapes[name], **f32)
                 continue
             shape = (n,) + self.shapes[out]
-            self.t[out] = torch.empty(shape, **f32)
-            if kind == 'bn':
+            if kind != 'bnstats':
+                self.t[out] = torch.empty(shape, **f32)
+            if kind in ('bn', 'bnstats'):
                 c = shape[-1]
                 self.bn[out] = dict(mean=torch.empty(c, **f32), rstd=torch.empty(c, **f32), scale=torch.empty(c, **f32),
                                     shift=torch.empty(c, **f32))
@@ -442,6 +484,10 @@ class GraphNet(Network):
         need = max(need, 4 * n * fdim, 12 * n * n)
         self.ws = torch.empty((need + 3) // 4 + 1024, **f32)
         self.ws_bytes = self.ws.numel() * 4
+        # filter gradients run on a second HIP stream beside the data-gradient chain (backward_body): their own workspace
+        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('FTE_SIDE_PRIO', '0'))) if os.environ.get('FTE_SIDE_STREAM', '1') != '0' else None
+        self.ws_side = torch.empty_like(self.ws) if self.side is not None else self.ws
+        self.side_batch = int(os.environ.get('FTE_SIDE_BATCH', '3'))
         self._act_n = n
 
     # ---- forward ----------------------------------------------------------------------------------------
@@ -480,10 +526,32 @@ class GraphNet(Network):
                 call('fte_dwconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[4], st)
             elif kind == 'gather':
                 a, b = op[2]['ins']
+                fa, fb = self.folded.get(a), self.folded.get(b)
                 for name, table in op[2]['outs']:
                     co = self.shapes[name][-1]
-                    call('fte_channel_gather', T[a], T[b] if b else None, T[name], table, T[name].numel() // co,
-                         self.shapes[a][-1], self.shapes[b][-1] if b else 0, co, st)
+                    rows = T[name].numel() // co
+                    if fa is None and fb is None:
+                        call('fte_channel_gather', T[a], T[b] if b else None, T[name], table, rows,
+                             self.shapes[a][-1], self.shapes[b][-1] if b else 0, co, st)
+                    else:
+                        sa = (T[fa[0]], self.bn[a]['scale'], self.bn[a]['shift'], fa[1]) if fa else (T[a], None, None, 0)
+                        sb = (T[fb[0]], self.bn[b]['scale'], self.bn[b]['shift'], fb[1]) if fb else (T[b] if b else None, None, None, 0)
+                        call('fte_channel_gather_affine', sa[0], sb[0], T[name], table, rows, self.shapes[a][-1],
+                             self.shapes[b][-1] if b else 0, co, sa[1], sa[2], sa[3], sb[1], sb[2], sb[3], st)
+            elif kind == 'bnstats':
+                _, _, inp, pre, _, _ = op
+                b = self.bn[out]
+                c = self.shapes[out][-1]
+                rows = T[inp].numel() // c
+                if is_training:
+                    upd = self.update_moving_stats
+                    call('fte_bn_train_stats', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
+                         b['mean'], b['rstd'], b['scale'], b['shift'],
+                         self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None,
+                         rows, c, BN_EPS, BN_DECAY, self.ws, self.ws_bytes, st)
+                else:
+                    call('fte_bn_infer_coef', self.view(pre + '/gamma'), self.view(pre + '/beta'),
+                         self.state[pre + '/moving_mean'], self.state[pre + '/moving_variance'], b['scale'], b['shift'], c, BN_EPS, st)
             elif kind == 'bn':
                 _, _, inp, pre, res, relu = op
                 b = self.bn[out]
@@ -655,6 +723,27 @@ class GraphNet(Network):
             self._dfeat = None
         G = self._grad
         ops = self.plan[:-1] if self.has_classifier else self.plan
+        # Filter gradients (conv / depthwise / grouped wgrad + their slab reductions) depend only on the layer's dz and its
+        # stored input, and nothing but the optimizer reads them: they go to a second stream and overlap the dgrad -> BN
+        # backward chain (these nets' kernels are 5-60 us long and leave CUs idle at their ramps and tails).  An event on
+        # the main stream costs it a ~7 us bubble, so the launches are queued and released a few layers at a time.
+        main, side = torch.cuda.current_stream(), self.side
+        wst, wws = (side.cuda_stream, self.ws_side) if side is not None else (st, self.ws)
+        pending = []
+
+        def wgrad(name, dy, *args):
+            if side is None:
+                call(name, *args)
+            else:
+                pending.append((name, dy, args))
+
+        def flush(limit=0):
+            if len(pending) > limit:
+                side.wait_event(main.record_event())
+                for name, dy, args in pending:
+                    dy.record_stream(side)
+                    call(name, *args)
+                del pending[:]
         for op in reversed(ops):
             kind, out = op[0], op[1]
             if out == self.feature_name and self._dfeat is not None and out in G:
@@ -669,7 +758,7 @@ class GraphNet(Network):
                 da = G.pop(ga)
                 db = G.pop(gb) if gb else None
                 for name, table in op[2]['bwd']:
-                    g = self._new(name)
+                    g = torch.empty((n,) + self.shapes[name], dtype=torch.float32, device=self.device)
                     co = self.shapes[name][-1]
                     call('fte_channel_gather', da, db, g, table, g.numel() // co, da.shape[-1],
                          db.shape[-1] if db is not None else 0, co, st)
@@ -681,7 +770,7 @@ class GraphNet(Network):
             if kind == 'dwconv':
                 _, _, inp, wname, stride = op
                 ih, iw, c = self.shapes[inp]
-                call('fte_dwconv3x3_wgrad', T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, stride, self.ws, self.ws_bytes, st)
+                wgrad('fte_dwconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
                 call('fte_dwconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, stride, st)
                 self._put(inp, dx)
@@ -729,11 +818,11 @@ class GraphNet(Network):
             elif kind == 'gconv':
                 _, _, inp, wname, stride, groups = op
                 ih, iw, c = self.shapes[inp]
-                call('fte_gconv3x3_wgrad', T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, self.ws, self.ws_bytes, st)
+                wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
                 call('fte_gconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, groups, stride, st)
                 self._put(inp, dx)
-            elif kind == 'bn':
+            elif kind in ('bn', 'bnstats'):
                 _, _, inp, pre, res, relu = op
                 b = self.bn[out]
                 c = self.shapes[out][-1]
@@ -742,13 +831,16 @@ class GraphNet(Network):
                     g = self._new(out)
                     call('fte_relu_bwd', dy, T[out], g, dy.numel(), st)
                     self._put(res, g)
-                    dy, mask = g, None
+                    dy, relu = g, 0
+                dz = torch.empty_like(T[inp])
+                if relu:                                 # ReLU mask recomputed from z: the output is not read
+                    call('fte_bn_train_bwd_zmask', dy, T[inp], self.view(pre + '/gamma'), b['mean'], b['rstd'], b['scale'], b['shift'],
+                         dz, self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), rows, c,
+                         self.ws, self.ws_bytes, st)
                 else:
-                    mask = T[out] if relu else None
-                dz = self._new(inp)
-                call('fte_bn_train_bwd', dy, mask, T[inp], self.view(pre + '/gamma'), b['mean'], b['rstd'], dz,
-                     self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), rows, c,
-                     self.ws, self.ws_bytes, st)
+                    call('fte_bn_train_bwd', dy, None, T[inp], self.view(pre + '/gamma'), b['mean'], b['rstd'], dz,
+                         self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), rows, c,
+                         self.ws, self.ws_bytes, st)
                 self._put(inp, dz)
             elif kind == 'conv':
                 _, _, inp, wname, stride = op
@@ -760,7 +852,8 @@ class GraphNet(Network):
                     oh, ow, _ = self.shapes[out]
                     call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, stem_kpad(k, cin), self.ws, self.ws_bytes, st)
                     continue
-                call('fte_conv2d_wgrad', T[inp], dy, gw, n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                wgrad('fte_conv2d_wgrad', dy, T[inp], dy, gw, n, ih, iw, cin, cout, k, stride, wws, self.ws_bytes, wst)
+                flush(self.side_batch)
                 prev = G.pop(inp, None)                  # accumulate into an existing contribution through `addin`
                 dx = self._new(inp)
                 call('fte_conv2d_dgrad', dy, self.view(wname), prev, None, None, None, dx, None, None,
@@ -768,6 +861,9 @@ class GraphNet(Network):
                 G[inp] = dx
             else:
                 raise RuntimeError(kind)
+        if side is not None:
+            flush()
+            main.wait_stream(side)
         self._grad = {}
 
     def _put(self, name, g):
