@@ -157,8 +157,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
 }
 
 // merge the splits; scale = gamma*rstd, shift = beta - mean*scale; moving statistics (decay, unbiased var).
-// Block = 16 channels x 16 split lanes: a lane merges splits lane, lane+16, ..., the 16 lanes merge through LDS
-// (a single thread walking 64 dependent Chan merges took 38 us -- as long as the statistics pass itself).
+// Block = 16 channels x 16 split lanes.  The split partials (n_i, mean_i, M2_i) are combined as plain sums around the first
+// split's mean m0:  N = sum n_i,  D = sum n_i*(mean_i - m0),  Q = sum [M2_i + n_i*(mean_i - m0)^2]  ->  mean = m0 + D/N,
+// M2 = Q - D^2/N.  The split means differ from m0 by ~sigma/sqrt(n_i), so the subtraction cancels nothing that matters, every
+// load is independent (4 splits = 12 loads in flight per lane and trip) and there is no chain of dependent divisions: the
+// pairwise Chan merges this replaces, one after the other, took 10.7 us -- longer than the statistics pass itself.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int splits, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float decay, float* __restrict__ mean_out,
@@ -168,26 +171,36 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __shared__ float sh[3][16][16];
     const int cl = threadIdx.x & 15, lane = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cl;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (ch < C)
-        for (int s0 = lane; s0 < splits; s0 += 64) {        // 4 splits per trip: 12 independent loads, then the merges
+    const bool ok = ch < C;
+    const float m0 = ok ? part[C + ch] : 0.f;
+    float n = 0.f, d1 = 0.f, q = 0.f;
+    if (ok)
+        for (int s0 = lane; s0 < splits; s0 += 64) {
             float nb[4], mb[4], qb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int s = s0 + 16 * u;
-                const bool ok = s < splits;
-                const float* pp = part + (long)(ok ? s : 0) * 3 * C;
-                nb[u] = ok ? pp[ch] : 0.f; mb[u] = pp[C + ch]; qb[u] = pp[2 * C + ch];
+                const bool in = s < splits;
+                const float* pp = part + (long)(in ? s : 0) * 3 * C;
+                nb[u] = in ? pp[ch] : 0.f; mb[u] = pp[C + ch]; qb[u] = in ? pp[2 * C + ch] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) chan_merge(n, mean, m2, nb[u], mb[u], qb[u]);
+            for (int u = 0; u < 4; ++u) {
+                const float d = mb[u] - m0;
+                n += nb[u];
+                d1 += nb[u] * d;
+                q += qb[u] + nb[u] * d * d;
+            }
         }
-    sh[0][lane][cl] = n; sh[1][lane][cl] = mean; sh[2][lane][cl] = m2;
+    sh[0][lane][cl] = n; sh[1][lane][cl] = d1; sh[2][lane][cl] = q;
     __syncthreads();
-    if (lane != 0 || ch >= C) return;
+    if (lane != 0 || !ok) return;
+    float N = 0.f, D = 0.f, Q = 0.f;
 #pragma unroll
-    for (int l = 1; l < 16; ++l) chan_merge(n, mean, m2, sh[0][l][cl], sh[1][l][cl], sh[2][l][cl]);
-    const float var = m2 / n;
+    for (int l = 0; l < 16; ++l) { N += sh[0][l][cl]; D += sh[1][l][cl]; Q += sh[2][l][cl]; }
+    const float mean = m0 + D / N;
+    const float m2 = fmaxf(Q - D * D / N, 0.f);
+    const float var = m2 / N;
     const float rstd = 1.f / sqrtf(var + eps);
     mean_out[ch] = mean;
     rstd_out[ch] = rstd;
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     shift[ch] = beta[ch] - mean * sc;
     if (mov_mean) {
         mov_mean[ch] = decay * mov_mean[ch] + (1.f - decay) * mean;
-        mov_var[ch] = decay * mov_var[ch] + (1.f - decay) * (m2 / fmaxf(n - 1.f, 1.f));
+        mov_var[ch] = decay * mov_var[ch] + (1.f - decay) * (m2 / fmaxf(N - 1.f, 1.f));
     }
 }
 
