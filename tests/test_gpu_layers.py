@@ -18,6 +18,7 @@ def _rng(s):
 @pytest.mark.parametrize('n,h,w,cin,cout,ks,stride', [
     (3, 14, 14, 64, 256, 1, 1), (2, 14, 14, 256, 64, 1, 1), (3, 12, 12, 256, 512, 1, 2), (2, 7, 7, 512, 128, 1, 2),
     (2, 9, 9, 64, 64, 3, 2), (40, 14, 14, 1024, 256, 1, 1),
+    (360, 14, 14, 128, 128, 1, 1), (131, 7, 7, 256, 256, 1, 1), (5, 3, 3, 64, 64, 1, 1), (77, 4, 4, 512, 512, 1, 1),
 ])
 def test_conv2d_1x1_and_3x3(n, h, w, cin, cout, ks, stride):
     r = _rng(1)
@@ -37,6 +38,20 @@ def test_conv2d_1x1_and_3x3(n, h, w, cin, cout, ks, stride):
     dw = torch.empty(ks, ks, cin, cout, device='cuda')
     call('fte_conv2d_wgrad', dev(x), dev(dz), dw, n, h, w, cin, cout, ks, stride, wsb, nb, stream())
     check_maxabs(host(dw), dw_ref, what='wgrad')
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout', [(300, 7, 7, 128, 192), (9, 5, 5, 64, 64)])
+def test_conv1x1_dgrad_accumulates_into_an_existing_gradient(n, h, w, cin, cout):
+    """`addin` (a tensor with two consumers, nets/resnet.py shortcut + branch): dx = addin + dz * w^T, on the persistent kernel
+    (several tiles per block at the first shape)."""
+    r = _rng(11)
+    x = r.standard_normal((n, h, w, cin)); wt = r.standard_normal((1, 1, cin, cout)) * 0.05
+    dz = r.standard_normal((n, h, w, cout)); prev = r.standard_normal(x.shape)
+    dx_ref, _ = ops.conv2d_bwd(x, wt, dz, 1)
+    dx = torch.full(x.shape, 7.0, device='cuda')
+    wsb, nb = ws(query('fte_conv2d_dgrad_ws_bytes', n, h, w, cin, cout, 1, 1))
+    call('fte_conv2d_dgrad', dev(dz), dev(wt), dev(prev), None, None, None, dx, None, None, n, h, w, cin, cout, 1, 1, wsb, nb, stream())
+    check_maxabs(host(dx), dx_ref + prev, what='dgrad + addin')
 
 
 @pytest.mark.parametrize('rows_shape,c', [((3, 9, 7), 64), ((16, 28, 28), 256), ((2, 4, 4), 2048), ((64, 14, 14), 1024)])
