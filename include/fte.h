@@ -253,14 +253,18 @@ int fte_channel_gather(const float* a, const float* b, float* out, const int32_t
                        int ca, int cb, int co, void* stream);
 /* The gather with batch norm applied to a source on the way: a source whose scale is not NULL contributes
  * [relu](fma(src[row,ch], scale[ch], shift[ch])).  conv3_1x1's BN + ReLU output (:110) and the stride-2 shortcut's (:96-101)
- * feed only the concat / shuffle / split: they are normalised inside the gather and never written to HBM. */
-int fte_channel_gather_affine(const float* a, const float* b, float* out, const int32_t* table, long rows,
-                              int ca, int cb, int co, const float* scale_a, const float* shift_a, int relu_a,
+ * feed only the concat / shuffle / split: they are normalised inside the gather and never written to HBM.
+ * out1 / table1 / co1 (optional, NULL / NULL / 0): a second output of the same two sources in the same launch -- the two
+ * halves a block hands to the next one (forward), the gradients of the two sources (backward). */
+int fte_channel_gather_affine(const float* a, const float* b, float* out, const int32_t* table, int co,
+                              float* out1, const int32_t* table1, int co1, long rows, int ca, int cb,
+                              const float* scale_a, const float* shift_a, int relu_a,
                               const float* scale_b, const float* shift_b, int relu_b, void* stream);
 
 /* ---------------------------------------------------------------------------
- * First conv of the net (Cin = 1 or 3, stride 2; nets/sphere.py:57): K = 9*Cin
- * is too short for a GEMM -- HBM-bound direct convolution, fused bias+PReLU.
+ * First conv of the net (Cin = 1 or 3; nets/sphere.py:57, nets/shufflenet_v2.py:148-149): K = 9*Cin
+ * is too short for a GEMM -- HBM-bound direct convolution, fused bias+PReLU (both optional).
+ * cout = 64, or 32 for the 24-wide ShuffleNet-v2 stem stored 32 channels wide (w is [3,3,cin,cout]).
  * ------------------------------------------------------------------------- */
 int fte_conv3x3_first_fwd(const float* x, const float* w, const float* bias, const float* alpha,
                           float* z, float* y, int n, int h, int wd, int cin, int cout,

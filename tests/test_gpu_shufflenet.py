@@ -100,11 +100,17 @@ def test_bn_folded_into_the_gather_is_the_unfused_sequence_bit_for_bit(rows, c):
     table = torch.tensor([((j // c) << 16) | (j % c) for j in perm[:c]], dtype=torch.int32, device='cuda')
     o0 = torch.empty(rows, c, device='cuda'); o1 = torch.empty(rows, c, device='cuda'); o2 = torch.empty(rows, c, device='cuda')
     _lib.call('fte_channel_gather', s_in, y, o0, table, rows, c, c, c, stream())
-    _lib.call('fte_channel_gather_affine', s_in, z, o1, table, rows, c, c, c, None, None, 0, m1[2], m1[3], 1, stream())
+    _lib.call('fte_channel_gather_affine', s_in, z, o1, table, c, None, None, 0, rows, c, c, None, None, 0, m1[2], m1[3], 1, stream())
     assert torch.equal(o0, o1)
     _lib.call('fte_channel_gather', y, s_in, o0, table, rows, c, c, c, stream())
-    _lib.call('fte_channel_gather_affine', z, s_in, o2, table, rows, c, c, c, m1[2], m1[3], 1, None, None, 0, stream())
+    _lib.call('fte_channel_gather_affine', z, s_in, o2, table, c, None, None, 0, rows, c, c, m1[2], m1[3], 1, None, None, 0, stream())
     assert torch.equal(o0, o2)
+    # two outputs in one launch == two launches
+    table_b = torch.tensor([((j // c) << 16) | (j % c) for j in perm[c:]], dtype=torch.int32, device='cuda')
+    o3 = torch.empty(rows, c, device='cuda'); o4 = torch.empty(rows, c, device='cuda'); o5 = torch.empty(rows, c, device='cuda')
+    _lib.call('fte_channel_gather', y, s_in, o3, table_b, rows, c, c, c, stream())
+    _lib.call('fte_channel_gather_affine', z, s_in, o4, table, c, o5, table_b, c, rows, c, c, m1[2], m1[3], 1, None, None, 0, stream())
+    assert torch.equal(o4, o0) and torch.equal(o5, o3)
     outs = []
     for zmask in (False, True):
         dz = torch.empty_like(z); dg = torch.empty(c, device='cuda'); db = torch.empty(c, device='cuda')

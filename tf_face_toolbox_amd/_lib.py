@@ -68,7 +68,7 @@ _SIGS = {
     'fte_dwconv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),
     'fte_dwconv3x3_wgrad_ws_bytes': (c_size_t, [c_int] * 5),
     'fte_channel_gather': (c_int, [_P] * 4 + [c_long] + [c_int] * 3 + [_P]),
-    'fte_channel_gather_affine': (c_int, [_P] * 4 + [c_long] + [c_int] * 3 + [_P, _P, c_int, _P, _P, c_int, _P]),
+    'fte_channel_gather_affine': (c_int, [_P] * 4 + [c_int, _P, _P, c_int, c_long, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P]),
     'fte_conv3x3_first_fwd': (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
     'fte_conv3x3_first_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_first_wgrad_ws_bytes': (c_size_t, [c_int] * 6),

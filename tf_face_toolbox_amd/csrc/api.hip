@@ -560,9 +560,9 @@ int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, 
 // ------------------------------------------------------------------------------------------------
 int fte_conv3x3_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
                           int n, int h, int wd, int cin, int cout, int stride, void* stream) {
-    if (!x || !w || !y || cout != 64 || (cin != 1 && cin != 3)) return FTE_EINVAL;
+    if (!x || !w || !y || (cout != 64 && cout != 32) || (cin != 1 && cin != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
-    return rc(k_conv_first_fwd(x, w, bias, alpha, z, y, n, h, wd, cin, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+    return rc(k_conv_first_fwd(x, w, bias, alpha, z, y, n, h, wd, cin, cout, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
 }
 
 size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -572,12 +572,12 @@ size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout,
 
 int fte_conv3x3_first_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
                             void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dz || !dw || cout != 64 || (cin != 1 && cin != 3)) return FTE_EINVAL;
+    if (!x || !dz || !dw || (cout != 64 && cout != 32) || (cin != 1 && cin != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     const int blocks = k_conv_first_wgrad_blocks((long)n * ph.out * pw.out);
     const size_t need = align_up((size_t)blocks * 9 * cin * cout * sizeof(float));
     if (!ws || ws_bytes < need + SCRATCH_BYTES) return FTE_EWORKSPACE;
-    hipError_t e = k_conv_first_wgrad(x, dz, (float*)ws, n, h, wd, cin, ph.out, pw.out, stride, ph.before, pw.before, blocks, (hipStream_t)stream);
+    hipError_t e = k_conv_first_wgrad(x, dz, (float*)ws, n, h, wd, cin, cout, ph.out, pw.out, stride, ph.before, pw.before, blocks, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, blocks, 9L * cin * cout, 1, 1.f, (float*)((char*)ws + need), (hipStream_t)stream));
 }
@@ -940,12 +940,14 @@ int fte_channel_gather(const float* a, const float* b, float* out, const int32_t
     if (!a || !out || !table || rows <= 0 || co <= 0 || co % 4) return FTE_EINVAL;      // the table is read 4 entries at a time
     return rc(l_channel_gather(a, b ? b : a, out, table, rows, ca, cb, co, (hipStream_t)stream));
 }
-int fte_channel_gather_affine(const float* a, const float* b, float* out, const int32_t* table, long rows, int ca, int cb, int co,
+int fte_channel_gather_affine(const float* a, const float* b, float* out, const int32_t* table, int co,
+                              float* out1, const int32_t* table1, int co1, long rows, int ca, int cb,
                               const float* scale_a, const float* shift_a, int relu_a,
                               const float* scale_b, const float* shift_b, int relu_b, void* stream) {
     if (!a || !out || !table || rows <= 0 || co <= 0 || co % 4 || (scale_a && !shift_a) || (scale_b && (!shift_b || !b))) return FTE_EINVAL;
-    return rc(l_channel_gather_affine(a, b ? b : a, out, table, rows, ca, cb, co, scale_a, shift_a, relu_a, scale_b, shift_b, relu_b,
-                                      (hipStream_t)stream));
+    if (out1 ? (!table1 || co1 <= 0 || co1 % 4) : co1 != 0) return FTE_EINVAL;
+    return rc(l_channel_gather_affine(a, b ? b : a, out, table, co, out1, table1, co1, rows, ca, cb, scale_a, shift_a, relu_a,
+                                      scale_b, shift_b, relu_b, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -46,15 +46,16 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 // A wave walks 32-pixel groups of whole output rows.
 // ------------------------------------------------------------------------------------
 typedef float f32x16f __attribute__((ext_vector_type(16)));
-template <int CIN>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ alpha, float* __restrict__ z, float* __restrict__ y,
     int n, int h, int wd, int ho, int wo, int stride, int pt, int pl) {
-    constexpr int COUT = 64, K = 9 * CIN, KS = (K + 1) / 2;
+    constexpr int NH = COUT / 32, K = 9 * CIN, KS = (K + 1) / 2;      // NH accumulator blocks of 32 output channels
+    static_assert(COUT == 32 || COUT == 64, "cout 32 (the 24-wide ShuffleNet stem, padded) or 64");
     const int lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
-    float wb0[KS], wb1[KS];
+    float wb[NH][KS];
     int kr[KS], kq[KS], kc[KS];                 // (row tap, column tap, channel) of this lane's k index in every k-step
     bool kv[KS];
 #pragma unroll
@@ -64,11 +65,12 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
         const int kk = kv[s] ? k : 0;
         const int tap = kk / CIN;
         kc[s] = kk - tap * CIN; kr[s] = tap / 3; kq[s] = tap - 3 * (tap / 3);
-        wb0[s] = kv[s] ? w[kk * COUT + li] : 0.f;
-        wb1[s] = kv[s] ? w[kk * COUT + 32 + li] : 0.f;
+#pragma unroll
+        for (int e = 0; e < NH; ++e) wb[e][s] = kv[s] ? w[kk * COUT + 32 * e + li] : 0.f;
     }
-    const float b0 = bias ? bias[li] : 0.f, b1 = bias ? bias[32 + li] : 0.f;
-    const float a0 = alpha ? alpha[li] : 1.f, a1 = alpha ? alpha[32 + li] : 1.f;
+    float bb[NH], aa[NH];
+#pragma unroll
+    for (int e = 0; e < NH; ++e) { bb[e] = bias ? bias[32 * e + li] : 0.f; aa[e] = alpha ? alpha[32 * e + li] : 1.f; }
     const int gpr = (wo + 31) / 32;                                  // 32-pixel groups per output row
     const long ngrp = (long)n * ho * gpr;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -78,9 +80,11 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
         const int oh = (int)(row % ho), img = (int)(row / ho);
         const int ow = g * 32 + li;
         const bool pok = ow < wo;
-        f32x16f acc0, acc1;
+        f32x16f acc[NH];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        for (int e = 0; e < NH; ++e)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
         float av[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -90,10 +94,9 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
             av[s] = ok ? v : 0.f;
         }
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb0[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb1[s], acc1, 0, 0, 0);
-        }
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < NH; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], wb[e][s], acc[e], 0, 0, 0);
         // C layout: column (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         const long obase = ((long)(img * ho + oh) * wo + g * 32) * COUT;
 #pragma unroll
@@ -101,10 +104,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
             const int pr = (i & 3) + 8 * (i >> 2) + 4 * lh;
             if (g * 32 + pr < wo) {
                 const long o = obase + (long)pr * COUT + li;
-                float v0 = acc0[i] + b0, v1 = acc1[i] + b1;
-                if (z) { z[o] = v0; z[o + 32] = v1; }
-                if (alpha) { v0 = v0 > 0.f ? v0 : a0 * v0; v1 = v1 > 0.f ? v1 : a1 * v1; }
-                y[o] = v0; y[o + 32] = v1;
+#pragma unroll
+                for (int e = 0; e < NH; ++e) {
+                    float v = acc[e][i] + bb[e];
+                    if (z) z[o + 32 * e] = v;
+                    if (alpha) v = v > 0.f ? v : aa[e] * v;
+                    y[o + 32 * e] = v;
+                }
             }
         }
     }
@@ -117,11 +123,11 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
 // of the 28 loads per pixel of a lane-per-output-channel loop (which ran at 10 % of HBM speed).  A wave owns whole output
 // rows; the 4 waves of a block are summed through LDS and each block writes one ordered partial.
 typedef float f32x16k __attribute__((ext_vector_type(16)));
-template <int CIN>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ part,
     int n, int h, int wd, int ho, int wo, int stride, int pt, int pl, long rows_per_block) {
-    constexpr int COUT = 64, K = 9 * CIN;
+    constexpr int NH = COUT / 32, K = 9 * CIN;
     __shared__ float red[4][32][COUT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -130,9 +136,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
     const int r = tap / 3, sx = tap - r * 3;
     const long nrows = (long)n * ho;                       // output rows (img, oh)
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
-    f32x16k acc0, acc1;
+    f32x16k acc[NH];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int e = 0; e < NH; ++e)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
     for (long row = r0 + wv; row < r1; row += 4) {
         const int img = (int)(row / ho), oh = (int)(row - (long)img * ho);
         const int ih = oh * stride + r - pt;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
         const float* drow = dz + row * wo * COUT;
         constexpr int UP = 4;                               // pixel pairs per trip: 12 independent loads
         for (int ow0 = 0; ow0 < wo; ow0 += 2 * UP) {
-            float a[UP], b0[UP], b1[UP];
+            float a[UP], bv[NH][UP];
 #pragma unroll
             for (int u = 0; u < UP; ++u) {
                 const int ow = ow0 + 2 * u + lh;
@@ -151,23 +159,21 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
                 const float av = xrow[(long)(ok ? iw : 0) * CIN];
                 a[u] = ok ? av : 0.f;
                 const float* d = drow + (long)(pok ? ow : 0) * COUT;
-                const float v0 = d[li], v1 = d[32 + li];
-                b0[u] = pok ? v0 : 0.f;
-                b1[u] = pok ? v1 : 0.f;
+#pragma unroll
+                for (int e = 0; e < NH; ++e) { const float v = d[32 * e + li]; bv[e][u] = pok ? v : 0.f; }
             }
 #pragma unroll
-            for (int u = 0; u < UP; ++u) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b1[u], acc1, 0, 0, 0);
-            }
+            for (int u = 0; u < UP; ++u)
+#pragma unroll
+                for (int e = 0; e < NH; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[e][u], acc[e], 0, 0, 0);
         }
     }
     // C layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int k = (i & 3) + 8 * (i >> 2) + 4 * lh;
-        red[wv][k][li] = acc0[i];
-        red[wv][k][32 + li] = acc1[i];
+#pragma unroll
+        for (int e = 0; e < NH; ++e) red[wv][k][32 * e + li] = acc[e][i];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K * COUT; i += 256) {
@@ -569,24 +575,32 @@ inline int grid_for(long n, int per) { long b = (n + per - 1) / per; return (int
 // host launchers
 // ---------------------------------------------------------------------------------------------------
 hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
-                            int n, int h, int wd, int cin, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
+                            int n, int h, int wd, int cin, int cout, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
     const long ngrp = (long)n * ho * ((wo + 31) / 32);
     long nb = (ngrp + 3) / 4;
     if (nb > 4096) nb = 4096;
     const int blocks = (int)nb;
-    if (cin == 1) hipLaunchKernelGGL(conv_first_fwd_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl);
-    else if (cin == 3) hipLaunchKernelGGL(conv_first_fwd_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl);
+#define FTE_CF(CI_, CO_) hipLaunchKernelGGL((conv_first_fwd_kernel<CI_, CO_>), dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl)
+    if (cin == 1 && cout == 64) FTE_CF(1, 64);
+    else if (cin == 3 && cout == 64) FTE_CF(3, 64);
+    else if (cin == 1 && cout == 32) FTE_CF(1, 32);
+    else if (cin == 3 && cout == 32) FTE_CF(3, 32);
     else return hipErrorInvalidValue;
+#undef FTE_CF
     return hipGetLastError();
 }
 int k_conv_first_wgrad_blocks(long npix) { long b = (npix + 511) / 512; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
-hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int cin, int ho, int wo,
+hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int cin, int cout, int ho, int wo,
                               int stride, int pt, int pl, int blocks, hipStream_t st) {
     const long nrows = (long)n * ho;
     const long rpb = (nrows + blocks - 1) / blocks;           // blocks that get no rows write zero partials
-    if (cin == 1) hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(blocks), dim3(256), 0, st, x, dz, part, n, h, wd, ho, wo, stride, pt, pl, rpb);
-    else if (cin == 3) hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(blocks), dim3(256), 0, st, x, dz, part, n, h, wd, ho, wo, stride, pt, pl, rpb);
+#define FTE_CW(CI_, CO_) hipLaunchKernelGGL((conv_first_wgrad_kernel<CI_, CO_>), dim3(blocks), dim3(256), 0, st, x, dz, part, n, h, wd, ho, wo, stride, pt, pl, rpb)
+    if (cin == 1 && cout == 64) FTE_CW(1, 64);
+    else if (cin == 3 && cout == 64) FTE_CW(3, 64);
+    else if (cin == 1 && cout == 32) FTE_CW(1, 32);
+    else if (cin == 3 && cout == 32) FTE_CW(3, 32);
     else return hipErrorInvalidValue;
+#undef FTE_CW
     return hipGetLastError();
 }
 // scratch: REDUCE_SCRATCH_FLOATS floats, only touched when the matrix is tall and narrow

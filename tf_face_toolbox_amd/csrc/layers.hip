@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
 
 inline int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
-inline int quads_per_block(int C) { return C % 4 ? 0 : (C >= 256 ? 64 : (C >= 128 ? 32 : (C >= 64 ? 16 : 0))); }
+inline int quads_per_block(int C) { return C % 4 ? 0 : (C >= 256 ? 64 : (C >= 128 ? 32 : (C >= 64 ? 16 : (C >= 32 ? 8 : 0)))); }
 
 inline void stat_split(long rows, int C, int* splits, long* rps) {
     const int Q = quads_per_block(C);
@@ -516,6 +516,7 @@ hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* bet
         case 64: hipLaunchKernelGGL(bn_stats_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
         case 32: hipLaunchKernelGGL(bn_stats_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
         case 16: hipLaunchKernelGGL(bn_stats_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
+        case 8: hipLaunchKernelGGL(bn_stats_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
         default: hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
@@ -547,6 +548,7 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
         case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
         case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
         case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
+        case 8: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
         default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
@@ -1057,18 +1059,22 @@ __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __rest
 
 // the same gather with batch norm (+ ReLU) applied to a source on the way: v = [relu](fma(src, scale[ch], shift[ch])) for a
 // source whose scale is given.  conv3_1x1's BN+ReLU output (and the stride-2 shortcut's) is consumed only by the concat /
-// shuffle / split that follows (nets/shufflenet_v2.py:110-113): it is never written to HBM.
+// shuffle / split that follows (nets/shufflenet_v2.py:110-113): it is never written to HBM.  Two outputs in one launch
+// (out1 / table1 / co1, optional): the two halves a block hands to the next one, or the gradients of both sources.
 __global__ __launch_bounds__(256) void channel_gather_affine_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                                    float* __restrict__ out, const int* __restrict__ table,
-                                                                    long rows, int ca, int cb, int co,
+                                                                    float* __restrict__ out0, const int* __restrict__ table0, int co0,
+                                                                    float* __restrict__ out1, const int* __restrict__ table1, int co1,
+                                                                    long rows, int ca, int cb,
                                                                     const float* __restrict__ sca, const float* __restrict__ sfa, int relu_a,
                                                                     const float* __restrict__ scb, const float* __restrict__ sfb, int relu_b) {
-    const int q = co >> 2;
+    const int q0 = co0 >> 2, q = q0 + (co1 >> 2);
     const long total = rows * q;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int k4 = (int)(i % q);
+        int k4 = (int)(i % q);
         const long row = i / q;
-        const int4 t = *reinterpret_cast<const int4*>(table + 4 * k4);
+        const bool second = k4 >= q0;
+        if (second) k4 -= q0;
+        const int4 t = *reinterpret_cast<const int4*>((second ? table1 : table0) + 4 * k4);
         const int tt[4] = {t.x, t.y, t.z, t.w};
         f32x4 v;
 #pragma unroll
@@ -1086,7 +1092,7 @@ __global__ __launch_bounds__(256) void channel_gather_affine_kernel(const float*
             }
             v[e] = x;
         }
-        *reinterpret_cast<f32x4*>(out + row * co + 4 * k4) = v;
+        *reinterpret_cast<f32x4*>((second ? out1 + row * co1 : out0 + row * co0) + 4 * k4) = v;
     }
 }
 
@@ -1131,11 +1137,12 @@ hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, i
 #undef FTE_DWW
     return hipGetLastError();
 }
-hipError_t l_channel_gather_affine(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co,
+hipError_t l_channel_gather_affine(const float* a, const float* b, float* out0, const int* table0, int co0,
+                                   float* out1, const int* table1, int co1, long rows, int ca, int cb,
                                    const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st) {
-    const long total = rows * (co / 4);
+    const long total = rows * ((co0 + co1) / 4);
     hipLaunchKernelGGL(channel_gather_affine_kernel, dim3((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0, st,
-                       a, b, out, table, rows, ca, cb, co, sca, sfa, relu_a, scb, sfb, relu_b);
+                       a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b);
     return hipGetLastError();
 }
 hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st) {

@@ -109,6 +109,20 @@ class GraphNet(Network):
         self.cpad = (self.num_classes + 127) // 128 * 128
         self.graph, spec = self.build_graph(channels, num_classes)
         self.spec = OrderedDict((n, (s, k)) for n, s, k in spec)
+        # A 3x3 stem of at most 32 filters (ShuffleNet-v2 small: 24) is stored 32 channels wide, not channel_pad wide: its
+        # 56x56 output is the largest tensor of the net, and every pass over it (BN statistics / apply, max-pool, their
+        # gradients) is pure HBM traffic -- 64-wide storage made 62 % of those bytes padding.  `narrow` = the variables
+        # (filter, BN gamma / beta) that follow that width.
+        self.narrow = set()
+        if self.channel_pad > 32 and os.environ.get('FTE_DIRECT_STEM', '1') != '0':
+            for op in self.graph:
+                if op[0] == 'conv':
+                    k, _, cin, cout = self.spec[op[3]][0]
+                    if cin <= 4 and k == 3 and cout <= 32:
+                        self.narrow.add(op[3])
+                        for o2 in self.graph:
+                            if o2[0] == 'bn' and o2[2] == op[1]:
+                                self.narrow.update([o2[3] + '/gamma', o2[3] + '/beta'])
         self._infer_shapes()
         small = [(n, s, k) for n, s, k in spec if k in ('gamma', 'beta', 'bias')]
         convs = [(n, s, k) for n, s, k in spec if k in ('conv_w', 'gconv_w', 'fc_w', 'dw_w')]
@@ -117,7 +131,7 @@ class GraphNet(Network):
         off = 0
         self.ishape = {}
         for n, s, k in small + convs + cls:
-            self.ishape[n] = self._internal_shape(s, k)
+            self.ishape[n] = self._internal_shape(s, k, n)
             size = 1
             for d in self.ishape[n]:
                 size *= d
@@ -137,17 +151,18 @@ class GraphNet(Network):
         for n, s, k in small:
             if k == 'gamma':
                 pre = n[:-len('/gamma')]
-                self.state[pre + '/moving_mean'] = torch.zeros(self._pc(s[0]), dtype=torch.float32, device=dev)
-                self.state[pre + '/moving_variance'] = torch.ones(self._pc(s[0]), dtype=torch.float32, device=dev)
+                cp = self.ishape[n][0]
+                self.state[pre + '/moving_mean'] = torch.zeros(cp, dtype=torch.float32, device=dev)
+                self.state[pre + '/moving_variance'] = torch.ones(cp, dtype=torch.float32, device=dev)
                 self.state_ref[pre + '/moving_mean'] = self.state_ref[pre + '/moving_variance'] = s[0]
         self._init_params()
         self._compile()
         self.built = True
         return self
 
-    def _internal_shape(self, shape, kind):
+    def _internal_shape(self, shape, kind, name=None):
         """arena layout of a variable whose reference shape is `shape`"""
-        pc = self._pc
+        pc = (lambda c: (c + 31) // 32 * 32) if name in self.narrow else self._pc
         if kind == 'cls_w':
             assert pc(shape[0]) == shape[0]
             return (shape[0], self.cpad)
@@ -268,6 +283,8 @@ class GraphNet(Network):
                 k, _, cin, cout = self.spec[op[3]][0]
                 assert cin == real[op[2]], (op, cin, real[op[2]])
                 put(out, same_pads(ih, k, op[4])[0], same_pads(iw, k, op[4])[0], cout)
+                if op[3] in self.narrow:
+                    shp[out] = shp[out][:2] + ((cout + 31) // 32 * 32,)
             elif kind in ('gconv', 'dwconv'):
                 ih, iw, _ = shp[op[2]]
                 put(out, same_pads(ih, 3, op[4])[0], same_pads(iw, 3, op[4])[0], real[op[2]])
@@ -275,8 +292,9 @@ class GraphNet(Network):
                 shp[out] = shp[op[2]]
                 real[out] = real[op[2]]
             elif kind == 'maxpool':
-                ih, iw, _ = shp[op[2]]
+                ih, iw, cp = shp[op[2]]
                 put(out, same_pads(ih, 3, 2)[0], same_pads(iw, 3, 2)[0], real[op[2]])
+                shp[out] = shp[out][:2] + (cp,)                 # keeps its input's stored width
             elif kind == 'gap':
                 shp[out] = (shp[op[2]][2],)
                 real[out] = real[op[2]]
@@ -448,6 +466,8 @@ class GraphNet(Network):
                     need = max(need, q('fte_conv2d_fwd_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_dgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_wgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]))
+                elif self._direct_stem(k, cin, cout):
+                    need = max(need, q('fte_conv3x3_first_wgrad_ws_bytes', n, ih, iw, cin, cout, op[4]))
                 else:
                     oh, ow, _ = self.shapes[out]
                     kpad = stem_kpad(k, cin)
@@ -515,7 +535,9 @@ class GraphNet(Network):
                 if cin >= 32:
                     call('fte_conv2d_fwd', T[inp], self.view(wname), None, None, None, None, T[out],
                          n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
-                else:                                          # stem: im2col + dense MFMA GEMM
+                elif self._direct_stem(k, cin, cout):          # 3x3 stem of 32 / 64 stored filters: the direct MFMA kernel
+                    call('fte_conv3x3_first_fwd', T[inp], self.view(wname), None, None, None, T[out], n, ih, iw, cin, cout, stride, st)
+                else:                                          # other stems (7x7): im2col + dense MFMA GEMM
                     oh, ow, _ = self.shapes[out]
                     kpad = stem_kpad(k, cin)
                     call('fte_im2col_first', T[inp], self.cols, n, ih, iw, cin, k, stride, kpad, st)
@@ -527,17 +549,20 @@ class GraphNet(Network):
             elif kind == 'gather':
                 a, b = op[2]['ins']
                 fa, fb = self.folded.get(a), self.folded.get(b)
-                for name, table in op[2]['outs']:
+                outs = op[2]['outs']
+                if fa is None and fb is None and len(outs) == 1:
+                    name, table = outs[0]
                     co = self.shapes[name][-1]
-                    rows = T[name].numel() // co
-                    if fa is None and fb is None:
-                        call('fte_channel_gather', T[a], T[b] if b else None, T[name], table, rows,
-                             self.shapes[a][-1], self.shapes[b][-1] if b else 0, co, st)
-                    else:
-                        sa = (T[fa[0]], self.bn[a]['scale'], self.bn[a]['shift'], fa[1]) if fa else (T[a], None, None, 0)
-                        sb = (T[fb[0]], self.bn[b]['scale'], self.bn[b]['shift'], fb[1]) if fb else (T[b] if b else None, None, None, 0)
-                        call('fte_channel_gather_affine', sa[0], sb[0], T[name], table, rows, self.shapes[a][-1],
-                             self.shapes[b][-1] if b else 0, co, sa[1], sa[2], sa[3], sb[1], sb[2], sb[3], st)
+                    call('fte_channel_gather', T[a], T[b] if b else None, T[name], table, T[name].numel() // co,
+                         self.shapes[a][-1], self.shapes[b][-1] if b else 0, co, st)
+                else:                                          # both halves in one launch, BN applied to a folded source
+                    sa = (T[fa[0]], self.bn[a]['scale'], self.bn[a]['shift'], fa[1]) if fa else (T[a], None, None, 0)
+                    sb = (T[fb[0]], self.bn[b]['scale'], self.bn[b]['shift'], fb[1]) if fb else (T[b] if b else None, None, None, 0)
+                    (n0, t0), (n1, t1) = outs[0], (outs[1] if len(outs) > 1 else (None, None))
+                    co0 = self.shapes[n0][-1]
+                    call('fte_channel_gather_affine', sa[0], sb[0], T[n0], t0, co0, T[n1] if n1 else None, t1,
+                         self.shapes[n1][-1] if n1 else 0, T[n0].numel() // co0, self.shapes[a][-1],
+                         self.shapes[b][-1] if b else 0, sa[1], sa[2], sa[3], sb[1], sb[2], sb[3], st)
             elif kind == 'bnstats':
                 _, _, inp, pre, _, _ = op
                 b = self.bn[out]
@@ -604,6 +629,12 @@ class GraphNet(Network):
                 call('fte_gemm_nn', T[op[2]], self.view(op[3]), None, T[out], n, self.cpad, k, self.ws, self.ws_bytes, st)
             else:
                 raise RuntimeError('op %s must have been fused away' % kind)
+
+    @staticmethod
+    def _direct_stem(k, cin, cout):
+        """3x3 first conv on 1 / 3 image channels with 32 or 64 stored filters: fte_conv3x3_first_* (K = 9*cin is too short for
+        the GEMM path's im2col round trip through HBM)"""
+        return k == 3 and cin in (1, 3) and cout in (32, 64) and os.environ.get('FTE_DIRECT_STEM', '1') != '0'
 
     def _se_names(self, op):
         """('se', out, inp, prefix[, scope1, scope2]) -> weight / bias names of the two FCs and the (padded) hidden width"""
@@ -757,11 +788,17 @@ class GraphNet(Network):
                     continue
                 da = G.pop(ga)
                 db = G.pop(gb) if gb else None
-                for name, table in op[2]['bwd']:
-                    g = torch.empty((n,) + self.shapes[name], dtype=torch.float32, device=self.device)
-                    co = self.shapes[name][-1]
-                    call('fte_channel_gather', da, db, g, table, g.numel() // co, da.shape[-1],
-                         db.shape[-1] if db is not None else 0, co, st)
+                gs = [(name, table, torch.empty((n,) + self.shapes[name], dtype=torch.float32, device=self.device))
+                      for name, table in op[2]['bwd']]
+                (n0, t0, g0), (n1, t1, g1) = gs[0], (gs[1] if len(gs) > 1 else (None, None, None))
+                co0 = self.shapes[n0][-1]
+                if g1 is None:
+                    call('fte_channel_gather', da, db, g0, t0, g0.numel() // co0, da.shape[-1],
+                         db.shape[-1] if db is not None else 0, co0, st)
+                else:                                    # the gradients of both sources in one launch
+                    call('fte_channel_gather_affine', da, db, g0, t0, co0, g1, t1, self.shapes[n1][-1], g0.numel() // co0,
+                         da.shape[-1], db.shape[-1] if db is not None else 0, None, None, 0, None, None, 0, st)
+                for name, _, g in gs:
                     self._put(name, g)
                 continue
             if out not in G:
@@ -848,6 +885,9 @@ class GraphNet(Network):
                 k = self.spec[wname][0][0]
                 cout = self.shapes[out][-1]
                 gw = self.view(wname, self.grads)
+                if cin < 32 and self._direct_stem(k, cin, cout):
+                    call('fte_conv3x3_first_wgrad', T[inp], dy, gw, n, ih, iw, cin, cout, stride, self.ws, self.ws_bytes, st)
+                    continue
                 if cin < 32:                             # stem: filter gradient only
                     oh, ow, _ = self.shapes[out]
                     call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, stem_kpad(k, cin), self.ws, self.ws_bytes, st)
