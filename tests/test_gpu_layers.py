@@ -94,7 +94,7 @@ def test_batch_norm_train_fwd_bwd(rows_shape, c):
     check_maxabs(host(y), ops.bn_infer(z, gamma, beta, mm, mv), what='bn infer')
 
 
-@pytest.mark.parametrize('n,h,w,c', [(2, 56, 56, 64), (3, 7, 6, 8), (2, 13, 9, 24)])
+@pytest.mark.parametrize('n,h,w,c', [(2, 56, 56, 64), (3, 7, 6, 8), (2, 13, 9, 24), (1, 2, 2, 4), (3, 4, 6, 32), (2, 8, 7, 8)])
 def test_maxpool_gap_dropout(n, h, w, c):
     r = _rng(3)
     x = r.integers(0, 4, (n, h, w, c)).astype(np.float64) + 0.25 * r.integers(0, 2, (n, h, w, c))   # plenty of ties

@@ -273,6 +273,49 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     if (threadIdx.x == 0) loss_rows[row] = bad ? NAN : logf(s) - (z[y] - mx);
 }
 
+// The same loss with the row held in registers (c <= 256 * NPT): one read of the logits instead of three passes -- 512 rows x
+// 10575 classes took 36 us (15 % of HBM speed) walking each 42-KB row three times with two blocks per CU.  Same arithmetic in the
+// same order per thread (strided ownership j = t + 256*i), same block reductions: results are bit-identical to the generic kernel.
+template <int NPT>
+__global__ __launch_bounds__(256) void softmax_ce_reg_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                             float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                             int c, int ld, float gscale) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    const float* z = logits + (long)row * ld;
+    float* d = dlogits + (long)row * ld;
+    float v[NPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int j = threadIdx.x + 256 * i;
+        v[i] = j < c ? z[j] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = block_max(mx, sh);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int j = threadIdx.x + 256 * i;
+        v[i] = expf(v[i] - mx);
+        if (j < c) s += v[i];
+    }
+    s = block_sum(s, sh);
+    const int yl = labels[row];
+    const bool bad = (unsigned)yl >= (unsigned)c;
+    const int y = bad ? 0 : yl;
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int j = threadIdx.x + 256 * i;
+        if (j < ld) {
+            const float g = j < c ? (v[i] * inv - (j == y ? 1.f : 0.f)) * gscale : 0.f;
+            d[j] = bad ? NAN : g;
+        }
+    }
+    if (threadIdx.x == 0) loss_rows[row] = bad ? NAN : logf(s) - (z[y] - mx);
+}
+
 // Focal loss (loss.py:18-27): F_i = gamma * (1 - p_y)^alpha * CE_i.  With q = p_y, dF/dz_j = coef * (p_j - [j = y]),
 // coef = gamma * ((1-q)^alpha - alpha * q * (1-q)^(alpha-1) * log q): the softmax-CE gradient rescaled per row.
 __global__ __launch_bounds__(256) void focal_loss_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
@@ -644,7 +687,9 @@ hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, boo
     return hipGetLastError();
 }
 hipError_t k_softmax_ce(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld, float gs, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gs);
+    if (ld <= 256 * 8) hipLaunchKernelGGL(softmax_ce_reg_kernel<8>, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gs);
+    else if (ld <= 256 * 48) hipLaunchKernelGGL(softmax_ce_reg_kernel<48>, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gs);
+    else hipLaunchKernelGGL(softmax_ce_kernel, dim3(n), dim3(256), 0, st, logits, labels, loss_rows, dlogits, c, ld, gs);
     return hipGetLastError();
 }
 namespace {

@@ -413,6 +413,46 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// Even image, no leading pad (112 / 56 / 28 inputs): a thread owns a 2x2 input patch of 4 channels.  Window (a,b) covers rows
+// 2a..2a+2 and columns 2b..2b+2, so the patch (2a.., 2b..) is touched by exactly the windows (a-1,b-1), (a-1,b), (a,b-1), (a,b):
+// 4 window loads serve 4 input pixels (the per-pixel gather above issues 9 for them, behind data-dependent loop bounds) and are
+// summed in the same order, so the result is bit-identical.
+__global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                               float* __restrict__ dx, int n, int h, int w, int c) {
+    const int ho = h >> 1, wo = w >> 1, cq = c >> 2;
+    const long total = (long)n * ho * wo * cq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % cq);
+        long t = i / cq;
+        const int b = (int)(t % wo); t /= wo;
+        const int a = (int)(t % ho);
+        const int img = (int)(t / ho);
+        f32x4 p00 = {0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
+        auto window = [&](int oh, int ow, uchar4& k, f32x4& d) {
+            const long o = (((long)(img * ho + oh) * wo + ow) * c) + c4 * 4;
+            k = *reinterpret_cast<const uchar4*>(idx + o);
+            d = *reinterpret_cast<const f32x4*>(dy + o);
+        };
+        auto take = [](f32x4& acc, const uchar4& k, const f32x4& d, int pos) {
+            if (k.x == pos) acc[0] += d[0];
+            if (k.y == pos) acc[1] += d[1];
+            if (k.z == pos) acc[2] += d[2];
+            if (k.w == pos) acc[3] += d[3];
+        };
+        uchar4 k; f32x4 d;
+        if (a > 0 && b > 0) { window(a - 1, b - 1, k, d); take(p00, k, d, 8); }
+        if (a > 0) { window(a - 1, b, k, d); take(p00, k, d, 6); take(p01, k, d, 7); }
+        if (b > 0) { window(a, b - 1, k, d); take(p00, k, d, 2); take(p10, k, d, 5); }
+        window(a, b, k, d);
+        take(p00, k, d, 0); take(p01, k, d, 1); take(p10, k, d, 3); take(p11, k, d, 4);
+        float* o = dx + (((long)(img * h + 2 * a) * w + 2 * b) * c) + c4 * 4;
+        *reinterpret_cast<f32x4*>(o) = p00;
+        *reinterpret_cast<f32x4*>(o + c) = p01;
+        *reinterpret_cast<f32x4*>(o + (long)w * c) = p10;
+        *reinterpret_cast<f32x4*>(o + (long)w * c + c) = p11;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // global average pool: y[n,c] = mean_hw x[n,h,w,c]
 // ---------------------------------------------------------------------------------------------------
@@ -562,6 +602,10 @@ hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, i
     return hipGetLastError();
 }
 hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {
+    if (pt == 0 && pl == 0 && h % 2 == 0 && w % 2 == 0) {
+        hipLaunchKernelGGL(maxpool_bwd_even_kernel, dim3(grid_for((long)n * ho * wo * (c / 4))), dim3(256), 0, st, dy, idx, dx, n, h, w, c);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)n * h * w * (c / 4))), dim3(256), 0, st, dy, idx, dx, n, h, w, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
