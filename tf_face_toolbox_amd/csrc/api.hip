@@ -81,7 +81,12 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     static const bool narrow_env = getenv("FTE_NARROW_TILE") != nullptr;
     const bool fills_n = ((M + 127) / 128) * (N / 64) >= SLOTS_BIG;
     const int narrow = (!narrow_env && plan_bf16() && !small_only && fills_n) ? TILE_128x64 : narrow_tile;   // N = 64 layers: +3 %
-    const int big = (N % 128 == 0) ? wide : narrow;
+    // fp32, very tall outputs (>= 4096 tiles of 128 x 64: the 56x56 and 28x28 layers at batch 512): 128 x 64 tiles -- two
+    // accumulator blocks per wave, 32 MFMAs per barrier instead of 16 -- measured after the K-order / priority work of round 2:
+    // 28x28x128->128 forward 123.5 -> 130.1, dgrad 120.3 -> 127.3 TFLOP/s, 56x56x64->64 91.2 -> 93.3 / 94.8 -> 97.1; at 14x14 and
+    // below (fewer tiles than ~4 rounds of the big tile's slots) the 64 x 64 tile stays ahead
+    const bool tall = !wide_env && !narrow_env && !plan_bf16() && !small_only && ((M + 127) / 128) * (N / 64) >= 4096;
+    const int big = tall ? TILE_128x64 : ((N % 128 == 0) ? wide : narrow);
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
     const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn, ksteps = (K + 31) / 32;
