@@ -293,6 +293,12 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         // forward only: the dgrad epilogue's column partials are numbered by the PLANNED tile's rows (api.hip)
         if (epi == EPI_FWD) return launch16<256, 128, 4, 2, EPI_FWD, 3, 2>(p, splits, st);
     }
+    if (cfg == 3 && tile == TILE_128x128 && epi == EPI_FWD && !p.PW && (p.M - p.m_base) >= 256 && p.N % 256 == 0) {
+        // 256x256, eight waves of 64 x 128 (two per SIMD), one block per CU: half the staged bytes per FLOP of the 128x128 tile.
+        // Measured (forward, batch 512): 14x14x512->512 (784 tiles) 0.729 -> 0.618 ms = 767 TFLOP/s, but the net's own layers are
+        // too small for it -- 14x14x256 is 392 tiles on 256 CUs (0.239 -> 0.243 ms), 7x7x512 196 tiles (0.244 -> 0.287 ms).
+        return launch16<256, 256, 4, 2, EPI_FWD, 2, 2>(p, splits, st);
+    }
     if (tile == TILE_128x128) {
         if (epi == EPI_FWD) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1>(p, splits, st);
         return launch16<128, 128, 2, 2, EPI_DGRAD, 4, 1>(p, splits, st);
