@@ -250,3 +250,30 @@ def test_shufflenet_training_steps_and_eval_mode():
     assert out.shape == (n, ncls) and torch.isfinite(out).all()
     assert net.get_variable('ShuffleNet_v2_small_x2/conv2/resBlock_1/conv1_1x1/BatchNorm/moving_mean').shape == (122,)
     assert net.get_variable('ShuffleNet_v2_small_x2/conv2/resBlock_0/separable_conv_shortcut_3x3/depthwise_weights').shape == (3, 3, 12, 1)
+
+
+@pytest.mark.parametrize('name,n', [('ShuffleNet-v2-small', 8), ('ResNet-26', 6)])
+def test_second_stream_and_folded_gather_change_no_bit(name, n, monkeypatch):
+    """The filter gradients run on a second HIP stream, BN is folded into the channel gather and the 3x3 stem runs on the direct
+    conv: every kernel is deterministic and the folds evaluate the same fused multiply-adds, so after five optimizer steps the
+    parameter arena is BIT-IDENTICAL to a run with the side stream and the gather fold switched off."""
+    ncls, h, w = 10, 64, 64
+    rng = np.random.default_rng(3)
+    x = dev(rng.uniform(-1, 1, (n, h, w, 3))); y = dev(rng.integers(0, ncls, n), torch.int32)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = net_select(name, 'NCHW', 5e-4)
+        net.dropout_seed = 11
+        step, losses, _, _ = Singular(net, 0.05, 'Momentum')({'images': x, 'labels': y, 'num_classes': ncls, 'num_examples': n})
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        return net.params.clone(), float(losses[0]), net
+    p1, l1, net1 = run({'FTE_SIDE_STREAM': '1', 'FTE_BN_GATHER': '1'})
+    p0, l0, net0 = run({'FTE_SIDE_STREAM': '0', 'FTE_BN_GATHER': '0'})
+    assert net1.side is not None and net0.side is None
+    assert (len(net1.folded) > 0) == name.startswith('Shuffle') and len(net0.folded) == 0
+    assert np.isfinite(l1) and l1 == l0
+    assert torch.equal(p1, p0)
