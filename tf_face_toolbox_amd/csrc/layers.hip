@@ -27,6 +27,28 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
     n = tot;
 }
 
+// i = ((img*H + b)*W + a)*C4 + c4  ->  (c4, a, b, img).  Every tensor here has fewer than 2^32 16-byte units, and those indices
+// are decomposed with 32-bit unsigned arithmetic: a 64-bit division by a run-time value is ~100 instructions, and the
+// grid-stride loops below did up to six of them per 16 bytes of output (`small` is uniform: total <= 0xffffffff).
+__device__ __forceinline__ void unflat4(long i, bool small, int C4, int W, int H, int& c4, int& a, int& b, int& img) {
+    if (small) {
+        unsigned u = (unsigned)i;
+        c4 = (int)(u % (unsigned)C4); u /= (unsigned)C4;
+        a = (int)(u % (unsigned)W); u /= (unsigned)W;
+        b = (int)(u % (unsigned)H);
+        img = (int)(u / (unsigned)H);
+    } else {
+        c4 = (int)(i % C4); long t = i / C4;
+        a = (int)(t % W); t /= W;
+        b = (int)(t % H);
+        img = (int)(t / H);
+    }
+}
+__device__ __forceinline__ void unflat2(long i, bool small, int Q, int& k, long& row) {
+    if (small) { const unsigned u = (unsigned)i; k = (int)(u % (unsigned)Q); row = (long)(u / (unsigned)Q); }
+    else { k = (int)(i % Q); row = i / Q; }
+}
+
 // scale*z + shift as ONE fused multiply-add per element: the backward pass recomputes the ReLU mask from z with this same
 // expression (the normalised activation need not be kept, or even stored: bn_gather), so both must round identically
 __device__ __forceinline__ f32x4 bn_affine(const f32x4 z, const f32x4 sc, const f32x4 sf) {
@@ -225,15 +247,26 @@ __global__ __launch_bounds__(256) void bn_infer_coef_kernel(const float* __restr
 }
 
 // y = [relu]( scale[c]*z + shift[c] [+ res] )
+// The launchers size the grid so that the grid stride is a multiple of C/4 (grid_for_c): a thread then stays on ONE channel
+// quad for its whole walk, and scale / shift are loaded once instead of being re-derived -- with a 64-bit modulo -- for every
+// 16 bytes (`inv`; any other grid still works through the per-iteration path).
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        float* __restrict__ y, long n4, int C, int relu) {
     const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
     const f32x4* r4 = reinterpret_cast<const f32x4*>(res);
     f32x4* y4 = reinterpret_cast<f32x4*>(y);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sf = *reinterpret_cast<const f32x4*>(shift + c);
+    const unsigned q = (unsigned)C >> 2;
+    const long step = (long)gridDim.x * 256;
+    const bool inv = step % q == 0;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int c = (int)((unsigned)(i % q) << 2);
+    f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sf = *reinterpret_cast<const f32x4*>(shift + c);
+    for (; i < n4; i += step) {
+        if (!inv) {
+            c = (int)((unsigned)(i % q) << 2);
+            sc = *reinterpret_cast<const f32x4*>(scale + c); sf = *reinterpret_cast<const f32x4*>(shift + c);
+        }
         f32x4 v = bn_affine(z4[i], sc, sf);
         if (res) v += r4[i];
         if (relu) {
@@ -328,14 +361,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const f32x4* m4 = reinterpret_cast<const f32x4*>(ymask);
     const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
     f32x4* o4 = reinterpret_cast<f32x4*>(dz);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const int c = (int)((i * 4) % C);
-        const f32x4 A = *reinterpret_cast<const f32x4*>(coef + c), B = *reinterpret_cast<const f32x4*>(coef + C + c),
-                    C0 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
+    const unsigned q = (unsigned)C >> 2;
+    const long step = (long)gridDim.x * 256;
+    const bool inv = step % q == 0;                            // one channel quad per thread (see bn_apply_kernel)
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    f32x4 A, B, C0, msc = {0.f, 0.f, 0.f, 0.f}, msf = msc;
+    auto coefs = [&](long ii) {
+        const int c = (int)((unsigned)(ii % q) << 2);
+        A = *reinterpret_cast<const f32x4*>(coef + c); B = *reinterpret_cast<const f32x4*>(coef + C + c);
+        C0 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
+        if (zsc) { msc = *reinterpret_cast<const f32x4*>(zsc + c); msf = *reinterpret_cast<const f32x4*>(zsf + c); }
+    };
+    coefs(i);
+    for (; i < n4; i += step) {
+        if (!inv) coefs(i);
         f32x4 g = d4[i];
         const f32x4 zz = z4[i];
         if (zsc) {
-            const f32x4 m = bn_affine(zz, *reinterpret_cast<const f32x4*>(zsc + c), *reinterpret_cast<const f32x4*>(zsf + c));
+            const f32x4 m = bn_affine(zz, msc, msf);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
         } else if (ymask) {
@@ -356,11 +399,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                                                           int ho, int wo, int pt, int pl) {
     const long total = (long)n * ho * wo * (c >> 2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c4 = (int)(i % (c >> 2));
-        long t = i / (c >> 2);
-        const int ow = (int)(t % wo); t /= wo;
-        const int oh = (int)(t % ho);
-        const int img = (int)(t / ho);
+        int c4, ow, oh, img;
+        unflat4(i, total <= 0xffffffffL, (c >> 2), wo, ho, c4, ow, oh, img);
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bi[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -386,11 +426,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                                                           int ho, int wo, int pt, int pl) {
     const long total = (long)n * h * w * (c >> 2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c4 = (int)(i % (c >> 2));
-        long t = i / (c >> 2);
-        const int iw = (int)(t % w); t /= w;
-        const int ih = (int)(t % h);
-        const int img = (int)(t / h);
+        int c4, iw, ih, img;
+        unflat4(i, total <= 0xffffffffL, (c >> 2), w, h, c4, iw, ih, img);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         // windows oh with oh*2 - pt <= ih <= oh*2 - pt + 2
         for (int oh = (ih + pt - 2 + 1) >> 1; oh * 2 - pt <= ih; ++oh) {
@@ -422,11 +459,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __re
     const int ho = h >> 1, wo = w >> 1, cq = c >> 2;
     const long total = (long)n * ho * wo * cq;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c4 = (int)(i % cq);
-        long t = i / cq;
-        const int b = (int)(t % wo); t /= wo;
-        const int a = (int)(t % ho);
-        const int img = (int)(t / ho);
+        int c4, b, a, img;
+        unflat4(i, total <= 0xffffffffL, cq, wo, ho, c4, b, a, img);
         f32x4 p00 = {0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
         auto window = [&](int oh, int ow, uchar4& k, f32x4& d) {
             const long o = (((long)(img * ho + oh) * wo + ow) * c) + c4 * 4;
@@ -529,6 +563,16 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
 }
 
 inline int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+// grid for a walk over [rows][C] in 16-byte steps whose stride (blocks * 256 threads) is a multiple of C / 4: every thread keeps
+// its channel quad (bn_apply_kernel).  blocks is rounded UP to a multiple of (C/4) / gcd(C/4, 256).
+inline int grid_for_c(long n4, int C) {
+    long q = C / 4, a = q, b = 256;
+    while (b) { const long t = a % b; a = b; b = t; }
+    const long m = q / a;                                       // blocks must be a multiple of m
+    long blocks = grid_for(n4);
+    blocks = (blocks + m - 1) / m * m;
+    return (int)blocks;
+}
 
 inline int quads_per_block(int C) { return C % 4 ? 0 : (C >= 256 ? 64 : (C >= 128 ? 32 : (C >= 64 ? 16 : (C >= 32 ? 8 : 0)))); }
 
@@ -571,7 +615,7 @@ hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* m
 hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, const float* res, float* y, long rows, int C,
                       int relu, hipStream_t st) {
     const long n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, st, z, scale, shift, res, y, n4, C, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, z, scale, shift, res, y, n4, C, relu);
     return hipGetLastError();
 }
 hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st) {
@@ -594,7 +638,7 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
                        dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C);
     return hipGetLastError();
 }
 hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {
@@ -645,10 +689,13 @@ namespace {
 
 // GPBK groups share a block so that a wave reads GPBK*GW CONTIGUOUS channels of a pixel (one group per block made every
 // lane fetch 16-128 B out of a different 512-B+ pixel row, and every row was fetched by all 32 group-blocks).
-template <int GW, bool DGRAD, int GPBK>
+// S = stride (1 or 2) is a template parameter: the dgrad index map divides by it for every tap of every pixel, and a run-time
+// divisor made that ~35 instructions each (the data gradient ran 2.5x slower than the forward pass of the same layer)
+template <int GW, bool DGRAD, int GPBK, int S>
 __global__ __launch_bounds__(256) void gconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        float* __restrict__ y, int n, int h, int wd, int c,
-                                                       int ho, int wo, int stride, int pt, int pl) {
+                                                       int ho, int wo, int pt, int pl) {
+    constexpr int stride = S;
     // DGRAD = false: y[n,ho,wo] = sum_taps x[n, oh*s + r - pt, ow*s + q - pl] * W[r][q][ic][oc]
     // DGRAD = true : x is dz [n,ho,wo,C], y is dx [n,h,wd,C]: dx[ih,iw][ic] = sum dz[(ih+pt-r)/s,(iw+pl-q)/s][oc] * W[r][q][ic][oc]
     constexpr int PX = 4, OC4 = GW / 4;
@@ -740,7 +787,11 @@ __global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __rest
     if (g < groups && threadIdx.x < GPB * TPG) {
         // 4 pixels per trip: their 40 loads are independent and issued together (branch-free: clamped address, zero
         // factor) -- one pixel per trip left the loop waiting on one memory round trip per pixel
+        // (img, oh, ow) of the running pixel is kept incrementally: decomposing the 64-bit pixel index cost four long divisions
+        // per pixel -- several times the 36 multiply-adds the pixel is there for
         constexpr int UP = 4;
+        int ow = (int)(p0 % wo);
+        int oh = (int)((p0 / wo) % ho), img = (int)(p0 / ((long)wo * ho));
         for (long pb = p0; pb < p1; pb += UP) {
             f32x4 d[UP];
             float xs[UP][9];
@@ -749,22 +800,21 @@ __global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __rest
                 const long p = pb + u;
                 const bool pok = p < p1;
                 const long pp = pok ? p : p0;
-                const int ow = (int)(pp % wo);
-                const long t2 = pp / wo;
-                const int oh = (int)(t2 % ho), img = (int)(t2 / ho);
                 d[u] = *reinterpret_cast<const f32x4*>(dz + pp * c + g * GW + oq * 4);
                 if (!pok) d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int im = pok ? img : 0;                      // pixels past the chunk read image 0 (in bounds) times zero
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int ih = oh * stride + r - pt;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const int iw = ow * stride + q - pl;
-                        const bool ok = ih >= 0 && ih < h && iw >= 0 && iw < wd;
-                        const float v = x[((long)(img * h + (ok ? ih : 0)) * wd + (ok ? iw : 0)) * c + g * GW + ic];
+                        const bool ok = pok && ih >= 0 && ih < h && iw >= 0 && iw < wd;
+                        const float v = x[((long)(im * h + (ok ? ih : 0)) * wd + (ok ? iw : 0)) * c + g * GW + ic];
                         xs[u][r * 3 + q] = ok ? v : 0.f;
                     }
                 }
+                if (++ow == wo) { ow = 0; if (++oh == ho) { oh = 0; ++img; } }
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u)
@@ -829,11 +879,15 @@ template <bool DGRAD>
 hipError_t gconv_launch(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int ho, int wo,
                         int stride, int pt, int pl, hipStream_t st) {
     const int gw = c / groups;
+    if (stride != 1 && stride != 2) return hipErrorInvalidValue;
     const int oh_ = DGRAD ? h : ho, ow_ = DGRAD ? wd : wo;
     const long units = (long)n * oh_ * ((ow_ + 3) / 4);
     auto blocks = [&](int upb) { long b = (units + upb - 1) / upb; return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); };
-#define FTE_GCONV(GW_, GPBK_) hipLaunchKernelGGL((gconv3x3_kernel<GW_, DGRAD, GPBK_>), dim3(blocks(256 / ((GW_ / 4) * GPBK_)), groups / GPBK_), \
-                                                 dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, stride, pt, pl)
+#define FTE_GCONV(GW_, GPBK_) do { \
+        if (stride == 1) hipLaunchKernelGGL((gconv3x3_kernel<GW_, DGRAD, GPBK_, 1>), dim3(blocks(256 / ((GW_ / 4) * GPBK_)), groups / GPBK_), \
+                                            dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl); \
+        else hipLaunchKernelGGL((gconv3x3_kernel<GW_, DGRAD, GPBK_, 2>), dim3(blocks(256 / ((GW_ / 4) * GPBK_)), groups / GPBK_), \
+                                dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl); } while (0)
     switch (gw) {
         case 4:  if (groups % 32 == 0) FTE_GCONV(4, 32); else FTE_GCONV(4, 1); break;
         case 8:  if (groups % 16 == 0) FTE_GCONV(8, 16); else FTE_GCONV(8, 1); break;
@@ -934,11 +988,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
     const int oh_ = DGRAD ? h : ho, ow_ = DGRAD ? wd : wo;
     const long total = (long)n * oh_ * ow_ * c4n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c4 = (int)(i % c4n);
-        long t = i / c4n;
-        const int ox = (int)(t % ow_); t /= ow_;
-        const int oy = (int)(t % oh_);
-        const int img = (int)(t / oh_);
+        int c4, ox, oy, img;
+        unflat4(i, total <= 0xffffffffL, c4n, ow_, oh_, c4, ox, oy, img);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -975,11 +1026,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
     const int wq = (wo + PX - 1) / PX;
     const long total = (long)n * ho * wq * c4n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c4 = (int)(i % c4n);
-        long t = i / c4n;
-        const int xq = (int)(t % wq); t /= wq;
-        const int oy = (int)(t % ho);
-        const int img = (int)(t / ho);
+        int c4, xq, oy, img;
+        unflat4(i, total <= 0xffffffffL, c4n, wq, ho, c4, xq, oy, img);
         const int ox0 = xq * PX;
         f32x4 wv[9];
 #pragma unroll
@@ -1083,8 +1131,8 @@ __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __rest
     const int q = co >> 2;
     const long total = rows * q;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int k4 = (int)(i % q);
-        const long row = i / q;
+        int k4; long row;
+        unflat2(i, total <= 0xffffffffL, q, k4, row);
         const int4 t = *reinterpret_cast<const int4*>(table + 4 * k4);
         const int tt[4] = {t.x, t.y, t.z, t.w};
         f32x4 v;
@@ -1114,8 +1162,8 @@ __global__ __launch_bounds__(256) void channel_gather_affine_kernel(const float*
     const int q0 = co0 >> 2, q = q0 + (co1 >> 2);
     const long total = rows * q;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int k4 = (int)(i % q);
-        const long row = i / q;
+        int k4; long row;
+        unflat2(i, total <= 0xffffffffL, q, k4, row);
         const bool second = k4 >= q0;
         if (second) k4 -= q0;
         const int4 t = *reinterpret_cast<const int4*>((second ? table1 : table0) + 4 * k4);
