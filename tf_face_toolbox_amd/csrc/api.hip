@@ -843,7 +843,7 @@ int fte_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n, 
     return rc(l_maxpool_bwd(dy, idx, dx, n, h, wd, c, ph.out, pw.out, ph.before, pw.before, (hipStream_t)stream));
 }
 int fte_gap_fwd(const float* x, float* y, int n, int hw, int c, void* stream) {
-    if (!x || !y || n <= 0 || hw <= 0) return FTE_EINVAL;
+    if (!x || !y || n <= 0 || hw <= 0 || c <= 0 || c % 4) return FTE_EINVAL;
     return rc(l_gap_fwd(x, y, n, hw, c, (hipStream_t)stream));
 }
 int fte_gap_bwd(const float* dy, float* dx, int n, int hw, int c, void* stream) {
@@ -910,7 +910,7 @@ int fte_channel_scale_fwd(const float* x, const float* gate, float* y, int n, in
     return rc(l_chscale_fwd(x, gate, y, n, hw, c, (hipStream_t)stream));
 }
 int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c, void* stream) {
-    if (!dy || !x || !gate || !dx || !dgate || n <= 0) return FTE_EINVAL;
+    if (!dy || !x || !gate || !dx || !dgate || n <= 0 || c <= 0 || c % 4) return FTE_EINVAL;
     return rc(l_chscale_bwd(dy, x, gate, dx, dgate, n, hw, c, (hipStream_t)stream));
 }
 
