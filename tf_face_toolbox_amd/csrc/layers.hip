@@ -786,61 +786,67 @@ __global__ __launch_bounds__(256) void gconv3x3_kernel(const float* __restrict__
     }
 }
 
-// filter gradient: block = (pixel chunk, group); thread = (ic, oc quad) pairs; partial [chunk][G*9*gw*gw]
+// filter gradient: block = (pixel chunk, group set); thread = (group, kernel row r, ic quad, oc quad); partial [chunk][G*9*gw*gw].
+// Per pixel a thread loads ONE float4 of dz (its oc quad) and THREE float4 of x (its ic quad at the three taps of row r) for
+// 3 x 4 x 4 multiply-adds into 12 float4 accumulators: 12 FMAs per load instruction.  (A thread per (ic, oc quad) with nine scalar
+// x loads per pixel -- 3.6 FMAs per load -- kept every layer at ~117 us whatever its size: bound by the count of 4-byte loads.)
 template <int GW>
 __global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                              float* __restrict__ part, int n, int h, int wd, int c,
                                                              int ho, int wo, int stride, int pt, int pl, long pix_per_block, int groups) {
-    constexpr int OC4 = GW / 4, TPG = GW * OC4;              // threads per group
+    constexpr int Q = GW / 4, TPG = 3 * Q * Q;               // threads per group
     constexpr int GPB = 256 / TPG > 0 ? 256 / TPG : 1;       // groups per block
     const int gl = threadIdx.x / TPG, rem = threadIdx.x % TPG;
     const int g = blockIdx.y * GPB + gl;
-    const int ic = rem / OC4, oq = rem % OC4;
+    const int r = rem / (Q * Q), iq = (rem / Q) % Q, oq = rem % Q;
     const long npix = (long)n * ho * wo;
     const long p0 = (long)blockIdx.x * pix_per_block, p1 = min(npix, p0 + pix_per_block);
-    f32x4 acc[9];
+    f32x4 acc[3][4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (g < groups && threadIdx.x < GPB * TPG) {
-        // 4 pixels per trip: their 40 loads are independent and issued together (branch-free: clamped address, zero
-        // factor) -- one pixel per trip left the loop waiting on one memory round trip per pixel
-        // (img, oh, ow) of the running pixel is kept incrementally: decomposing the 64-bit pixel index cost four long divisions
-        // per pixel -- several times the 36 multiply-adds the pixel is there for
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g < groups && gl < GPB) {
+        // 4 pixels per trip: their 16 loads are independent and issued together (branch-free: clamped address, zero factor);
+        // (img, oh, ow) of the running pixel is kept incrementally (a 64-bit index decomposition per pixel cost more than the FMAs)
         constexpr int UP = 4;
         int ow = (int)(p0 % wo);
         int oh = (int)((p0 / wo) % ho), img = (int)(p0 / ((long)wo * ho));
+        const float* xg = x + g * GW + iq * 4;
+        const float* dg = dz + g * GW + oq * 4;
         for (long pb = p0; pb < p1; pb += UP) {
-            f32x4 d[UP];
-            float xs[UP][9];
+            f32x4 d[UP], xs[UP][3];
 #pragma unroll
             for (int u = 0; u < UP; ++u) {
                 const long p = pb + u;
                 const bool pok = p < p1;
-                const long pp = pok ? p : p0;
-                d[u] = *reinterpret_cast<const f32x4*>(dz + pp * c + g * GW + oq * 4);
+                d[u] = *reinterpret_cast<const f32x4*>(dg + (pok ? p : p0) * c);
                 if (!pok) d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int im = pok ? img : 0;                      // pixels past the chunk read image 0 (in bounds) times zero
+                const int ih = oh * stride + r - pt;
+                const bool rok = pok && ih >= 0 && ih < h;
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int ih = oh * stride + r - pt;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int iw = ow * stride + q - pl;
-                        const bool ok = pok && ih >= 0 && ih < h && iw >= 0 && iw < wd;
-                        const float v = x[((long)(im * h + (ok ? ih : 0)) * wd + (ok ? iw : 0)) * c + g * GW + ic];
-                        xs[u][r * 3 + q] = ok ? v : 0.f;
-                    }
+                for (int q = 0; q < 3; ++q) {
+                    const int iw = ow * stride + q - pl;
+                    const bool ok = rok && iw >= 0 && iw < wd;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xg + ((long)(im * h + (ok ? ih : 0)) * wd + (ok ? iw : 0)) * c);
+                    xs[u][q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (++ow == wo) { ow = 0; if (++oh == ho) { oh = 0; ++img; } }
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) acc[t] += xs[u][t] * d[u];
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][e] += xs[u][q][e] * d[u];
         }
         float* out = part + ((long)blockIdx.x * groups + g) * 9 * GW * GW;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(out + (t * GW + ic) * GW + oq * 4) = acc[t];
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<f32x4*>(out + ((r * 3 + q) * GW + iq * 4 + e) * GW + oq * 4) = acc[q][e];
     }
 }
 
@@ -945,13 +951,15 @@ hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, in
                          int stride, int pt, int pl, int chunks, hipStream_t st) {
     const int gw = c / groups;
     const long npix = (long)n * ho * wo, ppb = (npix + chunks - 1) / chunks;
-    const int tpg = gw * (gw / 4), gpb = 256 / tpg > 0 ? 256 / tpg : 1;
-    const dim3 grid(chunks, (groups + gpb - 1) / gpb);
+    const int tpg = 3 * (gw / 4) * (gw / 4), gpb = 256 / tpg > 0 ? 256 / tpg : 1;
+    const int gy = (groups + gpb - 1) / gpb;
+    const int used = (groups < gpb ? groups : gpb) * tpg;          // active threads: the block is cut to whole waves of them
+    const dim3 grid(chunks, gy), blk((used + 63) / 64 * 64);
     switch (gw) {
-        case 4:  hipLaunchKernelGGL(gconv3x3_wgrad_kernel<4>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
-        case 8:  hipLaunchKernelGGL(gconv3x3_wgrad_kernel<8>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
-        case 16: hipLaunchKernelGGL(gconv3x3_wgrad_kernel<16>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
-        case 32: hipLaunchKernelGGL(gconv3x3_wgrad_kernel<32>, grid, dim3(256), 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        case 4:  hipLaunchKernelGGL(gconv3x3_wgrad_kernel<4>, grid, blk, 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        case 8:  hipLaunchKernelGGL(gconv3x3_wgrad_kernel<8>, grid, blk, 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        case 16: hipLaunchKernelGGL(gconv3x3_wgrad_kernel<16>, grid, blk, 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
+        case 32: hipLaunchKernelGGL(gconv3x3_wgrad_kernel<32>, grid, blk, 0, st, x, dz, part, n, h, wd, c, ho, wo, stride, pt, pl, ppb, groups); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
