@@ -87,20 +87,24 @@ def test_conv3x3_wgrad(n, h, w, cin, cout, stride):
     check_maxabs(host(dw), dw_ref, what='dw')
 
 
-@pytest.mark.parametrize('n,h,w,cin', [(3, 16, 16, 3), (2, 13, 9, 1), (2, 112, 112, 3)])
-def test_first_conv_fwd_and_wgrad(n, h, w, cin):
+@pytest.mark.parametrize('n,h,w,cin,cout,stride', [(3, 16, 16, 3, 64, 2), (2, 13, 9, 1, 64, 2), (2, 112, 112, 3, 64, 2),
+                                                   (3, 16, 16, 3, 32, 2), (2, 13, 9, 1, 32, 1), (2, 112, 112, 3, 32, 2)])
+def test_first_conv_fwd_and_wgrad(n, h, w, cin, cout, stride):
+    """cout 64: SphereNet's first conv (bias + PReLU fused); cout 32: ShuffleNet-v2's 24-filter stem stored 32 wide (plain)."""
     r = _rng(4)
-    x = r.uniform(-1, 1, (n, h, w, cin)); wt = r.standard_normal((3, 3, cin, 64)) * 0.2
-    b = r.standard_normal(64); al = 0.25 + 0.1 * r.standard_normal(64)
-    z_ref = ops.conv2d_fwd(x, wt, 2, b); y_ref = ops.prelu_fwd(z_ref, al)
+    x = r.uniform(-1, 1, (n, h, w, cin)); wt = r.standard_normal((3, 3, cin, cout)) * 0.2
+    b = r.standard_normal(cout); al = 0.25 + 0.1 * r.standard_normal(cout)
+    z_ref = ops.conv2d_fwd(x, wt, stride, b); y_ref = ops.prelu_fwd(z_ref, al)
     z = torch.empty(z_ref.shape, device='cuda'); y = torch.empty_like(z)
-    call('fte_conv3x3_first_fwd', dev(x), dev(wt), dev(b), dev(al), z, y, n, h, w, cin, 64, 2, stream())
+    call('fte_conv3x3_first_fwd', dev(x), dev(wt), dev(b), dev(al), z, y, n, h, w, cin, cout, stride, stream())
     check_maxabs(host(z), z_ref, what='z'); check_maxabs(host(y), y_ref, what='y')
+    call('fte_conv3x3_first_fwd', dev(x), dev(wt), None, None, None, y, n, h, w, cin, cout, stride, stream())
+    check_maxabs(host(y), ops.conv2d_fwd(x, wt, stride), what='plain')
     dz = r.standard_normal(z_ref.shape)
-    _, dw_ref = ops.conv2d_bwd(x, wt, dz, 2, need_dx=False)
-    dw = torch.empty(3, 3, cin, 64, device='cuda')
-    wsb, nb = ws(query('fte_conv3x3_first_wgrad_ws_bytes', n, h, w, cin, 64, 2))
-    call('fte_conv3x3_first_wgrad', dev(x), dev(dz), dw, n, h, w, cin, 64, 2, wsb, nb, stream())
+    _, dw_ref = ops.conv2d_bwd(x, wt, dz, stride, need_dx=False)
+    dw = torch.empty(3, 3, cin, cout, device='cuda')
+    wsb, nb = ws(query('fte_conv3x3_first_wgrad_ws_bytes', n, h, w, cin, cout, stride))
+    call('fte_conv3x3_first_wgrad', dev(x), dev(dz), dw, n, h, w, cin, cout, stride, wsb, nb, stream())
     check_maxabs(host(dw), dw_ref, what='dw')
 
 

@@ -54,7 +54,8 @@ def test_conv1x1_dgrad_accumulates_into_an_existing_gradient(n, h, w, cin, cout)
     check_maxabs(host(dx), dx_ref + prev, what='dgrad + addin')
 
 
-@pytest.mark.parametrize('rows_shape,c', [((3, 9, 7), 64), ((16, 28, 28), 256), ((2, 4, 4), 2048), ((64, 14, 14), 1024)])
+@pytest.mark.parametrize('rows_shape,c', [((3, 9, 7), 64), ((16, 28, 28), 256), ((2, 4, 4), 2048), ((64, 14, 14), 1024),
+                                          ((5, 11, 13), 32), ((2, 3, 3), 192), ((37,), 8)])
 def test_batch_norm_train_fwd_bwd(rows_shape, c):
     r = _rng(2)
     shape = rows_shape + (c,)
