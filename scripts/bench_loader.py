@@ -24,10 +24,13 @@ def main():
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--batches', type=int, default=8)
     ap.add_argument('--src', type=int, default=250)
-    ap.add_argument('--device', default='cpu')
+    ap.add_argument('--device', default=None, help="default: cuda when a GPU is present (the training path: pinned staging ring + async copy), else cpu")
     ap.add_argument('--workers', type=int, default=None, help='decode worker processes (default: data.train_inputs picks; 0 = threads)')
     args = ap.parse_args()
     from tf_face_toolbox_amd import data
+    if args.device is None:
+        import torch
+        args.device = 'cuda' if torch.cuda.is_available() else 'cpu'
     rng = np.random.default_rng(0)
     with tempfile.TemporaryDirectory() as d:
         lines = []

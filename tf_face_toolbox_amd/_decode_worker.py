@@ -21,37 +21,74 @@ def _resize_table(n_in, n_out):
     return t
 
 
-def resize_bilinear_tf1(image, height, width):
-    """tf.image.resize_images(image, [height, width]) of TF 1.x on a float32 HWC image: bilinear, align_corners=False,
-    no antialiasing (PIL's BILINEAR widens its kernel when shrinking and gives different pixels), float32 arithmetic.
-    Same size -> returned unchanged (TF skips the op)."""
+_S255 = np.float32(1.0 / 255.0)
+
+
+def resize_window(image, height, width, y0=0, win_h=None, x0=0, win_w=None):
+    """Rows [y0, y0 + win_h) x columns [x0, x0 + win_w) of tf.image.resize_images(image, [height, width]) as TF 1.x computes it
+    on a float32 HWC image: bilinear, align_corners=False, no antialiasing (PIL's BILINEAR widens its kernel when shrinking and
+    gives different pixels), float32 arithmetic in the kernel's own order -- the two neighbours of a row are blended along x
+    first, then the two rows along y.  `image` may be uint8: it is scaled by 1/255 (convert_image_dtype) on the way, element
+    by element, i.e. to exactly the values a conversion of the whole image would give.  Only the window is computed: a
+    random crop of the resized image costs the crop's area, not the image's (the pipeline's second largest cost after the
+    JPEG decode).  Same size and a full window -> the (converted) image itself (TF skips the op)."""
     h, w = image.shape[:2]
+    win_h = height if win_h is None else win_h
+    win_w = width if win_w is None else win_w
+    u8 = image.dtype == np.uint8
     if (h, w) == (height, width):
-        return image
-    ylo, yhi, yw = _resize_table(h, height)
-    xlo, xhi, xw = _resize_table(w, width)
-    top = image[ylo]
-    rows = top + (image[yhi] - top) * yw[:, None, None]                 # [height, w, c]: blend of the two source rows
-    left = rows[:, xlo]
-    return left + (rows[:, xhi] - left) * xw[None, :, None]             # then of the two source columns
+        out = image[y0:y0 + win_h, x0:x0 + win_w]
+        return out.astype(np.float32) * _S255 if u8 else out
+    ylo, yhi, yw = (t[y0:y0 + win_h] for t in _resize_table(h, height))
+    xlo, xhi, xw = (t[x0:x0 + win_w] for t in _resize_table(w, width))
+
+    s = _S255 if u8 else None
+
+    def blend_x(rows):                                            # rows: the gathered source rows, [win_h, w, c]
+        left, right = np.take(rows, xlo, axis=1), np.take(rows, xhi, axis=1)
+        if u8:
+            left = left.astype(np.float32); left *= s
+            right = right.astype(np.float32); right *= s
+        right -= left
+        right *= xw3
+        right += left
+        return right
+    xw3 = xw[None, :, None]
+    top = blend_x(image[ylo])
+    bot = blend_x(image[yhi])
+    bot -= top
+    bot *= yw[:, None, None]
+    bot += top
+    return bot
+
+
+def resize_bilinear_tf1(image, height, width):
+    """tf.image.resize_images(image, [height, width]) of TF 1.x (see resize_window)."""
+    return resize_window(image, height, width)
+
+
+def _load(path, num_channels):
+    """tf.read_file + decode_jpeg(channels): uint8 HWC"""
+    from PIL import Image
+    img = Image.open(path)
+    img = img.convert('RGB' if num_channels == 3 else 'L')
+    a = np.asarray(img, dtype=np.uint8)
+    return a.reshape(a.shape[0], a.shape[1], num_channels)
 
 
 def decode(path, num_channels, height, width):
     """tf.read_file + decode_jpeg(channels) + convert_image_dtype(float32) + resize_images (data.py:208-213)."""
-    from PIL import Image
-    img = Image.open(path)
-    img = img.convert('RGB' if num_channels == 3 else 'L')
-    a = np.asarray(img, dtype=np.float32) * np.float32(1.0 / 255.0)   # convert_image_dtype(uint8 -> float32): x * (1/255)
-    a = a.reshape(a.shape[0], a.shape[1], num_channels)
-    return resize_bilinear_tf1(a, height, width)
+    return resize_window(_load(path, num_channels), height, width)
 
 
 def train_example(path, num_channels, input_height, input_width, crop_height, crop_width, augmentation, rng):
-    image = decode(path, num_channels, input_height, input_width)
-    if crop_height != -1 and crop_width != -1:                      # tf.random_crop
+    raw = _load(path, num_channels)
+    if crop_height != -1 and crop_width != -1:                      # tf.random_crop: only the cropped window is resized
         y0 = rng.integers(0, input_height - crop_height + 1)
         x0 = rng.integers(0, input_width - crop_width + 1)
-        image = image[y0:y0 + crop_height, x0:x0 + crop_width, :]
+        image = resize_window(raw, input_height, input_width, y0, crop_height, x0, crop_width)
+    else:
+        image = resize_window(raw, input_height, input_width)
     if augmentation:
         from .preprocessing import data_augmentation
         image = data_augmentation(image, rng)

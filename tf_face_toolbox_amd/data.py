@@ -81,8 +81,31 @@ class _Prefetcher(object):
         self.num_classes = num_classes
         self._cur = None
         self._dead = None
+        # Host staging buffers, allocated ONCE and used in rotation (pinned when the device is a GPU): copying a 77 MB batch
+        # into a fresh allocation every step cost 60-90 ms on the MI355X host (page faults of the new pages, 128 OpenMP threads
+        # woken for one memcpy; `pin_memory()` registers new host memory every time) against 3 ms into a resident buffer --
+        # it capped the pipeline at 5.5 k images/s whatever the number of decode workers.  depth + 3 buffers: the queue, the
+        # batch the consumer holds, the one being filled, and one spare; a GPU copy's event is waited for before reuse.
+        self._ring, self._slot = [], 0
+        self._nslots = depth + 3
         self._t = threading.Thread(target=self._run, daemon=True)
         self._t.start()
+
+    def _stage(self, x):
+        """x (numpy, possibly the workers' shared buffer) -> a staging tensor of this prefetcher's ring"""
+        if not self._ring or tuple(self._ring[0]['buf'].shape) != tuple(x.shape):
+            self._ring = []
+            for _ in range(self._nslots):
+                b = torch.empty(tuple(x.shape), dtype=torch.float32)
+                self._ring.append({'buf': b.pin_memory() if self.device.type == 'cuda' else b, 'ev': None})
+            self._slot = 0
+        e = self._ring[self._slot]
+        self._slot = (self._slot + 1) % self._nslots
+        if e['ev'] is not None:
+            e['ev'].synchronize()                             # the host-to-device copy that read this buffer has finished
+            e['ev'] = None
+        np.copyto(e['buf'].numpy(), x, casting='same_kind')
+        return e
 
     def _run(self):
         try:
@@ -92,13 +115,8 @@ class _Prefetcher(object):
                     lo, hi = int(y.min()), int(y.max())
                     if lo < 0 or hi >= self.num_classes:      # the loss kernels index rows / columns by label
                         raise ValueError('label out of range: batch has labels in [%d, %d], num_classes = %d' % (lo, hi, self.num_classes))
-                xt = torch.from_numpy(x)
                 yt = torch.from_numpy(y) if y is not None else None
-                if self.device.type == 'cuda':
-                    xt = xt.pin_memory()                      # a copy: the workers' shared batch buffer is free again
-                elif isinstance(x, np.memmap):
-                    xt = xt.clone()
-                self.q.put((xt, yt))
+                self.q.put((self._stage(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x), yt))
         except BaseException as e:                            # noqa: B902 -- everything goes to the consumer
             self.q.put(e)
 
@@ -116,9 +134,15 @@ class _Prefetcher(object):
         if isinstance(item, BaseException):
             self._dead = RuntimeError('input pipeline failed: %s: %s' % (type(item).__name__, item))
             raise self._dead from item
-        xt, yt = item
-        self._cur = (xt.to(self.device, non_blocking=True),
-                     yt.to(self.device, non_blocking=True) if yt is not None else None)
+        slot, yt = item
+        if self.device.type == 'cuda':
+            xd = slot['buf'].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            slot['ev'] = ev                                   # the producer waits for it before it overwrites the buffer
+        else:
+            xd = slot['buf'].clone()                          # CPU consumers (tests) may keep a batch: hand out a copy, not the ring buffer
+        self._cur = (xd, yt.to(self.device, non_blocking=True) if yt is not None else None)
         return self._cur
 
 
@@ -127,9 +151,8 @@ class _WorkerPool(object):
     that write their rows straight into a float32 batch buffer under /dev/shm mapped by everybody.  Threads top out at a
     few hundred images/s (the numpy part of decode/resize holds the GIL); the GPU step consumes 10-30 k images/s."""
 
-    GROUP = 16       # workers that share one batch.  Measured on the MI355X host (2 x 64 cores, 512-image batches): 16 workers on
-    # one batch decode 5.1 k images/s, 128 workers on one batch 2.9 k (10 ms of work per worker and batch, then asleep:
-    # wake-ups dominate) -- so the pool is cut into groups and every group works on a DIFFERENT batch.
+    GROUP = 16       # workers that share one batch: with 128 workers on one 512-image batch each has ~5 ms of work per batch and is
+    # asleep most of the time (wake-ups dominate) -- so the pool is cut into groups and every group works on a DIFFERENT batch.
 
     def __init__(self, workers, shape):
         import atexit
@@ -148,7 +171,10 @@ class _WorkerPool(object):
         self.groups = [self.procs[i:i + gs] for i in range(0, workers - gs + 1, gs)]
         if workers % gs:
             self.groups[-1] = self.groups[-1] + self.procs[workers - workers % gs:]
-        self.RING = len(self.groups) + 1         # batch buffers in rotation: one per group in flight + the one being copied out
+        # Every group has TWO batches in the pipe (one being decoded, the next already waiting on its workers' stdin): a group
+        # that has to wait for the parent to copy its batch out before it gets the next one idles a third of the time.
+        self.DEPTH = 2 * len(self.groups)
+        self.RING = self.DEPTH + 1               # batch buffers in rotation: the open tickets + the one being copied out
         for k in range(self.RING):
             fd, path = tempfile.mkstemp(prefix='fte_batch_%d_%d_' % (os.getpid(), k), dir=base)
             os.close(fd)
@@ -178,8 +204,8 @@ class _WorkerPool(object):
         self.files = []
 
     def submit(self, rows, params):
-        """Hand rows [(row, path, seed)] to the next group of workers; returns a ticket for wait().  At most len(groups)
-        tickets may be open, and they must be waited for in submission order."""
+        """Hand rows [(row, path, seed)] to the next group of workers; returns a ticket for wait().  At most DEPTH tickets may
+        be open (a group works through its tasks in order), and they must be waited for in submission order."""
         import pickle
         import struct
         k = self.turn % self.RING
@@ -277,7 +303,8 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
     if num_workers is None:
         num_workers = int(os.environ.get('FTE_LOADER_WORKERS', '-1'))
         if num_workers < 0:
-            # measured on the MI355X host: 16 workers 5.1 k, 32 workers 5.5 k images/s, more workers are SLOWER (64: 4.7 k, 128: 4.0 k)
+            # measured on the MI355X host (to the GPU through the pinned staging ring): 16 workers 19.3 k, 32 workers 23.7 k,
+            # 48 workers 24.5 k, 64 workers 23.4 k images/s
             num_workers = min(max(1, cpu_count() // 2 // max(1, world_size)), 32, shard // 4) if shard >= 64 else 0
     procs = _WorkerPool(num_workers, (shard, out_h, out_w, num_channels)) if num_workers > 0 else None
     pool = None if procs else ThreadPoolExecutor(max(1, cpu_count() // 2))
@@ -292,7 +319,7 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
 
     def make_batch():
         if procs is not None:
-            while len(pending) < len(procs.groups):
+            while len(pending) < procs.DEPTH:
                 items, seeds, labels = draw()
                 pending.append((procs.submit([(i, it[0], int(sd)) for i, (it, sd) in enumerate(zip(items, seeds))], params), labels))
             ticket, labels = pending.pop(0)
