@@ -105,3 +105,18 @@ def test_worker_processes_give_the_same_batches_as_threads(workers, group, monke
         assert np.array_equal(held.numpy(), xb.numpy())
     finally:
         os.remove(lst)
+
+
+def test_eval_batches_from_worker_processes_equal_the_in_process_path(tmp_path):
+    """evaluate.py's input (data.py:153-191: list order, resize, (x-0.5)/0.5) decoded by the worker processes == decoded by
+    threads in this process, bit for bit, over the wrap-around of the repeating list."""
+    lst = tmp_path / 'eval.txt'
+    lst.write_text(''.join('%s\n' % os.path.join(IMG, n) for n in NAMES))
+    nxt_t, n_t = data.eval_inputs(str(lst), 64, True, 48, 40, device='cpu', num_workers=0)
+    nxt_p, n_p = data.eval_inputs(str(lst), 64, True, 48, 40, device='cpu', num_workers=3)
+    assert n_t == n_p == 8
+    for _ in range(3):
+        a, b = nxt_t().numpy(), nxt_p().numpy()
+        assert a.shape == (64, 48, 40, 3) and np.array_equal(a, b)
+    ref = (image_ops.resize_bilinear_tf1(_raw01(NAMES[1], 3), 48, 40) - 0.5) / 0.5
+    assert np.abs(b[1] - ref).max() <= 5e-6 and np.array_equal(b[1], b[9])      # rows repeat with the list's period
