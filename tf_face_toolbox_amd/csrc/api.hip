@@ -106,9 +106,12 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     }
     const long tmt = (tail_rows + bm - 1) / bm, R = tmt * ntn;
     long P = (SLOTS + R / 2) / R;
-    // every split keeps >= 16 K-steps (K = 512): the 4x4x512->512 1x1 convs of ShuffleNet's last stage (1024 tiles, P = 2) ran
-    // 58 us split + fixed up against 43 us in one launch; the 3x3 layers this plan was measured on have K >= 1152
-    if (P > ksteps / 16) P = ksteps / 16;
+    // every split keeps >= 32 K-steps (K = 1024): the 4x4x512->512 1x1 convs of ShuffleNet's last stage (1024 tiles, P = 2) ran
+    // 58 us split + fixed up against 43 us in one launch, and with 16..32 K-steps per split the 1x1 convs of the ResNet family
+    // lose too (SE-ResNet-50 at 128 per GPU +1.1 % without those splits); the 3x3 layers of SphereNet at 64 images per GPU
+    // (K = 2304 / 4608, 36 K-steps per split) keep theirs (48 would cost them 1.4 %)
+    static const int min_steps = getenv("FTE_SPLIT_MINSTEPS") ? atoi(getenv("FTE_SPLIT_MINSTEPS")) : 32;      // tuning hook
+    if (P > ksteps / min_steps) P = ksteps / min_steps;
     // Split-K pays only when there is NO whole round (small per-GPU shards): measured on MI355X at batch
     // 512 a 32-tile tail split 16 ways is slower than the 64x64 tail (which costs ~3 % of the kernel).
     // P = 2 already pays (batch 64, 14x14x256: 96 -> 101 TFLOP/s forward, 89 -> 95
