@@ -136,10 +136,22 @@ def _ptr(t):
     return t.data_ptr()
 
 
+_FN = {}
+_Tensor = None
+
+
 def call(name, *args):
-    """Call an int-returning entry point; tensors are passed as device pointers."""
-    lib = load()
-    r = getattr(lib, name)(*[_ptr(a) if (a is None or hasattr(a, 'data_ptr')) else a for a in args])
+    """Call an int-returning entry point; tensors are passed as device pointers.  (Kept lean: the graph nets make ~700 calls per
+    step and a ShuffleNet-v2 step at <= 128 images per GPU is bound by this host loop, not by the GPU.)"""
+    global _Tensor
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+        if _Tensor is None:
+            import torch
+            _Tensor = torch.Tensor
+    T = _Tensor
+    r = fn(*[a.data_ptr() if type(a) is T else (a.data_ptr() if hasattr(a, 'data_ptr') else a) for a in args])
     if r != 0:
         what = _CODES.get(r, 'hipError_t %d (see hip_runtime_api.h)' % r if r > 0 else 'unknown')
         raise FteError('%s failed with code %d: %s' % (name, r, what))

@@ -83,6 +83,7 @@ class GraphNet(Network):
         super(GraphNet, self).__init__(weight_decay, data_format, name)
         self.seed = seed
         self.built = False
+        self._views = {}
         self.tower_scale = 1.0
         self.global_step = 0
         self.update_moving_stats = True      # data_parallel.py:242-243: UPDATE_OPS of tower 0 only
@@ -181,8 +182,17 @@ class GraphNet(Network):
         return tuple(shape)
 
     def view(self, name, arena=None):
-        v = self.variables[name]
+        """flat view of a variable in the parameter arena (or in `arena`, e.g. the gradient arena).  Views of the two arenas that
+        live as long as the net are cached: the step makes ~1000 of these lookups and is host-bound at small shards."""
         a = self.params if arena is None else arena
+        if a is self.params or a is self.grads:
+            key = (name, a is self.grads)
+            t = self._views.get(key)
+            if t is None or t.data_ptr() != a.data_ptr() + self.variables[name].offset * 4:
+                v = self.variables[name]
+                t = self._views[key] = a[v.offset:v.offset + v.size]
+            return t
+        v = self.variables[name]
         return a[v.offset:v.offset + v.size]
 
     def _init_params(self):
