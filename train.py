@@ -2,9 +2,8 @@
 """train.py -- the reference's training CLI (train.py:33-262) on the MI355X engine.
 
 Same flags, defaults, assertions, LR schedules, log line and checkpoint cadence as the reference
-(SURVEY.md Appendix D).  One process per GPU: with --num_gpus N > 1 launch it as
-    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train.py --num_gpus N ...
-(the reference drives N towers from one process; here WORLD_SIZE must equal --num_gpus).
+(SURVEY.md Appendix D).  One process per GPU: `python train.py --num_gpus N ...` (the reference's invocation) starts its own N
+ranks through torch.distributed.run; under torch.distributed.run it runs as one rank (WORLD_SIZE must equal --num_gpus).
 Extra, not in the reference: --synthetic 1 trains on a resident random batch when no list is given,
 --max_steps stops early (smoke runs)."""
 import argparse
@@ -121,9 +120,24 @@ def train(FLAGS):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if FLAGS.num_gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python train.py --num_gpus N` as the reference is invoked: this process starts the N ranks as fresh children (it has not
+        # touched the GPU and never will), passes their output through and exits with their status
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(FLAGS.num_gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '8')
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if FLAGS.num_gpus != world:
-        raise SystemExit('--num_gpus %d needs one process per GPU: python -m torch.distributed.run --nproc-per-node %d '
-                         '--master-addr 127.0.0.1 train.py ... (WORLD_SIZE is %d)' % (FLAGS.num_gpus, FLAGS.num_gpus, world))
+        raise SystemExit('--num_gpus %d but WORLD_SIZE is %d: one process per GPU (python -m torch.distributed.run --nproc-per-node %d '
+                         '--master-addr 127.0.0.1 train.py ..., or plain `python train.py --num_gpus %d`, which launches them)'
+                         % (FLAGS.num_gpus, world, FLAGS.num_gpus, FLAGS.num_gpus))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
