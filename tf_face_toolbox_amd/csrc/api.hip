@@ -94,7 +94,12 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     long tail_rows = 0;
     if (T >= SLOTS) {
         const long full = T / SLOTS * SLOTS;
-        if ((bm == 64 && bn == 64) || T - full == 0 || T - full >= SLOTS * 4 / 5) {        // smallest tile, or (nearly) whole rounds
+        // A leftover fraction of a round used to go to a separate small-tile TAIL launch (mode 1 below).  Measured again at the end of
+        // round 2 it no longer pays: blocks of a many-round launch drift apart, the last partial round is absorbed, and the tail
+        // launch's own ramp costs more -- SphereNet step 49.30 -> 49.16 ms fp32, 17.15 -> 16.78 ms in the bf16 mode (whose main
+        // launches are 4x shorter).  FTE_TAIL_SPLIT=1 brings the tail back (A/B hook).
+        static const bool tail_split = getenv("FTE_TAIL_SPLIT") != nullptr;
+        if ((bm == 64 && bn == 64) || T - full == 0 || T - full >= SLOTS * 4 / 5 || !tail_split) {
             r.main_rows = M; r.main_mtiles = MT;
             return r;
         }
