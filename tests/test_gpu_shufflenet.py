@@ -252,7 +252,7 @@ def test_shufflenet_training_steps_and_eval_mode():
     assert net.get_variable('ShuffleNet_v2_small_x2/conv2/resBlock_0/separable_conv_shortcut_3x3/depthwise_weights').shape == (3, 3, 12, 1)
 
 
-@pytest.mark.parametrize('name,n', [('ShuffleNet-v2-small', 8), ('ResNet-26', 6)])
+@pytest.mark.parametrize('name,n', [('ShuffleNet-v2-small', 8), ('ResNet-26', 6), ('ResNeXt-26', 4), ('SENet-50', 4)])
 def test_second_stream_and_folded_gather_change_no_bit(name, n, monkeypatch):
     """The filter gradients run on a second HIP stream, BN is folded into the channel gather and the 3x3 stem runs on the direct
     conv: every kernel is deterministic and the folds evaluate the same fused multiply-adds, so after five optimizer steps the
