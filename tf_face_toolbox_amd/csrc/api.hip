@@ -31,7 +31,7 @@ inline long tiles_of(int tile, long M, long N) {
 
 // Largest tile that still gives the chip >= 1.5 blocks per CU; else the smallest legal one.
 inline int pick_tile(long M, long N) {
-    const long want = 384;
+    const long want = 384;      // (measured again in round 2 on the BN nets: 384 / 800 / 1200 / always-smallest are within 0.5 %)
     int cands[3];
     int nc = 0;
     if (N % 128 == 0) { cands[nc++] = TILE_128x128; cands[nc++] = TILE_128x64; cands[nc++] = TILE_64x64; }
@@ -85,7 +85,8 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     // accumulator blocks per wave, 32 MFMAs per barrier instead of 16 -- measured after the K-order / priority work of round 2:
     // 28x28x128->128 forward 123.5 -> 130.1, dgrad 120.3 -> 127.3 TFLOP/s, 56x56x64->64 91.2 -> 93.3 / 94.8 -> 97.1; at 14x14 and
     // below (fewer tiles than ~4 rounds of the big tile's slots) the 64 x 64 tile stays ahead
-    const bool tall = !wide_env && !narrow_env && !plan_bf16() && !small_only && ((M + 127) / 128) * (N / 64) >= 4096;
+    // (not for K < 576: with two K-steps per tile the bigger tile only lengthens the epilogue -- 28x28x64->256 dgrad 122 vs 92 us)
+    const bool tall = !wide_env && !narrow_env && !plan_bf16() && !small_only && K >= 576 && ((M + 127) / 128) * (N / 64) >= 4096;
     const int big = tall ? TILE_128x64 : ((N % 128 == 0) ? wide : narrow);
     int bm, bn;
     igemm_tile_dims(big, &bm, &bn);
