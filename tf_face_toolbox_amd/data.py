@@ -74,8 +74,9 @@ class _Prefetcher(object):
 
     POLL_SECONDS = 5.0
 
-    def __init__(self, make_batch, device, depth=2, num_classes=None):
+    def __init__(self, make_batch, device, depth=2, num_classes=None, pool=None):
         self.q = queue.Queue(maxsize=depth)
+        self.pool = pool                                          # a _WorkerPool with page-locked buffers, or None
         self.device = device
         self.make_batch = make_batch
         self.num_classes = num_classes
@@ -116,7 +117,11 @@ class _Prefetcher(object):
                     if lo < 0 or hi >= self.num_classes:      # the loss kernels index rows / columns by label
                         raise ValueError('label out of range: batch has labels in [%d, %d], num_classes = %d' % (lo, hi, self.num_classes))
                 yt = torch.from_numpy(y) if y is not None else None
-                self.q.put((self._stage(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x), yt))
+                d = self.pool.direct(x) if (self.pool is not None and self.device.type == 'cuda') else None
+                if d is not None:                                 # page-locked worker buffer: no staging copy at all
+                    self.q.put(({'buf': d[0], 'ev': None, 'release': d[1]}, yt))
+                else:
+                    self.q.put((self._stage(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x), yt))
         except BaseException as e:                            # noqa: B902 -- everything goes to the consumer
             self.q.put(e)
 
@@ -139,7 +144,10 @@ class _Prefetcher(object):
             xd = slot['buf'].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            slot['ev'] = ev                                   # the producer waits for it before it overwrites the buffer
+            if slot.get('release') is not None:
+                slot['release'](ev)                           # worker buffer: the pool waits for it before the next refill
+            else:
+                slot['ev'] = ev                               # the producer waits for it before it overwrites the buffer
         else:
             xd = slot['buf'].clone()                          # CPU consumers (tests) may keep a batch: hand out a copy, not the ring buffer
         self._cur = (xd, yt.to(self.device, non_blocking=True) if yt is not None else None)
@@ -154,11 +162,12 @@ class _WorkerPool(object):
     GROUP = 16       # workers that share one batch: with 128 workers on one 512-image batch each has ~5 ms of work per batch and is
     # asleep most of the time (wake-ups dominate) -- so the pool is cut into groups and every group works on a DIFFERENT batch.
 
-    def __init__(self, workers, shape):
+    def __init__(self, workers, shape, pin=False):
         import atexit
         import subprocess
         import sys
         self.shape = tuple(shape)
+        self.pin = bool(pin)
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1',
                    OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
@@ -174,13 +183,24 @@ class _WorkerPool(object):
         # Every group has TWO batches in the pipe (one being decoded, the next already waiting on its workers' stdin): a group
         # that has to wait for the parent to copy its batch out before it gets the next one idles a third of the time.
         self.DEPTH = 2 * len(self.groups)
-        self.RING = self.DEPTH + 1               # batch buffers in rotation: the open tickets + the one being copied out
+        # batch buffers in rotation: the open tickets + the one being copied out; with `pin` the buffers themselves are
+        # page-locked (hipHostRegister on the /dev/shm mapping) and the GPU copies straight out of them, so a buffer also stays
+        # busy while it waits in the prefetch queue and until its copy's event has fired: 4 more
+        self.RING = self.DEPTH + (5 if self.pin else 1)
         for k in range(self.RING):
             fd, path = tempfile.mkstemp(prefix='fte_batch_%d_%d_' % (os.getpid(), k), dir=base)
             os.close(fd)
             self.files.append(path)
             self.maps.append(np.memmap(path, dtype=np.float32, mode='w+', shape=self.shape))
         self.turn = 0
+        self.events = [None] * self.RING         # per buffer: the event of the host-to-device copy that last read it
+        self.tensors = None
+        if self.pin:
+            rt = torch.cuda.cudart()
+            self.tensors = [torch.from_numpy(m) for m in self.maps]
+            for t in self.tensors:
+                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 4, 0)) != 0 or not t.is_pinned():
+                    raise RuntimeError('hipHostRegister of a /dev/shm batch buffer failed')
         atexit.register(self.close)
 
     def close(self):
@@ -195,6 +215,15 @@ class _WorkerPool(object):
             except Exception:
                 p.kill()
         self.procs = []
+        if self.tensors:
+            try:
+                torch.cuda.synchronize()
+                rt = torch.cuda.cudart()
+                for t in self.tensors:
+                    rt.cudaHostUnregister(t.data_ptr())
+            except Exception:
+                pass
+            self.tensors = None
         self.maps = []
         for f in self.files:
             try:
@@ -211,6 +240,9 @@ class _WorkerPool(object):
         k = self.turn % self.RING
         procs = self.groups[self.turn % len(self.groups)]
         self.turn += 1
+        if self.events[k] is not None:           # the GPU copy that read this buffer must have finished before workers refill it
+            self.events[k].synchronize()
+            self.events[k] = None
         n = len(procs)
         used = []
         for i, p in enumerate(procs):
@@ -239,6 +271,16 @@ class _WorkerPool(object):
         if err is not None:
             raise RuntimeError('decode worker: %s' % err)
         return self.maps[k]
+
+    def direct(self, array):
+        """(page-locked tensor over `array`, callback taking the copy's event) if `array` is one of this pool's registered
+        buffers, else None"""
+        if not self.tensors:
+            return None
+        for k, m in enumerate(self.maps):
+            if m is array:
+                return self.tensors[k], (lambda ev, k=k: self.events.__setitem__(k, ev))
+        return None
 
     def fill(self, rows, params):
         return self.wait(self.submit(rows, params))
@@ -303,10 +345,11 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
     if num_workers is None:
         num_workers = int(os.environ.get('FTE_LOADER_WORKERS', '-1'))
         if num_workers < 0:
-            # measured on the MI355X host (to the GPU through the pinned staging ring): 16 workers 19.3 k, 32 workers 23.7 k,
-            # 48 workers 24.5 k, 64 workers 23.4 k images/s
-            num_workers = min(max(1, cpu_count() // 2 // max(1, world_size)), 32, shard // 4) if shard >= 64 else 0
-    procs = _WorkerPool(num_workers, (shard, out_h, out_w, num_channels)) if num_workers > 0 else None
+            # measured on the MI355X host (to the GPU straight out of the page-locked worker buffers): 16 workers 18.7 k,
+            # 32 workers 23.8 k, 48 workers 27.1 k images/s (through a staging copy: 24.5 k at 48)
+            num_workers = min(max(1, cpu_count() // 2 // max(1, world_size)), 48, shard // 4) if shard >= 64 else 0
+    on_gpu = torch.device(device).type == 'cuda'
+    procs = _WorkerPool(num_workers, (shard, out_h, out_w, num_channels), pin=on_gpu) if num_workers > 0 else None
     pool = None if procs else ThreadPoolExecutor(max(1, cpu_count() // 2))
     params = (num_channels, input_height, input_width, crop_height, crop_width, augmentation)
 
@@ -331,7 +374,7 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
         x = np.stack(imgs).reshape(shard, out_h, out_w, num_channels)
         return x, labels
 
-    src = _BatchSource(_Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total))
+    src = _BatchSource(_Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total, pool=procs))
     return {'images': src.images, 'labels': src.labels, 'num_classes': num_classes_total,
             'num_examples': num_examples_total, 'batch_size': batch_size}
 
@@ -346,7 +389,7 @@ def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width,
         num_workers = int(os.environ.get('FTE_LOADER_WORKERS', '-1'))
         if num_workers < 0:
             num_workers = min(max(1, cpu_count() // 2), 32, batch_size // 4) if batch_size >= 64 else 0
-    procs = _WorkerPool(num_workers, (batch_size, input_height, input_width, num_channels)) if num_workers > 0 else None
+    procs = _WorkerPool(num_workers, (batch_size, input_height, input_width, num_channels), pin=torch.device(device).type == 'cuda') if num_workers > 0 else None
     pool = None if procs else ThreadPoolExecutor(8)
     state = {'pos': 0}
     params = (num_channels, input_height, input_width, -1, -1, 0)
@@ -365,7 +408,7 @@ def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width,
         imgs = list(pool.map(lambda q: (_decode(q, num_channels, input_height, input_width) - 0.5) / 0.5, draw()))
         return np.stack(imgs).astype(np.float32), None
 
-    pf = _Prefetcher(make_batch, torch.device(device))
+    pf = _Prefetcher(make_batch, torch.device(device), pool=procs)
     return (lambda: pf.advance()[0]), num_examples
 
 
