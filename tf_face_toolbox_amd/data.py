@@ -174,6 +174,14 @@ class _WorkerPool(object):
         self.procs = [subprocess.Popen([sys.executable, '-m', 'tf_face_toolbox_amd._decode_worker'], stdin=subprocess.PIPE,
                                        stdout=subprocess.PIPE, env=env) for _ in range(workers)]
         base = '/dev/shm' if os.path.isdir('/dev/shm') else None
+        if base is not None:                      # a small /dev/shm (container default 64 MB) would end the workers with SIGBUS
+            try:
+                vfs = os.statvfs(base)
+                need = (2 * max(1, workers // self.GROUP) + 6) * int(np.prod(self.shape)) * 4
+                if vfs.f_bavail * vfs.f_frsize < need + (64 << 20):
+                    base = None                   # fall back to the default temporary directory (file-backed mapping)
+            except OSError:
+                base = None
         import tempfile
         self.files, self.maps = [], []
         gs = min(self.GROUP, workers)
