@@ -164,6 +164,12 @@ int fte_bn_train_bwd(const float* dy, const float* ymask, const float* z, const 
 int fte_bn_train_bwd_zmask(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
                            const float* scale, const float* shift, float* dz, float* dgamma, float* dbeta, long rows, int c,
                            void* ws, size_t ws_bytes, void* stream);
+/* Residual blocks (BN -> add shortcut -> ReLU, nets/resnet.py:97-112): g = dy * (y > 0) is needed twice, by the shortcut and by
+ * this BN's backward.  The reduce pass writes it to g_out as a by-product and the apply pass reads it back -- no separate
+ * fte_relu_bwd launch (3 tensor passes).  Bit-identical to fte_relu_bwd followed by fte_bn_train_bwd without a mask. */
+int fte_bn_train_bwd_res(const float* dy, const float* y, const float* z, const float* gamma, const float* mean, const float* rstd,
+                         float* g_out, float* dz, float* dgamma, float* dbeta, long rows, int c,
+                         void* ws, size_t ws_bytes, void* stream);
 /* The two halves of fte_bn_train_fwd / fte_bn_infer_fwd without the apply pass: batch statistics -> mean, rstd,
  * scale = gamma*rstd, shift = beta - mean*scale (+ the moving statistics), and the inference coefficients from the
  * moving statistics.  For consumers that apply scale / shift themselves (fte_channel_gather_affine). */

@@ -190,3 +190,23 @@ def test_se_gate_pieces():
         check_maxabs(host(o), f(v), 1e-6, 'act fwd')
         d = torch.empty(1000, device='cuda'); call('fte_act_bwd', dev(v), o, d, 1000, kind, stream())
         check_maxabs(host(d), v * df(f(v)), 1e-5, 'act bwd')
+
+
+@pytest.mark.parametrize('rows,c', [(3 * 14 * 14, 256), (128 * 7 * 7, 1024), (50, 64), (37, 8)])
+def test_residual_bn_backward_writes_the_masked_gradient_as_a_by_product(rows, c):
+    """fte_bn_train_bwd_res == fte_relu_bwd followed by fte_bn_train_bwd without a mask, bit for bit: g = dy * (y > 0) for the
+    shortcut, dz / dgamma / dbeta for the branch."""
+    g = torch.Generator(device='cuda').manual_seed(rows + c)
+    rnd = lambda *sh: torch.randn(*sh, device='cuda', generator=g)
+    z, res, dy = rnd(rows, c), rnd(rows, c), rnd(rows, c)
+    gamma, beta = rnd(c) * 0.5 + 1.0, rnd(c) * 0.3
+    buf, nb = ws(query('fte_bn_ws_bytes', c))
+    mean, rstd, scale, shift = [torch.empty(c, device='cuda') for _ in range(4)]
+    y = torch.empty_like(z)
+    call('fte_bn_train_fwd', z, gamma, beta, res, y, mean, rstd, scale, shift, None, None, rows, c, 1e-5, 0.9, 1, buf, nb, stream())
+    g0 = torch.empty_like(z); dz0 = torch.empty_like(z); dg0 = torch.empty(c, device='cuda'); db0 = torch.empty(c, device='cuda')
+    call('fte_relu_bwd', dy, y, g0, dy.numel(), stream())
+    call('fte_bn_train_bwd', g0, None, z, gamma, mean, rstd, dz0, dg0, db0, rows, c, buf, nb, stream())
+    g1 = torch.full_like(z, 7.0); dz1 = torch.empty_like(z); dg1 = torch.empty(c, device='cuda'); db1 = torch.empty(c, device='cuda')
+    call('fte_bn_train_bwd_res', dy, y, z, gamma, mean, rstd, g1, dz1, dg1, db1, rows, c, buf, nb, stream())
+    assert torch.equal(g0, g1) and torch.equal(dz0, dz1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)

@@ -38,6 +38,7 @@ _SIGS = {
     'fte_bn_infer_fwd': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_int, _P]),
     'fte_bn_train_bwd': (c_int, [_P] * 9 + [c_long, c_int, _P, c_size_t, _P]),
     'fte_bn_train_bwd_zmask': (c_int, [_P] * 10 + [c_long, c_int, _P, c_size_t, _P]),
+    'fte_bn_train_bwd_res': (c_int, [_P] * 10 + [c_long, c_int, _P, c_size_t, _P]),
     'fte_bn_train_stats': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_float, _P, c_size_t, _P]),
     'fte_bn_infer_coef': (c_int, [_P] * 6 + [c_int, c_float, _P]),
     'fte_relu_bwd': (c_int, [_P] * 3 + [c_long, _P]),

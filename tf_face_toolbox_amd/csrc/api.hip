@@ -822,14 +822,21 @@ int fte_bn_train_bwd(const float* dy, const float* ymask, const float* z, const 
                      void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !z || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || rows <= 0 || c % 4) return FTE_EINVAL;
     if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
-    return rc(l_bn_bwd(dy, ymask, z, gamma, mean, rstd, nullptr, nullptr, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
+    return rc(l_bn_bwd(dy, ymask, z, gamma, mean, rstd, nullptr, nullptr, nullptr, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
+}
+int fte_bn_train_bwd_res(const float* dy, const float* y, const float* z, const float* gamma, const float* mean, const float* rstd,
+                         float* g_out, float* dz, float* dgamma, float* dbeta, long rows, int c,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !y || !z || !gamma || !mean || !rstd || !g_out || !dz || !dgamma || !dbeta || rows <= 0 || c % 4) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    return rc(l_bn_bwd(dy, y, z, gamma, mean, rstd, nullptr, nullptr, g_out, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
 }
 int fte_bn_train_bwd_zmask(const float* dy, const float* z, const float* gamma, const float* mean, const float* rstd,
                            const float* scale, const float* shift, float* dz, float* dgamma, float* dbeta, long rows, int c,
                            void* ws, size_t ws_bytes, void* stream) {
     if (!dy || !z || !gamma || !mean || !rstd || !scale || !shift || !dz || !dgamma || !dbeta || rows <= 0 || c % 4) return FTE_EINVAL;
     if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
-    return rc(l_bn_bwd(dy, nullptr, z, gamma, mean, rstd, scale, shift, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
+    return rc(l_bn_bwd(dy, nullptr, z, gamma, mean, rstd, scale, shift, nullptr, dz, dgamma, dbeta, rows, c, (float*)ws, (hipStream_t)stream));
 }
 int fte_bn_train_stats(const float* z, const float* gamma, const float* beta, float* mean, float* rstd, float* scale, float* shift,
                        float* moving_mean, float* moving_var, long rows, int c, float eps, float decay,

@@ -14,8 +14,8 @@ hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, co
                       int relu, hipStream_t st);
 hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st);
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
-                    const float* rstd, const float* zsc, const float* zsf, float* dz, float* dgamma, float* dbeta, long rows, int C,
-                    float* part, hipStream_t st);
+                    const float* rstd, const float* zsc, const float* zsf, float* gout, float* dz, float* dgamma, float* dbeta,
+                    long rows, int C, float* part, hipStream_t st);
 hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
 hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
 hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st);

@@ -135,8 +135,8 @@ template <int Q>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                                const float* __restrict__ z, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ zsc,
-                                                               const float* __restrict__ zsf, float* __restrict__ part,
-                                                               long rows, int C, long rows_per_split) {
+                                                               const float* __restrict__ zsf, float* __restrict__ gout,
+                                                               float* __restrict__ part, long rows, int C, long rows_per_split) {
     constexpr int RL = 256 / Q;
     __shared__ f32x4 sh[2][RL][Q];
     const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
             }
+            if (gout) *reinterpret_cast<f32x4*>(gout + r * C + ch) = g;      // the masked gradient as a by-product (residual BN)
             sg += g;
             sgx += g * ((zz - mu) * rs);
         };
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                             const float* __restrict__ z, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ zsc,
-                                                            const float* __restrict__ zsf, float* __restrict__ part,
-                                                            long rows, int C, long rows_per_split) {
+                                                            const float* __restrict__ zsf, float* __restrict__ gout,
+                                                            float* __restrict__ part, long rows, int C, long rows_per_split) {
     __shared__ float sh[2][4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int ch = blockIdx.x * 64 + c;
@@ -310,6 +311,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             float g = dy[r * C + ch];
             const float zz = z[r * C + ch];
             if (zsc ? !(__builtin_fmaf(zz, sc, sf) > 0.f) : (ymask && !(ymask[r * C + ch] > 0.f))) g = 0.f;
+            if (gout) gout[r * C + ch] = g;
             sg += g;
             sgx += g * ((zz - mu) * rs);
         }
@@ -640,22 +642,23 @@ hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStre
     return hipGetLastError();
 }
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
-                    const float* rstd, const float* zsc, const float* zsf, float* dz, float* dgamma, float* dbeta, long rows, int C,
-                    float* part, hipStream_t st) {
+                    const float* rstd, const float* zsc, const float* zsf, float* gout, float* dz, float* dgamma, float* dbeta,
+                    long rows, int C, float* part, hipStream_t st) {
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
     float* coef = part + (long)splits * 2 * C;
     switch (quads_per_block(C)) {
-        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
-        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
-        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
-        case 8: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps); break;
-        default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, part, rows, C, rps);
+        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
+        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
+        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
+        case 8: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
+        default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
                        dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C);
+    if (gout) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C);
     return hipGetLastError();
 }
 hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {

@@ -874,13 +874,14 @@ class GraphNet(Network):
                 b = self.bn[out]
                 c = self.shapes[out][-1]
                 rows = dy.numel() // c
-                if res is not None:                      # the shortcut gets g = dy * (out > 0)
-                    g = self._new(out)
-                    call('fte_relu_bwd', dy, T[out], g, dy.numel(), st)
-                    self._put(res, g)
-                    dy, relu = g, 0
                 dz = torch.empty_like(T[inp])
-                if relu:                                 # ReLU mask recomputed from z: the output is not read
+                if res is not None:                      # the shortcut gets g = dy * (out > 0): a by-product of the reduce pass
+                    g = self._new(out)
+                    call('fte_bn_train_bwd_res', dy, T[out], T[inp], self.view(pre + '/gamma'), b['mean'], b['rstd'], g, dz,
+                         self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), rows, c,
+                         self.ws, self.ws_bytes, st)
+                    self._put(res, g)
+                elif relu:                                 # ReLU mask recomputed from z: the output is not read
                     call('fte_bn_train_bwd_zmask', dy, T[inp], self.view(pre + '/gamma'), b['mean'], b['rstd'], b['scale'], b['shift'],
                          dz, self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), rows, c,
                          self.ws, self.ws_bytes, st)
