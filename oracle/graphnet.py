@@ -6,6 +6,8 @@ reverse accumulating gradients.  The HIP engine (tf_face_toolbox_amd/nets/graph.
 op lists, which is what makes the layer-by-layer parity checks line up."""
 from collections import OrderedDict
 
+import contextlib
+
 import numpy as np
 
 from . import ops
@@ -51,7 +53,9 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
             _, _, inp, wname, stride, groups = op
             x = env[inp]
             gw = x.shape[-1] // groups
-            with ops.operand_rounding(None):          # the engine's grouped 3x3 kernel is plain fp32 in every mode
+            # bf16 mode: the engine's stride-1 grouped 3x3 runs on the bf16 MFMA (operands rounded like every other MFMA product);
+            # the stride-2 ones stay plain fp32 vector code
+            with (contextlib.nullcontext() if stride == 1 else ops.operand_rounding(None)):
                 env[out] = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], params[wname][g], stride)
                                            for g in range(groups)], axis=-1)
         elif kind == 'se':          # ('se', out, inp, prefix[, scope1, scope2]): nets/shufflenet_v2.py:79-85
@@ -183,11 +187,15 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
             gw = x.shape[-1] // groups
             dx = np.zeros_like(x)
             dw = np.zeros_like(params[wname])
-            with ops.operand_rounding(None):
-                for g in range(groups):
-                    dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw], stride)
-                    dx[..., g * gw:(g + 1) * gw] = dxg
-                    dw[g] = dwg
+            # data gradient: bf16 MFMA at stride 1 in the bf16 mode (rounded operands); filter gradient: fp32 vector code in every mode
+            for g in range(groups):
+                xg, wg, dyg = x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw]
+                with ops.operand_rounding(None):
+                    dxg, dwg = ops.conv2d_bwd(xg, wg, dyg, stride)
+                if stride == 1 and ops.rounding_active():
+                    dxg, _ = ops.conv2d_bwd(xg, wg, dyg, stride)
+                dx[..., g * gw:(g + 1) * gw] = dxg
+                dw[g] = dwg
             acc(gp, wname, dw)
             acc(gt, inp, dx)
         elif kind == 'se':

@@ -47,6 +47,11 @@ def _r(a):
     return a if _OPERAND_ROUND is None else _OPERAND_ROUND(a)
 
 
+def rounding_active():
+    """True inside operand_rounding('bf16')"""
+    return _OPERAND_ROUND is not None
+
+
 def mfma_matmul(a, b):
     """a @ b as the engine's MFMA kernels compute it: operands rounded per operand_rounding(), fp32/64 accumulate."""
     return _r(a) @ _r(b)

@@ -201,3 +201,28 @@ def test_spherenet_step_with_bf16_copies_equals_operand_mode(bf16_mode):
         outs[-1] += (e_eval,)
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
     _close(outs[1][1], outs[0][1], 'gradient arena', 1e-4); _close(outs[1][2], outs[0][2], 'embedding', 2e-5); _close(outs[1][3], outs[0][3], 'eval embedding', 2e-5)
+
+
+@pytest.mark.parametrize('n,h,w,c,groups', [(3, 14, 14, 128, 32), (2, 9, 7, 256, 32), (2, 8, 8, 512, 32), (1, 5, 5, 1024, 32), (2, 6, 6, 64, 8)])
+def test_grouped_3x3_on_the_bf16_mfma(n, h, w, c, groups):
+    """fte_gconv3x3_pack_bf16 + fte_gconv3x3_s1_bf16 (stride 1: block-diagonal 32-channel slices on v_mfma_f32_32x32x16_bf16) against
+    the grouped convolution with bf16-rounded operands (oracle/ops.py operand_rounding): forward and data gradient, 2e-5."""
+    r = np.random.default_rng(c + groups)
+    gw = c // groups
+    x = r.standard_normal((n, h, w, c)); wt = r.standard_normal((groups, 3, 3, gw, gw)) * 0.2
+    dz = r.standard_normal((n, h, w, c))
+    with ops.operand_rounding('bf16'):
+        y_ref = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], wt[g], 1) for g in range(groups)], axis=-1)
+        dx_ref = np.concatenate([ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], wt[g], dz[..., g * gw:(g + 1) * gw], 1)[0]
+                                 for g in range(groups)], axis=-1)
+    words = (c // 32) * 9 * 1024
+    wf = torch.empty(words, dtype=torch.int16, device='cuda'); wd = torch.empty(words, dtype=torch.int16, device='cuda')
+    _lib.call('fte_gconv3x3_pack_bf16', dev(wt.reshape(groups, 9, gw, gw)), wf, wd, c, groups, stream())
+    y = torch.full((n, h, w, c), 7.0, device='cuda'); dx = torch.full((n, h, w, c), 7.0, device='cuda')
+    _lib.call('fte_gconv3x3_s1_bf16', dev(x), wf, y, n, h, w, c, stream())
+    _lib.call('fte_gconv3x3_s1_bf16', dev(dz), wd, dx, n, h, w, c, stream())
+    check_maxabs(host(y), y_ref, 2e-5, 'grouped fwd, bf16 operands')
+    check_maxabs(host(dx), dx_ref, 2e-5, 'grouped dgrad, bf16 operands')
+    # and it really is the rounded product: the unrounded one is far outside that tolerance
+    y_plain = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], wt[g], 1) for g in range(groups)], axis=-1)
+    assert np.abs(host(y) - y_plain).max() > 1e-4 * np.abs(y_plain).max()

@@ -894,6 +894,16 @@ int fte_gconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     return rc(l_gconv_fwd(x, w, y, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
 }
+int fte_gconv3x3_pack_bf16(const float* w, uint16_t* wpk_fwd, uint16_t* wpk_dgrad, int c, int groups, void* stream) {
+    if (!w || !wpk_fwd || !wpk_dgrad || groups <= 0 || c % groups || c % 32) return FTE_EINVAL;
+    const int gw = c / groups;
+    if (gw != 4 && gw != 8 && gw != 16 && gw != 32) return FTE_EINVAL;
+    return rc(l_gconv_pack16(w, wpk_fwd, wpk_dgrad, c, groups, (hipStream_t)stream));
+}
+int fte_gconv3x3_s1_bf16(const float* x, const uint16_t* wpk, float* y, int n, int h, int wd, int c, void* stream) {
+    if (!x || !wpk || !y || n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32 || (long)n * h * wd >= ((long)1 << 31)) return FTE_EINVAL;
+    return rc(l_gconv_mfma16(x, wpk, y, n, h, wd, c, (hipStream_t)stream));
+}
 int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int stride, void* stream) {
     if (!dz || !w || !dx || n <= 0 || groups <= 0 || c % groups || (stride != 1 && stride != 2)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);

@@ -789,6 +789,94 @@ __global__ __launch_bounds__(256) void gconv3x3_kernel(const float* __restrict__
     }
 }
 
+// ---- bf16-mode grouped 3x3 (stride 1) on the matrix cores -------------------------------------------------------------------
+// ResNeXt's grouped conv has 4..32 channels per group: as fp32 vector code it runs at the VALU roofline (60 us for 3.7 GFLOP)
+// and, in the bf16 MFMA mode of the step, became a quarter of it.  Here a 32-channel SLICE of the tensor (= 32 / gw whole
+// groups, input and output channels alike) is a dense 3x3 convolution 32 -> 32 whose filter is block-diagonal: per wave a
+// [32 pixels] x [32 channels] output tile = 9 taps x 2 k-steps of v_mfma_f32_32x32x16_bf16.  The zero blocks multiply for
+// nothing (8x the FLOPs at gw = 4), but at 16x the fp32 MFMA rate the kernel is HBM-bound anyway.  No LDS, no barrier: a lane
+// loads the 8 channels of ITS pixel and k-half for a tap straight from global memory (fp32, rounded to bf16 in registers --
+// the operand rounding of the bf16 mode, RNE) and the slice's 18 filter fragments live in registers for the wave's whole walk.
+typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
+typedef float f32x16_l __attribute__((ext_vector_type(16)));
+typedef float f32x2_l __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_l __attribute__((ext_vector_type(2)));
+
+// wpk[slice][tap][col 32][k 32] (k contiguous), bf16.  fwd: col = output channel, k = input channel, tap as given;
+// dgrad (dx = conv of dz with the mirrored, transposed filter): col = input channel, k = output channel, tap mirrored.
+// w is [group][tap][ic][oc] fp32 (the grouped layer's own layout).
+__global__ __launch_bounds__(256) void gconv_pack16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                                           unsigned short* __restrict__ wd, int c, int gw) {
+    const int total = (c / 32) * 9 * 32 * 32;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int k = i & 31, col = (i >> 5) & 31, tap = (i >> 10) % 9, slice = (i >> 10) / 9;
+        const bool same = (k / gw) == (col / gw);
+        const int g = slice * (32 / gw) + col / gw;
+        float vf = 0.f, vd = 0.f;
+        if (same) {
+            vf = w[(((long)g * 9 + tap) * gw + (k % gw)) * gw + (col % gw)];            // W[tap][ic = k][oc = col]
+            vd = w[(((long)g * 9 + (8 - tap)) * gw + (col % gw)) * gw + (k % gw)];      // W[mirror][ic = col][oc = k]
+        }
+        wf[i] = __builtin_bit_cast(unsigned short, (__bf16)vf);
+        wd[i] = __builtin_bit_cast(unsigned short, (__bf16)vd);
+    }
+}
+
+__global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
+                                                              float* __restrict__ y, int n, int h, int wd, int c) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int slice = blockIdx.y;
+    bf16x8_l fb[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            fb[t][ks] = *reinterpret_cast<const bf16x8_l*>(wpk + ((((long)slice * 9 + t) * 32 + li) * 32 + 16 * ks + 8 * lh));
+    const long npix = (long)n * h * wd;
+    const long ntiles = (npix + 31) / 32;
+    const float* xs = x + slice * 32 + 8 * lh;
+    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long p = tile * 32 + li;
+        const bool pok = p < npix;
+        const unsigned pu = (unsigned)(pok ? p : 0);
+        const int ox = (int)(pu % (unsigned)wd);
+        const unsigned t2 = pu / (unsigned)wd;
+        const int oy = (int)(t2 % (unsigned)h), img = (int)(t2 / (unsigned)h);
+        f32x16_l acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int sy = oy + r - 1;
+            const bool rok = pok && sy >= 0 && sy < h;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sx = ox + q - 1;
+                const bool ok = rok && sx >= 0 && sx < wd;
+                const float* src = xs + ((long)(img * h + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
+                    if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+                    bf16x8_l fa;
+                    const bf16x2_l c0 = __builtin_convertvector(f32x2_l{v0[0], v0[1]}, bf16x2_l), c1 = __builtin_convertvector(f32x2_l{v0[2], v0[3]}, bf16x2_l);
+                    const bf16x2_l c2 = __builtin_convertvector(f32x2_l{v1[0], v1[1]}, bf16x2_l), c3 = __builtin_convertvector(f32x2_l{v1[2], v1[3]}, bf16x2_l);
+                    fa[0] = c0[0]; fa[1] = c0[1]; fa[2] = c1[0]; fa[3] = c1[1]; fa[4] = c2[0]; fa[5] = c2[1]; fa[6] = c3[0]; fa[7] = c3[1];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[r * 3 + q][ks], acc, 0, 0, 0);
+                }
+            }
+        }
+        // C layout: column (channel) = lane & 31, row (pixel) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5): 32 lanes write one pixel's 128 B
+        float* yo = y + slice * 32 + li;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (pr < npix) yo[pr * c] = acc[i];
+        }
+    }
+}
+
 // filter gradient: block = (pixel chunk, group set); thread = (group, kernel row r, ic quad, oc quad); partial [chunk][G*9*gw*gw].
 // Per pixel a thread loads ONE float4 of dz (its oc quad) and THREE float4 of x (its ic quad at the three taps of row r) for
 // 3 x 4 x 4 multiply-adds into 12 float4 accumulators: 12 FMAs per load instruction.  (A thread per (ic, oc quad) with nine scalar
@@ -939,6 +1027,19 @@ hipError_t l_gconv_fwd(const float* x, const float* w, float* y, int n, int h, i
 hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int ho, int wo,
                          int stride, int pt, int pl, hipStream_t st) {
     return gconv_launch<true>(dz, w, dx, n, h, wd, c, groups, ho, wo, stride, pt, pl, st);
+}
+hipError_t l_gconv_pack16(const float* w, unsigned short* wf, unsigned short* wd, int c, int groups, hipStream_t st) {
+    const int total = (c / 32) * 9 * 1024;
+    hipLaunchKernelGGL(gconv_pack16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wf, wd, c, c / groups);
+    return hipGetLastError();
+}
+hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, hipStream_t st) {
+    const long ntiles = ((long)n * h * wd + 31) / 32;
+    long bx = (ntiles + 3) / 4;
+    const long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(gconv3x3_mfma16_kernel, dim3((unsigned)bx, c / 32), dim3(256), 0, st, x, wpk, y, n, h, wd, c);
+    return hipGetLastError();
 }
 // pixel chunks of the grouped filter gradient: every thread walks its chunk serially (10 dependent-latency loads per
 // pixel), so the chunk count IS the memory-level parallelism -- 64 pixels per chunk, bounded by a 96 MiB partial buffer

@@ -84,6 +84,7 @@ class GraphNet(Network):
         self.seed = seed
         self.built = False
         self._views = {}
+        self._gpacks = {}
         self.tower_scale = 1.0
         self.global_step = 0
         self.update_moving_stats = True      # data_parallel.py:242-243: UPDATE_OPS of tower 0 only
@@ -605,7 +606,12 @@ class GraphNet(Network):
                          b['scale'], b['shift'], rows, c, BN_EPS, relu, st)
             elif kind == 'gconv':
                 ih, iw, c = self.shapes[op[2]]
-                call('fte_gconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[5], op[4], st)
+                pk = self._gconv_pack(op)
+                if pk is not None:                             # bf16 MFMA mode, stride 1: block-diagonal slices on the matrix cores
+                    call('fte_gconv3x3_pack_bf16', self.view(op[3]), pk[0], pk[1], c, op[5], st)
+                    call('fte_gconv3x3_s1_bf16', T[op[2]], pk[0], T[out], n, ih, iw, c, st)
+                else:
+                    call('fte_gconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[5], op[4], st)
             elif kind == 'se':
                 inp = op[2]
                 w1, b1, w2, b2, hd = self._se_names(op)
@@ -639,6 +645,21 @@ class GraphNet(Network):
                 call('fte_gemm_nn', T[op[2]], self.view(op[3]), None, T[out], n, self.cpad, k, self.ws, self.ws_bytes, st)
             else:
                 raise RuntimeError('op %s must have been fused away' % kind)
+
+    def _gconv_pack(self, op):
+        """(forward, dgrad) packed bf16 filters of a grouped 3x3 that runs on the matrix cores -- bf16 MFMA mode, stride 1,
+        4 / 8 / 16 / 32 channels per group -- else None (fp32 vector kernels)."""
+        _, _, inp, wname, stride, groups = op
+        c = self.shapes[inp][-1]
+        if stride != 1 or c % 32 or (c // groups) not in (4, 8, 16, 32) or _lib.get_mfma_dtype() != 'bf16' \
+                or os.environ.get('FTE_GCONV_MFMA', '1') == '0':
+            return None
+        pk = self._gpacks.get(wname)
+        if pk is None:
+            words = (c // 32) * 9 * 1024
+            pk = self._gpacks[wname] = (torch.empty(words, dtype=torch.int16, device=self.device),
+                                        torch.empty(words, dtype=torch.int16, device=self.device))
+        return pk
 
     @staticmethod
     def _direct_stem(k, cin, cout):
@@ -867,7 +888,11 @@ class GraphNet(Network):
                 ih, iw, c = self.shapes[inp]
                 wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
-                call('fte_gconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, groups, stride, st)
+                pk = self._gconv_pack(op)
+                if pk is not None:                       # packed by this step's forward pass (the weights have not changed since)
+                    call('fte_gconv3x3_s1_bf16', dy, pk[1], dx, n, ih, iw, c, st)
+                else:
+                    call('fte_gconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, groups, stride, st)
                 self._put(inp, dx)
             elif kind in ('bn', 'bnstats'):
                 _, _, inp, pre, res, relu = op
