@@ -824,48 +824,85 @@ __global__ __launch_bounds__(256) void gconv_pack16_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                               float* __restrict__ y, int n, int h, int wd, int c) {
+    // the slice's 9 x [32][32] bf16 filter (18 KB) sits in LDS; a fragment is one ds_read_b128 right before its MFMA
+    __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
+    // per wave: the 32 pixels x 128 B of one tap, twice (the next tap lands while this one multiplies).  A lane FETCHES 16-byte
+    // piece (lane & 7) of pixels (lane >> 3) + 8 j -- one instruction = 8 whole 128-byte rows -- and READS the 32 bytes of ITS
+    // pixel and k-half back as an MFMA operand.  (Fetching the operand layout directly -- 16 bytes of 64 different rows per
+    // instruction -- made every row go through the L1 tags four times: 67 us for the 28x28x128 layer, address-bound.)
+    // piece p of pixel r is stored at slot p ^ (r & 7): fetch-side stores and operand-side loads are both conflict-free.
+    __shared__ __attribute__((aligned(16))) float stage[4][2][32 * 32];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int slice = blockIdx.y;
-    bf16x8_l fb[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            fb[t][ks] = *reinterpret_cast<const bf16x8_l*>(wpk + ((((long)slice * 9 + t) * 32 + li) * 32 + 16 * ks + 8 * lh));
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wpk + (long)slice * 9 * 1024);
+        uint4* dst = reinterpret_cast<uint4*>(wsh);
+        for (int i = threadIdx.x; i < 9 * 1024 / 8; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
     const long npix = (long)n * h * wd;
     const long ntiles = (npix + 31) / 32;
-    const float* xs = x + slice * 32 + 8 * lh;
+    const float* xs = x + slice * 32 + ((lane & 7) << 2);
+    const int fr = lane >> 3;                         // fetch row inside a group of 8 pixels
+    float* st = &stage[wv][0][0];
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
-        const long p = tile * 32 + li;
-        const bool pok = p < npix;
-        const unsigned pu = (unsigned)(pok ? p : 0);
-        const int ox = (int)(pu % (unsigned)wd);
-        const unsigned t2 = pu / (unsigned)wd;
-        const int oy = (int)(t2 % (unsigned)h), img = (int)(t2 / (unsigned)h);
+        // the four pixels this lane fetches for: coordinates once per tile
+        int foy[4], fox[4];
+        long fbase[4];
+        bool fok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long p = tile * 32 + fr + 8 * j;
+            fok[j] = p < npix;
+            const unsigned pu = (unsigned)(fok[j] ? p : 0);
+            fox[j] = (int)(pu % (unsigned)wd);
+            const unsigned t2 = pu / (unsigned)wd;
+            foy[j] = (int)(t2 % (unsigned)h);
+            fbase[j] = (long)(t2 / (unsigned)h) * h;
+        }
+        auto fetch = [&](int t, f32x4 (&v)[4]) {
+            const int r = t / 3, q = t - 3 * r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sy = foy[j] + r - 1, sx = fox[j] + q - 1;
+                const bool ok = fok[j] && sy >= 0 && sy < h && sx >= 0 && sx < wd;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(xs + ((fbase[j] + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c);
+                v[j] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto stash = [&](int buf, const f32x4 (&v)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = fr + 8 * j;
+                *reinterpret_cast<f32x4*>(st + buf * 1024 + row * 32 + (((lane & 7) ^ (row & 7)) << 2)) = v[j];
+            }
+        };
         f32x16_l acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        f32x4 va[4], vb[4];
+        fetch(0, va);
+        fetch(1, vb);
+        stash(0, va);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int sy = oy + r - 1;
-            const bool rok = pok && sy >= 0 && sy < h;
+        for (int t = 0; t < 9; ++t) {
+            // registers: tap t + 1 is in (t odd ? va : vb) ... kept simple: two register sets alternate, LDS buffers alternate
+            if (t + 2 < 9) { if (t & 1) fetch(t + 2, vb); else fetch(t + 2, va); }
+            const float* sb = st + (t & 1) * 1024 + li * 32;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int sx = ox + q - 1;
-                const bool ok = rok && sx >= 0 && sx < wd;
-                const float* src = xs + ((long)(img * h + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(src + 16 * ks + 4);
-                    if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-                    bf16x8_l fa;
-                    const bf16x2_l c0 = __builtin_convertvector(f32x2_l{v0[0], v0[1]}, bf16x2_l), c1 = __builtin_convertvector(f32x2_l{v0[2], v0[3]}, bf16x2_l);
-                    const bf16x2_l c2 = __builtin_convertvector(f32x2_l{v1[0], v1[1]}, bf16x2_l), c3 = __builtin_convertvector(f32x2_l{v1[2], v1[3]}, bf16x2_l);
-                    fa[0] = c0[0]; fa[1] = c0[1]; fa[2] = c1[0]; fa[3] = c1[1]; fa[4] = c2[0]; fa[5] = c2[1]; fa[6] = c3[0]; fa[7] = c3[1];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[r * 3 + q][ks], acc, 0, 0, 0);
-                }
+            for (int ks = 0; ks < 2; ++ks) {
+                const int p0 = 4 * ks + 2 * lh;                                  // 16-byte pieces p0, p0 + 1 of this lane's pixel
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(sb + ((p0 ^ (li & 7)) << 2));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(sb + (((p0 + 1) ^ (li & 7)) << 2));
+                bf16x8_l fa;
+                const bf16x2_l c0 = __builtin_convertvector(f32x2_l{v0[0], v0[1]}, bf16x2_l), c1 = __builtin_convertvector(f32x2_l{v0[2], v0[3]}, bf16x2_l);
+                const bf16x2_l c2 = __builtin_convertvector(f32x2_l{v1[0], v1[1]}, bf16x2_l), c3 = __builtin_convertvector(f32x2_l{v1[2], v1[3]}, bf16x2_l);
+                fa[0] = c0[0]; fa[1] = c0[1]; fa[2] = c1[0]; fa[3] = c1[1]; fa[4] = c2[0]; fa[5] = c2[1]; fa[6] = c3[0]; fa[7] = c3[1];
+                const bf16x8_l fb = *reinterpret_cast<const bf16x8_l*>(wsh + ((t * 32 + li) * 32 + 16 * ks + 8 * lh));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
             }
+            if (t + 1 < 9) { if (t & 1) stash(0, va); else stash(1, vb); }      // tap t + 1 -> the other LDS buffer
         }
         // C layout: column (channel) = lane & 31, row (pixel) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5): 32 lanes write one pixel's 128 B
         float* yo = y + slice * 32 + li;
