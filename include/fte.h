@@ -206,6 +206,12 @@ int fte_gconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int
  * wpk_*: (c / 32) * 9 * 1024 uint16.  gw = c / groups in {4, 8, 16, 32}, c % 32 == 0. */
 int fte_gconv3x3_pack_bf16(const float* w, uint16_t* wpk_fwd, uint16_t* wpk_dgrad, int c, int groups, void* stream);
 int fte_gconv3x3_s1_bf16(const float* x, const uint16_t* wpk, float* y, int n, int h, int wd, int c, void* stream);
+/* ... and the filter gradient of those layers: per slice and tap a [32 ic] x [32 oc] product over the pixels (operands rounded to
+ * bf16, fragments transposed out of LDS by ds_read_b64_tr_b16), ordered partials in ws, the groups' diagonal blocks summed into
+ * dw [groups][3][3][gw][gw]. */
+size_t fte_gconv3x3_wgrad_s1_bf16_ws_bytes(int n, int h, int wd, int c);
+int fte_gconv3x3_wgrad_s1_bf16(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups,
+                               void* ws, size_t ws_bytes, void* stream);
 int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups,
                        int stride, void* stream);
 int fte_gconv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups,

@@ -187,15 +187,12 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
             gw = x.shape[-1] // groups
             dx = np.zeros_like(x)
             dw = np.zeros_like(params[wname])
-            # data gradient: bf16 MFMA at stride 1 in the bf16 mode (rounded operands); filter gradient: fp32 vector code in every mode
-            for g in range(groups):
-                xg, wg, dyg = x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw]
-                with ops.operand_rounding(None):
-                    dxg, dwg = ops.conv2d_bwd(xg, wg, dyg, stride)
-                if stride == 1 and ops.rounding_active():
-                    dxg, _ = ops.conv2d_bwd(xg, wg, dyg, stride)
-                dx[..., g * gw:(g + 1) * gw] = dxg
-                dw[g] = dwg
+            # stride 1: all three products on the bf16 MFMA in the bf16 mode (rounded operands); stride 2: fp32 vector code in every mode
+            with (contextlib.nullcontext() if stride == 1 else ops.operand_rounding(None)):
+                for g in range(groups):
+                    dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw], stride)
+                    dx[..., g * gw:(g + 1) * gw] = dxg
+                    dw[g] = dwg
             acc(gp, wname, dw)
             acc(gt, inp, dx)
         elif kind == 'se':

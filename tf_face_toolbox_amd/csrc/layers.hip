@@ -914,6 +914,129 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
     }
 }
 
+// Filter gradient of the same layers on the bf16 MFMA: per 32-channel slice and tap a dense [32 ic] x [32 oc] product over the
+// pixels, D_tap[ic][oc] = sum_p x[p + tap][ic] * dz[p][oc] (the diagonal gw x gw blocks are the groups' gradients; the rest is
+// discarded by the reduction).  Both operands need 8 consecutive PIXELS of one channel per lane while memory is channel-
+// contiguous: rows are fetched whole (coalesced), rounded to bf16 and stored [pixel][channel] in LDS, and the fragments come
+// back through ds_read_b64_tr_b16 -- gfx950's transposing LDS read (scripts/probes/ds_read_tr16.hip pins its lane map).
+// Block = 3 waves, wave r owns kernel row r (3 taps = 3 accumulator blocks); 16 pixels per step; the next step's rows are in
+// flight while this one multiplies.  Partials [chunk][slice][tap][32 oc][gw ic], summed in order by gconv_wgrad16_reduce_kernel.
+typedef short s16x4_l __attribute__((ext_vector_type(4)));
+typedef short s16x8_l __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                    float* __restrict__ part, int n, int h, int wd, int c,
+                                                                    int gw, long steps_per_chunk) {
+    __shared__ __attribute__((aligned(16))) unsigned short img[3][4][16 * 32];      // per wave: 3 taps of x + dz, [16 pixels][32 channels]
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;                        // r = kernel row of this wave
+    const int li = lane & 31, lh = lane >> 5;
+    const int slice = blockIdx.y;
+    const long npix = (long)n * h * wd;
+    const long nsteps = (npix + 15) / 16;
+    const long s0 = (long)blockIdx.x * steps_per_chunk, s1 = min(nsteps, s0 + steps_per_chunk);
+    const int frow = lane >> 3, fpiece = lane & 7;                                  // fetch: rows frow, frow + 8; 16-byte piece
+    const float* xs = x + slice * 32 + (fpiece << 2);
+    const float* ds = dz + slice * 32 + (fpiece << 2);
+    unsigned short* mine = &img[r][0][0];
+    f32x16_l acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    // transposed-read addresses: group g = lane >> 4 reads the 4 x 16 block at (pixel 8 (g >> 1) [+4], channel 16 (g & 1));
+    // lane 4 qq + pp of the group supplies row qq, columns 4 pp .. 4 pp + 3
+    const int g4 = lane >> 4, idx = lane & 15;
+    const int troff = (8 * (g4 >> 1) + (idx >> 2)) * 32 + 16 * (g4 & 1) + 4 * (idx & 3);
+    f32x4 cur[4][2], nxt[4][2];                                                      // [x tap 0..2, dz][row half]
+    auto fetch = [&](long step, f32x4 (&v)[4][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long p = step * 16 + frow + 8 * j;
+            const bool pok = p < npix;
+            const unsigned pu = (unsigned)(pok ? p : 0);
+            const int ox = (int)(pu % (unsigned)wd);
+            const unsigned t2 = pu / (unsigned)wd;
+            const int oy = (int)(t2 % (unsigned)h);
+            const long ib = (long)(t2 / (unsigned)h) * h;
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(ds + (long)pu * c);
+            v[3][j] = pok ? dv : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int sy = oy + r - 1;
+            const bool rok = pok && sy >= 0 && sy < h;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sx = ox + q - 1;
+                const bool ok = rok && sx >= 0 && sx < wd;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + ((ib + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c);
+                v[q][j] = ok ? xv : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    if (s0 < s1) fetch(s0, cur);
+    for (long step = s0; step < s1; ++step) {
+        if (step + 1 < s1) fetch(step + 1, nxt);
+        // round to bf16 and lay the four [16][32] images down ([pixel][channel], 64-byte rows)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 v = cur[t][j];
+                const s16x4_l w = __builtin_bit_cast(s16x4_l, __builtin_convertvector(v, bf16x4_l));      // whole-vector casts: element-wise bit_casts of bf16 lanes were miscompiled
+                *reinterpret_cast<s16x4_l*>(mine + t * 512 + (frow + 8 * j) * 32 + (fpiece << 2)) = w;
+            }
+        // one wave: its LDS accesses execute in order, no barrier -- but the compiler must not move the transposing reads (an
+        // intrinsic on an LDS-address-space pointer) above the plain stores that fill the images
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        auto frag = [&](int t) -> bf16x8_l {
+            const s16x4_l a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_l*)(mine + t * 512 + troff));
+            const s16x4_l b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_l*)(mine + t * 512 + troff + 4 * 32));
+            return __builtin_bit_cast(bf16x8_l, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        const bf16x8_l fz = frag(3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(q), fz, acc[q], 0, 0, 0);
+        if (step + 1 < s1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) cur[t][j] = nxt[t][j];
+        }
+    }
+    // C layout: row (ic) = (i & 3) + 8 (i >> 2) + 4 lh, column (oc) = li.  Only the diagonal gw x gw blocks are groups: a lane keeps
+    // the row quads of its column's group and writes them [oc][ic % gw] (32 * gw floats per tap instead of 1024)
+    float* out = part + (((long)blockIdx.x * gridDim.y + slice) * 9 + r * 3) * 32 * gw + li * gw;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row0 = 8 * j + 4 * lh;
+            if (row0 / gw == li / gw)
+                *reinterpret_cast<f32x4*>(out + q * 32 * gw + (row0 % gw)) = f32x4{acc[q][4 * j], acc[q][4 * j + 1], acc[q][4 * j + 2], acc[q][4 * j + 3]};
+        }
+}
+
+// dW[g][tap][ic][oc] = sum over chunks of the slice partials [chunk][slice][tap][oc 32][ic gw]: 64 outputs x 4 chunk lanes per
+// block, every lane sums its chunks (k = lane, lane + 4, ...) in order and the four are added in a fixed order
+__global__ __launch_bounds__(256) void gconv_wgrad16_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                   int chunks, int slices, int gw, int groups) {
+    const int total = groups * 9 * gw * gw;                      // = slices * 9 * 32 * gw
+    const int kl = threadIdx.x & 3;
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2);          // compact order: (slice, tap, oc 32, ic gw)
+    const bool ok = i < total;
+    const long stride = (long)slices * 9 * 32 * gw;
+    float s = 0.f;
+    if (ok)
+        for (int k = kl; k < chunks; k += 4) s += part[(long)k * stride + i];
+    const float s1 = __shfl_xor(s, 1);
+    const float a = (kl & 1) ? s1 + s : s + s1;                  // (lane 0 + lane 1), (lane 2 + lane 3): the even lane's value first
+    const float a2 = __shfl_xor(a, 2);
+    const float t = (kl & 2) ? a2 + a : a + a2;
+    if (ok && kl == 0) {
+        const int ic = i % gw, col = (i / gw) & 31, tap = (i / (32 * gw)) % 9, slice = i / (9 * 32 * gw);
+        const int ch = slice * 32 + col, g = ch / gw, oc = ch % gw;
+        dw[(((long)g * 9 + tap) * gw + ic) * gw + oc] = t;
+    }
+}
+
 // filter gradient: block = (pixel chunk, group set); thread = (group, kernel row r, ic quad, oc quad); partial [chunk][G*9*gw*gw].
 // Per pixel a thread loads ONE float4 of dz (its oc quad) and THREE float4 of x (its ic quad at the three taps of row r) for
 // 3 x 4 x 4 multiply-adds into 12 float4 accumulators: 12 FMAs per load instruction.  (A thread per (ic, oc quad) with nine scalar
@@ -1076,6 +1199,20 @@ hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, i
     const long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
     if (bx > cap) bx = cap;
     hipLaunchKernelGGL(gconv3x3_mfma16_kernel, dim3((unsigned)bx, c / 32), dim3(256), 0, st, x, wpk, y, n, h, wd, c);
+    return hipGetLastError();
+}
+int l_gconv_wgrad16_chunks(long npix, int c) {
+    const long steps = (npix + 15) / 16;
+    long ch = 1024 / (c / 32);
+    if (ch > steps / 8) ch = steps / 8;
+    return (int)(ch < 1 ? 1 : ch);
+}
+hipError_t l_gconv_wgrad16(const float* x, const float* dz, float* part, float* dw, int n, int h, int wd, int c, int groups,
+                           int chunks, hipStream_t st) {
+    const long steps = ((long)n * h * wd + 15) / 16, spc = (steps + chunks - 1) / chunks;
+    const int gw = c / groups, total = groups * 9 * gw * gw;
+    hipLaunchKernelGGL(gconv3x3_wgrad_mfma16_kernel, dim3(chunks, c / 32), dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc);
+    hipLaunchKernelGGL(gconv_wgrad16_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, part, dw, chunks, c / 32, gw, groups);
     return hipGetLastError();
 }
 // pixel chunks of the grouped filter gradient: every thread walks its chunk serially (10 dependent-latency loads per

@@ -490,6 +490,8 @@ class GraphNet(Network):
             elif kind == 'gconv':
                 ih, iw, cc = self.shapes[op[2]]
                 need = max(need, q('fte_gconv3x3_wgrad_ws_bytes', n, ih, iw, cc, op[5], op[4]))
+                if op[4] == 1 and cc % 32 == 0:
+                    need = max(need, q('fte_gconv3x3_wgrad_s1_bf16_ws_bytes', n, ih, iw, cc))
             elif kind == 'se':
                 cc = shape[-1]
                 hd = self._se_names(op)[4]
@@ -886,7 +888,10 @@ class GraphNet(Network):
             elif kind == 'gconv':
                 _, _, inp, wname, stride, groups = op
                 ih, iw, c = self.shapes[inp]
-                wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
+                if self._gconv_pack(op) is not None:     # bf16 MFMA mode, stride 1
+                    wgrad('fte_gconv3x3_wgrad_s1_bf16', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, wws, self.ws_bytes, wst)
+                else:
+                    wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
                 pk = self._gconv_pack(op)
                 if pk is not None:                       # packed by this step's forward pass (the weights have not changed since)
