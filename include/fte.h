@@ -199,19 +199,20 @@ int fte_dropout_bwd(const float* dy, const float* mask, float* dx, long n, float
  * ------------------------------------------------------------------------- */
 int fte_gconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups,
                      int stride, void* stream);
-/* bf16 MFMA mode, stride 1: the grouped 3x3 on the matrix cores.  A 32-channel slice (32 / gw whole groups) is a dense 3x3
- * conv 32 -> 32 with a block-diagonal filter; fte_gconv3x3_pack_bf16 builds that filter (bf16, k-contiguous) for the forward
- * pass and -- mirrored and transposed -- for the data gradient; fte_gconv3x3_s1_bf16(x, wpk_fwd) = forward,
- * fte_gconv3x3_s1_bf16(dz, wpk_dgrad) = data gradient.  Operands rounded to bf16 (RNE), fp32 accumulate, fp32 tensors.
+/* bf16 MFMA mode: the grouped 3x3 on the matrix cores.  A 32-channel slice (32 / gw whole groups) is a dense 3x3 conv 32 -> 32
+ * with a block-diagonal filter; fte_gconv3x3_pack_bf16 builds that filter (bf16, k-contiguous) for the forward pass and --
+ * mirrored and transposed -- for the data gradient.  fte_gconv3x3_bf16(x, wpk_fwd, y, ..., dgrad = 0) = forward,
+ * fte_gconv3x3_bf16(dz, wpk_dgrad, dx, ..., dgrad = 1) = data gradient; n, h, wd are the FORWARD layer's input size in both,
+ * TF-SAME, stride 1 or 2.  Operands rounded to bf16 (RNE), fp32 accumulate, fp32 tensors.
  * wpk_*: (c / 32) * 9 * 1024 uint16.  gw = c / groups in {4, 8, 16, 32}, c % 32 == 0. */
 int fte_gconv3x3_pack_bf16(const float* w, uint16_t* wpk_fwd, uint16_t* wpk_dgrad, int c, int groups, void* stream);
-int fte_gconv3x3_s1_bf16(const float* x, const uint16_t* wpk, float* y, int n, int h, int wd, int c, void* stream);
+int fte_gconv3x3_bf16(const float* x, const uint16_t* wpk, float* y, int n, int h, int wd, int c, int stride, int dgrad, void* stream);
 /* ... and the filter gradient of those layers: per slice and tap a [32 ic] x [32 oc] product over the pixels (operands rounded to
  * bf16, fragments transposed out of LDS by ds_read_b64_tr_b16), ordered partials in ws, the groups' diagonal blocks summed into
  * dw [groups][3][3][gw][gw]. */
-size_t fte_gconv3x3_wgrad_s1_bf16_ws_bytes(int n, int h, int wd, int c);
-int fte_gconv3x3_wgrad_s1_bf16(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups,
-                               void* ws, size_t ws_bytes, void* stream);
+size_t fte_gconv3x3_wgrad_bf16_ws_bytes(int n, int h, int wd, int c, int groups, int stride);
+int fte_gconv3x3_wgrad_bf16(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups, int stride,
+                            void* ws, size_t ws_bytes, void* stream);
 int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups,
                        int stride, void* stream);
 int fte_gconv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups,

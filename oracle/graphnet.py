@@ -6,7 +6,6 @@ reverse accumulating gradients.  The HIP engine (tf_face_toolbox_amd/nets/graph.
 op lists, which is what makes the layer-by-layer parity checks line up."""
 from collections import OrderedDict
 
-import contextlib
 
 import numpy as np
 
@@ -53,11 +52,9 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
             _, _, inp, wname, stride, groups = op
             x = env[inp]
             gw = x.shape[-1] // groups
-            # bf16 mode: the engine's stride-1 grouped 3x3 runs on the bf16 MFMA (operands rounded like every other MFMA product);
-            # the stride-2 ones stay plain fp32 vector code
-            with (contextlib.nullcontext() if stride == 1 else ops.operand_rounding(None)):
-                env[out] = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], params[wname][g], stride)
-                                           for g in range(groups)], axis=-1)
+            # bf16 mode: the engine's grouped 3x3 runs on the bf16 MFMA (operands rounded like every other MFMA product)
+            env[out] = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], params[wname][g], stride)
+                                       for g in range(groups)], axis=-1)
         elif kind == 'se':          # ('se', out, inp, prefix[, scope1, scope2]): nets/shufflenet_v2.py:79-85
             inp, pre = op[2], op[3]
             s1, s2 = (op[4], op[5]) if len(op) > 4 else ('fc1', 'fc2')
@@ -187,12 +184,11 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
             gw = x.shape[-1] // groups
             dx = np.zeros_like(x)
             dw = np.zeros_like(params[wname])
-            # stride 1: all three products on the bf16 MFMA in the bf16 mode (rounded operands); stride 2: fp32 vector code in every mode
-            with (contextlib.nullcontext() if stride == 1 else ops.operand_rounding(None)):
-                for g in range(groups):
-                    dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw], stride)
-                    dx[..., g * gw:(g + 1) * gw] = dxg
-                    dw[g] = dwg
+            # all three products on the bf16 MFMA in the bf16 mode (rounded operands)
+            for g in range(groups):
+                dxg, dwg = ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], params[wname][g], dy[..., g * gw:(g + 1) * gw], stride)
+                dx[..., g * gw:(g + 1) * gw] = dxg
+                dw[g] = dwg
             acc(gp, wname, dw)
             acc(gt, inp, dx)
         elif kind == 'se':

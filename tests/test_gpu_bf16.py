@@ -203,32 +203,35 @@ def test_spherenet_step_with_bf16_copies_equals_operand_mode(bf16_mode):
     _close(outs[1][1], outs[0][1], 'gradient arena', 1e-4); _close(outs[1][2], outs[0][2], 'embedding', 2e-5); _close(outs[1][3], outs[0][3], 'eval embedding', 2e-5)
 
 
-@pytest.mark.parametrize('n,h,w,c,groups', [(3, 14, 14, 128, 32), (2, 9, 7, 256, 32), (2, 8, 8, 512, 32), (1, 5, 5, 1024, 32), (2, 6, 6, 64, 8)])
-def test_grouped_3x3_on_the_bf16_mfma(n, h, w, c, groups):
-    """fte_gconv3x3_pack_bf16 + fte_gconv3x3_s1_bf16 (stride 1: block-diagonal 32-channel slices on v_mfma_f32_32x32x16_bf16) against
-    the grouped convolution with bf16-rounded operands (oracle/ops.py operand_rounding): forward, data gradient and filter gradient (fragments through ds_read_b64_tr_b16), 2e-5."""
-    r = np.random.default_rng(c + groups)
+@pytest.mark.parametrize('n,h,w,c,groups,stride', [(3, 14, 14, 128, 32, 1), (2, 9, 7, 256, 32, 1), (2, 8, 8, 512, 32, 1), (1, 5, 5, 1024, 32, 1),
+                                                   (2, 6, 6, 64, 8, 1), (2, 14, 14, 256, 32, 2), (3, 7, 7, 1024, 32, 2), (2, 9, 6, 512, 32, 2),
+                                                   (1, 8, 11, 128, 32, 2)])
+def test_grouped_3x3_on_the_bf16_mfma(n, h, w, c, groups, stride):
+    """fte_gconv3x3_pack_bf16 + fte_gconv3x3_bf16 (block-diagonal 32-channel slices on v_mfma_f32_32x32x16_bf16; stride 1 and the
+    TF-SAME stride 2 of even and odd sizes) against the grouped convolution with bf16-rounded operands (oracle/ops.py
+    operand_rounding): forward, data gradient and filter gradient (fragments through ds_read_b64_tr_b16), 2e-5."""
+    r = np.random.default_rng(c + groups + stride)
     gw = c // groups
+    ho, wo = -(-h // stride), -(-w // stride)
     x = r.standard_normal((n, h, w, c)); wt = r.standard_normal((groups, 3, 3, gw, gw)) * 0.2
-    dz = r.standard_normal((n, h, w, c))
+    dz = r.standard_normal((n, ho, wo, c))
     with ops.operand_rounding('bf16'):
-        y_ref = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], wt[g], 1) for g in range(groups)], axis=-1)
-        dx_ref = np.concatenate([ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], wt[g], dz[..., g * gw:(g + 1) * gw], 1)[0]
-                                 for g in range(groups)], axis=-1)
+        y_ref = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], wt[g], stride) for g in range(groups)], axis=-1)
+        bwd = [ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], wt[g], dz[..., g * gw:(g + 1) * gw], stride) for g in range(groups)]
+    dx_ref = np.concatenate([b[0] for b in bwd], axis=-1)
+    dw_ref = np.stack([b[1] for b in bwd])
     words = (c // 32) * 9 * 1024
     wf = torch.empty(words, dtype=torch.int16, device='cuda'); wd = torch.empty(words, dtype=torch.int16, device='cuda')
     _lib.call('fte_gconv3x3_pack_bf16', dev(wt.reshape(groups, 9, gw, gw)), wf, wd, c, groups, stream())
-    y = torch.full((n, h, w, c), 7.0, device='cuda'); dx = torch.full((n, h, w, c), 7.0, device='cuda')
-    _lib.call('fte_gconv3x3_s1_bf16', dev(x), wf, y, n, h, w, c, stream())
-    _lib.call('fte_gconv3x3_s1_bf16', dev(dz), wd, dx, n, h, w, c, stream())
+    y = torch.full((n, ho, wo, c), 7.0, device='cuda'); dx = torch.full((n, h, w, c), 7.0, device='cuda')
+    _lib.call('fte_gconv3x3_bf16', dev(x), wf, y, n, h, w, c, stride, 0, stream())
+    _lib.call('fte_gconv3x3_bf16', dev(dz), wd, dx, n, h, w, c, stride, 1, stream())
     check_maxabs(host(y), y_ref, 2e-5, 'grouped fwd, bf16 operands')
     check_maxabs(host(dx), dx_ref, 2e-5, 'grouped dgrad, bf16 operands')
-    with ops.operand_rounding('bf16'):
-        dw_ref = np.stack([ops.conv2d_bwd(x[..., g * gw:(g + 1) * gw], wt[g], dz[..., g * gw:(g + 1) * gw], 1)[1] for g in range(groups)])
-    buf, nb = ws(_lib.query('fte_gconv3x3_wgrad_s1_bf16_ws_bytes', n, h, w, c))
+    buf, nb = ws(_lib.query('fte_gconv3x3_wgrad_bf16_ws_bytes', n, h, w, c, groups, stride))
     dw = torch.full((groups, 3, 3, gw, gw), 7.0, device='cuda')
-    _lib.call('fte_gconv3x3_wgrad_s1_bf16', dev(x), dev(dz), dw, n, h, w, c, groups, buf, nb, stream())
+    _lib.call('fte_gconv3x3_wgrad_bf16', dev(x), dev(dz), dw, n, h, w, c, groups, stride, buf, nb, stream())
     check_maxabs(host(dw), dw_ref, 2e-5, 'grouped wgrad, bf16 operands')
     # and it really is the rounded product: the unrounded one is far outside that tolerance
-    y_plain = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], wt[g], 1) for g in range(groups)], axis=-1)
+    y_plain = np.concatenate([ops.conv2d_fwd(x[..., g * gw:(g + 1) * gw], wt[g], stride) for g in range(groups)], axis=-1)
     assert np.abs(host(y) - y_plain).max() > 1e-4 * np.abs(y_plain).max()

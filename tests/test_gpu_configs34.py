@@ -162,8 +162,8 @@ def test_resnext50_center_step_in_bf16_mode():
     evaluation by 5 %), so an end-to-end gradient comparison says nothing about the kernels.  What is checked instead:
       1. layer by layer, teacher-forced: every convolution / dense product of the net, fed the HIP path's OWN input
          tensor, equals the float64 oracle on the same bf16-rounded operands to 2e-5 (fp32 accumulation error only) --
-         51 convolutions incl. the 7x7 stem and all 1x1s, the classifier, and the 13 stride-1 grouped 3x3s (the three stride-2
-         grouped layers are plain fp32 vector code in both);
+         51 convolutions incl. the 7x7 stem and all 1x1s, the classifier, and the 16 grouped 3x3s (13 of stride 1, three of
+         stride 2: on the bf16 MFMA in this mode);
       2. end to end the HIP path deviates from the unrounded oracle no more than bf16-operand arithmetic must on this
          input: features rel-L2 <= 1.5 x the deviation of the oracle's own bf16-operand evaluation, losses likewise;
       3. every gradient is finite and optimizer steps run in this mode.
@@ -201,14 +201,14 @@ def test_resnext50_center_step_in_bf16_mode():
                     ref = oops.fc_fwd(host(net.t[op[2]]), p[op[3]])
                     worst = max(worst, check_maxabs(host(net.t[op[1]])[:, :ncls], ref, 2e-5, 'fc ' + op[1]))
                     checked += 1
-                elif op[0] == 'gconv' and op[4] == 1:          # stride-1 grouped 3x3: on the bf16 MFMA in this mode
+                elif op[0] == 'gconv':                         # grouped 3x3: on the bf16 MFMA in this mode
                     xin = host(net.t[op[2]])
                     gw = xin.shape[-1] // op[5]
-                    ref = np.concatenate([oops.conv2d_fwd(xin[..., g * gw:(g + 1) * gw], p[op[3]][g], 1) for g in range(op[5])], axis=-1)
+                    ref = np.concatenate([oops.conv2d_fwd(xin[..., g * gw:(g + 1) * gw], p[op[3]][g], op[4]) for g in range(op[5])], axis=-1)
                     worst = max(worst, check_maxabs(host(net.t[op[1]]), ref, 2e-5, 'gconv ' + op[1]))
                     grouped += 1
         assert checked == 1 + 16 * 2 + 4 + 1, checked          # stem + (conv1, conv3) x 16 blocks + 4 projection shortcuts + classifier
-        assert grouped == 13, grouped                            # 16 grouped 3x3 layers, three of them stride 2 (fp32 vector code)
+        assert grouped == 16, grouped                            # 16 grouped 3x3 layers, three of them stride 2
         # ---- 2. end to end against the unrounded oracle ----
         masks = {'features_drop': host(net.t['features_drop/mask'])}
         center = dict(centers=cen, alpha=net.center_alpha, weight=net.center_weight)

@@ -50,9 +50,9 @@ _SIGS = {
     'fte_dropout_bwd': (c_int, [_P] * 3 + [c_long, c_float, _P]),
     'fte_gconv3x3_fwd': (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
     'fte_gconv3x3_pack_bf16': (c_int, [_P] * 3 + [c_int, c_int, _P]),
-    'fte_gconv3x3_s1_bf16': (c_int, [_P] * 3 + [c_int] * 4 + [_P]),
-    'fte_gconv3x3_wgrad_s1_bf16_ws_bytes': (c_size_t, [c_int] * 4),
-    'fte_gconv3x3_wgrad_s1_bf16': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),
+    'fte_gconv3x3_bf16': (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
+    'fte_gconv3x3_wgrad_bf16_ws_bytes': (c_size_t, [c_int] * 6),
+    'fte_gconv3x3_wgrad_bf16': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_gconv3x3_dgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
     'fte_gconv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_gconv3x3_wgrad_ws_bytes': (c_size_t, [c_int] * 6),

@@ -900,21 +900,29 @@ int fte_gconv3x3_pack_bf16(const float* w, uint16_t* wpk_fwd, uint16_t* wpk_dgra
     if (gw != 4 && gw != 8 && gw != 16 && gw != 32) return FTE_EINVAL;
     return rc(l_gconv_pack16(w, wpk_fwd, wpk_dgrad, c, groups, (hipStream_t)stream));
 }
-int fte_gconv3x3_s1_bf16(const float* x, const uint16_t* wpk, float* y, int n, int h, int wd, int c, void* stream) {
-    if (!x || !wpk || !y || n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32 || (long)n * h * wd >= ((long)1 << 31)) return FTE_EINVAL;
-    return rc(l_gconv_mfma16(x, wpk, y, n, h, wd, c, (hipStream_t)stream));
+int fte_gconv3x3_bf16(const float* x, const uint16_t* wpk, float* y, int n, int h, int wd, int c, int stride, int dgrad, void* stream) {
+    if (!x || !wpk || !y || n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32 || (stride != 1 && stride != 2) ||
+        (long)n * h * wd >= ((long)1 << 31)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    if (stride == 1) return rc(l_gconv_mfma16(x, wpk, y, n, h, wd, c, h, wd, 0, 1, 1, (hipStream_t)stream));
+    if (!dgrad) return rc(l_gconv_mfma16(x, wpk, y, n, ph.out, pw.out, c, h, wd, 1, ph.before, pw.before, (hipStream_t)stream));
+    return rc(l_gconv_mfma16(x, wpk, y, n, h, wd, c, ph.out, pw.out, 2, ph.before, pw.before, (hipStream_t)stream));
 }
-size_t fte_gconv3x3_wgrad_s1_bf16_ws_bytes(int n, int h, int wd, int c) {
-    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32) return 0;
-    return align_up((size_t)l_gconv_wgrad16_chunks((long)n * h * wd, c) * (c / 32) * 9 * 1024 * sizeof(float));
+size_t fte_gconv3x3_wgrad_bf16_ws_bytes(int n, int h, int wd, int c, int groups, int stride) {
+    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || groups <= 0 || c % groups || c % 32 || (stride != 1 && stride != 2)) return 0;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return align_up((size_t)l_gconv_wgrad16_chunks((long)n * ph.out * pw.out, c) * c * 9 * (c / groups) * sizeof(float));
 }
-int fte_gconv3x3_wgrad_s1_bf16(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups,
-                               void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dz || !dw || n <= 0 || h <= 0 || wd <= 0 || groups <= 0 || c % groups || c % 32 || (long)n * h * wd >= ((long)1 << 31)) return FTE_EINVAL;
+int fte_gconv3x3_wgrad_bf16(const float* x, const float* dz, float* dw, int n, int h, int wd, int c, int groups, int stride,
+                            void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dz || !dw || n <= 0 || h <= 0 || wd <= 0 || groups <= 0 || c % groups || c % 32 || (stride != 1 && stride != 2) ||
+        (long)n * h * wd >= ((long)1 << 31)) return FTE_EINVAL;
     const int gw = c / groups;
     if (gw != 4 && gw != 8 && gw != 16 && gw != 32) return FTE_EINVAL;
-    if (!ws || ws_bytes < fte_gconv3x3_wgrad_s1_bf16_ws_bytes(n, h, wd, c)) return FTE_EWORKSPACE;
-    return rc(l_gconv_wgrad16(x, dz, (float*)ws, dw, n, h, wd, c, groups, l_gconv_wgrad16_chunks((long)n * h * wd, c), (hipStream_t)stream));
+    if (!ws || ws_bytes < fte_gconv3x3_wgrad_bf16_ws_bytes(n, h, wd, c, groups, stride)) return FTE_EWORKSPACE;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_gconv_wgrad16(x, dz, (float*)ws, dw, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before,
+                              l_gconv_wgrad16_chunks((long)n * ph.out * pw.out, c), (hipStream_t)stream));
 }
 int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int stride, void* stream) {
     if (!dz || !w || !dx || n <= 0 || groups <= 0 || c % groups || (stride != 1 && stride != 2)) return FTE_EINVAL;

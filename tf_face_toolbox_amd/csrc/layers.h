@@ -29,10 +29,11 @@ hipError_t l_gconv_fwd(const float* x, const float* w, float* y, int n, int h, i
 hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int ho, int wo,
                          int stride, int pt, int pl, hipStream_t st);
 hipError_t l_gconv_pack16(const float* w, unsigned short* wf, unsigned short* wd, int c, int groups, hipStream_t st);
-hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, hipStream_t st);
+hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
+                          int mode, int pt, int pl, hipStream_t st);
 int l_gconv_wgrad16_chunks(long npix, int c);
 hipError_t l_gconv_wgrad16(const float* x, const float* dz, float* part, float* dw, int n, int h, int wd, int c, int groups,
-                           int chunks, hipStream_t st);
+                           int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st);
 int l_gconv_wgrad_chunks(long npix, int c, int gw);
 hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int c, int groups, int ho, int wo,
                          int stride, int pt, int pl, int chunks, hipStream_t st);

@@ -822,8 +822,13 @@ __global__ __launch_bounds__(256) void gconv_pack16_kernel(const float* __restri
     }
 }
 
+// MODE 0: stride 1 (forward, or data gradient with the mirrored filter: the same index map); 1: forward at stride 2 (x is
+// [n, hs, ws], y [n, h, wd] = the walked grid); 2: data gradient at stride 2 (x is dz [n, hs, ws], y is dx [n, h, wd]; tap (r, q) of
+// the mirrored filter reads dz[(iy + pt - (2 - r)) / 2] when that is whole).  pt, pl = the TF-SAME pads before.
+template <int MODE>
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
-                                                              float* __restrict__ y, int n, int h, int wd, int c) {
+                                                              float* __restrict__ y, int n, int h, int wd, int c,
+                                                              int hs, int ws, int pt, int pl) {
     // the slice's 9 x [32][32] bf16 filter (18 KB) sits in LDS; a fragment is one ds_read_b128 right before its MFMA
     __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
     // per wave: the 32 pixels x 128 B of one tap, twice (the next tap lands while this one multiplies).  A lane FETCHES 16-byte
@@ -859,15 +864,23 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
             fox[j] = (int)(pu % (unsigned)wd);
             const unsigned t2 = pu / (unsigned)wd;
             foy[j] = (int)(t2 % (unsigned)h);
-            fbase[j] = (long)(t2 / (unsigned)h) * h;
+            fbase[j] = (long)(t2 / (unsigned)h) * hs;                     // image base in rows of the SOURCE
         }
         auto fetch = [&](int t, f32x4 (&v)[4]) {
             const int r = t / 3, q = t - 3 * r;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int sy = foy[j] + r - 1, sx = fox[j] + q - 1;
-                const bool ok = fok[j] && sy >= 0 && sy < h && sx >= 0 && sx < wd;
-                const f32x4 val = *reinterpret_cast<const f32x4*>(xs + ((fbase[j] + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c);
+                int sy, sx;
+                bool ok = fok[j];
+                if (MODE == 0) { sy = foy[j] + r - 1; sx = fox[j] + q - 1; }
+                else if (MODE == 1) { sy = 2 * foy[j] + r - pt; sx = 2 * fox[j] + q - pl; }
+                else {
+                    const int ny = foy[j] + pt - (2 - r), nx = fox[j] + pl - (2 - q);
+                    ok = ok && !((ny | nx) & 1);
+                    sy = ny >> 1; sx = nx >> 1;
+                }
+                ok = ok && sy >= 0 && sy < hs && sx >= 0 && sx < ws;
+                const f32x4 val = *reinterpret_cast<const f32x4*>(xs + ((fbase[j] + (ok ? sy : 0)) * ws + (ok ? sx : 0)) * c);
                 v[j] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
@@ -924,14 +937,16 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
 typedef short s16x4_l __attribute__((ext_vector_type(4)));
 typedef short s16x8_l __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
+template <int S>
 __global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                     float* __restrict__ part, int n, int h, int wd, int c,
-                                                                    int gw, long steps_per_chunk) {
+                                                                    int gw, long steps_per_chunk, int ho, int wo, int pt, int pl) {
+    // S = stride: the walked pixels are dz's [n, ho, wo]; x is [n, h, wd]
     __shared__ __attribute__((aligned(16))) unsigned short img[3][4][16 * 32];      // per wave: 3 taps of x + dz, [16 pixels][32 channels]
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;                        // r = kernel row of this wave
     const int li = lane & 31, lh = lane >> 5;
     const int slice = blockIdx.y;
-    const long npix = (long)n * h * wd;
+    const long npix = (long)n * ho * wo;
     const long nsteps = (npix + 15) / 16;
     const long s0 = (long)blockIdx.x * steps_per_chunk, s1 = min(nsteps, s0 + steps_per_chunk);
     const int frow = lane >> 3, fpiece = lane & 7;                                  // fetch: rows frow, frow + 8; 16-byte piece
@@ -954,17 +969,17 @@ __global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float*
             const long p = step * 16 + frow + 8 * j;
             const bool pok = p < npix;
             const unsigned pu = (unsigned)(pok ? p : 0);
-            const int ox = (int)(pu % (unsigned)wd);
-            const unsigned t2 = pu / (unsigned)wd;
-            const int oy = (int)(t2 % (unsigned)h);
-            const long ib = (long)(t2 / (unsigned)h) * h;
+            const int ox = (int)(pu % (unsigned)wo);
+            const unsigned t2 = pu / (unsigned)wo;
+            const int oy = (int)(t2 % (unsigned)ho);
+            const long ib = (long)(t2 / (unsigned)ho) * h;
             const f32x4 dv = *reinterpret_cast<const f32x4*>(ds + (long)pu * c);
             v[3][j] = pok ? dv : f32x4{0.f, 0.f, 0.f, 0.f};
-            const int sy = oy + r - 1;
+            const int sy = oy * S + r - pt;
             const bool rok = pok && sy >= 0 && sy < h;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int sx = ox + q - 1;
+                const int sx = ox * S + q - pl;
                 const bool ok = rok && sx >= 0 && sx < wd;
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + ((ib + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c);
                 v[q][j] = ok ? xv : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1193,12 +1208,17 @@ hipError_t l_gconv_pack16(const float* w, unsigned short* wf, unsigned short* wd
     hipLaunchKernelGGL(gconv_pack16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, wf, wd, c, c / groups);
     return hipGetLastError();
 }
-hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, hipStream_t st) {
+// y [n, h, wd] is the walked grid, x [n, hs, ws] the source; mode as gconv3x3_mfma16_kernel's MODE
+hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
+                          int mode, int pt, int pl, hipStream_t st) {
     const long ntiles = ((long)n * h * wd + 31) / 32;
     long bx = (ntiles + 3) / 4;
     const long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(gconv3x3_mfma16_kernel, dim3((unsigned)bx, c / 32), dim3(256), 0, st, x, wpk, y, n, h, wd, c);
+    const dim3 grid((unsigned)bx, c / 32);
+    if (mode == 0) hipLaunchKernelGGL(gconv3x3_mfma16_kernel<0>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+    else if (mode == 1) hipLaunchKernelGGL(gconv3x3_mfma16_kernel<1>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+    else hipLaunchKernelGGL(gconv3x3_mfma16_kernel<2>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
     return hipGetLastError();
 }
 int l_gconv_wgrad16_chunks(long npix, int c) {
@@ -1208,10 +1228,11 @@ int l_gconv_wgrad16_chunks(long npix, int c) {
     return (int)(ch < 1 ? 1 : ch);
 }
 hipError_t l_gconv_wgrad16(const float* x, const float* dz, float* part, float* dw, int n, int h, int wd, int c, int groups,
-                           int chunks, hipStream_t st) {
-    const long steps = ((long)n * h * wd + 15) / 16, spc = (steps + chunks - 1) / chunks;
+                           int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st) {
+    const long steps = ((long)n * ho * wo + 15) / 16, spc = (steps + chunks - 1) / chunks;
     const int gw = c / groups, total = groups * 9 * gw * gw;
-    hipLaunchKernelGGL(gconv3x3_wgrad_mfma16_kernel, dim3(chunks, c / 32), dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc);
+    if (stride == 1) hipLaunchKernelGGL(gconv3x3_wgrad_mfma16_kernel<1>, dim3(chunks, c / 32), dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
+    else hipLaunchKernelGGL(gconv3x3_wgrad_mfma16_kernel<2>, dim3(chunks, c / 32), dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
     hipLaunchKernelGGL(gconv_wgrad16_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, part, dw, chunks, c / 32, gw, groups);
     return hipGetLastError();
 }

@@ -490,8 +490,8 @@ class GraphNet(Network):
             elif kind == 'gconv':
                 ih, iw, cc = self.shapes[op[2]]
                 need = max(need, q('fte_gconv3x3_wgrad_ws_bytes', n, ih, iw, cc, op[5], op[4]))
-                if op[4] == 1 and cc % 32 == 0:
-                    need = max(need, q('fte_gconv3x3_wgrad_s1_bf16_ws_bytes', n, ih, iw, cc))
+                if cc % 32 == 0 and cc // op[5] in (4, 8, 16, 32):
+                    need = max(need, q('fte_gconv3x3_wgrad_bf16_ws_bytes', n, ih, iw, cc, op[5], op[4]))
             elif kind == 'se':
                 cc = shape[-1]
                 hd = self._se_names(op)[4]
@@ -609,9 +609,9 @@ class GraphNet(Network):
             elif kind == 'gconv':
                 ih, iw, c = self.shapes[op[2]]
                 pk = self._gconv_pack(op)
-                if pk is not None:                             # bf16 MFMA mode, stride 1: block-diagonal slices on the matrix cores
+                if pk is not None:                             # bf16 MFMA mode: block-diagonal slices on the matrix cores
                     call('fte_gconv3x3_pack_bf16', self.view(op[3]), pk[0], pk[1], c, op[5], st)
-                    call('fte_gconv3x3_s1_bf16', T[op[2]], pk[0], T[out], n, ih, iw, c, st)
+                    call('fte_gconv3x3_bf16', T[op[2]], pk[0], T[out], n, ih, iw, c, op[4], 0, st)
                 else:
                     call('fte_gconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[5], op[4], st)
             elif kind == 'se':
@@ -649,11 +649,11 @@ class GraphNet(Network):
                 raise RuntimeError('op %s must have been fused away' % kind)
 
     def _gconv_pack(self, op):
-        """(forward, dgrad) packed bf16 filters of a grouped 3x3 that runs on the matrix cores -- bf16 MFMA mode, stride 1,
+        """(forward, dgrad) packed bf16 filters of a grouped 3x3 that runs on the matrix cores -- bf16 MFMA mode,
         4 / 8 / 16 / 32 channels per group -- else None (fp32 vector kernels)."""
         _, _, inp, wname, stride, groups = op
         c = self.shapes[inp][-1]
-        if stride != 1 or c % 32 or (c // groups) not in (4, 8, 16, 32) or _lib.get_mfma_dtype() != 'bf16' \
+        if c % 32 or (c // groups) not in (4, 8, 16, 32) or _lib.get_mfma_dtype() != 'bf16' \
                 or os.environ.get('FTE_GCONV_MFMA', '1') == '0':
             return None
         pk = self._gpacks.get(wname)
@@ -888,14 +888,14 @@ class GraphNet(Network):
             elif kind == 'gconv':
                 _, _, inp, wname, stride, groups = op
                 ih, iw, c = self.shapes[inp]
-                if self._gconv_pack(op) is not None:     # bf16 MFMA mode, stride 1
-                    wgrad('fte_gconv3x3_wgrad_s1_bf16', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, wws, self.ws_bytes, wst)
+                if self._gconv_pack(op) is not None:     # bf16 MFMA mode
+                    wgrad('fte_gconv3x3_wgrad_bf16', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 else:
                     wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
                 pk = self._gconv_pack(op)
                 if pk is not None:                       # packed by this step's forward pass (the weights have not changed since)
-                    call('fte_gconv3x3_s1_bf16', dy, pk[1], dx, n, ih, iw, c, st)
+                    call('fte_gconv3x3_bf16', dy, pk[1], dx, n, ih, iw, c, stride, 1, st)
                 else:
                     call('fte_gconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, groups, stride, st)
                 self._put(inp, dx)
