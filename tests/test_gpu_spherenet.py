@@ -54,6 +54,35 @@ def test_forward_loss_and_every_gradient(name, data_format, n, h, w, ch, ncls):
         check_rell2(host(net.get_variable(k, net.grads)), data_grad, what='grad ' + k)
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_filter_gradients_on_the_second_stream_are_bit_identical(mode):
+    """SphereNet's backward walk launches wgrad(l) on a second stream beside dgrad(l) (nets/sphere.py _body_walk): the same kernels on
+    the same operands, so the whole gradient arena equals the one-stream walk bit for bit -- at a size where kernels really overlap
+    (16 x 112 x 112), three backward passes in a row (the dz ping-pong buffers are reused across layers and steps)."""
+    from tf_face_toolbox_amd import _lib
+    prev = _lib.get_mfma_dtype()
+    _lib.set_mfma_dtype(mode)
+    try:
+        arenas = []
+        for two_streams in (True, False):
+            net, p, x, y = _setup('SphereNet-ASoftmax', 'NCHW', 16, 112, 112, 3, 100)
+            xd, yd = dev(x), dev(y, torch.int32)
+            net.tower_scale = 1.0
+            for it in range(3):
+                logits = net.forward(xd, yd, num_classes=100, is_training=True)
+                if not two_streams:
+                    assert it > 0 or net._side_stream(16) is not None       # 16 per GPU: the two-stream walk is the default
+                    net.side, net.ws_side = None, net.ws
+                net.loss_function('TOWER', yd, **logits)
+                net.backward()
+            torch.cuda.synchronize()
+            arenas.append(net.grads.clone())
+        assert torch.equal(arenas[0], arenas[1])
+        assert float(arenas[0].abs().max()) > 0
+    finally:
+        _lib.set_mfma_dtype(prev)
+
+
 @pytest.mark.parametrize('optimizer', ['Momentum', 'Adam'])
 def test_three_training_steps_match_oracle(optimizer):
     n, h, w, ch, ncls = 4, 32, 32, 3, 10
