@@ -227,8 +227,9 @@ int fte_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, 
 int fte_act_fwd(const float* x, float* y, long n, int kind, void* stream);
 int fte_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, void* stream);
 int fte_channel_scale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, void* stream);
+/* pre_sigmoid != 0: dgate is multiplied by gate * (1 - gate), i.e. it is the gradient w.r.t. the pre-sigmoid value */
 int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate,
-                          int n, int hw, int c, void* stream);
+                          int n, int hw, int c, int pre_sigmoid, void* stream);
 
 /* ---------------------------------------------------------------------------
  * bf16 OPERAND COPIES (mixed precision with bf16 storage of what the MFMAs read; BASELINE.json config 3).

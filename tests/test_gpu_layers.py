@@ -182,8 +182,10 @@ def test_se_gate_pieces():
     call('fte_channel_scale_fwd', dev(x), dev(gate), y, n, hw, c, stream())
     check_maxabs(host(y), x * gate[:, None, :], 1e-6, 'scale fwd')
     dy = r.standard_normal((n, hw, c)); dx = torch.empty(n, hw, c, device='cuda'); dg = torch.empty(n, c, device='cuda')
-    call('fte_channel_scale_bwd', dev(dy), dev(x), dev(gate), dx, dg, n, hw, c, stream())
+    call('fte_channel_scale_bwd', dev(dy), dev(x), dev(gate), dx, dg, n, hw, c, 0, stream())
     check_maxabs(host(dx), dy * gate[:, None, :], 1e-6, 'scale dx'); check_maxabs(host(dg), (dy * x).sum(1), 1e-5, 'scale dgate')
+    call('fte_channel_scale_bwd', dev(dy), dev(x), dev(gate), dx, dg, n, hw, c, 1, stream())
+    check_maxabs(host(dg), (dy * x).sum(1) * gate * (1 - gate), 1e-5, 'scale d(pre-sigmoid)')
     v = r.standard_normal(1000) * 3
     for kind, f, df in ((0, lambda a: np.maximum(a, 0), lambda o: (o > 0).astype(float)), (1, lambda a: 1 / (1 + np.exp(-a)), lambda o: o * (1 - o))):
         o = torch.empty(1000, device='cuda'); call('fte_act_fwd', dev(v), o, 1000, kind, stream())

@@ -962,9 +962,10 @@ int fte_channel_scale_fwd(const float* x, const float* gate, float* y, int n, in
     if (!x || !gate || !y || n <= 0 || c % 4) return FTE_EINVAL;
     return rc(l_chscale_fwd(x, gate, y, n, hw, c, (hipStream_t)stream));
 }
-int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c, void* stream) {
+int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c,
+                          int pre_sigmoid, void* stream) {
     if (!dy || !x || !gate || !dx || !dgate || n <= 0 || c <= 0 || c % 4) return FTE_EINVAL;
-    return rc(l_chscale_bwd(dy, x, gate, dx, dgate, n, hw, c, (hipStream_t)stream));
+    return rc(l_chscale_bwd(dy, x, gate, dx, dgate, n, hw, c, pre_sigmoid ? 1 : 0, (hipStream_t)stream));
 }
 
 // ------------------------------------------------------------------------------------------------

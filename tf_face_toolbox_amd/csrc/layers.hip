@@ -1145,13 +1145,14 @@ __global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restric
 // dx = dy * gate ; dgate[n,c] = sum_hw dy * x   (block = one image x 16 channel quads x 16 row lanes, float4, fixed-order LDS sum)
 __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ gate, float* __restrict__ dx,
-                                                          float* __restrict__ dgate, int hw, int c) {
+                                                          float* __restrict__ dgate, int hw, int c, int pre_sigmoid) {
     __shared__ f32x4 sh[16][16];
     const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int ch = (blockIdx.x * 16 + q) * 4, img = blockIdx.y;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gt = {0.f, 0.f, 0.f, 0.f};
     if (ch < c) {
-        const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + (long)img * c + ch);
+        gt = *reinterpret_cast<const f32x4*>(gate + (long)img * c + ch);
         for (int r = rl; r < hw; r += 16) {
             const long o = ((long)img * hw + r) * c + ch;
             const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
@@ -1165,6 +1166,7 @@ __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restric
         f32x4 t = sh[0][q];
 #pragma unroll
         for (int l = 1; l < 16; ++l) t += sh[l][q];
+        if (pre_sigmoid) t = t * gt * (1.f - gt);                // gate = sigmoid(pre): the gradient w.r.t. pre
         *reinterpret_cast<f32x4*>(dgate + (long)img * c + ch) = t;
     }
 }
@@ -1276,8 +1278,9 @@ hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int
     hipLaunchKernelGGL(chscale_fwd_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)), dim3(256), 0, st, x, gate, y, n4, hw, c);
     return hipGetLastError();
 }
-hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c, hipStream_t st) {
-    hipLaunchKernelGGL(chscale_bwd_kernel, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, dy, x, gate, dx, dgate, hw, c);
+hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c,
+                         int pre_sigmoid, hipStream_t st) {
+    hipLaunchKernelGGL(chscale_bwd_kernel, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, dy, x, gate, dx, dgate, hw, c, pre_sigmoid);
     return hipGetLastError();
 }
 

@@ -499,6 +499,9 @@ class GraphNet(Network):
                 self.t[out + '/hid'] = torch.empty(n, hd, **f32)
                 self.t[out + '/gate'] = torch.empty(n, cc, **f32)
                 need = max(need, q('fte_gemm_ws_bytes', n, cc, hd), q('fte_gemm_ws_bytes', n, hd, cc))
+                for nm, wdt in (('dgate', cc), ('dhid', hd), ('dsq', cc)):           # backward scratch, shared by all SE blocks of a width
+                    if ('se', nm, wdt) not in self.ident:
+                        self.ident[('se', nm, wdt)] = torch.empty(n, wdt, **f32)
             elif kind == 'addrelu':
                 cc = shape[-1]
                 if cc not in self.ident:
@@ -871,17 +874,15 @@ class GraphNet(Network):
                 sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
                 f32 = dict(dtype=torch.float32, device=self.device)
                 dx = self._new(inp)
-                dgate = torch.empty(n, c, **f32)
-                call('fte_channel_scale_bwd', dy, T[inp], gate, dx, dgate, n, hw, c, st)
-                call('fte_act_bwd', dgate, gate, dgate, dgate.numel(), 1, st)                       # -> d(pre-sigmoid)
+                # scratch preallocated in _alloc (three allocator calls per SE block and step otherwise)
+                dgate, dhid, dsq = (self.ident[('se', nm, wdt)] for nm, wdt in (('dgate', c), ('dhid', hd), ('dsq', c)))
+                call('fte_channel_scale_bwd', dy, T[inp], gate, dx, dgate, n, hw, c, 1, st)         # dgate = d(pre-sigmoid)
                 call('fte_gemm_tn', hid, dgate, self.view(w2, self.grads), n, c, hd, self.ws, self.ws_bytes, st)
                 call('fte_reduce_rows', dgate, self.view(b2, self.grads), None, 1, n, c, 1, 1.0, st)
-                dhid = torch.empty(n, hd, **f32)
                 call('fte_gemm_nt', dgate, self.view(w2), None, None, 0, None, dhid, None, n, c, hd, self.ws, self.ws_bytes, st)
                 call('fte_act_bwd', dhid, hid, dhid, dhid.numel(), 0, st)                            # -> d(pre-ReLU)
                 call('fte_gemm_tn', sq, dhid, self.view(w1, self.grads), n, hd, c, self.ws, self.ws_bytes, st)
                 call('fte_reduce_rows', dhid, self.view(b1, self.grads), None, 1, n, hd, 1, 1.0, st)
-                dsq = torch.empty(n, c, **f32)
                 call('fte_gemm_nt', dhid, self.view(w1), None, None, 0, None, dsq, None, n, hd, c, self.ws, self.ws_bytes, st)
                 call('fte_bcast_add', dx, dsq, n, hw, c, 1.0 / hw, st)
                 self._put(inp, dx)
