@@ -801,6 +801,9 @@ typedef __bf16 bf16x8_l __attribute__((ext_vector_type(8)));
 typedef float f32x16_l __attribute__((ext_vector_type(16)));
 typedef float f32x2_l __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_l __attribute__((ext_vector_type(2)));
+typedef short s16x4_l __attribute__((ext_vector_type(4)));
+typedef short s16x8_l __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
 
 // wpk[slice][tap][col 32][k 32] (k contiguous), bf16.  fwd: col = output channel, k = input channel, tap as given;
 // dgrad (dx = conv of dz with the mirrored, transposed filter): col = input channel, k = output channel, tap mirrored.
@@ -927,6 +930,106 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
     }
 }
 
+// Stride 1 (forward and data gradient), second formulation: the taps of one kernel ROW are shifted views of the same 34
+// consecutive pixels.  In linear pixel space the source of (pixel p, tap (r, q)) is p + (r - 1) * W + (q - 1) whenever it lies
+// inside the image, so per tile of 32 pixels and kernel row r a wave fetches the 34 rows [p0 - 1 + (r - 1) W, p0 + 32 + (r - 1) W]
+// ONCE (coalesced 128-byte rows, rounded to bf16, 80-byte LDS rows), and the three taps q read window rows li + q; the image /
+// row edges are a 9-bit mask per lane that zeroes the fragment.  gconv3x3_mfma16_kernel<0> fetched every tap on its own: 9 x the
+// tensor through L2 -> L1 (461 MB for the 28x28x128 layer at 128 images, 52 us = the L2 rate); this one moves 3.2 x.
+__global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
+                                                                  float* __restrict__ y, int n, int h, int wd, int c) {
+    __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
+    constexpr int WROW = 40, WBUF = 34 * WROW;                    // bf16 per window row (32 + 8 pad: conflict-free b128 reads), per buffer
+    __shared__ __attribute__((aligned(16))) unsigned short win[4][2][WBUF];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int slice = blockIdx.y;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wpk + (long)slice * 9 * 1024);
+        uint4* dst = reinterpret_cast<uint4*>(wsh);
+        for (int i = threadIdx.x; i < 9 * 1024 / 8; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const long npix = (long)n * h * wd;
+    const long ntiles = (npix + 31) / 32;
+    const int fr = lane >> 3, fp = lane & 7;
+    const float* xs = x + slice * 32 + (fp << 2);
+    unsigned short* wb = &win[wv][0][0];
+    auto fetch = [&](long tile, int r, f32x4 (&v)[5]) {
+        const long s0 = tile * 32 - 1 + (long)(r - 1) * wd + fr;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const long sp = s0 + 8 * i;
+            const bool ok = fr + 8 * i < 34 && sp >= 0 && sp < npix;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(xs + (ok ? sp : 0) * c);
+            v[i] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf, const f32x4 (&v)[5]) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int j = fr + 8 * i;
+            if (j < 34)
+                *reinterpret_cast<s16x4_l*>(wb + buf * WBUF + j * WROW + (fp << 2)) = __builtin_bit_cast(s16x4_l, __builtin_convertvector(v[i], bf16x4_l));
+        }
+    };
+    const long stride_t = (long)gridDim.x * 4;
+    long tile = (long)blockIdx.x * 4 + wv;
+    f32x4 va[5], vb[5];
+    if (tile < ntiles) fetch(tile, 0, va);
+    int sb = 0;
+    for (; tile < ntiles; tile += stride_t) {
+        const long p = tile * 32 + li;
+        const bool pok = p < npix;
+        const unsigned pu = (unsigned)(pok ? p : 0);
+        const int ox = (int)(pu % (unsigned)wd);
+        const int oy = (int)((pu / (unsigned)wd) % (unsigned)h);
+        unsigned vm = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int sy = oy + r - 1, sx = ox + q - 1;
+                if (pok && sy >= 0 && sy < h && sx >= 0 && sx < wd) vm |= 1u << (3 * r + q);
+            }
+        f32x16_l acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        auto row = [&](int r, int buf) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int t = 3 * r + q;
+                const bool ok = (vm >> t) & 1;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    s16x8_l raw = *reinterpret_cast<const s16x8_l*>(wb + buf * WBUF + (li + q) * WROW + 16 * ks + 8 * lh);
+                    if (!ok) raw = s16x8_l{0, 0, 0, 0, 0, 0, 0, 0};
+                    const bf16x8_l fa = __builtin_bit_cast(bf16x8_l, raw);
+                    const bf16x8_l fb = *reinterpret_cast<const bf16x8_l*>(wsh + ((t * 32 + li) * 32 + 16 * ks + 8 * lh));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+                }
+            }
+        };
+        // rows alternate between the two window buffers; the next row (or the next tile's first row) is in flight while this one multiplies
+        stash(sb, va);
+        fetch(tile, 1, vb);
+        row(0, sb);
+        stash(sb ^ 1, vb);
+        fetch(tile, 2, va);
+        row(1, sb ^ 1);
+        stash(sb, va);
+        if (tile + stride_t < ntiles) fetch(tile + stride_t, 0, va);
+        row(2, sb);
+        sb ^= 1;
+        float* yo = y + slice * 32 + li;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (pr < npix) yo[pr * c] = acc[i];
+        }
+    }
+}
+
 // Filter gradient of the same layers on the bf16 MFMA: per 32-channel slice and tap a dense [32 ic] x [32 oc] product over the
 // pixels, D_tap[ic][oc] = sum_p x[p + tap][ic] * dz[p][oc] (the diagonal gw x gw blocks are the groups' gradients; the rest is
 // discarded by the reduction).  Both operands need 8 consecutive PIXELS of one channel per lane while memory is channel-
@@ -934,9 +1037,6 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
 // back through ds_read_b64_tr_b16 -- gfx950's transposing LDS read (scripts/probes/ds_read_tr16.hip pins its lane map).
 // Block = 3 waves, wave r owns kernel row r (3 taps = 3 accumulator blocks); 16 pixels per step; the next step's rows are in
 // flight while this one multiplies.  Partials [chunk][slice][tap][32 oc][gw ic], summed in order by gconv_wgrad16_reduce_kernel.
-typedef short s16x4_l __attribute__((ext_vector_type(4)));
-typedef short s16x8_l __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_l __attribute__((ext_vector_type(4)));
 template <int S>
 __global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                     float* __restrict__ part, int n, int h, int wd, int c,
@@ -1218,7 +1318,9 @@ hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, i
     const long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
     if (bx > cap) bx = cap;
     const dim3 grid((unsigned)bx, c / 32);
-    if (mode == 0) hipLaunchKernelGGL(gconv3x3_mfma16_kernel<0>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+    static const bool win = !(getenv("FTE_GCONV_WIN") && atoi(getenv("FTE_GCONV_WIN")) == 0);     // A/B hook: 0 = a fetch per tap
+    if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c);
+    else if (mode == 0) hipLaunchKernelGGL(gconv3x3_mfma16_kernel<0>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
     else if (mode == 1) hipLaunchKernelGGL(gconv3x3_mfma16_kernel<1>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
     else hipLaunchKernelGGL(gconv3x3_mfma16_kernel<2>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
     return hipGetLastError();
