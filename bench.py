@@ -287,6 +287,11 @@ def main():
     # timed step: an event pair costs a queue barrier per launch -- recording all steps lowers the measured rate by 4.6 %
     # at 64 images per GPU (7.57 k -> 7.24 k images/s), by 0.5 % at 512.  FTE_BENCH_NO_PROF=1 turns them off (exploration).
     PROF_EVERY = 4
+    two_streams = getattr(net, '_side_stream', None) is not None and net._side_stream(shard) is not None
+    if two_streams:
+        # small shards / bf16 mode: the backward walk uses two streams and a recorded step does not (below) -- two recorded steps
+        # (the first and the middle one) are enough for the per-shape table and cost the timed region < 1 %
+        PROF_EVERY = max(4, (args.steps + 1) // 2)
     prof = os.environ.get('FTE_BENCH_NO_PROF') != '1'
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step device times (no host sync)
     first = True
@@ -296,9 +301,12 @@ def main():
         if prof and i % PROF_EVERY == 0:
             _lib.query('fte_prof_enable', 1 if first else 2)
             first = False
+            net.one_stream = True          # the recorded steps run the one-stream backward walk: a launch's duration is then its own,
+                                           # not that of two kernels sharing the chip (small shards / bf16 mode: nets/sphere.py _side_stream)
         train_ops()
         if prof and i % PROF_EVERY == 0:
             _lib.query('fte_prof_enable', 0)
+            net.one_stream = False
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -400,7 +400,7 @@ class SphereNet(Network):
         two): 64 per GPU 7.95 k -> 8.30 k, 128: 9.08 k -> 9.44 k, 256: 9.79 k -> 9.96 k, 512: 10.44 k -> 10.30 k -- at 512 every
         kernel is many rounds of blocks, nothing is left to cover and two MFMA-bound kernels sharing the chip cost 1.3 %; in the
         bf16 mode (launches 3x shorter) 512 gains too: 16.63 -> 16.13 ms.  FTE_SIDE_STREAM=0 / 1 forces one / two streams."""
-        if self.side is None:
+        if self.side is None or getattr(self, 'one_stream', False):      # one_stream: bench.py's launch-record steps (a launch's duration is its own)
             return None
         if os.environ.get('FTE_SIDE_STREAM') == '1':
             return self.side
