@@ -127,7 +127,10 @@ def _bf16_bits(t):
 @pytest.mark.parametrize('n,h,w,cin,cout,k,stride', [(4, 14, 14, 64, 64, 3, 1), (3, 15, 9, 64, 128, 3, 2), (2, 28, 28, 128, 64, 3, 1),
                                                      (5, 8, 8, 256, 128, 1, 1), (64, 14, 14, 128, 128, 3, 2), (2, 7, 7, 512, 512, 3, 1),
                                                      (512, 14, 14, 128, 128, 3, 1), (32, 56, 56, 64, 64, 3, 1), (500, 14, 14, 256, 256, 3, 1),
-                                                     (130, 28, 28, 128, 128, 1, 1)])
+                                                     (130, 28, 28, 128, 128, 1, 1),
+                                                     # 128x128-tile launches of 3x3 / stride 1 layers run igemm16.hip's WINDOW kernel (A rows fetched once per
+                                                     # 64-channel chunk, taps as row-shifted views + edge masks): W = 28 with a ragged last tile, W = 7
+                                                     (126, 28, 28, 128, 128, 3, 1), (512, 7, 7, 512, 512, 3, 1)])
 def test_bf16_source_entry_points_equal_the_operand_mode(bf16_mode, n, h, w, cin, cout, k, stride):
     """fte_conv2d_{fwd,dgrad,wgrad}16 read bf16 COPIES of the operands; the FTE_MFMA_BF16 mode rounds the fp32 operands
     inside the kernel.  Same rounded operands, fp32 accumulation: the results agree to fp32 summation order (the LDS-DMA

@@ -239,6 +239,193 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
     igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, c_ph, c_pw, prow);
 }
 
+// ---- window variant (3x3, stride 1, TF-SAME; W <= 30): the A operand of a 64-channel chunk is fetched ONCE per tile -------------
+// In linear pixel space the source row of (output row m, tap (dh, dw)) is m + dh * W + dw wherever it lies inside the image, so
+// the nine taps of a chunk are row-shifted views of the BM + 2 W + 2 rows [m0 - W - 1, m0 + BM + W]: that window is DMA'd once
+// per chunk (two buffers: the next chunk's window arrives one piece per K-step under the current chunk's taps), a tap's fragment
+// is the row li + W + 1 + dh W + dw of it, and the image edges are a 9-bit mask per lane that zeroes the fragment.  igemm16_kernel
+// re-fetches the A tile for every (tap, chunk): 16 of the 32 LDS-DMA pieces of a K-step; here 16 (B) + 24 / 9 (window).
+template <int BM, int BN, int WM, int WN, int EPI, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const IgemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    constexpr int RP = 32, B_P = BN / RP, BSTAGE = BN * ROWB, MAXWP = 6;
+    static_assert(BN % RP == 0, "tile rows per DMA pass");
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ntn = p.N / BN;
+    int bid = blockIdx.x;
+    const int split = blockIdx.y;
+    {
+        const int ntiles = gridDim.x;
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int NT = p.a_NT;
+    const int mt = bid / ntn, nt_ = bid - mt * ntn;
+    const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg) / BK16;
+    const int Wd = p.a_IW;
+    const int NR = BM + 2 * Wd + 2;                     // window rows
+    const int NPC = (NR + 7) >> 3;                      // 1-KiB DMA pieces per window
+    const int WINB = NPC * 1024;
+    char* const win = smem16;
+    char* const bring = smem16 + 2 * WINB;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    // window pieces of this wave: wid, wid + 4, ...; a lane owns row 8 piece + (lane >> 3), LDS slot lane & 7 = source chunk ^ ((row >> 1) & 7)
+    unsigned w_off[MAXWP];
+#pragma unroll
+    for (int i = 0; i < MAXWP; ++i) {
+        const int r = (wid + 4 * i) * 8 + (lane >> 3);
+        const int g = m0 - Wd - 1 + r;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        w_off[i] = (r < NR && g >= 0 && g < p.M) ? (unsigned)(g * p.a_ld + (chunk << 3)) * 2u : OOB;
+    }
+    unsigned b_base[B_P];
+#pragma unroll
+    for (int i = 0; i < B_P; ++i) {
+        const int r = (tid >> 3) + RP * i;
+        const int chunk = (tid & 7) ^ ((r >> 1) & 7);
+        b_base[i] = (unsigned)((n0 + r) * p.b_ld + (chunk << 3)) * 2u;
+    }
+    auto issueW = [&](int buf, int chunk, int i) {
+        if (wid + 4 * i < NPC) dma16(rsrcA, win + buf * WINB + (wid + 4 * i) * 1024, w_off[i], (unsigned)chunk * (BK16 * 2));
+    };
+
+    // fragment rows and their tap masks
+    int a_row[TM], fmask[TM], b_row[TN];
+    {
+        const int a_hw = p.a_OH * p.a_OW;
+        const float r_ahw = 1.f / (float)a_hw, r_aow = 1.f / (float)p.a_OW;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            a_row[i] = wm * (TM * 32) + i * 32 + li;
+            const int m = m0 + a_row[i];
+            int mask = 0;
+            if (m < p.M) {
+                const int n = fdiv(m, a_hw, r_ahw), rem = m - n * a_hw;
+                const int oh = fdiv(rem, p.a_OW, r_aow), ow = rem - oh * p.a_OW;
+                for (int t = 0; t < NT; ++t) {
+                    const int ih = oh + p.a_dh[t], iw = ow + p.a_dw[t];
+                    if (ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW) mask |= 1 << t;
+                }
+            }
+            fmask[i] = mask;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_row[j] = wn * (TN * 32) + j * 32 + li;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // K-step sigma = chunk * NT + tap (chunk outer, tap inner)
+    const int s_first = kbeg / BK16;
+    int ctap = s_first % NT, cchunk = s_first / NT;
+    const int last_chunk = (s_first + nk - 1) / NT;
+    int wnext = 0;                                       // pieces of the NEXT chunk's window issued so far (per wave)
+    if (nk > 0) {
+#pragma unroll
+        for (int i = 0; i < MAXWP; ++i) issueW(cchunk & 1, cchunk, i);
+        const unsigned boff = (unsigned)(p.b_tapoff[ctap] + cchunk * BK16) * 2u;
+#pragma unroll
+        for (int i = 0; i < B_P; ++i) dma16(rsrcB, bring + wid * 1024 + i * (RP * ROWB), b_base[i], boff);
+    }
+    int wlast = 0;                                       // window pieces issued at the END of the previous step (the youngest DMAs)
+    for (int t = 0; t < nk; ++t) {
+        // this step's B tile (and every older window piece) must have landed; the window piece issued after it may stay in flight:
+        // it belongs to the NEXT chunk and has up to nine steps to arrive (DMAs retire in order, so it is issued last)
+        if (wlast == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int stage = t & 1;
+        const char* Aw = win + (cchunk & 1) * WINB;
+        const char* Bs = bring + stage * BSTAGE;
+        // the step being issued
+        int ntap = ctap + 1, nchunk = cchunk;
+        if (ntap == NT) { ntap = 0; ++nchunk; }
+        const bool fillnext = t + 1 < nk;
+        char* Bd = bring + (stage ^ 1) * BSTAGE + wid * 1024;
+        const unsigned boff = fillnext ? (unsigned)(p.b_tapoff[ntap] + nchunk * BK16) * 2u : 0u;
+        const int offt = Wd + 1 + p.a_dh[ctap] * Wd + p.a_dw[ctap];          // wave-uniform
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int wr = a_row[i] + offt;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(Aw + wr * ROWB + (((2 * ks + lh) ^ ((wr >> 1) & 7)) << 4));
+                const bool ok = (fmask[i] >> ctap) & 1;
+                const u32x4 raw = __builtin_bit_cast(u32x4, v);
+                fa[i] = __builtin_bit_cast(bf16x8, ok ? raw : u32x4{0u, 0u, 0u, 0u});
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+            if (fillnext) {
+#pragma unroll
+                for (int idx = 0; idx < B_P; ++idx)
+                    if (idx * 4 / B_P == ks) dma16(rsrcB, Bd + idx * (RP * ROWB), b_base[idx], boff);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // window of the next chunk: one piece per step, issued after this step's B pieces; whatever is left on the chunk's last step
+        wlast = 0;
+        if (cchunk < last_chunk) {
+            const int want = (ctap == NT - 1) ? MAXWP : min(MAXWP, wnext + 1);
+            for (; wnext < want; ++wnext) {
+                if (wid + 4 * wnext < NPC) ++wlast;                 // pieces actually issued (a short window has fewer than MAXWP per wave)
+#pragma unroll
+                for (int i = 0; i < MAXWP; ++i)
+                    if (i == wnext) issueW((cchunk + 1) & 1, cchunk + 1, i);
+            }
+        }
+        if (ntap == 0) wnext = 0;
+        ctap = ntap; cchunk = nchunk;
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, p.c_ph, p.c_pw, p.prow0);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int MINW>
+hipError_t launch16w(const IgemmParams& p, int splits, hipStream_t st) {
+    const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
+    const int npc = (BM + 2 * p.a_IW + 2 + 7) / 8;
+    const size_t ring = (size_t)2 * npc * 1024 + (size_t)2 * BN * ROWB;
+    const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    auto kern = igemm16w_kernel<BM, BN, WM, WN, EPI, MINW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(64 * WM * WN), lds, st, p);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0>
 hipError_t launch16(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
@@ -284,6 +471,19 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
     // 0.29; 2-stage ring at two blocks per CU 0.24 / 0.30 / 0.23 (default); 256x128 tile, 8 waves, 3 stages 0.24 / 0.31 / 0.28;
     // the register-staged BF = 2 kernel 0.25 / 0.32 / 0.26.  Two co-resident blocks hide each other's prologue, epilogue and
     // DMA latency better than a deeper ring of one block does.
+    // 3x3 / stride 1 / W <= 30 layers: the window kernel (A fetched once per 64-channel chunk instead of once per tap).  Measured on
+    // SphereNet at batch 512, bf16 mode, one stream: 17.19 -> 16.81 ms per step; with vmcnt(0) at every step (the window piece of the
+    // NEXT chunk forced to land within one K-step) it was no faster than the per-tap kernel: the K-step waits for the DMAs issued
+    // during the previous step -- what bounds these launches is that one-step look-ahead of the two-stage ring (LDS holds no more at
+    // two blocks per CU), not the number of pieces.  FTE_IGEMM16_WIN=0: A/B hook.
+    static const int winmode = getenv("FTE_IGEMM16_WIN") ? atoi(getenv("FTE_IGEMM16_WIN")) : 1;
+    bool near = true;                                   // every tap within one pixel of the output position (3x3, pad 1)
+    for (int t = 0; t < p.a_NT && t < 9; ++t) near = near && p.a_dh[t] >= -1 && p.a_dh[t] <= 1 && p.a_dw[t] >= -1 && p.a_dw[t] <= 1;
+    if (winmode && tile == TILE_128x128 && p.a_NT == 9 && near && p.a_stride == 1 && p.ncls <= 1 && p.a_IW <= 30 && p.a_IW >= 2 &&
+        p.a_OH == p.a_IH && p.a_OW == p.a_IW) {
+        if (epi == EPI_FWD) return launch16w<128, 128, 2, 2, EPI_FWD, 2>(p, splits, st);
+        return launch16w<128, 128, 2, 2, EPI_DGRAD, 2>(p, splits, st);
+    }
     static const int cfg = getenv("FTE_IGEMM16_CFG") ? atoi(getenv("FTE_IGEMM16_CFG")) : 1;      // tuning hook
     if (cfg == 1 && tile == TILE_128x128) {          // 2-stage ring, two blocks per CU
         if (epi == EPI_FWD) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2>(p, splits, st);
