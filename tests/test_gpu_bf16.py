@@ -128,8 +128,8 @@ def _bf16_bits(t):
                                                      (5, 8, 8, 256, 128, 1, 1), (64, 14, 14, 128, 128, 3, 2), (2, 7, 7, 512, 512, 3, 1),
                                                      (512, 14, 14, 128, 128, 3, 1), (32, 56, 56, 64, 64, 3, 1), (500, 14, 14, 256, 256, 3, 1),
                                                      (130, 28, 28, 128, 128, 1, 1),
-                                                     # 128x128-tile launches of 3x3 / stride 1 layers run igemm16.hip's WINDOW kernel (A rows fetched once per
-                                                     # 64-channel chunk, taps as row-shifted views + edge masks): W = 28 with a ragged last tile, W = 7
+                                                     # 128x128-tile launches of 3x3 / stride 1 layers: W = 28 with a ragged last tile, W = 7 (also the shapes of
+                                                     # igemm16.hip's optional WINDOW kernel, test_window_kernel_option below)
                                                      (126, 28, 28, 128, 128, 3, 1), (512, 7, 7, 512, 512, 3, 1)])
 def test_bf16_source_entry_points_equal_the_operand_mode(bf16_mode, n, h, w, cin, cout, k, stride):
     """fte_conv2d_{fwd,dgrad,wgrad}16 read bf16 COPIES of the operands; the FTE_MFMA_BF16 mode rounds the fp32 operands
@@ -175,6 +175,20 @@ def test_bf16_source_entry_points_equal_the_operand_mode(bf16_mode, n, h, w, cin
     dw1 = torch.empty_like(wt)
     _lib.call('fte_conv2d_wgrad16', x16, dz16, dw1, n, h, w, cin, cout, k, stride, buf, nb, st)
     assert torch.equal(dw1, dw0)
+
+
+@pytest.mark.parametrize('mode', ['8', '1'])
+def test_window_kernel_option(mode):
+    """igemm16.hip's window kernel (FTE_IGEMM16_WIN: A rows fetched once per 64-channel chunk, the nine taps as row-shifted views with
+    per-lane edge masks; 8 = eight waves per block, 1 = four) is an option read once per process: the entry-point test above, which
+    holds its shapes (14x14 / 28x28 ragged / 7x7, forward and data gradient), runs again in a child process with the option set."""
+    import os, subprocess, sys
+    env = dict(os.environ, FTE_IGEMM16_WIN=mode)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_bf16.py'), '-m', 'gpu', '-q', '-x',
+                        '-k', 'source_entry_points'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
 
 
 def _close(a, b, what, tol=2e-6):

@@ -233,7 +233,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) keep_alive(acc[i][j]);
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep_alive(acc[i][j][r]);
         return;
     }
     igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, c_ph, c_pw, prow);
@@ -245,11 +247,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
 // per chunk (two buffers: the next chunk's window arrives one piece per K-step under the current chunk's taps), a tap's fragment
 // is the row li + W + 1 + dh W + dw of it, and the image edges are a 9-bit mask per lane that zeroes the fragment.  igemm16_kernel
 // re-fetches the A tile for every (tap, chunk): 16 of the 32 LDS-DMA pieces of a K-step; here 16 (B) + 24 / 9 (window).
-template <int BM, int BN, int WM, int WN, int EPI, int MINW>
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {           // s_waitcnt takes an immediate: n is wave-uniform and small
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+        default: wait_vmcnt<12>(); break;
+    }
+}
+// NSTB = stages of the B ring (NSTB - 1 K-steps of B in flight)
+template <int BM, int BN, int WM, int WN, int EPI, int MINW, int NSTB = 2>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
-    constexpr int RP = 32, B_P = BN / RP, BSTAGE = BN * ROWB, MAXWP = 6;
+    static_assert((WM * WN == 4 || WM * WN == 8 || WM * WN == 16) && TM >= 1 && TN >= 1 && NSTB >= 2 && NSTB <= 4, "4, 8 or 16 waves");
+    constexpr int NW = WM * WN, RP = 8 * NW, B_P = BN / RP, BSTAGE = BN * ROWB, MAXWP = (24 + NW - 1) / NW;
     static_assert(BN % RP == 0, "tile rows per DMA pass");
     extern __shared__ __attribute__((aligned(16))) char smem16[];
 
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
     unsigned w_off[MAXWP];
 #pragma unroll
     for (int i = 0; i < MAXWP; ++i) {
-        const int r = (wid + 4 * i) * 8 + (lane >> 3);
+        const int r = (wid + NW * i) * 8 + (lane >> 3);
         const int g = m0 - Wd - 1 + r;
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
         w_off[i] = (r < NR && g >= 0 && g < p.M) ? (unsigned)(g * p.a_ld + (chunk << 3)) * 2u : OOB;
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
         b_base[i] = (unsigned)((n0 + r) * p.b_ld + (chunk << 3)) * 2u;
     }
     auto issueW = [&](int buf, int chunk, int i) {
-        if (wid + 4 * i < NPC) dma16(rsrcA, win + buf * WINB + (wid + 4 * i) * 1024, w_off[i], (unsigned)chunk * (BK16 * 2));
+        if (wid + NW * i < NPC) dma16(rsrcA, win + buf * WINB + (wid + NW * i) * 1024, w_off[i], (unsigned)chunk * (BK16 * 2));
     };
 
     // fragment rows and their tap masks
@@ -341,28 +353,44 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
     int ctap = s_first % NT, cchunk = s_first / NT;
     const int last_chunk = (s_first + nk - 1) / NT;
     int wnext = 0;                                       // pieces of the NEXT chunk's window issued so far (per wave)
+    int itap = ctap, ichunk = cchunk;                    // the step whose B tile is issued next
+    auto issueB = [&](int stage) {
+        const unsigned boff = (unsigned)(p.b_tapoff[itap] + ichunk * BK16) * 2u;
+#pragma unroll
+        for (int i = 0; i < B_P; ++i) dma16(rsrcB, bring + stage * BSTAGE + wid * 1024 + i * (RP * ROWB), b_base[i], boff);
+        if (++itap == NT) { itap = 0; ++ichunk; }
+    };
     if (nk > 0) {
 #pragma unroll
         for (int i = 0; i < MAXWP; ++i) issueW(cchunk & 1, cchunk, i);
-        const unsigned boff = (unsigned)(p.b_tapoff[ctap] + cchunk * BK16) * 2u;
 #pragma unroll
-        for (int i = 0; i < B_P; ++i) dma16(rsrcB, bring + wid * 1024 + i * (RP * ROWB), b_base[i], boff);
+        for (int s2 = 0; s2 < NSTB - 1; ++s2)
+            if (s2 < nk) issueB(s2);
     }
-    int wlast = 0;                                       // window pieces issued at the END of the previous step (the youngest DMAs)
+    // DMAs retire in order.  Issued per step s, in this order: the B tile of step s + NSTB - 1, then (at most) one piece of the next
+    // chunk's window.  Step t needs its own B tile (issued in step t - NSTB + 1) and every older piece; everything issued in steps
+    // t - NSTB + 2 .. t - 1 -- and the window piece of step t - NSTB + 1 -- may stay in flight.
+    int wq[NSTB];                                        // window pieces issued at the end of the last NSTB - 1 steps (wq[0] = oldest)
+#pragma unroll
+    for (int i = 0; i < NSTB; ++i) wq[i] = 0;
+    int stage = 0, fill = NSTB - 1;
     for (int t = 0; t < nk; ++t) {
-        // this step's B tile (and every older window piece) must have landed; the window piece issued after it may stay in flight:
-        // it belongs to the NEXT chunk and has up to nine steps to arrive (DMAs retire in order, so it is issued last)
-        if (wlast == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        {
+            int allowed = 0;
+#pragma unroll
+            for (int i = 0; i < NSTB - 1; ++i) allowed += wq[i];
+            const int btiles = min(NSTB - 2, nk - 1 - t);                  // younger B tiles in flight (fewer near the end)
+            allowed += (btiles > 0 ? btiles : 0) * B_P;
+            wait_vmcnt_dyn(allowed);
+        }
         __builtin_amdgcn_s_barrier();
-        const int stage = t & 1;
         const char* Aw = win + (cchunk & 1) * WINB;
         const char* Bs = bring + stage * BSTAGE;
-        // the step being issued
         int ntap = ctap + 1, nchunk = cchunk;
         if (ntap == NT) { ntap = 0; ++nchunk; }
-        const bool fillnext = t + 1 < nk;
-        char* Bd = bring + (stage ^ 1) * BSTAGE + wid * 1024;
-        const unsigned boff = fillnext ? (unsigned)(p.b_tapoff[ntap] + nchunk * BK16) * 2u : 0u;
+        const bool fillnext = t + NSTB - 1 < nk;
+        char* Bd = bring + fill * BSTAGE + wid * 1024;
+        const unsigned boff = fillnext ? (unsigned)(p.b_tapoff[itap] + ichunk * BK16) * 2u : 0u;
         const int offt = Wd + 1 + p.a_dh[ctap] * Wd + p.a_dw[ctap];          // wave-uniform
 #pragma unroll
         for (int ks = 0; ks < BK16 / 16; ++ks) {
@@ -389,12 +417,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (fillnext && ++itap == NT) { itap = 0; ++ichunk; }
         // window of the next chunk: one piece per step, issued after this step's B pieces; whatever is left on the chunk's last step
-        wlast = 0;
+        int wlast = 0;
         if (cchunk < last_chunk) {
             const int want = (ctap == NT - 1) ? MAXWP : min(MAXWP, wnext + 1);
             for (; wnext < want; ++wnext) {
-                if (wid + 4 * wnext < NPC) ++wlast;                 // pieces actually issued (a short window has fewer than MAXWP per wave)
+                if (wid + NW * wnext < NPC) ++wlast;                 // pieces actually issued (a short window has fewer than MAXWP per wave)
 #pragma unroll
                 for (int i = 0; i < MAXWP; ++i)
                     if (i == wnext) issueW((cchunk + 1) & 1, cchunk + 1, i);
@@ -402,23 +431,28 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
         }
         if (ntap == 0) wnext = 0;
         ctap = ntap; cchunk = nchunk;
+#pragma unroll
+        for (int i = 0; i + 1 < NSTB - 1; ++i) wq[i] = wq[i + 1];
+        wq[NSTB - 2] = wlast;
+        stage = stage + 1 == NSTB ? 0 : stage + 1;
+        fill = fill + 1 == NSTB ? 0 : fill + 1;
     }
     wait_vmcnt<0>();
     __syncthreads();
     igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, p.c_ph, p.c_pw, p.prow0);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int MINW>
+template <int BM, int BN, int WM, int WN, int EPI, int MINW, int NSTB = 2>
 hipError_t launch16w(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
     const int npc = (BM + 2 * p.a_IW + 2 + 7) / 8;
-    const size_t ring = (size_t)2 * npc * 1024 + (size_t)2 * BN * ROWB;
+    const size_t ring = (size_t)2 * npc * 1024 + (size_t)NSTB * BN * ROWB;
     const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = igemm16w_kernel<BM, BN, WM, WN, EPI, MINW>;
+    auto kern = igemm16w_kernel<BM, BN, WM, WN, EPI, MINW, NSTB>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
@@ -466,25 +500,59 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         if (abl == 1) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1, 1>(p, splits, st);
         if (abl == 2) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1, 2>(p, splits, st);
         if (abl == 3) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1, 3>(p, splits, st);
+        // the default configuration (two-stage ring, two blocks per CU) with the same ablations: 11, 12, 13; 10 = that kernel itself
+        if (abl == 10) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2, 0>(p, splits, st);
+        if (abl == 11) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2, 1>(p, splits, st);
+        if (abl == 12) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2, 2>(p, splits, st);
+        if (abl == 13) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2, 3>(p, splits, st);
     }
     // Measured on MI355X at batch 512 (forward, ms: 14x14x256 / 28x28x128 / 7x7x512): 4-stage ring at one block per CU 0.30 / 0.41 /
     // 0.29; 2-stage ring at two blocks per CU 0.24 / 0.30 / 0.23 (default); 256x128 tile, 8 waves, 3 stages 0.24 / 0.31 / 0.28;
     // the register-staged BF = 2 kernel 0.25 / 0.32 / 0.26.  Two co-resident blocks hide each other's prologue, epilogue and
     // DMA latency better than a deeper ring of one block does.
-    // 3x3 / stride 1 / W <= 30 layers: the window kernel (A fetched once per 64-channel chunk instead of once per tap).  Measured on
-    // SphereNet at batch 512, bf16 mode, one stream: 17.19 -> 16.81 ms per step; with vmcnt(0) at every step (the window piece of the
-    // NEXT chunk forced to land within one K-step) it was no faster than the per-tap kernel: the K-step waits for the DMAs issued
-    // during the previous step -- what bounds these launches is that one-step look-ahead of the two-stage ring (LDS holds no more at
-    // two blocks per CU), not the number of pieces.  FTE_IGEMM16_WIN=0: A/B hook.
-    static const int winmode = getenv("FTE_IGEMM16_WIN") ? atoi(getenv("FTE_IGEMM16_WIN")) : 1;
+    // The window kernel (3x3 / stride 1 / W <= 30: A fetched once per 64-channel chunk instead of once per tap) is an OPTION, not the
+    // default.  Measured on SphereNet at batch 512, bf16 mode, one stream, ms per step (per-tap kernel -> window kernel):
+    //   four waves per block   17.19 -> 16.81   (16 + 24/9 DMA pieces per K-step instead of 32: the piece count is not the bound;
+    //                                            with vmcnt(0) at every step -- the next chunk's window piece forced to land within one
+    //                                            K-step -- nothing at all)
+    //   three / four B stages  20.5 / 20.9      (96 / 112 KB of LDS = ONE block per CU: deeper look-ahead loses to fewer waves)
+    //   eight waves (4 x 2)    15.77 -> 15.75   two blocks per CU = four waves per SIMD; 2 x 4: 16.1; sixteen waves: 17.3
+    // i.e. these launches are paced by how many waves a SIMD has to switch between while one waits on its LDS reads / barrier, and
+    // eight waves per block give the per-tap kernel the same gain.  FTE_IGEMM16_WIN = 1 (4 waves), 8, 9 (2 x 4), 16, 3 / 4 (B stages).
+    static const int winmode = getenv("FTE_IGEMM16_WIN") ? atoi(getenv("FTE_IGEMM16_WIN")) : 0;
     bool near = true;                                   // every tap within one pixel of the output position (3x3, pad 1)
     for (int t = 0; t < p.a_NT && t < 9; ++t) near = near && p.a_dh[t] >= -1 && p.a_dh[t] <= 1 && p.a_dw[t] >= -1 && p.a_dw[t] <= 1;
     if (winmode && tile == TILE_128x128 && p.a_NT == 9 && near && p.a_stride == 1 && p.ncls <= 1 && p.a_IW <= 30 && p.a_IW >= 2 &&
         p.a_OH == p.a_IH && p.a_OW == p.a_IW) {
+        if (winmode == 8) {          // eight waves (4 x 2, wave tile 32 x 64), two blocks per CU: four waves per SIMD
+            if (epi == EPI_FWD) return launch16w<128, 128, 4, 2, EPI_FWD, 4>(p, splits, st);
+            return launch16w<128, 128, 4, 2, EPI_DGRAD, 4>(p, splits, st);
+        }
+        if (winmode == 9) {          // eight waves as 2 x 4 (wave tile 64 x 32)
+            if (epi == EPI_FWD) return launch16w<128, 128, 2, 4, EPI_FWD, 4>(p, splits, st);
+            return launch16w<128, 128, 2, 4, EPI_DGRAD, 4>(p, splits, st);
+        }
+        if (winmode == 16) {         // sixteen waves (4 x 4, wave tile 32 x 32), two blocks per CU: eight waves per SIMD
+            if (epi == EPI_FWD) return launch16w<128, 128, 4, 4, EPI_FWD, 8>(p, splits, st);
+            return launch16w<128, 128, 4, 4, EPI_DGRAD, 8>(p, splits, st);
+        }
+        if (winmode == 3) {          // three B stages (two K-steps of B in flight), 96 KB: one block per CU
+            if (epi == EPI_FWD) return launch16w<128, 128, 2, 2, EPI_FWD, 1, 3>(p, splits, st);
+            return launch16w<128, 128, 2, 2, EPI_DGRAD, 1, 3>(p, splits, st);
+        }
+        if (winmode == 4) {          // four B stages, 112 KB: one block per CU
+            if (epi == EPI_FWD) return launch16w<128, 128, 2, 2, EPI_FWD, 1, 4>(p, splits, st);
+            return launch16w<128, 128, 2, 2, EPI_DGRAD, 1, 4>(p, splits, st);
+        }
         if (epi == EPI_FWD) return launch16w<128, 128, 2, 2, EPI_FWD, 2>(p, splits, st);
         return launch16w<128, 128, 2, 2, EPI_DGRAD, 2>(p, splits, st);
     }
-    static const int cfg = getenv("FTE_IGEMM16_CFG") ? atoi(getenv("FTE_IGEMM16_CFG")) : 1;      // tuning hook
+    // cfg 4 = cfg 1 with eight waves per block: SphereNet bf16 step 16.57 -> 15.77 ms (one stream), 16.0 -> 15.5 (two streams)
+    static const int cfg = getenv("FTE_IGEMM16_CFG") ? atoi(getenv("FTE_IGEMM16_CFG")) : 4;      // tuning hook
+    if (cfg == 4 && tile == TILE_128x128) {          // as cfg 1 with eight waves per block (4 x 2): four waves per SIMD
+        if (epi == EPI_FWD) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4>(p, splits, st);
+        return launch16<128, 128, 4, 2, EPI_DGRAD, 2, 4>(p, splits, st);
+    }
     if (cfg == 1 && tile == TILE_128x128) {          // 2-stage ring, two blocks per CU
         if (epi == EPI_FWD) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2>(p, splits, st);
         return launch16<128, 128, 2, 2, EPI_DGRAD, 2, 2>(p, splits, st);
