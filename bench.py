@@ -92,6 +92,8 @@ def cpu_baseline_and_parity(dev, mfma_dtype='f32', min_seconds=10.0, max_steps=1
     y = np.random.default_rng(1).integers(0, NUM_CLASSES, n)
     lam = float(oops.asoftmax_lambda(0))
     threads = torch.get_num_threads()
+    from tf_face_toolbox_amd.data import usable_cpus          # affinity mask and cgroup CPU quota
+    quota = usable_cpus()
     # ---- parity first (weights untouched): CPU forward vs HIP forward on the same inputs ----
     tp = torch_ref.to_torch(p, torch.float32, requires_grad=False)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
@@ -128,7 +130,7 @@ def cpu_baseline_and_parity(dev, mfma_dtype='f32', min_seconds=10.0, max_steps=1
     # a fair baseline uses the thread count the CPU library runs this batch fastest at (64 images do not scale to every
     # core of a 2-socket host): one untimed step per candidate, the best one is timed
     best = (None, threads)
-    for cand in sorted({threads, max(1, threads // 2), max(1, threads // 4), max(1, threads // 8)}, reverse=True):
+    for cand in sorted({threads, max(1, threads // 2), max(1, threads // 4), max(1, threads // 8), min(threads, quota)}, reverse=True):
         torch.set_num_threads(cand)
         t0 = time.time()
         torch_ref.train_step(tp, slots, xt, yt, LR, 5e-4, 'NCHW', 'asoftmax', lam)
@@ -146,7 +148,7 @@ def cpu_baseline_and_parity(dev, mfma_dtype='f32', min_seconds=10.0, max_steps=1
         if el >= min_seconds or reps >= max_steps:
             break
     base = {'value': round(n * reps / el, 3), 'unit': 'images/sec', 'cores': int(threads), 'kind': 'port',
-            'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(),
+            'cpu_model': cpu_model(), 'os_cpu_count': os.cpu_count(), 'usable_cpus': quota,
             'sample': '%d training steps (fwd + A-softmax loss + bwd + Momentum) of BASELINE configs[0] = 64 gray 112x112 images, '
                       'float32 torch-CPU restatement of the reference graph (oracle/torch_ref.py: F.conv2d + autograd), %.1f s on %d threads'
                       % (reps, el, threads)}

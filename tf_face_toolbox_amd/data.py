@@ -20,6 +20,30 @@ import torch
 from .preprocessing import data_augmentation  # noqa: F401
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the smaller of os.cpu_count(), the affinity mask and the cgroup CPU quota (a container
+    limited to 16 cores of a 256-thread host reports 256).  Reported by bench.py / scripts/bench_loader.py next to their figures;
+    the worker count is NOT derived from it: on such a host 48 decode workers still fed train.py 1.5x faster than 14."""
+    n = cpu_count()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:                                                    # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(q) // int(per)))
+    except (OSError, ValueError):
+        try:                                                # cgroup v1
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 # ------------------------------------------------------------------ list parsers (names kept)
 def get_image_paths(list_path):
     """data.py:30-41: first whitespace-separated token of every line."""
