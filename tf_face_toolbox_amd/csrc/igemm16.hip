@@ -488,9 +488,10 @@ hipError_t launch16(const IgemmParams& p, int splits, hipStream_t st) {
 bool igemm16_handles(const IgemmParams& p, int al, int bl, int tile) {
     if (!p.src16 || al != AL_MK || bl != BL_NK) return false;
     if (p.a_KC % BK16 || p.kchunk % BK16 || p.split_major > 0) return false;
-    // N = 64 layers (TILE_128x64) stay on the register-staged kernel: measured 0.49 vs 0.51 ms (forward) and 0.65 vs 0.69 ms (dgrad)
-    // on the 56x56x64 layer at batch 512 -- those launches are bound by their epilogue's HBM traffic, not by operand staging
-    static const bool narrow = getenv("FTE_IGEMM16_NARROW") != nullptr;
+    // N = 64 layers (TILE_128x64; bound by their epilogue's HBM traffic, not by operand staging): with four waves per block this kernel
+    // lost to the register-staged one (0.51 vs 0.49 ms forward, 0.69 vs 0.65 dgrad on 56x56x64 at batch 512); with eight waves
+    // (three blocks per CU = six waves per SIMD) it wins: SphereNet bf16 step 16.04 -> 15.82 ms.  FTE_IGEMM16_NARROW=0 keeps them there.
+    static const bool narrow = !(getenv("FTE_IGEMM16_NARROW") && atoi(getenv("FTE_IGEMM16_NARROW")) == 0);
     return tile == TILE_128x128 || (narrow && tile == TILE_128x64);
 }
 
@@ -572,6 +573,15 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         return launch16<128, 128, 2, 2, EPI_DGRAD, 4, 1>(p, splits, st);
     }
     if (tile == TILE_128x64) {
+        static const int nmode = getenv("FTE_IGEMM16_NARROW") ? atoi(getenv("FTE_IGEMM16_NARROW")) : 8;      // 1: four waves, 3-stage ring; 4: four waves, 2-stage
+        if (nmode == 8) {            // eight waves (4 x 2, wave tile 32 x 32), 2-stage ring of 24 KB stages: three blocks per CU
+            if (epi == EPI_FWD) return launch16<128, 64, 4, 2, EPI_FWD, 2, 6>(p, splits, st);
+            return launch16<128, 64, 4, 2, EPI_DGRAD, 2, 6>(p, splits, st);
+        }
+        if (nmode == 4) {            // four waves, 2-stage ring, three blocks per CU
+            if (epi == EPI_FWD) return launch16<128, 64, 2, 2, EPI_FWD, 2, 3>(p, splits, st);
+            return launch16<128, 64, 2, 2, EPI_DGRAD, 2, 3>(p, splits, st);
+        }
         if (epi == EPI_FWD) return launch16<128, 64, 2, 2, EPI_FWD, 3, 2>(p, splits, st);
         return launch16<128, 64, 2, 2, EPI_DGRAD, 3, 2>(p, splits, st);
     }
