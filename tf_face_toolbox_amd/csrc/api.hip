@@ -115,8 +115,12 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     // every split keeps >= 32 K-steps (K = 1024): the 4x4x512->512 1x1 convs of ShuffleNet's last stage (1024 tiles, P = 2) ran
     // 58 us split + fixed up against 43 us in one launch, and with 16..32 K-steps per split the 1x1 convs of the ResNet family
     // lose too (SE-ResNet-50 at 128 per GPU +1.1 % without those splits); the 3x3 layers of SphereNet at 64 images per GPU
-    // (K = 2304 / 4608, 36 K-steps per split) keep theirs (48 would cost them 1.4 %)
-    static const int min_steps = getenv("FTE_SPLIT_MINSTEPS") ? atoi(getenv("FTE_SPLIT_MINSTEPS")) : 32;      // tuning hook
+    // (K = 2304 / 4608, 36 K-steps per split) kept theirs while the step ran on one stream (48 cost them 1.4 %).  With the filter
+    // gradients on a second stream (nets/sphere.py) a half-filled launch is no longer alone on the chip and the 2-way splits of the
+    // K = 2304 layers stop paying once the unsplit launch has a block for every CU: 48 steps per split there, one GPU, images/s:
+    // 32 per GPU 6.99 k -> 7.15 k, 64: 8.40 k -> 8.50 k (bf16 mode 16.2 k -> 17.5 k), 128 / 256 and the BN nets unchanged.
+    static const int min_steps_env = getenv("FTE_SPLIT_MINSTEPS") ? atoi(getenv("FTE_SPLIT_MINSTEPS")) : 0;      // tuning hook
+    const int min_steps = min_steps_env > 0 ? min_steps_env : (R >= 256 ? 48 : 32);
     if (P > ksteps / min_steps) P = ksteps / min_steps;
     // Split-K pays only when there is NO whole round (small per-GPU shards): measured on MI355X at batch
     // 512 a 32-tile tail split 16 ways is slower than the 64x64 tail (which costs ~3 % of the kernel).
