@@ -54,7 +54,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3                    # MI355X_MICROARCH.md, "Peak FP
 BF16_MFMA_PEAK_TFLOPS = 2500.0                   # same table, "Peak BF16/FP16 MFMA" (dense)
 HBM_PEAK_GBPS = 8000.0                           # same table, HBM3E peak (spec)
 LR = 1e-4
-TILES = {0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64', 4: '192,64', 5: '192,128'}
+TILES = {0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64', 4: '192,64', 5: '64,64 (1 wave)', 6: '64,64 (2 waves)'}   # igemm.h's TILE_* enum
 
 
 def kernel_src_sha():
@@ -199,15 +199,8 @@ def latest_traffic_file(dtype='f32'):
     return best[1] if best else None
 
 
-def symbol_name(key, bf):
-    al, bl, epi, tile = key
-    if bf == 2 and al == 0 and bl == 1 and tile == 0 and os.environ.get('FTE_NO_IGEMM16') is None:
-        return 'igemm16_kernel<128,128,2,2,%d,2,2,0>' % epi       # the LDS-DMA kernel takes these launches (igemm16.hip)
-    return 'igemm_kernel<%s,%s,%d,%d,%d,%d>' % (TILES.get(tile, '?'), '2,2' if tile != 1 else '4,1', al, bl, epi, bf)
-
-
 def op_kind(key):
-    al, bl, epi, _ = key
+    al, bl, epi = key[:3]
     if al == 1:
         return 'wgrad'                           # A = x^T (k = pixel): filter gradient / dense tn
     return 'dgrad' if epi == 1 or bl == 1 else 'fwd'
@@ -216,8 +209,8 @@ def op_kind(key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)      # mean over >= 50 timed steps after >= 10 warm-up
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--global-batch', type=int, default=GLOBAL_BATCH,
                     help='exploration only (e.g. the per-rank shard sizes of N=2/4/8 on one GPU); the metric is quoted at 512')
@@ -280,7 +273,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    bf = 0 if args.mfma_dtype == 'f32' else (2 if getattr(net, 'bf16_copies', False) else 1)
     peak = FP32_MFMA_PEAK_TFLOPS if args.mfma_dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
     for _ in range(args.warmup):
         train_ops()
@@ -379,10 +371,12 @@ def main():
             print(json.dumps({'value': round(gb * args.steps / elapsed, 2), 'ms_per_step': round(ms, 3), 'n_gpus': world, 'note': 'launch records off'}))
             return
         sampled = (args.steps + PROF_EVERY - 1) // PROF_EVERY
-        # per-symbol table: key = (A layout, B layout, epilogue, tile) -> [launches, flops, ms, alg bytes]
-        table, shapes = {}, {}
-        for sig, fl, ms_, mnk, by in records:
-            t = table.setdefault(sig[:4], [0, 0.0, 0.0, 0.0])
+        # per-symbol table: key = the kernel symbol the launch was dispatched to, as the library recorded it
+        # (fte_prof_get_name: the template arguments rocprofv3 prints) -> [launches, flops, ms, alg bytes]; kinds: its op
+        table, shapes, kinds = {}, {}, {}
+        for sig, fl, ms_, mnk, by, sym in records:
+            t = table.setdefault(sym, [0, 0.0, 0.0, 0.0])
+            kinds[sym] = op_kind(sig)
             t[0] += 1; t[1] += fl; t[2] += ms_; t[3] += by
             s = shapes.setdefault((op_kind(sig[:4]),) + tuple(mnk) + (sig[3], sig[4]), [0, 0.0, 0.0, 0.0])
             s[0] += 1; s[1] += fl; s[2] += ms_; s[3] += by
@@ -398,7 +392,7 @@ def main():
         tpath = latest_traffic_file(args.mfma_dtype)
         if world == 1 and tpath and gb == GLOBAL_BATCH:
             tinfo = json.load(open(tpath))
-            ent = (tinfo.get('symbols') or {}).get(symbol_name(DOM, bf))
+            ent = (tinfo.get('symbols') or {}).get(DOM)
             if tinfo.get('kernel_src_sha') != kernel_src_sha():
                 tnote = 'profiles/%s was measured on other kernel sources (%s != %s): traffic nulled' % (
                     os.path.basename(tpath), tinfo.get('kernel_src_sha'), kernel_src_sha())
@@ -431,7 +425,7 @@ def main():
             'step_mfma_frac': round(gb * args.steps / elapsed * 12.2698e9 / (peak * 1e12) / world, 4),
             'losses': dict(zip(losses_name, [round(v, 6) for v in loss_vals])),
             'roofline': {'bound': 'mfma',
-                         'kernel': '%s = %s (MFMA implicit GEMM)' % (symbol_name(DOM, bf), {'fwd': 'conv3x3 forward + bias/PReLU/residual', 'dgrad': 'conv3x3 data gradient + PReLU gradient', 'wgrad': 'conv3x3 filter gradient'}[op_kind(DOM)]),
+                         'kernel': '%s = %s (MFMA implicit GEMM)' % (DOM, {'fwd': 'conv3x3 forward + bias/PReLU/residual', 'dgrad': 'conv3x3 data gradient + PReLU gradient', 'wgrad': 'conv3x3 filter gradient'}[kinds[DOM]]),
                          'achieved': round(achieved, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'launches_timed': cnt, 'avg_launch_ms': round(avg_ms, 4),
@@ -443,7 +437,7 @@ def main():
                                               'ms_per_step': round(all_ms / sampled, 3),
                                               'achieved': round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                               'frac': round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4)},
-                         'per_symbol': {symbol_name(k, bf): {'launches_per_step': round(v[0] / sampled, 2), 'ms_per_step': round(v[2] / sampled, 3),
+                         'per_symbol': {k: {'op': kinds[k], 'launches_per_step': round(v[0] / sampled, 2), 'ms_per_step': round(v[2] / sampled, 3),
                                                              'tflops': round(v[1] / (v[2] * 1e-3) / 1e12, 1),
                                                              'frac': round(v[1] / (v[2] * 1e-3) / 1e12 / peak, 3),
                                                              'algorithmic_bytes_per_launch': round(v[3] / v[0])}

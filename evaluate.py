@@ -47,20 +47,37 @@ def evaluate(FLAGS):
     latest = saver.latest_checkpoint(os.path.join(FLAGS.model_dir, tag))
     if not latest:
         raise IOError('No checkpoint file found')
-    state = torch.load(latest, map_location='cpu')
-    ncls = state['variables']['classifier/fc_classifier/weights'].shape[1]
-    model = net_select(FLAGS.net_name, FLAGS.data_format)
-    model.build(FLAGS.input_height, FLAGS.input_width, 3 if FLAGS.is_color else 1, ncls, device)
-    saver.restore(model, latest)
-    step = str(saver.step_of(latest))
-    print('Extracting features from model saved in iteration %s...' % step)
-    wfea = None
-    while wfea is None or wfea.shape[0] < num_images:
-        start_time = time.time()
-        fea = model.forward(next_images(), is_training=False).cpu().numpy()
-        wfea = fea if wfea is None else np.vstack((wfea, fea))
-        print('%d/%d features extracted... %.2fms elapsed' % (min(wfea.shape[0], num_images), num_images,
-                                                            (time.time() - start_time) * 1000))
+    try:
+        state = torch.load(latest, map_location='cpu')
+        # The extractor needs the backbone only (evaluate.py:62-63: forward(images, is_training=False), no num_classes).  This
+        # engine sizes its arena at build time, so the classifier's width is read from the checkpoint WHEN the net has one;
+        # nets trained without a classifier (the triplet heads: nets/resnet.py:67-68) are built without one.
+        cls = [k for k in state['variables'] if k.startswith('classifier/') and k.endswith('/weights')]
+        ncls = int(state['variables'][cls[0]].shape[-1]) if cls else 1
+        del state
+        model = net_select(FLAGS.net_name, FLAGS.data_format)
+        model.build(FLAGS.input_height, FLAGS.input_width, 3 if FLAGS.is_color else 1, ncls, device)
+        saver.restore(model, latest)
+        step = str(saver.step_of(latest))
+        print('Extracting features from model saved in iteration %s...' % step)
+        wfea = None
+        while wfea is None or wfea.shape[0] < num_images:
+            start_time = time.time()
+            # SphereNet: forward(is_training=False) is the flip-averaged embedding (nets/sphere.py:97-101); the graph nets: the
+            # pooled backbone features (their reference forward() cannot be called without num_classes, nets/resnet.py:147)
+            batch = next_images()
+            fea = (model.eval_features(batch) if hasattr(model, 'eval_features') else model.forward(batch, is_training=False)).cpu().numpy()
+            wfea = fea if wfea is None else np.vstack((wfea, fea))
+            print('%d/%d features extracted... %.2fms elapsed' % (min(wfea.shape[0], num_images), num_images,
+                                                                (time.time() - start_time) * 1000))
+    finally:
+        # orderly shutdown: producer thread joined, decode workers reaped, device drained (see train.py _run_and_leave)
+        if not next_images.close():
+            raise SystemExit('evaluate.py: the input pipeline thread did not stop')
+        try:
+            torch.cuda.synchronize()
+        except Exception as e:
+            print('evaluate.py: device synchronise failed during shutdown: %s' % e, file=sys.stderr)
     wfea = wfea[0:num_images, :]
     print('Totally extracted %d features.' % (wfea.shape[0]))
     print('Saving features to .mat files...')
@@ -71,9 +88,5 @@ def evaluate(FLAGS):
 
 
 if __name__ == '__main__':
-    evaluate(build_parser().parse_args())
-    # leave without running interpreter / HIP runtime teardown: on ROCm 7 an exit-time race between torch's helper
-    # threads and the runtime's static destructors occasionally ends a finished run with std::terminate (exit code -6)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    from train import _run_and_leave           # orderly shutdown above; leaves with the real status (not an unconditional 0)
+    _run_and_leave(lambda: evaluate(build_parser().parse_args()))

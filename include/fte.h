@@ -72,6 +72,10 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms);
 /* the GEMM shape of record i, mnk = {rows, N, K} (conv forward: rows = n*ho*wo, N = cout, K = 9*cin), and its ALGORITHMIC
  * bytes: every operand and result tensor of that launch once -- what bench.py's per-shape roofline divides by. */
 int fte_prof_get_shape(int i, int* mnk, double* bytes);
+/* the kernel symbol record i was dispatched to, with its template arguments as `rocprofv3 --kernel-trace` prints them minus
+ * blanks (e.g. "igemm_kernel<128,128,2,2,1,0,0,0>", "igemm16_kernel<128,128,4,2,0,2,4,0>"): bench.py's per-symbol table and
+ * scripts/pmc_summary.py join the launch records with the profiler's rows on this string -- no name is rebuilt by hand. */
+int fte_prof_get_name(int i, char* buf, int buflen);
 
 /* ---------------------------------------------------------------------------
  * 3x3 convolution, TF-SAME, stride 1 or 2, Cin % 32 == 0, Cout % 64 == 0
@@ -355,10 +359,19 @@ int fte_add_scaled_rows_cols(float* a, const float* b, const float* rc, const fl
 /* center loss (loss.py:29-45): loss_rows[i] = sum_j (f_ij - c_{y_i} j)^2 (caller takes the mean over n*d);
  * dfeat = 2(f - c_y)*grad_scale; then centers[y] -= (1-alpha)(c_y - f), duplicates accumulating
  * (scatter_sub).  Every gather is served from the centers as they were BEFORE the update
- * (loss.py:37 before :39).  In place on `centers`; ws >= n*d floats. */
+ * (loss.py:37 before :39).  In place on `centers` [num_classes, d]; ws >= n*d floats, and after the call
+ * ws[0 : n*d] holds diff = f - c_y (what fte_center_scatter_update consumes).  alpha == 1 evaluates loss and gradient
+ * only (no update launch).  A label outside [0, num_classes) gives a NaN loss / gradient row and no update -- never an
+ * out-of-bounds access. */
 int fte_center_loss_fwd_bwd_update(const float* feat, const int32_t* labels, float* centers,
-                                   float* loss_rows, float* dfeat, int n, int d, float alpha,
+                                   float* loss_rows, float* dfeat, int n, int d, int num_classes, float alpha,
                                    float grad_scale, void* ws, size_t ws_bytes, void* stream);
+/* the scatter_sub half of loss.py:38-39 on its own: centers[labels[i]] += (1 - alpha) * diff[i] for i < n, duplicates
+ * accumulating.  Used by the opt-in replica reconciliation (DataParallel(sync_centers=True)): every rank evaluates the loss
+ * with alpha = 1, the ranks all-gather their (labels, diff) rows and each applies ALL of them, so the replicas keep ONE
+ * table equal to the single-tower update of the global batch; the default reproduces the reference's per-tower tables. */
+int fte_center_scatter_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes,
+                              float alpha, void* stream);
 
 /* batch-hard triplet (loss.py:47-78): per-sample loss [n] and d(sum w_i*loss_i)/dfeat.
  * margin < 0 selects softplus (margin=None in the reference).  ws >= 3*n*n floats. */

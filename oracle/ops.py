@@ -98,17 +98,20 @@ def conv2d_fwd(x, w, stride=1, bias=None):
     return z.reshape(n, ho, wo, co)
 
 
-def conv2d_bwd(x, w, dz, stride=1, need_dx=True):
+def conv2d_bwd(x, w, dz, stride=1, need_dx=True, need_dw=True):
     """Gradients of conv2d_fwd wrt x and w (what tf.gradients lowers to:
-    Conv2DBackpropInput / Conv2DBackpropFilter; data_parallel.py:33)."""
+    Conv2DBackpropInput / Conv2DBackpropFilter; data_parallel.py:33).  `need_dw=False` skips the filter gradient
+    (x then only gives the shape)."""
     n, h, wd, c = x.shape
     kh, kw, ci, co = w.shape
     ho, pt, pb = same_pads(h, kh, stride)
     wo, pl, pr = same_pads(wd, kw, stride)
     xp = _pad_nhwc(x, pt, pb, pl, pr)
-    cols = _im2col(xp, kh, kw, stride, ho, wo)
     dz2 = dz.reshape(n * ho * wo, co)
-    dw = mfma_matmul(cols.T, dz2).reshape(kh, kw, ci, co)
+    dw = None
+    if need_dw:
+        cols = _im2col(xp, kh, kw, stride, ho, wo)
+        dw = mfma_matmul(cols.T, dz2).reshape(kh, kw, ci, co)
     dx = None
     if need_dx:
         dcols = mfma_matmul(dz2, w.reshape(kh * kw * ci, co).T).reshape(n, ho, wo, kh, kw, ci)

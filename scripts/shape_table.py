@@ -20,7 +20,7 @@ for _ in range(steps): step()
 torch.cuda.synchronize()
 _lib.query('fte_prof_enable', 0)
 agg = collections.OrderedDict()
-for sig, fl, ms, mnk, by in _lib.prof_records(shapes=True):
+for sig, fl, ms, mnk, by, _sym in _lib.prof_records(shapes=True):
     k = (tuple(sig), tuple(mnk))
     a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += fl; a[2] += ms
 rows = sorted(agg.items(), key=lambda kv: -kv[1][2])

@@ -58,3 +58,44 @@ def test_single_rank_rccl_data_parallel_equals_singular(name):
         dist.destroy_process_group()
     assert got_losses == ref_losses
     assert torch.equal(net.params, ref.params)
+
+
+@pytest.mark.parametrize('name', ['ResNeXt-26', 'ShuffleNet-v2-small'])
+def test_single_rank_rccl_bn_nets_equal_singular(name):
+    """The graph-engine nets (two all-reduce buckets: classifier, then the body; filter gradients on a second stream) through the
+    same world-size-1 RCCL run: async all-reduce per backward stage, per-bucket optimizer after each wait -- bit-identical to
+    Singular (same seeds: one replica's dropout seed is base * 1 + 0)."""
+    n, h, w, ch, ncls = 8, 64, 64, 3, 10
+    rng = np.random.default_rng(64)
+    x = rng.uniform(-1, 1, (n, h, w, ch)); y = rng.integers(0, ncls, n)
+    inputs = {'images': dev(x), 'labels': dev(y, torch.int32), 'num_classes': ncls, 'num_examples': n}
+
+    def make():
+        net = net_select(name, 'NCHW', 5e-4)
+        net.seed = 7
+        net.build(h, w, ch, ncls, 'cuda')
+        return net
+    ref = make()
+    step, losses, _, _ = Singular(ref, 0.05, 'Momentum')(inputs)
+    for _ in range(3):
+        step()
+    ref_losses = [float(v) for v in losses]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        net = make()
+        model = DataParallel_margin(net, 0.05, 'Momentum', num_gpus=2)
+        model.num_gpus = 1
+        assert len(net.grad_buckets()) == 2 == len(net.backward_stages())
+        step, losses, names, others = model(inputs)
+        for _ in range(3):
+            step()
+        got_losses = [float(v) for v in losses]
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert got_losses == ref_losses
+    assert torch.equal(net.params, ref.params)
+    for k in ref.state:
+        assert torch.equal(net.state[k], ref.state[k]), k

@@ -1,5 +1,6 @@
-"""-m gpu: a real 2-rank data-parallel run on the test box's one GPU (two processes launched the way the driver launches
-bench.py, gloo as the transport).  Checks SURVEY 8c's N-rank pins with the HIP kernels in the loop: replicas identical
+"""-m gpu: a real 2-rank data-parallel run (two processes launched the way the driver launches bench.py).  With two or more
+GPUs on the box the ranks take one device each and talk over RCCL ('nccl' backend, tests/dp_worker.py); on the one-GPU test box
+they share the device and gloo is the transport.  Checks SURVEY 8c's N-rank pins with the HIP kernels in the loop: replicas identical
 after the initial broadcast and after every step, and the result equal to the oracle's 2-tower step
 (data_parallel.py:203-256: shard, 1/n pre-scale, SUM, same update everywhere)."""
 import os
@@ -15,6 +16,14 @@ from oracle import spherenet as osn
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check_transport(r0, r1):
+    """>= 2 GPUs: both ranks ran RCCL on their own device; one GPU: gloo on device 0."""
+    if torch.cuda.device_count() >= 2 and os.environ.get('FTE_TEST_FORCE_GLOO') != '1':
+        assert str(r0['backend']) == 'nccl' == str(r1['backend']) and int(r0['device']) == 0 and int(r1['device']) == 1
+    else:
+        assert str(r0['backend']) == 'gloo' == str(r1['backend'])
 
 
 def _free_port():
@@ -41,8 +50,10 @@ def test_two_ranks_equal_the_oracle_two_tower_step(tmp_path, name, head):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:]
     r0, r1 = np.load(out + '.rank0.npz'), np.load(out + '.rank1.npz')
+    _check_transport(r0, r1)
     for k in r0.files:                                     # replicas bit-identical (weights AND displayed losses)
-        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+        if k not in ('backend', 'device'):
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
     # oracle: the same two steps with 2 towers
     ref = dict(p)
     slots = {k: np.zeros_like(v) for k, v in p.items()}
@@ -66,7 +77,10 @@ def test_bench_py_runs_with_two_ranks(tmp_path, launcher):
     ranks as child processes before touching the GPU and relays rank 0's line) and under torch.distributed.run.  One JSON
     line from rank 0; the two ranks share the box's GPU over gloo (FTE_BENCH_SHARED_GPU=1)."""
     import json
-    env = dict(os.environ, PYTHONPATH=ROOT, FTE_BENCH_SHARED_GPU='1')
+    shared = torch.cuda.device_count() < 2             # one GPU: both ranks on it, gloo; otherwise the driver's configuration (RCCL)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    if shared:
+        env['FTE_BENCH_SHARED_GPU'] = '1'
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     tail = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--global-batch', '16']
@@ -86,7 +100,10 @@ def test_bench_py_runs_with_two_ranks(tmp_path, launcher):
     assert out['cpu_baseline'] is None and out['roofline']['frac'] > 0
     assert all(np.isfinite(v) for v in out['losses'].values())
     ar = out['allreduce']
-    assert ar['rccl_ranks'] == 0 and ar['backend'].startswith('gloo')          # the test transport; on the 8-GPU box: nccl, N ranks
+    if shared:
+        assert ar['rccl_ranks'] == 0 and ar['backend'].startswith('gloo')      # the test transport
+    else:
+        assert ar['rccl_ranks'] == 2 and ar['backend'].startswith('nccl')      # one GPU per rank: RCCL, as the driver runs it
     assert len(ar['bucket_bytes']) == 5 == len(ar['bucket_alone_ms']) and sum(ar['bucket_bytes']) == 4 * (out_arena(out) + 4)
     assert ar['ms_per_step_without_allreduce'] > 0
     assert {'fwd', 'dgrad', 'wgrad'} <= set(e['op'] for e in out['roofline']['per_shape'])
@@ -173,3 +190,42 @@ def test_two_ranks_center_loss_state_is_per_replica(tmp_path):
         assert err <= 5e-4 * np.abs(newc).max(), (rank, err)      # centers = 0.01 x features of a BN net at 4 images per tower: fp32 noise ~1e-4
         untouched = [c for c in range(ncls) if c not in set(y[sl])]
         assert np.abs(got[untouched]).max() == 0                              # rows of classes outside the shard stay zero
+
+
+def test_two_ranks_center_loss_reconciled_tables(tmp_path):
+    """DataParallel(sync_centers=True) (opt-in; the default above is the reference's per-tower tables): the ranks all-gather
+    each step's (labels, f - c_y) rows and every rank applies all of them, so after a step BOTH replicas hold the SAME table,
+    bit for bit, and it equals the single-tower scatter_sub of the GLOBAL batch (loss.py:37-39 applied to the concatenated
+    shards; features per shard, as each tower's BN sees only its own rows)."""
+    from oracle import graphnet as og, ops as oops
+    n, h, w, ch, ncls = 8, 32, 32, 3, 10
+    rng = np.random.default_rng(15)
+    x = rng.uniform(-1, 1, (n, h, w, ch))
+    y = np.array([0, 1, 2, 0, 5, 0, 5, 7])                       # class 0 in both shards, duplicates inside each
+    graph, spec = og.resnet_train_graph(26, ch, ncls, 'resnext')
+    p, state = og.init_params(spec, 16)
+    p = og.perturb(p, 17)
+    fix = str(tmp_path / 'fix.npz')
+    np.savez(fix, x=x, y=y, ncls=ncls, **{'p:' + k: v for k, v in p.items()})
+    out = str(tmp_path / 'out')
+    env = dict(os.environ, PYTHONPATH=ROOT, FTE_TEST_SYNC_CENTERS='1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(ROOT, 'tests', 'dp_worker.py'), fix, out, 'ResNeXt-26-center', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    r0, r1 = np.load(out + '.rank0.npz'), np.load(out + '.rank1.npz')
+    for k in r0.files:
+        if k.startswith('w:'):
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    c0, c1 = r0['s:centers'], r1['s:centers']
+    np.testing.assert_array_equal(c0, c1)                                       # ONE table
+    feats = []
+    for rank in range(2):
+        sl = slice(rank * 4, rank * 4 + 4)
+        env_, _, _ = og.forward(graph, p, x[sl], train=True, masks={'features_drop': np.ones((4, 2048))}, state=state)
+        feats.append(env_['features'])
+    _, _, newc = oops.center_loss(np.concatenate(feats), y, np.zeros((ncls, 2048)), 0.99)
+    err = np.abs(c0 - newc).max()
+    assert err <= 5e-4 * np.abs(newc).max(), err
+    assert np.abs(c0[[3, 4, 6, 8, 9]]).max() == 0 and np.abs(c0[0]).max() > 0

@@ -70,7 +70,7 @@ def test_head_goldens():
     check_maxabs(host(dl)[:, :c], g['ce_dlogits'], what='ce dlogits')
     cen = dev(g['centers']); df = torch.empty(n, d, device='cuda')
     wsb, nb = ws(n * d * 4)
-    call('fte_center_loss_fwd_bwd_update', dev(x), dev(y, torch.int32), cen, lrows, df, n, d, 0.99, 1.0 / (n * d), wsb, nb, stream())
+    call('fte_center_loss_fwd_bwd_update', dev(x), dev(y, torch.int32), cen, lrows, df, n, d, c, 0.99, 1.0 / (n * d), wsb, nb, stream())
     check_maxabs(host(cen), g['center_new'], what='centers'); check_maxabs(host(df), g['center_df'], what='center df')
     for m in (None, 0.3):
         tl = torch.empty(n, device='cuda'); tg = torch.empty(n, d, device='cuda')

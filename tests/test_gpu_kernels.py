@@ -193,7 +193,7 @@ def test_center_loss_and_triplet():
     loss_ref, df_ref, newc_ref = ops.center_loss(f, y, cen, 0.99)
     cd = dev(cen); lrows = torch.empty(n, device='cuda'); df = torch.empty(n, d, device='cuda')
     wsb, nb = ws(n * d * 4)
-    call('fte_center_loss_fwd_bwd_update', dev(f), dev(y, torch.int32), cd, lrows, df, n, d, 0.99, 1.0 / (n * d), wsb, nb, stream())
+    call('fte_center_loss_fwd_bwd_update', dev(f), dev(y, torch.int32), cd, lrows, df, n, d, c, 0.99, 1.0 / (n * d), wsb, nb, stream())
     assert abs(host(lrows).sum() / (n * d) - loss_ref) <= 1e-5 * loss_ref
     check_maxabs(host(df), df_ref, 1e-5, 'dfeat'); check_maxabs(host(cd), newc_ref, 1e-5, 'centers')
     for margin in (None, 0.3):

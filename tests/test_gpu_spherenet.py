@@ -54,6 +54,37 @@ def test_forward_loss_and_every_gradient(name, data_format, n, h, w, ch, ncls):
         check_rell2(host(net.get_variable(k, net.grads)), data_grad, what='grad ' + k)
 
 
+def test_config1_at_its_own_batch_64_gray_112():
+    """BASELINE.json configs[0] at ITS size -- SphereFaceNet-20 + A-softmax, 64 gray 112x112 images, 10575 classes, one replica:
+    embeddings / logits / losses against BOTH float64 oracles (numpy oracle/spherenet.py and the independent torch-autograd
+    restatement oracle/torch_ref.py, which bench.py times as the CPU baseline) and every gradient against the numpy oracle
+    (kink-band elements resolved as everywhere else).  At 64 images the backward walk runs on two streams (nets/sphere.py)."""
+    from oracle import torch_ref
+    n, h, w, ch, ncls = 64, 112, 112, 1, 10575
+    net, p, x, y = _setup('SphereNet-ASoftmax', 'NCHW', n, h, w, ch, ncls, seed=51)
+    lam = ops.asoftmax_lambda(0)
+    xd, yd = dev(x), dev(y, torch.int32)
+    net.tower_scale = 1.0
+    logits = net.forward(xd, yd, num_classes=ncls, is_training=True)
+    losses, names, others = net.loss_function('TOWER', yd, **logits)
+    net.backward()
+    torch.cuda.synchronize()
+    tp = torch_ref.to_torch(p, torch.float64, requires_grad=False)
+    with torch.no_grad():
+        ce_t, reg_t, emb_t, log_t = torch_ref.spherenet_loss(tp, torch.from_numpy(x), torch.from_numpy(y), 5e-4, 'NCHW', 'asoftmax', float(lam))
+    check_maxabs(host(net.emb), emb_t.numpy(), what='embedding vs torch_ref')
+    check_maxabs(host(logits['logits']), log_t.numpy(), what='logits vs torch_ref')
+    assert abs(float(losses[0]) - float(ce_t)) <= 1e-5 * max(1, abs(float(ce_t)))
+    assert abs(float(losses[1]) - float(reg_t)) <= 1e-5 * max(1, abs(float(reg_t)))
+    losses_ref, g_ref, ex = osn.loss_and_grads(p, x, y, 5e-4, 'NCHW', 'asoftmax', lam, kink=kink_of(net))
+    check_maxabs(host(net.emb), ex['embedding'], what='embedding')
+    check_maxabs(host(logits['logits']), ex['logits'], what='logits')
+    assert abs(float(losses[0]) - losses_ref[0]) <= 1e-5 * max(1, abs(losses_ref[0]))
+    for k in p:
+        data_grad = g_ref[k] - (5e-4 * p[k] if k.endswith('/weights') else 0)
+        check_rell2(host(net.get_variable(k, net.grads)), data_grad, what='grad ' + k)
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 def test_filter_gradients_on_the_second_stream_are_bit_identical(mode):
     """SphereNet's backward walk launches wgrad(l) on a second stream beside dgrad(l) (nets/sphere.py _body_walk): the same kernels on

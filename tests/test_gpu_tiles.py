@@ -1,0 +1,120 @@
+"""-m gpu: oracle parity for EVERY tile instantiation the headline run (SphereFaceNet-20, 512 x 112 x 112 x 3) launches.
+
+Round-2 review: the planner (csrc/api.hip plan_rows / wgrad_plan) picks the 192x64 filter-gradient tile only for K ranges of
+>= 1024 pixels per split (>= ~84 images of 56x56), the tall 128x64 forward / dgrad tile only at >= 4096 such tiles, and split counts
+of 153-256 only at the full batch -- none of which the small cases of test_gpu_kernels.py reach, so those instantiations were only
+ever compared with themselves (additivity 512 = 256 + 256).  Here each one runs at a size that triggers it NATURALLY (no hook) and
+is compared with the float64 oracle block by block; small hooked cases add ragged shapes.  The launch records (fte_prof_get_name)
+say which kernel symbol actually ran, and the last test checks the union against the symbol list of the committed bench line.
+Shapes: nets/sphere.py:56-70 at 112x112."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SEEN = set()          # kernel symbols the cases of this module ran (filled in file order; the last test reads it)
+
+
+def _run(cases, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ('FTE_WGRAD_TILE', 'FTE_NARROW_TILE', 'FTE_WIDE_TILE', 'FTE_WGRAD_SPLIT_MAJOR', 'FTE_SPLIT_MINK'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'tile_worker.py'), json.dumps(cases)], env=e, cwd=ROOT,
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert lines, 'tile_worker produced no result line:\n' + r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads(lines[-1])
+    for c in res['cases']:
+        SEEN.update(c['symbols'])
+        assert c['ok'], 'parity failure: %s' % json.dumps(c)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return res['cases']
+
+
+def _has(case, symbol):
+    assert symbol in case['symbols'], '%s did not run for %s (ran: %s)' % (symbol, case['case'], case['symbols'])
+
+
+def test_wgrad_192x64_natural_and_256_way_split():
+    """stage 1 (56x56, 64 -> 64): M = 9*64 = 576 = three 192-row tiles; 96 images give K ranges >= 1024 pixels, the planner keeps the
+    192x64 tile and splits K ~256 ways, split-major (one pixel range per XCD)."""
+    c = _run([['wgrad', 96, 56, 56, 64, 64, 1]])[0]
+    _has(c, 'igemm_kernel<192,64,2,2,1,0,0,0>')
+    assert max(c['splits']) >= 200, c['splits']
+
+
+def test_wgrad_128x128_natural_many_splits():
+    """stages 2 and 3: 128x128 filter-gradient tile with ~85-170 splits (28x28x128->128: nine tiles), plus the stride-2 entry conv
+    of stage 2 (56x56x64 -> 28x28x128, M = 576 on the 128x128 tile: 4.5 tiles, ragged M) and a 14x14x256 layer (42 splits in the headline)."""
+    cs = _run([['wgrad', 112, 28, 28, 128, 128, 1], ['wgrad', 120, 56, 56, 64, 128, 2], ['wgrad', 160, 14, 14, 256, 256, 1]])
+    for c in cs:
+        _has(c, 'igemm_kernel<128,128,2,2,1,0,0,0>')
+    assert max(cs[0]['splits']) >= 80 and max(cs[1]['splits']) >= 80, (cs[0]['splits'], cs[1]['splits'])
+
+
+def test_tall_128x64_fwd_dgrad_n64_natural():
+    """stage 1 at >= 4096 tiles of 128x64: forward and data gradient of 56x56x64->64 on the tall tile (N = 64)."""
+    cs = _run([['fwd', 168, 56, 56, 64, 64, 1], ['dgrad', 168, 56, 56, 64, 64, 1]])
+    _has(cs[0], 'igemm_kernel<128,64,2,2,0,0,0,0>')
+    _has(cs[1], 'igemm_kernel<128,64,2,2,0,1,1,0>')
+
+
+def test_tall_128x64_fwd_dgrad_n128_natural():
+    """stage 2 at >= 4096 tiles: 28x28x128->128 forward / data gradient on the tall tile (N = 128: two column tiles), and the stage-2
+    entry conv's forward (56x56x64 -> 28x28x128, stride 2, K = 576)."""
+    cs = _run([['fwd', 336, 28, 28, 128, 128, 1], ['dgrad', 336, 28, 28, 128, 128, 1], ['fwd', 336, 56, 56, 64, 128, 2]])
+    _has(cs[0], 'igemm_kernel<128,64,2,2,0,0,0,0>')
+    _has(cs[1], 'igemm_kernel<128,64,2,2,0,1,1,0>')
+    _has(cs[2], 'igemm_kernel<128,64,2,2,0,0,0,0>')
+
+
+def test_default_64x64_fwd_dgrad_at_many_rounds():
+    """stages 3 and 4 stay on the 64x64 tile; sizes with several rounds of blocks and a ragged last round, and the stride-2 data
+    gradient's four parity classes as separate launches (>= one round of tiles per class)."""
+    cs = _run([['fwd', 130, 14, 14, 256, 256, 1], ['dgrad', 130, 14, 14, 256, 256, 1], ['dgrad', 256, 28, 28, 128, 256, 2],
+               ['fwd', 200, 7, 7, 512, 512, 1], ['dgrad', 200, 7, 7, 512, 512, 1]])
+    _has(cs[0], 'igemm_kernel<64,64,2,2,0,0,0,0>')
+    _has(cs[1], 'igemm_kernel<64,64,2,2,0,1,1,0>')
+    _has(cs[2], 'igemm_kernel<64,64,2,2,0,1,1,0>')
+    assert len(cs[2]['splits']) == 4, cs[2]           # four class launches
+
+
+@pytest.mark.parametrize('split_major', ['1', '0'])
+def test_wgrad_192x64_hooked_small_and_ragged(split_major):
+    """FTE_WGRAD_TILE=4 forces the 192x64 tile on small shapes: ragged K (pixels not a multiple of 32), a ragged last split,
+    stride 2, M = 1152 (six tiles), >= 100 splits; with split-major block placement (the default) and with the 2-D grid."""
+    env = {'FTE_WGRAD_TILE': '4', 'FTE_WGRAD_SPLIT_MAJOR': split_major}
+    cs = _run([['wgrad', 3, 9, 7, 64, 64, 1], ['wgrad', 40, 28, 28, 64, 64, 1], ['wgrad', 5, 13, 13, 64, 64, 2],
+               ['wgrad', 9, 14, 14, 128, 64, 1], ['wgrad', 37, 28, 28, 64, 128, 1]], env)
+    for c in cs:
+        _has(c, 'igemm_kernel<192,64,2,2,1,0,0,0>')
+    assert max(cs[1]['splits']) >= 100, cs[1]['splits']
+
+
+def test_wgrad_128x128_hooked_ragged_splits():
+    """the 128x128 and 128x64 filter-gradient tiles at > 100 splits with a ragged last split (FTE_SPLIT_MINK lowers the K floor)."""
+    cs = _run([['wgrad', 21, 28, 28, 128, 128, 1], ['wgrad', 21, 27, 29, 128, 256, 2]], {'FTE_WGRAD_TILE': '0', 'FTE_SPLIT_MINK': '96'})
+    for c in cs:
+        _has(c, 'igemm_kernel<128,128,2,2,1,0,0,0>')
+    assert max(cs[0]['splits']) >= 100, cs[0]['splits']
+    cs = _run([['wgrad', 21, 28, 28, 64, 64, 1]], {'FTE_WGRAD_TILE': '2', 'FTE_SPLIT_MINK': '96'})
+    _has(cs[0], 'igemm_kernel<128,64,2,2,1,0,0,0>')
+
+
+def test_every_conv_symbol_of_the_headline_run_was_checked():
+    """tests/golden/headline_symbols.json lists roofline.per_symbol of the committed bench line (profiles/); every conv symbol in
+    it must have run -- against the oracle -- in the tests above; the dense symbols (FC / classifier products) are the
+    instantiations test_gpu_kernels.py::test_dense_nn_nt_tn runs at (512, 512, 25088) and (70, 10624, 512)."""
+    if not SEEN:
+        pytest.skip('run the whole module: the earlier tests collect the symbols')
+    want = json.load(open(os.path.join(HERE, 'golden', 'headline_symbols.json')))
+    missing = [s for s in want['conv_symbols'] if s not in SEEN]
+    assert not missing, 'headline conv symbols never compared with the oracle: %s' % missing

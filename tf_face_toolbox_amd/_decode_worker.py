@@ -98,13 +98,19 @@ def train_example(path, num_channels, input_height, input_width, crop_height, cr
 
 
 def fill_rows(task):
-    """(buffer file, batch shape, [(row, path, seed), ...], num_channels, in_h, in_w, crop_h, crop_w, augmentation): decode the
-    listed images (seed None: the evaluation transform) into rows of the shared batch buffer (a float32 file under /dev/shm mapped by the parent and every worker).
-    Returns the number of rows written (errors propagate)."""
+    """(buffer, batch shape, [(row, path, seed), ...], num_channels, in_h, in_w, crop_h, crop_w, augmentation): decode the
+    listed images (seed None: the evaluation transform) into rows of the shared batch buffer -- a float32 array in anonymous shared
+    memory named by the file DESCRIPTOR this process inherited from the parent (data._WorkerPool: memfd_create + pass_fds), or by a
+    file path.  Returns the number of rows written (errors propagate)."""
     name, shape, rows, num_channels, in_h, in_w, crop_h, crop_w, augmentation = task
     batch = _SHM.get(name)
     if batch is None or batch.shape != tuple(shape):
-        batch = _SHM[name] = np.memmap(name, dtype=np.float32, mode='r+', shape=tuple(shape))
+        if isinstance(name, int):
+            import mmap
+            mm = mmap.mmap(name, int(np.prod(shape)) * 4)
+            batch = _SHM[name] = np.frombuffer(mm, dtype=np.float32).reshape(tuple(shape))
+        else:
+            batch = _SHM[name] = np.memmap(name, dtype=np.float32, mode='r+', shape=tuple(shape))
     for row, path, seed in rows:
         if seed is None:                          # evaluation: decode + resize + normalise, nothing random (data.py:153-191)
             batch[row] = (decode(path, num_channels, in_h, in_w) - np.float32(0.5)) / np.float32(0.5)

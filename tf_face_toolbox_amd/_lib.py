@@ -20,6 +20,7 @@ _SIGS = {
     'fte_prof_count': (c_int, []),
     'fte_prof_get': (c_int, [c_int, _P, _P, _P]),
     'fte_prof_get_shape': (c_int, [c_int, _P, _P]),
+    'fte_prof_get_name': (c_int, [c_int, _P, c_int]),
     'fte_conv3x3_fwd': (c_int, [_P] * 7 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_fwd_ws_bytes': (c_size_t, [c_int] * 6),
     'fte_conv3x3_dgrad': (c_int, [_P] * 9 + [c_int] * 6 + [_P, c_size_t, _P]),
@@ -88,7 +89,8 @@ _SIGS = {
     'fte_row_norms': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
     'fte_col_norms': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
     'fte_add_scaled_rows_cols': (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
-    'fte_center_loss_fwd_bwd_update': (c_int, [_P] * 5 + [c_int] * 2 + [c_float] * 2 + [_P, c_size_t, _P]),
+    'fte_center_loss_fwd_bwd_update': (c_int, [_P] * 5 + [c_int] * 3 + [c_float] * 2 + [_P, c_size_t, _P]),
+    'fte_center_scatter_update': (c_int, [_P] * 3 + [c_int] * 3 + [c_float, _P]),
     'fte_batch_hard_triplet_fwd_bwd': (c_int, [_P] * 2 + [c_float] * 2 + [_P] * 2 + [c_int] * 2 + [_P, c_size_t, _P]),
     'fte_reduce_rows': (c_int, [_P] * 3 + [c_int, c_long, c_long, c_int, c_float, _P]),
     'fte_sumsq': (c_int, [_P, c_long, c_float, _P, _P, c_size_t, _P]),
@@ -183,7 +185,7 @@ def get_mfma_dtype():
 
 def prof_records(shapes=False):
     """All launch records since fte_prof_enable(1): list of (sig tuple, flops, ms) -- with `shapes`, of
-    (sig tuple, flops, ms, (rows, N, K), algorithmic bytes).  Synchronise first."""
+    (sig tuple, flops, ms, (rows, N, K), algorithmic bytes, kernel symbol).  Synchronise first."""
     lib = load()
     out = []
     sig = (ctypes.c_int * 5)()
@@ -200,7 +202,11 @@ def prof_records(shapes=False):
             r = lib.fte_prof_get_shape(i, ctypes.cast(mnk, c_void_p), ctypes.cast(ctypes.pointer(by), c_void_p))
             if r != 0:
                 raise FteError('fte_prof_get_shape(%d) failed with code %d' % (i, r))
-            out.append((tuple(sig), fl.value, ms.value, tuple(mnk), by.value))
+            name = ctypes.create_string_buffer(96)
+            r = lib.fte_prof_get_name(i, ctypes.cast(name, c_void_p), 96)
+            if r != 0:
+                raise FteError('fte_prof_get_name(%d) failed with code %d' % (i, r))
+            out.append((tuple(sig), fl.value, ms.value, tuple(mnk), by.value, name.value.decode()))
         else:
             out.append((tuple(sig), fl.value, ms.value))
     return out

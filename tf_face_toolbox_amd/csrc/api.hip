@@ -247,6 +247,10 @@ int fte_prof_get_shape(int i, int* mnk, double* bytes) {
     if (!mnk || !bytes) return FTE_EINVAL;
     return rc(igemm_prof_get_shape(i, mnk, bytes));
 }
+int fte_prof_get_name(int i, char* buf, int buflen) {
+    if (!buf || buflen <= 0) return FTE_EINVAL;
+    return rc(igemm_prof_get_name(i, buf, buflen));
+}
 int fte_prof_get(int i, int* sig, double* flops, float* ms) {
     if (!sig || !flops || !ms) return FTE_EINVAL;
     return rc(igemm_prof_get(i, sig, flops, ms));
@@ -518,8 +522,11 @@ void wgrad_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride, 
     // slab bytes (14x14x128->128 at batch 512: 65 -> 51 us, 7x7x256->256: 52 -> 44 us with the slab reduction)
     const bool tiny = ksize == 1 && M * cout <= 256L * 256;
     *tile = wg_tile >= 0 ? wg_tile : (tiny ? TILE_64x64 : (cout % 128 == 0) ? TILE_128x128 : narrow);
-    // prefer8 / split-major placement (one pixel range per XCD) cut wgrad's HBM traffic ~9x on MI355X but the
-    // kernel is MFMA-bound: 18.4 -> 18.9 ms per step.  Left off (FTE_WGRAD_SPLIT_MAJOR=1 turns it on: tuning hook).
+    // Block placement: split-major (wgrad_split_major(), ON by default since round 2; FTE_WGRAD_SPLIT_MAJOR=0 gives the 2-D grid
+    // back): the tiles of one pixel range sit 8 block ids apart -- same XCD, same L2 -- so x / dz leave HBM once per pixel range
+    // instead of once per tile (stage-1 symbol 2844 -> 904 MB per launch, 128x128 symbol 1923 -> 523 MB) at unchanged kernel
+    // time.  `prefer8` (split counts that are multiples of 8) stays off in plan_splits: the kernels are MFMA-bound and the
+    // rounder split count cost more than the L2 locality gave (18.4 -> 18.9 ms per step when first measured).
     plan_splits(tiles_of(*tile, M, cout), *K, splits, kchunk, false);
     // Small per-GPU shards: when filling the chip with big tiles leaves every block fewer than 1024 pixels of K (32 K-steps), take
     // 64 x 64 tiles instead -- 4x the tiles, a quarter of the splits, K ranges 4x as long and a quarter of the slab traffic.
@@ -761,10 +768,14 @@ int fte_add_scaled_rows_cols(float* a, const float* b, const float* rcf, const f
     return rc(k_add_scaled(a, b, rcf, cc, rows, cols, ld, (hipStream_t)stream));
 }
 int fte_center_loss_fwd_bwd_update(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
-                                   int n, int d, float alpha, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
-    if (!feat || !labels || !centers || !loss_rows || !dfeat || n <= 0) return FTE_EINVAL;
+                                   int n, int d, int num_classes, float alpha, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !labels || !centers || !loss_rows || !dfeat || n <= 0 || d <= 0 || num_classes <= 0) return FTE_EINVAL;
     if (!ws || ws_bytes < (size_t)n * d * sizeof(float)) return FTE_EWORKSPACE;
-    return rc(k_center_loss(feat, labels, centers, loss_rows, dfeat, n, d, alpha, grad_scale, (float*)ws, (hipStream_t)stream));
+    return rc(k_center_loss(feat, labels, centers, loss_rows, dfeat, n, d, num_classes, alpha, grad_scale, (float*)ws, (hipStream_t)stream));
+}
+int fte_center_scatter_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes, float alpha, void* stream) {
+    if (!diff || !labels || !centers || n <= 0 || d <= 0 || num_classes <= 0) return FTE_EINVAL;
+    return rc(k_center_update(diff, labels, centers, n, d, num_classes, alpha, (hipStream_t)stream));
 }
 int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, float margin, float loss_weight,
                                    float* loss_rows, float* dfeat, int n, int d, void* ws, size_t ws_bytes, void* stream) {

@@ -73,6 +73,11 @@ bool igemm_get_bf16();
 
 // launch records for the roofline measurement (see igemm.hip)
 void igemm_prof_enable(bool on, bool clear);
+bool igemm_prof_on();
+// called by every launcher of the family while records are on: the kernel symbol of this dispatch with its template
+// arguments, spelled as rocprofv3 --kernel-trace prints them (minus blanks), e.g. "igemm_kernel<128,128,2,2,1,0,0,0>"
+void igemm_note_symbol(const char* family, const int* targs, int ntargs);
+hipError_t igemm_prof_get_name(int i, char* buf, int buflen);
 int igemm_prof_count();
 hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms);
 hipError_t igemm_prof_get_shape(int i, int* mnk, double* bytes);      // GEMM shape {rows, N, K} and algorithmic bytes of record i

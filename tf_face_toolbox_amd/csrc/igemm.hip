@@ -31,7 +31,9 @@
 // pass) and multiplied by v_mfma_f32_32x32x16_bf16.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 #include <vector>
@@ -1017,6 +1019,7 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     static const size_t lds_pad = getenv("FTE_LDS_PAD") ? (size_t)atoi(getenv("FTE_LDS_PAD")) : 0;      // tuning hook: fewer blocks per CU
     const size_t lds_x = lds + lds_pad;
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>;
+    if (igemm_prof_on()) { const int ta[8] = {BM, BN, WM, WN, AL, BL, EPI, BF}; igemm_note_symbol("igemm_kernel", ta, 8); }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1076,9 +1079,10 @@ hipError_t launch_tile(const IgemmParams& p, int tile, int splits, hipStream_t s
 // stream and its algorithmic FLOPs (2 * rows * N * K of THAT launch) are noted, so that a caller can
 // report FLOPs / duration per kernel symbol -- the same per-symbol average rocprofv3 --stats prints.
 namespace {
-struct ProfRec { int sig[5]; int mnk[3]; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfRec { int sig[5]; int mnk[3]; double flops, bytes; hipEvent_t e0, e1; char sym[96]; };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
+char g_last_sym[96] = "";
 void prof_clear() {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
@@ -1138,8 +1142,10 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
     e = hipEventCreate(&r.e1);
     if (e != hipSuccess) return e;
     (void)hipEventRecord(r.e0, st);
+    g_last_sym[0] = 0;
     e = dispatch(p, al, bl, epi, tile, splits, st);
     (void)hipEventRecord(r.e1, st);
+    memcpy(r.sym, g_last_sym, sizeof(r.sym));
     g_prof.push_back(r);
     return e;
 }
@@ -1155,6 +1161,17 @@ bool igemm_get_bf16() { return g_bf16; }
 void igemm_prof_enable(bool on, bool clear) {
     if (on && clear) prof_clear();
     g_prof_on = on;
+}
+bool igemm_prof_on() { return g_prof_on; }
+void igemm_note_symbol(const char* family, const int* targs, int ntargs) {
+    int n = snprintf(g_last_sym, sizeof(g_last_sym), "%s<", family);
+    for (int i = 0; i < ntargs && n < (int)sizeof(g_last_sym) - 16; ++i) n += snprintf(g_last_sym + n, sizeof(g_last_sym) - n, i ? ",%d" : "%d", targs[i]);
+    snprintf(g_last_sym + n, sizeof(g_last_sym) - n, ">");
+}
+hipError_t igemm_prof_get_name(int i, char* buf, int buflen) {
+    if (i < 0 || i >= (int)g_prof.size() || !buf || buflen <= 0) return hipErrorInvalidValue;
+    snprintf(buf, (size_t)buflen, "%s", g_prof[i].sym);
+    return hipSuccess;
 }
 int igemm_prof_count() { return (int)g_prof.size(); }
 hipError_t igemm_prof_get_shape(int i, int* mnk, double* bytes) {

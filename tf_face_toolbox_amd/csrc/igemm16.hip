@@ -450,6 +450,7 @@ hipError_t launch16w(const IgemmParams& p, int splits, hipStream_t st) {
     const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
     auto kern = igemm16w_kernel<BM, BN, WM, WN, EPI, MINW, NSTB>;
+    if (igemm_prof_on()) { const int ta[7] = {BM, BN, WM, WN, EPI, MINW, NSTB}; igemm_note_symbol("igemm16w_kernel", ta, 7); }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
@@ -467,6 +468,7 @@ hipError_t launch16(const IgemmParams& p, int splits, hipStream_t st) {
     const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
     auto kern = igemm16_kernel<BM, BN, WM, WN, EPI, NST, MINW, ABL>;
+    if (igemm_prof_on()) { const int ta[8] = {BM, BN, WM, WN, EPI, NST, MINW, ABL}; igemm_note_symbol("igemm16_kernel", ta, 8); }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

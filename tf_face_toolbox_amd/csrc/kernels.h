@@ -27,7 +27,8 @@ hipError_t k_row_norms(const float* a, float* out, int rows, int cols, int ld, h
 hipError_t k_col_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st);
 hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* cc, int rows, int cols, int ld, hipStream_t st);
 hipError_t k_center_loss(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
-                         int n, int d, float alpha, float gs, float* ws, hipStream_t st);
+                         int n, int d, int num_classes, float alpha, float gs, float* ws, hipStream_t st);
+hipError_t k_center_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes, float alpha, hipStream_t st);
 hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, float lw, float* loss_rows, float* dfeat,
                      int n, int d, float* ws, hipStream_t st);
 hipError_t k_momentum(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gs, hipStream_t st);

@@ -478,9 +478,14 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ a, 
 __global__ __launch_bounds__(256) void center_loss_kernel(const float* __restrict__ feat, const int32_t* __restrict__ labels,
                                                           const float* __restrict__ centers, float* __restrict__ diff,
                                                           float* __restrict__ loss_rows, float* __restrict__ dfeat,
-                                                          int d, float gscale) {
+                                                          int d, int num_classes, float gscale) {
     __shared__ float sh[4];
     const int i = blockIdx.x, y = labels[i];
+    if ((unsigned)y >= (unsigned)num_classes) {      // a label outside the table: NaN loss / gradient row, zero update -- never an out-of-bounds access
+        for (int j = threadIdx.x; j < d; j += 256) { dfeat[(long)i * d + j] = NAN; diff[(long)i * d + j] = 0.f; }
+        if (threadIdx.x == 0) loss_rows[i] = NAN;
+        return;
+    }
     float s = 0.f;
     for (int j = threadIdx.x; j < d; j += 256) {
         const float df = feat[(long)i * d + j] - centers[(long)y * d + j];
@@ -493,10 +498,40 @@ __global__ __launch_bounds__(256) void center_loss_kernel(const float* __restric
 }
 // scatter_sub after every gather has been served from the OLD centers (loss.py:37-39):
 // centers[y] -= (1-alpha)*(c_y - f)  ==  += (1-alpha)*(f - c_y); duplicate labels accumulate.
+// Deterministic (no float atomics): the block of the FIRST sample carrying a label owns that row of the table and sums the rows
+// of all samples with the same label in sample order; the other blocks of that label leave.  Replicas that apply the same
+// (labels, diff) list therefore produce bit-identical tables (the opt-in reconciliation of data_parallel.py), and a repeated
+// step repeats bit for bit.  Labels are staged in LDS (n <= CENTER_LDS_LABELS), else read from global memory.
+constexpr int CENTER_LDS_LABELS = 8192;
 __global__ __launch_bounds__(256) void center_update_kernel(const float* __restrict__ diff, const int32_t* __restrict__ labels,
-                                                            float* __restrict__ centers, int d, float alpha) {
+                                                            float* __restrict__ centers, int n, int d, int num_classes, float alpha) {
+    __shared__ int lab[CENTER_LDS_LABELS];
     const int i = blockIdx.x, y = labels[i];
-    for (int j = threadIdx.x; j < d; j += 256) atomicAdd(centers + (long)y * d + j, (1.f - alpha) * diff[(long)i * d + j]);
+    if ((unsigned)y >= (unsigned)num_classes) return;
+    const bool staged = n <= CENTER_LDS_LABELS;
+    if (staged) {
+        for (int k = threadIdx.x; k < n; k += 256) lab[k] = labels[k];
+        __syncthreads();
+    }
+    const int* L = staged ? lab : labels;
+    for (int k = 0; k < i; ++k)
+        if (L[k] == y) return;                       // an earlier sample owns this row (block-uniform)
+    for (int j0 = threadIdx.x; j0 < d; j0 += 256 * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = i; k < n; ++k) {
+            if (L[k] != y) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * 256;
+                if (j < d) acc[u] += diff[(long)k * d + j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 256;
+            if (j < d) centers[(long)y * d + j] += (1.f - alpha) * acc[u];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -756,9 +791,14 @@ hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* 
     return hipGetLastError();
 }
 hipError_t k_center_loss(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
-                         int n, int d, float alpha, float gs, float* ws, hipStream_t st) {
-    hipLaunchKernelGGL(center_loss_kernel, dim3(n), dim3(256), 0, st, feat, labels, centers, ws, loss_rows, dfeat, d, gs);
-    hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), 0, st, ws, labels, centers, d, alpha);
+                         int n, int d, int num_classes, float alpha, float gs, float* ws, hipStream_t st) {
+    hipLaunchKernelGGL(center_loss_kernel, dim3(n), dim3(256), 0, st, feat, labels, centers, ws, loss_rows, dfeat, d, num_classes, gs);
+    if (alpha != 1.f)      // alpha == 1: loss and gradient only (graph construction, or the update is applied later by k_center_update)
+        hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), 0, st, ws, labels, centers, n, d, num_classes, alpha);
+    return hipGetLastError();
+}
+hipError_t k_center_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes, float alpha, hipStream_t st) {
+    hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), 0, st, diff, labels, centers, n, d, num_classes, alpha);
     return hipGetLastError();
 }
 hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, float lw, float* loss_rows, float* dfeat,

@@ -113,8 +113,38 @@ class _Prefetcher(object):
         # batch the consumer holds, the one being filled, and one spare; a GPU copy's event is waited for before reuse.
         self._ring, self._slot = [], 0
         self._nslots = depth + 3
+        self._stop = threading.Event()
         self._t = threading.Thread(target=self._run, daemon=True)
         self._t.start()
+
+    def _put(self, item):
+        """q.put that gives up when close() has been called (the consumer is gone)"""
+        while not self._stop.is_set():
+            try:
+                self.q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def close(self, timeout=30.0):
+        """Orderly shutdown (train.py / evaluate.py call it before they leave): stop the producer thread, wait for it, then end
+        the decode workers and release their buffers.  Returns True when the thread has ended."""
+        self._stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
+        self._t.join(timeout)
+        ended = not self._t.is_alive()
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize()                          # host-to-device copies still reading the ring / the workers' buffers
+        if self.pool is not None and ended:
+            self.pool.close()
+        if self._dead is None:
+            self._dead = RuntimeError('input pipeline closed')
+        return ended
 
     def _stage(self, x):
         """x (numpy, possibly the workers' shared buffer) -> a staging tensor of this prefetcher's ring"""
@@ -134,7 +164,7 @@ class _Prefetcher(object):
 
     def _run(self):
         try:
-            while True:
+            while not self._stop.is_set():
                 x, y = self.make_batch()
                 if y is not None and self.num_classes is not None and y.size:
                     lo, hi = int(y.min()), int(y.max())
@@ -143,11 +173,11 @@ class _Prefetcher(object):
                 yt = torch.from_numpy(y) if y is not None else None
                 d = self.pool.direct(x) if (self.pool is not None and self.device.type == 'cuda') else None
                 if d is not None:                                 # page-locked worker buffer: no staging copy at all
-                    self.q.put(({'buf': d[0], 'ev': None, 'release': d[1]}, yt))
+                    self._put(({'buf': d[0], 'ev': None, 'release': d[1]}, yt))
                 else:
-                    self.q.put((self._stage(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x), yt))
+                    self._put((self._stage(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x), yt))
         except BaseException as e:                            # noqa: B902 -- everything goes to the consumer
-            self.q.put(e)
+            self._put(e)
 
     def advance(self):
         if self._dead is not None:
@@ -180,7 +210,7 @@ class _Prefetcher(object):
 
 class _WorkerPool(object):
     """Decode workers as separate PROCESSES (`python -m tf_face_toolbox_amd._decode_worker`: numpy + PIL only, no torch, no GPU)
-    that write their rows straight into a float32 batch buffer under /dev/shm mapped by everybody.  Threads top out at a
+    that write their rows straight into a float32 batch buffer in anonymous shared memory (memfd) mapped by everybody.  Threads top out at a
     few hundred images/s (the numpy part of decode/resize holds the GIL); the GPU step consumes 10-30 k images/s."""
 
     GROUP = 16       # workers that share one batch: with 128 workers on one 512-image batch each has ~5 ms of work per batch and is
@@ -188,52 +218,62 @@ class _WorkerPool(object):
 
     def __init__(self, workers, shape, pin=False):
         import atexit
+        import mmap
         import subprocess
         import sys
         self.shape = tuple(shape)
         self.pin = bool(pin)
+        self.procs, self.fds, self.mms, self.maps, self.tensors = [], [], [], [], None
+        atexit.register(self.close)                # registered before anything below can raise: a half-built pool is torn down too
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1',
                    OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
-        self.procs = [subprocess.Popen([sys.executable, '-m', 'tf_face_toolbox_amd._decode_worker'], stdin=subprocess.PIPE,
-                                       stdout=subprocess.PIPE, env=env) for _ in range(workers)]
-        base = '/dev/shm' if os.path.isdir('/dev/shm') else None
-        if base is not None:                      # a small /dev/shm (container default 64 MB) would end the workers with SIGBUS
-            try:
-                vfs = os.statvfs(base)
-                need = (2 * max(1, workers // self.GROUP) + 6) * int(np.prod(self.shape)) * 4
-                if vfs.f_bavail * vfs.f_frsize < need + (64 << 20):
-                    base = None                   # fall back to the default temporary directory (file-backed mapping)
-            except OSError:
-                base = None
-        import tempfile
-        self.files, self.maps = [], []
         gs = min(self.GROUP, workers)
+        ngroups = max(1, workers // gs)
+        # Every group has TWO batches in the pipe (one being decoded, the next already waiting on its workers' stdin): a group
+        # that has to wait for the parent to copy its batch out before it gets the next one idles a third of the time.
+        self.DEPTH = 2 * ngroups
+        # batch buffers in rotation: the open tickets + the one being copied out; with `pin` the buffers themselves are
+        # page-locked (hipHostRegister on the shared mapping) and the GPU copies straight out of them, so a buffer also stays
+        # busy while it waits in the prefetch queue and until its copy's event has fired: 4 more
+        self.RING = self.DEPTH + (5 if self.pin else 1)
+        # The batch buffers are ANONYMOUS shared memory (memfd_create), inherited by the workers as file descriptors: nothing has a
+        # name under /dev/shm, so a rank that is SIGTERMed / SIGKILLed (torch.distributed.run does that to the survivors of a
+        # failed rank; so do schedulers and `timeout`) leaves nothing behind -- the kernel frees the pages with the last process
+        # that holds the descriptor -- and the size of the /dev/shm mount (64 MB by default in containers) does not matter.
+        nbytes = int(np.prod(self.shape)) * 4
+        for k in range(self.RING):
+            fd = os.memfd_create('fte_batch_%d' % k)
+            self.fds.append(fd)
+            os.ftruncate(fd, nbytes)
+            mm = mmap.mmap(fd, nbytes)
+            self.mms.append(mm)
+            self.maps.append(np.frombuffer(mm, dtype=np.float32).reshape(self.shape))
+        self.procs = [subprocess.Popen([sys.executable, '-m', 'tf_face_toolbox_amd._decode_worker'], stdin=subprocess.PIPE,
+                                       stdout=subprocess.PIPE, env=env, pass_fds=self.fds) for _ in range(workers)]
         self.groups = [self.procs[i:i + gs] for i in range(0, workers - gs + 1, gs)]
         if workers % gs:
             self.groups[-1] = self.groups[-1] + self.procs[workers - workers % gs:]
-        # Every group has TWO batches in the pipe (one being decoded, the next already waiting on its workers' stdin): a group
-        # that has to wait for the parent to copy its batch out before it gets the next one idles a third of the time.
-        self.DEPTH = 2 * len(self.groups)
-        # batch buffers in rotation: the open tickets + the one being copied out; with `pin` the buffers themselves are
-        # page-locked (hipHostRegister on the /dev/shm mapping) and the GPU copies straight out of them, so a buffer also stays
-        # busy while it waits in the prefetch queue and until its copy's event has fired: 4 more
-        self.RING = self.DEPTH + (5 if self.pin else 1)
-        for k in range(self.RING):
-            fd, path = tempfile.mkstemp(prefix='fte_batch_%d_%d_' % (os.getpid(), k), dir=base)
-            os.close(fd)
-            self.files.append(path)
-            self.maps.append(np.memmap(path, dtype=np.float32, mode='w+', shape=self.shape))
         self.turn = 0
         self.events = [None] * self.RING         # per buffer: the event of the host-to-device copy that last read it
-        self.tensors = None
         if self.pin:
+            # page-lock the shared buffers so that the GPU copies straight out of them; if the runtime refuses (locked-memory
+            # limit, exotic mapping) the batches go through _Prefetcher's pinned staging ring instead -- slower, never fatal
             rt = torch.cuda.cudart()
-            self.tensors = [torch.from_numpy(m) for m in self.maps]
-            for t in self.tensors:
+            tensors = [torch.from_numpy(m) for m in self.maps]
+            done = []
+            for t in tensors:
                 if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 4, 0)) != 0 or not t.is_pinned():
-                    raise RuntimeError('hipHostRegister of a /dev/shm batch buffer failed')
-        atexit.register(self.close)
+                    break
+                done.append(t)
+            if len(done) == len(tensors):
+                self.tensors = tensors
+            else:
+                for t in done:
+                    rt.cudaHostUnregister(t.data_ptr())
+                self.pin = False
+                print('tf_face_toolbox_amd.data: hipHostRegister of the shared batch buffers failed -- batches are staged through '
+                      'pinned host buffers instead')
 
     def close(self):
         for p in self.procs:
@@ -256,13 +296,14 @@ class _WorkerPool(object):
             except Exception:
                 pass
             self.tensors = None
-        self.maps = []
-        for f in self.files:
+        self.maps = []                            # the mmaps are released with the last numpy view of them (handed-out batches may outlive the pool)
+        self.mms = []
+        for fd in self.fds:
             try:
-                os.remove(f)
+                os.close(fd)
             except OSError:
                 pass
-        self.files = []
+        self.fds = []
 
     def submit(self, rows, params):
         """Hand rows [(row, path, seed)] to the next group of workers; returns a ticket for wait().  At most DEPTH tickets may
@@ -281,7 +322,7 @@ class _WorkerPool(object):
             ch = rows[i::n]
             if not ch:
                 continue
-            b = pickle.dumps((self.files[k], self.shape, ch) + tuple(params))
+            b = pickle.dumps((self.fds[k], self.shape, ch) + tuple(params))
             p.stdin.write(struct.pack('<I', len(b)) + b)
             p.stdin.flush()
             used.append(p)
@@ -406,9 +447,16 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
         x = np.stack(imgs).reshape(shard, out_h, out_w, num_channels)
         return x, labels
 
-    src = _BatchSource(_Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total, pool=procs))
+    pf = _Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total, pool=procs)
+    src = _BatchSource(pf)
+
+    def close():
+        ended = pf.close()
+        if pool is not None:
+            pool.shutdown(wait=True)
+        return ended
     return {'images': src.images, 'labels': src.labels, 'num_classes': num_classes_total,
-            'num_examples': num_examples_total, 'batch_size': batch_size}
+            'num_examples': num_examples_total, 'batch_size': batch_size, 'close': close}
 
 
 def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width, device='cuda', num_workers=None):
@@ -441,7 +489,17 @@ def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width,
         return np.stack(imgs).astype(np.float32), None
 
     pf = _Prefetcher(make_batch, torch.device(device), pool=procs)
-    return (lambda: pf.advance()[0]), num_examples
+
+    def next_batch():
+        return pf.advance()[0]
+
+    def close():
+        ended = pf.close()
+        if pool is not None:
+            pool.shutdown(wait=True)
+        return ended
+    next_batch.close = close                     # orderly shutdown of the producer thread and the decode workers (evaluate.py)
+    return next_batch, num_examples
 
 
 def synthetic_inputs(batch_size, height, width, is_color, num_classes, device='cuda', rank=0, world_size=1, seed=0):

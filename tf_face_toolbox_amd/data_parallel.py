@@ -94,6 +94,10 @@ class _HostComm(object):
     def broadcast(self, t, src=0):
         self.dist.broadcast(t, src=src, group=self.group)
 
+    def all_gather(self, out, t):
+        """out [world * len(t)] <- every rank's t, in rank order (the center loss's opt-in reconciliation)."""
+        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+
 
 class Singular(object):
     """data_parallel.py:24-79."""
@@ -204,12 +208,16 @@ class Singular(object):
 class DataParallel(Singular):
     """data_parallel.py:81-166: synchronous data parallelism, one replica per GPU."""
 
-    def __init__(self, model, lr, optimizer, num_gpus=4, weight_decay=5e-4, comm=None):
+    def __init__(self, model, lr, optimizer, num_gpus=4, weight_decay=5e-4, comm=None, sync_centers=False):
+        """`sync_centers` (not in the reference; default off = the reference's behaviour): the center loss's `centers` table
+        is per-tower state there (loss.py:34-39) and the towers' tables drift apart; True all-gathers every step's scatter rows
+        so that all replicas keep ONE table, equal to the single-tower update of the global batch (nets/graph.py)."""
         assert num_gpus > 1, 'DataParallel objects are only used for multi-gpu training tasks.'
         super(DataParallel, self).__init__(model, lr, optimizer, weight_decay)
         self.num_gpus = num_gpus
         self.pretrained_param = []
         self.comm = comm
+        self.sync_centers = bool(sync_centers)
         self._global_batch = None
 
     def _shard(self, t):
@@ -253,6 +261,8 @@ class DataParallel(Singular):
         assert self.comm.world_size() == self.num_gpus, \
             'one process per GPU: launch with torch.distributed.run --nproc-per-node %d' % self.num_gpus
         self._setup(inputs)
+        if hasattr(self.model, 'center_comm'):
+            self.model.center_comm = self.comm if self.sync_centers else None
         num_classes = inputs['num_classes']
         self._global_batch = inputs.get('batch_size')
         scope = 'TOWER_%d' % self.comm.rank()

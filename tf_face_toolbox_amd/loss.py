@@ -43,7 +43,7 @@ def center_loss(features, labels, num_classes, alpha=0.99, weight=1.0, centers=N
     rows = torch.empty(n, dtype=torch.float32, device=features.device)
     df = torch.empty_like(features)
     ws = torch.empty(max(n * d, 1024) + 1024, dtype=torch.float32, device=features.device)
-    _lib.call('fte_center_loss_fwd_bwd_update', features, labels, centers, rows, df, n, d, float(alpha),
+    _lib.call('fte_center_loss_fwd_bwd_update', features, labels, centers, rows, df, n, d, int(centers.shape[0]), float(alpha),
               float(weight) / (n * d), ws, ws.numel() * 4, _stream())
     return rows.sum() / (n * d), centers, df
 

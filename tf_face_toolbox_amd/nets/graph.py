@@ -93,6 +93,7 @@ class GraphNet(Network):
         self.center_weight = 0.0          # 'softmax+center': total loss = CE + center_weight * center_loss
         self.center_alpha = 0.99          # loss.py:29 default
         self.update_centers = True        # False: the loss is evaluated without running centers_update_op (loss.py:39,43 returns it to the caller)
+        self.center_comm = None           # set by DataParallel(sync_centers=True): all-gather the scatter rows, one table for all replicas
         self.triplet_margin = None        # 'triplet': None = soft-margin (softplus), loss.py:47
         self.focal_gamma, self.focal_alpha = 1.0, 2.0     # 'focal': loss.py:18 defaults (names as in the reference)
 
@@ -327,6 +328,19 @@ class GraphNet(Network):
                 put(out, ih, iw, real[op[2]] + real[op[3]])
             else:
                 raise ValueError(kind)
+        # A tensor stored narrower than channel_pad (the 32-wide stem) may only feed ops that take their width from the stored
+        # input: BN / ReLU / max-pool, the channel gathers, and a 1x1 conv (which reads a valid row prefix).  A 3x3, grouped or
+        # depthwise conv, an SE gate or an add would lay out its weights / output for pc(real) channels while the kernel is
+        # launched with the stored width -- a silent wrong stride.  No net of the factory does that; a new one must not.
+        narrow_stored = {n for n in shp if n != 'images' and len(shp[n]) == 3 and shp[n][2] != pc(real[n])}
+        for op in self.graph:
+            ins = [a for a in op[2:] if isinstance(a, str) and a in narrow_stored]
+            if not ins:
+                continue
+            ok = op[0] in ('bn', 'relu', 'maxpool', 'split', 'shufsplit', 'shufcat', 'dropout') or \
+                (op[0] == 'conv' and self.spec[op[3]][0][0] == 1)
+            assert ok, 'op %r consumes %s, which is stored %d channels wide (not %d): unsupported consumer of the narrow stem' % (
+                op, ins[0], shp[ins[0]][2], pc(real[ins[0]]))
         self.shapes = shp
         self.real_c = real
 
@@ -696,6 +710,13 @@ class GraphNet(Network):
         self._run_forward(inputs, is_training)
         return self.t[self.feature_name]
 
+    def eval_features(self, images):
+        """The extractor's output for these nets (evaluate.py): the pooled backbone features in inference mode (BN on the
+        moving statistics, no dropout).  The reference's ResNet.forward asserts num_classes even for is_training=False
+        (nets/resnet.py:147), so its evaluate.py:63 only ever worked for SphereNet; this is what that call was after."""
+        assert self.built, 'build() / restore the variables first'
+        return self.backbone(images, is_training=False)
+
     def forward(self, images, num_classes=None, is_training=True):
         assert num_classes is not None, 'num_classes must be given when is_training=True'   # nets/resnet.py:147
         self._ensure_built(images, num_classes)
@@ -711,6 +732,22 @@ class GraphNet(Network):
             d = self.shapes[self.feature_name][0]
             self.state['centers'] = torch.zeros(self.num_classes, d, dtype=torch.float32, device=self.device)
         return self.state['centers']
+
+    def _reconcile_centers(self, comm, labels, n, d):
+        """Opt-in (DataParallel(sync_centers=True)): one `centers` table for all replicas.  The reference creates the table inside
+        every tower's variable scope and each tower scatter_subs only ITS shard (loss.py:34-39), so its replicas drift apart
+        silently (SURVEY.md 8e caveat).  Here every rank has evaluated loss and gradient against the OLD table without touching it;
+        the ranks all-gather their (labels, f - c_y) rows -- n x (d + 1) words per rank, the sparse rows only, never the table --
+        and each applies ALL rows in rank order with the deterministic scatter kernel: tables stay bit-identical across replicas and
+        equal the single-tower update of the GLOBAL batch."""
+        world = comm.world_size()
+        diff = self.ws[:n * d]
+        all_diff = torch.empty(world * n * d, dtype=torch.float32, device=self.device)
+        all_lab = torch.empty(world * n, dtype=torch.int32, device=self.device)
+        comm.all_gather(all_diff, diff)
+        comm.all_gather(all_lab, labels)
+        _lib.call('fte_center_scatter_update', all_diff, all_lab, self._centers(), world * n, d, self.num_classes,
+                  self.center_alpha, _stream())
 
     def loss_function(self, scope, labels, **logits):
         """nets/resnet.py:163-176 + Network._regularize; the center / triplet terms are loss.py's functions wired to
@@ -743,9 +780,12 @@ class GraphNet(Network):
             call('fte_sum', self.loss_rows, n, self.tower_scale / n, slots[0:1], self.ws, self.ws_bytes, st)
             losses.append(slots[0]); names.append('focal_entropy' if self.head == 'focal' else 'cross_entropy')
             if self.head == 'softmax+center':
-                call('fte_center_loss_fwd_bwd_update', feat, labels, self._centers(), self.loss_rows, self.dfeat, n, d,
-                     self.center_alpha if self.update_centers else 1.0,      # alpha = 1: centers += 0 * diff
+                comm = self.center_comm if self.update_centers else None
+                call('fte_center_loss_fwd_bwd_update', feat, labels, self._centers(), self.loss_rows, self.dfeat, n, d, self.num_classes,
+                     self.center_alpha if (self.update_centers and comm is None) else 1.0,      # alpha = 1: loss + gradient only
                      self.center_weight * self.tower_scale / (n * d), self.ws, self.ws_bytes, st)
+                if comm is not None:
+                    self._reconcile_centers(comm, labels, n, d)
                 call('fte_sum', self.loss_rows, n, self.tower_scale / (n * d), slots[2:3], self.ws, self.ws_bytes, st)
                 self._dfeat = self.dfeat
                 losses.append(slots[2]); names.append('center_loss')

@@ -55,6 +55,10 @@ def build_parser():
     # Not in the reference
     parser.add_argument('--synthetic', type=int, default=0, help='1: resident random batch instead of a list file.')
     parser.add_argument('--synthetic_classes', type=int, default=10575)
+    parser.add_argument('--sync_centers', type=int, default=0,
+                        help='center-loss nets under --num_gpus > 1.  0 (default) = the reference: every replica keeps and updates its own '
+                             '`centers` table from its own shard (loss.py:34-39) and the tables drift apart; 1 = the replicas all-gather '
+                             "each step's scatter rows and keep ONE table, equal to the single-tower update of the global batch.")
     parser.add_argument('--max_steps', type=int, default=-1, help='Stop after this many steps (smoke runs).')
     parser.add_argument('--mfma_dtype', type=str, default='f32',
                         help='f32 (the reference arithmetic) or bf16 (bf16 MFMA operands, fp32 accumulate and storage).')
@@ -157,63 +161,77 @@ def train(FLAGS):
                               crop_height=FLAGS.crop_height, crop_width=FLAGS.crop_width, is_color=FLAGS.is_color,
                               augmentation=FLAGS.augmentation, batch_size=FLAGS.batch_size, num_classes=FLAGS.num_classes,
                               num_per_class=FLAGS.num_per_class, device=device, seed=1234, rank=rank, world_size=world)
-    batches_per_epoch = inputs['num_examples'] // batch_size + 1                                  # train.py:172
-    network = net_select(FLAGS.net_name, FLAGS.data_format, FLAGS.weight_decay)                  # train.py:174
-    lr = lr_config(FLAGS, FLAGS.lr_decay_method, batches_per_epoch)                              # train.py:176
-    if FLAGS.num_gpus > 1:                                                                        # train.py:178-183
-        model = DataParallel_margin(network, lr, optimizer=FLAGS.optimizer, weight_decay=FLAGS.weight_decay, num_gpus=FLAGS.num_gpus)
-    else:
-        model = Singular(network, lr, optimizer=FLAGS.optimizer, weight_decay=FLAGS.weight_decay)
-    train_ops, losses, losses_name, others = model(inputs)
+    try:
+        batches_per_epoch = inputs['num_examples'] // batch_size + 1                                  # train.py:172
+        network = net_select(FLAGS.net_name, FLAGS.data_format, FLAGS.weight_decay)                  # train.py:174
+        lr = lr_config(FLAGS, FLAGS.lr_decay_method, batches_per_epoch)                              # train.py:176
+        if FLAGS.num_gpus > 1:                                                                        # train.py:178-183
+            model = DataParallel_margin(network, lr, optimizer=FLAGS.optimizer, weight_decay=FLAGS.weight_decay, num_gpus=FLAGS.num_gpus,
+                                        sync_centers=bool(FLAGS.sync_centers))
+        else:
+            model = Singular(network, lr, optimizer=FLAGS.optimizer, weight_decay=FLAGS.weight_decay)
+        train_ops, losses, losses_name, others = model(inputs)
 
-    tag = FLAGS.net_name + '_' + FLAGS.model_name
-    ckpt_dir = os.path.join(FLAGS.model_dir, tag)
-    latest = saver.latest_checkpoint(ckpt_dir)                                                    # train.py:207-215
-    if latest:
-        model.global_step = saver.restore(network, latest, optimizer=model._opt)
-        print('Model restored from %s' % ckpt_dir)
-    elif FLAGS.pretrained_path != '':
-        saver.restore(network, FLAGS.pretrained_path, only=model.pretrained_param)
-        print('Network parameters initialized from %s' % FLAGS.pretrained_path)
-    else:
-        print('Network parameters initialized from scratch.')
-    if world > 1:
-        model.comm.broadcast(network.params, src=0)
+        tag = FLAGS.net_name + '_' + FLAGS.model_name
+        ckpt_dir = os.path.join(FLAGS.model_dir, tag)
+        latest = saver.latest_checkpoint(ckpt_dir)                                                    # train.py:207-215
+        if latest:
+            model.global_step = saver.restore(network, latest, optimizer=model._opt)
+            print('Model restored from %s' % ckpt_dir)
+        elif FLAGS.pretrained_path != '':
+            saver.restore(network, FLAGS.pretrained_path, only=model.pretrained_param)
+            print('Network parameters initialized from %s' % FLAGS.pretrained_path)
+        else:
+            print('Network parameters initialized from scratch.')
+        if world > 1:
+            model.comm.broadcast(network.params, src=0)
 
-    print('%s training start...' % tag)
-    step, epoch = 0, 1
-    time_sim, image_sim = 0.0, 0.0
-    while epoch <= FLAGS.max_epoches:                                                             # train.py:223-250
-        step = model.global_step
-        epoch = step // batches_per_epoch + 1
-        start_time = time.time()
-        train_ops()
-        losses_value = [float(l) for l in losses]            # reading the losses synchronises, like sess.run
-        duration = time.time() - start_time
-        if not all(math.isfinite(v) for v in losses_value):
-            raise SystemExit('Model diverged with losses = %s' % losses_value)
-        if step % FLAGS.display_interval == 0 and rank == 0:
-            format_list = [datetime.now(), epoch, step, model.learning_rate]
-            for loss_value in losses_value:
-                format_list.extend([datetime.now(), loss_value])
-            format_list.extend([datetime.now(), duration * 1000, batch_size / duration])
-            print(format_str(losses_name) % tuple(format_list))
-            for other_name, other_value in others.items():
-                print('%s: %s' % (other_name, other_value))
-        if step > 0:
-            time_sim += duration
-            image_sim += batch_size / duration
-        last = step == FLAGS.max_epoches * batches_per_epoch or (FLAGS.max_steps > 0 and step + 1 >= FLAGS.max_steps)
-        if ((step > 0 and step % FLAGS.save_interval == 0) or last) and rank == 0:
-            path = saver.save(network, model._opt.slots, model.global_step, os.path.join(ckpt_dir, tag + '.ckpt'))
-            print('[%s]: Model has been saved in Iteration %d (%s)' % (datetime.now(), step, path))
-        if FLAGS.max_steps > 0 and step + 1 >= FLAGS.max_steps:
-            break
-    if rank == 0 and step > 0:
-        print('mean batch_time=%.2f, mean throughput=%.2f' % (time_sim / step * 1000, image_sim / step))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        print('%s training start...' % tag)
+        step, epoch = 0, 1
+        time_sim, image_sim = 0.0, 0.0
+        while epoch <= FLAGS.max_epoches:                                                             # train.py:223-250
+            step = model.global_step
+            epoch = step // batches_per_epoch + 1
+            start_time = time.time()
+            train_ops()
+            losses_value = [float(l) for l in losses]            # reading the losses synchronises, like sess.run
+            duration = time.time() - start_time
+            if not all(math.isfinite(v) for v in losses_value):
+                raise SystemExit('Model diverged with losses = %s' % losses_value)
+            if step % FLAGS.display_interval == 0 and rank == 0:
+                format_list = [datetime.now(), epoch, step, model.learning_rate]
+                for loss_value in losses_value:
+                    format_list.extend([datetime.now(), loss_value])
+                format_list.extend([datetime.now(), duration * 1000, batch_size / duration])
+                print(format_str(losses_name) % tuple(format_list))
+                for other_name, other_value in others.items():
+                    print('%s: %s' % (other_name, other_value))
+            if step > 0:
+                time_sim += duration
+                image_sim += batch_size / duration
+            last = step == FLAGS.max_epoches * batches_per_epoch or (FLAGS.max_steps > 0 and step + 1 >= FLAGS.max_steps)
+            if ((step > 0 and step % FLAGS.save_interval == 0) or last) and rank == 0:
+                path = saver.save(network, model._opt.slots, model.global_step, os.path.join(ckpt_dir, tag + '.ckpt'))
+                print('[%s]: Model has been saved in Iteration %d (%s)' % (datetime.now(), step, path))
+            if FLAGS.max_steps > 0 and step + 1 >= FLAGS.max_steps:
+                break
+        if rank == 0 and step > 0:
+            print('mean batch_time=%.2f, mean throughput=%.2f' % (time_sim / step * 1000, image_sim / step))
+        if world > 1:
+            dist.barrier()
+    finally:
+        # orderly shutdown, whatever happened above: stop the input pipeline's producer thread and wait for it, end the decode
+        # workers and release their shared buffers, drain the device, leave the process group
+        close = inputs.get('close')
+        if close is not None and not close():
+            print('train.py: the input pipeline thread did not stop', file=sys.stderr)
+            FLAGS._shutdown_failed = True
+        try:
+            torch.cuda.synchronize()
+        except Exception as e:                 # a device fault is what brought us here: report it, keep the original error
+            print('train.py: device synchronise failed during shutdown: %s' % e, file=sys.stderr)
+        if world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def main(argv=None):
@@ -222,12 +240,43 @@ def main(argv=None):
     os.makedirs(os.path.join(FLAGS.train_dir, FLAGS.net_name + '_' + FLAGS.model_name), exist_ok=True)
     os.makedirs(os.path.join(FLAGS.model_dir, FLAGS.net_name + '_' + FLAGS.model_name), exist_ok=True)
     train(FLAGS)
+    return FLAGS
+
+
+def _run_and_leave(fn):
+    """Runs the program and leaves with ITS status.  By the time fn() returns or raises, everything this program started has been
+    shut down in order (train()'s finally block: producer thread joined, decode workers reaped, device drained, process group
+    destroyed), so nothing of ours can still fail.  What remains is interpreter / HIP runtime teardown, where ROCm 7 occasionally
+    ends a finished process with std::terminate (exit code -6: torch's helper threads race the runtime's static destructors).
+    Only when the GPU runtime was initialised, os._exit skips that teardown -- with the real status (a failure stays a failure;
+    round 2 left with an unconditional 0)."""
+    import traceback
+    status = 0
+    try:
+        status = 1 if getattr(fn(), '_shutdown_failed', False) else 0
+    except SystemExit as e:
+        if e.code is None or e.code == 0:
+            status = 0
+        elif isinstance(e.code, int):
+            status = e.code
+        else:
+            print(e.code, file=sys.stderr)
+            status = 1
+    except BaseException:                      # noqa: B902
+        traceback.print_exc()
+        status = 1
+    sys.stdout.flush()
+    sys.stderr.flush()
+    gpu_up = False
+    try:
+        import torch
+        gpu_up = torch.cuda.is_initialized()
+    except Exception:
+        pass
+    if gpu_up:
+        os._exit(status)
+    sys.exit(status)
 
 
 if __name__ == '__main__':
-    main()
-    # leave without running interpreter / HIP runtime teardown: on ROCm 7 an exit-time race between torch's helper
-    # threads and the runtime's static destructors occasionally ends a finished run with std::terminate (exit code -6)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    _run_and_leave(main)
