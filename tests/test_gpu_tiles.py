@@ -54,7 +54,7 @@ def test_wgrad_192x64_natural_and_256_way_split():
 def test_wgrad_128x128_natural_many_splits():
     """stages 2 and 3: 128x128 filter-gradient tile with ~85-170 splits (28x28x128->128: nine tiles), plus the stride-2 entry conv
     of stage 2 (56x56x64 -> 28x28x128, M = 576 on the 128x128 tile: 4.5 tiles, ragged M) and a 14x14x256 layer (42 splits in the headline)."""
-    cs = _run([['wgrad', 112, 28, 28, 128, 128, 1], ['wgrad', 120, 56, 56, 64, 128, 2], ['wgrad', 160, 14, 14, 256, 256, 1]])
+    cs = _run([['wgrad', 384, 28, 28, 128, 128, 1], ['wgrad', 384, 56, 56, 64, 128, 2], ['wgrad', 384, 14, 14, 256, 256, 1]])
     for c in cs:
         _has(c, 'igemm_kernel<128,128,2,2,1,0,0,0>')
     assert max(cs[0]['splits']) >= 80 and max(cs[1]['splits']) >= 80, (cs[0]['splits'], cs[1]['splits'])
@@ -80,11 +80,13 @@ def test_default_64x64_fwd_dgrad_at_many_rounds():
     """stages 3 and 4 stay on the 64x64 tile; sizes with several rounds of blocks and a ragged last round, and the stride-2 data
     gradient's four parity classes as separate launches (>= one round of tiles per class)."""
     cs = _run([['fwd', 130, 14, 14, 256, 256, 1], ['dgrad', 130, 14, 14, 256, 256, 1], ['dgrad', 256, 28, 28, 128, 256, 2],
-               ['fwd', 200, 7, 7, 512, 512, 1], ['dgrad', 200, 7, 7, 512, 512, 1]])
+               ['fwd', 256, 7, 7, 512, 512, 1], ['dgrad', 256, 7, 7, 512, 512, 1]])
     _has(cs[0], 'igemm_kernel<64,64,2,2,0,0,0,0>')
     _has(cs[1], 'igemm_kernel<64,64,2,2,0,1,1,0>')
     _has(cs[2], 'igemm_kernel<64,64,2,2,0,1,1,0>')
     assert len(cs[2]['splits']) == 4, cs[2]           # four class launches
+    _has(cs[3], 'igemm_kernel<64,64,2,2,0,0,0,0>')
+    _has(cs[4], 'igemm_kernel<64,64,2,2,0,1,1,0>')
 
 
 @pytest.mark.parametrize('split_major', ['1', '0'])

@@ -27,6 +27,87 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
     n = tot;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// In-launch finalize of the split reductions (BN statistics, BN backward sums): instead of a second, 7-8 us launch that merges
+// the row splits (112 of ShuffleNet-v2's 688 launches per step were those), the blocks of a channel column hand their partials
+// over inside the launch.  Two levels so that no block reads more than a few tens of KB: the splits of a column form groups of
+// GROUP consecutive splits; the LAST block of a group to arrive merges the group's partials (in split order, whoever arrives
+// last: deterministic) into a group partial; the last GROUP-merger of the column merges those and finalizes.  Hand-off =
+// the counter form of the programming guide's Guideline 16: plain stores -> every wave s_waitcnt vmcnt(0) -> barrier -> one
+// lane: agent-scope release fence, wait, relaxed agent-scope fetch_add on the arrival counter; the block that draws the last
+// ticket: agent-scope acquire fence, wait, barrier, plain loads.  Placement-independent (any XCD / CU).  Counters come from a
+// per-device ring that is zero when a launch starts; the last arriver puts its counter back to zero.
+// ---------------------------------------------------------------------------------------------------
+constexpr int TAIL_GROUP = 16;
+struct SplitTail {
+    unsigned* cnt;      // [columns][1 + groups] arrival counters of THIS launch; NULL: no in-launch finalize
+    float* part2;       // group partials
+    int splits, groups;
+};
+__device__ __forceinline__ bool last_arriver(unsigned* cnt, unsigned expected, volatile unsigned* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // every wave's partial stores have left; `flag`'s LDS is free
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t + 1 == expected;
+        if (last) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the ring slot's next user finds zero
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *flag != 0u;
+}
+// (n, mean, M2) partials [s][3][C] of `cnt` splits merged as plain sums around the first one's mean (see bn_finalize_kernel)
+__device__ __forceinline__ void stat_merge(const float* __restrict__ p, int cnt, int C, int ch, float& N, float& mean, float& M2) {
+    const float m0 = p[C + ch];
+    float n = 0.f, d1 = 0.f, q = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < cnt; ++s) {
+        const float* pp = p + (long)s * 3 * C;
+        const float nb = pp[ch], d = pp[C + ch] - m0;
+        n += nb;
+        d1 += nb * d;
+        q += pp[2 * C + ch] + nb * d * d;
+    }
+    N = n;
+    mean = n > 0.f ? m0 + d1 / n : m0;
+    M2 = n > 0.f ? fmaxf(q - d1 * d1 / n, 0.f) : 0.f;
+}
+struct BnFwdOut {
+    const float* gamma; const float* beta; float eps, decay;
+    float* mean; float* rstd; float* scale; float* shift; float* mov_mean; float* mov_var;
+};
+__device__ __forceinline__ void bn_finalize_channel(const BnFwdOut& o, int ch, float N, float mean, float m2) {
+    const float var = m2 / N;
+    const float rstd = 1.f / sqrtf(var + o.eps);
+    o.mean[ch] = mean;
+    o.rstd[ch] = rstd;
+    const float sc = o.gamma[ch] * rstd;
+    o.scale[ch] = sc;
+    o.shift[ch] = o.beta[ch] - mean * sc;
+    if (o.mov_mean) {
+        o.mov_mean[ch] = o.decay * o.mov_mean[ch] + (1.f - o.decay) * mean;
+        o.mov_var[ch] = o.decay * o.mov_var[ch] + (1.f - o.decay) * (m2 / fmaxf(N - 1.f, 1.f));
+    }
+}
+struct BnBwdOut {
+    float count; const float* gamma; const float* mean; const float* rstd; float* dgamma; float* dbeta; float* coef;
+};
+__device__ __forceinline__ void bn_bwd_finalize_channel(const BnBwdOut& o, int C, int ch, float sg, float sgx) {
+    o.dbeta[ch] = sg;
+    o.dgamma[ch] = sgx;
+    const float gr = o.gamma[ch] * o.rstd[ch];
+    const float b = -gr * o.rstd[ch] * sgx / o.count;
+    o.coef[ch] = gr;
+    o.coef[C + ch] = b;
+    o.coef[2 * C + ch] = -gr * sg / o.count - b * o.mean[ch];
+}
+
 // i = ((img*H + b)*W + a)*C4 + c4  ->  (c4, a, b, img).  Every tensor here has fewer than 2^32 16-byte units, and those indices
 // are decomposed with 32-bit unsigned arithmetic: a 64-bit division by a run-time value is ~100 instructions, and the
 // grid-stride loops below did up to six of them per 16 bytes of output (`small` is uniform: total <= 0xffffffff).
@@ -91,7 +172,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // 1 KiB (C >= 256) or several whole rows per instruction, two rows in flight per lane.
 template <int Q>
 __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restrict__ x, float* __restrict__ part,
-                                                          long rows, int C, long rows_per_split) {
+                                                          long rows, int C, long rows_per_split, SplitTail tail, BnFwdOut fin) {
     constexpr int RL = 256 / Q;
     __shared__ f32x4 sh[3][RL][Q];
     const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -129,6 +210,26 @@ __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restric
             pp[ch + e] = nn; pp[C + ch + e] = mm; pp[2 * C + ch + e] = m22 < 0.f ? 0.f : m22;
         }
     }
+    if (!tail.cnt) return;                                   // the splits are merged by bn_finalize_kernel
+    // ---- in-launch finalize: thread t of the column's last block owns channel col*4Q + t
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(&sh[0][0][0]);
+    unsigned* cnt = tail.cnt + blockIdx.x * (tail.groups + 1);
+    const int g = blockIdx.y / TAIL_GROUP, s0 = g * TAIL_GROUP;
+    const int gcount = min(TAIL_GROUP, tail.splits - s0);
+    if (!last_arriver(cnt + 1 + g, (unsigned)gcount, flag)) return;
+    const int fch = blockIdx.x * Q * 4 + threadIdx.x;
+    const bool fok = threadIdx.x < Q * 4 && fch < C;
+    float N = 0.f, mean = 0.f, M2 = 0.f;
+    if (fok) stat_merge(part + (long)s0 * 3 * C, gcount, C, fch, N, mean, M2);
+    if (tail.groups > 1) {
+        if (fok) {
+            float* p2 = tail.part2 + (long)g * 3 * C;
+            p2[fch] = N; p2[C + fch] = mean; p2[2 * C + fch] = M2;
+        }
+        if (!last_arriver(cnt, (unsigned)tail.groups, flag)) return;
+        if (fok) stat_merge(tail.part2, tail.groups, C, fch, N, mean, M2);
+    }
+    if (fok) bn_finalize_channel(fin, fch, N, mean, M2);
 }
 
 template <int Q>
@@ -136,7 +237,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
                                                                const float* __restrict__ z, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ zsc,
                                                                const float* __restrict__ zsf, float* __restrict__ gout,
-                                                               float* __restrict__ part, long rows, int C, long rows_per_split) {
+                                                               float* __restrict__ part, long rows, int C, long rows_per_split,
+                                                               SplitTail tail, BnBwdOut fin) {
     constexpr int RL = 256 / Q;
     __shared__ f32x4 sh[2][RL][Q];
     const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
@@ -177,6 +279,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) { pp[ch + e] = a[e]; pp[C + ch + e] = b[e]; }
     }
+    if (!tail.cnt) return;                                   // the splits are summed by bn_bwd_finalize_kernel
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(&sh[0][0][0]);
+    unsigned* cnt = tail.cnt + blockIdx.x * (tail.groups + 1);
+    const int g = blockIdx.y / TAIL_GROUP, s0 = g * TAIL_GROUP;
+    const int gcount = min(TAIL_GROUP, tail.splits - s0);
+    if (!last_arriver(cnt + 1 + g, (unsigned)gcount, flag)) return;
+    const int fch = blockIdx.x * Q * 4 + threadIdx.x;
+    const bool fok = threadIdx.x < Q * 4 && fch < C;
+    float a = 0.f, b = 0.f;
+    if (fok) {
+#pragma unroll 4
+        for (int s = 0; s < gcount; ++s) { const float* pp = part + (long)(s0 + s) * 2 * C; a += pp[fch]; b += pp[C + fch]; }
+    }
+    if (tail.groups > 1) {
+        if (fok) { float* p2 = tail.part2 + (long)g * 2 * C; p2[fch] = a; p2[C + fch] = b; }
+        if (!last_arriver(cnt, (unsigned)tail.groups, flag)) return;
+        if (fok) {
+            a = 0.f; b = 0.f;
+#pragma unroll 4
+            for (int s = 0; s < tail.groups; ++s) { const float* pp = tail.part2 + (long)s * 2 * C; a += pp[fch]; b += pp[C + fch]; }
+        }
+    }
+    if (fok) bn_bwd_finalize_channel(fin, C, fch, a, b);
 }
 
 // merge the splits; scale = gamma*rstd, shift = beta - mean*scale; moving statistics (decay, unbiased var).
