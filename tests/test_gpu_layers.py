@@ -212,3 +212,16 @@ def test_residual_bn_backward_writes_the_masked_gradient_as_a_by_product(rows, c
     g1 = torch.full_like(z, 7.0); dz1 = torch.empty_like(z); dg1 = torch.empty(c, device='cuda'); db1 = torch.empty(c, device='cuda')
     call('fte_bn_train_bwd_res', dy, y, z, gamma, mean, rstd, g1, dz1, dg1, db1, rows, c, buf, nb, stream())
     assert torch.equal(g0, g1) and torch.equal(dz0, dz1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+
+
+def test_batch_norm_with_the_in_launch_finalize_option():
+    """FTE_BN_TAIL=1 (off by default: measured no faster, csrc/layers.hip ticket_slot): the BN statistics / backward sums are merged
+    inside the producing launch by its last-arriving blocks (arrival tickets, write-through partials) instead of by a second
+    launch.  Same oracle, same tolerances -- the batch-norm cases of this file re-run in a child process with the option on (the hook
+    is read once per process)."""
+    import os, subprocess, sys
+    env = dict(os.environ, FTE_BN_TAIL='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'batch_norm and not in_launch',
+                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -813,7 +813,8 @@ int fte_adam_update(float* w, float* m, float* v, const float* g, long n, float 
 
 // ------------------------------------------------------------------------------------------------
 // layers of the BN / pooling nets
-size_t fte_bn_ws_bytes(int c) { return ((size_t)BN_MAX_SPLITS * 3 * c + 3 * (size_t)c) * sizeof(float); }
+// split partials (3 per channel: n, mean, M2) + the group partials of the in-launch finalize (one per 16 splits) + the backward coefficients
+size_t fte_bn_ws_bytes(int c) { return ((size_t)BN_MAX_SPLITS * 3 * c + (size_t)(BN_MAX_SPLITS / 16) * 3 * c + 3 * (size_t)c) * sizeof(float); }
 
 int fte_bn_train_fwd(const float* z, const float* gamma, const float* beta, const float* res, float* y,
                      float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,

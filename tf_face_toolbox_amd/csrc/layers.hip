@@ -5,6 +5,7 @@
 // through 16-byte coalesced accesses.  All reductions are ordered (two-level, no float atomics).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "layers.h"
 
@@ -33,10 +34,12 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 // over inside the launch.  Two levels so that no block reads more than a few tens of KB: the splits of a column form groups of
 // GROUP consecutive splits; the LAST block of a group to arrive merges the group's partials (in split order, whoever arrives
 // last: deterministic) into a group partial; the last GROUP-merger of the column merges those and finalizes.  Hand-off =
-// the counter form of the programming guide's Guideline 16: plain stores -> every wave s_waitcnt vmcnt(0) -> barrier -> one
-// lane: agent-scope release fence, wait, relaxed agent-scope fetch_add on the arrival counter; the block that draws the last
-// ticket: agent-scope acquire fence, wait, barrier, plain loads.  Placement-independent (any XCD / CU).  Counters come from a
-// per-device ring that is zero when a launch starts; the last arriver puts its counter back to zero.
+// the write-through form of the programming guide's Guideline 16 (R1): every partial word is stored sc1 (relaxed agent-scope
+// atomic store: straight to memory, no release fence -- a release fence in each of ~2000 blocks, tried first, made the step
+// 12 % SLOWER than the separate launch) -> every wave s_waitcnt vmcnt(0) -> barrier -> one lane: relaxed agent-scope fetch_add
+// on the arrival counter; the block that draws the last ticket reads EVERY partial word with sc1 loads (relaxed agent-scope
+// atomic loads: past its L1, which may hold stale lines of a reused workspace).  Placement-independent (any XCD / CU).
+// Counters come from a per-device ring that is zero when a launch starts; the last arriver puts its counter back to zero.
 // ---------------------------------------------------------------------------------------------------
 constexpr int TAIL_GROUP = 16;
 struct SplitTail {
@@ -48,31 +51,30 @@ __device__ __forceinline__ bool last_arriver(unsigned* cnt, unsigned expected, v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // every wave's partial stores have left; `flag`'s LDS is free
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool last = t + 1 == expected;
-        if (last) {
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the ring slot's next user finds zero
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the ring slot's next user finds zero
         *flag = last ? 1u : 0u;
     }
     __syncthreads();
-    return *flag != 0u;
+    const bool last = *flag != 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the compiler from hoisting the partial loads
+    return last;
 }
+// a word handed to another block inside the launch: write-through store / L1-bypassing load
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // (n, mean, M2) partials [s][3][C] of `cnt` splits merged as plain sums around the first one's mean (see bn_finalize_kernel)
-__device__ __forceinline__ void stat_merge(const float* __restrict__ p, int cnt, int C, int ch, float& N, float& mean, float& M2) {
-    const float m0 = p[C + ch];
+__device__ __forceinline__ void stat_merge(const float* p, int cnt, int C, int ch, float& N, float& mean, float& M2) {
+    const float m0 = ld_wt(p + C + ch);
     float n = 0.f, d1 = 0.f, q = 0.f;
 #pragma unroll 4
     for (int s = 0; s < cnt; ++s) {
         const float* pp = p + (long)s * 3 * C;
-        const float nb = pp[ch], d = pp[C + ch] - m0;
+        const float nb = ld_wt(pp + ch), d = ld_wt(pp + C + ch) - m0;
         n += nb;
         d1 += nb * d;
-        q += pp[2 * C + ch] + nb * d * d;
+        q += ld_wt(pp + 2 * C + ch) + nb * d * d;
     }
     N = n;
     mean = n > 0.f ? m0 + d1 / n : m0;
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restric
         for (int e = 0; e < 4; ++e) {
             float nn = n[e], mm = mean[e], m22 = m2[e];
             for (int l = 1; l < RL; ++l) chan_merge(nn, mm, m22, sh[0][l][q][e], sh[1][l][q][e], sh[2][l][q][e]);
-            pp[ch + e] = nn; pp[C + ch + e] = mm; pp[2 * C + ch + e] = m22 < 0.f ? 0.f : m22;
+            m22 = m22 < 0.f ? 0.f : m22;
+            if (tail.cnt) { st_wt(pp + ch + e, nn); st_wt(pp + C + ch + e, mm); st_wt(pp + 2 * C + ch + e, m22); }
+            else { pp[ch + e] = nn; pp[C + ch + e] = mm; pp[2 * C + ch + e] = m22; }
         }
     }
     if (!tail.cnt) return;                                   // the splits are merged by bn_finalize_kernel
@@ -219,17 +223,17 @@ __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restric
     if (!last_arriver(cnt + 1 + g, (unsigned)gcount, flag)) return;
     const int fch = blockIdx.x * Q * 4 + threadIdx.x;
     const bool fok = threadIdx.x < Q * 4 && fch < C;
-    float N = 0.f, mean = 0.f, M2 = 0.f;
-    if (fok) stat_merge(part + (long)s0 * 3 * C, gcount, C, fch, N, mean, M2);
+    float fN = 0.f, fmean = 0.f, fM2 = 0.f;
+    if (fok) stat_merge(part + (long)s0 * 3 * C, gcount, C, fch, fN, fmean, fM2);
     if (tail.groups > 1) {
         if (fok) {
             float* p2 = tail.part2 + (long)g * 3 * C;
-            p2[fch] = N; p2[C + fch] = mean; p2[2 * C + fch] = M2;
+            st_wt(p2 + fch, fN); st_wt(p2 + C + fch, fmean); st_wt(p2 + 2 * C + fch, fM2);
         }
         if (!last_arriver(cnt, (unsigned)tail.groups, flag)) return;
-        if (fok) stat_merge(tail.part2, tail.groups, C, fch, N, mean, M2);
+        if (fok) stat_merge(tail.part2, tail.groups, C, fch, fN, fmean, fM2);
     }
-    if (fok) bn_finalize_channel(fin, fch, N, mean, M2);
+    if (fok) bn_finalize_channel(fin, fch, fN, fmean, fM2);
 }
 
 template <int Q>
@@ -277,7 +281,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
         f32x4 a = sg, b = sgx;
         for (int l = 1; l < RL; ++l) { a += sh[0][l][q]; b += sh[1][l][q]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { pp[ch + e] = a[e]; pp[C + ch + e] = b[e]; }
+        for (int e = 0; e < 4; ++e) {
+            if (tail.cnt) { st_wt(pp + ch + e, a[e]); st_wt(pp + C + ch + e, b[e]); }
+            else { pp[ch + e] = a[e]; pp[C + ch + e] = b[e]; }
+        }
     }
     if (!tail.cnt) return;                                   // the splits are summed by bn_bwd_finalize_kernel
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(&sh[0][0][0]);
@@ -290,15 +297,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
     float a = 0.f, b = 0.f;
     if (fok) {
 #pragma unroll 4
-        for (int s = 0; s < gcount; ++s) { const float* pp = part + (long)(s0 + s) * 2 * C; a += pp[fch]; b += pp[C + fch]; }
+        for (int s = 0; s < gcount; ++s) { const float* pp = part + (long)(s0 + s) * 2 * C; a += ld_wt(pp + fch); b += ld_wt(pp + C + fch); }
     }
     if (tail.groups > 1) {
-        if (fok) { float* p2 = tail.part2 + (long)g * 2 * C; p2[fch] = a; p2[C + fch] = b; }
+        if (fok) { float* p2 = tail.part2 + (long)g * 2 * C; st_wt(p2 + fch, a); st_wt(p2 + C + fch, b); }
         if (!last_arriver(cnt, (unsigned)tail.groups, flag)) return;
         if (fok) {
             a = 0.f; b = 0.f;
 #pragma unroll 4
-            for (int s = 0; s < tail.groups; ++s) { const float* pp = tail.part2 + (long)s * 2 * C; a += pp[fch]; b += pp[C + fch]; }
+            for (int s = 0; s < tail.groups; ++s) { const float* pp = tail.part2 + (long)s * 2 * C; a += ld_wt(pp + fch); b += ld_wt(pp + C + fch); }
         }
     }
     if (fok) bn_bwd_finalize_channel(fin, C, fch, a, b);
@@ -720,6 +727,31 @@ inline int grid_for_c(long n4, int C) {
 
 inline int quads_per_block(int C) { return C % 4 ? 0 : (C >= 256 ? 64 : (C >= 128 ? 32 : (C >= 64 ? 16 : (C >= 32 ? 8 : 0)))); }
 
+// arrival counters of the in-launch finalize: a per-device ring of zeroed words; a launch takes the next slot and its last
+// arrivers put every counter they drew the last ticket of back to zero.  2048 slots: a slot is reused 2048 BN launches later.
+constexpr int TICKET_SLOT = 512, TICKET_SLOTS = 2048, TICKET_DEVS = 16;
+unsigned* g_tickets[TICKET_DEVS];
+unsigned g_ticket_pos[TICKET_DEVS];
+unsigned* ticket_slot(int need) {
+    // OFF by default (FTE_BN_TAIL=1 turns it on).  Measured on MI355X, ShuffleNet-v2 x2 step, in-launch finalize vs the separate
+    // 7-8 us finalize launches (112 of 688 launches per step): batch 512 14.30 vs 14.16 ms, batch 256 8.79 vs 8.61 ms, ResNet-50
+    // 39.8 vs 39.7 ms -- the tail's own chain (drain stores, barrier, agent-scope atomic, barrier, two levels of write-through
+    // loads that miss every cache by construction) costs what the kernel boundary (~2 us) plus the small kernel cost, and the
+    // step is not launch-bound at these sizes.  With a release fence per block instead of write-through stores: 15.68 ms.
+    static const bool off = !(getenv("FTE_BN_TAIL") && atoi(getenv("FTE_BN_TAIL")) == 1);
+    int dev = 0;
+    if (off || need > TICKET_SLOT || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TICKET_DEVS) return nullptr;
+    if (!g_tickets[dev]) {
+        unsigned* p = nullptr;
+        const size_t bytes = (size_t)TICKET_SLOT * TICKET_SLOTS * sizeof(unsigned);
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;                 // first BN launch on this device (once, 4 MB)
+        if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        g_tickets[dev] = p;
+    }
+    const unsigned k = g_ticket_pos[dev]++ % TICKET_SLOTS;
+    return g_tickets[dev] + (size_t)k * TICKET_SLOT;
+}
+
 inline void stat_split(long rows, int C, int* splits, long* rps) {
     const int Q = quads_per_block(C);
     const long cb = Q ? (C / 4 + Q - 1) / Q : (C + 63) / 64;
@@ -740,15 +772,20 @@ hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* bet
                             float* part, hipStream_t st) {
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
-    switch (quads_per_block(C)) {
-        case 64: hipLaunchKernelGGL(bn_stats_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
-        case 32: hipLaunchKernelGGL(bn_stats_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
-        case 16: hipLaunchKernelGGL(bn_stats_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
-        case 8: hipLaunchKernelGGL(bn_stats_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, z, part, rows, C, rps); break;
+    const int Q = quads_per_block(C);
+    SplitTail tail = {nullptr, part + (long)splits * 3 * C, splits, (splits + TAIL_GROUP - 1) / TAIL_GROUP};
+    const BnFwdOut fin = {gamma, beta, eps, decay, mean, rstd, scale, shift, mov_mean, mov_var};
+    if (Q) tail.cnt = ticket_slot(((C / 4 + Q - 1) / Q) * (tail.groups + 1));
+    switch (Q) {
+        case 64: hipLaunchKernelGGL(bn_stats_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
+        case 32: hipLaunchKernelGGL(bn_stats_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
+        case 16: hipLaunchKernelGGL(bn_stats_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
+        case 8: hipLaunchKernelGGL(bn_stats_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
         default: hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
-                       mean, rstd, scale, shift, mov_mean, mov_var);
+    if (!tail.cnt)      // scalar-channel layouts (C % 4 != 0, C < 32) and FTE_BN_TAIL=0: the splits are merged by a second launch
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
+                           mean, rstd, scale, shift, mov_mean, mov_var);
     return hipGetLastError();
 }
 hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int C,
@@ -772,15 +809,20 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
     float* coef = part + (long)splits * 2 * C;
-    switch (quads_per_block(C)) {
-        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
-        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
-        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
-        case 8: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps); break;
+    const int Q = quads_per_block(C);
+    SplitTail tail = {nullptr, coef + 3 * (long)C, splits, (splits + TAIL_GROUP - 1) / TAIL_GROUP};
+    const BnBwdOut fin = {(float)rows, gamma, mean, rstd, dgamma, dbeta, coef};
+    if (Q) tail.cnt = ticket_slot(((C / 4 + Q - 1) / Q) * (tail.groups + 1));
+    switch (Q) {
+        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
+        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
+        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
+        case 8: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
         default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps);
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
-                       dgamma, dbeta, coef);
+    if (!tail.cnt)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
+                           dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
     if (gout) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C);
