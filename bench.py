@@ -119,7 +119,7 @@ def cpu_baseline_and_parity(dev, mfma_dtype='f32', min_seconds=10.0, max_steps=1
               'embedding_rell2': rell2(emb_g, emb_c),
               'logits_maxabs': maxabs(log_g, log_c), 'logits_max_ref': float(log_c.abs().max()),
               'logits_rell2': rell2(log_g, log_c),
-              'tolerance': 'max-abs <= %g * max|ref| (%s HIP path vs fp32 CPU path)' % (tol, 'fp32' if mfma_dtype == 'f32' else 'bf16-operand')}
+              'tolerance': 'max-abs <= %g * max|ref| (%s HIP path vs fp32 CPU path)' % (tol, {'f32': 'fp32', 'bf16': 'bf16-operand', 'bf16s': 'bf16-storage'}[mfma_dtype])}
     parity['ok'] = bool(parity['embedding_maxabs'] <= tol * parity['embedding_max_ref'] and
                         parity['logits_maxabs'] <= tol * parity['logits_max_ref'])
     del net
@@ -199,10 +199,12 @@ def latest_traffic_file(dtype='f32'):
     return best[1] if best else None
 
 
-def op_kind(key):
+def op_kind(key, sym=''):
     al, bl, epi = key[:3]
     if al == 1:
         return 'wgrad'                           # A = x^T (k = pixel): filter gradient / dense tn
+    if epi == 0 and bl == 1 and (sym.startswith('igemm16') or sym.endswith(',2>')):
+        return 'fwd'                             # bf16-source forward: the weights are packed [tap][cout][cin] (the NK layout)
     return 'dgrad' if epi == 1 or bl == 1 else 'fwd'
 
 
@@ -214,7 +216,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--global-batch', type=int, default=GLOBAL_BATCH,
                     help='exploration only (e.g. the per-rank shard sizes of N=2/4/8 on one GPU); the metric is quoted at 512')
-    ap.add_argument('--mfma-dtype', choices=['f32', 'bf16'], default='f32',
+    ap.add_argument('--mfma-dtype', choices=['f32', 'bf16', 'bf16s'], default='f32',
                     help="operand precision of the MFMA products (fte_set_mfma_dtype).  The metric (BASELINE.json configs[1]) is "
                          "fp32 = the default; bf16 = bf16 operands, fp32 accumulate, fp32 storage (exploration, configs[2]'s precision)")
     args = ap.parse_args()
@@ -376,9 +378,9 @@ def main():
         table, shapes, kinds = {}, {}, {}
         for sig, fl, ms_, mnk, by, sym in records:
             t = table.setdefault(sym, [0, 0.0, 0.0, 0.0])
-            kinds[sym] = op_kind(sig)
+            kinds[sym] = op_kind(sig, sym)
             t[0] += 1; t[1] += fl; t[2] += ms_; t[3] += by
-            s = shapes.setdefault((op_kind(sig[:4]),) + tuple(mnk) + (sig[3], sig[4]), [0, 0.0, 0.0, 0.0])
+            s = shapes.setdefault((op_kind(sig, sym),) + tuple(mnk) + (sig[3], sig[4]), [0, 0.0, 0.0, 0.0])
             s[0] += 1; s[1] += fl; s[2] += ms_; s[3] += by
         DOM = max(table, key=lambda k: table[k][2])              # the symbol with the most device time
         cnt, dom_flops, dom_ms, dom_bytes = table[DOM]
@@ -419,7 +421,7 @@ def main():
             'vs_baseline': None,
             'dtype': args.mfma_dtype,
             'data': 'synthetic',
-            'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch %d, 10575 classes, Momentum, %s' % (gb, 'fp32' if args.mfma_dtype == 'f32' else 'bf16 MFMA operands / fp32 accumulate + storage'),
+            'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch %d, 10575 classes, Momentum, %s' % (gb, {'f32': 'fp32', 'bf16': 'bf16 MFMA operands / fp32 accumulate + storage', 'bf16s': 'bf16 MFMA operands + bf16 storage of activations and inter-layer gradients / fp32 accumulate, sums, master weights'}[args.mfma_dtype]),
                        'global_batch': gb, 'per_gpu_batch': shard, 'lr': LR, 'parallelism': 'dp%d' % world,
                        'train_gflop_per_image': 12.2698},
             'step_mfma_frac': round(gb * args.steps / elapsed * 12.2698e9 / (peak * 1e12) / world, 4),

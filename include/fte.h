@@ -262,6 +262,35 @@ int fte_conv2d_wgrad16(const uint16_t* x16, const uint16_t* dz16, float* dw, int
                        int ksize, int stride, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * bf16 STORAGE (the third precision contract, next to fp32 and "bf16 operands, fp32 tensors"; BASELINE.json config 3's
+ * precision, SURVEY.md section 7 step 8 "bf16 storage path, fp32 master weights").  The activations the backward pass keeps -- z, y -- and the
+ * gradients that travel between layers -- dz, and the skip-path gradient `raw` -- live in HBM as bf16 ONLY: the epilogues
+ * move 6-8 bytes per output element instead of 10-18.  Arithmetic is unchanged: fp32 accumulation, fp32 bias / PReLU /
+ * residual / PReLU-gradient math, fp32 dalpha / dbias / filter gradients, fp32 master weights and optimizer.  Every stored
+ * value is rounded exactly once, to nearest even, where it is written; every consumer sees the rounded value:
+ *   y16  = bf16( prelu(acc + bias) + float(res16) )       z16 = bf16( acc + bias )
+ *   g    = acc + float(addin16)        raw16 = bf16(g)     dz = g * prelu'(float(zprev16))      dzprev16 = bf16(dz)
+ *   dalpha = sum g * min(float(zprev16), 0)                dbias = sum dz                       (fp32 sums of unrounded terms)
+ * oracle/ops.py storage_rounding('bf16') rounds at the same points (tests/test_gpu_bf16_storage.py).
+ *   fte_conv2d_fwd_s16          as fte_conv2d_fwd16 with a bf16 shortcut, bf16 z / y outputs; z32 / y32 (optional) also
+ *                               receive the unrounded fp32 values (the last conv layer, whose consumer is the dense layer)
+ *   fte_conv2d_dgrad_s16        as fte_conv2d_dgrad16 with bf16 skip gradient / z inputs and bf16 raw / dz outputs
+ *   fte_conv3x3_first_fwd_s16   the first layer (fp32 images in, bf16 z / y out)
+ *   fte_conv3x3_first_wgrad_s16 its filter gradient from a bf16 dz
+ * The filter gradient of every other layer is fte_conv2d_wgrad16 (bf16 x and dz in, fp32 dw out).
+ * ------------------------------------------------------------------------- */
+int fte_conv2d_fwd_s16(const uint16_t* x16, const uint16_t* w16t, const float* bias, const float* alpha, const uint16_t* res16,
+                       uint16_t* z16, uint16_t* y16, float* z32, float* y32, int n, int h, int wd, int cin, int cout,
+                       int ksize, int stride, void* ws, size_t ws_bytes, void* stream);
+int fte_conv2d_dgrad_s16(const uint16_t* dz16, const uint16_t* w16, const uint16_t* addin16, const uint16_t* zprev16,
+                         const float* alpha_prev, uint16_t* raw16, uint16_t* dzprev16, float* dalpha_prev, float* dbias_prev,
+                         int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream);
+int fte_conv3x3_first_fwd_s16(const float* x, const float* w, const float* bias, const float* alpha, uint16_t* z16, uint16_t* y16,
+                              int n, int h, int wd, int cin, int cout, int stride, void* stream);
+int fte_conv3x3_first_wgrad_s16(const float* x, const uint16_t* dz16, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                                void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * ShuffleNet-v2 (nets/shufflenet_v2.py).  Depthwise 3x3, TF-SAME, stride 1 or 2: the DepthwiseConv2dNative half of
  * layers.separable_conv2d (:98,104; the pointwise half is fte_conv2d_* with ksize 1).  x [n,h,wd,c], w [3,3,c].
  * HBM-bound (9 MAC per element).

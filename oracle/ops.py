@@ -47,6 +47,37 @@ def _r(a):
     return a if _OPERAND_ROUND is None else _OPERAND_ROUND(a)
 
 
+# --------------------------------------------------------------------------
+# bf16 STORAGE (the build's 'bf16s' mode; include/fte.h "bf16 STORAGE"): the activations the backward
+# pass keeps (z, y) and the gradients that travel between layers (dz, the skip-path gradient) live in HBM as bfloat16.  Every
+# such tensor is rounded ONCE, to nearest even, where it is written, and every consumer sees the rounded value; sums
+# (dalpha, dbias, filter gradients) are formed from the unrounded fp32 terms.  `storage_rounding('bf16')` makes the nets'
+# oracles (oracle/spherenet.py) round at exactly those points via stored().  Default: no rounding.
+# --------------------------------------------------------------------------
+_STORAGE_ROUND = None
+
+
+@contextlib.contextmanager
+def storage_rounding(mode):
+    global _STORAGE_ROUND
+    assert mode in (None, 'bf16'), mode
+    prev = _STORAGE_ROUND
+    _STORAGE_ROUND = bf16_round if mode == 'bf16' else None
+    try:
+        yield
+    finally:
+        _STORAGE_ROUND = prev
+
+
+def stored(a):
+    """`a` as its consumers see it after a round trip through HBM in the active storage precision."""
+    return a if _STORAGE_ROUND is None else _STORAGE_ROUND(a)
+
+
+def storage_active():
+    return _STORAGE_ROUND is not None
+
+
 def rounding_active():
     """True inside operand_rounding('bf16')"""
     return _OPERAND_ROUND is not None

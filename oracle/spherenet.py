@@ -99,18 +99,28 @@ def _unflatten(d, shape, data_format):
 
 
 def backbone_fwd(p, images, data_format='NCHW', keep=True):
-    """images NHWC in [-1,1] -> embedding [N,512]; cache holds what backward needs."""
+    """images NHWC in [-1,1] -> embedding [N,512]; cache holds what backward needs.
+    Precision modes of the engine (ops.operand_rounding / ops.storage_rounding): the FIRST conv (K = 9*Cin <= 27) is not on the
+    bf16 MFMA path in any mode -- its operands are never rounded; under bf16 storage every layer's z and block output are
+    rounded where they are stored, except the LAST conv layer's (the dense layer reads them from an fp32 buffer)."""
     cache = []
     x = images
     shortcut = None
-    for name, si, stride, has_bias, second in conv_layer_names():
+    specs = conv_layer_names()
+    for li, (name, si, stride, has_bias, second) in enumerate(specs):
         if second == 0:
             shortcut = x
-        z = ops.conv2d_fwd(x, p[name + '/weights'], stride, p.get(name + '/biases'))
+        if li == 0:
+            with ops.operand_rounding(None):
+                z = ops.conv2d_fwd(x, p[name + '/weights'], stride, p.get(name + '/biases'))
+        else:
+            z = ops.conv2d_fwd(x, p[name + '/weights'], stride, p.get(name + '/biases'))
         y = ops.prelu_fwd(z, p[name + '/alpha'])
+        out = y + shortcut if second == 1 else y
+        last = li == len(specs) - 1
         if keep:
-            cache.append((name, x, z))
-        x = y + shortcut if second == 1 else y
+            cache.append((name, x, z if last else ops.stored(z)))
+        x = out if last else ops.stored(out)
     feat_shape = x.shape
     flat = _flatten(x, data_format)
     emb = ops.fc_fwd(flat, p['SphereNet/fully_connected/weights'], p['SphereNet/fully_connected/biases'])
@@ -152,14 +162,19 @@ def backbone_bwd(p, cache, demb, trace=None, kink=None, kink_mode='fp32'):
         name, si, stride, has_bias, second = specs[li]
         _, x, z = cache['layers'][li]
         if second == 1:
-            dskip = dx                                   # out = shortcut + prelu(z2)
+            dskip = ops.stored(dx)                       # out = shortcut + prelu(z2): the skip-path gradient waits in HBM
         zs = kink_resolved(z, kink[name], kink_mode) if kink is not None and name in kink else None
         dz, g[name + '/alpha'] = ops.prelu_bwd(z, p[name + '/alpha'], dx, zs)
         if trace is not None:
             trace[name] = dz
         if has_bias:
             g[name + '/biases'] = dz.sum(axis=(0, 1, 2))
-        dxl, g[name + '/weights'] = ops.conv2d_bwd(x, p[name + '/weights'], dz, stride, need_dx=li > 0)
+        dz = ops.stored(dz)                              # what the data / filter gradient kernels read
+        if li == 0:
+            with ops.operand_rounding(None):             # the first conv's filter gradient is an fp32 product in every mode
+                dxl, g[name + '/weights'] = ops.conv2d_bwd(x, p[name + '/weights'], dz, stride, need_dx=False)
+        else:
+            dxl, g[name + '/weights'] = ops.conv2d_bwd(x, p[name + '/weights'], dz, stride, need_dx=True)
         if second == 0:
             dxl = dxl + dskip
         dx = dxl

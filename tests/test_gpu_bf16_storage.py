@@ -1,0 +1,169 @@
+"""-m gpu: bf16 STORAGE ('bf16s': include/fte.h "bf16 STORAGE"; SURVEY.md section 7 step 8, BASELINE.json configs[2]'s precision).
+
+The activations backward keeps (z, y) and the gradients between layers (dz, the skip-path gradient) live in HBM as bf16 only; the
+arithmetic stays fp32.  Two layers of evidence:
+  * entry points: fte_conv2d_{fwd,dgrad}_s16 against the bf16-COPIES entry points (fte_conv2d_*16, themselves held to the
+    operand-rounded float64 oracle at 2e-5 by tests/test_gpu_bf16.py) on the same bf16 inputs -- the stored bf16 tensors must be the
+    round-to-nearest-even of the copies path's fp32 results BIT FOR BIT, the fp32 sums (dalpha, dbias) bit-identical;
+  * whole net: SphereNet in the bf16s mode against the float64 oracle with the SAME rounding points (ops.operand_rounding +
+    ops.storage_rounding) at the stated tolerance, and against the unrounded oracle at the mixed-precision tolerance of the bf16 mode.
+Stated tolerances (whole net, 20 conv layers, vs the rounded oracle): logits rel-L2 <= 5e-3, every gradient rel-L2 <= 1e-2 -- a bf16
+rounding of a value that fp32 and float64 evaluate a hair apart can land on neighbouring bf16 values (1 ulp = 0.4 % of that element;
+~1e-4 of the elements), and those differences travel on through the net."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops, spherenet as osn
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from util_gpu import dev, host, stream, ws, check_rell2
+    from tf_face_toolbox_amd import _lib, net_select, Singular
+
+
+def _bits(t):
+    return t.bfloat16().view(torch.int16)
+
+
+def _f(t16):
+    return t16.view(torch.bfloat16).float()
+
+
+@pytest.fixture
+def bf16s_mode():
+    _lib.set_mfma_dtype('bf16s')
+    assert _lib.get_mfma_dtype() == 'bf16' and _lib.bf16_storage() and _lib.precision_mode() == 'bf16s'
+    yield
+    _lib.set_mfma_dtype('f32')
+    assert not _lib.bf16_storage()
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,stride', [
+    (4, 14, 14, 64, 64, 3, 1), (3, 15, 9, 64, 128, 3, 2), (2, 28, 28, 128, 64, 3, 1), (64, 14, 14, 128, 128, 3, 2),
+    (2, 7, 7, 512, 512, 3, 1),                              # few tiles: split-K partial tiles + the fix-up kernel's epilogue
+    (512, 14, 14, 128, 128, 3, 1), (40, 56, 56, 64, 64, 3, 1),   # the LDS-DMA kernel's 128x128 / 128x64 tiles (igemm16.hip)
+    (126, 28, 28, 128, 128, 3, 1), (130, 28, 28, 64, 128, 3, 2)])
+def test_s16_entry_points_are_the_rounding_of_the_copies_path(bf16s_mode, n, h, w, cin, cout, k, stride):
+    g = torch.Generator(device='cuda').manual_seed(n + cin + cout + k)
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    x16 = _bits(torch.randn(n, h, w, cin, device='cuda', generator=g))
+    wt = torch.randn(k, k, cin, cout, device='cuda', generator=g) * 0.1
+    bias = torch.randn(cout, device='cuda', generator=g) * 0.1; alpha = torch.rand(cout, device='cuda', generator=g) * 0.3 + 0.1
+    alp = torch.rand(cin, device='cuda', generator=g) * 0.3 + 0.1
+    res16 = _bits(torch.randn(n, ho, wo, cout, device='cuda', generator=g))
+    dz16 = _bits(torch.randn(n, ho, wo, cout, device='cuda', generator=g))
+    zp16 = _bits(torch.randn(n, h, w, cin, device='cuda', generator=g)); zp16.view(-1)[:4] = 0      # z == 0: slope alpha / 2
+    add16 = _bits(torch.randn(n, h, w, cin, device='cuda', generator=g))
+    q = _lib.query
+    buf, nb = ws(max(q('fte_conv2d_fwd_ws_bytes', n, h, w, cin, cout, k, stride), q('fte_conv2d_dgrad_ws_bytes', n, h, w, cin, cout, k, stride)))
+    st = stream()
+    i16 = dict(dtype=torch.int16, device='cuda')
+    w16 = torch.empty(wt.shape, **i16); w16t = torch.empty(k, k, cout, cin, **i16)
+    _lib.call('fte_pack_weights_bf16', wt, w16, w16t, k, cin, cout, st)
+    shp_o, shp_i = (n, ho, wo, cout), (n, h, w, cin)
+    # ---- forward: copies path (fp32 tensors + a bf16 copy of y) vs storage path (bf16 tensors only)
+    z1 = torch.empty(shp_o, device='cuda'); y1 = torch.empty(shp_o, device='cuda'); y16c = torch.empty(shp_o, **i16)
+    _lib.call('fte_conv2d_fwd16', x16, w16t, bias, alpha, _f(res16), z1, y1, y16c, n, h, w, cin, cout, k, stride, buf, nb, st)
+    z16 = torch.empty(shp_o, **i16); y16 = torch.empty(shp_o, **i16)
+    _lib.call('fte_conv2d_fwd_s16', x16, w16t, bias, alpha, res16, z16, y16, None, None, n, h, w, cin, cout, k, stride, buf, nb, st)
+    assert torch.equal(y16, y16c) and torch.equal(y16, _bits(y1)) and torch.equal(z16, _bits(z1))
+    # ... and with the optional fp32 outputs (the last conv layer of SphereNet), no residual, no z
+    z2 = torch.empty(shp_o, device='cuda'); y2 = torch.empty(shp_o, device='cuda'); y16b = torch.empty(shp_o, **i16)
+    _lib.call('fte_conv2d_fwd_s16', x16, w16t, bias, alpha, res16, None, y16b, z2, y2, n, h, w, cin, cout, k, stride, buf, nb, st)
+    assert torch.equal(y16b, y16) and torch.equal(z2, z1) and torch.equal(y2, y1)
+    # ---- data gradient + PReLU gradient of the producing layer
+    raw1 = torch.empty(shp_i, device='cuda'); dx1 = torch.empty(shp_i, device='cuda'); dx16c = torch.empty(shp_i, **i16)
+    da1 = torch.empty(cin, device='cuda'); db1 = torch.empty(cin, device='cuda')
+    _lib.call('fte_conv2d_dgrad16', dz16, w16, _f(add16), _f(zp16), alp, raw1, dx1, dx16c, da1, db1, n, h, w, cin, cout, k, stride, buf, nb, st)
+    raw16 = torch.empty(shp_i, **i16); dx16 = torch.empty(shp_i, **i16)
+    da2 = torch.empty(cin, device='cuda'); db2 = torch.empty(cin, device='cuda')
+    _lib.call('fte_conv2d_dgrad_s16', dz16, w16, add16, zp16, alp, raw16, dx16, da2, db2, n, h, w, cin, cout, k, stride, buf, nb, st)
+    assert torch.equal(raw16, _bits(raw1)) and torch.equal(dx16, dx16c) and torch.equal(dx16, _bits(dx1))
+    assert torch.equal(da2, da1) and torch.equal(db2, db1)
+    # plain data gradient (no skip gradient, no mask, no raw): the stage-entry layers' dgrad into the images is never needed,
+    # but the entry point must take NULLs like its fp32 twin
+    dx16p = torch.empty(shp_i, **i16); dxp = torch.empty(shp_i, device='cuda')
+    _lib.call('fte_conv2d_dgrad_s16', dz16, w16, None, None, None, None, dx16p, None, None, n, h, w, cin, cout, k, stride, buf, nb, st)
+    _lib.call('fte_conv2d_dgrad16', dz16, w16, None, None, None, None, dxp, None, None, None, n, h, w, cin, cout, k, stride, buf, nb, st)
+    assert torch.equal(dx16p, _bits(dxp))
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,stride', [(3, 16, 16, 3, 64, 2), (2, 13, 9, 1, 64, 2), (2, 112, 112, 3, 64, 2)])
+def test_first_conv_s16(n, h, w, cin, cout, stride):
+    """first layer: fp32 images in, bf16 z / y out (= the rounding of the fp32 entry point's results, bit for bit); its filter gradient
+    from a bf16 dz equals the fp32 entry point's on the same (bf16-exact) dz, bit for bit."""
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.rand(n, h, w, cin, device='cuda', generator=g) * 2 - 1
+    wt = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * 0.2
+    b = torch.randn(cout, device='cuda', generator=g); al = 0.25 + 0.1 * torch.randn(cout, device='cuda', generator=g)
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    z = torch.empty(n, ho, wo, cout, device='cuda'); y = torch.empty_like(z)
+    _lib.call('fte_conv3x3_first_fwd', x, wt, b, al, z, y, n, h, w, cin, cout, stride, stream())
+    z16 = torch.empty(z.shape, dtype=torch.int16, device='cuda'); y16 = torch.empty_like(z16)
+    _lib.call('fte_conv3x3_first_fwd_s16', x, wt, b, al, z16, y16, n, h, w, cin, cout, stride, stream())
+    assert torch.equal(z16, _bits(z)) and torch.equal(y16, _bits(y))
+    dz16 = _bits(torch.randn(z.shape, device='cuda', generator=g))
+    wsb, nb = ws(_lib.query('fte_conv3x3_first_wgrad_ws_bytes', n, h, w, cin, cout, stride))
+    dw0 = torch.empty_like(wt); dw1 = torch.empty_like(wt)
+    _lib.call('fte_conv3x3_first_wgrad', x, _f(dz16), dw0, n, h, w, cin, cout, stride, wsb, nb, stream())
+    _lib.call('fte_conv3x3_first_wgrad_s16', x, dz16, dw1, n, h, w, cin, cout, stride, wsb, nb, stream())
+    assert torch.equal(dw1, dw0)
+
+
+def _z_of(net):
+    return {c.name: host(_f(net.z16[i])) if net.z[i] is None else host(net.z[i]) for i, c in enumerate(net.convs)}
+
+
+@pytest.mark.parametrize('name,head', [('SphereNet', 'softmax'), ('SphereNet-ASoftmax', 'asoftmax')])
+def test_spherenet_bf16s_step_vs_the_rounded_oracle(bf16s_mode, name, head):
+    n, h, w, ch, ncls = 8, 64, 64, 3, 40
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (n, h, w, ch)); y = rng.integers(0, ncls, n)
+    net = net_select(name, 'NHWC', 5e-4)
+    net.build(h, w, ch, ncls, 'cuda')
+    p = {k: host(net.get_variable(k)) for k in net.variables}
+    lam = ops.asoftmax_lambda(0)
+    xd, yd = dev(x), dev(y, torch.int32)
+    out = net.forward(xd, yd, num_classes=ncls, is_training=True) if net.needs_labels else net.forward(xd, num_classes=ncls, is_training=True)
+    losses, names, _ = net.loss_function('T', yd, **out)
+    net.backward()
+    torch.cuda.synchronize()
+    assert net.z[0] is None and net.y[0] is None and net.z16[0].dtype == torch.int16          # no fp32 activations but the last layer's
+    assert net.z[-1] is not None
+    zk = _z_of(net)
+    with ops.operand_rounding('bf16'), ops.storage_rounding('bf16'):
+        l_ref, g_ref, cache = osn.loss_and_grads(p, x, y, data_format='NHWC', weight_decay=5e-4, head=head, lam=lam, kink=zk, kink_mode='bf16')
+    l_un, g_un, cache_un = osn.loss_and_grads(p, x, y, data_format='NHWC', weight_decay=5e-4, head=head, lam=lam, kink=zk, kink_mode='bf16')
+    e_log = check_rell2(host(out['logits']), cache['logits'], 5e-3, 'logits vs the rounded oracle')
+    check_rell2(host(out['logits']), cache_un['logits'], 2e-2, 'logits vs the unrounded oracle')
+    assert abs(float(losses[0]) - l_ref[0]) <= 5e-3 * l_ref[0]
+    worst = worst_un = 0.0
+    for k in net.variables:
+        got = host(net.get_variable(k, net.grads)) + (5e-4 * p[k] if k.endswith('/weights') else 0)
+        worst = max(worst, check_rell2(got, g_ref[k], 1e-2, 'grad %s vs the rounded oracle' % k))
+        worst_un = max(worst_un, check_rell2(got, g_un[k], 5e-2, 'grad %s vs the unrounded oracle' % k))
+    print('bf16s %s: logits %.2e, worst gradient %.2e vs the rounded oracle (%.2e vs the unrounded one)' % (name, e_log, worst, worst_un))
+    assert worst < worst_un                                 # the rounded oracle is the counterpart of this path, the unrounded one is not
+
+
+def test_spherenet_bf16s_trains_and_two_streams_change_no_bit(bf16s_mode):
+    n, h, w, ch, ncls = 16, 64, 64, 3, 40
+    rng = np.random.default_rng(12)
+    x = dev(rng.uniform(-1, 1, (n, h, w, ch))); y = dev(rng.integers(0, ncls, n), torch.int32)
+    arenas = []
+    for one_stream in (False, True):
+        net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+        net.seed = 3
+        step, ls, names, _ = Singular(net, 0.01, 'Momentum')({'images': x, 'labels': y, 'num_classes': ncls, 'num_examples': n})
+        net.one_stream = one_stream
+        hist = []
+        for _ in range(25):
+            step()
+            hist.append(float(ls[0]))
+        assert np.isfinite(hist).all() and hist[-1] < hist[0]
+        arenas.append(net.params.clone())
+    assert torch.equal(arenas[0], arenas[1])
+    f = net.forward(x, is_training=False)                                       # inference in the bf16s mode (flip-averaged embedding)
+    assert f.shape == (n, 512) and torch.isfinite(f).all()

@@ -67,6 +67,10 @@ _SIGS = {
     'fte_conv2d_fwd16': (c_int, [_P] * 8 + [c_int] * 7 + [_P, c_size_t, _P]),
     'fte_conv2d_dgrad16': (c_int, [_P] * 10 + [c_int] * 7 + [_P, c_size_t, _P]),
     'fte_conv2d_wgrad16': (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),
+    'fte_conv2d_fwd_s16': (c_int, [_P] * 9 + [c_int] * 7 + [_P, c_size_t, _P]),
+    'fte_conv2d_dgrad_s16': (c_int, [_P] * 9 + [c_int] * 7 + [_P, c_size_t, _P]),
+    'fte_conv3x3_first_fwd_s16': (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
+    'fte_conv3x3_first_wgrad_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_set_mfma_dtype': (c_int, [c_int]),
     'fte_get_mfma_dtype': (c_int, []),
     'fte_dwconv3x3_fwd': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
@@ -110,7 +114,10 @@ _CODES = {-1: 'FTE_EINVAL -- a null pointer, a shape the kernel family does not 
               'ksize) or a tensor of 2 GiB or more (buffer-load range)',
           -2: 'FTE_EWORKSPACE -- workspace missing or smaller than the matching *_ws_bytes() query'}
 
-MFMA_DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}
+MFMA_DTYPES = {'f32': 0, 'fp32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1, 'bf16s': 1}
+# 'bf16s' = bf16 MFMA operands AND bf16 storage of the activations / inter-layer gradients (fte.h, "bf16 STORAGE"): the library's
+# MFMA dtype is bf16; which entry points a net calls (the *_s16 ones) is the net's business and follows this flag
+_storage16 = False
 
 
 def load():
@@ -130,8 +137,10 @@ def load():
     env = os.environ.get('FTE_MFMA_DTYPE')          # process-wide default of fte_set_mfma_dtype: f32 | bf16
     if env:
         if env not in MFMA_DTYPES:
-            raise FteError('FTE_MFMA_DTYPE=%r: expected f32 or bf16' % env)
+            raise FteError('FTE_MFMA_DTYPE=%r: expected f32, bf16 or bf16s' % env)
         lib.fte_set_mfma_dtype(MFMA_DTYPES[env])
+        global _storage16
+        _storage16 = env == 'bf16s'
     return lib
 
 
@@ -175,12 +184,25 @@ def version():
 def set_mfma_dtype(name):
     """'f32' (default, the reference's arithmetic) or 'bf16' (bf16 operands, fp32 accumulate and storage): fte.h."""
     if name not in MFMA_DTYPES:
-        raise ValueError('unknown MFMA dtype %r (f32 | bf16)' % (name,))
+        raise ValueError('unknown MFMA dtype %r (f32 | bf16 | bf16s)' % (name,))
+    global _storage16
     call('fte_set_mfma_dtype', MFMA_DTYPES[name])
+    _storage16 = name == 'bf16s'
 
 
 def get_mfma_dtype():
+    """'f32' or 'bf16' -- the operand precision of the MFMA products (storage: see bf16_storage())."""
     return 'bf16' if query('fte_get_mfma_dtype') == 1 else 'f32'
+
+
+def bf16_storage():
+    """True in the 'bf16s' mode: activations and inter-layer gradients live in HBM as bf16 (nets that implement it: SphereNet)."""
+    return _storage16 and query('fte_get_mfma_dtype') == 1
+
+
+def precision_mode():
+    """'f32' | 'bf16' | 'bf16s' -- what set_mfma_dtype() was last given."""
+    return 'bf16s' if bf16_storage() else get_mfma_dtype()
 
 
 def prof_records(shapes=False):

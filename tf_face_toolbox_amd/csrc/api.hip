@@ -266,8 +266,8 @@ size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksiz
 // x / w are bf16 copies (x16 [n,h,wd,cin]; w16t [k*k][cout][cin], fte_pack_weights_bf16) when `src16`
 static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float* bias, const float* alpha, const float* res,
                            float* z, float* y, uint16_t* y16, int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                           void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !y || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3))
+                           void* ws, size_t ws_bytes, void* stream, const uint16_t* res16 = nullptr, uint16_t* z16 = nullptr) {
+    if (!x || !w || (!y && !(src16 && y16)) || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3))
         return FTE_EINVAL;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     IgemmParams p;
@@ -281,6 +281,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
     p.B = (const float*)w;
     p.c_ld = cout;
     p.Y = y; p.Z = z; p.R = res; p.bias = bias; p.alpha = alpha; p.Y16 = y16;
+    p.R16 = res16; p.Z16 = z16;
     int bl = BL_KN;
     if (src16) {                                     // transposed pack: rows = output channels, k-contiguous per tap
         p.src16 = 1; p.b_ld = cin; bl = BL_NK;
@@ -303,6 +304,14 @@ int fte_conv2d_fwd16(const uint16_t* x16, const uint16_t* w16t, const float* bia
                      void* ws, size_t ws_bytes, void* stream) {
     Plan16 guard;
     return conv2d_fwd_impl(x16, w16t, true, bias, alpha, res, z, y, y16, n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
+}
+
+int fte_conv2d_fwd_s16(const uint16_t* x16, const uint16_t* w16t, const float* bias, const float* alpha, const uint16_t* res16,
+                       uint16_t* z16, uint16_t* y16, float* z32, float* y32, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                       void* ws, size_t ws_bytes, void* stream) {
+    if (!y16 || (res16 && ((uintptr_t)res16 & 15))) return FTE_EINVAL;
+    Plan16 guard;
+    return conv2d_fwd_impl(x16, w16t, true, bias, alpha, nullptr, z32, y32, y16, n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream, res16, z16);
 }
 
 size_t fte_conv3x3_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -394,8 +403,11 @@ size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
 // dz / w are bf16 copies (dz16 [n,ho,wo,cout]; w16 [k*k][cin][cout], the HWIO layout) when `src16`
 static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const float* addin, const float* zprev,
                              const float* alpha_prev, float* raw, float* dzprev, uint16_t* dzprev16, float* dalpha_prev, float* dbias_prev,
-                             int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
-    if (!dz || !w || !dzprev || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
+                             int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream,
+                             const uint16_t* addin16 = nullptr, const uint16_t* zprev16 = nullptr, uint16_t* raw16 = nullptr) {
+    if (zprev16 && !zprev) zprev = reinterpret_cast<const float*>(zprev16);      // "has a PReLU mask" below; the kernels read p.Zin16
+    const bool z16only = zprev16 != nullptr;
+    if (!dz || !w || (!dzprev && !(src16 && dzprev16)) || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
     if (zprev && !alpha_prev) return FTE_EINVAL;
     const Pads pho = same_pads(h, ksize, stride), pwo = same_pads(wd, ksize, stride);
     DgradClass cls[4];
@@ -435,7 +447,8 @@ static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const fl
         p.a_NT = t; p.K = t * cout; p.kchunk = p.K;
         p.B = (const float*)w; p.b_ld = cout;
         p.c_OH = c0.hq; p.c_OW = c0.wq; p.c_FH = h; p.c_FW = wd; p.c_step = stride; p.c_ld = cin;
-        p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
+        p.ADD = addin; p.RAW = raw; p.Zin = z16only ? nullptr : zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
+        p.ADD16 = addin16; p.Zin16 = zprev16; p.RAW16 = raw16;
         p.PA = PA; p.PB = PB; p.prow0 = 0;
         p.src16 = src16 ? 1 : 0; p.DZ16 = dzprev16;
         if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
@@ -459,7 +472,8 @@ static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const fl
         if (stride == 1) { p.c_OH = 0; }
         else { p.c_OH = c.hq; p.c_OW = c.wq; p.c_FH = h; p.c_FW = wd; p.c_step = stride; p.c_ph = c.ph; p.c_pw = c.pw; }
         p.c_ld = cin;
-        p.ADD = addin; p.RAW = raw; p.Zin = zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
+        p.ADD = addin; p.RAW = raw; p.Zin = z16only ? nullptr : zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
+        p.ADD16 = addin16; p.Zin16 = zprev16; p.RAW16 = raw16;
         p.PA = PA; p.PB = PB;
         if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
         hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, pwbuf, (hipStream_t)stream);
@@ -491,6 +505,15 @@ int fte_conv2d_dgrad16(const uint16_t* dz16, const uint16_t* w16, const float* a
     Plan16 guard;
     return conv2d_dgrad_impl(dz16, w16, true, addin, zprev, alpha_prev, raw, dzprev, dzprev16, dalpha_prev, dbias_prev,
                              n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream);
+}
+
+int fte_conv2d_dgrad_s16(const uint16_t* dz16, const uint16_t* w16, const uint16_t* addin16, const uint16_t* zprev16,
+                         const float* alpha_prev, uint16_t* raw16, uint16_t* dzprev16, float* dalpha_prev, float* dbias_prev,
+                         int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
+    if (!dzprev16) return FTE_EINVAL;
+    Plan16 guard;
+    return conv2d_dgrad_impl(dz16, w16, true, nullptr, nullptr, alpha_prev, nullptr, nullptr, dzprev16, dalpha_prev, dbias_prev,
+                             n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream, addin16, zprev16, raw16);
 }
 
 size_t fte_conv3x3_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -594,7 +617,13 @@ int fte_conv3x3_first_fwd(const float* x, const float* w, const float* bias, con
                           int n, int h, int wd, int cin, int cout, int stride, void* stream) {
     if (!x || !w || !y || (cout != 64 && cout != 32) || (cin != 1 && cin != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
-    return rc(k_conv_first_fwd(x, w, bias, alpha, z, y, n, h, wd, cin, cout, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+    return rc(k_conv_first_fwd(x, w, bias, alpha, z, y, nullptr, nullptr, n, h, wd, cin, cout, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
+}
+int fte_conv3x3_first_fwd_s16(const float* x, const float* w, const float* bias, const float* alpha, uint16_t* z16, uint16_t* y16,
+                              int n, int h, int wd, int cin, int cout, int stride, void* stream) {
+    if (!x || !w || !y16 || (cout != 64 && cout != 32) || (cin != 1 && cin != 3)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(k_conv_first_fwd(x, w, bias, alpha, nullptr, nullptr, z16, y16, n, h, wd, cin, cout, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream));
 }
 
 size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -602,16 +631,24 @@ size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout,
     return align_up((size_t)k_conv_first_wgrad_blocks((long)n * ph.out * pw.out) * 9 * cin * cout * sizeof(float)) + SCRATCH_BYTES;
 }
 
-int fte_conv3x3_first_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
-                            void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !dz || !dw || (cout != 64 && cout != 32) || (cin != 1 && cin != 3)) return FTE_EINVAL;
+static int conv_first_wgrad_impl(const float* x, const float* dz, const uint16_t* dz16, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!x || (!dz && !dz16) || !dw || (cout != 64 && cout != 32) || (cin != 1 && cin != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     const int blocks = k_conv_first_wgrad_blocks((long)n * ph.out * pw.out);
     const size_t need = align_up((size_t)blocks * 9 * cin * cout * sizeof(float));
     if (!ws || ws_bytes < need + SCRATCH_BYTES) return FTE_EWORKSPACE;
-    hipError_t e = k_conv_first_wgrad(x, dz, (float*)ws, n, h, wd, cin, cout, ph.out, pw.out, stride, ph.before, pw.before, blocks, (hipStream_t)stream);
+    hipError_t e = k_conv_first_wgrad(x, dz, dz16, (float*)ws, n, h, wd, cin, cout, ph.out, pw.out, stride, ph.before, pw.before, blocks, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, blocks, 9L * cin * cout, 1, 1.f, (float*)((char*)ws + need), (hipStream_t)stream));
+}
+int fte_conv3x3_first_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                            void* ws, size_t ws_bytes, void* stream) {
+    return conv_first_wgrad_impl(x, dz, nullptr, dw, n, h, wd, cin, cout, stride, ws, ws_bytes, stream);
+}
+int fte_conv3x3_first_wgrad_s16(const float* x, const uint16_t* dz16, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                                void* ws, size_t ws_bytes, void* stream) {
+    return conv_first_wgrad_impl(x, nullptr, dz16, dw, n, h, wd, cin, cout, stride, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -51,6 +51,11 @@ struct IgemmParams {
     // BF = 2 kernels run; Y16 / DZ16 != NULL -> the epilogue also writes a bf16 copy of Y / DZ for the next consumer
     int src16;
     unsigned short* Y16; unsigned short* DZ16;
+    // bf16 STORAGE (src16 launches only; fte_conv2d_*_s16): the epilogue's tensors as bf16 in HBM -- inputs R16 (shortcut), ADD16
+    // (skip gradient), Zin16 (z of the previous layer) replace R / ADD / Zin; outputs Z16, RAW16 next to Y16 / DZ16; the fp32
+    // outputs Y / DZ may then be NULL
+    const unsigned short* R16; const unsigned short* ADD16; const unsigned short* Zin16;
+    unsigned short* Z16; unsigned short* RAW16;
 };
 
 hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st);

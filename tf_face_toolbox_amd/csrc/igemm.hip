@@ -857,7 +857,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
     }
 
     if (FTE_PRIO_EPILOGUE && BF == 0) __builtin_amdgcn_s_setprio(FTE_PRIO_EPILOGUE);      // drain quickly, free the slot
-    igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow);
+    igemm_epilogue<BM, BN, WM, WN, EPI, BF == 2>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow);
 #ifdef FTE_STAMP
     if constexpr (BF == 0) {
         __syncthreads();
@@ -927,6 +927,7 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, i
                 if (off[u] >= 0) {
                     for (int sidx = 0; sidx < splits; ++sidx) v[u] += W[sidx * tile_stride + rl * BN];
                     if (p.R) rres[u] = p.R[(long)off[u] + col];
+                    else if (p.R16) rres[u] = bf2f(p.R16[(long)off[u] + col]);
                 }
             }
 #pragma unroll
@@ -935,13 +936,14 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, i
                 const long o = (long)off[u] + col;
                 float x = v[u] + bias;
                 if (p.Z) p.Z[o] = x;
+                if (p.Z16) p.Z16[o] = tobf(x);
                 if (act) x = x > 0.f ? x : al * x;
-                p.Y[o] = x + rres[u];
+                if (p.Y) p.Y[o] = x + rres[u];
                 if (p.Y16) p.Y16[o] = tobf(x + rres[u]);
             }
         }
     } else {
-        const bool msk = p.Zin != nullptr;
+        const bool msk = p.Zin != nullptr || p.Zin16 != nullptr;
         const float al = msk ? p.alpha[col % p.amod] : 1.f;
         for (int i0 = 0; i0 < NR; i0 += UNR) {
             float v[UNR], zz[UNR];
@@ -956,7 +958,9 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, i
                     for (int sidx = 0; sidx < splits; ++sidx) v[u] += W[sidx * tile_stride + rl * BN];
                     const long o = (long)off[u] + col;
                     if (p.ADD) v[u] += p.ADD[o];
-                    if (msk) zz[u] = p.Zin[o];
+                    else if (p.ADD16) v[u] += bf2f(p.ADD16[o]);
+                    if (p.Zin) zz[u] = p.Zin[o];
+                    else if (p.Zin16) zz[u] = bf2f(p.Zin16[o]);
                 }
             }
 #pragma unroll
@@ -965,12 +969,13 @@ __global__ __launch_bounds__(256) void igemm_fixup_kernel(const IgemmParams p, i
                 const long o = (long)off[u] + col;
                 float x = v[u];
                 if (p.RAW) p.RAW[o] = x;
+                if (p.RAW16) p.RAW16[o] = tobf(x);
                 if (msk) {
                     sa += x * fminf(zz[u], 0.f);
                     x *= prelu_slope(zz[u], al);
                     sb += x;
                 }
-                p.DZ[o] = x;
+                if (p.DZ) p.DZ[o] = x;
                 if (p.DZ16) p.DZ16[o] = tobf(x);
             }
         }
@@ -1102,7 +1107,12 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
     // the loaders and the epilogue move 16 bytes per lane: every tensor the kernel touches must be 16-byte aligned and
     // its row pitch a multiple of 4 floats (torch allocations and the arenas' views are)
     const uintptr_t ptrs = (uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.Y | (uintptr_t)p.Z | (uintptr_t)p.R | (uintptr_t)p.ADD |
-                           (uintptr_t)p.RAW | (uintptr_t)p.Zin | (uintptr_t)p.DZ | (uintptr_t)p.PW | (uintptr_t)p.bias;
+                           (uintptr_t)p.RAW | (uintptr_t)p.Zin | (uintptr_t)p.DZ | (uintptr_t)p.PW | (uintptr_t)p.bias |
+                           (uintptr_t)p.R16 | (uintptr_t)p.ADD16 | (uintptr_t)p.Zin16 | (uintptr_t)p.Z16 | (uintptr_t)p.RAW16 |
+                           (uintptr_t)p.Y16 | (uintptr_t)p.DZ16;
+    if ((p.R16 || p.ADD16 || p.Zin16 || p.Z16 || p.RAW16) && !p.src16) return hipErrorInvalidValue;      // bf16 storage: the bf16-source kernels only
+    if (epi == EPI_FWD ? (!p.Y && !p.Y16 && !p.PW) : (!p.DZ && !p.DZ16 && !p.PW)) return hipErrorInvalidValue;
+    if (!p.src16 && (epi == EPI_FWD ? !p.Y : !p.DZ)) return hipErrorInvalidValue;
     const uintptr_t al_ptr = epi == EPI_FWD ? (uintptr_t)p.alpha : 0;      // read as float4 by the forward epilogue only
     if (((ptrs | al_ptr) & 15) || (p.c_ld & 3) || (p.a_ld & 3) || (p.b_ld & 3)) return hipErrorInvalidValue;
     if (p.M >= (1 << 24) || (al == AL_KM && p.K >= (1 << 24))) return hipErrorInvalidValue;      // fdiv() range (see the kernel)
@@ -1124,16 +1134,21 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
         const double tile = rows * (double)p.N * 4.0;
         if (p.PW) b += tile * splits;
         else if (epi == EPI_FWD) {
-            b += tile * splits;                               // Y (split-K: one slab per split)
+            if (p.Y) b += tile * splits;                      // Y (split-K: one slab per split)
             if (p.Z) b += tile;
             if (p.R) b += tile;
             if (p.Y16) b += tile / 2;
+            if (p.Z16) b += tile / 2;
+            if (p.R16) b += tile / 2;
         } else {
-            b += tile;                                        // DZ
+            if (p.DZ) b += tile;
             if (p.ADD) b += tile;
             if (p.Zin) b += tile;
             if (p.RAW) b += tile;
             if (p.DZ16) b += tile / 2;
+            if (p.ADD16) b += tile / 2;
+            if (p.Zin16) b += tile / 2;
+            if (p.RAW16) b += tile / 2;
         }
         r.bytes = b;
     }

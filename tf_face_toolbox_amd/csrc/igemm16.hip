@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
                 for (int r = 0; r < 16; ++r) keep_alive(acc[i][j][r]);
         return;
     }
-    igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, c_ph, c_pw, prow);
+    igemm_epilogue<BM, BN, WM, WN, EPI, true>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, c_ph, c_pw, prow);
 }
 
 // ---- window variant (3x3, stride 1, TF-SAME; W <= 30): the A operand of a 64-channel chunk is fetched ONCE per tile -------------
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
     }
     wait_vmcnt<0>();
     __syncthreads();
-    igemm_epilogue<BM, BN, WM, WN, EPI>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, p.c_ph, p.c_pw, p.prow0);
+    igemm_epilogue<BM, BN, WM, WN, EPI, true>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, p.c_ph, p.c_pw, p.prow0);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int MINW, int NSTB = 2>

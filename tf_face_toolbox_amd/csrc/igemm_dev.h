@@ -47,6 +47,17 @@ __device__ __forceinline__ int fdiv(int a, int d, float rd) {
     return q;
 }
 
+// four consecutive bf16 values (8 bytes) <-> f32x4
+__device__ __forceinline__ f32x4 ld_bf4(const unsigned short* q) {
+    const u32x2 u = *reinterpret_cast<const u32x2*>(q);
+    return f32x4{__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ void st_bf4(unsigned short* q, const f32x4 v) {
+    *reinterpret_cast<u32x2*>(q) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
 __device__ __forceinline__ float prelu_slope(float z, float a) {
     // d/dz [relu(z) + a*(z-|z|)/2]; TF's grad of relu(0) and sign(0) are 0 -> a/2 at exactly 0.
     return z > 0.f ? 1.f : (z == 0.f ? 0.5f * a : a);
@@ -56,7 +67,10 @@ __device__ __forceinline__ float prelu_slope(float z, float a) {
 // acc[i][j][r]: row wm*TM*32 + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), column wn*TN*32 + j*32 + (lane&31) (the C/D map of
 // every 32x32 MFMA).  `smem` (dynamic LDS, free for reuse -- the caller has passed a barrier after its last operand read)
 // must hold BM + WM*WN*32*36 + 2*WM*BN floats.  bid = tile index of the launch (after the XCD remap), mt = its row-tile index.
-template <int BM, int BN, int WM, int WN, int EPI>
+// CAP16 (the bf16-source kernels): the tensors of the epilogue may live in HBM as bf16 ("bf16 storage", fte_conv2d_*_s16): R16 /
+// ADD16 / Zin16 replace the fp32 inputs when set, Z16 / RAW16 (and Y16 / DZ16) are written, and the fp32 outputs Y / DZ are
+// optional.  The arithmetic stays fp32; every stored value is rounded once, to nearest even, where it is written.
+template <int BM, int BN, int WM, int WN, int EPI, bool CAP16 = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                                int bid, int split, int m0, int n0, int mt, int c_ph, int c_pw, int prow) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = 64 * WM * WN;
@@ -125,6 +139,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                 if (act) al4 = *reinterpret_cast<const f32x4*>(p.alpha + col);
             } else {
                 act = p.Zin != nullptr;
+                if constexpr (CAP16) act = act || p.Zin16 != nullptr;
                 if (act) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) al4[e] = p.alpha[(col + e) % p.amod];
@@ -143,10 +158,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     in0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
                     in1[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if constexpr (EPI == EPI_FWD) {
+                        if constexpr (CAP16) { if (p.R16 && offs[ps] >= 0) in0[ps] = ld_bf4(p.R16 + o); }
                         if (p.R && offs[ps] >= 0) in0[ps] = *reinterpret_cast<const f32x4*>(p.R + o);
                     } else {
+                        if constexpr (CAP16) {
+                            if (p.ADD16 && offs[ps] >= 0) in0[ps] = ld_bf4(p.ADD16 + o);
+                            if (p.Zin16 && offs[ps] >= 0) in1[ps] = ld_bf4(p.Zin16 + o);
+                        }
                         if (p.ADD && offs[ps] >= 0) in0[ps] = *reinterpret_cast<const f32x4*>(p.ADD + o);
-                        if (act && offs[ps] >= 0) in1[ps] = *reinterpret_cast<const f32x4*>(p.Zin + o);
+                        if (p.Zin && offs[ps] >= 0) in1[ps] = *reinterpret_cast<const f32x4*>(p.Zin + o);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -164,16 +184,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                     if constexpr (EPI == EPI_FWD) {
                         v += bias4;
                         if (p.Z) *reinterpret_cast<f32x4*>(p.Z + o) = v;
+                        if constexpr (CAP16) { if (p.Z16) st_bf4(p.Z16 + o, v); }
                         if (act) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : al4[e] * v[e];
                         }
                         v += in0[ps];
-                        *reinterpret_cast<f32x4*>(Y + o) = v;
-                        if (p.Y16) *reinterpret_cast<u32x2*>(p.Y16 + o) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
+                        if constexpr (CAP16) { if (p.Y) *reinterpret_cast<f32x4*>(Y + o) = v; }
+                        else *reinterpret_cast<f32x4*>(Y + o) = v;
+                        if (p.Y16) st_bf4(p.Y16 + o, v);
                     } else {
                         v += in0[ps];
                         if (p.RAW) *reinterpret_cast<f32x4*>(p.RAW + o) = v;
+                        if constexpr (CAP16) { if (p.RAW16) st_bf4(p.RAW16 + o, v); }
                         if (act) {
                             const f32x4 z = in1[ps];
 #pragma unroll
@@ -183,8 +206,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                                 sb4[j][e] += v[e];
                             }
                         }
-                        *reinterpret_cast<f32x4*>(p.DZ + o) = v;
-                        if (p.DZ16) *reinterpret_cast<u32x2*>(p.DZ16 + o) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
+                        if constexpr (CAP16) { if (p.DZ) *reinterpret_cast<f32x4*>(p.DZ + o) = v; }
+                        else *reinterpret_cast<f32x4*>(p.DZ + o) = v;
+                        if (p.DZ16) st_bf4(p.DZ16 + o, v);
                     }
                 }
             }

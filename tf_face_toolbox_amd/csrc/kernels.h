@@ -4,9 +4,9 @@
 #include <stdint.h>
 
 hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
-                            int n, int h, int wd, int cin, int cout, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
+                            unsigned short* z16, unsigned short* y16, int n, int h, int wd, int cin, int cout, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
 int k_conv_first_wgrad_blocks(long npix);
-hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int cin, int cout, int ho, int wo,
+hipError_t k_conv_first_wgrad(const float* x, const float* dz, const unsigned short* dz16, float* part, int n, int h, int wd, int cin, int cout, int ho, int wo,
                               int stride, int pt, int pl, int blocks, hipStream_t st);
 constexpr long REDUCE_SCRATCH_FLOATS = 1 << 18;      // 1 MiB of scratch for the tall-and-narrow case of k_reduce_rows
 hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale,

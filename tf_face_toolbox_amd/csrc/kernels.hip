@@ -50,6 +50,7 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ alpha, float* __restrict__ z, float* __restrict__ y,
+    unsigned short* __restrict__ z16, unsigned short* __restrict__ y16,      // bf16 storage: z / y rounded once, where they are written
     int n, int h, int wd, int ho, int wo, int stride, int pt, int pl) {
     constexpr int NH = COUT / 32, K = 9 * CIN, KS = (K + 1) / 2;      // NH accumulator blocks of 32 output channels
     static_assert(COUT == 32 || COUT == 64, "cout 32 (the 24-wide ShuffleNet stem, padded) or 64");
@@ -108,8 +109,10 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
                 for (int e = 0; e < NH; ++e) {
                     float v = acc[e][i] + bb[e];
                     if (z) z[o + 32 * e] = v;
+                    if (z16) z16[o + 32 * e] = __builtin_bit_cast(unsigned short, (__bf16)v);
                     if (alpha) v = v > 0.f ? v : aa[e] * v;
-                    y[o + 32 * e] = v;
+                    if (y) y[o + 32 * e] = v;
+                    if (y16) y16[o + 32 * e] = __builtin_bit_cast(unsigned short, (__bf16)v);
                 }
             }
         }
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
 typedef float f32x16k __attribute__((ext_vector_type(16)));
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
-    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ part,
+    const float* __restrict__ x, const float* __restrict__ dz, const unsigned short* __restrict__ dz16, float* __restrict__ part,
     int n, int h, int wd, int ho, int wo, int stride, int pt, int pl, long rows_per_block) {
     constexpr int NH = COUT / 32, K = 9 * CIN;
     __shared__ float red[4][32][COUT];
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
         const int ih = oh * stride + r - pt;
         const bool rok = kok && ih >= 0 && ih < h;
         const float* xrow = x + ((long)(img * h + (rok ? ih : 0)) * wd) * CIN + ch;
-        const float* drow = dz + row * wo * COUT;
+        const float* drow = dz ? dz + row * wo * COUT : nullptr;
+        const unsigned short* drow16 = dz16 ? dz16 + row * wo * COUT : nullptr;
         constexpr int UP = 4;                               // pixel pairs per trip: 12 independent loads
         for (int ow0 = 0; ow0 < wo; ow0 += 2 * UP) {
             float a[UP], bv[NH][UP];
@@ -158,9 +162,13 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
                 const bool ok = rok && pok && iw >= 0 && iw < wd;
                 const float av = xrow[(long)(ok ? iw : 0) * CIN];
                 a[u] = ok ? av : 0.f;
-                const float* d = drow + (long)(pok ? ow : 0) * COUT;
+                const long doff = (long)(pok ? ow : 0) * COUT;
 #pragma unroll
-                for (int e = 0; e < NH; ++e) { const float v = d[32 * e + li]; bv[e][u] = pok ? v : 0.f; }
+                for (int e = 0; e < NH; ++e) {
+                    const float v = drow ? drow[doff + 32 * e + li]
+                                         : __builtin_bit_cast(float, (unsigned)drow16[doff + 32 * e + li] << 16);
+                    bv[e][u] = pok ? v : 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < UP; ++u)
@@ -653,12 +661,13 @@ inline int grid_for(long n, int per) { long b = (n + per - 1) / per; return (int
 // host launchers
 // ---------------------------------------------------------------------------------------------------
 hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
+                            unsigned short* z16, unsigned short* y16,
                             int n, int h, int wd, int cin, int cout, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
     const long ngrp = (long)n * ho * ((wo + 31) / 32);
     long nb = (ngrp + 3) / 4;
     if (nb > 4096) nb = 4096;
     const int blocks = (int)nb;
-#define FTE_CF(CI_, CO_) hipLaunchKernelGGL((conv_first_fwd_kernel<CI_, CO_>), dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, n, h, wd, ho, wo, stride, pt, pl)
+#define FTE_CF(CI_, CO_) hipLaunchKernelGGL((conv_first_fwd_kernel<CI_, CO_>), dim3(blocks), dim3(256), 0, st, x, w, bias, alpha, z, y, z16, y16, n, h, wd, ho, wo, stride, pt, pl)
     if (cin == 1 && cout == 64) FTE_CF(1, 64);
     else if (cin == 3 && cout == 64) FTE_CF(3, 64);
     else if (cin == 1 && cout == 32) FTE_CF(1, 32);
@@ -668,11 +677,11 @@ hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, c
     return hipGetLastError();
 }
 int k_conv_first_wgrad_blocks(long npix) { long b = (npix + 511) / 512; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
-hipError_t k_conv_first_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int cin, int cout, int ho, int wo,
+hipError_t k_conv_first_wgrad(const float* x, const float* dz, const unsigned short* dz16, float* part, int n, int h, int wd, int cin, int cout, int ho, int wo,
                               int stride, int pt, int pl, int blocks, hipStream_t st) {
     const long nrows = (long)n * ho;
     const long rpb = (nrows + blocks - 1) / blocks;           // blocks that get no rows write zero partials
-#define FTE_CW(CI_, CO_) hipLaunchKernelGGL((conv_first_wgrad_kernel<CI_, CO_>), dim3(blocks), dim3(256), 0, st, x, dz, part, n, h, wd, ho, wo, stride, pt, pl, rpb)
+#define FTE_CW(CI_, CO_) hipLaunchKernelGGL((conv_first_wgrad_kernel<CI_, CO_>), dim3(blocks), dim3(256), 0, st, x, dz, dz16, part, n, h, wd, ho, wo, stride, pt, pl, rpb)
     if (cin == 1 && cout == 64) FTE_CW(1, 64);
     else if (cin == 3 && cout == 64) FTE_CW(3, 64);
     else if (cin == 1 && cout == 32) FTE_CW(1, 32);

@@ -187,15 +187,28 @@ class SphereNet(Network):
             self.set_variable(k, val)
 
     # ---- buffers that depend on the batch size -----------------------------------------
+    def _storage16(self):
+        """bf16 STORAGE ('bf16s', fte.h): z, y, dz and the skip-path gradient live in HBM as bf16 only; the last conv layer's z / y
+        (the dense layer's operands, 25088 values per image) are kept in fp32 as well."""
+        return _lib.bf16_storage()
+
     def _alloc_acts(self, n):
-        if self._act_n == n:
+        s16 = self._storage16()
+        if self._act_n == n and getattr(self, '_act_s16', False) == s16:
             return
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
+        i16 = dict(dtype=torch.int16, device=dev)
+        self._act_s16 = s16
+        self.y16 = None
         self.z, self.y = [], []
-        for c in self.convs:
-            self.z.append(torch.empty(n, c.hout, c.wout, c.cout, **f32))
-            self.y.append(torch.empty(n, c.hout, c.wout, c.cout, **f32))
+        last = len(self.convs) - 1
+        for l, c in enumerate(self.convs):
+            keep32 = not s16 or l == last
+            self.z.append(torch.empty(n, c.hout, c.wout, c.cout, **f32) if keep32 else None)
+            self.y.append(torch.empty(n, c.hout, c.wout, c.cout, **f32) if keep32 else None)
+        if s16:
+            self.z16 = [torch.empty(n, c.hout, c.wout, c.cout, **i16) for c in self.convs]
         self.emb = torch.empty(n, EMBED, **f32)
         self.s_raw = torch.empty(n, self.cpad, **f32)
         self.G = torch.empty(n, self.cpad, **f32)
@@ -210,8 +223,14 @@ class SphereNet(Network):
         for si in range(4):
             c = [q for q in self.convs if q.stage == si][0]
             shp = (n, c.hout, c.wout, c.cout)
-            self.bwd[si] = dict(dz=[torch.empty(shp, **f32) for _ in range(self._dz_buffers())],
-                                raw=[torch.empty(shp, **f32), torch.empty(shp, **f32)], dzi=0, rawi=0)
+            if s16:      # bf16 only (dz16 / raw16); the last stage keeps one fp32 dz / raw for the dense layer's backward epilogue
+                one = [torch.empty(shp, **f32)] if si == 3 else []
+                self.bwd[si] = dict(dz=one, raw=list(one and [torch.empty(shp, **f32)]), dzi=0, rawi=0,
+                                    dz16=[torch.empty(shp, **i16) for _ in range(self._dz_buffers())],
+                                    raw16=[torch.empty(shp, **i16), torch.empty(shp, **i16)])
+            else:
+                self.bwd[si] = dict(dz=[torch.empty(shp, **f32) for _ in range(self._dz_buffers())],
+                                    raw=[torch.empty(shp, **f32), torch.empty(shp, **f32)], dzi=0, rawi=0)
         need = 4096
         q = _lib.query
         for c in self.convs[1:]:
@@ -239,10 +258,12 @@ class SphereNet(Network):
         if self.y16 is not None and self.y16[0].shape[0] == self._act_n:
             return
         i16 = dict(dtype=torch.int16, device=self.device)
-        self.y16 = [torch.empty(t.shape, **i16) for t in self.y]
+        n = self._act_n
+        self.y16 = [torch.empty(n, c.hout, c.wout, c.cout, **i16) for c in self.convs]
         for si in range(4):
             b = self.bwd[si]
-            b['dz16'] = [torch.empty(b['dz'][0].shape, **i16) for _ in b['dz']]
+            if 'dz16' not in b:
+                b['dz16'] = [torch.empty(b['dz'][0].shape, **i16) for _ in b['dz']]
         if getattr(self, 'w16', None) is None:
             self.w16 = {c.name: torch.empty(3, 3, c.cin, c.cout, **i16) for c in self.convs[1:]}
             self.w16t = {c.name: torch.empty(3, 3, c.cout, c.cin, **i16) for c in self.convs[1:]}
@@ -274,8 +295,10 @@ class SphereNet(Network):
         call = _lib.call
         keep = is_training
         self._images = x
-        copies = self._use_copies()
+        s16 = self._storage16()
+        copies = self._use_copies() or s16
         self._copies_live = copies and keep              # backward of THIS forward may use the bf16 copies
+        self._s16_live = s16 and keep
         if copies:
             self._alloc_copies()
             self._pack_weights(st)
@@ -284,7 +307,15 @@ class SphereNet(Network):
             bv = self.view(c.name + '/biases') if c.has_bias else None
             av = self.view(c.name + '/alpha')
             zz = self.z[l] if keep else None
-            if l == 0:
+            if s16:
+                # bf16 storage: every layer writes bf16 z / y only (+ the unrounded fp32 pair for the last layer: the dense layer reads it)
+                z16 = self.z16[l] if keep else None
+                if l == 0:
+                    call('fte_conv3x3_first_fwd_s16', x, wv, bv, av, z16, self.y16[0], n, c.hin, c.win, c.cin, c.cout, c.stride, st)
+                else:
+                    call('fte_conv2d_fwd_s16', self.y16[l - 1], self.w16t[c.name], bv, av, self.y16[l - 2] if c.second == 1 else None,
+                         z16, self.y16[l], zz, self.y[l], n, c.hin, c.win, c.cin, c.cout, 3, c.stride, self.ws, self.ws_bytes, st)
+            elif l == 0:
                 call('fte_conv3x3_first_fwd', x, wv, bv, av, zz, self.y[0], n, c.hin, c.win, c.cin, c.cout, c.stride, st)
                 if copies:
                     call('fte_to_bf16', self.y[0], self.y16[0], self.y[0].numel(), st)
@@ -424,11 +455,16 @@ class SphereNet(Network):
         b4['rawi'], b4['dzi'] = 0, 0
         call('fte_gemm_nt', self.demb, self.view(fcw), self.z[last], self.view(L[last].name + '/alpha'), L[last].cout,
              d_out, dz_cur, self.view(L[last].name + '/alpha', g), n, EMBED, self.fin, self.ws, self.ws_bytes, st)
-        copies = getattr(self, '_copies_live', False) and self._use_copies()
+        s16 = getattr(self, '_s16_live', False) and self._storage16()
+        copies = s16 or (getattr(self, '_copies_live', False) and self._use_copies())
         dz16_cur = None
+        d16_out = None                                  # bf16 storage: the skip-path gradient (what `d_out` is in fp32)
         if copies:
             dz16_cur = b4['dz16'][0]
             call('fte_to_bf16', dz_cur, dz16_cur, dz_cur.numel(), st)
+        if s16:
+            d16_out = b4['raw16'][0]
+            call('fte_to_bf16', d_out, d16_out, d_out.numel(), st)
         trace = getattr(self, '_trace_dz', None)
         # Second stream: wgrad(l) and dgrad(l) both consume dz(l) and are independent of each other (and of every other layer's
         # wgrad), so the filter gradients are queued on `side` and share the chip with the dgrad chain -- at small per-GPU shards a
@@ -443,13 +479,17 @@ class SphereNet(Network):
         for l in range(last, -1, -1):
             c = L[l]
             if trace is not None:
-                trace[c.name] = dz_cur.clone()
+                trace[c.name] = (dz16_cur if s16 else dz_cur).clone()
             gw = self.view(c.name + '/weights', g)
             if l == 0:
                 if last_w is not None:
                     main.wait_event(last_w)
-                call('fte_conv3x3_first_wgrad', self._images, dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
-                     self.ws, self.ws_bytes, st)
+                if s16:
+                    call('fte_conv3x3_first_wgrad_s16', self._images, dz16_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
+                         self.ws, self.ws_bytes, st)
+                else:
+                    call('fte_conv3x3_first_wgrad', self._images, dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
+                         self.ws, self.ws_bytes, st)
                 break
             if side is not None:
                 side.wait_event(main.record_event())    # dz(l) is complete
@@ -460,9 +500,38 @@ class SphereNet(Network):
                 call('fte_conv3x3_wgrad', self.y[l - 1], dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
                      wws, self.ws_bytes, wst)
             if side is not None:
-                last_w = readers[dz_cur.data_ptr()] = side.record_event()
+                last_w = readers[(dz16_cur if s16 else dz_cur).data_ptr()] = side.record_event()
             p = L[l - 1]
             bp = self.bwd[p.stage]
+            if s16:
+                # bf16 storage: dz and the skip-path gradient exist as bf16 only (same buffer rotation as below)
+                if p.stage != c.stage:
+                    bp['dzi'], bp['rawi'] = 0, 0
+                    raw16_t = bp['raw16'][0]
+                else:
+                    bp['dzi'] = (bp['dzi'] + 1) % len(bp['dz16'])
+                    raw16_t = bp['raw16'][bp['rawi'] ^ 1]
+                dz16_prev = bp['dz16'][bp['dzi']]
+                raw16 = raw16_t if p.second == 1 else None
+                ev = readers.pop(dz16_prev.data_ptr(), None)
+                if ev is not None:
+                    main.wait_event(ev)
+                call('fte_conv2d_dgrad_s16', dz16_cur, self.w16[c.name], d16_out if c.second == 0 else None, self.z16[l - 1],
+                     self.view(p.name + '/alpha'), raw16, dz16_prev, self.view(p.name + '/alpha', g),
+                     self.view(p.name + '/biases', g) if p.has_bias else None,
+                     n, c.hin, c.win, c.cin, c.cout, 3, c.stride, self.ws, self.ws_bytes, st)
+                if raw16 is not None:
+                    d16_out = raw16
+                    if p.stage == c.stage:
+                        bp['rawi'] ^= 1
+                dz16_cur = dz16_prev
+                if p.stage != c.stage:
+                    if last_w is not None:
+                        main.wait_event(last_w)
+                        last_w = None
+                        readers.clear()
+                    yield
+                continue
             addin = d_out if c.second == 0 else None
             if p.stage != c.stage:
                 bp['dzi'], bp['rawi'] = 0, 0

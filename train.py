@@ -61,7 +61,8 @@ def build_parser():
                              "each step's scatter rows and keep ONE table, equal to the single-tower update of the global batch.")
     parser.add_argument('--max_steps', type=int, default=-1, help='Stop after this many steps (smoke runs).')
     parser.add_argument('--mfma_dtype', type=str, default='f32',
-                        help='f32 (the reference arithmetic) or bf16 (bf16 MFMA operands, fp32 accumulate and storage).')
+                        help='f32 (the reference arithmetic), bf16 (bf16 MFMA operands, fp32 accumulate and storage) or bf16s (bf16 operands and bf16 '
+                             'storage of activations / inter-layer gradients; fp32 accumulate, sums and master weights: SphereNet).')
     return parser
 
 
