@@ -5,7 +5,7 @@ TAG="${1:-r2}"; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py --steps 20 --warmup 5 "$@" > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/p_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/p_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/p_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/p_write.log 2>&1

@@ -1,0 +1,15 @@
+"""Copies what the judge reads from gpurun_out/prof_<tag>[_mode]/ (scripts/collect_all.sh, run on the GPU box) into profiles/:
+kernel stats, PMC summary, traffic file, bench lines.   python scripts/keep_profiles.py r3"""
+import os, shutil, sys
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for mode in ('', '_bf16', '_bf16s'):
+    d = os.path.join(root, 'gpurun_out', 'prof_%s%s' % (tag, mode))
+    if not os.path.isdir(d):
+        continue
+    pre = os.path.join(root, 'profiles', tag + mode + '_')
+    for src, dst in (('kernel_stats.csv', 'bench_kernel_stats.csv'), ('pmc_summary.csv', 'pmc_hbm_traffic_summary.csv'),
+                     ('traffic.json', 'traffic.json'), ('bench_final.json', 'bench_n1.json'), ('bench.json', 'bench_n1_first.json')):
+        if os.path.exists(os.path.join(d, src)):
+            shutil.copy(os.path.join(d, src), pre + dst)
+            print('kept', pre + dst)

@@ -16,7 +16,8 @@ if torch.cuda.is_available():
 
 
 @pytest.mark.parametrize('n,h,w,c,stride', [(3, 14, 14, 128, 1), (2, 28, 28, 64, 2), (2, 7, 9, 256, 2), (1, 4, 4, 512, 1),
-                                            (5, 13, 8, 192, 1), (64, 14, 14, 128, 2)])
+                                            (5, 13, 8, 192, 1), (64, 14, 14, 128, 2),
+                                            (2, 13, 8, 64, 2), (3, 28, 27, 128, 2), (2, 5, 5, 64, 2)])       # stride 2 with SAME pads (1,0) / (0,1) / (1,1): the parity-patch dgrad
 def test_depthwise_conv_kernels(n, h, w, c, stride):
     rng = np.random.default_rng(n * 100 + c + stride)
     x = rng.standard_normal((n, h, w, c)); wt = rng.standard_normal((3, 3, c, 1)) * 0.3

@@ -1664,6 +1664,79 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
     }
 }
 
+// Data gradient at stride 2 by PARITY PATCHES.  dx[iy,ix] = sum_{r,q} dy[(iy+pt-r)/2, (ix+pl-q)/2] * w[r,q] over the taps for which
+// both quotients are whole: the four pixels of a 2x2 patch of dx (rows 2a, 2a+1; columns 2b, 2b+1) draw on the SAME 2x2 window of dy
+// -- rows a-1+pt, a+pt, columns b-1+pl, b+pl -- with 4 / 2 / 2 / 1 of the nine taps.  A thread owns two horizontally adjacent
+// patches of one channel quad: 6 dy vectors in, 8 dx vectors out, every tap's weight held in registers as a [patch row][dy row] x
+// [patch column][dy column] table with zeros where the tap does not exist (16 multiply-adds per patch, 9 of them real): no
+// division, no branch on the parity, and 0.75 loads per output vector instead of the 2.25 + 2.25 (weights) of the
+// pixel-per-thread gather above (44-52 % of the HBM roofline; the grid stride is a multiple of the channel-quad count, so the
+// weights are loaded once per thread).
+__global__ __launch_bounds__(256) void dwconv3x3_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int n, int h, int wd, int c,
+                                                                 int ho, int wo, int pt, int pl) {
+    const int c4n = c >> 2;
+    const int ph = (h + 1) >> 1, pw2 = (((wd + 1) >> 1) + 1) >> 1;        // patch rows, PAIRS of patch columns
+    const long total = (long)n * ph * pw2 * c4n;
+    const long step = (long)gridDim.x * 256;
+    const bool inv = step % c4n == 0;                                    // this thread keeps its channel quad
+    f32x4 wt[2][2][2][2];                                                // [dx row parity][dy row k][dx column parity][dy column j]
+    auto load_w = [&](int c4) {
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = py + pt - 2 * (k - 1 + pt);               // iy = 2a + py, sy = a - 1 + pt + k  ->  r = iy + pt - 2 sy
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int q = px + pl - 2 * (j - 1 + pl);
+                        const bool ok = r >= 0 && r < 3 && q >= 0 && q < 3;
+                        wt[py][k][px][j] = ok ? *reinterpret_cast<const f32x4*>(w + (r * 3 + q) * c + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+    };
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (inv && i < total) load_w((int)(i % c4n));
+    for (; i < total; i += step) {
+        int c4, bq, a, img;
+        unflat4(i, total <= 0xffffffffL, c4n, pw2, ph, c4, bq, a, img);
+        if (!inv) load_w(c4);
+        const int b0 = 2 * bq;                                           // first of the two patch columns
+        f32x4 v[2][3];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int sy = a - 1 + pt + k;
+            const bool rok = sy >= 0 && sy < ho;
+            const float* rowp = dy + ((long)(img * ho + (rok ? sy : 0)) * wo) * c + c4 * 4;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sx = b0 - 1 + pl + j;
+                v[k][j] = (rok && sx >= 0 && sx < wo) ? *reinterpret_cast<const f32x4*>(rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const int iy = 2 * a + py;
+            if (iy >= h) continue;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int ix = 2 * (b0 + pb) + px;
+                    if (ix >= wd) continue;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc += v[k][pb + j] * wt[py][k][px][j];
+                    *reinterpret_cast<f32x4*>(dx + (((long)(img * h + iy) * wd + ix) * c) + c4 * 4) = acc;
+                }
+        }
+    }
+}
+
 // dw[r,q,c] partials: block = Q channel quads x (256/Q) lanes over one chunk of 4-pixel groups (4 consecutive outputs of
 // one row): a lane loads the group's 4 dy vectors and each source column of the 3-row window once (3*(3*S+3) + 4 loads
 // per 4 pixels instead of 40)
@@ -1805,9 +1878,15 @@ hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int
         hipLaunchKernelGGL((dwconv3x3_win_kernel<true, 1>), grid, dim3(256), 0, st, dy, w, dx, n, ho, wo, c, h, wd, pt, pl);
         return hipGetLastError();
     }
-    const long total = (long)n * h * wd * (c / 4);
-    const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
-    hipLaunchKernelGGL((dwconv3x3_kernel<true, 2>), grid, dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
+    static const bool old_gather = getenv("FTE_DW_DGRAD_S2") && atoi(getenv("FTE_DW_DGRAD_S2")) == 0;      // A/B hook: the pixel-per-thread gather
+    if (old_gather) {
+        const long total = (long)n * h * wd * (c / 4);
+        const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+        hipLaunchKernelGGL((dwconv3x3_kernel<true, 2>), grid, dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
+        return hipGetLastError();
+    }
+    const long total = (long)n * ((h + 1) / 2) * ((((wd + 1) / 2) + 1) / 2) * (c / 4);
+    hipLaunchKernelGGL(dwconv3x3_dgrad_s2_kernel, dim3(grid_for_c(total, c)), dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
 static int dw_quads(int c) { return c >= 256 ? 64 : (c >= 128 ? 32 : 16); }
