@@ -290,6 +290,35 @@ int fte_conv3x3_first_fwd_s16(const float* x, const float* w, const float* bias,
 int fte_conv3x3_first_wgrad_s16(const float* x, const uint16_t* dz16, float* dw, int n, int h, int wd, int cin, int cout, int stride,
                                 void* ws, size_t ws_bytes, void* stream);
 
+/* bf16 STORAGE for the BN nets (nets/resnet.py, nets/resnext.py: BASELINE.json configs[2] "bf16").  Same contract as above: the
+ * tensors between the layers are bf16 in HBM, every kernel computes in fp32 and rounds once where it stores.  `flags` says which
+ * tensors of a call are bf16: FTE_S16_Z = the pre-activation side (z, and dz in backward), FTE_S16_A = the activation side (y, the
+ * shortcut `res`, dy, the masked gradient g_out); the other side is fp32 (the stem, whose conv output comes from an fp32 GEMM).
+ * Pointers are void*: bf16 (uint16_t) or float elements per the flags.  c % 4 == 0 and c >= 32.
+ *   fte_bn_train_fwd_s16 / fte_bn_infer_fwd_s16   = fte_bn_train_fwd / fte_bn_infer_fwd
+ *   fte_bn_train_bwd_s16   the three backward forms in one: g_out + y given = the residual form (fte_bn_train_bwd_res), scale + shift
+ *                          given = the ReLU mask recomputed from z (fte_bn_train_bwd_zmask), neither = fte_bn_train_bwd (y = optional mask)
+ *   fte_relu_bwd_s16, fte_maxpool3x3s2_{fwd,bwd}_s16, fte_gap_{fwd,bwd}_s16 (features / their gradient stay fp32)
+ *   fte_gconv3x3_bf16_s16, fte_gconv3x3_wgrad_bf16_s16   the grouped 3x3 on the bf16 MFMA with bf16 x / y / dz in HBM (dw fp32) */
+#define FTE_S16_Z 1
+#define FTE_S16_A 2
+int fte_bn_train_fwd_s16(const void* z, const float* gamma, const float* beta, const void* res, void* y,
+                         float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                         long rows, int c, float eps, float decay, int relu, int flags, void* ws, size_t ws_bytes, void* stream);
+int fte_bn_infer_fwd_s16(const void* z, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                         const void* res, void* y, float* scale, float* shift, long rows, int c, float eps, int relu, int flags, void* stream);
+int fte_bn_train_bwd_s16(const void* dy, const void* y, const void* z, const float* gamma, const float* mean, const float* rstd,
+                         const float* scale, const float* shift, void* g_out, void* dz, float* dgamma, float* dbeta,
+                         long rows, int c, int flags, void* ws, size_t ws_bytes, void* stream);
+int fte_relu_bwd_s16(const uint16_t* dy16, const uint16_t* y16, uint16_t* g16, long n, void* stream);
+int fte_maxpool3x3s2_fwd_s16(const uint16_t* x16, uint16_t* y16, uint8_t* idx, int n, int h, int wd, int c, void* stream);
+int fte_maxpool3x3s2_bwd_s16(const uint16_t* dy16, const uint8_t* idx, uint16_t* dx16, int n, int h, int wd, int c, void* stream);
+int fte_gap_fwd_s16(const uint16_t* x16, float* y, int n, int hw, int c, void* stream);
+int fte_gap_bwd_s16(const float* dy, uint16_t* dx16, int n, int hw, int c, void* stream);
+int fte_gconv3x3_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* y16, int n, int h, int wd, int c, int stride, int dgrad, void* stream);
+int fte_gconv3x3_wgrad_bf16_s16(const uint16_t* x16, const uint16_t* dz16, float* dw, int n, int h, int wd, int c, int groups, int stride,
+                                void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * ShuffleNet-v2 (nets/shufflenet_v2.py).  Depthwise 3x3, TF-SAME, stride 1 or 2: the DepthwiseConv2dNative half of
  * layers.separable_conv2d (:98,104; the pointwise half is fte_conv2d_* with ksize 1).  x [n,h,wd,c], w [3,3,c].

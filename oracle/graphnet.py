@@ -12,13 +12,20 @@ import numpy as np
 from . import ops
 
 
-def forward(graph, params, images, labels=None, train=True, masks=None, state=None):
-    """graph: list of tuples.  Returns env (all tensors), caches."""
+def forward(graph, params, images, labels=None, train=True, masks=None, state=None, stored=None):
+    """graph: list of tuples.  Returns env (all tensors), caches.
+    `stored` (bf16 storage, ops.storage_rounding): names of the tensors the engine keeps in HBM -- the net's `h16` set, i.e. the
+    outputs of its FUSED ops (a BN + add + ReLU group stores only the ReLU's output) -- each rounded once, where it is computed,
+    before any consumer reads it."""
     env = {'images': images}
     cache = {}
     new_state = {}
+    prev_out = None
     for op in graph:
+        if stored and prev_out in stored:
+            env[prev_out] = ops.stored(env[prev_out])
         kind, out = op[0], op[1]
+        prev_out = out
         if kind == 'conv':          # ('conv', out, inp, wname, stride)
             _, _, inp, wname, stride = op
             env[out] = ops.conv2d_fwd(env[inp], params[wname], stride)
@@ -76,6 +83,8 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
             env[out] = ops.channel_shuffle(np.concatenate([env[op[2]], env[op[3]]], axis=-1), op[4])
         else:
             raise ValueError(kind)
+    if stored and prev_out in stored:
+        env[prev_out] = ops.stored(env[prev_out])
     return env, cache, new_state
 
 
@@ -101,7 +110,7 @@ def noise_bands(graph, params, images, masks=None, state=None):
     return out
 
 
-def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='fp32', bands=None):
+def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='fp32', bands=None, stored=None):
     """dout: {tensor name: gradient}.  Returns (param grads, tensor grads).
     `kink` (optional): tensors of the implementation under test.  ReLU's derivative jumps at 0 and a
     max-pool routes its gradient to ONE of several near-equal candidates; where the float64 values are
@@ -124,6 +133,8 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
 
     def acc(d, k, v):
         d[k] = v if k not in d else d[k] + v
+        if d is gt and stored and k in stored:       # bf16 storage: the gradient of a stored tensor is itself stored, rounded where it is written
+            d[k] = ops.stored(d[k])
     for op in reversed(graph):
         kind, out = op[0], op[1]
         if out not in gt:
@@ -469,13 +480,13 @@ def perturb(p, seed, scale=0.1):
 
 
 def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None, grad_scale=None, state=None, kink=None,
-                   center=None, triplet_margin='off', focal=None, kink_mode='fp32', bands=None):
+                   center=None, triplet_margin='off', focal=None, kink_mode='fp32', bands=None, stored=None):
     """softmax-CE (+ center loss) or batch-hard triplet, + L2 on conv / fc weights (gamma, beta, biases are not
     regularised).  center = dict(centers=[C,D], alpha=, weight=): loss.py:29-45 on the pooled features, added to the
     total loss with `weight` (the reference leaves the wiring to the caller, loss.py:43).  triplet_margin != 'off':
     the net has no classifier; the loss is the MEAN of loss.py:47-78's per-sample vector.
     Returns (losses, grads incl. wd*w, env, new moving stats [, new centers])."""
-    env, cache, new_state = forward(graph, params, images, train=True, masks=masks, state=state)
+    env, cache, new_state = forward(graph, params, images, train=True, masks=masks, state=state, stored=stored)
     n = images.shape[0]
     dout, losses, extra = {}, [], {}
     if triplet_margin != 'off':
@@ -495,7 +506,7 @@ def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None,
             scale = center['weight'] * (1.0 if grad_scale is None else grad_scale * n)
             dout['features'] = dfe * scale
             extra['centers'] = newc
-    gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink, kink_mode=kink_mode, bands=bands)
+    gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink, kink_mode=kink_mode, bands=bands, stored=stored)
     reg_names = [k for k in params if k.endswith('weights')]      # weights, depthwise_weights, pointwise_weights
     reg = ops.l2_reg([params[k] for k in reg_names], weight_decay)
     for k in reg_names:

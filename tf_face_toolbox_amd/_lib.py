@@ -71,6 +71,16 @@ _SIGS = {
     'fte_conv2d_dgrad_s16': (c_int, [_P] * 9 + [c_int] * 7 + [_P, c_size_t, _P]),
     'fte_conv3x3_first_fwd_s16': (c_int, [_P] * 6 + [c_int] * 6 + [_P]),
     'fte_conv3x3_first_wgrad_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
+    'fte_bn_train_fwd_s16': (c_int, [_P] * 11 + [c_long, c_int, c_float, c_float, c_int, c_int, _P, c_size_t, _P]),
+    'fte_bn_infer_fwd_s16': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_int, c_int, _P]),
+    'fte_bn_train_bwd_s16': (c_int, [_P] * 12 + [c_long, c_int, c_int, _P, c_size_t, _P]),
+    'fte_relu_bwd_s16': (c_int, [_P] * 3 + [c_long, _P]),
+    'fte_maxpool3x3s2_fwd_s16': (c_int, [_P] * 3 + [c_int] * 4 + [_P]),
+    'fte_maxpool3x3s2_bwd_s16': (c_int, [_P] * 3 + [c_int] * 4 + [_P]),
+    'fte_gap_fwd_s16': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
+    'fte_gap_bwd_s16': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
+    'fte_gconv3x3_bf16_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
+    'fte_gconv3x3_wgrad_bf16_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_set_mfma_dtype': (c_int, [c_int]),
     'fte_get_mfma_dtype': (c_int, []),
     'fte_dwconv3x3_fwd': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),

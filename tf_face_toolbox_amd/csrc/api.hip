@@ -926,6 +926,58 @@ int fte_gap_bwd(const float* dy, float* dx, int n, int hw, int c, void* stream) 
     if (!dy || !dx || n <= 0 || hw <= 0) return FTE_EINVAL;
     return rc(l_gap_bwd(dy, dx, n, hw, c, (hipStream_t)stream));
 }
+// ---- bf16 STORAGE twins of the BN-net layers (fte.h): flags bit 0 (FTE_S16_Z) = z / dz are bf16, bit 1 (FTE_S16_A) = y / shortcut /
+// dy / masked gradient are bf16; channel counts of the float4 layouts only (c % 4 == 0, c >= 32)
+static inline const float* f32p(const void* p) { return reinterpret_cast<const float*>(p); }
+static inline float* f32p(void* p) { return reinterpret_cast<float*>(p); }
+int fte_bn_train_fwd_s16(const void* z, const float* gamma, const float* beta, const void* res, void* y,
+                         float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                         long rows, int c, float eps, float decay, int relu, int flags, void* ws, size_t ws_bytes, void* stream) {
+    if (!z || !gamma || !beta || !y || !mean || !rstd || !scale || !shift || rows <= 0 || c % 4 || c < 32 || (flags & ~3)) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    hipError_t e = l_bn_train_stats(f32p(z), gamma, beta, rows, c, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
+                                    (float*)ws, (hipStream_t)stream, flags);
+    if (e != hipSuccess) return (int)e;
+    return rc(l_bn_apply(f32p(z), scale, shift, f32p(res), f32p(y), rows, c, relu, (hipStream_t)stream, flags));
+}
+int fte_bn_infer_fwd_s16(const void* z, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                         const void* res, void* y, float* scale, float* shift, long rows, int c, float eps, int relu, int flags, void* stream) {
+    if (!z || !gamma || !beta || !moving_mean || !moving_var || !y || !scale || !shift || rows <= 0 || c % 4 || (flags & ~3)) return FTE_EINVAL;
+    hipError_t e = l_bn_infer_coef(gamma, beta, moving_mean, moving_var, eps, c, scale, shift, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return rc(l_bn_apply(f32p(z), scale, shift, f32p(res), f32p(y), rows, c, relu, (hipStream_t)stream, flags));
+}
+int fte_bn_train_bwd_s16(const void* dy, const void* y, const void* z, const float* gamma, const float* mean, const float* rstd,
+                         const float* scale, const float* shift, void* g_out, void* dz, float* dgamma, float* dbeta,
+                         long rows, int c, int flags, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !z || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta || rows <= 0 || c % 4 || c < 32 || (flags & ~3)) return FTE_EINVAL;
+    if ((g_out && !y) || ((scale == nullptr) != (shift == nullptr)) || (scale && (g_out || y))) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    return rc(l_bn_bwd(f32p(dy), f32p(y), f32p(z), gamma, mean, rstd, scale, shift, f32p(g_out), f32p(dz), dgamma, dbeta, rows, c,
+                       (float*)ws, (hipStream_t)stream, flags));
+}
+int fte_relu_bwd_s16(const uint16_t* dy16, const uint16_t* y16, uint16_t* g16, long n, void* stream) {
+    if (!dy16 || !y16 || !g16 || n <= 0 || n % 4) return FTE_EINVAL;
+    return rc(l_relu_bwd(f32p(dy16), f32p(y16), f32p(g16), n, (hipStream_t)stream, 2));
+}
+int fte_maxpool3x3s2_fwd_s16(const uint16_t* x16, uint16_t* y16, uint8_t* idx, int n, int h, int wd, int c, void* stream) {
+    if (!x16 || !y16 || !idx || n <= 0 || c % 4) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, 2), pw = same_pads(wd, 3, 2);
+    return rc(l_maxpool_fwd(f32p(x16), f32p(y16), idx, n, h, wd, c, ph.out, pw.out, ph.before, pw.before, (hipStream_t)stream, 2));
+}
+int fte_maxpool3x3s2_bwd_s16(const uint16_t* dy16, const uint8_t* idx, uint16_t* dx16, int n, int h, int wd, int c, void* stream) {
+    if (!dy16 || !idx || !dx16 || n <= 0 || c % 4) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, 2), pw = same_pads(wd, 3, 2);
+    return rc(l_maxpool_bwd(f32p(dy16), idx, f32p(dx16), n, h, wd, c, ph.out, pw.out, ph.before, pw.before, (hipStream_t)stream, 2));
+}
+int fte_gap_fwd_s16(const uint16_t* x16, float* y, int n, int hw, int c, void* stream) {
+    if (!x16 || !y || n <= 0 || hw <= 0 || c <= 0 || c % 4) return FTE_EINVAL;
+    return rc(l_gap_fwd(f32p(x16), y, n, hw, c, (hipStream_t)stream, 2));
+}
+int fte_gap_bwd_s16(const float* dy, uint16_t* dx16, int n, int hw, int c, void* stream) {
+    if (!dy || !dx16 || n <= 0 || hw <= 0) return FTE_EINVAL;
+    return rc(l_gap_bwd(dy, f32p(dx16), n, hw, c, (hipStream_t)stream, 2));
+}
 int fte_dropout_fwd(const float* x, float* mask, float* y, long n, float keep_prob, uint64_t seed, void* stream) {
     if (!x || !mask || !y || n <= 0 || !(keep_prob > 0.f)) return FTE_EINVAL;
     return rc(l_dropout_fwd(x, mask, y, n, keep_prob, seed, (hipStream_t)stream));
@@ -961,6 +1013,16 @@ int fte_gconv3x3_bf16(const float* x, const uint16_t* wpk, float* y, int n, int 
     if (!dgrad) return rc(l_gconv_mfma16(x, wpk, y, n, ph.out, pw.out, c, h, wd, 1, ph.before, pw.before, (hipStream_t)stream));
     return rc(l_gconv_mfma16(x, wpk, y, n, h, wd, c, ph.out, pw.out, 2, ph.before, pw.before, (hipStream_t)stream));
 }
+int fte_gconv3x3_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* y16, int n, int h, int wd, int c, int stride, int dgrad, void* stream) {
+    if (!x16 || !wpk || !y16 || n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32 || (stride != 1 && stride != 2) ||
+        (long)n * h * wd >= ((long)1 << 31)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    const float* x = f32p(x16);
+    float* y = f32p(y16);
+    if (stride == 1) return rc(l_gconv_mfma16(x, wpk, y, n, h, wd, c, h, wd, 0, 1, 1, (hipStream_t)stream, 1));
+    if (!dgrad) return rc(l_gconv_mfma16(x, wpk, y, n, ph.out, pw.out, c, h, wd, 1, ph.before, pw.before, (hipStream_t)stream, 1));
+    return rc(l_gconv_mfma16(x, wpk, y, n, h, wd, c, ph.out, pw.out, 2, ph.before, pw.before, (hipStream_t)stream, 1));
+}
 size_t fte_gconv3x3_wgrad_bf16_ws_bytes(int n, int h, int wd, int c, int groups, int stride) {
     if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || groups <= 0 || c % groups || c % 32 || (stride != 1 && stride != 2)) return 0;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
@@ -976,6 +1038,17 @@ int fte_gconv3x3_wgrad_bf16(const float* x, const float* dz, float* dw, int n, i
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     return rc(l_gconv_wgrad16(x, dz, (float*)ws, dw, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before,
                               l_gconv_wgrad16_chunks((long)n * ph.out * pw.out, c), (hipStream_t)stream));
+}
+int fte_gconv3x3_wgrad_bf16_s16(const uint16_t* x16, const uint16_t* dz16, float* dw, int n, int h, int wd, int c, int groups, int stride,
+                                void* ws, size_t ws_bytes, void* stream) {
+    if (!x16 || !dz16 || !dw || n <= 0 || h <= 0 || wd <= 0 || groups <= 0 || c % groups || c % 32 || (stride != 1 && stride != 2) ||
+        (long)n * h * wd >= ((long)1 << 31)) return FTE_EINVAL;
+    const int gw = c / groups;
+    if (gw != 4 && gw != 8 && gw != 16 && gw != 32) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_gconv3x3_wgrad_bf16_ws_bytes(n, h, wd, c, groups, stride)) return FTE_EWORKSPACE;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_gconv_wgrad16(f32p(x16), f32p(dz16), (float*)ws, dw, n, h, wd, c, groups, ph.out, pw.out, stride, ph.before, pw.before,
+                              l_gconv_wgrad16_chunks((long)n * ph.out * pw.out, c), (hipStream_t)stream, 1));
 }
 int fte_gconv3x3_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int stride, void* stream) {
     if (!dz || !w || !dx || n <= 0 || groups <= 0 || c % groups || (stride != 1 && stride != 2)) return FTE_EINVAL;

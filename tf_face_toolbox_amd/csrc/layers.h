@@ -7,19 +7,19 @@ constexpr int BN_MAX_SPLITS = 512;     // row splits of the two-level per-channe
 
 hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* beta, long rows, int C, float eps, float decay,
                             float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var,
-                            float* part, hipStream_t st);
+                            float* part, hipStream_t st, int flags = 0);
 hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int C,
                            float* scale, float* shift, hipStream_t st);
 hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, const float* res, float* y, long rows, int C,
-                      int relu, hipStream_t st);
-hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st);
+                      int relu, hipStream_t st, int flags = 0);
+hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st, int flags = 0);
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
                     const float* rstd, const float* zsc, const float* zsf, float* gout, float* dz, float* dgamma, float* dbeta,
-                    long rows, int C, float* part, hipStream_t st);
-hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
-hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st);
-hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st);
-hipError_t l_gap_bwd(const float* dy, float* dx, int n, int hw, int c, hipStream_t st);
+                    long rows, int C, float* part, hipStream_t st, int flags = 0);
+hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st, int flags = 0);
+hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st, int flags = 0);
+hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st, int flags = 0);
+hipError_t l_gap_bwd(const float* dy, float* dx, int n, int hw, int c, hipStream_t st, int flags = 0);
 hipError_t l_dropout_fwd(const float* x, float* mask, float* y, long n, float keep, uint64_t seed, hipStream_t st);
 hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, float inv_keep, hipStream_t st);
 hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
@@ -30,10 +30,10 @@ hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int 
                          int stride, int pt, int pl, hipStream_t st);
 hipError_t l_gconv_pack16(const float* w, unsigned short* wf, unsigned short* wd, int c, int groups, hipStream_t st);
 hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
-                          int mode, int pt, int pl, hipStream_t st);
+                          int mode, int pt, int pl, hipStream_t st, int h16 = 0);
 int l_gconv_wgrad16_chunks(long npix, int c);
 hipError_t l_gconv_wgrad16(const float* x, const float* dz, float* part, float* dw, int n, int h, int wd, int c, int groups,
-                           int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st);
+                           int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st, int h16 = 0);
 int l_gconv_wgrad_chunks(long npix, int c, int gw);
 hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, int h, int wd, int c, int groups, int ho, int wo,
                          int stride, int pt, int pl, int chunks, hipStream_t st);

@@ -29,6 +29,39 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// bf16 STORAGE of the BN nets (fte.h, "bf16 STORAGE": the *_s16 layer entry points).  A tensor is either fp32 or bf16 in HBM; the
+// kernels below take the choice as template flags -- ZH: the pre-activation side (z, dz), AH: the activation side (y, the
+// shortcut, dy, the masked gradient) -- and move 4 channels per lane either way (16 or 8 bytes).  Arithmetic is fp32; a value
+// is rounded to nearest even once, where it is stored.  Pointers stay `float*` in the signatures; with the flag set they
+// address bf16 elements.
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned u32x2_l __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4_s __attribute__((ext_vector_type(4)));
+template <bool H>
+__device__ __forceinline__ f32x4 ldq(const float* p, long off) {            // 4 consecutive elements at element offset `off`
+    if constexpr (H) {
+        const u32x2_l u = *reinterpret_cast<const u32x2_l*>(reinterpret_cast<const unsigned short*>(p) + off);
+        return f32x4{__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                     __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+    } else {
+        return *reinterpret_cast<const f32x4*>(p + off);
+    }
+}
+template <bool H>
+__device__ __forceinline__ void stq(float* p, long off, const f32x4 v) {
+    if constexpr (H) {
+        *reinterpret_cast<u32x2_l*>(reinterpret_cast<unsigned short*>(p) + off) = __builtin_bit_cast(u32x2_l, __builtin_convertvector(v, bf16x4_s));
+    } else {
+        *reinterpret_cast<f32x4*>(p + off) = v;
+    }
+}
+template <bool H>
+__device__ __forceinline__ void st1(float* p, long off, float v) {
+    if constexpr (H) reinterpret_cast<unsigned short*>(p)[off] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    else p[off] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // In-launch finalize of the split reductions (BN statistics, BN backward sums): instead of a second, 7-8 us launch that merges
 // the row splits (112 of ShuffleNet-v2's 688 launches per step were those), the blocks of a channel column hand their partials
 // over inside the launch.  Two levels so that no block reads more than a few tens of KB: the splits of a column form groups of
@@ -172,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 
 // float4 version: Q channel quads per row segment (Q = min(C/4, 64)), RL = 256/Q row lanes; a wave reads
 // 1 KiB (C >= 256) or several whole rows per instruction, two rows in flight per lane.
-template <int Q>
+template <int Q, bool ZH = false>
 __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restrict__ x, float* __restrict__ part,
                                                           long rows, int C, long rows_per_split, SplitTail tail, BnFwdOut fin) {
     constexpr int RL = 256 / Q;
@@ -184,16 +217,16 @@ __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restric
     const bool ok = ch < C;
     if (ok) {
         long r = r0 + rl;
-        if (r < r1) shift = *reinterpret_cast<const f32x4*>(x + r * C + ch);
+        if (r < r1) shift = ldq<ZH>(x, r * C + ch);
         for (; r + RL < r1; r += 2 * RL) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + ch) - shift;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(x + (r + RL) * C + ch) - shift;
+            const f32x4 a = ldq<ZH>(x, r * C + ch) - shift;
+            const f32x4 b = ldq<ZH>(x, (r + RL) * C + ch) - shift;
             s += a + b;
             ss += a * a + b * b;
             n += 2.f;
         }
         if (r < r1) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + ch) - shift;
+            const f32x4 a = ldq<ZH>(x, r * C + ch) - shift;
             s += a;
             ss += a * a;
             n += 1.f;
@@ -236,7 +269,7 @@ __global__ __launch_bounds__(256) void bn_stats_v4_kernel(const float* __restric
     if (fok) bn_finalize_channel(fin, fch, fN, fmean, fM2);
 }
 
-template <int Q>
+template <int Q, bool ZH = false, bool AH = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                                const float* __restrict__ z, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ zsc,
@@ -255,18 +288,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
         f32x4 sc = mu, sf = mu;
         if (zsc) { sc = *reinterpret_cast<const f32x4*>(zsc + ch); sf = *reinterpret_cast<const f32x4*>(zsf + ch); }
         auto one = [&](long r) {
-            f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + ch);
-            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + r * C + ch);
+            f32x4 g = ldq<AH>(dy, r * C + ch);
+            const f32x4 zz = ldq<ZH>(z, r * C + ch);
             if (zsc) {                                   // ReLU mask recomputed from z (the output is not read)
                 const f32x4 m = bn_affine(zz, sc, sf);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
             } else if (ymask) {
-                const f32x4 m = *reinterpret_cast<const f32x4*>(ymask + r * C + ch);
+                const f32x4 m = ldq<AH>(ymask, r * C + ch);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
             }
-            if (gout) *reinterpret_cast<f32x4*>(gout + r * C + ch) = g;      // the masked gradient as a by-product (residual BN)
+            if (gout) stq<AH>(gout, r * C + ch, g);      // the masked gradient as a by-product (residual BN)
             sg += g;
             sgx += g * ((zz - mu) * rs);
         };
@@ -383,12 +416,10 @@ __global__ __launch_bounds__(256) void bn_infer_coef_kernel(const float* __restr
 // The launchers size the grid so that the grid stride is a multiple of C/4 (grid_for_c): a thread then stays on ONE channel
 // quad for its whole walk, and scale / shift are loaded once instead of being re-derived -- with a 64-bit modulo -- for every
 // 16 bytes (`inv`; any other grid still works through the per-iteration path).
+template <bool ZH = false, bool AH = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
                                                        float* __restrict__ y, long n4, int C, int relu) {
-    const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
-    const f32x4* r4 = reinterpret_cast<const f32x4*>(res);
-    f32x4* y4 = reinterpret_cast<f32x4*>(y);
     const unsigned q = (unsigned)C >> 2;
     const long step = (long)gridDim.x * 256;
     const bool inv = step % q == 0;
@@ -400,28 +431,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             c = (int)((unsigned)(i % q) << 2);
             sc = *reinterpret_cast<const f32x4*>(scale + c); sf = *reinterpret_cast<const f32x4*>(shift + c);
         }
-        f32x4 v = bn_affine(z4[i], sc, sf);
-        if (res) v += r4[i];
+        f32x4 v = bn_affine(ldq<ZH>(z, i * 4), sc, sf);
+        if (res) v += ldq<AH>(res, i * 4);
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        y4[i] = v;
+        stq<AH>(y, i * 4, v);
     }
 }
 
 // g = dy * (y > 0)
+template <bool AH = false>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                        float* __restrict__ g, long n4) {
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
-    const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
-    f32x4* g4 = reinterpret_cast<f32x4*>(g);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 d = d4[i];
-        const f32x4 yy = y4[i];
+        f32x4 d = ldq<AH>(dy, i * 4);
+        const f32x4 yy = ldq<AH>(y, i * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = yy[e] > 0.f ? d[e] : 0.f;
-        g4[i] = d;
+        stq<AH>(g, i * 4, d);
     }
 }
 
@@ -487,14 +516,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     coef[2 * C + ch] = -gr * sg / count - b * mean[ch];
 }
 
+template <bool ZH = false, bool AH = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                            const float* __restrict__ z, const float* __restrict__ coef,
                                                            const float* __restrict__ zsc, const float* __restrict__ zsf,
                                                            float* __restrict__ dz, long n4, int C) {
-    const f32x4* d4 = reinterpret_cast<const f32x4*>(dy);
-    const f32x4* m4 = reinterpret_cast<const f32x4*>(ymask);
-    const f32x4* z4 = reinterpret_cast<const f32x4*>(z);
-    f32x4* o4 = reinterpret_cast<f32x4*>(dz);
     const unsigned q = (unsigned)C >> 2;
     const long step = (long)gridDim.x * 256;
     const bool inv = step % q == 0;                            // one channel quad per thread (see bn_apply_kernel)
@@ -509,18 +535,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     coefs(i);
     for (; i < n4; i += step) {
         if (!inv) coefs(i);
-        f32x4 g = d4[i];
-        const f32x4 zz = z4[i];
+        f32x4 g = ldq<AH>(dy, i * 4);
+        const f32x4 zz = ldq<ZH>(z, i * 4);
         if (zsc) {
             const f32x4 m = bn_affine(zz, msc, msf);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
         } else if (ymask) {
-            const f32x4 m = m4[i];
+            const f32x4 m = ldq<AH>(ymask, i * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
         }
-        o4[i] = A * g + B * zz + C0;
+        stq<ZH>(dz, i * 4, A * g + B * zz + C0);
     }
 }
 
@@ -528,6 +554,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // max_pool 3x3 stride 2 SAME.  idx = window position (0..8) of the FIRST maximum; backward is a gather
 // over the <= 4 windows that cover an input pixel (ordered, no atomics).
 // ---------------------------------------------------------------------------------------------------
+template <bool AH = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int n, int h, int w, int c,
                                                           int ho, int wo, int pt, int pl) {
@@ -544,17 +571,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
             for (int s = 0; s < 3; ++s) {
                 const int iw = ow * 2 + s - pl;
                 if (ih < 0 || ih >= h || iw < 0 || iw >= w) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((long)(img * h + ih) * w + iw) * c + c4 * 4);
+                const f32x4 v = ldq<AH>(x, ((long)(img * h + ih) * w + iw) * c + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (v[e] > best[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
             }
         }
-        *reinterpret_cast<f32x4*>(y + i * 4) = best;
+        stq<AH>(y, i * 4, best);
         *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
     }
 }
 
+template <bool AH = false>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                           float* __restrict__ dx, int n, int h, int w, int c,
                                                           int ho, int wo, int pt, int pl) {
@@ -572,7 +600,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                 const int s = iw - (ow * 2 - pl);
                 const long o = (((long)(img * ho + oh) * wo + ow) * c) + c4 * 4;
                 const uchar4 k = *reinterpret_cast<const uchar4*>(idx + o);
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
+                const f32x4 d = ldq<AH>(dy, o);
                 const int pos = r * 3 + s;
                 if (k.x == pos) acc[0] += d[0];
                 if (k.y == pos) acc[1] += d[1];
@@ -580,7 +608,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                 if (k.w == pos) acc[3] += d[3];
             }
         }
-        *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+        stq<AH>(dx, i * 4, acc);
     }
 }
 
@@ -588,6 +616,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // 2a..2a+2 and columns 2b..2b+2, so the patch (2a.., 2b..) is touched by exactly the windows (a-1,b-1), (a-1,b), (a,b-1), (a,b):
 // 4 window loads serve 4 input pixels (the per-pixel gather above issues 9 for them, behind data-dependent loop bounds) and are
 // summed in the same order, so the result is bit-identical.
+template <bool AH = false>
 __global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
                                                                float* __restrict__ dx, int n, int h, int w, int c) {
     const int ho = h >> 1, wo = w >> 1, cq = c >> 2;
@@ -599,7 +628,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __re
         auto window = [&](int oh, int ow, uchar4& k, f32x4& d) {
             const long o = (((long)(img * ho + oh) * wo + ow) * c) + c4 * 4;
             k = *reinterpret_cast<const uchar4*>(idx + o);
-            d = *reinterpret_cast<const f32x4*>(dy + o);
+            d = ldq<AH>(dy, o);
         };
         auto take = [](f32x4& acc, const uchar4& k, const f32x4& d, int pos) {
             if (k.x == pos) acc[0] += d[0];
@@ -613,11 +642,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __re
         if (b > 0) { window(a, b - 1, k, d); take(p00, k, d, 2); take(p10, k, d, 5); }
         window(a, b, k, d);
         take(p00, k, d, 0); take(p01, k, d, 1); take(p10, k, d, 3); take(p11, k, d, 4);
-        float* o = dx + (((long)(img * h + 2 * a) * w + 2 * b) * c) + c4 * 4;
-        *reinterpret_cast<f32x4*>(o) = p00;
-        *reinterpret_cast<f32x4*>(o + c) = p01;
-        *reinterpret_cast<f32x4*>(o + (long)w * c) = p10;
-        *reinterpret_cast<f32x4*>(o + (long)w * c + c) = p11;
+        const long o = (((long)(img * h + 2 * a) * w + 2 * b) * c) + c4 * 4;
+        stq<AH>(dx, o, p00);
+        stq<AH>(dx, o + c, p01);
+        stq<AH>(dx, o + (long)w * c, p10);
+        stq<AH>(dx, o + (long)w * c + c, p11);
     }
 }
 
@@ -627,19 +656,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __re
 // block = one image x 16 channel quads x 16 row lanes (float4 loads, two rows in flight per lane), lanes summed through LDS in a
 // fixed order.  (One thread per (image, channel) walking all hw positions serially left a 128-image SE squeeze at 128 blocks
 // and 52 us for <= 51 MB.)
+template <bool AH = false>
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int hw, int c) {
     __shared__ f32x4 sh[16][16];
     const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int ch = (blockIdx.x * 16 + q) * 4, img = blockIdx.y;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (ch < c) {
-        const float* px = x + (long)img * hw * c + ch;
+        const long px = (long)img * hw * c + ch;
         int r = rl;
         for (; r + 16 < hw; r += 32) {
-            s0 += *reinterpret_cast<const f32x4*>(px + (long)r * c);
-            s1 += *reinterpret_cast<const f32x4*>(px + (long)(r + 16) * c);
+            s0 += ldq<AH>(x, px + (long)r * c);
+            s1 += ldq<AH>(x, px + (long)(r + 16) * c);
         }
-        if (r < hw) s0 += *reinterpret_cast<const f32x4*>(px + (long)r * c);
+        if (r < hw) s0 += ldq<AH>(x, px + (long)r * c);
     }
     sh[rl][q] = s0 + s1;
     __syncthreads();
@@ -650,11 +680,12 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ 
         *reinterpret_cast<f32x4*>(y + (long)img * c + ch) = s / (float)hw;
     }
 }
+template <bool AH = false>
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long total, int hw, int c) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int ch = (int)(i % c);
         const long img = i / ((long)hw * c);
-        dx[i] = dy[img * c + ch] / hw;
+        st1<AH>(dx, i, dy[img * c + ch] / hw);
     }
 }
 
@@ -767,23 +798,34 @@ inline void stat_split(long rows, int C, int* splits, long* rps) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
+// storage flags of the *_s16 entry points (fte.h): bit 0 = the pre-activation side (z, dz) is bf16, bit 1 = the activation side
+// (y, shortcut, dy, masked gradient) is bf16.  The bf16 forms need the float4 layouts (C % 4 == 0, C >= 32).
+#define FTE_ZA(ZH_, AH_, ...) do { if (ZH_ && AH_) { constexpr bool ZH = true, AH = true; __VA_ARGS__; } \
+                                    else if (ZH_) { constexpr bool ZH = true, AH = false; __VA_ARGS__; } \
+                                    else if (AH_) { constexpr bool ZH = false, AH = true; __VA_ARGS__; } \
+                                    else { constexpr bool ZH = false, AH = false; __VA_ARGS__; } } while (0)
 hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* beta, long rows, int C, float eps, float decay,
                             float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var,
-                            float* part, hipStream_t st) {
+                            float* part, hipStream_t st, int flags) {
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
     const int Q = quads_per_block(C);
+    const bool zh = flags & 1;
+    if (zh && !Q) return hipErrorInvalidValue;
     SplitTail tail = {nullptr, part + (long)splits * 3 * C, splits, (splits + TAIL_GROUP - 1) / TAIL_GROUP};
     const BnFwdOut fin = {gamma, beta, eps, decay, mean, rstd, scale, shift, mov_mean, mov_var};
     if (Q) tail.cnt = ticket_slot(((C / 4 + Q - 1) / Q) * (tail.groups + 1));
+#define FTE_ST(Q_) do { if (zh) hipLaunchKernelGGL((bn_stats_v4_kernel<Q_, true>), dim3((C / 4 + Q_ - 1) / Q_, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); \
+                         else hipLaunchKernelGGL((bn_stats_v4_kernel<Q_, false>), dim3((C / 4 + Q_ - 1) / Q_, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); } while (0)
     switch (Q) {
-        case 64: hipLaunchKernelGGL(bn_stats_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
-        case 32: hipLaunchKernelGGL(bn_stats_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
-        case 16: hipLaunchKernelGGL(bn_stats_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
-        case 8: hipLaunchKernelGGL(bn_stats_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, z, part, rows, C, rps, tail, fin); break;
+        case 64: FTE_ST(64); break;
+        case 32: FTE_ST(32); break;
+        case 16: FTE_ST(16); break;
+        case 8: FTE_ST(8); break;
         default: hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, z, part, rows, C, rps);
     }
-    if (!tail.cnt)      // scalar-channel layouts (C % 4 != 0, C < 32) and FTE_BN_TAIL=0: the splits are merged by a second launch
+#undef FTE_ST
+    if (!tail.cnt)      // scalar-channel layouts (C % 4 != 0, C < 32) and FTE_BN_TAIL unset: the splits are merged by a second launch
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
                            mean, rstd, scale, shift, mov_mean, mov_var);
     return hipGetLastError();
@@ -794,59 +836,72 @@ hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* m
     return hipGetLastError();
 }
 hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, const float* res, float* y, long rows, int C,
-                      int relu, hipStream_t st) {
+                      int relu, hipStream_t st, int flags) {
     const long n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, z, scale, shift, res, y, n4, C, relu);
+    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, z, scale, shift, res, y, n4, C, relu));
     return hipGetLastError();
 }
-hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st) {
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, dy, y, g, n / 4);
+hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st, int flags) {
+    if (flags & 2) hipLaunchKernelGGL(relu_bwd_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, st, dy, y, g, n / 4);
+    else hipLaunchKernelGGL(relu_bwd_kernel<false>, dim3(grid_for(n / 4)), dim3(256), 0, st, dy, y, g, n / 4);
     return hipGetLastError();
 }
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
                     const float* rstd, const float* zsc, const float* zsf, float* gout, float* dz, float* dgamma, float* dbeta,
-                    long rows, int C, float* part, hipStream_t st) {
+                    long rows, int C, float* part, hipStream_t st, int flags) {
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
     float* coef = part + (long)splits * 2 * C;
     const int Q = quads_per_block(C);
+    if (flags && !Q) return hipErrorInvalidValue;
     SplitTail tail = {nullptr, coef + 3 * (long)C, splits, (splits + TAIL_GROUP - 1) / TAIL_GROUP};
     const BnBwdOut fin = {(float)rows, gamma, mean, rstd, dgamma, dbeta, coef};
     if (Q) tail.cnt = ticket_slot(((C / 4 + Q - 1) / Q) * (tail.groups + 1));
+#define FTE_BR(Q_) FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_reduce_v4_kernel<Q_, ZH, AH>), dim3((C / 4 + Q_ - 1) / Q_, splits), dim3(256), 0, st, \
+                                                                   dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin))
     switch (Q) {
-        case 64: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<64>, dim3((C / 4 + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
-        case 32: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<32>, dim3((C / 4 + 31) / 32, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
-        case 16: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<16>, dim3((C / 4 + 15) / 16, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
-        case 8: hipLaunchKernelGGL(bn_bwd_reduce_v4_kernel<8>, dim3((C / 4 + 7) / 8, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps, tail, fin); break;
+        case 64: FTE_BR(64); break;
+        case 32: FTE_BR(32); break;
+        case 16: FTE_BR(16); break;
+        case 8: FTE_BR(8); break;
         default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps);
     }
+#undef FTE_BR
     if (!tail.cnt)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
                            dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
-    if (gout) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C);
+    if (gout) FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
+    else FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C));
     return hipGetLastError();
 }
-hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)n * ho * wo * (c / 4))), dim3(256), 0, st, x, y, idx, n, h, w, c, ho, wo, pt, pl);
+hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st, int flags) {
+    const dim3 grid(grid_for((long)n * ho * wo * (c / 4)));
+    if (flags & 2) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, grid, dim3(256), 0, st, x, y, idx, n, h, w, c, ho, wo, pt, pl);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<false>, grid, dim3(256), 0, st, x, y, idx, n, h, w, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
-hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st) {
+hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st, int flags) {
     if (pt == 0 && pl == 0 && h % 2 == 0 && w % 2 == 0) {
-        hipLaunchKernelGGL(maxpool_bwd_even_kernel, dim3(grid_for((long)n * ho * wo * (c / 4))), dim3(256), 0, st, dy, idx, dx, n, h, w, c);
+        const dim3 grid(grid_for((long)n * ho * wo * (c / 4)));
+        if (flags & 2) hipLaunchKernelGGL(maxpool_bwd_even_kernel<true>, grid, dim3(256), 0, st, dy, idx, dx, n, h, w, c);
+        else hipLaunchKernelGGL(maxpool_bwd_even_kernel<false>, grid, dim3(256), 0, st, dy, idx, dx, n, h, w, c);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)n * h * w * (c / 4))), dim3(256), 0, st, dy, idx, dx, n, h, w, c, ho, wo, pt, pl);
+    const dim3 grid(grid_for((long)n * h * w * (c / 4)));
+    if (flags & 2) hipLaunchKernelGGL(maxpool_bwd_kernel<true>, grid, dim3(256), 0, st, dy, idx, dx, n, h, w, c, ho, wo, pt, pl);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<false>, grid, dim3(256), 0, st, dy, idx, dx, n, h, w, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
-hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st) {
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, x, y, hw, c);
+hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st, int flags) {
+    if (flags & 2) hipLaunchKernelGGL(gap_fwd_kernel<true>, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, x, y, hw, c);
+    else hipLaunchKernelGGL(gap_fwd_kernel<false>, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, x, y, hw, c);
     return hipGetLastError();
 }
-hipError_t l_gap_bwd(const float* dy, float* dx, int n, int hw, int c, hipStream_t st) {
+hipError_t l_gap_bwd(const float* dy, float* dx, int n, int hw, int c, hipStream_t st, int flags) {
     const long total = (long)n * hw * c;
-    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, dy, dx, total, hw, c);
+    if (flags & 2) hipLaunchKernelGGL(gap_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, dy, dx, total, hw, c);
+    else hipLaunchKernelGGL(gap_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, dy, dx, total, hw, c);
     return hipGetLastError();
 }
 hipError_t l_dropout_fwd(const float* x, float* mask, float* y, long n, float keep, uint64_t seed, hipStream_t st) {
@@ -995,7 +1050,7 @@ __global__ __launch_bounds__(256) void gconv_pack16_kernel(const float* __restri
 // MODE 0: stride 1 (forward, or data gradient with the mirrored filter: the same index map); 1: forward at stride 2 (x is
 // [n, hs, ws], y [n, h, wd] = the walked grid); 2: data gradient at stride 2 (x is dz [n, hs, ws], y is dx [n, h, wd]; tap (r, q) of
 // the mirrored filter reads dz[(iy + pt - (2 - r)) / 2] when that is whole).  pt, pl = the TF-SAME pads before.
-template <int MODE>
+template <int MODE, bool H = false>      // H: x and y are bf16 in HBM (bf16 storage)
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                               float* __restrict__ y, int n, int h, int wd, int c,
                                                               int hs, int ws, int pt, int pl) {
@@ -1018,7 +1073,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
     __syncthreads();
     const long npix = (long)n * h * wd;
     const long ntiles = (npix + 31) / 32;
-    const float* xs = x + slice * 32 + ((lane & 7) << 2);
+    const long xs = slice * 32 + ((lane & 7) << 2);
     const int fr = lane >> 3;                         // fetch row inside a group of 8 pixels
     float* st = &stage[wv][0][0];
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
@@ -1050,7 +1105,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
                     sy = ny >> 1; sx = nx >> 1;
                 }
                 ok = ok && sy >= 0 && sy < hs && sx >= 0 && sx < ws;
-                const f32x4 val = *reinterpret_cast<const f32x4*>(xs + ((fbase[j] + (ok ? sy : 0)) * ws + (ok ? sx : 0)) * c);
+                const f32x4 val = ldq<H>(x, xs + ((fbase[j] + (ok ? sy : 0)) * ws + (ok ? sx : 0)) * c);
                 v[j] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         };
@@ -1088,11 +1143,11 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
             if (t + 1 < 9) { if (t & 1) stash(0, va); else stash(1, vb); }      // tap t + 1 -> the other LDS buffer
         }
         // C layout: column (channel) = lane & 31, row (pixel) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5): 32 lanes write one pixel's 128 B
-        float* yo = y + slice * 32 + li;
+        const long yo = slice * 32 + li;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (pr < npix) yo[pr * c] = acc[i];
+            if (pr < npix) st1<H>(y, yo + pr * c, acc[i]);
         }
     }
 }
@@ -1103,6 +1158,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
 // ONCE (coalesced 128-byte rows, rounded to bf16, 80-byte LDS rows), and the three taps q read window rows li + q; the image /
 // row edges are a 9-bit mask per lane that zeroes the fragment.  gconv3x3_mfma16_kernel<0> fetched every tap on its own: 9 x the
 // tensor through L2 -> L1 (461 MB for the 28x28x128 layer at 128 images, 52 us = the L2 rate); this one moves 3.2 x.
+template <bool H = false>
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                                   float* __restrict__ y, int n, int h, int wd, int c) {
     __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
@@ -1120,7 +1176,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
     const long npix = (long)n * h * wd;
     const long ntiles = (npix + 31) / 32;
     const int fr = lane >> 3, fp = lane & 7;
-    const float* xs = x + slice * 32 + (fp << 2);
+    const long xs = slice * 32 + (fp << 2);
     unsigned short* wb = &win[wv][0][0];
     auto fetch = [&](long tile, int r, f32x4 (&v)[5]) {
         const long s0 = tile * 32 - 1 + (long)(r - 1) * wd + fr;
@@ -1128,7 +1184,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
         for (int i = 0; i < 5; ++i) {
             const long sp = s0 + 8 * i;
             const bool ok = fr + 8 * i < 34 && sp >= 0 && sp < npix;
-            const f32x4 val = *reinterpret_cast<const f32x4*>(xs + (ok ? sp : 0) * c);
+            const f32x4 val = ldq<H>(x, xs + (ok ? sp : 0) * c);
             v[i] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -1188,11 +1244,11 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
         if (tile + stride_t < ntiles) fetch(tile + stride_t, 0, va);
         row(2, sb);
         sb ^= 1;
-        float* yo = y + slice * 32 + li;
+        const long yo = slice * 32 + li;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (pr < npix) yo[pr * c] = acc[i];
+            if (pr < npix) st1<H>(y, yo + pr * c, acc[i]);
         }
     }
 }
@@ -1204,7 +1260,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
 // back through ds_read_b64_tr_b16 -- gfx950's transposing LDS read (scripts/probes/ds_read_tr16.hip pins its lane map).
 // Block = 3 waves, wave r owns kernel row r (3 taps = 3 accumulator blocks); 16 pixels per step; the next step's rows are in
 // flight while this one multiplies.  Partials [chunk][slice][tap][32 oc][gw ic], summed in order by gconv_wgrad16_reduce_kernel.
-template <int S>
+template <int S, bool H = false>
 __global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                     float* __restrict__ part, int n, int h, int wd, int c,
                                                                     int gw, long steps_per_chunk, int ho, int wo, int pt, int pl) {
@@ -1217,8 +1273,7 @@ __global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float*
     const long nsteps = (npix + 15) / 16;
     const long s0 = (long)blockIdx.x * steps_per_chunk, s1 = min(nsteps, s0 + steps_per_chunk);
     const int frow = lane >> 3, fpiece = lane & 7;                                  // fetch: rows frow, frow + 8; 16-byte piece
-    const float* xs = x + slice * 32 + (fpiece << 2);
-    const float* ds = dz + slice * 32 + (fpiece << 2);
+    const long xs = slice * 32 + (fpiece << 2);
     unsigned short* mine = &img[r][0][0];
     f32x16_l acc[3];
 #pragma unroll
@@ -1240,7 +1295,7 @@ __global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float*
             const unsigned t2 = pu / (unsigned)wo;
             const int oy = (int)(t2 % (unsigned)ho);
             const long ib = (long)(t2 / (unsigned)ho) * h;
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(ds + (long)pu * c);
+            const f32x4 dv = ldq<H>(dz, xs + (long)pu * c);
             v[3][j] = pok ? dv : f32x4{0.f, 0.f, 0.f, 0.f};
             const int sy = oy * S + r - pt;
             const bool rok = pok && sy >= 0 && sy < h;
@@ -1248,7 +1303,7 @@ __global__ __launch_bounds__(192) void gconv3x3_wgrad_mfma16_kernel(const float*
             for (int q = 0; q < 3; ++q) {
                 const int sx = ox * S + q - pl;
                 const bool ok = rok && sx >= 0 && sx < wd;
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + ((ib + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c);
+                const f32x4 xv = ldq<H>(x, xs + ((ib + (ok ? sy : 0)) * wd + (ok ? sx : 0)) * c);
                 v[q][j] = ok ? xv : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -1479,17 +1534,24 @@ hipError_t l_gconv_pack16(const float* w, unsigned short* wf, unsigned short* wd
 }
 // y [n, h, wd] is the walked grid, x [n, hs, ws] the source; mode as gconv3x3_mfma16_kernel's MODE
 hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
-                          int mode, int pt, int pl, hipStream_t st) {
+                          int mode, int pt, int pl, hipStream_t st, int h16) {
     const long ntiles = ((long)n * h * wd + 31) / 32;
     long bx = (ntiles + 3) / 4;
     const long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
     if (bx > cap) bx = cap;
     const dim3 grid((unsigned)bx, c / 32);
     static const bool win = !(getenv("FTE_GCONV_WIN") && atoi(getenv("FTE_GCONV_WIN")) == 0);     // A/B hook: 0 = a fetch per tap
-    if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c);
-    else if (mode == 0) hipLaunchKernelGGL(gconv3x3_mfma16_kernel<0>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
-    else if (mode == 1) hipLaunchKernelGGL(gconv3x3_mfma16_kernel<1>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
-    else hipLaunchKernelGGL(gconv3x3_mfma16_kernel<2>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+    if (h16) {
+        if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel<true>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c);
+        else if (mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<0, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+        else if (mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+        else hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+        return hipGetLastError();
+    }
+    if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel<false>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c);
+    else if (mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<0, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+    else if (mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+    else hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
     return hipGetLastError();
 }
 int l_gconv_wgrad16_chunks(long npix, int c) {
@@ -1499,11 +1561,15 @@ int l_gconv_wgrad16_chunks(long npix, int c) {
     return (int)(ch < 1 ? 1 : ch);
 }
 hipError_t l_gconv_wgrad16(const float* x, const float* dz, float* part, float* dw, int n, int h, int wd, int c, int groups,
-                           int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st) {
+                           int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st, int h16) {
     const long steps = ((long)n * ho * wo + 15) / 16, spc = (steps + chunks - 1) / chunks;
     const int gw = c / groups, total = groups * 9 * gw * gw;
-    if (stride == 1) hipLaunchKernelGGL(gconv3x3_wgrad_mfma16_kernel<1>, dim3(chunks, c / 32), dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
-    else hipLaunchKernelGGL(gconv3x3_wgrad_mfma16_kernel<2>, dim3(chunks, c / 32), dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
+    const dim3 grid(chunks, c / 32);
+    if (h16) {
+        if (stride == 1) hipLaunchKernelGGL((gconv3x3_wgrad_mfma16_kernel<1, true>), grid, dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
+        else hipLaunchKernelGGL((gconv3x3_wgrad_mfma16_kernel<2, true>), grid, dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
+    } else if (stride == 1) hipLaunchKernelGGL((gconv3x3_wgrad_mfma16_kernel<1, false>), grid, dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
+    else hipLaunchKernelGGL((gconv3x3_wgrad_mfma16_kernel<2, false>), grid, dim3(192), 0, st, x, dz, part, n, h, wd, c, gw, spc, ho, wo, pt, pl);
     hipLaunchKernelGGL(gconv_wgrad16_reduce_kernel, dim3((total + 63) / 64), dim3(256), 0, st, part, dw, chunks, c / 32, gw, groups);
     return hipGetLastError();
 }

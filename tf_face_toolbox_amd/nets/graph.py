@@ -459,11 +459,40 @@ class GraphNet(Network):
         return False
 
     # ---- buffers --------------------------------------------------------------------------------------
+    S16_OPS = ('conv', 'bn', 'gconv', 'maxpool', 'addrelu', 'gap', 'dropout', 'fc')
+
+    def _storage16(self):
+        """bf16 STORAGE ('bf16s', fte.h): the tensors between the layers live in HBM as bf16 -- implemented for the ResNet family's
+        op set (conv / BN / grouped 3x3 on the bf16 MFMA / max-pool / add+ReLU / GAP; BASELINE.json configs[2]).  Nets with other ops
+        (channel gathers, depthwise convs, SE gates) run the 'bf16' operand mode instead: same MFMA precision, fp32 tensors."""
+        if not _lib.bf16_storage():
+            return False
+        ok = all(op[0] in self.S16_OPS for op in self.plan) and \
+            all(self._gconv_pack(op) is not None for op in self.plan if op[0] == 'gconv')
+        if not ok and not getattr(self, '_s16_note', False):
+            self._s16_note = True
+            print('%s: bf16 storage is implemented for the ResNet-family op set; this net runs bf16 MFMA operands with fp32 tensors' % self.name)
+        return ok
+
+    def _is16(self, name):
+        return name in self.h16
+
     def _alloc(self, n):
-        if self._act_n == n:
+        s16 = self._storage16()
+        if self._act_n == n and getattr(self, '_act_s16', False) == s16:
             return
+        self._act_s16 = s16
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
+        i16 = dict(dtype=torch.int16, device=dev)
+        # names of the tensors stored as bf16: conv / BN / grouped-conv / pool / add outputs; the stem conv's output (an fp32 GEMM),
+        # the pooled features and everything after them stay fp32
+        self.h16 = set()
+        if s16:
+            for op in self.plan:
+                if op[0] in ('bn', 'gconv', 'maxpool', 'addrelu') or (op[0] == 'conv' and self.shapes[op[2]][-1] >= 32):
+                    self.h16.add(op[1])
+            self.w16, self.w16t = {}, {}
         self.t = _Activations(self)
         self.bn = {}
         self.ident = {}
@@ -477,7 +506,7 @@ class GraphNet(Network):
                 continue
             shape = (n,) + self.shapes[out]
             if kind != 'bnstats':
-                self.t[out] = torch.empty(shape, **f32)
+                self.t[out] = torch.empty(shape, **(i16 if out in self.h16 else f32))
             if kind in ('bn', 'bnstats'):
                 c = shape[-1]
                 self.bn[out] = dict(mean=torch.empty(c, **f32), rstd=torch.empty(c, **f32), scale=torch.empty(c, **f32),
@@ -491,6 +520,9 @@ class GraphNet(Network):
                     need = max(need, q('fte_conv2d_fwd_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_dgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_wgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]))
+                    if s16:          # bf16 packs of the filter: HWIO (data gradient) and [tap][cout][cin] (forward), refreshed every step
+                        self.w16[op[3]] = torch.empty(k, k, cin, cout, **i16)
+                        self.w16t[op[3]] = torch.empty(k, k, cout, cin, **i16)
                 elif self._direct_stem(k, cin, cout):
                     need = max(need, q('fte_conv3x3_first_wgrad_ws_bytes', n, ih, iw, cin, cout, op[4]))
                 else:
@@ -555,6 +587,8 @@ class GraphNet(Network):
         call = _lib.call
         T = self.t
         T['images'] = x
+        s16 = self._act_s16
+        h16 = self.h16
         for op in self.plan:
             kind, out = op[0], op[1]
             if kind == 'conv':
@@ -562,7 +596,11 @@ class GraphNet(Network):
                 ih, iw, cin = self.shapes[inp]
                 k = self.spec[wname][0][0]
                 cout = self.shapes[out][-1]
-                if cin >= 32:
+                if cin >= 32 and s16:          # bf16 storage: bf16 x in, bf16 z out, filters packed once per step
+                    call('fte_pack_weights_bf16', self.view(wname), self.w16[wname], self.w16t[wname], k, cin, cout, st)
+                    call('fte_conv2d_fwd_s16', T[inp], self.w16t[wname], None, None, None, None, T[out], None, None,
+                         n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                elif cin >= 32:
                     call('fte_conv2d_fwd', T[inp], self.view(wname), None, None, None, None, T[out],
                          n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 elif self._direct_stem(k, cin, cout):          # 3x3 stem of 32 / 64 stored filters: the direct MFMA kernel
@@ -613,7 +651,20 @@ class GraphNet(Network):
                 c = self.shapes[out][-1]
                 rows = T[out].numel() // c
                 resbuf = T[res] if res is not None else None
-                if is_training:
+                if s16:
+                    assert res is None or res in h16, 'bf16 storage: the shortcut of %s is an fp32 tensor' % out
+                    fl = (1 if inp in h16 else 0) | 2
+                    if is_training:
+                        upd = self.update_moving_stats
+                        call('fte_bn_train_fwd_s16', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'), resbuf, T[out],
+                             b['mean'], b['rstd'], b['scale'], b['shift'],
+                             self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None,
+                             rows, c, BN_EPS, BN_DECAY, relu, fl, self.ws, self.ws_bytes, st)
+                    else:
+                        call('fte_bn_infer_fwd_s16', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
+                             self.state[pre + '/moving_mean'], self.state[pre + '/moving_variance'], resbuf, T[out],
+                             b['scale'], b['shift'], rows, c, BN_EPS, relu, fl, st)
+                elif is_training:
                     upd = self.update_moving_stats
                     call('fte_bn_train_fwd', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'), resbuf, T[out],
                          b['mean'], b['rstd'], b['scale'], b['shift'],
@@ -628,7 +679,7 @@ class GraphNet(Network):
                 pk = self._gconv_pack(op)
                 if pk is not None:                             # bf16 MFMA mode: block-diagonal slices on the matrix cores
                     call('fte_gconv3x3_pack_bf16', self.view(op[3]), pk[0], pk[1], c, op[5], st)
-                    call('fte_gconv3x3_bf16', T[op[2]], pk[0], T[out], n, ih, iw, c, op[4], 0, st)
+                    call('fte_gconv3x3_bf16_s16' if s16 else 'fte_gconv3x3_bf16', T[op[2]], pk[0], T[out], n, ih, iw, c, op[4], 0, st)
                 else:
                     call('fte_gconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[5], op[4], st)
             elif kind == 'se':
@@ -645,14 +696,19 @@ class GraphNet(Network):
             elif kind == 'addrelu':
                 c = self.shapes[out][-1]
                 one, zero = self.ident[c]
-                call('fte_bn_infer_fwd', T[op[2]], one, zero, zero, one, T[op[3]], T[out], self._scr(c, 0), self._scr(c, 1),
-                     T[out].numel() // c, c, 0.0, 1, st)
+                if s16:
+                    assert op[2] in h16 and op[3] in h16
+                    call('fte_bn_infer_fwd_s16', T[op[2]], one, zero, zero, one, T[op[3]], T[out], self._scr(c, 0), self._scr(c, 1),
+                         T[out].numel() // c, c, 0.0, 1, 3, st)
+                else:
+                    call('fte_bn_infer_fwd', T[op[2]], one, zero, zero, one, T[op[3]], T[out], self._scr(c, 0), self._scr(c, 1),
+                         T[out].numel() // c, c, 0.0, 1, st)
             elif kind == 'maxpool':
                 ih, iw, c = self.shapes[op[2]]
-                call('fte_maxpool3x3s2_fwd', T[op[2]], T[out], T[out + '/idx'], n, ih, iw, c, st)
+                call('fte_maxpool3x3s2_fwd_s16' if s16 else 'fte_maxpool3x3s2_fwd', T[op[2]], T[out], T[out + '/idx'], n, ih, iw, c, st)
             elif kind == 'gap':
                 ih, iw, c = self.shapes[op[2]]
-                call('fte_gap_fwd', T[op[2]], T[out], n, ih * iw, c, st)
+                call('fte_gap_fwd_s16' if op[2] in h16 else 'fte_gap_fwd', T[op[2]], T[out], n, ih * iw, c, st)
             elif kind == 'dropout':
                 if is_training:
                     seed = (self.dropout_seed * 1000003 + self.global_step) & 0x7FFFFFFFFFFFFFFF
@@ -825,6 +881,8 @@ class GraphNet(Network):
         st = _stream()
         call = _lib.call
         T = self.t
+        s16 = self._act_s16
+        h16 = self.h16
         if not self.has_classifier:
             self._grad = {self.feature_name: self._dfeat}
             self._dfeat = None
@@ -894,16 +952,16 @@ class GraphNet(Network):
             elif kind == 'gap':
                 ih, iw, c = self.shapes[op[2]]
                 g = self._new(op[2])
-                call('fte_gap_bwd', dy, g, n, ih * iw, c, st)
+                call('fte_gap_bwd_s16' if op[2] in h16 else 'fte_gap_bwd', dy, g, n, ih * iw, c, st)
                 self._put(op[2], g)
             elif kind == 'maxpool':
                 ih, iw, c = self.shapes[op[2]]
                 g = self._new(op[2])
-                call('fte_maxpool3x3s2_bwd', dy, T[out + '/idx'], g, n, ih, iw, c, st)
+                call('fte_maxpool3x3s2_bwd_s16' if s16 else 'fte_maxpool3x3s2_bwd', dy, T[out + '/idx'], g, n, ih, iw, c, st)
                 self._put(op[2], g)
             elif kind == 'addrelu':
                 g = self._new(out)
-                call('fte_relu_bwd', dy, T[out], g, dy.numel(), st)
+                call('fte_relu_bwd_s16' if s16 else 'fte_relu_bwd', dy, T[out], g, dy.numel(), st)
                 self._put(op[2], g)
                 self._put(op[3], g)                      # both addends see the same (read-only) gradient
             elif kind == 'se':
@@ -930,13 +988,13 @@ class GraphNet(Network):
                 _, _, inp, wname, stride, groups = op
                 ih, iw, c = self.shapes[inp]
                 if self._gconv_pack(op) is not None:     # bf16 MFMA mode
-                    wgrad('fte_gconv3x3_wgrad_bf16', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
+                    wgrad('fte_gconv3x3_wgrad_bf16_s16' if s16 else 'fte_gconv3x3_wgrad_bf16', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 else:
                     wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
                 pk = self._gconv_pack(op)
                 if pk is not None:                       # packed by this step's forward pass (the weights have not changed since)
-                    call('fte_gconv3x3_bf16', dy, pk[1], dx, n, ih, iw, c, stride, 1, st)
+                    call('fte_gconv3x3_bf16_s16' if s16 else 'fte_gconv3x3_bf16', dy, pk[1], dx, n, ih, iw, c, stride, 1, st)
                 else:
                     call('fte_gconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, groups, stride, st)
                 self._put(inp, dx)
@@ -946,7 +1004,21 @@ class GraphNet(Network):
                 c = self.shapes[out][-1]
                 rows = dy.numel() // c
                 dz = torch.empty_like(T[inp])
-                if res is not None:                      # the shortcut gets g = dy * (out > 0): a by-product of the reduce pass
+                if s16:
+                    fl = (1 if inp in h16 else 0) | 2
+                    gam, dgam, dbet = self.view(pre + '/gamma'), self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads)
+                    if res is not None:
+                        g = self._new(out)
+                        call('fte_bn_train_bwd_s16', dy, T[out], T[inp], gam, b['mean'], b['rstd'], None, None, g, dz, dgam, dbet,
+                             rows, c, fl, self.ws, self.ws_bytes, st)
+                        self._put(res, g)
+                    elif relu:
+                        call('fte_bn_train_bwd_s16', dy, None, T[inp], gam, b['mean'], b['rstd'], b['scale'], b['shift'], None, dz, dgam, dbet,
+                             rows, c, fl, self.ws, self.ws_bytes, st)
+                    else:
+                        call('fte_bn_train_bwd_s16', dy, None, T[inp], gam, b['mean'], b['rstd'], None, None, None, dz, dgam, dbet,
+                             rows, c, fl, self.ws, self.ws_bytes, st)
+                elif res is not None:                      # the shortcut gets g = dy * (out > 0): a by-product of the reduce pass
                     g = self._new(out)
                     call('fte_bn_train_bwd_res', dy, T[out], T[inp], self.view(pre + '/gamma'), b['mean'], b['rstd'], g, dz,
                          self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), rows, c,
@@ -974,12 +1046,16 @@ class GraphNet(Network):
                     oh, ow, _ = self.shapes[out]
                     call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, stem_kpad(k, cin), self.ws, self.ws_bytes, st)
                     continue
-                wgrad('fte_conv2d_wgrad', dy, T[inp], dy, gw, n, ih, iw, cin, cout, k, stride, wws, self.ws_bytes, wst)
+                wgrad('fte_conv2d_wgrad16' if s16 else 'fte_conv2d_wgrad', dy, T[inp], dy, gw, n, ih, iw, cin, cout, k, stride, wws, self.ws_bytes, wst)
                 flush(self.side_batch)
                 prev = G.pop(inp, None)                  # accumulate into an existing contribution through `addin`
                 dx = self._new(inp)
-                call('fte_conv2d_dgrad', dy, self.view(wname), prev, None, None, None, dx, None, None,
-                     n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                if s16:          # bf16 dz in, bf16 dx out (+ the bf16 contribution already there); the HWIO pack is this step's
+                    call('fte_conv2d_dgrad_s16', dy, self.w16[wname], prev, None, None, None, dx, None, None,
+                         n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                else:
+                    call('fte_conv2d_dgrad', dy, self.view(wname), prev, None, None, None, dx, None, None,
+                         n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 G[inp] = dx
             else:
                 raise RuntimeError(kind)
