@@ -251,6 +251,11 @@ int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, fl
  * ------------------------------------------------------------------------- */
 int fte_to_bf16(const float* x, uint16_t* y16, long n, void* stream);
 int fte_pack_weights_bf16(const float* w, uint16_t* w16, uint16_t* w16t, int ksize, int cin, int cout, void* stream);
+/* every filter of a net in ONE launch per layout (a step of a 50-layer net made 36-53 pack launches of ~7 us otherwise): `table` is a
+ * DEVICE array of nconv <= 64 rows {source offset in `params` (floats), destination offset in `dst` (bf16 elements, a multiple of 8),
+ * taps, cin, cout, first index of this conv in the flattened walk / 4}, cin % 4 == 0 and cout % 4 == 0, total = sum of
+ * taps*cin*cout.  transposed = 1 writes the [tap][cout][cin] packs (forward), 0 the HWIO packs (data gradient). */
+int fte_pack_weights_bf16_table(const float* params, uint16_t* dst, const int32_t* table, int nconv, long total, int transposed, void* stream);
 int fte_conv2d_fwd16(const uint16_t* x16, const uint16_t* w16t, const float* bias, const float* alpha, const float* res,
                      float* z, float* y, uint16_t* y16, int n, int h, int wd, int cin, int cout, int ksize, int stride,
                      void* ws, size_t ws_bytes, void* stream);

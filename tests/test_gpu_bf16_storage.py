@@ -361,3 +361,24 @@ def test_resnext_bf16s_trains_two_streams_and_falls_back_for_other_nets(bf16s_mo
     step, ls, _, _ = Singular(sh, 0.02, 'Momentum')({'images': x, 'labels': y, 'num_classes': ncls, 'num_examples': n})
     step()
     assert not sh._act_s16 and np.isfinite(float(ls[0]))
+
+
+def test_filter_packs_table_equals_per_conv_packs():
+    """fte_pack_weights_bf16_table (every filter of a net, one launch per layout) against fte_pack_weights_bf16 (one launch per conv):
+    bit-identical packs, for 3x3 and 1x1 filters of different shapes scattered through an arena, in chunks of up to 64 rows."""
+    from tf_face_toolbox_amd.nets._packs import FilterPacks
+    g = torch.Generator(device='cuda').manual_seed(3)
+    shapes = [(3, 64, 64), (1, 256, 64), (3, 128, 256), (1, 64, 2048), (3, 32, 32)] * 15          # 75 convs: two table launches
+    entries, off = [], 12                                                                           # 16-byte aligned, not at 0
+    for i, (k, cin, cout) in enumerate(shapes):
+        entries.append(('c%d' % i, off, k, cin, cout))
+        off += k * k * cin * cout + 4 * (i % 3)                                                     # gaps between the variables
+    arena = torch.randn(off, device='cuda', generator=g)
+    packs = FilterPacks(entries, 'cuda')
+    assert len(packs.launches) == 2
+    packs.refresh(arena, stream())
+    for name, src, k, cin, cout in entries:
+        w = arena[src:src + k * k * cin * cout].view(k, k, cin, cout)
+        assert torch.equal(packs.w16[name], _bits(w)), name
+        assert torch.equal(packs.w16t[name], _bits(w).permute(0, 1, 3, 2).contiguous()), name
+        assert packs.w16[name].data_ptr() % 16 == 0 and packs.w16t[name].data_ptr() % 16 == 0

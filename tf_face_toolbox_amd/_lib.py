@@ -64,6 +64,7 @@ _SIGS = {
     'fte_channel_scale_bwd': (c_int, [_P] * 5 + [c_int] * 4 + [_P]),
     'fte_to_bf16': (c_int, [_P, _P, c_long, _P]),
     'fte_pack_weights_bf16': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    'fte_pack_weights_bf16_table': (c_int, [_P, _P, _P, c_int, c_long, c_int, _P]),
     'fte_conv2d_fwd16': (c_int, [_P] * 8 + [c_int] * 7 + [_P, c_size_t, _P]),
     'fte_conv2d_dgrad16': (c_int, [_P] * 10 + [c_int] * 7 + [_P, c_size_t, _P]),
     'fte_conv2d_wgrad16': (c_int, [_P] * 3 + [c_int] * 7 + [_P, c_size_t, _P]),

@@ -234,6 +234,11 @@ int fte_pack_weights_bf16(const float* w, uint16_t* w16, uint16_t* w16t, int ksi
     return rc(k_pack_weights_bf16(w, w16, w16t, ksize * ksize, cin, cout, (hipStream_t)stream));
 }
 
+int fte_pack_weights_bf16_table(const float* params, uint16_t* dst, const int32_t* table, int nconv, long total, int transposed, void* stream) {
+    if (!params || !dst || !table || nconv <= 0 || nconv > 64 || total <= 0 || total % 4) return FTE_EINVAL;
+    return rc(k_pack_weights_table(params, dst, table, nconv, total, transposed, (hipStream_t)stream));
+}
+
 int fte_set_mfma_dtype(int dtype) {
     if (dtype != FTE_MFMA_F32 && dtype != FTE_MFMA_BF16) return FTE_EINVAL;
     igemm_set_bf16(dtype == FTE_MFMA_BF16);

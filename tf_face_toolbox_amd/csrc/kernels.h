@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+hipError_t k_pack_weights_table(const float* params, unsigned short* w16t, const int* table, int nconv, long total, int transposed, hipStream_t st);
 hipError_t k_conv_first_fwd(const float* x, const float* w, const float* bias, const float* alpha, float* z, float* y,
                             unsigned short* z16, unsigned short* y16, int n, int h, int wd, int cin, int cout, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
 int k_conv_first_wgrad_blocks(long npix);

@@ -761,7 +761,48 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         }
     }
 }
+// All filters of a net in ONE launch: table row k = {source offset in `params`, destination offset in `w16t`, taps, cin, cout,
+// first destination index of this conv in the flattened walk}; thread = 4 consecutive cin of one (conv, tap, cout): the bf16
+// [tap][cout][cin] pack is written in 8-byte pieces, the fp32 HWIO source is gathered through the caches.
+typedef float f32x4k __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void pack_weights_table_kernel(const float* __restrict__ params, unsigned short* __restrict__ w16t,
+                                                                 const int* __restrict__ table, int nconv, long total4, int transposed) {
+    __shared__ int tb[64 * 6];
+    for (int i = threadIdx.x; i < nconv * 6; i += 256) tb[i] = table[i];
+    __syncthreads();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        int lo = 0, hi = nconv - 1;                      // last conv whose first index (in units of 4 elements) is <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((long)tb[mid * 6 + 5] <= i) lo = mid; else hi = mid - 1;
+        }
+        const int* d = tb + lo * 6;
+        const int cin = d[3], cout = d[4];
+        const long j = (i - d[5]) * 4;                   // destination index inside this conv: ((tap * cout + co) * cin + ci)
+        if (!transposed) {                               // the HWIO pack: a plain conversion, same index on both sides
+            const f32x4k v = *reinterpret_cast<const f32x4k*>(params + d[0] + j);
+            *reinterpret_cast<uint2*>(w16t + d[1] + j) = make_uint2(
+                __builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16),
+                __builtin_bit_cast(unsigned short, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16));
+            continue;
+        }
+        const int ci = (int)(j % cin);
+        const long t2 = j / cin;
+        const int co = (int)(t2 % cout), tap = (int)(t2 / cout);
+        const float* src = params + d[0] + ((long)tap * cin + ci) * cout + co;
+        unsigned short o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(unsigned short, (__bf16)src[(long)e * cout]);
+        *reinterpret_cast<uint2*>(w16t + d[1] + j) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+    }
+}
 }  // namespace
+hipError_t k_pack_weights_table(const float* params, unsigned short* w16t, const int* table, int nconv, long total, int transposed, hipStream_t st) {
+    const long t4 = total / 4;
+    hipLaunchKernelGGL(pack_weights_table_kernel, dim3((unsigned)((t4 + 255) / 256 > 8192 ? 8192 : (t4 + 255) / 256)), dim3(256), 0, st,
+                       params, w16t, table, nconv, t4, transposed);
+    return hipGetLastError();
+}
 hipError_t k_to_bf16(const float* x, unsigned short* y, long n, hipStream_t st) {
     const long n4 = n / 4;
     hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)), dim3(256), 0, st, x, y, n4);

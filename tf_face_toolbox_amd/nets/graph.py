@@ -492,7 +492,7 @@ class GraphNet(Network):
             for op in self.plan:
                 if op[0] in ('bn', 'gconv', 'maxpool', 'addrelu') or (op[0] == 'conv' and self.shapes[op[2]][-1] >= 32):
                     self.h16.add(op[1])
-            self.w16, self.w16t = {}, {}
+            self._pack_entries = []
         self.t = _Activations(self)
         self.bn = {}
         self.ident = {}
@@ -521,8 +521,7 @@ class GraphNet(Network):
                                q('fte_conv2d_dgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_wgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]))
                     if s16:          # bf16 packs of the filter: HWIO (data gradient) and [tap][cout][cin] (forward), refreshed every step
-                        self.w16[op[3]] = torch.empty(k, k, cin, cout, **i16)
-                        self.w16t[op[3]] = torch.empty(k, k, cout, cin, **i16)
+                        self._pack_entries.append((op[3], self.variables[op[3]].offset, k, cin, cout))
                 elif self._direct_stem(k, cin, cout):
                     need = max(need, q('fte_conv3x3_first_wgrad_ws_bytes', n, ih, iw, cin, cout, op[4]))
                 else:
@@ -558,6 +557,10 @@ class GraphNet(Network):
                 self.t[out + '/mask'] = torch.empty(shape, **f32)
             elif kind == 'fc':
                 need = max(need, q('fte_gemm_ws_bytes', n, self.cpad, self.shapes[op[2]][0]))
+        if s16:
+            from ._packs import FilterPacks
+            self.packs = FilterPacks(self._pack_entries, dev)
+            self.w16, self.w16t = self.packs.w16, self.packs.w16t
         self.G = torch.empty(n, self.cpad, **f32)
         self.loss_rows = torch.empty(n, **f32)
         fdim = self.shapes[self.feature_name][0]
@@ -589,6 +592,8 @@ class GraphNet(Network):
         T['images'] = x
         s16 = self._act_s16
         h16 = self.h16
+        if s16:
+            self.packs.refresh(self.params, st)          # every filter's bf16 packs, two launches
         for op in self.plan:
             kind, out = op[0], op[1]
             if kind == 'conv':
@@ -597,7 +602,6 @@ class GraphNet(Network):
                 k = self.spec[wname][0][0]
                 cout = self.shapes[out][-1]
                 if cin >= 32 and s16:          # bf16 storage: bf16 x in, bf16 z out, filters packed once per step
-                    call('fte_pack_weights_bf16', self.view(wname), self.w16[wname], self.w16t[wname], k, cin, cout, st)
                     call('fte_conv2d_fwd_s16', T[inp], self.w16t[wname], None, None, None, None, T[out], None, None,
                          n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 elif cin >= 32:

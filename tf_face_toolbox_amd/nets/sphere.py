@@ -264,13 +264,13 @@ class SphereNet(Network):
             b = self.bwd[si]
             if 'dz16' not in b:
                 b['dz16'] = [torch.empty(b['dz'][0].shape, **i16) for _ in b['dz']]
-        if getattr(self, 'w16', None) is None:
-            self.w16 = {c.name: torch.empty(3, 3, c.cin, c.cout, **i16) for c in self.convs[1:]}
-            self.w16t = {c.name: torch.empty(3, 3, c.cout, c.cin, **i16) for c in self.convs[1:]}
+        if getattr(self, 'packs', None) is None:
+            from ._packs import FilterPacks
+            self.packs = FilterPacks([(c.name, self.variables[c.name + '/weights'].offset, 3, c.cin, c.cout) for c in self.convs[1:]], self.device)
+            self.w16, self.w16t = self.packs.w16, self.packs.w16t
 
     def _pack_weights(self, st):
-        for c in self.convs[1:]:
-            _lib.call('fte_pack_weights_bf16', self.view(c.name + '/weights'), self.w16[c.name], self.w16t[c.name], 3, c.cin, c.cout, st)
+        self.packs.refresh(self.params, st)          # all 19 filters, one launch per layout
 
     # ------------------------------------------------------------------ forward
     def prelu(self, x, name='prelu'):
