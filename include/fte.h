@@ -323,6 +323,21 @@ int fte_gap_bwd_s16(const float* dy, uint16_t* dx16, int n, int hw, int c, void*
 int fte_gconv3x3_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* y16, int n, int h, int wd, int c, int stride, int dgrad, void* stream);
 int fte_gconv3x3_wgrad_bf16_s16(const uint16_t* x16, const uint16_t* dz16, float* dw, int n, int h, int wd, int c, int groups, int stride,
                                 void* ws, size_t ws_bytes, void* stream);
+/* ShuffleNet-v2's layers on bf16 tensors (nets/shufflenet_v2.py): depthwise 3x3 forward / data gradient / filter gradient (fp32 filter
+ * and dw), the channel gather and the gather with batch norm folded in (sources and results bf16, tables / scale / shift unchanged),
+ * and the statistics-only pass of a folded batch norm (`flags` as above: FTE_S16_Z = z is bf16). */
+int fte_dwconv3x3_fwd_s16(const uint16_t* x16, const float* w, uint16_t* y16, int n, int h, int wd, int c, int stride, void* stream);
+int fte_dwconv3x3_dgrad_s16(const uint16_t* dy16, const float* w, uint16_t* dx16, int n, int h, int wd, int c, int stride, void* stream);
+int fte_dwconv3x3_wgrad_s16(const uint16_t* x16, const uint16_t* dy16, float* dw, int n, int h, int wd, int c, int stride,
+                            void* ws, size_t ws_bytes, void* stream);
+int fte_channel_gather_s16(const uint16_t* a, const uint16_t* b, uint16_t* out, const int32_t* table, long rows, int ca, int cb, int co, void* stream);
+int fte_channel_gather_affine_s16(const uint16_t* a, const uint16_t* b, uint16_t* out, const int32_t* table, int co,
+                                  uint16_t* out1, const int32_t* table1, int co1, long rows, int ca, int cb,
+                                  const float* scale_a, const float* shift_a, int relu_a,
+                                  const float* scale_b, const float* shift_b, int relu_b, void* stream);
+int fte_bn_train_stats_s16(const void* z, const float* gamma, const float* beta, float* mean, float* rstd, float* scale, float* shift,
+                           float* moving_mean, float* moving_var, long rows, int c, float eps, float decay, int flags,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * ShuffleNet-v2 (nets/shufflenet_v2.py).  Depthwise 3x3, TF-SAME, stride 1 or 2: the DepthwiseConv2dNative half of

@@ -20,12 +20,13 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
     env = {'images': images}
     cache = {}
     new_state = {}
-    prev_out = None
+    prev_outs = ()
     for op in graph:
-        if stored and prev_out in stored:
-            env[prev_out] = ops.stored(env[prev_out])
+        for nm in prev_outs:
+            if stored and nm in stored:
+                env[nm] = ops.stored(env[nm])
         kind, out = op[0], op[1]
-        prev_out = out
+        prev_outs = (out, op[3]) if kind == 'split' else ((out, op[4]) if kind == 'shufsplit' else (out,))
         if kind == 'conv':          # ('conv', out, inp, wname, stride)
             _, _, inp, wname, stride = op
             env[out] = ops.conv2d_fwd(env[inp], params[wname], stride)
@@ -83,8 +84,9 @@ def forward(graph, params, images, labels=None, train=True, masks=None, state=No
             env[out] = ops.channel_shuffle(np.concatenate([env[op[2]], env[op[3]]], axis=-1), op[4])
         else:
             raise ValueError(kind)
-    if stored and prev_out in stored:
-        env[prev_out] = ops.stored(env[prev_out])
+    for nm in prev_outs:
+        if stored and nm in stored:
+            env[nm] = ops.stored(env[nm])
     return env, cache, new_state
 
 
@@ -110,7 +112,7 @@ def noise_bands(graph, params, images, masks=None, state=None):
     return out
 
 
-def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='fp32', bands=None, stored=None):
+def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='fp32', bands=None, stored=None, stored_grad=None):
     """dout: {tensor name: gradient}.  Returns (param grads, tensor grads).
     `kink` (optional): tensors of the implementation under test.  ReLU's derivative jumps at 0 and a
     max-pool routes its gradient to ONE of several near-equal candidates; where the float64 values are
@@ -130,10 +132,12 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
         return max(thr, NOISE_MULT * (bands or {}).get(out, 0.0))
     gt = dict(dout)
     gp = OrderedDict()
+    if stored_grad is None:
+        stored_grad = stored                         # gradients of tensors that are never stored themselves (a BN folded into a gather) may be stored too
 
     def acc(d, k, v):
         d[k] = v if k not in d else d[k] + v
-        if d is gt and stored and k in stored:       # bf16 storage: the gradient of a stored tensor is itself stored, rounded where it is written
+        if d is gt and stored_grad and k in stored_grad:       # bf16 storage: the gradient of a stored tensor is itself stored, rounded where it is written
             d[k] = ops.stored(d[k])
     for op in reversed(graph):
         kind, out = op[0], op[1]
@@ -480,7 +484,7 @@ def perturb(p, seed, scale=0.1):
 
 
 def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None, grad_scale=None, state=None, kink=None,
-                   center=None, triplet_margin='off', focal=None, kink_mode='fp32', bands=None, stored=None):
+                   center=None, triplet_margin='off', focal=None, kink_mode='fp32', bands=None, stored=None, stored_grad=None):
     """softmax-CE (+ center loss) or batch-hard triplet, + L2 on conv / fc weights (gamma, beta, biases are not
     regularised).  center = dict(centers=[C,D], alpha=, weight=): loss.py:29-45 on the pooled features, added to the
     total loss with `weight` (the reference leaves the wiring to the caller, loss.py:43).  triplet_margin != 'off':
@@ -506,7 +510,7 @@ def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None,
             scale = center['weight'] * (1.0 if grad_scale is None else grad_scale * n)
             dout['features'] = dfe * scale
             extra['centers'] = newc
-    gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink, kink_mode=kink_mode, bands=bands, stored=stored)
+    gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink, kink_mode=kink_mode, bands=bands, stored=stored, stored_grad=stored_grad)
     reg_names = [k for k in params if k.endswith('weights')]      # weights, depthwise_weights, pointwise_weights
     reg = ops.l2_reg([params[k] for k in reg_names], weight_decay)
     for k in reg_names:

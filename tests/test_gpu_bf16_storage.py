@@ -332,7 +332,7 @@ def test_bn_net_bf16s_step_vs_the_rounded_oracle(bf16s_mode, name, variant, laye
     assert abs(float(losses[0]) - l_r[0]) <= 2e-3 * l_r[0]
 
 
-def test_resnext_bf16s_trains_two_streams_and_falls_back_for_other_nets(bf16s_mode):
+def test_resnext_bf16s_trains_two_streams_and_se_nets_fall_back(bf16s_mode):
     n, ncls, hh = 16, 10, 64
     rng = np.random.default_rng(21)
     x = dev(rng.uniform(-1, 1, (n, hh, hh, 3))); y = dev(rng.integers(0, ncls, n), torch.int32)
@@ -357,10 +357,10 @@ def test_resnext_bf16s_trains_two_streams_and_falls_back_for_other_nets(bf16s_mo
     assert torch.equal(arenas[0], arenas[1])
     f = net.eval_features(x)
     assert f.shape == (n, 2048) and f.dtype == torch.float32 and torch.isfinite(f).all()
-    sh = net_select('ShuffleNet-v2-small', 'NCHW', 5e-4)                      # channel gathers / depthwise convs: bf16 operands, fp32 tensors
-    step, ls, _, _ = Singular(sh, 0.02, 'Momentum')({'images': x, 'labels': y, 'num_classes': ncls, 'num_examples': n})
+    se = net_select('SENet-50', 'NCHW', 5e-4)                                 # SE gates: bf16 operands, fp32 tensors (a printed note, not an error)
+    step, ls, _, _ = Singular(se, 0.02, 'Momentum')({'images': x, 'labels': y, 'num_classes': ncls, 'num_examples': n})
     step()
-    assert not sh._act_s16 and np.isfinite(float(ls[0]))
+    assert not se._act_s16 and np.isfinite(float(ls[0]))
 
 
 def test_filter_packs_table_equals_per_conv_packs():
@@ -382,3 +382,125 @@ def test_filter_packs_table_equals_per_conv_packs():
         assert torch.equal(packs.w16[name], _bits(w)), name
         assert torch.equal(packs.w16t[name], _bits(w).permute(0, 1, 3, 2).contiguous()), name
         assert packs.w16[name].data_ptr() % 16 == 0 and packs.w16t[name].data_ptr() % 16 == 0
+
+
+# ------------------------------------------------------------------------------------------------ ShuffleNet-v2's layers
+@pytest.mark.parametrize('n,h,w,c,stride', [(3, 14, 14, 128, 1), (2, 28, 28, 64, 2), (2, 7, 9, 256, 2), (5, 13, 8, 192, 1), (2, 13, 8, 64, 2)])
+def test_depthwise_s16(n, h, w, c, stride):
+    g = torch.Generator(device='cuda').manual_seed(n * 100 + c + stride)
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    x16 = _bits(torch.randn(n, h, w, c, device='cuda', generator=g)); wt = torch.randn(3, 3, c, device='cuda', generator=g) * 0.3
+    dy16 = _bits(torch.randn(n, ho, wo, c, device='cuda', generator=g))
+    st = stream()
+    i16 = dict(dtype=torch.int16, device='cuda')
+    y32 = torch.empty(n, ho, wo, c, device='cuda'); y16 = torch.empty(n, ho, wo, c, **i16)
+    _lib.call('fte_dwconv3x3_fwd', _f(x16), wt, y32, n, h, w, c, stride, st)
+    _lib.call('fte_dwconv3x3_fwd_s16', x16, wt, y16, n, h, w, c, stride, st)
+    assert torch.equal(y16, _bits(y32))
+    dx32 = torch.empty(n, h, w, c, device='cuda'); dx16 = torch.empty(n, h, w, c, **i16)
+    _lib.call('fte_dwconv3x3_dgrad', _f(dy16), wt, dx32, n, h, w, c, stride, st)
+    _lib.call('fte_dwconv3x3_dgrad_s16', dy16, wt, dx16, n, h, w, c, stride, st)
+    assert torch.equal(dx16, _bits(dx32))
+    buf, nb = ws(_lib.query('fte_dwconv3x3_wgrad_ws_bytes', n, h, w, c, stride))
+    dw0 = torch.empty(3, 3, c, device='cuda'); dw1 = torch.empty(3, 3, c, device='cuda')
+    _lib.call('fte_dwconv3x3_wgrad', _f(x16), _f(dy16), dw0, n, h, w, c, stride, buf, nb, st)
+    _lib.call('fte_dwconv3x3_wgrad_s16', x16, dy16, dw1, n, h, w, c, stride, buf, nb, st)
+    assert torch.equal(dw0, dw1)
+
+
+def test_channel_gathers_and_folded_bn_stats_s16():
+    g = torch.Generator(device='cuda').manual_seed(5)
+    rows, ca, cb = 3 * 7 * 5, 128, 64
+    a16 = _bits(torch.randn(rows, ca, device='cuda', generator=g)); b16 = _bits(torch.randn(rows, cb, device='cuda', generator=g))
+    co0, co1 = 128, 64
+    perm = torch.randperm(ca + cb, generator=torch.Generator().manual_seed(1)).tolist()
+    ent = [((0, k) if k < ca else (1, k - ca)) for k in perm]
+    t0 = torch.tensor([(s << 16) | ch for s, ch in ent[:co0 - 4]] + [-1] * 4, dtype=torch.int32, device='cuda')
+    t1 = torch.tensor([(s << 16) | ch for s, ch in ent[co0:co0 + co1]], dtype=torch.int32, device='cuda')
+    st = stream()
+    i16 = dict(dtype=torch.int16, device='cuda')
+    o32 = torch.empty(rows, co0, device='cuda'); o16 = torch.empty(rows, co0, **i16)
+    _lib.call('fte_channel_gather', _f(a16), _f(b16), o32, t0, rows, ca, cb, co0, st)
+    _lib.call('fte_channel_gather_s16', a16, b16, o16, t0, rows, ca, cb, co0, st)
+    assert torch.equal(o16, _bits(o32))
+    sca = torch.rand(ca, device='cuda', generator=g) + 0.5; sfa = torch.randn(ca, device='cuda', generator=g) * 0.2
+    scb = torch.rand(cb, device='cuda', generator=g) + 0.5; sfb = torch.randn(cb, device='cuda', generator=g) * 0.2
+    p32 = torch.empty(rows, co1, device='cuda'); p16 = torch.empty(rows, co1, **i16)
+    _lib.call('fte_channel_gather_affine', _f(a16), _f(b16), o32, t0, co0, p32, t1, co1, rows, ca, cb, sca, sfa, 1, scb, sfb, 0, st)
+    _lib.call('fte_channel_gather_affine_s16', a16, b16, o16, t0, co0, p16, t1, co1, rows, ca, cb, sca, sfa, 1, scb, sfb, 0, st)
+    assert torch.equal(o16, _bits(o32)) and torch.equal(p16, _bits(p32))
+    c = ca
+    gam = torch.rand(c, device='cuda', generator=g) + 0.5; bet = torch.randn(c, device='cuda', generator=g) * 0.2
+    wsb, nb = ws(_lib.query('fte_bn_ws_bytes', c))
+    v0 = [torch.empty(c, device='cuda') for _ in range(4)]; v1 = [torch.empty(c, device='cuda') for _ in range(4)]
+    _lib.call('fte_bn_train_stats', _f(a16), gam, bet, v0[0], v0[1], v0[2], v0[3], None, None, rows, c, 1e-3, 0.999, wsb, nb, st)
+    _lib.call('fte_bn_train_stats_s16', a16, gam, bet, v1[0], v1[1], v1[2], v1[3], None, None, rows, c, 1e-3, 0.999, 1, wsb, nb, st)
+    assert all(torch.equal(x, y) for x, y in zip(v0, v1))
+
+
+def env_width(net, name):
+    return net.real_c[name]
+
+
+def test_shufflenet_bf16s_step_vs_the_rounded_oracle(bf16s_mode):
+    """ShuffleNet-v2 x2.0 (small) in the bf16s mode: every tensor between two kernels is bf16 (the concat / shuffle / split
+    gathers, the depthwise convs, the folded batch norms' z) -- against the graph oracle with the same rounding points, and closer to
+    it than to the unrounded oracle.  Same loose whole-net tolerances as the ResNet-family test, for the same reason."""
+    from oracle import graphnet as og
+    n, ncls, hh = 16, 10, 112          # 256 samples per channel in the last stage: batch norm over fewer amplifies every rounding difference beyond use
+    graph, spec = og.shufflenet_train_graph('small', 3, ncls, 'NCHW')
+    p, state = og.init_params(spec, 181)
+    p = og.perturb(p, 182)
+    rng = np.random.default_rng(183)
+    x = rng.uniform(-1, 1, (n, hh, hh, 3)); y = rng.integers(0, ncls, n)
+    net = net_select('ShuffleNet-v2-small', 'NCHW', 5e-4)
+    net.build(hh, hh, 3, ncls, 'cuda')
+    net.load_params(p)
+    net.dropout_seed = 5
+    out = net.forward(dev(x), num_classes=ncls, is_training=True)
+    losses, names, _ = net.loss_function('T', dev(y, torch.int32), **out)
+    net.backward()
+    torch.cuda.synchronize()
+    assert net._act_s16 and len(net.folded) > 0 and all(net.t[k].dtype == torch.int16 for k in net.h16)
+    mask = host(net.t['features_drop/mask'])[:, :env_width(net, 'features_drop')]
+    kink = {}
+
+    def real(name):                                       # the tensor without its channel padding, as float64
+        t = net.t[name]
+        return host(_f(t) if t.dtype == torch.int16 else t)[..., :net.real_c[name]]
+    for op in net.graph:
+        if op[0] == 'relu':
+            kink[op[1]] = real(op[1])
+    # (the max-pool keeps the oracle's own arg-max: among bf16 values ties are exact, and against the UNROUNDED oracle the engine's choice
+    # can sit a bf16 ulp below the maximum -- outside the tie band that check allows)
+    kw = dict(masks={'features_drop': mask}, state=state, kink=kink, kink_mode='bf16')
+    with ops.operand_rounding('bf16'), ops.storage_rounding('bf16'):
+        l_r, g_r, env_r, _ = og.loss_and_grads(graph, p, x, y, 5e-4, stored=net.h16, stored_grad=net.g16, **kw)
+    l_u, g_u, env_u, _ = og.loss_and_grads(graph, p, x, y, 5e-4, **kw)
+
+    def rel(a, b):
+        return float(np.sqrt(((np.asarray(a, np.float64) - b) ** 2).sum()) / max(np.sqrt((b * b).sum()), 1e-30))
+    nf = env_r['features'].shape[1]
+    fr, fu = rel(host(net.t['features'])[:, :nf], env_r['features']), rel(host(net.t['features'])[:, :nf], env_u['features'])
+    own = rel(env_r['features'], env_u['features'])      # what the rounding points alone do to this net: oracle vs oracle
+    # all gradients as ONE vector (single small tensors of a 56-BN-layer net are noise at this precision, in the oracle too)
+    num_r = num_u = num_o = den = 0.0
+    for k in p:
+        got = host(net.get_variable(k, net.grads)) + (5e-4 * p[k] if k.endswith('weights') else 0)
+        assert np.isfinite(got).all(), k
+        num_r += ((got - g_r[k]) ** 2).sum(); num_u += ((got - g_u[k]) ** 2).sum(); num_o += ((g_r[k] - g_u[k]) ** 2).sum(); den += (g_u[k] ** 2).sum()
+    gr, gu, go = np.sqrt(num_r / den), np.sqrt(num_u / den), np.sqrt(num_o / den)
+    print('bf16s ShuffleNet-v2-small: features vs rounded oracle %.2e, vs unrounded %.2e (rounded vs unrounded oracle: %.2e); all gradients %.2e / %.2e (%.2e); loss %.5f vs %.5f' % (
+        fr, fu, own, gr, gu, go, float(losses[0]), l_r[0]))
+    # ShuffleNet-v2 is chaotic at bf16 precision even at 16 x 112 x 112: the ORACLE moves its own features by 13 % between its rounded and
+    # unrounded evaluation.  The engine must not be further from either than they are from each other (x 1.5); what the kernels
+    # compute is pinned bit for bit by the entry-point tests above -- this is the wiring check.
+    assert fr <= 1.5 * own and fu <= 1.5 * own and gr <= 1.5 * go and gu <= 1.5 * go
+    assert abs(float(losses[0]) - l_r[0]) <= 5e-3 * l_r[0]
+    step, ls, _, _ = Singular(net_select('ShuffleNet-v2-small', 'NCHW', 5e-4), 0.02, 'Momentum')(
+        {'images': dev(x), 'labels': dev(y, torch.int32), 'num_classes': ncls, 'num_examples': n})
+    hist = []
+    for _ in range(15):
+        step()
+        hist.append(float(ls[0]))
+    assert np.isfinite(hist).all() and min(hist[-4:]) < hist[0]

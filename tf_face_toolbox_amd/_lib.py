@@ -82,6 +82,12 @@ _SIGS = {
     'fte_gap_bwd_s16': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
     'fte_gconv3x3_bf16_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
     'fte_gconv3x3_wgrad_bf16_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
+    'fte_dwconv3x3_fwd_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
+    'fte_dwconv3x3_dgrad_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
+    'fte_dwconv3x3_wgrad_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),
+    'fte_channel_gather_s16': (c_int, [_P] * 4 + [c_long] + [c_int] * 3 + [_P]),
+    'fte_channel_gather_affine_s16': (c_int, [_P] * 4 + [c_int, _P, _P, c_int, c_long, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P]),
+    'fte_bn_train_stats_s16': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
     'fte_set_mfma_dtype': (c_int, [c_int]),
     'fte_get_mfma_dtype': (c_int, []),
     'fte_dwconv3x3_fwd': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),

@@ -1140,4 +1140,48 @@ int fte_channel_gather_affine(const float* a, const float* b, float* out, const 
                                       scale_b, shift_b, relu_b, (hipStream_t)stream));
 }
 
+// ---- bf16 STORAGE twins of ShuffleNet-v2's layers: every activation-side tensor bf16, filters / tables / per-channel vectors unchanged
+int fte_dwconv3x3_fwd_s16(const uint16_t* x16, const float* w, uint16_t* y16, int n, int h, int wd, int c, int stride, void* stream) {
+    if (!x16 || !w || !y16 || n <= 0 || c % 4 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_dwconv_fwd(f32p(x16), w, f32p(y16), n, h, wd, c, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream, 1));
+}
+int fte_dwconv3x3_dgrad_s16(const uint16_t* dy16, const float* w, uint16_t* dx16, int n, int h, int wd, int c, int stride, void* stream) {
+    if (!dy16 || !w || !dx16 || n <= 0 || c % 4 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    return rc(l_dwconv_dgrad(f32p(dy16), w, f32p(dx16), n, h, wd, c, ph.out, pw.out, stride, ph.before, pw.before, (hipStream_t)stream, 1));
+}
+int fte_dwconv3x3_wgrad_s16(const uint16_t* x16, const uint16_t* dy16, float* dw, int n, int h, int wd, int c, int stride,
+                            void* ws, size_t ws_bytes, void* stream) {
+    if (!x16 || !dy16 || !dw || n <= 0 || c % 4 || (stride != 1 && stride != 2)) return FTE_EINVAL;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    const int splits = l_dwconv_wgrad_splits((long)n * ph.out * pw.out, c);
+    const size_t need = align_up((size_t)splits * 9 * c * sizeof(float));
+    if (!ws || ws_bytes < need + SCRATCH_BYTES) return FTE_EWORKSPACE;
+    hipError_t e = l_dwconv_wgrad(f32p(x16), f32p(dy16), (float*)ws, n, h, wd, c, ph.out, pw.out, stride, ph.before, pw.before, splits, (hipStream_t)stream, 1);
+    if (e != hipSuccess) return (int)e;
+    return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, splits, 9L * c, 1, 1.f, (float*)((char*)ws + need), (hipStream_t)stream));
+}
+int fte_channel_gather_s16(const uint16_t* a, const uint16_t* b, uint16_t* out, const int32_t* table, long rows, int ca, int cb, int co, void* stream) {
+    if (!a || !out || !table || rows <= 0 || co <= 0 || co % 4) return FTE_EINVAL;
+    return rc(l_channel_gather(f32p(a), f32p(b ? b : a), f32p(out), table, rows, ca, cb, co, (hipStream_t)stream, 1));
+}
+int fte_channel_gather_affine_s16(const uint16_t* a, const uint16_t* b, uint16_t* out, const int32_t* table, int co,
+                                  uint16_t* out1, const int32_t* table1, int co1, long rows, int ca, int cb,
+                                  const float* scale_a, const float* shift_a, int relu_a,
+                                  const float* scale_b, const float* shift_b, int relu_b, void* stream) {
+    if (!a || !out || !table || rows <= 0 || co <= 0 || co % 4 || (scale_a && !shift_a) || (scale_b && (!shift_b || !b))) return FTE_EINVAL;
+    if (out1 ? (!table1 || co1 <= 0 || co1 % 4) : co1 != 0) return FTE_EINVAL;
+    return rc(l_channel_gather_affine(f32p(a), f32p(b ? b : a), f32p(out), table, co, f32p(out1), table1, co1, rows, ca, cb, scale_a, shift_a, relu_a,
+                                      scale_b, shift_b, relu_b, (hipStream_t)stream, 1));
+}
+int fte_bn_train_stats_s16(const void* z, const float* gamma, const float* beta, float* mean, float* rstd, float* scale, float* shift,
+                           float* moving_mean, float* moving_var, long rows, int c, float eps, float decay, int flags,
+                           void* ws, size_t ws_bytes, void* stream) {
+    if (!z || !gamma || !beta || !mean || !rstd || !scale || !shift || rows <= 0 || c % 4 || c < 32 || (flags & ~3)) return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_bn_ws_bytes(c)) return FTE_EWORKSPACE;
+    return rc(l_bn_train_stats(f32p(z), gamma, beta, rows, c, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
+                               (float*)ws, (hipStream_t)stream, flags));
+}
+
 }  // extern "C"

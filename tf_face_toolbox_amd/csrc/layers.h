@@ -43,12 +43,12 @@ hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int
 hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c,
                          int pre_sigmoid, hipStream_t st);
 hipError_t l_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, hipStream_t st);
-hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
-hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st);
+hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st, int h16 = 0);
+hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st, int h16 = 0);
 int l_dwconv_wgrad_splits(long npix, int c);
 hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, int h, int wd, int c, int ho, int wo, int stride,
-                          int pt, int pl, int splits, hipStream_t st);
-hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st);
+                          int pt, int pl, int splits, hipStream_t st, int h16 = 0);
+hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st, int h16 = 0);
 hipError_t l_channel_gather_affine(const float* a, const float* b, float* out0, const int* table0, int co0,
                                    float* out1, const int* table1, int co1, long rows, int ca, int cb,
-                                   const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st);
+                                   const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st, int h16 = 0);

@@ -1683,7 +1683,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 // source column of the window once -- (PX-1)*S + 3 loads per row instead of 3*PX, and no weight re-loads (the
 // one-pixel-per-thread loop issued 18 loads per output vector and ran at 25-35 % of HBM speed).
 // DGRAD at stride 1 is the same gather with the taps mirrored: dx[iy,ix] = sum dy[iy+pt-r, ix+pl-q] * w[r,q].
-template <bool DGRAD, int S>
+template <bool DGRAD, int S, bool H = false>      // H: x and y are bf16 in HBM (bf16 storage); the filter stays fp32
 __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             float* __restrict__ y, int n, int hs, int ws_, int c,
                                                             int ho, int wo, int pt, int pl) {
@@ -1708,12 +1708,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
         for (int r = 0; r < 3; ++r) {
             const int sy = DGRAD ? oy + pt - r : oy * S + r - pt;
             if (sy < 0 || sy >= hs) continue;
-            const float* rowp = x + ((long)(img * hs + sy) * ws_) * c + c4 * 4;
+            const long rowp = ((long)(img * hs + sy) * ws_) * c + c4 * 4;
             f32x4 v[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 const int sx = sx0 + j;
-                v[j] = (sx >= 0 && sx < ws_) ? *reinterpret_cast<const f32x4*>(rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[j] = (sx >= 0 && sx < ws_) ? ldq<H>(x, rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int p = 0; p < PX; ++p)
@@ -1726,7 +1726,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
         }
 #pragma unroll
         for (int p = 0; p < PX; ++p)
-            if (ox0 + p < wo) *reinterpret_cast<f32x4*>(y + (((long)(img * ho + oy) * wo + ox0 + p) * c) + c4 * 4) = acc[p];
+            if (ox0 + p < wo) stq<H>(y, (((long)(img * ho + oy) * wo + ox0 + p) * c) + c4 * 4, acc[p]);
     }
 }
 
@@ -1738,6 +1738,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_win_kernel(const float* __restr
 // division, no branch on the parity, and 0.75 loads per output vector instead of the 2.25 + 2.25 (weights) of the
 // pixel-per-thread gather above (44-52 % of the HBM roofline; the grid stride is a multiple of the channel-quad count, so the
 // weights are loaded once per thread).
+template <bool H = false>
 __global__ __launch_bounds__(256) void dwconv3x3_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                  float* __restrict__ dx, int n, int h, int wd, int c,
                                                                  int ho, int wo, int pt, int pl) {
@@ -1775,11 +1776,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_dgrad_s2_kernel(const float* __
         for (int k = 0; k < 2; ++k) {
             const int sy = a - 1 + pt + k;
             const bool rok = sy >= 0 && sy < ho;
-            const float* rowp = dy + ((long)(img * ho + (rok ? sy : 0)) * wo) * c + c4 * 4;
+            const long rowp = ((long)(img * ho + (rok ? sy : 0)) * wo) * c + c4 * 4;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int sx = b0 - 1 + pl + j;
-                v[k][j] = (rok && sx >= 0 && sx < wo) ? *reinterpret_cast<const f32x4*>(rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v[k][j] = (rok && sx >= 0 && sx < wo) ? ldq<H>(dy, rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll
@@ -1797,7 +1798,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_dgrad_s2_kernel(const float* __
                     for (int k = 0; k < 2; ++k)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc += v[k][pb + j] * wt[py][k][px][j];
-                    *reinterpret_cast<f32x4*>(dx + (((long)(img * h + iy) * wd + ix) * c) + c4 * 4) = acc;
+                    stq<H>(dx, (((long)(img * h + iy) * wd + ix) * c) + c4 * 4, acc);
                 }
         }
     }
@@ -1806,7 +1807,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_dgrad_s2_kernel(const float* __
 // dw[r,q,c] partials: block = Q channel quads x (256/Q) lanes over one chunk of 4-pixel groups (4 consecutive outputs of
 // one row): a lane loads the group's 4 dy vectors and each source column of the 3-row window once (3*(3*S+3) + 4 loads
 // per 4 pixels instead of 40)
-template <int Q, int S>
+template <int Q, int S, bool H = false>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ part, int n, int h, int wd, int c,
                                                               int ho, int wo, int pt, int pl, long grp_per_split) {
@@ -1829,19 +1830,18 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
             f32x4 d[PX];
 #pragma unroll
             for (int p = 0; p < PX; ++p)
-                d[p] = (ow0 + p < wo) ? *reinterpret_cast<const f32x4*>(dy + (((long)(img * ho + oh) * wo + ow0 + p) * c) + ch)
-                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+                d[p] = (ow0 + p < wo) ? ldq<H>(dy, (((long)(img * ho + oh) * wo + ow0 + p) * c) + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
             const int sx0 = ow0 * S - pl;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int ih = oh * S + r - pt;
                 if (ih < 0 || ih >= h) continue;
-                const float* rowp = x + ((long)(img * h + ih) * wd) * c + ch;
+                const long rowp = ((long)(img * h + ih) * wd) * c + ch;
                 f32x4 v[NC];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
                     const int sx = sx0 + j;
-                    v[j] = (sx >= 0 && sx < wd) ? *reinterpret_cast<const f32x4*>(rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[j] = (sx >= 0 && sx < wd) ? ldq<H>(x, rowp + (long)sx * c) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
@@ -1865,6 +1865,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
 // out[row, k] = (table[k] < 0) ? 0 : src[table[k] >> 16][row, table[k] & 0xffff]      (src 0 = a, 1 = b)
 // thread = 4 consecutive output channels: four 4-byte gathers (neighbouring lanes read neighbouring source channels), one
 // 16-byte store
+template <bool H>
+__device__ __forceinline__ float ld1(const float* p, long off) {
+    if constexpr (H) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p)[off] << 16);
+    else return p[off];
+}
+template <bool H = false>
 __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              float* __restrict__ out, const int* __restrict__ table,
                                                              long rows, int ca, int cb, int co) {
@@ -1881,11 +1887,11 @@ __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __rest
             float x = 0.f;
             if (tt[e] >= 0) {
                 const int ch = tt[e] & 0xffff;
-                x = (tt[e] >> 16) ? b[row * cb + ch] : a[row * ca + ch];
+                x = (tt[e] >> 16) ? ld1<H>(b, row * cb + ch) : ld1<H>(a, row * ca + ch);
             }
             v[e] = x;
         }
-        *reinterpret_cast<f32x4*>(out + row * co + 4 * k4) = v;
+        stq<H>(out, row * co + 4 * k4, v);
     }
 }
 
@@ -1893,6 +1899,7 @@ __global__ __launch_bounds__(256) void channel_gather_kernel(const float* __rest
 // source whose scale is given.  conv3_1x1's BN+ReLU output (and the stride-2 shortcut's) is consumed only by the concat /
 // shuffle / split that follows (nets/shufflenet_v2.py:110-113): it is never written to HBM.  Two outputs in one launch
 // (out1 / table1 / co1, optional): the two halves a block hands to the next one, or the gradients of both sources.
+template <bool H = false>
 __global__ __launch_bounds__(256) void channel_gather_affine_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                     float* __restrict__ out0, const int* __restrict__ table0, int co0,
                                                                     float* __restrict__ out1, const int* __restrict__ table1, int co1,
@@ -1915,44 +1922,50 @@ __global__ __launch_bounds__(256) void channel_gather_affine_kernel(const float*
             if (tt[e] >= 0) {
                 const int ch = tt[e] & 0xffff;
                 if (tt[e] >> 16) {
-                    x = b[row * cb + ch];
+                    x = ld1<H>(b, row * cb + ch);
                     if (scb) { x = __builtin_fmaf(x, scb[ch], sfb[ch]); if (relu_b) x = fmaxf(x, 0.f); }
                 } else {
-                    x = a[row * ca + ch];
+                    x = ld1<H>(a, row * ca + ch);
                     if (sca) { x = __builtin_fmaf(x, sca[ch], sfa[ch]); if (relu_a) x = fmaxf(x, 0.f); }
                 }
             }
             v[e] = x;
         }
-        *reinterpret_cast<f32x4*>((second ? out1 + row * co1 : out0 + row * co0) + 4 * k4) = v;
+        if (second) stq<H>(out1, row * co1 + 4 * k4, v);
+        else stq<H>(out0, row * co0 + 4 * k4, v);
     }
 }
 
 }  // namespace
 
-hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
+hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st, int h16) {
     const long total = (long)n * ho * ((wo + 3) / 4) * (c / 4);
     const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
-    if (stride == 1) hipLaunchKernelGGL((dwconv3x3_win_kernel<false, 1>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
-    else hipLaunchKernelGGL((dwconv3x3_win_kernel<false, 2>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
+    if (h16) {
+        if (stride == 1) hipLaunchKernelGGL((dwconv3x3_win_kernel<false, 1, true>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
+        else hipLaunchKernelGGL((dwconv3x3_win_kernel<false, 2, true>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
+    } else if (stride == 1) hipLaunchKernelGGL((dwconv3x3_win_kernel<false, 1, false>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
+    else hipLaunchKernelGGL((dwconv3x3_win_kernel<false, 2, false>), grid, dim3(256), 0, st, x, w, y, n, h, wd, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
-hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st) {
+hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st, int h16) {
     if (stride == 1) {                       // source = dy (ho x wo = h x wd at stride 1), destination = dx
         const long total = (long)n * h * ((wd + 3) / 4) * (c / 4);
         const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
-        hipLaunchKernelGGL((dwconv3x3_win_kernel<true, 1>), grid, dim3(256), 0, st, dy, w, dx, n, ho, wo, c, h, wd, pt, pl);
+        if (h16) hipLaunchKernelGGL((dwconv3x3_win_kernel<true, 1, true>), grid, dim3(256), 0, st, dy, w, dx, n, ho, wo, c, h, wd, pt, pl);
+        else hipLaunchKernelGGL((dwconv3x3_win_kernel<true, 1, false>), grid, dim3(256), 0, st, dy, w, dx, n, ho, wo, c, h, wd, pt, pl);
         return hipGetLastError();
     }
-    static const bool old_gather = getenv("FTE_DW_DGRAD_S2") && atoi(getenv("FTE_DW_DGRAD_S2")) == 0;      // A/B hook: the pixel-per-thread gather
-    if (old_gather) {
+    static const bool old_gather = getenv("FTE_DW_DGRAD_S2") && atoi(getenv("FTE_DW_DGRAD_S2")) == 0;      // A/B hook: the pixel-per-thread gather (fp32 tensors only)
+    if (old_gather && !h16) {
         const long total = (long)n * h * wd * (c / 4);
         const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
         hipLaunchKernelGGL((dwconv3x3_kernel<true, 2>), grid, dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
         return hipGetLastError();
     }
     const long total = (long)n * ((h + 1) / 2) * ((((wd + 1) / 2) + 1) / 2) * (c / 4);
-    hipLaunchKernelGGL(dwconv3x3_dgrad_s2_kernel, dim3(grid_for_c(total, c)), dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
+    if (h16) hipLaunchKernelGGL(dwconv3x3_dgrad_s2_kernel<true>, dim3(grid_for_c(total, c)), dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
+    else hipLaunchKernelGGL(dwconv3x3_dgrad_s2_kernel<false>, dim3(grid_for_c(total, c)), dim3(256), 0, st, dy, w, dx, n, h, wd, c, ho, wo, pt, pl);
     return hipGetLastError();
 }
 static int dw_quads(int c) { return c >= 256 ? 64 : (c >= 128 ? 32 : 16); }
@@ -1965,11 +1978,12 @@ int l_dwconv_wgrad_splits(long npix, int c) {
     return (int)(s < 1 ? 1 : s);
 }
 hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, int h, int wd, int c, int ho, int wo, int stride,
-                          int pt, int pl, int splits, hipStream_t st) {
+                          int pt, int pl, int splits, hipStream_t st, int h16) {
     const long ngrp = (long)n * ho * ((wo + 3) / 4), gps = (ngrp + splits - 1) / splits;
     const int Q = dw_quads(c);
     const dim3 grid((c / 4 + Q - 1) / Q, splits);
-#define FTE_DWW(Q_, S_) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<Q_, S_>), grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, pt, pl, gps)
+#define FTE_DWW(Q_, S_) do { if (h16) hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<Q_, S_, true>), grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, pt, pl, gps); \
+                             else hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<Q_, S_, false>), grid, dim3(256), 0, st, x, dy, part, n, h, wd, c, ho, wo, pt, pl, gps); } while (0)
     if (stride == 1) { switch (Q) { case 64: FTE_DWW(64, 1); break; case 32: FTE_DWW(32, 1); break; default: FTE_DWW(16, 1); } }
     else { switch (Q) { case 64: FTE_DWW(64, 2); break; case 32: FTE_DWW(32, 2); break; default: FTE_DWW(16, 2); } }
 #undef FTE_DWW
@@ -1977,14 +1991,17 @@ hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, i
 }
 hipError_t l_channel_gather_affine(const float* a, const float* b, float* out0, const int* table0, int co0,
                                    float* out1, const int* table1, int co1, long rows, int ca, int cb,
-                                   const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st) {
+                                   const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st, int h16) {
     const long total = rows * ((co0 + co1) / 4);
-    hipLaunchKernelGGL(channel_gather_affine_kernel, dim3((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0, st,
-                       a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b);
+    const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+    if (h16) hipLaunchKernelGGL(channel_gather_affine_kernel<true>, grid, dim3(256), 0, st, a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b);
+    else hipLaunchKernelGGL(channel_gather_affine_kernel<false>, grid, dim3(256), 0, st, a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b);
     return hipGetLastError();
 }
-hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st) {
+hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st, int h16) {
     const long total = rows * (co / 4);
-    hipLaunchKernelGGL(channel_gather_kernel, dim3((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256)), dim3(256), 0, st, a, b, out, table, rows, ca, cb, co);
+    const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
+    if (h16) hipLaunchKernelGGL(channel_gather_kernel<true>, grid, dim3(256), 0, st, a, b, out, table, rows, ca, cb, co);
+    else hipLaunchKernelGGL(channel_gather_kernel<false>, grid, dim3(256), 0, st, a, b, out, table, rows, ca, cb, co);
     return hipGetLastError();
 }

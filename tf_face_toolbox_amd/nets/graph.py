@@ -55,7 +55,10 @@ class _Activations(dict):
             raise KeyError(name)
         z, relu = net.folded[name]
         b = net.bn[name]
-        y = torch.addcmul(b['shift'], self[z], b['scale'])
+        zz = self[z]
+        if zz.dtype == torch.int16:                      # bf16 storage
+            zz = zz.view(torch.bfloat16).float()
+        y = torch.addcmul(b['shift'], zz, b['scale'])
         return torch.relu(y) if relu else y
 
 
@@ -459,19 +462,20 @@ class GraphNet(Network):
         return False
 
     # ---- buffers --------------------------------------------------------------------------------------
-    S16_OPS = ('conv', 'bn', 'gconv', 'maxpool', 'addrelu', 'gap', 'dropout', 'fc')
+    S16_OPS = ('conv', 'bn', 'bnstats', 'gconv', 'dwconv', 'gather', 'maxpool', 'addrelu', 'gap', 'dropout', 'fc')
 
     def _storage16(self):
-        """bf16 STORAGE ('bf16s', fte.h): the tensors between the layers live in HBM as bf16 -- implemented for the ResNet family's
-        op set (conv / BN / grouped 3x3 on the bf16 MFMA / max-pool / add+ReLU / GAP; BASELINE.json configs[2]).  Nets with other ops
-        (channel gathers, depthwise convs, SE gates) run the 'bf16' operand mode instead: same MFMA precision, fp32 tensors."""
+        """bf16 STORAGE ('bf16s', fte.h): the tensors between the layers live in HBM as bf16 -- implemented for the op sets of the ResNet
+        family (conv / BN / grouped 3x3 on the bf16 MFMA / max-pool / add+ReLU / GAP; BASELINE.json configs[2]) and of ShuffleNet-v2
+        (depthwise 3x3, channel gathers with folded BN).  Nets with SE gates run the 'bf16' operand mode instead: same MFMA
+        precision, fp32 tensors."""
         if not _lib.bf16_storage():
             return False
         ok = all(op[0] in self.S16_OPS for op in self.plan) and \
             all(self._gconv_pack(op) is not None for op in self.plan if op[0] == 'gconv')
         if not ok and not getattr(self, '_s16_note', False):
             self._s16_note = True
-            print('%s: bf16 storage is implemented for the ResNet-family op set; this net runs bf16 MFMA operands with fp32 tensors' % self.name)
+            print('%s: bf16 storage is not implemented for SE gates; this net runs bf16 MFMA operands with fp32 tensors' % self.name)
         return ok
 
     def _is16(self, name):
@@ -490,9 +494,17 @@ class GraphNet(Network):
         self.h16 = set()
         if s16:
             for op in self.plan:
-                if op[0] in ('bn', 'gconv', 'maxpool', 'addrelu') or (op[0] == 'conv' and self.shapes[op[2]][-1] >= 32):
+                if op[0] in ('bn', 'gconv', 'dwconv', 'maxpool', 'addrelu'):
                     self.h16.add(op[1])
+                elif op[0] == 'conv':          # the MFMA convs and the direct 3x3 stem write bf16; the im2col stem is an fp32 GEMM
+                    cin = self.shapes[op[2]][-1]
+                    if cin >= 32 or self._direct_stem(self.spec[op[3]][0][0], cin, self.shapes[op[1]][-1]):
+                        self.h16.add(op[1])
+                elif op[0] == 'gather':
+                    self.h16.update(name for name, _ in op[2]['outs'])
             self._pack_entries = []
+        # tensors whose GRADIENT is stored as bf16: the stored ones and the BN outputs folded into a gather (never stored themselves)
+        self.g16 = set(self.h16) | (set(self.folded) if s16 else set())
         self.t = _Activations(self)
         self.bn = {}
         self.ident = {}
@@ -502,7 +514,7 @@ class GraphNet(Network):
             kind, out = op[0], op[1]
             if kind == 'gather':
                 for name, _ in op[2]['outs']:
-                    self.t[name] = torch.empty((n,) + self.shapes[name], **f32)
+                    self.t[name] = torch.empty((n,) + self.shapes[name], **(i16 if s16 else f32))
                 continue
             shape = (n,) + self.shapes[out]
             if kind != 'bnstats':
@@ -608,7 +620,10 @@ class GraphNet(Network):
                     call('fte_conv2d_fwd', T[inp], self.view(wname), None, None, None, None, T[out],
                          n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 elif self._direct_stem(k, cin, cout):          # 3x3 stem of 32 / 64 stored filters: the direct MFMA kernel
-                    call('fte_conv3x3_first_fwd', T[inp], self.view(wname), None, None, None, T[out], n, ih, iw, cin, cout, stride, st)
+                    if s16:
+                        call('fte_conv3x3_first_fwd_s16', T[inp], self.view(wname), None, None, None, T[out], n, ih, iw, cin, cout, stride, st)
+                    else:
+                        call('fte_conv3x3_first_fwd', T[inp], self.view(wname), None, None, None, T[out], n, ih, iw, cin, cout, stride, st)
                 else:                                          # other stems (7x7): im2col + dense MFMA GEMM
                     oh, ow, _ = self.shapes[out]
                     kpad = stem_kpad(k, cin)
@@ -617,7 +632,7 @@ class GraphNet(Network):
                          self.ws, self.ws_bytes, st)
             elif kind == 'dwconv':
                 ih, iw, c = self.shapes[op[2]]
-                call('fte_dwconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[4], st)
+                call('fte_dwconv3x3_fwd_s16' if s16 else 'fte_dwconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[4], st)
             elif kind == 'gather':
                 a, b = op[2]['ins']
                 fa, fb = self.folded.get(a), self.folded.get(b)
@@ -625,14 +640,14 @@ class GraphNet(Network):
                 if fa is None and fb is None and len(outs) == 1:
                     name, table = outs[0]
                     co = self.shapes[name][-1]
-                    call('fte_channel_gather', T[a], T[b] if b else None, T[name], table, T[name].numel() // co,
+                    call('fte_channel_gather_s16' if s16 else 'fte_channel_gather', T[a], T[b] if b else None, T[name], table, T[name].numel() // co,
                          self.shapes[a][-1], self.shapes[b][-1] if b else 0, co, st)
                 else:                                          # both halves in one launch, BN applied to a folded source
                     sa = (T[fa[0]], self.bn[a]['scale'], self.bn[a]['shift'], fa[1]) if fa else (T[a], None, None, 0)
                     sb = (T[fb[0]], self.bn[b]['scale'], self.bn[b]['shift'], fb[1]) if fb else (T[b] if b else None, None, None, 0)
                     (n0, t0), (n1, t1) = outs[0], (outs[1] if len(outs) > 1 else (None, None))
                     co0 = self.shapes[n0][-1]
-                    call('fte_channel_gather_affine', sa[0], sb[0], T[n0], t0, co0, T[n1] if n1 else None, t1,
+                    call('fte_channel_gather_affine_s16' if s16 else 'fte_channel_gather_affine', sa[0], sb[0], T[n0], t0, co0, T[n1] if n1 else None, t1,
                          self.shapes[n1][-1] if n1 else 0, T[n0].numel() // co0, self.shapes[a][-1],
                          self.shapes[b][-1] if b else 0, sa[1], sa[2], sa[3], sb[1], sb[2], sb[3], st)
             elif kind == 'bnstats':
@@ -640,7 +655,13 @@ class GraphNet(Network):
                 b = self.bn[out]
                 c = self.shapes[out][-1]
                 rows = T[inp].numel() // c
-                if is_training:
+                if is_training and s16:
+                    upd = self.update_moving_stats
+                    call('fte_bn_train_stats_s16', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
+                         b['mean'], b['rstd'], b['scale'], b['shift'],
+                         self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None,
+                         rows, c, BN_EPS, BN_DECAY, 1 if inp in h16 else 0, self.ws, self.ws_bytes, st)
+                elif is_training:
                     upd = self.update_moving_stats
                     call('fte_bn_train_stats', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
                          b['mean'], b['rstd'], b['scale'], b['shift'],
@@ -926,15 +947,15 @@ class GraphNet(Network):
                     continue
                 da = G.pop(ga)
                 db = G.pop(gb) if gb else None
-                gs = [(name, table, torch.empty((n,) + self.shapes[name], dtype=torch.float32, device=self.device))
+                gs = [(name, table, torch.empty((n,) + self.shapes[name], dtype=torch.int16 if s16 else torch.float32, device=self.device))
                       for name, table in op[2]['bwd']]
                 (n0, t0, g0), (n1, t1, g1) = gs[0], (gs[1] if len(gs) > 1 else (None, None, None))
                 co0 = self.shapes[n0][-1]
                 if g1 is None:
-                    call('fte_channel_gather', da, db, g0, t0, g0.numel() // co0, da.shape[-1],
+                    call('fte_channel_gather_s16' if s16 else 'fte_channel_gather', da, db, g0, t0, g0.numel() // co0, da.shape[-1],
                          db.shape[-1] if db is not None else 0, co0, st)
                 else:                                    # the gradients of both sources in one launch
-                    call('fte_channel_gather_affine', da, db, g0, t0, co0, g1, t1, self.shapes[n1][-1], g0.numel() // co0,
+                    call('fte_channel_gather_affine_s16' if s16 else 'fte_channel_gather_affine', da, db, g0, t0, co0, g1, t1, self.shapes[n1][-1], g0.numel() // co0,
                          da.shape[-1], db.shape[-1] if db is not None else 0, None, None, 0, None, None, 0, st)
                 for name, _, g in gs:
                     self._put(name, g)
@@ -945,9 +966,9 @@ class GraphNet(Network):
             if kind == 'dwconv':
                 _, _, inp, wname, stride = op
                 ih, iw, c = self.shapes[inp]
-                wgrad('fte_dwconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, stride, wws, self.ws_bytes, wst)
+                wgrad('fte_dwconv3x3_wgrad_s16' if s16 else 'fte_dwconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
-                call('fte_dwconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, stride, st)
+                call('fte_dwconv3x3_dgrad_s16' if s16 else 'fte_dwconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, stride, st)
                 self._put(inp, dx)
             elif kind == 'dropout':
                 g = self._new(op[2])
@@ -1044,7 +1065,7 @@ class GraphNet(Network):
                 cout = self.shapes[out][-1]
                 gw = self.view(wname, self.grads)
                 if cin < 32 and self._direct_stem(k, cin, cout):
-                    call('fte_conv3x3_first_wgrad', T[inp], dy, gw, n, ih, iw, cin, cout, stride, self.ws, self.ws_bytes, st)
+                    call('fte_conv3x3_first_wgrad_s16' if s16 else 'fte_conv3x3_first_wgrad', T[inp], dy, gw, n, ih, iw, cin, cout, stride, self.ws, self.ws_bytes, st)
                     continue
                 if cin < 32:                             # stem: filter gradient only
                     oh, ow, _ = self.shapes[out]
