@@ -326,6 +326,13 @@ int fte_gconv3x3_wgrad_bf16_s16(const uint16_t* x16, const uint16_t* dz16, float
 /* ShuffleNet-v2's layers on bf16 tensors (nets/shufflenet_v2.py): depthwise 3x3 forward / data gradient / filter gradient (fp32 filter
  * and dw), the channel gather and the gather with batch norm folded in (sources and results bf16, tables / scale / shift unchanged),
  * and the statistics-only pass of a folded batch norm (`flags` as above: FTE_S16_Z = z is bf16). */
+/* the SE gate on bf16 tensors: y = x * gate; dgate = sum_hw dy * x (reduction only); dx = dy * gate + dsq * scale in ONE pass -- written
+ * once, rounded once (gate, dgate, dsq are [n, c] fp32) */
+int fte_channel_scale_fwd_s16(const uint16_t* x16, const float* gate, uint16_t* y16, int n, int hw, int c, void* stream);
+int fte_channel_scale_bwd_s16(const uint16_t* dy16, const uint16_t* x16, const float* gate, float* dgate, int n, int hw, int c,
+                              int pre_sigmoid, void* stream);
+int fte_channel_scale_bwd_apply_s16(const uint16_t* dy16, const float* gate, const float* dsq, uint16_t* dx16, int n, int hw, int c,
+                                    float scale, void* stream);
 int fte_dwconv3x3_fwd_s16(const uint16_t* x16, const float* w, uint16_t* y16, int n, int h, int wd, int c, int stride, void* stream);
 int fte_dwconv3x3_dgrad_s16(const uint16_t* dy16, const float* w, uint16_t* dx16, int n, int h, int wd, int c, int stride, void* stream);
 int fte_dwconv3x3_wgrad_s16(const uint16_t* x16, const uint16_t* dy16, float* dw, int n, int h, int wd, int c, int stride,

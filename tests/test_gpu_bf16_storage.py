@@ -332,7 +332,7 @@ def test_bn_net_bf16s_step_vs_the_rounded_oracle(bf16s_mode, name, variant, laye
     assert abs(float(losses[0]) - l_r[0]) <= 2e-3 * l_r[0]
 
 
-def test_resnext_bf16s_trains_two_streams_and_se_nets_fall_back(bf16s_mode):
+def test_resnext_bf16s_trains_two_streams_and_senet_triplet_runs(bf16s_mode):
     n, ncls, hh = 16, 10, 64
     rng = np.random.default_rng(21)
     x = dev(rng.uniform(-1, 1, (n, hh, hh, 3))); y = dev(rng.integers(0, ncls, n), torch.int32)
@@ -357,10 +357,14 @@ def test_resnext_bf16s_trains_two_streams_and_se_nets_fall_back(bf16s_mode):
     assert torch.equal(arenas[0], arenas[1])
     f = net.eval_features(x)
     assert f.shape == (n, 2048) and f.dtype == torch.float32 and torch.isfinite(f).all()
-    se = net_select('SENet-50', 'NCHW', 5e-4)                                 # SE gates: bf16 operands, fp32 tensors (a printed note, not an error)
-    step, ls, _, _ = Singular(se, 0.02, 'Momentum')({'images': x, 'labels': y, 'num_classes': ncls, 'num_examples': n})
-    step()
-    assert not se._act_s16 and np.isfinite(float(ls[0]))
+    se = net_select('SENet-50-triplet', 'NCHW', 5e-4)                         # config 4's net (SE gates, no classifier) in the same mode
+    yk = dev(np.repeat(np.arange(4), 4), torch.int32)
+    step, ls, _, _ = Singular(se, 0.02, 'Momentum')({'images': x, 'labels': yk, 'num_classes': ncls, 'num_examples': n})
+    h0 = None
+    for _ in range(6):
+        step()
+        h0 = float(ls[0]) if h0 is None else h0
+    assert se._act_s16 and np.isfinite(float(ls[0])) and h0 > 0
 
 
 def test_filter_packs_table_equals_per_conv_packs():
@@ -504,3 +508,28 @@ def test_shufflenet_bf16s_step_vs_the_rounded_oracle(bf16s_mode):
         step()
         hist.append(float(ls[0]))
     assert np.isfinite(hist).all() and min(hist[-4:]) < hist[0]
+
+
+def test_se_gate_s16():
+    """the SE gate on bf16 tensors: scale and reduction equal the fp32 entry points on the same bf16-exact inputs; the one-pass input
+    gradient dx = dy * gate + dsq / hw equals the fp32 flow (dy * gate written, broadcast added in place) evaluated in fp32 and rounded ONCE."""
+    g = torch.Generator(device='cuda').manual_seed(9)
+    n, hw, c = 5, 7 * 7, 256
+    x16 = _bits(torch.randn(n, hw, c, device='cuda', generator=g)); dy16 = _bits(torch.randn(n, hw, c, device='cuda', generator=g))
+    gate = torch.rand(n, c, device='cuda', generator=g); dsq = torch.randn(n, c, device='cuda', generator=g)
+    st = stream()
+    i16 = dict(dtype=torch.int16, device='cuda')
+    y32 = torch.empty(n, hw, c, device='cuda'); y16 = torch.empty(n, hw, c, **i16)
+    _lib.call('fte_channel_scale_fwd', _f(x16), gate, y32, n, hw, c, st)
+    _lib.call('fte_channel_scale_fwd_s16', x16, gate, y16, n, hw, c, st)
+    assert torch.equal(y16, _bits(y32))
+    dx32 = torch.empty(n, hw, c, device='cuda'); dg0 = torch.empty(n, c, device='cuda'); dg1 = torch.empty(n, c, device='cuda')
+    _lib.call('fte_channel_scale_bwd', _f(dy16), _f(x16), gate, dx32, dg0, n, hw, c, 1, st)
+    _lib.call('fte_channel_scale_bwd_s16', dy16, x16, gate, dg1, n, hw, c, 1, st)
+    assert torch.equal(dg0, dg1)
+    dx16 = torch.empty(n, hw, c, **i16)
+    _lib.call('fte_channel_scale_bwd_apply_s16', dy16, gate, dsq, dx16, n, hw, c, 1.0 / hw, st)
+    ref = torch.addcmul(_f(dy16) * gate[:, None, :], dsq[:, None, :], torch.full((1,), 1.0 / hw, device='cuda'))
+    ok = (dx16 == _bits(ref))
+    assert float(ok.float().mean()) > 0.999          # fused multiply-add vs two roundings in the torch expression: a bf16 tie now and then
+    assert (_f(dx16) - ref).abs().max() <= 2 ** -7 * ref.abs().max()

@@ -82,6 +82,9 @@ _SIGS = {
     'fte_gap_bwd_s16': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
     'fte_gconv3x3_bf16_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P]),
     'fte_gconv3x3_wgrad_bf16_s16': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
+    'fte_channel_scale_fwd_s16': (c_int, [_P] * 3 + [c_int] * 3 + [_P]),
+    'fte_channel_scale_bwd_s16': (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
+    'fte_channel_scale_bwd_apply_s16': (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P]),
     'fte_dwconv3x3_fwd_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_dgrad_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_wgrad_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),

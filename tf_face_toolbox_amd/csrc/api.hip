@@ -1099,6 +1099,22 @@ int fte_channel_scale_bwd(const float* dy, const float* x, const float* gate, fl
     return rc(l_chscale_bwd(dy, x, gate, dx, dgate, n, hw, c, pre_sigmoid ? 1 : 0, (hipStream_t)stream));
 }
 
+// SE gate on bf16 tensors (fte.h, bf16 STORAGE): scale, the gate-gradient reduction (no dx), and the one-pass input gradient
+int fte_channel_scale_fwd_s16(const uint16_t* x16, const float* gate, uint16_t* y16, int n, int hw, int c, void* stream) {
+    if (!x16 || !gate || !y16 || n <= 0 || c % 4) return FTE_EINVAL;
+    return rc(l_chscale_fwd(f32p(x16), gate, f32p(y16), n, hw, c, (hipStream_t)stream, 1));
+}
+int fte_channel_scale_bwd_s16(const uint16_t* dy16, const uint16_t* x16, const float* gate, float* dgate, int n, int hw, int c,
+                              int pre_sigmoid, void* stream) {
+    if (!dy16 || !x16 || !gate || !dgate || n <= 0 || c <= 0 || c % 4) return FTE_EINVAL;
+    return rc(l_chscale_bwd(f32p(dy16), f32p(x16), gate, nullptr, dgate, n, hw, c, pre_sigmoid ? 1 : 0, (hipStream_t)stream, 1));
+}
+int fte_channel_scale_bwd_apply_s16(const uint16_t* dy16, const float* gate, const float* dsq, uint16_t* dx16, int n, int hw, int c,
+                                    float scale, void* stream) {
+    if (!dy16 || !gate || !dsq || !dx16 || n <= 0 || c <= 0 || c % 4) return FTE_EINVAL;
+    return rc(l_chscale_bwd_apply(f32p(dy16), gate, dsq, f32p(dx16), n, hw, c, scale, (hipStream_t)stream, 1));
+}
+
 // ------------------------------------------------------------------------------------------------
 // ShuffleNet-v2: depthwise 3x3, channel gather
 int fte_dwconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int stride, void* stream) {

@@ -39,9 +39,10 @@ hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, in
                          int stride, int pt, int pl, int chunks, hipStream_t st);
 hipError_t l_act_fwd(const float* x, float* y, long n, int kind, hipStream_t st);
 hipError_t l_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, hipStream_t st);
-hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st);
+hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st, int h16 = 0);
+hipError_t l_chscale_bwd_apply(const float* dy, const float* gate, const float* dsq, float* dx, int n, int hw, int c, float scale, hipStream_t st, int h16 = 0);
 hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c,
-                         int pre_sigmoid, hipStream_t st);
+                         int pre_sigmoid, hipStream_t st, int h16 = 0);
 hipError_t l_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, hipStream_t st);
 hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st, int h16 = 0);
 hipError_t l_dwconv_dgrad(const float* dy, const float* w, float* dx, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st, int h16 = 0);

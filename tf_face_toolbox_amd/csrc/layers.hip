@@ -1453,18 +1453,33 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 // y[n,hw,c] = x * gate[n,c]
+template <bool H = false>      // H: x / y (and dy / dx below) are bf16 in HBM; gate, dgate, dsq are [n, c] fp32
 __global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                           float* __restrict__ y, long n4, int hw, int c) {
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    f32x4* y4 = reinterpret_cast<f32x4*>(y);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const long e = i * 4;
         const int ch = (int)(e % c);
         const long img = e / ((long)hw * c);
-        y4[i] = x4[i] * *reinterpret_cast<const f32x4*>(gate + img * c + ch);
+        stq<H>(y, e, ldq<H>(x, e) * *reinterpret_cast<const f32x4*>(gate + img * c + ch));
+    }
+}
+// dx = dy * gate + dsq * scale: the whole gradient of an SE block's input in one pass (the gate path's dy * gate and the squeeze
+// path's broadcast), after chscale_bwd_kernel's reduction has gone through the two dense layers.  With bf16 storage dx is written
+// once, rounded once (the fp32 flow below writes dy * gate first and adds the broadcast in place).
+template <bool H = false>
+__global__ __launch_bounds__(256) void chscale_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ gate,
+                                                                const float* __restrict__ dsq, float* __restrict__ dx,
+                                                                long n4, int hw, int c, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int ch = (int)(e % c);
+        const long img = e / ((long)hw * c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gate + img * c + ch), q = *reinterpret_cast<const f32x4*>(dsq + img * c + ch);
+        stq<H>(dx, e, ldq<H>(dy, e) * g + q * scale);
     }
 }
 // dx = dy * gate ; dgate[n,c] = sum_hw dy * x   (block = one image x 16 channel quads x 16 row lanes, float4, fixed-order LDS sum)
+template <bool H = false>      // dx may be NULL: reduction only
 __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ gate, float* __restrict__ dx,
                                                           float* __restrict__ dgate, int hw, int c, int pre_sigmoid) {
@@ -1477,9 +1492,9 @@ __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restric
         gt = *reinterpret_cast<const f32x4*>(gate + (long)img * c + ch);
         for (int r = rl; r < hw; r += 16) {
             const long o = ((long)img * hw + r) * c + ch;
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o);
-            s += d * *reinterpret_cast<const f32x4*>(x + o);
-            *reinterpret_cast<f32x4*>(dx + o) = d * gt;
+            const f32x4 d = ldq<H>(dy, o);
+            s += d * ldq<H>(x, o);
+            if (dx) stq<H>(dx, o, d * gt);
         }
     }
     sh[rl][q] = s;
@@ -1608,14 +1623,24 @@ hipError_t l_act_bwd(const float* dy, const float* y, float* dx, long n, int kin
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, dy, y, dx, n, kind);
     return hipGetLastError();
 }
-hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st) {
+hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st, int h16) {
     const long n4 = (long)n * hw * c / 4;
-    hipLaunchKernelGGL(chscale_fwd_kernel, dim3((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256)), dim3(256), 0, st, x, gate, y, n4, hw, c);
+    const dim3 grid((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256));
+    if (h16) hipLaunchKernelGGL(chscale_fwd_kernel<true>, grid, dim3(256), 0, st, x, gate, y, n4, hw, c);
+    else hipLaunchKernelGGL(chscale_fwd_kernel<false>, grid, dim3(256), 0, st, x, gate, y, n4, hw, c);
     return hipGetLastError();
 }
 hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c,
-                         int pre_sigmoid, hipStream_t st) {
-    hipLaunchKernelGGL(chscale_bwd_kernel, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, dy, x, gate, dx, dgate, hw, c, pre_sigmoid);
+                         int pre_sigmoid, hipStream_t st, int h16) {
+    if (h16) hipLaunchKernelGGL(chscale_bwd_kernel<true>, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, dy, x, gate, dx, dgate, hw, c, pre_sigmoid);
+    else hipLaunchKernelGGL(chscale_bwd_kernel<false>, dim3((c / 4 + 15) / 16, n), dim3(256), 0, st, dy, x, gate, dx, dgate, hw, c, pre_sigmoid);
+    return hipGetLastError();
+}
+hipError_t l_chscale_bwd_apply(const float* dy, const float* gate, const float* dsq, float* dx, int n, int hw, int c, float scale, hipStream_t st, int h16) {
+    const long n4 = (long)n * hw * c / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256));
+    if (h16) hipLaunchKernelGGL(chscale_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, gate, dsq, dx, n4, hw, c, scale);
+    else hipLaunchKernelGGL(chscale_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, gate, dsq, dx, n4, hw, c, scale);
     return hipGetLastError();
 }
 

@@ -462,20 +462,20 @@ class GraphNet(Network):
         return False
 
     # ---- buffers --------------------------------------------------------------------------------------
-    S16_OPS = ('conv', 'bn', 'bnstats', 'gconv', 'dwconv', 'gather', 'maxpool', 'addrelu', 'gap', 'dropout', 'fc')
+    S16_OPS = ('conv', 'bn', 'bnstats', 'gconv', 'dwconv', 'gather', 'se', 'maxpool', 'addrelu', 'gap', 'dropout', 'fc')
 
     def _storage16(self):
         """bf16 STORAGE ('bf16s', fte.h): the tensors between the layers live in HBM as bf16 -- implemented for the op sets of the ResNet
         family (conv / BN / grouped 3x3 on the bf16 MFMA / max-pool / add+ReLU / GAP; BASELINE.json configs[2]) and of ShuffleNet-v2
-        (depthwise 3x3, channel gathers with folded BN).  Nets with SE gates run the 'bf16' operand mode instead: same MFMA
-        precision, fp32 tensors."""
+        (depthwise 3x3, channel gathers with folded BN) and SE gates.  A grouped 3x3 that cannot run on the bf16 MFMA (channels per
+        group not 4 / 8 / 16 / 32) makes the net fall back to the 'bf16' operand mode: same MFMA precision, fp32 tensors."""
         if not _lib.bf16_storage():
             return False
         ok = all(op[0] in self.S16_OPS for op in self.plan) and \
             all(self._gconv_pack(op) is not None for op in self.plan if op[0] == 'gconv')
         if not ok and not getattr(self, '_s16_note', False):
             self._s16_note = True
-            print('%s: bf16 storage is not implemented for SE gates; this net runs bf16 MFMA operands with fp32 tensors' % self.name)
+            print('%s: bf16 storage is not implemented for one of its ops; this net runs bf16 MFMA operands with fp32 tensors' % self.name)
         return ok
 
     def _is16(self, name):
@@ -494,7 +494,7 @@ class GraphNet(Network):
         self.h16 = set()
         if s16:
             for op in self.plan:
-                if op[0] in ('bn', 'gconv', 'dwconv', 'maxpool', 'addrelu'):
+                if op[0] in ('bn', 'gconv', 'dwconv', 'se', 'maxpool', 'addrelu'):
                     self.h16.add(op[1])
                 elif op[0] == 'conv':          # the MFMA convs and the direct 3x3 stem write bf16; the im2col stem is an fp32 GEMM
                     cin = self.shapes[op[2]][-1]
@@ -712,12 +712,12 @@ class GraphNet(Network):
                 w1, b1, w2, b2, hd = self._se_names(op)
                 ih, iw, c = self.shapes[inp]
                 sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
-                call('fte_gap_fwd', T[inp], sq, n, ih * iw, c, st)
+                call('fte_gap_fwd_s16' if s16 else 'fte_gap_fwd', T[inp], sq, n, ih * iw, c, st)
                 call('fte_gemm_nn', sq, self.view(w1), self.view(b1), hid, n, hd, c, self.ws, self.ws_bytes, st)
                 call('fte_act_fwd', hid, hid, hid.numel(), 0, st)
                 call('fte_gemm_nn', hid, self.view(w2), self.view(b2), gate, n, c, hd, self.ws, self.ws_bytes, st)
                 call('fte_act_fwd', gate, gate, gate.numel(), 1, st)
-                call('fte_channel_scale_fwd', T[inp], gate, T[out], n, ih * iw, c, st)
+                call('fte_channel_scale_fwd_s16' if s16 else 'fte_channel_scale_fwd', T[inp], gate, T[out], n, ih * iw, c, st)
             elif kind == 'addrelu':
                 c = self.shapes[out][-1]
                 one, zero = self.ident[c]
@@ -999,7 +999,10 @@ class GraphNet(Network):
                 dx = self._new(inp)
                 # scratch preallocated in _alloc (three allocator calls per SE block and step otherwise)
                 dgate, dhid, dsq = (self.ident[('se', nm, wdt)] for nm, wdt in (('dgate', c), ('dhid', hd), ('dsq', c)))
-                call('fte_channel_scale_bwd', dy, T[inp], gate, dx, dgate, n, hw, c, 1, st)         # dgate = d(pre-sigmoid)
+                if s16:          # reduction only; dx is written once by the apply pass below
+                    call('fte_channel_scale_bwd_s16', dy, T[inp], gate, dgate, n, hw, c, 1, st)
+                else:
+                    call('fte_channel_scale_bwd', dy, T[inp], gate, dx, dgate, n, hw, c, 1, st)         # dgate = d(pre-sigmoid)
                 call('fte_gemm_tn', hid, dgate, self.view(w2, self.grads), n, c, hd, self.ws, self.ws_bytes, st)
                 call('fte_reduce_rows', dgate, self.view(b2, self.grads), None, 1, n, c, 1, 1.0, st)
                 call('fte_gemm_nt', dgate, self.view(w2), None, None, 0, None, dhid, None, n, c, hd, self.ws, self.ws_bytes, st)
@@ -1007,7 +1010,10 @@ class GraphNet(Network):
                 call('fte_gemm_tn', sq, dhid, self.view(w1, self.grads), n, hd, c, self.ws, self.ws_bytes, st)
                 call('fte_reduce_rows', dhid, self.view(b1, self.grads), None, 1, n, hd, 1, 1.0, st)
                 call('fte_gemm_nt', dhid, self.view(w1), None, None, 0, None, dsq, None, n, hd, c, self.ws, self.ws_bytes, st)
-                call('fte_bcast_add', dx, dsq, n, hw, c, 1.0 / hw, st)
+                if s16:
+                    call('fte_channel_scale_bwd_apply_s16', dy, gate, dsq, dx, n, hw, c, 1.0 / hw, st)
+                else:
+                    call('fte_bcast_add', dx, dsq, n, hw, c, 1.0 / hw, st)
                 self._put(inp, dx)
             elif kind == 'gconv':
                 _, _, inp, wname, stride, groups = op
