@@ -150,7 +150,9 @@ inline void plan_splits(long tiles, int K, int* splits, int* kchunk, bool prefer
     static const int mink = getenv("FTE_SPLIT_MINK") ? atoi(getenv("FTE_SPLIT_MINK")) : 256;      // tuning hook: shortest K range per split
     const int maxs = K / mink > 0 ? K / mink : 1;
     const long SLOTS = SLOTS_BIG;
-    long lo = (SLOTS + tiles - 1) / tiles, hi = (3 * SLOTS + tiles - 1) / tiles;
+    static const int max_rounds = getenv("FTE_SPLIT_ROUNDS") ? atoi(getenv("FTE_SPLIT_ROUNDS")) : 3;      // tuning hook
+    static const int min_rounds = getenv("FTE_SPLIT_MINROUNDS") ? atoi(getenv("FTE_SPLIT_MINROUNDS")) : 1;
+    long lo = (min_rounds * SLOTS + tiles - 1) / tiles, hi = (max_rounds * SLOTS + tiles - 1) / tiles;
     if (lo < 1) lo = 1;
     if (hi > maxs) hi = maxs;
     if (lo > hi) lo = hi;
