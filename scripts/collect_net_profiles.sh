@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX: step-level HBM roofline + rocprofv3 kernel stats + FETCH / WRITE PMC passes of one net's training step.
 #   bash scripts/collect_net_profiles.sh ShuffleNet-v2-small 256 r3_shufflenet      -> gpurun_out/prof_<tag>/
-NAME="$1"; B="$2"; TAG="$3"; STEPS="${4:-6}"
+NAME="$1"; B="$2"; TAG="$3"; STEPS="${4:-6}"   # FTE_MFMA_DTYPE in the environment selects the precision mode
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -13,3 +13,13 @@ for mode in ('', '_bf16', '_bf16s'):
         if os.path.exists(os.path.join(d, src)):
             shutil.copy(os.path.join(d, src), pre + dst)
             print('kept', pre + dst)
+# net profiles (scripts/collect_net_profiles.sh TAG): step-level roofline, per-kernel PMC summary, kernel stats, step summary
+import glob
+for d in glob.glob(os.path.join(root, 'gpurun_out', 'prof_%s_*' % tag)):
+    name = os.path.basename(d)[len('prof_'):]
+    if not os.path.exists(os.path.join(d, 'step_roofline.md')):
+        continue
+    for src in ('step_roofline.md', 'pmc_summary.csv', 'kernel_stats.csv', 'step_summary.txt'):
+        if os.path.exists(os.path.join(d, src)):
+            shutil.copy(os.path.join(d, src), os.path.join(root, 'profiles', name + '_' + src))
+            print('kept', name + '_' + src)
