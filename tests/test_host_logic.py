@@ -182,3 +182,53 @@ def test_data_parallel_gives_every_rank_its_own_dropout_seed():
         dp(inputs)                                    # building twice does not compound the seed
         seeds.append(net.dropout_seed)
     assert seeds == [10, 11]
+
+
+# ------------------------------------------------------------------ round 3: precision modes, exits, loader shutdown
+def test_precision_modes_are_three_contracts():
+    """f32 | bf16 (bf16 MFMA operands, fp32 tensors) | bf16s (bf16 operands + bf16 storage): the library knows the MFMA dtype, the host
+    flag says which entry points the nets call.  (fte_set_mfma_dtype only sets a flag: no GPU needed.)"""
+    from tf_face_toolbox_amd import _lib
+    try:
+        for mode, dt, s16 in (('bf16s', 'bf16', True), ('bf16', 'bf16', False), ('f32', 'f32', False), ('bf16s', 'bf16', True)):
+            _lib.set_mfma_dtype(mode)
+            assert _lib.get_mfma_dtype() == dt and _lib.bf16_storage() is s16 and _lib.precision_mode() == mode
+        with pytest.raises(ValueError):
+            _lib.set_mfma_dtype('fp8')
+    finally:
+        _lib.set_mfma_dtype('f32')
+    assert not _lib.bf16_storage()
+
+
+def test_filter_pack_table_layout():
+    """nets/_packs.py: destination offsets are compact and 16-byte aligned, the walk starts are prefix sums / 4, chunks of 64 rows."""
+    import torch
+    from tf_face_toolbox_amd.nets._packs import FilterPacks
+    entries = [('c%d' % i, 100 + 7000 * i, 3 if i % 2 else 1, 32 * (1 + i % 3), 64) for i in range(70)]
+    packs = FilterPacks(entries, 'cpu')
+    assert [l[1] for l in packs.launches] == [64, 6]
+    off = 0
+    for li, (tab, n, total, base) in enumerate(packs.launches):
+        t = tab.tolist()
+        start = 0
+        for row, (name, src, k, cin, cout) in zip(t, entries[li * 64:li * 64 + n]):
+            assert row[0] == src and row[1] == off - base and row[2:5] == [k * k, cin, cout] and row[5] * 4 == start
+            assert (off * 2) % 16 == 0
+            assert packs.w16[name].shape == (k, k, cin, cout) and packs.w16t[name].shape == (k, k, cout, cin)
+            start += k * k * cin * cout
+            off += k * k * cin * cout
+        assert start == total
+    assert packs.total == off
+
+
+@pytest.mark.parametrize('body,code', [('return None', 0), ('raise SystemExit(3)', 3), ("raise SystemExit('bad flags')", 1),
+                                       ('raise RuntimeError("boom")', 1), ('raise SystemExit(0)', 0)])
+def test_cli_leaves_with_the_real_status(tmp_path, body, code):
+    """train.py / evaluate.py: _run_and_leave maps what the program did to the exit status (round 2 left with an unconditional 0)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = 'import sys; sys.path.insert(0, %r)\nimport train\ndef f():\n    %s\ntrain._run_and_leave(f)\n' % (root, body)
+    r = subprocess.run([sys.executable, '-c', src], capture_output=True, text=True, timeout=120)
+    assert r.returncode == code, (r.returncode, r.stderr[-500:])
