@@ -63,6 +63,11 @@
 #define FTE_SUPER_CHUNK 128
 #endif
 // filter-gradient addressing: 1 = incremental pixel tracking with wave-uniform taps where the shape allows (see the K loop)
+// 1: row-contiguous bf16 sources (the filter gradient's operands) are stored to LDS as loaded and read back with ds_read_b64_tr_b16;
+// 0: packed into k-pairs on the way in (round 2's path; A/B variant through scripts/build_variant.sh)
+#ifndef FTE_TR16
+#define FTE_TR16 1
+#endif
 #ifndef FTE_KM_FAST
 #define FTE_KM_FAST 1
 #endif
@@ -484,7 +489,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                 if (++ptap == NT) { ptap = 0; pkc += BK; }
             }
         };
+        // Row-contiguous sources (KM / KN: the filter gradient's x and dz, k = pixel), FTE_TR16: the rows go to LDS AS THEY ARE --
+        // image [32 k][rows] bf16, one ds_write_b128 per loaded row piece (16-byte chunk c of k-row k at slot c ^ 2 (k & 3)) -- and the
+        // 32x32x16 operand (8 consecutive k of one m per lane) comes back through ds_read_b64_tr_b16, gfx950's transposing LDS read:
+        // of each 16 lanes, lane 4 q + p addresses k-row q, columns 4 p .. 4 p + 3, and lane i receives column i of the four rows
+        // (scripts/probes/ds_read_tr16.hip; the grouped filter gradient of layers.hip reads its fragments the same way).  Two reads
+        // (k-rows 0-3, 4-7 of the lane's k-half) make one operand.  Replaces eight v_perm_b32 + eight ds_write_b32 per loaded pair of
+        // rows; the values every lane feeds its MFMAs are the same, so results are bit-identical to the packed-pair image.
+        typedef short s16x4t __attribute__((ext_vector_type(4)));
+        auto offk = [](int k, int chunk, int rowbytes) -> int { return k * rowbytes + ((chunk ^ ((k & 3) << 1)) << 4); };
+        auto store_rows = [&](char* T, int rows, const u32x4& v0, const u32x4& v1, int j) {
+            const int chunk = c16 + 16 * j;
+            if (8 * chunk < rows) {
+                *reinterpret_cast<u32x4*>(T + offk(2 * kp, chunk, rows * 2)) = v0;
+                *reinterpret_cast<u32x4*>(T + offk(2 * kp + 1, chunk, rows * 2)) = v1;
+            }
+        };
+        auto frag_tr = [&](const char* T, int rows, int row0, int h) -> bf16x8 {
+            const int g4 = lane >> 4, idx = lane & 15;
+            const int k = 16 * h + 8 * (g4 >> 1) + (idx >> 2);
+            const int m = row0 + 16 * (g4 & 1) + 4 * (idx & 3);
+            const char* q = T + offk(k, m >> 3, rows * 2) + (m & 7) * 2;
+            const s16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(q));
+            const s16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(q + 4 * rows * 2));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
         auto store_pairs = [&](char* T, int rows, const u32x4& v0, const u32x4& v1, int j) {
+            if constexpr (FTE_TR16) { store_rows(T, rows, v0, v1, j); return; }
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int r = 8 * (c16 + 16 * j) + 2 * w;
@@ -525,11 +556,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
             for (int h = 0; h < 2; ++h) {
                 bf16x8 fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fa[i] = *reinterpret_cast<const bf16x8*>(As + off16(wm * (TM * 32) + i * 32 + li, 2 * h + lh));
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (AL == AL_KM && FTE_TR16) fa[i] = frag_tr(As, BM, wm * (TM * 32) + i * 32, h);
+                    else fa[i] = *reinterpret_cast<const bf16x8*>(As + off16(wm * (TM * 32) + i * 32 + li, 2 * h + lh));
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[j] = *reinterpret_cast<const bf16x8*>(Bs + off16(wn * (TN * 32) + j * 32 + li, 2 * h + lh));
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (BL == BL_KN && FTE_TR16) fb[j] = frag_tr(Bs, BN, wn * (TN * 32) + j * 32, h);
+                    else fb[j] = *reinterpret_cast<const bf16x8*>(Bs + off16(wn * (TN * 32) + j * 32 + li, 2 * h + lh));
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
