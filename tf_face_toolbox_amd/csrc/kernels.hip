@@ -67,11 +67,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
         const int tap = kk / CIN;
         kc[s] = kk - tap * CIN; kr[s] = tap / 3; kq[s] = tap - 3 * (tap / 3);
 #pragma unroll
-        for (int e = 0; e < NH; ++e) wb[e][s] = kv[s] ? w[kk * COUT + 32 * e + li] : 0.f;
+        for (int e = 0; e < NH; ++e) wb[e][s] = kv[s] ? w[kk * COUT + NH * li + e] : 0.f;
     }
+    // column li of accumulator block e is output channel NH * li + e: a lane owns NH ADJACENT channels of a pixel, so its results leave
+    // as one 8-byte (fp32) or 4-byte (bf16) store per tensor instead of NH stores 128 bytes apart
     float bb[NH], aa[NH];
 #pragma unroll
-    for (int e = 0; e < NH; ++e) { bb[e] = bias ? bias[32 * e + li] : 0.f; aa[e] = alpha ? alpha[32 * e + li] : 1.f; }
+    for (int e = 0; e < NH; ++e) { bb[e] = bias ? bias[NH * li + e] : 0.f; aa[e] = alpha ? alpha[NH * li + e] : 1.f; }
     const int gpr = (wo + 31) / 32;                                  // 32-pixel groups per output row
     const long ngrp = (long)n * ho * gpr;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
@@ -104,15 +106,23 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(
         for (int i = 0; i < 16; ++i) {
             const int pr = (i & 3) + 8 * (i >> 2) + 4 * lh;
             if (g * 32 + pr < wo) {
-                const long o = obase + (long)pr * COUT + li;
+                const long o = obase + (long)pr * COUT + NH * li;
+                float zv[NH], yv[NH];
 #pragma unroll
                 for (int e = 0; e < NH; ++e) {
-                    float v = acc[e][i] + bb[e];
-                    if (z) z[o + 32 * e] = v;
-                    if (z16) z16[o + 32 * e] = __builtin_bit_cast(unsigned short, (__bf16)v);
-                    if (alpha) v = v > 0.f ? v : aa[e] * v;
-                    if (y) y[o + 32 * e] = v;
-                    if (y16) y16[o + 32 * e] = __builtin_bit_cast(unsigned short, (__bf16)v);
+                    zv[e] = acc[e][i] + bb[e];
+                    yv[e] = alpha ? (zv[e] > 0.f ? zv[e] : aa[e] * zv[e]) : zv[e];
+                }
+                if constexpr (NH == 2) {
+                    if (z) *reinterpret_cast<float2*>(z + o) = make_float2(zv[0], zv[1]);
+                    if (y) *reinterpret_cast<float2*>(y + o) = make_float2(yv[0], yv[1]);
+                    if (z16) *reinterpret_cast<unsigned*>(z16 + o) = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)zv[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)zv[1]) << 16);
+                    if (y16) *reinterpret_cast<unsigned*>(y16 + o) = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)yv[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)yv[1]) << 16);
+                } else {
+                    if (z) z[o] = zv[0];
+                    if (y) y[o] = yv[0];
+                    if (z16) z16[o] = __builtin_bit_cast(unsigned short, (__bf16)zv[0]);
+                    if (y16) y16[o] = __builtin_bit_cast(unsigned short, (__bf16)yv[0]);
                 }
             }
         }
@@ -162,12 +172,15 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
                 const bool ok = rok && pok && iw >= 0 && iw < wd;
                 const float av = xrow[(long)(ok ? iw : 0) * CIN];
                 a[u] = ok ? av : 0.f;
-                const long doff = (long)(pok ? ow : 0) * COUT;
-#pragma unroll
-                for (int e = 0; e < NH; ++e) {
-                    const float v = drow ? drow[doff + 32 * e + li]
-                                         : __builtin_bit_cast(float, (unsigned)drow16[doff + 32 * e + li] << 16);
-                    bv[e][u] = pok ? v : 0.f;
+                const long doff = (long)(pok ? ow : 0) * COUT + NH * li;      // column li of block e = channel NH * li + e (one load per lane and pixel)
+                if constexpr (NH == 2) {
+                    float v0, v1;
+                    if (drow) { const float2 t = *reinterpret_cast<const float2*>(drow + doff); v0 = t.x; v1 = t.y; }
+                    else { const unsigned t = *reinterpret_cast<const unsigned*>(drow16 + doff); v0 = __builtin_bit_cast(float, t << 16); v1 = __builtin_bit_cast(float, t & 0xffff0000u); }
+                    bv[0][u] = pok ? v0 : 0.f; bv[1][u] = pok ? v1 : 0.f;
+                } else {
+                    const float v = drow ? drow[doff] : __builtin_bit_cast(float, (unsigned)drow16[doff] << 16);
+                    bv[0][u] = pok ? v : 0.f;
                 }
             }
 #pragma unroll
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
     for (int i = 0; i < 16; ++i) {
         const int k = (i & 3) + 8 * (i >> 2) + 4 * lh;
 #pragma unroll
-        for (int e = 0; e < NH; ++e) red[wv][k][32 * e + li] = acc[e][i];
+        for (int e = 0; e < NH; ++e) red[wv][k][NH * li + e] = acc[e][i];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K * COUT; i += 256) {
