@@ -111,6 +111,21 @@ def test_wgrad_128x128_hooked_ragged_splits():
     _has(cs[0], 'igemm_kernel<128,64,2,2,1,0,0,0>')
 
 
+def test_persistent_bf16_kernels_at_the_sizes_that_select_them():
+    """bf16 storage (fte_conv2d_{fwd,dgrad}_s16): at >= 768 tiles of 128 rows the planner takes the 128x128 / 128x64 tile and the launch
+    runs on igemm16p_kernel -- resident blocks that walk several tiles (more tiles than block slots in every case here), swapped-operand
+    MFMAs, the register epilogue with the half-wave exchange, column partials through the lane butterfly.  Every stored bf16 value
+    must be within one bf16 step of the float64 result of the same bf16 inputs; dalpha / dbias as in the fp32 cases."""
+    env = {'FTE_MFMA_DTYPE': 'bf16s'}
+    cs = _run([['s16fwd', 64, 56, 56, 64, 64, 1], ['s16dgrad', 64, 56, 56, 64, 64, 1], ['s16fwd', 126, 28, 28, 128, 128, 1],
+               ['s16dgrad', 126, 28, 28, 128, 128, 1], ['s16fwd', 262, 14, 14, 256, 256, 1]], env, timeout=1500)
+    _has(cs[0], 'igemm16p_kernel<128,64,4,2,0,2,6,1,0>')
+    _has(cs[1], 'igemm16p_kernel<128,64,4,2,1,2,6,1,0>')
+    _has(cs[2], 'igemm16p_kernel<128,128,4,2,0,2,4,1,0>')
+    _has(cs[3], 'igemm16_kernel<128,128,4,2,1,2,4,0,0>')          # the 128x128 data gradient stays on the per-tile kernel
+    _has(cs[4], 'igemm16p_kernel<128,128,4,2,0,2,4,1,0>')
+
+
 def test_every_conv_symbol_of_the_headline_run_was_checked():
     """tests/golden/headline_symbols.json lists roofline.per_symbol of the committed bench line (profiles/); every conv symbol in
     it must have run -- against the oracle -- in the tests above; the dense symbols (FC / classifier products) are the

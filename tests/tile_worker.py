@@ -120,13 +120,101 @@ def run_wgrad(n, h, w, cin, cout, stride, r):
     return syms, splits, errs, e / s <= TOL_MAXABS
 
 
+def _bf(a):
+    """float32 array -> (bf16-exact float32 values, their int16 bit patterns on the GPU)"""
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda().bfloat16()
+    return t.float().cpu().numpy(), t.view(torch.int16)
+
+
+def _stored_ok(got16, ref64, scale):
+    """a bf16-STORED result against the float64 value it rounds: within one bf16 step of the reference (fp32 accumulation may tip a
+    value across a rounding boundary) -- |got - ref| <= 2^-8 |ref| + 2e-5 scale; returns (worst excess ratio, ok)"""
+    got = got16.view(torch.bfloat16).float().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref64)
+    lim = np.abs(ref64) * 2.0 ** -8 + TOL_MAXABS * scale
+    return float((err / lim).max()), bool((err <= lim).all())
+
+
+def run_s16fwd(n, h, w, cin, cout, stride, r):
+    """fte_conv2d_fwd_s16 (bf16 x / shortcut in, bf16 z / y out): the persistent bf16 kernels at the sizes that select them"""
+    assert stride == 1
+    x, x16 = _bf(r.standard_normal((n, h, w, cin), dtype=np.float32))
+    wt = (r.standard_normal((3, 3, cin, cout), dtype=np.float32) * 0.05).astype(np.float32)
+    wd = torch.from_numpy(wt).cuda()
+    w16 = torch.empty(3, 3, cin, cout, dtype=torch.int16, device='cuda'); w16t = torch.empty(3, 3, cout, cin, dtype=torch.int16, device='cuda')
+    call('fte_pack_weights_bf16', wd, w16, w16t, 3, cin, cout, stream())
+    wb = wd.bfloat16().float().cpu().numpy().astype(np.float64)
+    b = r.standard_normal(cout, dtype=np.float32)
+    al = (0.25 + 0.1 * r.standard_normal(cout, dtype=np.float32)).astype(np.float32)
+    res, res16 = _bf(r.standard_normal((n, h, w, cout), dtype=np.float32))
+    z16 = torch.empty(n, h, w, cout, dtype=torch.int16, device='cuda'); y16 = torch.empty_like(z16)
+    wsb, nb = ws(query('fte_conv2d_fwd_ws_bytes', n, h, w, cin, cout, 3, 1))
+    _lib.query('fte_prof_enable', 1)
+    call('fte_conv2d_fwd_s16', x16, w16t, torch.from_numpy(b).cuda(), torch.from_numpy(al).cuda(), res16, z16, y16, None, None,
+         n, h, w, cin, cout, 3, 1, wsb, nb, stream())
+    _lib.query('fte_prof_enable', 0)
+    syms, splits = _records()
+    b64, al64 = b.astype(np.float64), al.astype(np.float64)
+    wz = wy = 0.0
+    ok = True
+    for i in range(0, n, BLOCK):
+        zr = ops.conv2d_fwd(x[i:i + BLOCK].astype(np.float64), wb, 1, b64)
+        yr = ops.prelu_fwd(zr, al64) + res[i:i + BLOCK]
+        e, o = _stored_ok(z16[i:i + BLOCK], zr, np.abs(zr).max()); wz = max(wz, e); ok = ok and o
+        e, o = _stored_ok(y16[i:i + BLOCK], yr, np.abs(yr).max()); wy = max(wy, e); ok = ok and o
+    return syms, splits, {'z_worst_over_limit': wz, 'y_worst_over_limit': wy}, ok
+
+
+def run_s16dgrad(n, h, w, cin, cout, stride, r):
+    """fte_conv2d_dgrad_s16 (bf16 dz / skip gradient / previous z in, bf16 raw / dz out, fp32 dalpha / dbias sums)"""
+    assert stride == 1
+    wt = (r.standard_normal((3, 3, cin, cout), dtype=np.float32) * 0.05).astype(np.float32)
+    wd = torch.from_numpy(wt).cuda()
+    w16 = torch.empty(3, 3, cin, cout, dtype=torch.int16, device='cuda'); w16t = torch.empty(3, 3, cout, cin, dtype=torch.int16, device='cuda')
+    call('fte_pack_weights_bf16', wd, w16, w16t, 3, cin, cout, stream())
+    wb = wd.bfloat16().float().cpu().numpy().astype(np.float64)
+    dz, dz16 = _bf(r.standard_normal((n, h, w, cout), dtype=np.float32))
+    addin, add16 = _bf(r.standard_normal((n, h, w, cin), dtype=np.float32))
+    zp = r.standard_normal((n, h, w, cin), dtype=np.float32)
+    zp[0, 0, 0, :4] = 0.0
+    zprev, zp16 = _bf(zp)
+    alp = (0.25 + 0.1 * r.standard_normal(cin, dtype=np.float32)).astype(np.float32)
+    raw16 = torch.empty(n, h, w, cin, dtype=torch.int16, device='cuda'); dzp16 = torch.empty_like(raw16)
+    da = torch.empty(cin, device='cuda'); db = torch.empty(cin, device='cuda')
+    wsb, nb = ws(query('fte_conv2d_dgrad_ws_bytes', n, h, w, cin, cout, 3, 1))
+    _lib.query('fte_prof_enable', 1)
+    call('fte_conv2d_dgrad_s16', dz16, w16, add16, zp16, torch.from_numpy(alp).cuda(), raw16, dzp16, da, db, n, h, w, cin, cout, 3, 1, wsb, nb, stream())
+    _lib.query('fte_prof_enable', 0)
+    syms, splits = _records()
+    al64 = alp.astype(np.float64)
+    da_ref = np.zeros(cin); db_ref = np.zeros(cin)
+    xshape = np.zeros((1, h, w, cin))
+    wr = wd_ = 0.0
+    ok = True
+    for i in range(0, n, BLOCK):
+        m = min(BLOCK, n - i)
+        dx, _ = ops.conv2d_bwd(np.broadcast_to(xshape, (m, h, w, cin)), wb, dz[i:i + m].astype(np.float64), 1, need_dw=False)
+        g = dx + addin[i:i + m]
+        dzr, dar = ops.prelu_bwd(zprev[i:i + m].astype(np.float64), al64, g)
+        da_ref += dar; db_ref += dzr.sum(axis=(0, 1, 2))
+        e, o = _stored_ok(raw16[i:i + m], g, np.abs(g).max()); wr = max(wr, e); ok = ok and o
+        e, o = _stored_ok(dzp16[i:i + m], dzr, np.abs(dzr).max()); wd_ = max(wd_, e); ok = ok and o
+
+    def rl2(got, ref):
+        return float(np.sqrt(((got - ref) ** 2).sum() / (ref ** 2).sum()))
+    errs = {'raw_worst_over_limit': wr, 'dz_worst_over_limit': wd_,
+            'dalpha_rell2': rl2(da.cpu().numpy().astype(np.float64), da_ref), 'dbias_rell2': rl2(db.cpu().numpy().astype(np.float64), db_ref)}
+    ok = ok and errs['dalpha_rell2'] <= TOL_RELL2 and errs['dbias_rell2'] <= TOL_RELL2
+    return syms, splits, errs, ok
+
+
 def main():
     cases = json.loads(sys.argv[1])
     out, ok_all = [], True
     for ci, c in enumerate(cases):
         op, dims = c[0], [int(v) for v in c[1:]]
         r = np.random.default_rng(100 + ci)
-        syms, splits, errs, ok = {'fwd': run_fwd, 'dgrad': run_dgrad, 'wgrad': run_wgrad}[op](*dims, r)
+        syms, splits, errs, ok = {'fwd': run_fwd, 'dgrad': run_dgrad, 'wgrad': run_wgrad, 's16fwd': run_s16fwd, 's16dgrad': run_s16dgrad}[op](*dims, r)
         out.append({'case': c, 'symbols': syms, 'splits': splits, 'errors': errs, 'ok': bool(ok)})
         ok_all = ok_all and ok
         torch.cuda.empty_cache()

@@ -56,6 +56,8 @@ struct IgemmParams {
     // outputs Y / DZ may then be NULL
     const unsigned short* R16; const unsigned short* ADD16; const unsigned short* Zin16;
     unsigned short* Z16; unsigned short* RAW16;
+    int ptiles;           // igemm16p_kernel (persistent blocks): tiles of the launch; set by its launcher
+    int ptiles_dbg;       // diagnostic switches of that kernel (FTE_IGEMM16_DBG; 0 in production)
 };
 
 hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile, int splits, hipStream_t st);

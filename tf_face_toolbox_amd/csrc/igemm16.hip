@@ -23,6 +23,7 @@
 // bf16 result copies) is igemm_dev.h's, shared with igemm.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "igemm_dev.h"
@@ -53,8 +54,11 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// ABL (diagnostic builds only, FTE_IGEMM16_ABL): 0 = the kernel; 1 = no MFMAs, 2 = no DMA (stale LDS), 3 = no epilogue
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0>
+// ABL (diagnostic builds only, FTE_IGEMM16_ABL): 0 = the kernel; 1 = no MFMAs, 2 = no DMA (stale LDS), 3 = no epilogue, 4 = no
+// fragment reads (MFMAs on whatever the registers hold)
+// PF = 1: the fragments of sub-step ks + 1 are read while the MFMAs of sub-step ks run (register double buffer), and the scalar
+// loads of the next tile's tap offsets are taken before the barrier instead of between the fragment reads
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0, int PF = 0>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && NST >= 2, "4 or 8 waves");
@@ -185,10 +189,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(As + a_row[i] * ROWB + (((2 * ks + lh) ^ ((a_row[i] >> 1) & 7)) << 4));
+                if constexpr (ABL != 4) fa[i] = *reinterpret_cast<const bf16x8*>(As + a_row[i] * ROWB + (((2 * ks + lh) ^ ((a_row[i] >> 1) & 7)) << 4));
+                else asm volatile("" : "=v"(fa[i]));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+                if constexpr (ABL != 4) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+                else asm volatile("" : "=v"(fb[j]));
             if (fillnext) {
 #pragma unroll
                 for (int idx = 0; idx < L; ++idx) {
@@ -212,6 +218,44 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
         }
     };
 
+    // PF = 1: the same K-step with the fragment reads one sub-step ahead of their MFMAs
+    auto kstep_pf = [&](int stage, int fill, bool fillnext, unsigned toff, unsigned boff) {
+        const char* As = smem16 + stage * STAGE;
+        const char* Bs = As + BM * ROWB;
+        char* Ad = smem16 + fill * STAGE + wid * 1024;
+        char* Bd = Ad + BM * ROWB;
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto ld = [&](int ks, int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[b][i] = *reinterpret_cast<const bf16x8*>(As + a_row[i] * ROWB + (((2 * ks + lh) ^ ((a_row[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[b][j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            if (ks + 1 < BK16 / 16) ld(ks + 1, (ks + 1) & 1);
+            if (fillnext) {
+#pragma unroll
+                for (int idx = 0; idx < L; ++idx) {
+                    if (idx * 4 / L != ks) continue;
+                    if (idx < A_P) dma16(rsrcA, Ad + idx * (RP * ROWB), ((a_mask[idx < A_P ? idx : 0] >> itap) & 1) ? a_base[idx < A_P ? idx : 0] + toff : OOB, 0);
+                    else dma16(rsrcB, Bd + (idx - A_P) * (RP * ROWB), b_base[idx >= A_P ? idx - A_P : 0], boff);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (fillnext) {
+            if (++itap == NT) { itap = 0; ikc += BK16; }
+        }
+    };
+
     // ---- ring: NST - 1 K-steps in flight; step t: wait for (this wave's part of) tile t, barrier (everybody's part has landed
     // AND everybody has finished reading tile t - 1, whose stage is the one refilled during this step), compute tile t while
     // issuing tile t + NST - 1 ----
@@ -220,10 +264,19 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
         if (s < nk) issue(s);
     int stage = 0, fill = NST - 1;
     for (int t = 0; t < nk; ++t) {
+        unsigned toff = 0, boff = 0;
+        if constexpr (PF) {
+            if (t + NST - 1 < nk) {
+                toff = (unsigned)((p.a_dh[tap0 + itap] * p.a_IW + p.a_dw[tap0 + itap]) * p.a_ld + ikc) * 2u;    // wave-uniform
+                boff = (unsigned)(p.b_tapoff[tap0 + itap] + ikc) * 2u;
+            }
+            asm volatile("" : "+s"(toff), "+s"(boff));               // the scalar loads complete here, under the wait for the tile
+        }
         if (t + NST - 1 <= nk) wait_vmcnt<(NST - 2) * L>();          // steady state: the NST - 2 younger tiles stay in flight
         else wait_vmcnt<0>();                                        // last steps: fewer tiles are outstanding
         __builtin_amdgcn_s_barrier();
-        kstep(stage, fill, t + NST - 1 < nk);
+        if constexpr (PF) kstep_pf(stage, fill, t + NST - 1 < nk, toff, boff);
+        else kstep(stage, fill, t + NST - 1 < nk);
         stage = stage + 1 == NST ? 0 : stage + 1;
         fill = fill + 1 == NST ? 0 : fill + 1;
     }
@@ -442,6 +495,900 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
     igemm_epilogue<BM, BN, WM, WN, EPI, true>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, p.c_ph, p.c_pw, p.prow0);
 }
 
+// ---- persistent variant ------------------------------------------------------------------------------------------------------
+// Why: a launch of igemm16_kernel is rounds of co-resident blocks that run in phase -- every block of a round reaches its epilogue at
+// about the same time, the epilogues' HBM traffic arrives as one burst per round (ablation: 0.03 ms of a 0.167-ms 14x14x256 forward,
+// 0.08 of 0.22 at 28x28x128 = that traffic at HBM speed), a finished block holds its slot until its stores have drained, and its
+// successor starts with an address prologue and a cold ring.  Here a block stays resident and walks its XCD's tiles:
+//   * the ring never drains: the DMAs of the NEXT tile's first K-step are issued during the last K-step of the current one, so the
+//     K-step sequence of a block is one uninterrupted stream across tiles;
+//   * the epilogue's inputs (shortcut / skip gradient / previous z, bf16) are fetched into registers BEFORE the last K-step and its
+//     stores are fire-and-forget: vmcnt retires in order, the next tile's first DMAs are OLDER than the stores, so step 0 of the next
+//     tile waits with a counted vmcnt that leaves the stores in flight -- they drain under the next tile's K loop;
+//   * no LDS in the epilogue (the ring is live): the MFMAs run with swapped operands, which leaves the accumulator as
+//     lane = output row, registers = 4-column groups; v_permlane32_swap between the two half-waves gives every lane 8 consecutive
+//     columns = 16 bytes of a bf16 row per load / store.  Row offsets live in registers; alpha / bias of the tile's columns in LDS.
+//   * dalpha / dbias column partials (EPI_DGRAD): a halving butterfly over the 32 row-lanes (16 shuffles per 16 columns), then the
+//     usual fixed-order sum over the row-waves through LDS.
+// Restrictions (launch16p_ok): no split-K, no merged stride-2 classes, alpha period a multiple of 8.
+// ---- epilogue of the swapped-operand kernels (igemm16p / igemm16r): accumulator lane = output row, registers = columns ----------
+// acc[i][j][r] of lane (li, lh): output row m0 + wm*TM*32 + i*32 + li (its offset: roff[i], < 0 beyond M), column n0 + wn*TN*32 + j*32 +
+// (r & 3) + 8 (r >> 2) + 4 lh.  v_permlane32_swap between the half-waves gives every lane 8 consecutive columns -- 16 bytes of a bf16 row
+// per load / store; no LDS patches.  colf = [alpha[BN], bias[BN]] of the tile's columns (LDS), red = [2][WM][BN] floats (LDS).  ein0 /
+// ein1: the bf16 epilogue inputs (shortcut | skip gradient, previous z) fetched ahead, used when the 16-bit tensors are given.  With
+// EPI_DGRAD and p.PA the function holds ONE block barrier (every wave of the block must call it, or match it).  Returns the number of
+// stores a wave issued (0 after the barrier form: count nothing).
+template <int BM, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ int epilogue_rows(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&roff)[BM / WM / 32],
+                                             const u32x4 (&ein0)[BM / WM / 32][BN / WN / 32][2], const u32x4 (&ein1)[BM / WM / 32][BN / WN / 32][2],
+                                             const float* colf, float* red, int mt, int n0, int tid, int wm, int wn, int li, int lh) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    int nst = 0;                                        // stores issued (per wave; wave-uniform)
+    float csa[TN], csb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { csa[j] = 0.f; csb[j] = 0.f; }
+    bool act;
+    if constexpr (EPI == EPI_FWD) act = p.alpha != nullptr;
+    else act = p.Zin != nullptr || p.Zin16 != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int off = roff[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x16 a = acc[i][j];
+            if (i == 0 && j == 0) asm volatile("s_nop 15\n\ts_nop 15");      // MFMA results -> VALU reads (the asm below hides the hazard from the compiler)
+            // half-wave exchange: lower lanes end with columns 0-7 (a[0..7]) and 16-23 (a[8..15]) of the 32-column block,
+            // upper lanes with 8-15 and 24-31
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane32_swap into one once they
+                    // are cast to float -- every column came out as column 0 of its block)
+                    float x = a[8 * g + e], y = a[8 * g + 4 + e];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+                    a[8 * g + e] = x;
+                    a[8 * g + 4 + e] = y;
+                }
+            float sa16[16], sb16[16];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cl = wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
+                const long o = (long)(off < 0 ? 0 : off) + n0 + cl;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = a[8 * q + e];
+                const f32x4 al0 = *reinterpret_cast<const f32x4*>(colf + cl), al1 = *reinterpret_cast<const f32x4*>(colf + cl + 4);
+                const float al[8] = {al0[0], al0[1], al0[2], al0[3], al1[0], al1[1], al1[2], al1[3]};
+                auto ld8 = [&](const float* src, const u32x4& h, bool have16, float (&dst)[8]) {      // fp32 tensor or the prefetched bf16 piece
+                    if (have16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { dst[2 * e] = __builtin_bit_cast(float, h[e] << 16); dst[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xffff0000u); }
+                    } else if (src && off >= 0) {
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + o), x1 = *reinterpret_cast<const f32x4*>(src + o + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { dst[e] = x0[e]; dst[4 + e] = x1[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) dst[e] = 0.f;
+                    }
+                };
+                auto st32 = [&](float* dst, const float (&x)[8]) {
+                    if (dst && off >= 0) {
+                        *reinterpret_cast<f32x4*>(dst + o) = f32x4{x[0], x[1], x[2], x[3]};
+                        *reinterpret_cast<f32x4*>(dst + o + 4) = f32x4{x[4], x[5], x[6], x[7]};
+                    }
+                };
+                auto st16 = [&](unsigned short* dst, const float (&x)[8]) {
+                    if (dst && off >= 0) *reinterpret_cast<u32x4*>(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
+                };
+                if constexpr (EPI == EPI_FWD) {
+                    if (p.bias) {
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(colf + BN + cl), b1 = *reinterpret_cast<const f32x4*>(colf + BN + cl + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                    }
+                    st32(p.Z, v);
+                    st16(p.Z16, v);
+                    if (act) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : al[e] * v[e];
+                    }
+                    float rs[8];
+                    ld8(p.R, ein0[i][j][q], p.R16 != nullptr, rs);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rs[e];
+                    st32(p.Y, v);
+                    st16(p.Y16, v);
+                } else {
+                    float ad[8], z[8];
+                    ld8(p.ADD, ein0[i][j][q], p.ADD16 != nullptr, ad);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += ad[e];
+                    st32(p.RAW, v);
+                    st16(p.RAW16, v);
+                    if (act) {
+                        ld8(p.Zin, ein1[i][j][q], p.Zin16 != nullptr, z);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const bool in = off >= 0;
+                            sa16[8 * q + e] = in ? v[e] * fminf(z[e], 0.f) : 0.f;
+                            v[e] *= prelu_slope(z[e], al[e]);
+                            sb16[8 * q + e] = in ? v[e] : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { sa16[8 * q + e] = 0.f; sb16[8 * q + e] = 0.f; }
+                    }
+                    st32(p.DZ, v);
+                    st16(p.DZ16, v);
+                }
+            }
+            if constexpr (EPI == EPI_DGRAD) {
+                if (p.PA && act) {
+                    // halving butterfly over the 32 row-lanes: lane li ends with the sum of column 8 (c >> 3) ... c = li >> 1
+                    auto fold = [&](float (&x)[16]) -> float {
+                        float w8[8], w4[4], w2[2], w1;
+                        const bool h16 = li & 16, h8 = li & 8, h4 = li & 4, h2 = li & 2;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) w8[c] = (h16 ? x[c + 8] : x[c]) + __shfl_xor(h16 ? x[c] : x[c + 8], 16);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) w4[c] = (h8 ? w8[c + 4] : w8[c]) + __shfl_xor(h8 ? w8[c] : w8[c + 4], 8);
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) w2[c] = (h4 ? w4[c + 2] : w4[c]) + __shfl_xor(h4 ? w4[c] : w4[c + 2], 4);
+                        w1 = (h2 ? w2[1] : w2[0]) + __shfl_xor(h2 ? w2[0] : w2[1], 2);
+                        return w1 + __shfl_xor(w1, 1);
+                    };
+                    csa[j] += fold(sa16);
+                    csb[j] += fold(sb16);
+                }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_FWD) {
+        nst = TM * TN * 2 * ((p.Z ? 2 : 0) + (p.Z16 ? 1 : 0) + (p.Y ? 2 : 0) + (p.Y16 ? 1 : 0));
+    } else {
+        nst = TM * TN * 2 * ((p.RAW ? 2 : 0) + (p.RAW16 ? 1 : 0) + (p.DZ ? 2 : 0) + (p.DZ16 ? 1 : 0));
+        if (p.PA) {    // column partials (dalpha, dbias) per 128 rows -- the planner's partial rows -- reduced later in a fixed order
+            if ((li & 1) == 0) {
+                const int c16 = li >> 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int c = wn * (TN * 32) + j * 32 + 16 * (c16 >> 3) + 8 * lh + (c16 & 7);
+                    red[wm * BN + c] = csa[j];
+                    red[(WM + wm) * BN + c] = csb[j];
+                }
+            }
+            __syncthreads();
+            constexpr int NH = BM / 128, WH = WM / NH;          // 128-row parts of the tile, row-waves per part
+            if (tid < BN * NH) {
+                const int h = tid / BN, c = tid - h * BN;
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int w = 0; w < WH; ++w) {
+                    sa += red[(h * WH + w) * BN + c];
+                    sb += red[(WM + h * WH + w) * BN + c];
+                }
+                if (p.m_base + (mt * NH + h) * 128 < p.M) {
+                    const long o = (long)(p.prow0 + mt * NH + h) * p.N + n0 + c;
+                    p.PA[o] = sa;
+                    if (p.PB) p.PB[o] = sb;
+                }
+            }
+            nst = 0;          // the partials' stores are not counted: wait for everything
+        }
+    }
+    return nst;
+}
+
+// a counted vmcnt whose count is only known at run time (wave-uniform): the largest listed count <= n (waiting for more is safe)
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    if (n >= 16) {
+        if (n >= 48) wait_vmcnt<48>(); else if (n >= 40) wait_vmcnt<40>(); else if (n >= 32) wait_vmcnt<32>();
+        else if (n >= 28) wait_vmcnt<28>(); else if (n >= 24) wait_vmcnt<24>(); else if (n >= 20) wait_vmcnt<20>(); else wait_vmcnt<16>();
+    } else if (n >= 6) {
+        if (n >= 14) wait_vmcnt<14>(); else if (n >= 12) wait_vmcnt<12>(); else if (n >= 10) wait_vmcnt<10>();
+        else if (n >= 8) wait_vmcnt<8>(); else wait_vmcnt<6>();
+    } else {
+        if (n >= 4) wait_vmcnt<4>(); else if (n >= 3) wait_vmcnt<3>(); else if (n >= 2) wait_vmcnt<2>();
+        else if (n >= 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+    }
+}
+
+// NST = ring stages (NST - 1 K-steps in flight, across tile boundaries)
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+// DBG = 1 (diagnostic launches only, FTE_IGEMM16_STAMP): s_memtime stamps around the wait / barrier / body of every K-step
+// PFD = sub-steps by which the fragment reads run ahead of their MFMAs (1..3; 3 = every fragment of the K-step is requested at
+// its start): with two MFMAs per sub-step (wave tile 32 x 64) one sub-step of lookahead is 64 cycles, less than an LDS read takes
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int PFD = 1, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16p_kernel(const IgemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NW = WM * WN, RP = 8 * NW, A_P = BM / RP, B_P = BN / RP, L = A_P + B_P;
+    static_assert(BM % RP == 0 && BN % RP == 0 && L <= 12 && NST >= 2 && NST <= 5, "tile rows per DMA pass");
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int NQ = NST - 2;             // K-steps whose DMAs may stay in flight behind the awaited one
+    constexpr int DSUB = NST == 2 ? 2 : 4;  // the DMAs of a K-step go out during its first DSUB sub-steps (two-stage ring: early, they are awaited next step)
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    float* const colf = reinterpret_cast<float*>(smem16 + NST * STAGE);    // [2][BN]: alpha, bias of the tile's columns
+    float* const red = colf + 2 * BN;                                      // [2][WM][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- this block's tiles: XCD x (= blockIdx.x & 7: workgroups are dealt to the XCDs round-robin) owns a contiguous range of
+    // the launch's tiles (n-tiles fastest), its blocks walk that range with stride gridDim.x / 8 ----
+    const int ntn = p.N / BN;
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    const int q8 = p.ptiles >> 3, r8 = p.ptiles & 7;
+    const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+    int idx = blockIdx.x >> 3;
+    if (idx >= xcnt) return;
+    const int NT = p.a_NT, nk = p.K / BK16;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    // ---- loader state of one tile (as igemm16_kernel) ----
+    const int a_hw = p.a_OH * p.a_OW;
+    const float r_ahw = 1.f / (float)a_hw, r_aow = 1.f / (float)p.a_OW;
+    unsigned a_base[A_P], b_base[B_P];
+    int a_mask[A_P];
+    auto setup = [&](int tile) {
+        const int mt = tile / ntn, nt_ = tile - mt * ntn;
+        const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+#pragma unroll
+        for (int i = 0; i < A_P; ++i) {
+            const int r = (tid >> 3) + RP * i;
+            const int m = m0 + r;
+            int base = 0, mask = 0;
+            if (m < p.M) {
+                const int n = fdiv(m, a_hw, r_ahw), rem = m - n * a_hw;
+                const int oh = fdiv(rem, p.a_OW, r_aow), ow = rem - oh * p.a_OW;
+                const int ih0 = oh * p.a_stride, iw0 = ow * p.a_stride;
+                base = ((n * p.a_IH + ih0) * p.a_IW + iw0) * p.a_ld;
+                for (int t = 0; t < NT; ++t) {
+                    const int ih = ih0 + p.a_dh[t], iw = iw0 + p.a_dw[t];
+                    if (ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW) mask |= 1 << t;
+                }
+            }
+            const int chunk = (tid & 7) ^ ((r >> 1) & 7);
+            a_base[i] = (unsigned)(base + (chunk << 3)) * 2u;
+            a_mask[i] = mask;
+        }
+#pragma unroll
+        for (int i = 0; i < B_P; ++i) {
+            const int r = (tid >> 3) + RP * i;
+            const int chunk = (tid & 7) ^ ((r >> 1) & 7);
+            b_base[i] = (unsigned)((n0 + r) * p.b_ld + (chunk << 3)) * 2u;
+        }
+    };
+    int itap = 0, ikc = 0;                 // the K-step being ISSUED (chunk outer, tap inner)
+    // byte offsets of the taps, one per lane: a K-step's offsets come from v_readlane, not from three dependent scalar loads
+    // (measured with the stamped build: ~400 cycles per K-step on the critical path between two barriers)
+    int tapA = 0, tapB = 0;
+    if (lane < NT) {
+        tapA = ((p.a_dh[lane] * p.a_IW + p.a_dw[lane]) * p.a_ld) * 2;
+        tapB = p.b_tapoff[lane] * 2;
+    }
+    const bool dbg_skipA = p.ptiles_dbg & 1;      // timing experiment (wrong results): A tiles fetched for tap 0 only
+    const bool dbg_skipB = p.ptiles_dbg & 2;      // ... no B tiles after the first
+
+    f32x16 acc[TM][TN];
+    int a_row[TM], b_row[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_row[i] = wm * (TM * 32) + i * 32 + li;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_row[j] = wn * (TN * 32) + j * 32 + li;
+
+    // One K-step: fragments read one sub-step ahead of their MFMAs, a quarter of the next ring tile's DMAs per sub-step.  The
+    // MFMA operands are swapped (B rows first): accumulator lane = output ROW li of the 32x32 block, register r = column
+    // (r & 3) + 8 (r >> 2) + 4 lh.
+    auto kstep = [&](int stage, bool fillnext, unsigned toff, unsigned boff) {
+        const char* As = smem16 + stage * STAGE;
+        const char* Bs = As + BM * ROWB;
+        char* Ad = smem16 + (stage == 0 ? NST - 1 : stage - 1) * STAGE + wid * 1024;      // the stage read in the previous K-step
+        char* Bd = Ad + BM * ROWB;
+        constexpr int NB = PFD + 1;
+        bf16x8 fa[NB][TM], fb[NB][TN];
+        auto ld = [&](int ks, int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[b][i] = *reinterpret_cast<const bf16x8*>(As + a_row[i] * ROWB + (((2 * ks + lh) ^ ((a_row[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[b][j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+        };
+#pragma unroll
+        for (int k0 = 0; k0 < PFD; ++k0) ld(k0, k0);
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            if (ks + PFD < BK16 / 16) ld(ks + PFD, (ks + PFD) % NB);
+            if (fillnext) {
+#pragma unroll
+                for (int d = 0; d < L; ++d) {
+                    if (d * DSUB / L != ks) continue;
+                    if (d < A_P) { if (!(dbg_skipA && itap != 0)) dma16(rsrcA, Ad + d * (RP * ROWB), ((a_mask[d < A_P ? d : 0] >> itap) & 1) ? a_base[d < A_P ? d : 0] + toff : OOB, 0); }
+                    else if (!dbg_skipB) dma16(rsrcB, Bd + (d - A_P) * (RP * ROWB), b_base[d >= A_P ? d - A_P : 0], boff);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks % NB][j], fa[ks % NB][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (fillnext) {
+            if (++itap == NT) { itap = 0; ikc += BK16; }
+        }
+    };
+
+    // ---- first tile: loader state, the DMAs of its first NST - 1 K-steps (the launcher guarantees nk >= NST - 1) ----
+    setup(xbase + idx);
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) {
+        char* As = smem16 + s0 * STAGE + wid * 1024;
+        char* Bs = As + BM * ROWB;
+        const unsigned toff = (unsigned)(__builtin_amdgcn_readlane(tapA, itap) + ikc * 2);
+        const unsigned boff = (unsigned)(__builtin_amdgcn_readlane(tapB, itap) + ikc * 2);
+#pragma unroll
+        for (int i = 0; i < A_P; ++i) dma16(rsrcA, As + i * (RP * ROWB), ((a_mask[i] >> itap) & 1) ? a_base[i] + toff : OOB, 0);
+#pragma unroll
+        for (int i = 0; i < B_P; ++i) dma16(rsrcB, Bs + i * (RP * ROWB), b_base[i], boff);
+        if (++itap == NT) { itap = 0; ikc += BK16; }
+    }
+    const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
+    const int n_ein = !in16 ? 0 : TM * TN * 2 * (EPI == EPI_FWD ? 1 : (p.ADD16 ? 1 : 0) + (p.Zin16 ? 1 : 0));
+    int stage = 0;
+    // vmcnt retires in issue order: a K-step's tile has landed once at most as many operations are outstanding as were issued
+    // AFTER its DMAs.  qn[k] = vector-memory operations issued in each of the last NQ K-steps (oldest first); carry = the
+    // previous tile's epilogue stores, younger than the awaited DMAs for the first NST - 1 steps of a tile.
+    int qn[NQ > 0 ? NQ : 1];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) qn[k] = L;
+    int carry = 0;
+    int dbg_step = 0;
+
+    for (;;) {
+        const int tile = xbase + idx;
+        const int mt = tile / ntn, nt_ = tile - mt * ntn;
+        const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+        const int nidx = idx + per;
+        const bool hasnext = nidx < xcnt;
+
+        // output row of this lane per 32-row block
+        int roff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TM * 32) + i * 32 + li;
+            int off = -1;
+            if (m < p.M) {
+                if (p.c_OH == 0) {
+                    off = m * p.c_ld;
+                } else {
+                    const int hw = p.c_OH * p.c_OW;
+                    const int n = fdiv(m, hw, 1.f / (float)hw), rem = m - n * hw;
+                    const int oh = fdiv(rem, p.c_OW, 1.f / (float)p.c_OW), ow = rem - oh * p.c_OW;
+                    off = ((n * p.c_FH + oh * p.c_step + p.c_ph) * p.c_FW + ow * p.c_step + p.c_pw) * p.c_ld;
+                }
+            }
+            roff[i] = off;
+        }
+        // alpha / bias of the tile's columns -> LDS (read in the epilogue, nk barriers later; the previous tile's epilogue reads
+        // are separated from this write by its closing barrier)
+        if (tid < BN) {
+            float al = 1.f, bi = 0.f;
+            if constexpr (EPI == EPI_FWD) {
+                if (p.alpha) al = p.alpha[n0 + tid];
+                if (p.bias) bi = p.bias[n0 + tid];
+            } else {
+                if (p.alpha) al = p.alpha[(n0 + tid) % p.amod];
+            }
+            colf[tid] = al;
+            colf[BN + tid] = bi;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        u32x4 ein0[TM][TN][2], ein1[TM][TN][2];           // bf16 epilogue inputs, fetched before the last K-step
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { ein0[i][j][q] = u32x4{0u, 0u, 0u, 0u}; ein1[i][j][q] = u32x4{0u, 0u, 0u, 0u}; }
+
+        for (int t = 0; t < nk; ++t) {
+            const bool last = t == nk - 1;
+            const bool fillnext = t + NST - 1 < nk || hasnext;           // the K-step NST - 1 ahead: this tile's, or the next tile's
+            if (t + NST - 1 == nk && hasnext) { setup(xbase + nidx); itap = 0; ikc = 0; }
+            const unsigned toff = (unsigned)(__builtin_amdgcn_readlane(tapA, itap) + ikc * 2);      // wave-uniform
+            const unsigned boff = (unsigned)(__builtin_amdgcn_readlane(tapB, itap) + ikc * 2);
+            unsigned long long st0 = 0, st1 = 0, st2 = 0;
+            if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            {
+                int allowed = t < NST - 1 ? carry : 0;
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) allowed += qn[k];
+                wait_vmcnt_upto(allowed);
+            }
+            if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            __builtin_amdgcn_s_barrier();
+            if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st2 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            if (last && in16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
+                            if constexpr (EPI == EPI_FWD) {
+                                if (p.R16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.R16 + o);
+                            } else {
+                                if (p.ADD16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.ADD16 + o);
+                                if (p.Zin16) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(p.Zin16 + o);
+                            }
+                        }
+            }
+            kstep(stage, fillnext, toff, boff);
+            if constexpr (DBG) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long st3 = stamp_now();
+                __builtin_amdgcn_sched_barrier(0);
+                const int sb = blockIdx.x == 0 ? 0 : (blockIdx.x == 8 ? 1 : -1), sw = wid == 0 ? 0 : (wid == NW - 1 ? 1 : -1);
+                if (sb >= 0 && sw >= 0 && dbg_step < 80 && lane == 0) {
+                    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.PW) + ((sb * 2 + sw) * 80 + dbg_step) * 4;
+                    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+                }
+                ++dbg_step;
+            }
+            stage = stage + 1 == NST ? 0 : stage + 1;
+#pragma unroll
+            for (int k = 0; k + 1 < NQ; ++k) qn[k] = qn[k + 1];
+            if (NQ > 0) qn[NQ > 0 ? NQ - 1 : 0] = (fillnext ? L : 0) + (last ? n_ein : 0);
+        }
+
+        // ---- epilogue (no LDS patches, no block barrier in the forward form) ----
+        const int nst = epilogue_rows<BM, BN, WM, WN, EPI>(p, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        if (!hasnext) break;
+        // colf / red are rewritten at the top of the next tile: every wave must be done reading them
+        __syncthreads();
+        carry = nst;
+        idx = nidx;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int BPC, int PFD = 1>
+hipError_t launch16p(const IgemmParams& p, hipStream_t st) {
+    const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
+    IgemmParams q = p;
+    q.ptiles = mt * nt;
+    static const int dbg = getenv("FTE_IGEMM16_DBG") ? atoi(getenv("FTE_IGEMM16_DBG")) : 0;
+    q.ptiles_dbg = dbg;
+    const size_t lds = (size_t)NST * (BM + BN) * ROWB + (size_t)(2 * BN + 2 * WM * BN) * sizeof(float);
+    auto kern = igemm16p_kernel<BM, BN, WM, WN, EPI, NST, MINW, PFD>;
+    if (igemm_prof_on()) { const int ta[9] = {BM, BN, WM, WN, EPI, NST, MINW, PFD, 0}; igemm_note_symbol("igemm16p_kernel", ta, 9); }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        cus = prop.multiProcessorCount;
+    }
+    const int per_xcd = (cus / 8) * BPC;                               // resident blocks per XCD
+    const int need = (q.ptiles + 7) / 8;
+    const int grid = 8 * (need < per_xcd ? need : per_xcd);
+    static const bool stamps = getenv("FTE_IGEMM16_STAMP") != nullptr;
+    if (stamps) {              // diagnostic: the stamped build of this configuration, its table on stderr
+        auto dk = igemm16p_kernel<BM, BN, WM, WN, EPI, NST, MINW, PFD, 1>;
+        static unsigned long long* buf = nullptr;
+        const size_t nb = 2 * 2 * 80 * 4 * sizeof(unsigned long long);
+        if (!buf) {
+            if (hipMalloc(&buf, nb) != hipSuccess) return hipErrorOutOfMemory;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        (void)hipMemsetAsync(buf, 0, nb, st);
+        q.PW = reinterpret_cast<float*>(buf);
+        hipLaunchKernelGGL(dk, dim3(grid), dim3(64 * WM * WN), lds, st, q);
+        (void)hipStreamSynchronize(st);
+        static unsigned long long host[2 * 2 * 80 * 4];
+        (void)hipMemcpy(host, buf, nb, hipMemcpyDeviceToHost);
+        const int nk = q.K / BK16;
+        fprintf(stderr, "[stamp] igemm16p<%d,%d,%d,%d,%d,%d> M %d N %d K %d tiles %d grid %d\n", BM, BN, WM, WN, EPI, NST, q.M, q.N, q.K, q.ptiles, grid);
+        for (int b = 0; b < 2; ++b)
+            for (int w = 0; w < 2; ++w) {
+                const unsigned long long* h = host + (b * 2 + w) * 80 * 4;
+                double sw = 0, sb = 0, sk = 0, sp = 0; int n = 0;
+                for (int i = 4; i < nk && i < 80; ++i) {
+                    if (!h[i * 4]) break;
+                    sw += (double)(h[i * 4 + 1] - h[i * 4]); sb += (double)(h[i * 4 + 2] - h[i * 4 + 1]); sk += (double)(h[i * 4 + 3] - h[i * 4 + 2]);
+                    sp += (double)(h[i * 4] - h[(i - 1) * 4]); ++n;
+                }
+                if (n) fprintf(stderr, "[stamp]  block %d wave %d: per K-step (steps 4..%d of tile 0): period %.0f = vmcnt wait %.0f + barrier %.0f + body %.0f + rest  (s_memtime ticks)\n",
+                               b ? 8 : 0, w ? WM * WN - 1 : 0, 3 + n, sp / n, sw / n, sb / n, sk / n);
+                if (nk < 80 && h[nk * 4]) fprintf(stderr, "[stamp]   tile 0 -> tile 1: last body end to first wait start %.0f ticks, first wait %.0f, tile 0 start..end %.0f\n",
+                                                  (double)(h[nk * 4] - h[(nk - 1) * 4 + 3]), (double)(h[nk * 4 + 1] - h[nk * 4]), (double)(h[(nk - 1) * 4 + 3] - h[0]));
+            }
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, st, q);
+    return hipGetLastError();
+}
+
+// ---- ring variant with loader waves -----------------------------------------------------------------------------------------
+// What the stamped builds of igemm16p say (FTE_IGEMM16_STAMP, 14x14x256 at batch 512): a K-step of a block lasts ~1850-2000 cycles for
+// 256 cycles of MFMA per wave; the same with a four-stage ring, with one block per CU, with 44 % of the DMAs left out.  The MFMA pipe
+// and the LDS-DMA path are far from their limits (scripts/probes/lds_dma_vs_read.hip: 116 GB/s of DMA per CU BESIDE 93 % of the MFMA
+// peak, in different waves) -- what costs is a wave doing everything in turn: fragment reads it must wait for, two MFMAs, a DMA
+// instruction that holds the wave while the address path takes it, a wait for the landing, a barrier.  So the roles are split:
+//   * NLW loader waves only move tiles: per K-step each issues its share of the stage's 1-KiB pieces NST - 1 steps ahead (across tile
+//     boundaries), waits with a counted vmcnt for the stage the consumers need next, and meets them at the ONE barrier of the step;
+//   * WM x WN consumer waves (wave tile 64 x 64: four MFMAs per 16-deep sub-step, half the LDS fragment bytes per MFMA of the 32 x 64
+//     tile) only read fragments (PFD sub-steps ahead) and issue MFMAs; their epilogue is epilogue_rows, during which the loaders
+//     are already filling the ring for the next tile.
+// One block per CU (a 256 x 128 tile's three stages are 144 KB), three waves per SIMD.
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int NLW, int PFD, int DBG = 0>
+__global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16r_kernel(const IgemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NCW = WM * WN;
+    constexpr int KA = BM / 8 / NLW, KB = BN / 8 / NLW, PPL = KA + KB;      // 1-KiB pieces (8 rows x 128 B) per loader wave and K-step
+    static_assert((BM / 8) % NLW == 0 && (BN / 8) % NLW == 0 && NST >= 3 && NST <= 4 && PFD >= 1 && PFD <= 3, "pieces per loader");
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int NQ = NST - 2;
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    float* const colf2 = reinterpret_cast<float*>(smem16 + NST * STAGE);   // [2][2][BN]: alpha, bias of the tile's columns, double-buffered
+    float* const red = colf2 + 4 * BN;                                     // [2][WM][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int ntn = p.N / BN;
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    const int q8 = p.ptiles >> 3, r8 = p.ptiles & 7;
+    const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+    int idx = blockIdx.x >> 3;
+    if (idx >= xcnt) return;
+    const int NT = p.a_NT, nk = p.K / BK16;
+    const bool epi_barrier = EPI == EPI_DGRAD && p.PA != nullptr;
+    unsigned long long* const stamps = DBG ? reinterpret_cast<unsigned long long*>(p.PW) : nullptr;
+    int dbg_step = 0;
+
+    if (wid >= NCW) {
+        // =================================================== loader wave ===================================================
+        const int lw = wid - NCW;
+        constexpr unsigned OOB = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+        const int a_hw = p.a_OH * p.a_OW;
+        const float r_ahw = 1.f / (float)a_hw, r_aow = 1.f / (float)p.a_OW;
+        int tapA = 0, tapB = 0;                 // byte offsets of the taps, one per lane (v_readlane instead of dependent scalar loads)
+        if (lane < NT) {
+            tapA = ((p.a_dh[lane] * p.a_IW + p.a_dw[lane]) * p.a_ld) * 2;
+            tapB = p.b_tapoff[lane] * 2;
+        }
+        unsigned a_base[KA], b_base[KB];
+        int a_mask[KA];
+        // piece k of this wave = piece lw + NLW k of the stage: rows 8 (lw + NLW k) + (lane >> 3); k < KA: A rows, else B rows
+        auto setup = [&](int tile) {
+            const int mt = tile / ntn, nt_ = tile - mt * ntn;
+            const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                const int r = 8 * (lw + NLW * k) + (lane >> 3);
+                const int m = m0 + r;
+                int base = 0, mask = 0;
+                if (m < p.M) {
+                    const int n = fdiv(m, a_hw, r_ahw), rem = m - n * a_hw;
+                    const int oh = fdiv(rem, p.a_OW, r_aow), ow = rem - oh * p.a_OW;
+                    const int ih0 = oh * p.a_stride, iw0 = ow * p.a_stride;
+                    base = ((n * p.a_IH + ih0) * p.a_IW + iw0) * p.a_ld;
+                    for (int t = 0; t < NT; ++t) {
+                        const int ih = ih0 + p.a_dh[t], iw = iw0 + p.a_dw[t];
+                        if (ih >= 0 && ih < p.a_IH && iw >= 0 && iw < p.a_IW) mask |= 1 << t;
+                    }
+                }
+                const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+                a_base[k] = (unsigned)(base + (chunk << 3)) * 2u;
+                a_mask[k] = mask;
+            }
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int r = 8 * (lw + NLW * k) + (lane >> 3);
+                const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+                b_base[k] = (unsigned)((n0 + r) * p.b_ld + (chunk << 3)) * 2u;
+            }
+        };
+        int itap = 0, ikc = 0;
+        auto issue = [&](int stage) {
+            char* As = smem16 + stage * STAGE + lw * 1024;
+            char* Bs = As + BM * ROWB;
+            const unsigned toff = (unsigned)(__builtin_amdgcn_readlane(tapA, itap) + ikc * 2);
+            const unsigned boff = (unsigned)(__builtin_amdgcn_readlane(tapB, itap) + ikc * 2);
+#pragma unroll
+            for (int k = 0; k < KA; ++k) dma16(rsrcA, As + k * (NLW * 1024), ((a_mask[k] >> itap) & 1) ? a_base[k] + toff : OOB, 0);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) dma16(rsrcB, Bs + k * (NLW * 1024), b_base[k], boff);
+            if (++itap == NT) { itap = 0; ikc += BK16; }
+        };
+        setup(xbase + idx);
+#pragma unroll
+        for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
+        int qn[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) qn[k] = PPL;
+        int stage = 0;
+        for (;;) {
+            const int nidx = idx + per;
+            const bool hasnext = nidx < xcnt;
+            for (int t = 0; t < nk; ++t) {
+                const bool fillnext = t + NST - 1 < nk || hasnext;
+                if (t + NST - 1 == nk && hasnext) { setup(xbase + nidx); itap = 0; ikc = 0; }
+                unsigned long long st0 = 0, st1 = 0, st2 = 0;
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                {
+                    int allowed = 0;
+#pragma unroll
+                    for (int k = 0; k < NQ; ++k) allowed += qn[k];
+                    wait_vmcnt_upto(allowed);
+                }
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                __builtin_amdgcn_s_barrier();
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st2 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                if (fillnext) issue(stage == 0 ? NST - 1 : stage - 1);                  // the stage the consumers read in the previous K-step
+                if constexpr (DBG) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long st3 = stamp_now();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (blockIdx.x == 0 && lw == 0 && dbg_step < 80 && lane == 0) {
+                        unsigned long long* o = stamps + (1 * 80 + dbg_step) * 4;
+                        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+                    }
+                    ++dbg_step;
+                }
+                stage = stage + 1 == NST ? 0 : stage + 1;
+#pragma unroll
+                for (int k = 0; k + 1 < NQ; ++k) qn[k] = qn[k + 1];
+                qn[NQ - 1] = fillnext ? PPL : 0;
+            }
+            if (epi_barrier) __builtin_amdgcn_s_barrier();           // the consumers' epilogue holds one block barrier
+            if (!hasnext) break;
+            idx = nidx;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ===================================================== consumer wave =====================================================
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+    int a_row[TM], b_row[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_row[i] = wm * (TM * 32) + i * 32 + li;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_row[j] = wn * (TN * 32) + j * 32 + li;
+    auto kstep = [&](int stage) {
+        const char* As = smem16 + stage * STAGE;
+        const char* Bs = As + BM * ROWB;
+        constexpr int NB = PFD + 1;
+        bf16x8 fa[NB][TM], fb[NB][TN];
+        auto ld = [&](int ks, int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[b][i] = *reinterpret_cast<const bf16x8*>(As + a_row[i] * ROWB + (((2 * ks + lh) ^ ((a_row[i] >> 1) & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[b][j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+        };
+#pragma unroll
+        for (int k0 = 0; k0 < PFD; ++k0) ld(k0, k0);
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            if (ks + PFD < BK16 / 16) ld(ks + PFD, (ks + PFD) % NB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks % NB][j], fa[ks % NB][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
+    int stage = 0, kt = 0;
+    for (;;) {
+        const int tile = xbase + idx;
+        const int mt = tile / ntn, nt_ = tile - mt * ntn;
+        const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+        const int nidx = idx + per;
+        const bool hasnext = nidx < xcnt;
+        float* const colf = colf2 + (kt & 1) * 2 * BN;
+        int roff[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TM * 32) + i * 32 + li;
+            int off = -1;
+            if (m < p.M) {
+                if (p.c_OH == 0) {
+                    off = m * p.c_ld;
+                } else {
+                    const int hw = p.c_OH * p.c_OW;
+                    const int n = fdiv(m, hw, 1.f / (float)hw), rem = m - n * hw;
+                    const int oh = fdiv(rem, p.c_OW, 1.f / (float)p.c_OW), ow = rem - oh * p.c_OW;
+                    off = ((n * p.c_FH + oh * p.c_step + p.c_ph) * p.c_FW + ow * p.c_step + p.c_pw) * p.c_ld;
+                }
+            }
+            roff[i] = off;
+        }
+        // alpha / bias of the tile's columns -> this tile's half of colf2 (read in the epilogue, nk barriers later; the other half
+        // may still be read by waves in the previous tile's epilogue)
+        for (int c = tid; c < BN; c += 64 * NCW) {
+            float al = 1.f, bi = 0.f;
+            if constexpr (EPI == EPI_FWD) {
+                if (p.alpha) al = p.alpha[n0 + c];
+                if (p.bias) bi = p.bias[n0 + c];
+            } else {
+                if (p.alpha) al = p.alpha[(n0 + c) % p.amod];
+            }
+            colf[c] = al;
+            colf[BN + c] = bi;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        u32x4 ein0[TM][TN][2], ein1[TM][TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { ein0[i][j][q] = u32x4{0u, 0u, 0u, 0u}; ein1[i][j][q] = u32x4{0u, 0u, 0u, 0u}; }
+
+        for (int t = 0; t < nk; ++t) {
+            unsigned long long st0 = 0, st1 = 0;
+            if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            __builtin_amdgcn_s_barrier();
+            if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            if (t == nk - 1 && in16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
+                            if constexpr (EPI == EPI_FWD) {
+                                if (p.R16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.R16 + o);
+                            } else {
+                                if (p.ADD16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.ADD16 + o);
+                                if (p.Zin16) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(p.Zin16 + o);
+                            }
+                        }
+            }
+            kstep(stage);
+            if constexpr (DBG) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long st2 = stamp_now();
+                __builtin_amdgcn_sched_barrier(0);
+                if (blockIdx.x == 0 && wid == 0 && dbg_step < 80 && lane == 0) {
+                    unsigned long long* o = stamps + (0 * 80 + dbg_step) * 4;
+                    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = 0;
+                }
+                ++dbg_step;
+            }
+            stage = stage + 1 == NST ? 0 : stage + 1;
+        }
+        epilogue_rows<BM, BN, WM, WN, EPI>(p, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        if (!hasnext) break;
+        idx = nidx;
+        ++kt;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int NLW, int PFD>
+hipError_t launch16r(const IgemmParams& p, hipStream_t st) {
+    const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
+    IgemmParams q = p;
+    q.ptiles = mt * nt;
+    q.ptiles_dbg = 0;
+    const size_t lds = (size_t)NST * (BM + BN) * ROWB + (size_t)(4 * BN + 2 * WM * BN) * sizeof(float);
+    auto kern = igemm16r_kernel<BM, BN, WM, WN, EPI, NST, NLW, PFD>;
+    if (igemm_prof_on()) { const int ta[9] = {BM, BN, WM, WN, EPI, NST, NLW, PFD, 0}; igemm_note_symbol("igemm16r_kernel", ta, 9); }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        cus = prop.multiProcessorCount;
+    }
+    const int per_xcd = cus / 8;                                       // one block per CU
+    const int need = (q.ptiles + 7) / 8;
+    const int grid = 8 * (need < per_xcd ? need : per_xcd);
+    constexpr int THREADS = 64 * (WM * WN + NLW);
+    static const bool stamps = getenv("FTE_IGEMM16_STAMP") != nullptr;
+    if (stamps) {              // diagnostic: the stamped build, its table on stderr
+        auto dk = igemm16r_kernel<BM, BN, WM, WN, EPI, NST, NLW, PFD, 1>;
+        static unsigned long long* buf = nullptr;
+        const size_t nb = 2 * 80 * 4 * sizeof(unsigned long long);
+        if (!buf) {
+            if (hipMalloc(&buf, nb) != hipSuccess) return hipErrorOutOfMemory;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        (void)hipMemsetAsync(buf, 0, nb, st);
+        q.PW = reinterpret_cast<float*>(buf);
+        hipLaunchKernelGGL(dk, dim3(grid), dim3(THREADS), lds, st, q);
+        (void)hipStreamSynchronize(st);
+        static unsigned long long host[2 * 80 * 4];
+        (void)hipMemcpy(host, buf, nb, hipMemcpyDeviceToHost);
+        const int nk = q.K / BK16;
+        fprintf(stderr, "[stamp] igemm16r<%d,%d,%d,%d,%d,%d,%d,%d> M %d N %d K %d tiles %d grid %d\n", BM, BN, WM, WN, EPI, NST, NLW, PFD, q.M, q.N, q.K, q.ptiles, grid);
+        {
+            const unsigned long long* h = host;
+            double sb = 0, sk = 0, sp = 0; int n = 0;
+            for (int i = 4; i < nk && i < 80; ++i) {
+                if (!h[i * 4]) break;
+                sb += (double)(h[i * 4 + 1] - h[i * 4]); sk += (double)(h[i * 4 + 2] - h[i * 4 + 1]); sp += (double)(h[i * 4] - h[(i - 1) * 4]); ++n;
+            }
+            if (n) fprintf(stderr, "[stamp]  consumer wave 0: per K-step period %.0f = barrier %.0f + body %.0f + rest\n", sp / n, sb / n, sk / n);
+            if (nk < 80 && h[nk * 4]) fprintf(stderr, "[stamp]   tile 0 -> 1: last body end to next barrier entry %.0f ticks (epilogue), tile 0 K loop %.0f\n",
+                                              (double)(h[nk * 4] - h[(nk - 1) * 4 + 2]), (double)(h[(nk - 1) * 4 + 2] - h[0]));
+            h = host + 80 * 4;
+            double sw = 0, sbb = 0, si = 0; sp = 0; n = 0;
+            for (int i = 4; i < nk && i < 80; ++i) {
+                if (!h[i * 4]) break;
+                sw += (double)(h[i * 4 + 1] - h[i * 4]); sbb += (double)(h[i * 4 + 2] - h[i * 4 + 1]); si += (double)(h[i * 4 + 3] - h[i * 4 + 2]);
+                sp += (double)(h[i * 4] - h[(i - 1) * 4]); ++n;
+            }
+            if (n) fprintf(stderr, "[stamp]  loader wave 0:   per K-step period %.0f = vmcnt wait %.0f + barrier %.0f + issue %.0f + rest\n", sp / n, sw / n, sbb / n, si / n);
+        }
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, q);
+    return hipGetLastError();
+}
+
+// what the persistent kernel takes: whole-K launches of the 128-row tiles without merged dgrad classes
+static bool launch16p_ok(const IgemmParams& p, int epi, int tile, int splits) {
+    if (splits != 1 || p.PW || p.ncls > 1 || p.split_major > 0) return false;
+    if (tile != TILE_128x128 && tile != TILE_128x64) return false;
+    if (p.kchunk < p.K || p.K % BK16 || p.K / BK16 < 4 || p.a_KC % BK16 || p.a_NT > 9) return false;
+    if (epi == EPI_DGRAD && p.alpha && p.amod % 8) return false;
+    if (p.c_ld % 8 || p.N % 8) return false;
+    // bf16-STORAGE launches only: with fp32 tensors in the epilogue (the operand-copies mode, the last layer's fp32 z / y) the row-per-lane
+    // form moves 32 bytes per lane and tensor and loses to the LDS-transposed epilogue (SphereNet bf16 mode 14.54 -> 15.18 ms with it)
+    if (epi == EPI_FWD ? (p.Z || p.Y || p.R) : (p.RAW || p.DZ || p.ADD || p.Zin)) return false;
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int MINW, int NSTB = 2>
 hipError_t launch16w(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
@@ -461,14 +1408,14 @@ hipError_t launch16w(const IgemmParams& p, int splits, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0, int PF = 0>
 hipError_t launch16(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
     const size_t ring = (size_t)NST * (BM + BN) * ROWB;
     const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);
     const size_t lds = ring > epi ? ring : epi;
-    auto kern = igemm16_kernel<BM, BN, WM, WN, EPI, NST, MINW, ABL>;
-    if (igemm_prof_on()) { const int ta[8] = {BM, BN, WM, WN, EPI, NST, MINW, ABL}; igemm_note_symbol("igemm16_kernel", ta, 8); }
+    auto kern = igemm16_kernel<BM, BN, WM, WN, EPI, NST, MINW, ABL, PF>;
+    if (igemm_prof_on()) { const int ta[9] = {BM, BN, WM, WN, EPI, NST, MINW, ABL, PF}; igemm_note_symbol("igemm16_kernel", ta, 9); }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -550,8 +1497,91 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         if (epi == EPI_FWD) return launch16w<128, 128, 2, 2, EPI_FWD, 2>(p, splits, st);
         return launch16w<128, 128, 2, 2, EPI_DGRAD, 2>(p, splits, st);
     }
+    static const int pers = getenv("FTE_IGEMM16_PERSIST") ? atoi(getenv("FTE_IGEMM16_PERSIST")) : 1;      // 0: the per-tile kernels
+    if (pers && launch16p_ok(p, epi, tile, splits)) {
+        if (tile == TILE_128x128) {
+            if (pers == 2) {         // four-stage ring, one block per CU
+                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 4, 2, 1>(p, st);
+                return launch16p<128, 128, 4, 2, EPI_DGRAD, 4, 2, 1>(p, st);
+            }
+            if (pers == 3 && (p.M - p.m_base) >= 256) {         // 256 x 128 tile (wave tile 64 x 64), three-stage ring, one block per CU
+                if (epi == EPI_FWD) return launch16p<256, 128, 4, 2, EPI_FWD, 3, 2, 1>(p, st);
+                return launch16p<256, 128, 4, 2, EPI_DGRAD, 3, 2, 1>(p, st);
+            }
+            if (pers >= 10 && pers <= 13 && (p.M - p.m_base) >= 256) {      // loader waves + 64 x 64 consumers, 256 x 128 tile, one block per CU
+                if (pers == 10) {
+                    if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 4, 2>(p, st);
+                    return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 4, 2>(p, st);
+                }
+                if (pers == 11) {
+                    if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 4, 1>(p, st);
+                    return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 4, 1>(p, st);
+                }
+                if (pers == 12) {
+                    if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 2, 2>(p, st);
+                    return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 2, 2>(p, st);
+                }
+                if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 8, 2>(p, st);
+                return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 8, 2>(p, st);
+            }
+            if (pers == 6 || pers == 7) {         // four waves (2 x 2, wave tile 64 x 64), two blocks per CU = two waves per SIMD
+                if (pers == 6) {
+                    if (epi == EPI_FWD) return launch16p<128, 128, 2, 2, EPI_FWD, 2, 2, 2, 2>(p, st);
+                    return launch16p<128, 128, 2, 2, EPI_DGRAD, 2, 2, 2, 2>(p, st);
+                }
+                if (epi == EPI_FWD) return launch16p<128, 128, 2, 2, EPI_FWD, 2, 2, 2, 3>(p, st);
+                return launch16p<128, 128, 2, 2, EPI_DGRAD, 2, 2, 2, 3>(p, st);
+            }
+            if (pers == 8) {         // 256 x 128, eight waves of 64 x 64, three stages, all fragments up front
+                if (epi == EPI_FWD) return launch16p<256, 128, 4, 2, EPI_FWD, 3, 2, 1, 3>(p, st);
+                return launch16p<256, 128, 4, 2, EPI_DGRAD, 3, 2, 1, 3>(p, st);
+            }
+            if (pers == 9) {         // 128 x 128, eight waves, four stages, one block per CU, all fragments up front
+                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 4, 2, 1, 3>(p, st);
+                return launch16p<128, 128, 4, 2, EPI_DGRAD, 4, 2, 1, 3>(p, st);
+            }
+            if (pers == 4) {
+                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 2, 4, 2, 2>(p, st);
+                return launch16p<128, 128, 4, 2, EPI_DGRAD, 2, 4, 2, 2>(p, st);
+            }
+            if (pers == 5) {
+                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 2, 4, 2, 3>(p, st);
+                return launch16p<128, 128, 4, 2, EPI_DGRAD, 2, 4, 2, 3>(p, st);
+            }
+            if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 2, 4, 2>(p, st);
+            if (pers == 14) return launch16p<128, 128, 4, 2, EPI_DGRAD, 2, 4, 2>(p, st);
+            // the 128 x 128 data gradient stays on the per-tile kernel (default): its persistent form (two bf16 inputs per output, column
+            // partials, 128 registers) measured 0.214 / 0.297 ms against 0.202 / 0.296 (14x14x256 / 28x28x128, batch 512)
+        } else {
+        if (pers == 4 || pers == 5) {
+            if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 2, 6, 3, 3>(p, st);
+            return launch16p<128, 64, 4, 2, EPI_DGRAD, 2, 6, 3, 3>(p, st);
+        }
+        if (pers == 2 || pers == 3) {     // three-stage ring, two blocks per CU
+            if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 3, 4, 2>(p, st);
+            return launch16p<128, 64, 4, 2, EPI_DGRAD, 3, 4, 2>(p, st);
+        }
+        if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 2, 6, 3>(p, st);
+        return launch16p<128, 64, 4, 2, EPI_DGRAD, 2, 6, 3>(p, st);
+        }
+    }
     // cfg 4 = cfg 1 with eight waves per block: SphereNet bf16 step 16.57 -> 15.77 ms (one stream), 16.0 -> 15.5 (two streams)
     static const int cfg = getenv("FTE_IGEMM16_CFG") ? atoi(getenv("FTE_IGEMM16_CFG")) : 4;      // tuning hook
+    if (abl >= 20 && abl <= 24 && tile == TILE_128x128 && epi == EPI_FWD) {      // ablations of the default configuration
+        if (abl == 20) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4, 0>(p, splits, st);
+        if (abl == 21) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4, 1>(p, splits, st);
+        if (abl == 22) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4, 2>(p, splits, st);
+        if (abl == 23) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4, 3>(p, splits, st);
+        if (abl == 24) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4, 4>(p, splits, st);
+    }
+    if (cfg == 5 && tile == TILE_128x128) {          // four waves (2 x 2, wave tile 64 x 64), fragments read one sub-step ahead
+        if (epi == EPI_FWD) return launch16<128, 128, 2, 2, EPI_FWD, 2, 2, 0, 1>(p, splits, st);
+        return launch16<128, 128, 2, 2, EPI_DGRAD, 2, 2, 0, 1>(p, splits, st);
+    }
+    if (cfg == 6 && tile == TILE_128x128) {          // eight waves (4 x 2), fragments read one sub-step ahead
+        if (epi == EPI_FWD) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4, 0, 1>(p, splits, st);
+        return launch16<128, 128, 4, 2, EPI_DGRAD, 2, 4, 0, 1>(p, splits, st);
+    }
     if (cfg == 4 && tile == TILE_128x128) {          // as cfg 1 with eight waves per block (4 x 2): four waves per SIMD
         if (epi == EPI_FWD) return launch16<128, 128, 4, 2, EPI_FWD, 2, 4>(p, splits, st);
         return launch16<128, 128, 4, 2, EPI_DGRAD, 2, 4>(p, splits, st);
