@@ -81,7 +81,10 @@ def test_s16_entry_points_are_the_rounding_of_the_copies_path(bf16s_mode, n, h, 
     da2 = torch.empty(cin, device='cuda'); db2 = torch.empty(cin, device='cuda')
     _lib.call('fte_conv2d_dgrad_s16', dz16, w16, add16, zp16, alp, raw16, dx16, da2, db2, n, h, w, cin, cout, k, stride, buf, nb, st)
     assert torch.equal(raw16, _bits(raw1)) and torch.equal(dx16, dx16c) and torch.equal(dx16, _bits(dx1))
-    assert torch.equal(da2, da1) and torch.equal(db2, db1)
+    # dalpha / dbias are fp32 sums over all pixels: the storage launch may run on another kernel of the family (igemm16rw: per-tile
+    # partials through a lane butterfly) than the copies launch, i.e. in another -- equally fixed -- summation order
+    for got, ref in ((da2, da1), (db2, db1)):
+        assert float((got.double() - ref.double()).norm() / ref.double().norm()) <= 2e-6
     # plain data gradient (no skip gradient, no mask, no raw): the stage-entry layers' dgrad into the images is never needed,
     # but the entry point must take NULLs like its fp32 twin
     dx16p = torch.empty(shp_i, **i16); dxp = torch.empty(shp_i, device='cuda')

@@ -112,18 +112,26 @@ def test_wgrad_128x128_hooked_ragged_splits():
 
 
 def test_persistent_bf16_kernels_at_the_sizes_that_select_them():
-    """bf16 storage (fte_conv2d_{fwd,dgrad}_s16): at >= 768 tiles of 128 rows the planner takes the 128x128 / 128x64 tile and the launch
-    runs on igemm16p_kernel -- resident blocks that walk several tiles (more tiles than block slots in every case here), swapped-operand
-    MFMAs, the register epilogue with the half-wave exchange, column partials through the lane butterfly.  Every stored bf16 value
-    must be within one bf16 step of the float64 result of the same bf16 inputs; dalpha / dbias as in the fp32 cases."""
+    """bf16 storage (fte_conv2d_{fwd,dgrad}_s16): at >= 768 tiles of 128 rows the planner takes the 128x128 / 128x64 tile and the 3x3 /
+    stride-1 launches run on igemm16rw_kernel -- resident blocks (loader waves + consumer waves) that walk several tiles, the A operand
+    through a padded-slot window in LDS, swapped-operand MFMAs, the register epilogue with the half-wave exchange, column partials
+    through the lane butterfly -- or, by hook, on igemm16p_kernel.  Every stored bf16 value must be within half a bf16 step (+ fp32
+    noise) of the float64 result of the same bf16 inputs; dalpha / dbias as in the fp32 cases."""
     env = {'FTE_MFMA_DTYPE': 'bf16s'}
     cs = _run([['s16fwd', 64, 56, 56, 64, 64, 1], ['s16dgrad', 64, 56, 56, 64, 64, 1], ['s16fwd', 126, 28, 28, 128, 128, 1],
                ['s16dgrad', 126, 28, 28, 128, 128, 1], ['s16fwd', 262, 14, 14, 256, 256, 1]], env, timeout=1500)
+    _has(cs[0], 'igemm16rw_kernel<256,64,4,2,0,4,2,56,0>')
+    _has(cs[1], 'igemm16rw_kernel<256,64,4,2,1,4,2,56,0>')
+    _has(cs[2], 'igemm16rw_kernel<256,128,4,2,0,4,2,48,0>')
+    _has(cs[3], 'igemm16rw_kernel<256,128,4,2,1,4,2,48,0>')
+    _has(cs[4], 'igemm16rw_kernel<256,128,4,2,0,4,2,48,0>')
+    # the same layers on the persistent kernel without loader waves / window (FTE_IGEMM16_PERSIST=14: every eligible launch)
+    cs = _run([['s16fwd', 64, 56, 56, 64, 64, 1], ['s16dgrad', 64, 56, 56, 64, 64, 1], ['s16fwd', 126, 28, 28, 128, 128, 1],
+               ['s16dgrad', 126, 28, 28, 128, 128, 1]], dict(env, FTE_IGEMM16_PERSIST='14'), timeout=1500)
     _has(cs[0], 'igemm16p_kernel<128,64,4,2,0,2,6,1,0>')
     _has(cs[1], 'igemm16p_kernel<128,64,4,2,1,2,6,1,0>')
     _has(cs[2], 'igemm16p_kernel<128,128,4,2,0,2,4,1,0>')
-    _has(cs[3], 'igemm16_kernel<128,128,4,2,1,2,4,0,0>')          # the 128x128 data gradient stays on the per-tile kernel
-    _has(cs[4], 'igemm16p_kernel<128,128,4,2,0,2,4,1,0>')
+    _has(cs[3], 'igemm16p_kernel<128,128,4,2,1,2,4,1,0>')
 
 
 def test_every_conv_symbol_of_the_headline_run_was_checked():

@@ -1376,6 +1376,413 @@ hipError_t launch16r(const IgemmParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- loader waves + A WINDOW (3x3, stride 1, TF-SAME) -------------------------------------------------------------------------
+// igemm16r moves (BM + BN) x 128 bytes per K-step and its loaders are what the consumers wait for (stamped: 1000 of the 2000 cycles
+// of a K-step at the barrier; 12 pieces per loader and step at the address path's ~90 cycles each).  For a 3x3 / stride-1 layer the
+// nine taps of a 64-channel chunk read row-shifted views of the same pixels, so the A operand is fetched ONCE per chunk:
+//   * pixels live in LDS at PADDED slots -- slot(img, y, x) = img (H+1)(W+1) + (y+1)(W+1) + x + 1: one zero slot ahead of every image
+//     row and one zero row ahead of every image, which is all the padding the eight neighbours ever touch -- so tap (dh, dw) of an
+//     output pixel is slot + dh (W+1) + dw for EVERY pixel: no edge masks in the MFMA loop (the zero slots are LDS-DMA'd from an
+//     out-of-range offset: zeros, scripts/probes/lds_dma_oob.hip);
+//   * the window of a tile = slots [slot(m0) - W - 2, slot(m0 + BM - 1) + W + 2], at most WCAP 8-slot pieces (48 KB), double-buffered:
+//     the next chunk's window (or the next tile's first) arrives two pieces per loader and K-step under the current chunk;
+//   * B (weights) keeps its three-stage ring, 16 KB per K-step: a K-step moves 16 + 48/9 KB instead of 48;
+//   * vmcnt retires in order and the window pieces of chunk c + 1 are issued before the B pieces of its first K-step, so waiting
+//     for a step's B tile also waits for its window.
+// Fragment addresses: row s = slot - window start + tap shift, chunk q of it at slot q ^ ((s >> 1) & 7) (the writer's swizzle is keyed
+// by the same window-relative slot); the four 16-deep sub-steps are a0 ^ (ks << 5).
+template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int DBG = 0>
+__global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(const IgemmParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NCW = WM * WN, NSTB = 3;
+    constexpr int KB = BN / 8 / NLW;                    // B pieces per loader wave and K-step
+    constexpr int KW = WCAP / NLW;                      // window pieces (8 slots x 128 B) per loader wave; WCAP = the window's capacity
+    constexpr int WPS = (KW + 5) / 6;                   // window pieces a loader issues per K-step (all of them within a chunk's first six)
+    static_assert((BN / 8) % NLW == 0 && WCAP % NLW == 0 && (KW + WPS - 1) / WPS <= 9 - NSTB, "pieces per loader");
+    constexpr int WINB = WCAP * 1024, BSTAGE = BN * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    char* const bring = smem16 + 2 * WINB;
+    float* const colf2 = reinterpret_cast<float*>(bring + NSTB * BSTAGE);  // [2][2][BN]
+    float* const red = colf2 + 4 * BN;                                     // [2][WM][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int ntn = p.N / BN;
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    const int q8 = p.ptiles >> 3, r8 = p.ptiles & 7;
+    const int xbase = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+    int idx = blockIdx.x >> 3;
+    if (idx >= xcnt) return;
+    const int nk = p.K / BK16, nch = nk / 9;             // nine taps per 64-channel chunk
+    const bool epi_barrier = EPI == EPI_DGRAD && p.PA != nullptr;
+    unsigned long long* const stamps = DBG ? reinterpret_cast<unsigned long long*>(p.PW) : nullptr;
+    int dbg_step = 0;
+
+    // padded slot space
+    const int H = p.a_IH, W = p.a_IW, PW1 = W + 1, IS = (H + 1) * PW1, HW = H * W;
+    const float r_hw = 1.f / (float)HW, r_w = 1.f / (float)W, r_is = 1.f / (float)IS, r_pw1 = 1.f / (float)PW1;
+    auto slot_of = [&](int m) {                         // pixel index -> padded slot
+        const int n = fdiv(m, HW, r_hw), rem = m - n * HW;
+        const int y = fdiv(rem, W, r_w), x = rem - y * W;
+        return n * IS + (y + 1) * PW1 + x + 1;
+    };
+
+    if (wid >= NCW) {
+        // =================================================== loader wave ===================================================
+        const int lw = wid - NCW;
+        if (!(p.ptiles_dbg & 4)) __builtin_amdgcn_s_setprio(3);          // few instructions, all on the critical path of the block
+        constexpr unsigned OOB = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+        int tapB = 0;
+        if (lane < 9) tapB = p.b_tapoff[lane] * 2;
+        unsigned w_off[KW], b_base[KB];
+        int npc = 0;                                    // pieces of the current window (whole launch: <= WCAP, the launcher checks)
+        auto setup_w = [&](int tile) {                  // window piece k of this wave = piece lw + NLW k: slots lo + 8 (lw + NLW k) + (lane >> 3)
+            const int mt = tile / ntn;
+            const int m0 = p.m_base + mt * BM;
+            const int mlast = min(m0 + BM, p.M) - 1;
+            const int lo = slot_of(m0) - PW1 - 1, hi = slot_of(mlast) + PW1 + 1;
+            npc = (hi - lo + 8) >> 3;
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int srel = 8 * (lw + NLW * k) + (lane >> 3);
+                const int S = lo + srel;
+                unsigned off = OOB;
+                if (S >= 0 && S <= hi) {
+                    const int n = fdiv(S, IS, r_is), rem = S - n * IS;
+                    const int r = fdiv(rem, PW1, r_pw1), c = rem - r * PW1;
+                    const int m = n * HW + (r - 1) * W + (c - 1);
+                    if (r >= 1 && c >= 1 && m < p.M) {
+                        const int chunk = (lane & 7) ^ ((srel >> 1) & 7);
+                        off = (unsigned)(m * p.a_ld + (chunk << 3)) * 2u;
+                    }
+                }
+                w_off[k] = off;
+            }
+        };
+        auto setup_b = [&](int tile) {
+            const int mt = tile / ntn, nt_ = tile - mt * ntn;
+            const int n0 = nt_ * BN;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                const int r = 8 * (lw + NLW * k) + (lane >> 3);
+                const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+                b_base[k] = (unsigned)((n0 + r) * p.b_ld + (chunk << 3)) * 2u;
+            }
+        };
+        int btap = 0, bkc = 0;                          // the K-step whose B tile is issued next
+        auto issue_b = [&](int stage) {
+            char* Bs = bring + stage * BSTAGE + lw * 1024;
+            const unsigned boff = (unsigned)(__builtin_amdgcn_readlane(tapB, btap) + bkc * 2);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) dma16(rsrcB, Bs + k * (NLW * 1024), b_base[k], boff);
+            if (++btap == 9) { btap = 0; bkc += BK16; }
+        };
+        // window pieces [from, from + WPS) of this wave for channel chunk `kc` into buffer `buf`; returns how many were issued
+        auto issue_w = [&](int buf, int kc, int from) -> int {
+            int n = 0;
+            char* const dst = smem16 + buf * WINB + lw * 1024;
+            const unsigned so = (unsigned)kc * 2u;
+            static_for<0, (KW + WPS - 1) / WPS>([&](auto G) {          // `from` is a multiple of WPS: one uniform branch per group
+                constexpr int g = decltype(G)::value;
+                if (from == g * WPS) {
+#pragma unroll
+                    for (int k = g * WPS; k < g * WPS + WPS && k < KW; ++k)
+                        if (lw + NLW * k < npc) { dma16(rsrcA, dst + k * (NLW * 1024), w_off[k], so); ++n; }
+                }
+            });
+            return n;
+        };
+        // prologue: the first tile's first window (all of it), then the B tiles of its first NSTB - 1 K-steps
+        setup_w(xbase + idx);
+        setup_b(xbase + idx);
+        for (int f = 0; f < KW; f += WPS) issue_w(0, 0, f);
+#pragma unroll
+        for (int s0 = 0; s0 < NSTB - 1; ++s0) issue_b(s0);
+        // vmcnt retires in issue order: B(t) was issued in step t - 2 BEFORE that step's window pieces; younger than it are those
+        // window pieces and everything of step t - 1
+        int w2 = 0, b1 = KB, w1 = 0;                   // window pieces of step t - 2, B and window pieces of step t - 1
+        int stage = 0, gc = 0;                          // B ring stage of the current step; chunks so far (window buffer = gc & 1)
+        for (;;) {
+            const int nidx = idx + per;
+            const bool hasnext = nidx < xcnt;
+            int wfrom = 0, wbuf = 0, wkc = 0;          // the window being fetched under the current chunk
+            bool wnext = false;
+            for (int t = 0, tau = 0, ch = 0; t < nk; ++t) {
+                if (tau == 0) {                         // a chunk starts: what arrives under it?
+                    wfrom = 0; wbuf = (gc + 1) & 1;
+                    if (ch + 1 < nch) { wnext = true; wkc = (ch + 1) * BK16; }
+                    else if (hasnext) { wnext = true; wkc = 0; setup_w(xbase + nidx); }
+                    else wnext = false;
+                }
+                const bool fillb = t + NSTB - 1 < nk || hasnext;
+                if (t + NSTB - 1 == nk && hasnext) { setup_b(xbase + nidx); btap = 0; bkc = 0; }
+                unsigned long long st0 = 0, st1 = 0, st2 = 0;
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                wait_vmcnt_upto(w2 + b1 + w1);
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                __builtin_amdgcn_s_barrier();
+                if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st2 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                int nb = 0, nw = 0;
+                if (fillb) { issue_b(stage == 0 ? NSTB - 1 : stage - 1); nb = KB; }
+                if (wnext && wfrom < KW) { nw = issue_w(wbuf, wkc, wfrom); wfrom += WPS; }
+                if constexpr (DBG) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned long long st3 = stamp_now();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (blockIdx.x == 0 && lw == 0 && dbg_step < 80 && lane == 0) {
+                        unsigned long long* o = stamps + (1 * 80 + dbg_step) * 4;
+                        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+                    }
+                    ++dbg_step;
+                }
+                w2 = w1; b1 = nb; w1 = nw;
+                stage = stage + 1 == NSTB ? 0 : stage + 1;
+                if (++tau == 9) { tau = 0; ++ch; ++gc; }
+            }
+            if (epi_barrier) __builtin_amdgcn_s_barrier();           // the consumers' epilogue holds one block barrier
+            if (!hasnext) break;
+            idx = nidx;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ===================================================== consumer wave =====================================================
+    const int wm = wid / WN, wn = wid % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+    int b_row[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_row[j] = wn * (TN * 32) + j * 32 + li;
+    int tshift = 0;                                     // window-row shifts of the taps, one per lane
+    if (lane < 9) tshift = p.a_dh[lane] * PW1 + p.a_dw[lane] + PW1 + 1;      // >= 0: the window starts W + 2 slots ahead of the tile's first pixel
+    int sl[TM];                                         // this lane's fragment rows: slot - slot(m0) (>= 0)
+    auto kstep = [&](int stage, int wbuf, int tap) {
+        const char* Bs = bring + stage * BSTAGE;
+        const int sh = __builtin_amdgcn_readlane(tshift, tap);
+        unsigned a0[TM];                                   // byte offsets from smem16 (kept as integers: the XOR below must not cost the LDS address space)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int s_ = sl[i] + sh;
+            a0[i] = (unsigned)(wbuf * WINB + (s_ << 7) + (((lh ^ (s_ >> 1)) & 7) << 4));
+        }
+        constexpr int NB = PFD + 1;
+        bf16x8 fa[NB][TM], fb[NB][TN];
+        auto ld = [&](int ks, int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[b][i] = *reinterpret_cast<const bf16x8*>(smem16 + (a0[i] ^ (unsigned)(ks << 5)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[b][j] = *reinterpret_cast<const bf16x8*>(Bs + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+        };
+#pragma unroll
+        for (int k0 = 0; k0 < PFD; ++k0) ld(k0, k0);
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 16; ++ks) {
+            if (ks + PFD < BK16 / 16) ld(ks + PFD, (ks + PFD) % NB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks % NB][j], fa[ks % NB][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
+    int stage = 0, kt = 0, gc = 0;
+    for (;;) {
+        const int tile = xbase + idx;
+        const int mt = tile / ntn, nt_ = tile - mt * ntn;
+        const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
+        const int nidx = idx + per;
+        const bool hasnext = nidx < xcnt;
+        float* const colf = colf2 + (kt & 1) * 2 * BN;
+        int roff[TM];
+        const int s0_ = slot_of(m0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (TM * 32) + i * 32 + li;
+            int off = -1;
+            sl[i] = 0;
+            if (m < p.M) {
+                sl[i] = slot_of(m) - s0_;
+                if (p.c_OH == 0) {
+                    off = m * p.c_ld;
+                } else {
+                    const int hw = p.c_OH * p.c_OW;
+                    const int n = fdiv(m, hw, 1.f / (float)hw), rem = m - n * hw;
+                    const int oh = fdiv(rem, p.c_OW, 1.f / (float)p.c_OW), ow = rem - oh * p.c_OW;
+                    off = ((n * p.c_FH + oh * p.c_step + p.c_ph) * p.c_FW + ow * p.c_step + p.c_pw) * p.c_ld;
+                }
+            }
+            roff[i] = off;
+        }
+        for (int c = tid; c < BN; c += 64 * NCW) {
+            float al = 1.f, bi = 0.f;
+            if constexpr (EPI == EPI_FWD) {
+                if (p.alpha) al = p.alpha[n0 + c];
+                if (p.bias) bi = p.bias[n0 + c];
+            } else {
+                if (p.alpha) al = p.alpha[(n0 + c) % p.amod];
+            }
+            colf[c] = al;
+            colf[BN + c] = bi;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        u32x4 ein0[TM][TN][2], ein1[TM][TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { ein0[i][j][q] = u32x4{0u, 0u, 0u, 0u}; ein1[i][j][q] = u32x4{0u, 0u, 0u, 0u}; }
+
+        for (int t = 0, tau = 0; t < nk; ++t) {
+            unsigned long long st0 = 0, st1 = 0;
+            if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            __builtin_amdgcn_s_barrier();
+            if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+            if (t == nk - 1 && in16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
+                            if constexpr (EPI == EPI_FWD) {
+                                if (p.R16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.R16 + o);
+                            } else {
+                                if (p.ADD16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.ADD16 + o);
+                            }
+                        }
+            }
+            kstep(stage, gc & 1, tau);
+            if constexpr (DBG) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long st2 = stamp_now();
+                __builtin_amdgcn_sched_barrier(0);
+                if (blockIdx.x == 0 && wid == 0 && dbg_step < 80 && lane == 0) {
+                    unsigned long long* o = stamps + (0 * 80 + dbg_step) * 4;
+                    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = 0;
+                }
+                ++dbg_step;
+            }
+            stage = stage + 1 == NSTB ? 0 : stage + 1;
+            if (++tau == 9) { tau = 0; ++gc; }
+        }
+        if constexpr (EPI == EPI_DGRAD) {          // the second input (previous z) only now: 64 more registers under the last K-step would spill
+            if (p.Zin16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
+                            ein1[i][j][q] = *reinterpret_cast<const u32x4*>(p.Zin16 + o);
+                        }
+            }
+        }
+        epilogue_rows<BM, BN, WM, WN, EPI>(p, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        if (!hasnext) break;
+        idx = nidx;
+        ++kt;
+    }
+}
+
+// the window kernel's layers: 3x3 taps within one pixel, stride 1, output grid = image; every tile's padded window within WCAP pieces
+static bool launch16rw_ok(const IgemmParams& p, int BM, int wcap) {
+    if (p.a_NT != 9 || p.a_stride != 1 || p.a_OH != p.a_IH || p.a_OW != p.a_IW || p.a_KC % BK16 || p.K != 9 * p.a_KC) return false;
+    for (int t = 0; t < 9; ++t)
+        if (p.a_dh[t] < -1 || p.a_dh[t] > 1 || p.a_dw[t] < -1 || p.a_dw[t] > 1) return false;
+    if (p.M != p.a_OH * p.a_OW * (p.M / (p.a_OH * p.a_OW)) || p.m_base != 0) return false;
+    // widest window: BM pixels spread over padded rows / images, plus a padded row and a slot on either side
+    const long H = p.a_IH, W = p.a_IW, hw = H * W;
+    const long imgx = (BM + hw - 1) / hw, rowx = (BM - 1) / W + 1;       // image / row boundaries BM consecutive pixels can cross
+    const long span = (BM - 1) + rowx + imgx * (W + 1) + 2 * (W + 1) + 3;
+    return (span + 7) / 8 <= wcap;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP>
+hipError_t launch16rw(const IgemmParams& p, hipStream_t st) {
+    const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
+    IgemmParams q = p;
+    q.ptiles = mt * nt;
+    static const int dbg = getenv("FTE_IGEMM16_DBG") ? atoi(getenv("FTE_IGEMM16_DBG")) : 0;
+    q.ptiles_dbg = dbg;
+    const size_t lds = (size_t)2 * WCAP * 1024 + (size_t)3 * BN * ROWB + (size_t)(4 * BN + 2 * WM * BN) * sizeof(float);
+    auto kern = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP>;
+    if (igemm_prof_on()) { const int ta[9] = {BM, BN, WM, WN, EPI, NLW, PFD, WCAP, 0}; igemm_note_symbol("igemm16rw_kernel", ta, 9); }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+        cus = prop.multiProcessorCount;
+    }
+    const int per_xcd = cus / 8;
+    const int need = (q.ptiles + 7) / 8;
+    const int grid = 8 * (need < per_xcd ? need : per_xcd);
+    constexpr int THREADS = 64 * (WM * WN + NLW);
+    static const bool stamps = getenv("FTE_IGEMM16_STAMP") != nullptr;
+    if (stamps) {
+        auto dk = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, 1>;
+        static unsigned long long* buf = nullptr;
+        const size_t nb = 2 * 80 * 4 * sizeof(unsigned long long);
+        if (!buf) {
+            if (hipMalloc(&buf, nb) != hipSuccess) return hipErrorOutOfMemory;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        (void)hipMemsetAsync(buf, 0, nb, st);
+        q.PW = reinterpret_cast<float*>(buf);
+        hipLaunchKernelGGL(dk, dim3(grid), dim3(THREADS), lds, st, q);
+        (void)hipStreamSynchronize(st);
+        static unsigned long long host[2 * 80 * 4];
+        (void)hipMemcpy(host, buf, nb, hipMemcpyDeviceToHost);
+        const int nk = q.K / BK16;
+        fprintf(stderr, "[stamp] igemm16rw<%d,%d,%d,%d,%d,%d,%d> M %d N %d K %d tiles %d grid %d\n", BM, BN, WM, WN, EPI, NLW, PFD, q.M, q.N, q.K, q.ptiles, grid);
+        {
+            const unsigned long long* h = host;
+            double sb = 0, sk = 0, sp = 0; int n = 0;
+            for (int i = 4; i < nk && i < 80; ++i) {
+                if (!h[i * 4]) break;
+                sb += (double)(h[i * 4 + 1] - h[i * 4]); sk += (double)(h[i * 4 + 2] - h[i * 4 + 1]); sp += (double)(h[i * 4] - h[(i - 1) * 4]); ++n;
+            }
+            if (n) fprintf(stderr, "[stamp]  consumer wave 0: per K-step period %.0f = barrier %.0f + body %.0f + rest\n", sp / n, sb / n, sk / n);
+            if (nk < 80 && h[nk * 4]) fprintf(stderr, "[stamp]   tile 0 -> 1: last body end to next barrier entry %.0f ticks (epilogue), tile 0 K loop %.0f\n",
+                                              (double)(h[nk * 4] - h[(nk - 1) * 4 + 2]), (double)(h[(nk - 1) * 4 + 2] - h[0]));
+            h = host + 80 * 4;
+            double sw = 0, sbb = 0, si = 0; sp = 0; n = 0;
+            for (int i = 4; i < nk && i < 80; ++i) {
+                if (!h[i * 4]) break;
+                sw += (double)(h[i * 4 + 1] - h[i * 4]); sbb += (double)(h[i * 4 + 2] - h[i * 4 + 1]); si += (double)(h[i * 4 + 3] - h[i * 4 + 2]);
+                sp += (double)(h[i * 4] - h[(i - 1) * 4]); ++n;
+            }
+            if (n) fprintf(stderr, "[stamp]  loader wave 0:   per K-step period %.0f = vmcnt wait %.0f + barrier %.0f + issue %.0f + rest\n", sp / n, sw / n, sbb / n, si / n);
+        }
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, q);
+    return hipGetLastError();
+}
+
 // what the persistent kernel takes: whole-K launches of the 128-row tiles without merged dgrad classes
 static bool launch16p_ok(const IgemmParams& p, int epi, int tile, int splits) {
     if (splits != 1 || p.PW || p.ncls > 1 || p.split_major > 0) return false;
@@ -1508,6 +1915,17 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
                 if (epi == EPI_FWD) return launch16p<256, 128, 4, 2, EPI_FWD, 3, 2, 1>(p, st);
                 return launch16p<256, 128, 4, 2, EPI_DGRAD, 3, 2, 1>(p, st);
             }
+            // default (pers == 1): the window kernel where it applies -- forward of every 3x3 / stride-1 layer, data gradient up to N = 128
+            // (batch 512, ms, per-tile kernel -> igemm16p -> igemm16rw: forward 28x28x128 0.224 -> 0.208 -> 0.170, 14x14x256 0.166 -> 0.156
+            // -> 0.145; data gradient 28x28x128 0.307 -> . -> 0.283, 14x14x256 0.205 -> 0.214 -> 0.206: stays on the per-tile kernel)
+            if ((pers == 1 || (pers >= 20 && pers <= 22)) && launch16rw_ok(p, 256, 48) && (pers != 1 || epi == EPI_FWD || p.N <= 128)) {
+                if (pers == 21) {
+                    if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 1, 48>(p, st);
+                    return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 1, 48>(p, st);
+                }
+                if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 48>(p, st);
+                return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 48>(p, st);
+            }
             if (pers >= 10 && pers <= 13 && (p.M - p.m_base) >= 256) {      // loader waves + 64 x 64 consumers, 256 x 128 tile, one block per CU
                 if (pers == 10) {
                     if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 4, 2>(p, st);
@@ -1553,6 +1971,11 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
             // the 128 x 128 data gradient stays on the per-tile kernel (default): its persistent form (two bf16 inputs per output, column
             // partials, 128 registers) measured 0.214 / 0.297 ms against 0.202 / 0.296 (14x14x256 / 28x28x128, batch 512)
         } else {
+        // N = 64: 256 x 64 tile, consumers 64 x 32 (56x56x64 at batch 512: forward 0.42 -> 0.37 -> 0.24 ms, data gradient 0.62 -> 0.51 -> 0.44)
+        if ((pers == 1 || (pers >= 20 && pers <= 22)) && launch16rw_ok(p, 256, 56)) {
+            if (epi == EPI_FWD) return launch16rw<256, 64, 4, 2, EPI_FWD, 4, 2, 56>(p, st);
+            return launch16rw<256, 64, 4, 2, EPI_DGRAD, 4, 2, 56>(p, st);
+        }
         if (pers == 4 || pers == 5) {
             if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 2, 6, 3, 3>(p, st);
             return launch16p<128, 64, 4, 2, EPI_DGRAD, 2, 6, 3, 3>(p, st);
