@@ -511,25 +511,65 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
 //   * dalpha / dbias column partials (EPI_DGRAD): a halving butterfly over the 32 row-lanes (16 shuffles per 16 columns), then the
 //     usual fixed-order sum over the row-waves through LDS.
 // Restrictions (launch16p_ok): no split-K, no merged stride-2 classes, alpha period a multiple of 8.
-// ---- epilogue of the swapped-operand kernels (igemm16p / igemm16r): accumulator lane = output row, registers = columns ----------
+// ---- epilogue of the swapped-operand kernels (igemm16p / igemm16r / igemm16rw): accumulator lane = output row, registers = columns ----
 // acc[i][j][r] of lane (li, lh): output row m0 + wm*TM*32 + i*32 + li (its offset: roff[i], < 0 beyond M), column n0 + wn*TN*32 + j*32 +
 // (r & 3) + 8 (r >> 2) + 4 lh.  v_permlane32_swap between the half-waves gives every lane 8 consecutive columns -- 16 bytes of a bf16 row
-// per load / store; no LDS patches.  colf = [alpha[BN], bias[BN]] of the tile's columns (LDS), red = [2][WM][BN] floats (LDS).  ein0 /
-// ein1: the bf16 epilogue inputs (shortcut | skip gradient, previous z) fetched ahead, used when the 16-bit tensors are given.  With
-// EPI_DGRAD and p.PA the function holds ONE block barrier (every wave of the block must call it, or match it).  Returns the number of
-// stores a wave issued (0 after the barrier form: count nothing).
+// per load / store; no LDS patches.  These kernels only take bf16-STORAGE launches (launch16p_ok): the tensors of the epilogue are the
+// four 16-bit pointers of EpiPtrs, fetched from the kernel arguments ONCE per kernel -- a `p.Z16` inside the unrolled blocks is a
+// scalar load and a wait each time (stamped: 11-13k cycles per 256 x 128 tile, alone on the chip as in a full round, before this).
+// colf = [alpha[BN], bias[BN]] of the tile's columns (LDS), red = [2][WM][BN] floats (LDS).  ein0 / ein1: the inputs fetched ahead.
+// With EPI_DGRAD and PA the function holds ONE block barrier (every wave of the block must call it, or match it).  Returns the number
+// of stores a wave issued (0 after the barrier form: count nothing).
+struct EpiPtrs {
+    unsigned short* o0;          // EPI_FWD: Z16 (may be null)     EPI_DGRAD: RAW16 (may be null)
+    unsigned short* o1;          //          Y16                              DZ16
+    const unsigned short* i0;    //          R16 (may be null)                ADD16 (may be null)
+    const unsigned short* i1;    //          --                               Zin16 (null: no activation gradient)
+    float* PA; float* PB;        // EPI_DGRAD: column partials (may be null)
+    int has_bias, act, N, prow0, m_base, M;
+};
+template <class T>
+__device__ __forceinline__ T* pin_sgpr(T* q) {                 // the pointer stays in scalar registers from here on
+    unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    asm volatile("" : "+s"(v));
+    return reinterpret_cast<T*>(v);
+}
+template <int EPI>
+__device__ __forceinline__ EpiPtrs epi_ptrs(const IgemmParams& p) {
+    EpiPtrs e;
+    if constexpr (EPI == EPI_FWD) {
+        e.o0 = pin_sgpr(p.Z16); e.o1 = pin_sgpr(p.Y16); e.i0 = pin_sgpr(p.R16); e.i1 = nullptr; e.PA = nullptr; e.PB = nullptr;
+        e.has_bias = p.bias != nullptr; e.act = p.alpha != nullptr;
+    } else {
+        e.o0 = pin_sgpr(p.RAW16); e.o1 = pin_sgpr(p.DZ16); e.i0 = pin_sgpr(p.ADD16); e.i1 = pin_sgpr(p.Zin16);
+        e.PA = pin_sgpr(p.PA); e.PB = pin_sgpr(p.PB);
+        e.has_bias = 0; e.act = p.Zin16 != nullptr;
+    }
+    e.N = p.N; e.prow0 = p.prow0; e.m_base = p.m_base; e.M = p.M;
+    return e;
+}
 template <int BM, int BN, int WM, int WN, int EPI>
-__device__ __forceinline__ int epilogue_rows(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&roff)[BM / WM / 32],
-                                             const u32x4 (&ein0)[BM / WM / 32][BN / WN / 32][2], const u32x4 (&ein1)[BM / WM / 32][BN / WN / 32][2],
+__device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&roff)[BM / WM / 32],
+                                             u32x4 (&ein0)[BM / WM / 32][BN / WN / 32][2], u32x4 (&ein1)[BM / WM / 32][BN / WN / 32][2],
                                              const float* colf, float* red, int mt, int n0, int tid, int wm, int wn, int li, int lh) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    int nst = 0;                                        // stores issued (per wave; wave-uniform)
+    // Every fetched-ahead input is "used" here, in straight-line code BEFORE the first store: the compiler then waits for the loads
+    // once, now.  Left to the first real use inside the conditional blocks below, its wait-count pass cannot tell how many stores were
+    // issued since and writes vmcnt(0) before each piece -- every piece then waits for the stores of the piece before it to drain
+    // (stamped: 11k cycles per 256 x 128 tile even alone on the chip).
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                asm volatile("" : "+v"(ein0[i][j][q]));
+                if constexpr (EPI == EPI_DGRAD) asm volatile("" : "+v"(ein1[i][j][q]));
+            }
     float csa[TN], csb[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) { csa[j] = 0.f; csb[j] = 0.f; }
-    bool act;
-    if constexpr (EPI == EPI_FWD) act = p.alpha != nullptr;
-    else act = p.Zin != nullptr || p.Zin16 != nullptr;
+    const bool act = ep.act;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int off = roff[i];
@@ -560,55 +600,37 @@ __device__ __forceinline__ int epilogue_rows(const IgemmParams& p, f32x16 (&acc)
                 for (int e = 0; e < 8; ++e) v[e] = a[8 * q + e];
                 const f32x4 al0 = *reinterpret_cast<const f32x4*>(colf + cl), al1 = *reinterpret_cast<const f32x4*>(colf + cl + 4);
                 const float al[8] = {al0[0], al0[1], al0[2], al0[3], al1[0], al1[1], al1[2], al1[3]};
-                auto ld8 = [&](const float* src, const u32x4& h, bool have16, float (&dst)[8]) {      // fp32 tensor or the prefetched bf16 piece
-                    if (have16) {
+                auto bf8 = [&](const u32x4& h, float (&dst)[8]) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { dst[2 * e] = __builtin_bit_cast(float, h[e] << 16); dst[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xffff0000u); }
-                    } else if (src && off >= 0) {
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + o), x1 = *reinterpret_cast<const f32x4*>(src + o + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { dst[e] = x0[e]; dst[4 + e] = x1[e]; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) dst[e] = 0.f;
-                    }
-                };
-                auto st32 = [&](float* dst, const float (&x)[8]) {
-                    if (dst && off >= 0) {
-                        *reinterpret_cast<f32x4*>(dst + o) = f32x4{x[0], x[1], x[2], x[3]};
-                        *reinterpret_cast<f32x4*>(dst + o + 4) = f32x4{x[4], x[5], x[6], x[7]};
-                    }
+                    for (int e = 0; e < 4; ++e) { dst[2 * e] = __builtin_bit_cast(float, h[e] << 16); dst[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xffff0000u); }
                 };
                 auto st16 = [&](unsigned short* dst, const float (&x)[8]) {
                     if (dst && off >= 0) *reinterpret_cast<u32x4*>(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
                 };
                 if constexpr (EPI == EPI_FWD) {
-                    if (p.bias) {
+                    if (ep.has_bias) {
                         const f32x4 b0 = *reinterpret_cast<const f32x4*>(colf + BN + cl), b1 = *reinterpret_cast<const f32x4*>(colf + BN + cl + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
                     }
-                    st32(p.Z, v);
-                    st16(p.Z16, v);
+                    st16(ep.o0, v);
                     if (act) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : al[e] * v[e];
                     }
                     float rs[8];
-                    ld8(p.R, ein0[i][j][q], p.R16 != nullptr, rs);
+                    bf8(ein0[i][j][q], rs);                      // zeros when there is no shortcut
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rs[e];
-                    st32(p.Y, v);
-                    st16(p.Y16, v);
+                    st16(ep.o1, v);
                 } else {
                     float ad[8], z[8];
-                    ld8(p.ADD, ein0[i][j][q], p.ADD16 != nullptr, ad);
+                    bf8(ein0[i][j][q], ad);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ad[e];
-                    st32(p.RAW, v);
-                    st16(p.RAW16, v);
+                    st16(ep.o0, v);
                     if (act) {
-                        ld8(p.Zin, ein1[i][j][q], p.Zin16 != nullptr, z);
+                        bf8(ein1[i][j][q], z);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const bool in = off >= 0;
@@ -620,12 +642,11 @@ __device__ __forceinline__ int epilogue_rows(const IgemmParams& p, f32x16 (&acc)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { sa16[8 * q + e] = 0.f; sb16[8 * q + e] = 0.f; }
                     }
-                    st32(p.DZ, v);
-                    st16(p.DZ16, v);
+                    st16(ep.o1, v);
                 }
             }
             if constexpr (EPI == EPI_DGRAD) {
-                if (p.PA && act) {
+                if (ep.PA && act) {
                     // halving butterfly over the 32 row-lanes: lane li ends with the sum of column 8 (c >> 3) ... c = li >> 1
                     auto fold = [&](float (&x)[16]) -> float {
                         float w8[8], w4[4], w2[2], w1;
@@ -645,11 +666,9 @@ __device__ __forceinline__ int epilogue_rows(const IgemmParams& p, f32x16 (&acc)
             }
         }
     }
-    if constexpr (EPI == EPI_FWD) {
-        nst = TM * TN * 2 * ((p.Z ? 2 : 0) + (p.Z16 ? 1 : 0) + (p.Y ? 2 : 0) + (p.Y16 ? 1 : 0));
-    } else {
-        nst = TM * TN * 2 * ((p.RAW ? 2 : 0) + (p.RAW16 ? 1 : 0) + (p.DZ ? 2 : 0) + (p.DZ16 ? 1 : 0));
-        if (p.PA) {    // column partials (dalpha, dbias) per 128 rows -- the planner's partial rows -- reduced later in a fixed order
+    int nst = TM * TN * 2 * ((ep.o0 ? 1 : 0) + (ep.o1 ? 1 : 0));      // stores issued (per wave; wave-uniform)
+    if constexpr (EPI == EPI_DGRAD) {
+        if (ep.PA) {    // column partials (dalpha, dbias) per 128 rows -- the planner's partial rows -- reduced later in a fixed order
             if ((li & 1) == 0) {
                 const int c16 = li >> 1;
 #pragma unroll
@@ -669,10 +688,10 @@ __device__ __forceinline__ int epilogue_rows(const IgemmParams& p, f32x16 (&acc)
                     sa += red[(h * WH + w) * BN + c];
                     sb += red[(WM + h * WH + w) * BN + c];
                 }
-                if (p.m_base + (mt * NH + h) * 128 < p.M) {
-                    const long o = (long)(p.prow0 + mt * NH + h) * p.N + n0 + c;
-                    p.PA[o] = sa;
-                    if (p.PB) p.PB[o] = sb;
+                if (ep.m_base + (mt * NH + h) * 128 < ep.M) {
+                    const long o = (long)(ep.prow0 + mt * NH + h) * ep.N + n0 + c;
+                    ep.PA[o] = sa;
+                    if (ep.PB) ep.PB[o] = sb;
                 }
             }
             nst = 0;          // the partials' stores are not counted: wait for everything
@@ -846,6 +865,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16p_kernel(const Igem
         if (++itap == NT) { itap = 0; ikc += BK16; }
     }
     const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
+    const EpiPtrs ep = epi_ptrs<EPI>(p);
     const int n_ein = !in16 ? 0 : TM * TN * 2 * (EPI == EPI_FWD ? 1 : (p.ADD16 ? 1 : 0) + (p.Zin16 ? 1 : 0));
     int stage = 0;
     // vmcnt retires in issue order: a K-step's tile has landed once at most as many operations are outstanding as were issued
@@ -856,6 +876,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16p_kernel(const Igem
     for (int k = 0; k < NQ; ++k) qn[k] = L;
     int carry = 0;
     int dbg_step = 0;
+    int n0_colf = -1;
 
     for (;;) {
         const int tile = xbase + idx;
@@ -884,16 +905,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16p_kernel(const Igem
         }
         // alpha / bias of the tile's columns -> LDS (read in the epilogue, nk barriers later; the previous tile's epilogue reads
         // are separated from this write by its closing barrier)
-        if (tid < BN) {
-            float al = 1.f, bi = 0.f;
-            if constexpr (EPI == EPI_FWD) {
-                if (p.alpha) al = p.alpha[n0 + tid];
-                if (p.bias) bi = p.bias[n0 + tid];
-            } else {
-                if (p.alpha) al = p.alpha[(n0 + tid) % p.amod];
+        // (only when the column tile changes: a load here waits, vmcnt being in order, for every store of the previous tile's epilogue)
+        if (n0 != n0_colf) {
+            if (tid < BN) {
+                float al = 1.f, bi = 0.f;
+                if constexpr (EPI == EPI_FWD) {
+                    if (p.alpha) al = p.alpha[n0 + tid];
+                    if (p.bias) bi = p.bias[n0 + tid];
+                } else {
+                    if (p.alpha) al = p.alpha[(n0 + tid) % p.amod];
+                }
+                colf[tid] = al;
+                colf[BN + tid] = bi;
             }
-            colf[tid] = al;
-            colf[BN + tid] = bi;
+            n0_colf = n0;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -936,10 +961,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16p_kernel(const Igem
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                             if constexpr (EPI == EPI_FWD) {
-                                if (p.R16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.R16 + o);
+                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
                             } else {
-                                if (p.ADD16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.ADD16 + o);
-                                if (p.Zin16) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(p.Zin16 + o);
+                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
+                                if (ep.i1) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i1 + o);
                             }
                         }
             }
@@ -962,10 +987,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16p_kernel(const Igem
         }
 
         // ---- epilogue (no LDS patches, no block barrier in the forward form) ----
-        const int nst = epilogue_rows<BM, BN, WM, WN, EPI>(p, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        const int nst = epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
         if (!hasnext) break;
-        // colf / red are rewritten at the top of the next tile: every wave must be done reading them
-        __syncthreads();
+        // colf is rewritten at the top of the next tile if its column tile differs: every wave must be done reading it
+        {
+            const int ntile = xbase + nidx;
+            if ((ntile - (ntile / ntn) * ntn) * BN != n0) __syncthreads();
+        }
         carry = nst;
         idx = nidx;
     }
@@ -1214,13 +1242,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16r_kernel(const
         }
     };
     const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
-    int stage = 0, kt = 0;
+    const EpiPtrs ep = epi_ptrs<EPI>(p);
+    int stage = 0, kt = 0, n0_colf = -1;
     for (;;) {
         const int tile = xbase + idx;
         const int mt = tile / ntn, nt_ = tile - mt * ntn;
         const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
         const int nidx = idx + per;
         const bool hasnext = nidx < xcnt;
+        if (n0 != n0_colf) ++kt;                       // a new column tile: the other half of colf2
         float* const colf = colf2 + (kt & 1) * 2 * BN;
         int roff[TM];
 #pragma unroll
@@ -1241,16 +1271,21 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16r_kernel(const
         }
         // alpha / bias of the tile's columns -> this tile's half of colf2 (read in the epilogue, nk barriers later; the other half
         // may still be read by waves in the previous tile's epilogue)
-        for (int c = tid; c < BN; c += 64 * NCW) {
-            float al = 1.f, bi = 0.f;
-            if constexpr (EPI == EPI_FWD) {
-                if (p.alpha) al = p.alpha[n0 + c];
-                if (p.bias) bi = p.bias[n0 + c];
-            } else {
-                if (p.alpha) al = p.alpha[(n0 + c) % p.amod];
+        // (only when the column tile changes -- with an even block stride it never does: a load here waits, vmcnt being in order, for
+        // every store of the previous tile's epilogue to drain)
+        if (n0 != n0_colf) {
+            for (int c = tid; c < BN; c += 64 * NCW) {
+                float al = 1.f, bi = 0.f;
+                if constexpr (EPI == EPI_FWD) {
+                    if (p.alpha) al = p.alpha[n0 + c];
+                    if (p.bias) bi = p.bias[n0 + c];
+                } else {
+                    if (p.alpha) al = p.alpha[(n0 + c) % p.amod];
+                }
+                colf[c] = al;
+                colf[BN + c] = bi;
             }
-            colf[c] = al;
-            colf[BN + c] = bi;
+            n0_colf = n0;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1280,10 +1315,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16r_kernel(const
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                             if constexpr (EPI == EPI_FWD) {
-                                if (p.R16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.R16 + o);
+                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
                             } else {
-                                if (p.ADD16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.ADD16 + o);
-                                if (p.Zin16) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(p.Zin16 + o);
+                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
+                                if (ep.i1) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i1 + o);
                             }
                         }
             }
@@ -1300,10 +1335,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16r_kernel(const
             }
             stage = stage + 1 == NST ? 0 : stage + 1;
         }
-        epilogue_rows<BM, BN, WM, WN, EPI>(p, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
         if (!hasnext) break;
         idx = nidx;
-        ++kt;
     }
 }
 
@@ -1416,6 +1450,18 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
     int idx = blockIdx.x >> 3;
     if (idx >= xcnt) return;
     const int nk = p.K / BK16, nch = nk / 9;             // nine taps per 64-channel chunk
+    // Blocks that have one tile less than the longest of their XCD start late, spread over most of a tile's time: the resident blocks
+    // of a launch otherwise run in phase, every epilogue of a round hits HBM at once (stamped: 15k cycles per 256 x 128 tile = the
+    // burst at HBM speed, MFMAs idle) -- staggered, the traffic of the many is spread under the K loops of the others, and the
+    // launch still ends with the blocks that had the extra tile.
+    if (!(p.ptiles_dbg & 8)) {
+        const int mine = (xcnt - idx + per - 1) / per, longest = (xcnt + per - 1) / per;
+        if (mine < longest) {
+            const unsigned long long wait = (unsigned long long)(((idx * 37) % per) * (long)nk * 1500 / per);
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const bool epi_barrier = EPI == EPI_DGRAD && p.PA != nullptr;
     unsigned long long* const stamps = DBG ? reinterpret_cast<unsigned long long*>(p.PW) : nullptr;
     int dbg_step = 0;
@@ -1533,7 +1579,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                     __builtin_amdgcn_sched_barrier(0);
                     const unsigned long long st3 = stamp_now();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (blockIdx.x == 0 && lw == 0 && dbg_step < 80 && lane == 0) {
+                    if (blockIdx.x == 0 && lw == 0 && dbg_step < 70 && lane == 0) {
                         unsigned long long* o = stamps + (1 * 80 + dbg_step) * 4;
                         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
                     }
@@ -1593,13 +1639,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
         }
     };
     const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
-    int stage = 0, kt = 0, gc = 0;
+    const EpiPtrs ep = epi_ptrs<EPI>(p);
+    int stage = 0, kt = 0, gc = 0, n0_colf = -1, kt_dbg = 0;
     for (;;) {
         const int tile = xbase + idx;
         const int mt = tile / ntn, nt_ = tile - mt * ntn;
         const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
         const int nidx = idx + per;
         const bool hasnext = nidx < xcnt;
+        if (n0 != n0_colf) ++kt;                       // a new column tile: the other half of colf2
         float* const colf = colf2 + (kt & 1) * 2 * BN;
         int roff[TM];
         const int s0_ = slot_of(m0);
@@ -1621,16 +1669,21 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             }
             roff[i] = off;
         }
-        for (int c = tid; c < BN; c += 64 * NCW) {
-            float al = 1.f, bi = 0.f;
-            if constexpr (EPI == EPI_FWD) {
-                if (p.alpha) al = p.alpha[n0 + c];
-                if (p.bias) bi = p.bias[n0 + c];
-            } else {
-                if (p.alpha) al = p.alpha[(n0 + c) % p.amod];
+        // (only when the column tile changes -- with an even block stride it never does: a load here waits, vmcnt being in order, for
+        // every store of the previous tile's epilogue to drain)
+        if (n0 != n0_colf) {
+            for (int c = tid; c < BN; c += 64 * NCW) {
+                float al = 1.f, bi = 0.f;
+                if constexpr (EPI == EPI_FWD) {
+                    if (p.alpha) al = p.alpha[n0 + c];
+                    if (p.bias) bi = p.bias[n0 + c];
+                } else {
+                    if (p.alpha) al = p.alpha[(n0 + c) % p.amod];
+                }
+                colf[c] = al;
+                colf[BN + c] = bi;
             }
-            colf[c] = al;
-            colf[BN + c] = bi;
+            n0_colf = n0;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1651,7 +1704,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             __builtin_amdgcn_s_barrier();
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
-            if (t == nk - 1 && in16) {
+            if (t == nk - 1 && in16) {                  // (three K-steps ahead measured no better: 0.172 / 0.156 vs 0.171 / 0.154 ms)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1660,9 +1713,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                             if constexpr (EPI == EPI_FWD) {
-                                if (p.R16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.R16 + o);
+                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
                             } else {
-                                if (p.ADD16) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(p.ADD16 + o);
+                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
                             }
                         }
             }
@@ -1681,7 +1734,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             if (++tau == 9) { tau = 0; ++gc; }
         }
         if constexpr (EPI == EPI_DGRAD) {          // the second input (previous z) only now: 64 more registers under the last K-step would spill
-            if (p.Zin16) {
+            if (ep.i1) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1689,14 +1742,27 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
-                            ein1[i][j][q] = *reinterpret_cast<const u32x4*>(p.Zin16 + o);
+                            ein1[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i1 + o);
                         }
             }
         }
-        epilogue_rows<BM, BN, WM, WN, EPI>(p, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        unsigned long long se0 = 0;
+        if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); se0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+        epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        if constexpr (DBG) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long se1 = stamp_now();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long se2 = stamp_now();
+            __builtin_amdgcn_sched_barrier(0);
+            if (blockIdx.x == 0 && wid == 0 && lane == 0 && kt_dbg < 4) {
+                unsigned long long* o = stamps + (1 * 80 + 70 + kt_dbg) * 4;       // rows 70.. of the loader's table (the loader stops at 80 steps)
+                o[0] = se0; o[1] = se1; o[2] = se2; o[3] = 1;
+            }
+            ++kt_dbg;
+        }
         if (!hasnext) break;
         idx = nidx;
-        ++kt;
     }
 }
 
@@ -1776,6 +1842,11 @@ hipError_t launch16rw(const IgemmParams& p, hipStream_t st) {
                 sp += (double)(h[i * 4] - h[(i - 1) * 4]); ++n;
             }
             if (n) fprintf(stderr, "[stamp]  loader wave 0:   per K-step period %.0f = vmcnt wait %.0f + barrier %.0f + issue %.0f + rest\n", sp / n, sw / n, sbb / n, si / n);
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long* e = host + (80 + 70 + k) * 4;
+                if (e[3] == 1) fprintf(stderr, "[stamp]  consumer wave 0, tile %d: epilogue_rows %.0f ticks, then %.0f until its stores have drained\n", k,
+                                       (double)(e[1] - e[0]), (double)(e[2] - e[1]));
+            }
         }
         return hipGetLastError();
     }
