@@ -46,6 +46,14 @@ def bf16s_mode():
     (512, 14, 14, 128, 128, 3, 1), (40, 56, 56, 64, 64, 3, 1),   # the LDS-DMA kernel's 128x128 / 128x64 tiles (igemm16.hip)
     (126, 28, 28, 128, 128, 3, 1), (130, 28, 28, 64, 128, 3, 2)])
 def test_s16_entry_points_are_the_rounding_of_the_copies_path(bf16s_mode, n, h, w, cin, cout, k, stride):
+    """The storage entry points compute what the copies path computes and round it once.  Bit for bit where both launches run on the
+    same kernel; where the planner sends the storage launch to another kernel of the family (the persistent / window kernels of
+    igemm16.hip, an unsplit launch instead of split-K) the fp32 sums are taken in another order, so a stored value may sit on the
+    other side of a rounding boundary: it must still be within half a bf16 step (+ fp32 noise) of the copies path's fp32 value."""
+    def rounds(t16, ref32):
+        err = (_f(t16).double() - ref32.double()).abs()
+        lim = ref32.double().abs() * 2.0 ** -8 + 2e-5 * float(ref32.abs().max())
+        return bool((err <= lim).all())
     g = torch.Generator(device='cuda').manual_seed(n + cin + cout + k)
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
     x16 = _bits(torch.randn(n, h, w, cin, device='cuda', generator=g))
@@ -68,11 +76,12 @@ def test_s16_entry_points_are_the_rounding_of_the_copies_path(bf16s_mode, n, h, 
     _lib.call('fte_conv2d_fwd16', x16, w16t, bias, alpha, _f(res16), z1, y1, y16c, n, h, w, cin, cout, k, stride, buf, nb, st)
     z16 = torch.empty(shp_o, **i16); y16 = torch.empty(shp_o, **i16)
     _lib.call('fte_conv2d_fwd_s16', x16, w16t, bias, alpha, res16, z16, y16, None, None, n, h, w, cin, cout, k, stride, buf, nb, st)
-    assert torch.equal(y16, y16c) and torch.equal(y16, _bits(y1)) and torch.equal(z16, _bits(z1))
+    assert torch.equal(y16c, _bits(y1))
+    assert rounds(y16, y1) and rounds(z16, z1)
     # ... and with the optional fp32 outputs (the last conv layer of SphereNet), no residual, no z
     z2 = torch.empty(shp_o, device='cuda'); y2 = torch.empty(shp_o, device='cuda'); y16b = torch.empty(shp_o, **i16)
     _lib.call('fte_conv2d_fwd_s16', x16, w16t, bias, alpha, res16, None, y16b, z2, y2, n, h, w, cin, cout, k, stride, buf, nb, st)
-    assert torch.equal(y16b, y16) and torch.equal(z2, z1) and torch.equal(y2, y1)
+    assert torch.equal(y16b, _bits(y2)) and torch.equal(z2, z1) and torch.equal(y2, y1)      # fp32 outputs: the copies path's kernel
     # ---- data gradient + PReLU gradient of the producing layer
     raw1 = torch.empty(shp_i, device='cuda'); dx1 = torch.empty(shp_i, device='cuda'); dx16c = torch.empty(shp_i, **i16)
     da1 = torch.empty(cin, device='cuda'); db1 = torch.empty(cin, device='cuda')
@@ -80,7 +89,8 @@ def test_s16_entry_points_are_the_rounding_of_the_copies_path(bf16s_mode, n, h, 
     raw16 = torch.empty(shp_i, **i16); dx16 = torch.empty(shp_i, **i16)
     da2 = torch.empty(cin, device='cuda'); db2 = torch.empty(cin, device='cuda')
     _lib.call('fte_conv2d_dgrad_s16', dz16, w16, add16, zp16, alp, raw16, dx16, da2, db2, n, h, w, cin, cout, k, stride, buf, nb, st)
-    assert torch.equal(raw16, _bits(raw1)) and torch.equal(dx16, dx16c) and torch.equal(dx16, _bits(dx1))
+    assert torch.equal(dx16c, _bits(dx1))
+    assert rounds(raw16, raw1) and rounds(dx16, dx1)
     # dalpha / dbias are fp32 sums over all pixels: the storage launch may run on another kernel of the family (igemm16rw: per-tile
     # partials through a lane butterfly) than the copies launch, i.e. in another -- equally fixed -- summation order
     for got, ref in ((da2, da1), (db2, db1)):
@@ -90,7 +100,7 @@ def test_s16_entry_points_are_the_rounding_of_the_copies_path(bf16s_mode, n, h, 
     dx16p = torch.empty(shp_i, **i16); dxp = torch.empty(shp_i, device='cuda')
     _lib.call('fte_conv2d_dgrad_s16', dz16, w16, None, None, None, None, dx16p, None, None, n, h, w, cin, cout, k, stride, buf, nb, st)
     _lib.call('fte_conv2d_dgrad16', dz16, w16, None, None, None, None, dxp, None, None, None, n, h, w, cin, cout, k, stride, buf, nb, st)
-    assert torch.equal(dx16p, _bits(dxp))
+    assert rounds(dx16p, dxp)
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,stride', [(3, 16, 16, 3, 64, 2), (2, 13, 9, 1, 64, 2), (2, 112, 112, 3, 64, 2)])

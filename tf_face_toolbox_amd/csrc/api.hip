@@ -63,6 +63,9 @@ struct RowPlan {
 bool g_plan16 = false;
 struct Plan16 { bool prev; Plan16() : prev(g_plan16) { g_plan16 = true; } ~Plan16() { g_plan16 = prev; } };
 inline bool plan_bf16() { return g_plan16 || igemm_get_bf16(); }
+// ... and a storage-only launch (bf16 tensors in the epilogue, no fp32 outputs): the persistent kernels of igemm16.hip take it
+bool g_plan_s16 = false;
+struct PlanS16 { bool prev; explicit PlanS16(bool on) : prev(g_plan_s16) { g_plan_s16 = on; } ~PlanS16() { g_plan_s16 = prev; } };
 
 inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only = false) {
     RowPlan r;
@@ -93,6 +96,11 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     const long ntn = N / bn, MT = (M + bm - 1) / bm, T = MT * ntn, ksteps = (K + 31) / 32;
     r.main_tile = big;
     long tail_rows = 0;
+    // bf16-STORAGE launches (fte_conv2d_{fwd,dgrad}_s16 without fp32 outputs) with at least a round of the window kernel's 256-row
+    // tiles stay ONE unsplit launch: resident loader / consumer blocks (igemm16rw) beat split-K + fix-up there -- 7x7x512 at batch 512:
+    // forward 0.186 -> 0.134 ms, data gradient 0.214 -> 0.148.  FTE_PLAN_UNSPLIT16=0 restores the split plan.
+    static const bool unsplit16 = !(getenv("FTE_PLAN_UNSPLIT16") && atoi(getenv("FTE_PLAN_UNSPLIT16")) == 0);
+    if (unsplit16 && g_plan_s16 && !small_only && bm == 128 && T >= 512 && T < SLOTS) { r.main_rows = M; r.main_mtiles = MT; return r; }
     if (T >= SLOTS) {
         const long full = T / SLOTS * SLOTS;
         // A leftover fraction of a round used to go to a separate small-tile TAIL launch (mode 1 below).  Measured again at the end of
@@ -318,6 +326,7 @@ int fte_conv2d_fwd_s16(const uint16_t* x16, const uint16_t* w16t, const float* b
                        void* ws, size_t ws_bytes, void* stream) {
     if (!y16 || (res16 && ((uintptr_t)res16 & 15))) return FTE_EINVAL;
     Plan16 guard;
+    PlanS16 storage(!z32 && !y32);
     return conv2d_fwd_impl(x16, w16t, true, bias, alpha, nullptr, z32, y32, y16, n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream, res16, z16);
 }
 
@@ -519,6 +528,7 @@ int fte_conv2d_dgrad_s16(const uint16_t* dz16, const uint16_t* w16, const uint16
                          int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream) {
     if (!dzprev16) return FTE_EINVAL;
     Plan16 guard;
+    PlanS16 storage(true);
     return conv2d_dgrad_impl(dz16, w16, true, nullptr, nullptr, alpha_prev, nullptr, nullptr, dzprev16, dalpha_prev, dbias_prev,
                              n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream, addin16, zprev16, raw16);
 }

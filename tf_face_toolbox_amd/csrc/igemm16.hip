@@ -1986,10 +1986,10 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
                 if (epi == EPI_FWD) return launch16p<256, 128, 4, 2, EPI_FWD, 3, 2, 1>(p, st);
                 return launch16p<256, 128, 4, 2, EPI_DGRAD, 3, 2, 1>(p, st);
             }
-            // default (pers == 1): the window kernel where it applies -- forward of every 3x3 / stride-1 layer, data gradient up to N = 128
-            // (batch 512, ms, per-tile kernel -> igemm16p -> igemm16rw: forward 28x28x128 0.224 -> 0.208 -> 0.170, 14x14x256 0.166 -> 0.156
-            // -> 0.145; data gradient 28x28x128 0.307 -> . -> 0.283, 14x14x256 0.205 -> 0.214 -> 0.206: stays on the per-tile kernel)
-            if ((pers == 1 || (pers >= 20 && pers <= 22)) && launch16rw_ok(p, 256, 48) && (pers != 1 || epi == EPI_FWD || p.N <= 128)) {
+            // default (pers == 1): the window kernel where it applies -- every 3x3 / stride-1 layer, forward and data gradient (batch 512,
+            // ms on one box, per-tile kernel -> igemm16rw: forward 28x28x128 0.220 -> 0.166, 14x14x256 0.161 -> 0.145; data gradient
+            // 28x28x128 0.293 -> 0.229, 14x14x256 0.198 -> 0.178)
+            if ((pers == 1 || (pers >= 20 && pers <= 22)) && launch16rw_ok(p, 256, 48)) {
                 if (pers == 21) {
                     if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 1, 48>(p, st);
                     return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 1, 48>(p, st);
