@@ -100,7 +100,11 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     // tiles stay ONE unsplit launch: resident loader / consumer blocks (igemm16rw) beat split-K + fix-up there -- 7x7x512 at batch 512:
     // forward 0.186 -> 0.134 ms, data gradient 0.214 -> 0.148.  FTE_PLAN_UNSPLIT16=0 restores the split plan.
     static const bool unsplit16 = !(getenv("FTE_PLAN_UNSPLIT16") && atoi(getenv("FTE_PLAN_UNSPLIT16")) == 0);
-    if (unsplit16 && g_plan_s16 && !small_only && bm == 128 && T >= 512 && T < SLOTS) { r.main_rows = M; r.main_mtiles = MT; return r; }
+    if (unsplit16 && g_plan_s16 && !small_only) {
+        const int t16 = N % 128 == 0 ? TILE_128x128 : TILE_128x64;
+        const long m16 = (M + 127) / 128, n16 = (M + 127) / 128 * (N / (N % 128 == 0 ? 128 : 64));
+        if (n16 >= 512 && n16 < SLOTS) { r.main_tile = t16; r.main_rows = M; r.main_mtiles = m16; return r; }
+    }
     if (T >= SLOTS) {
         const long full = T / SLOTS * SLOTS;
         // A leftover fraction of a round used to go to a separate small-tile TAIL launch (mode 1 below).  Measured again at the end of

@@ -1425,13 +1425,17 @@ hipError_t launch16r(const IgemmParams& p, hipStream_t st) {
 //     for a step's B tile also waits for its window.
 // Fragment addresses: row s = slot - window start + tap shift, chunk q of it at slot q ^ ((s >> 1) & 7) (the writer's swizzle is keyed
 // by the same window-relative slot); the four 16-deep sub-steps are a0 ^ (ks << 5).
-template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int DBG = 0>
+// KS = K-steps per block barrier.  KS = 1: three B stages, the barrier of every K-step.  KS = 2 (stamped at KS = 1: of a 1700-cycle
+// K-step the two consumer waves of a SIMD fill the MFMA pipe for ~1050, the rest is the barrier -- waiting for the slowest of twelve
+// waves -- and loop overhead): four B stages, consumers run two K-steps (32 MFMAs per wave) between barriers, loaders fill the
+// other two stages meanwhile; the window shrinks to the layers' real need (WCAP = 45) to make room in the 160 KB.
+template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int KS = 1, int DBG = 0>
 __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(const IgemmParams p) {
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NCW = WM * WN, NSTB = 3;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NCW = WM * WN, NSTB = KS == 1 ? 3 : 2 * KS;
     constexpr int KB = BN / 8 / NLW;                    // B pieces per loader wave and K-step
-    constexpr int KW = WCAP / NLW;                      // window pieces (8 slots x 128 B) per loader wave; WCAP = the window's capacity
-    constexpr int WPS = (KW + 5) / 6;                   // window pieces a loader issues per K-step (all of them within a chunk's first six)
-    static_assert((BN / 8) % NLW == 0 && WCAP % NLW == 0 && (KW + WPS - 1) / WPS <= 9 - NSTB, "pieces per loader");
+    constexpr int KW = (WCAP + NLW - 1) / NLW;          // window pieces (8 slots x 128 B) per loader wave; WCAP = the window's capacity
+    constexpr int WPS = KS == 1 ? (KW + 5) / 6 : (KW + 2) / 3;      // window pieces a loader issues per barrier interval: all of them early in a chunk
+    static_assert((BN / 8) % NLW == 0 && (KS == 1 || KS == 2) && (KS == 2 || (KW + WPS - 1) / WPS <= 9 - NSTB), "pieces per loader");
     constexpr int WINB = WCAP * 1024, BSTAGE = BN * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     char* const bring = smem16 + 2 * WINB;
@@ -1547,7 +1551,60 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
         setup_b(xbase + idx);
         for (int f = 0; f < KW; f += WPS) issue_w(0, 0, f);
 #pragma unroll
-        for (int s0 = 0; s0 < NSTB - 1; ++s0) issue_b(s0);
+        for (int s0 = 0; s0 < (KS == 1 ? NSTB - 1 : KS); ++s0) issue_b(s0);
+        if constexpr (KS == 2) {
+            // two K-steps per barrier: interval I reads stages 2 (I & 1), 2 (I & 1) + 1; its B tiles were issued during interval I - 1
+            // BEFORE that interval's window pieces, which are all that may stay in flight at the barrier.  The window of the chunk
+            // after chunk c goes out in three intervals from the first interval that STARTS inside c (an interval that only ends in c
+            // still reads the buffer being replaced), i.e. at least a whole interval before the B tiles of the interval that needs it.
+            int wprev = 0, half = 0, gc = 0;
+            for (;;) {
+                const int nidx = idx + per;
+                const bool hasnext = nidx < xcnt;
+                int wfrom = KW, wbuf = 0, wkc = 0;
+                bool wnext = false, wstart = false;
+                for (int t = 0, tau = 0, ch = 0; t < nk; t += 2) {
+                    // a chunk whose first K-step is this interval's first: its successor's window may start now; one that starts at the
+                    // second K-step: next interval
+                    if (tau == 0 || wstart) {
+                        wfrom = 0; wbuf = (gc + 1) & 1; wstart = false;
+                        if (ch + 1 < nch) { wnext = true; wkc = (ch + 1) * BK16; }
+                        else if (hasnext) { wnext = true; wkc = 0; setup_w(xbase + nidx); }
+                        else wnext = false;
+                    }
+                    const bool fillb = t + 2 < nk || hasnext;
+                    if (t + 2 == nk && hasnext) { setup_b(xbase + nidx); btap = 0; bkc = 0; }
+                    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+                    if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                    wait_vmcnt_upto(wprev);
+                    if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st2 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+                    int nw = 0;
+                    if (fillb) { issue_b(2 * (half ^ 1)); issue_b(2 * (half ^ 1) + 1); }
+                    if (wnext && wfrom < KW) { nw = issue_w(wbuf, wkc, wfrom); wfrom += WPS; }
+                    if constexpr (DBG) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const unsigned long long st3 = stamp_now();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (blockIdx.x == 0 && lw == 0 && dbg_step < 70 && lane == 0) {
+                            unsigned long long* o = stamps + (1 * 80 + dbg_step) * 4;
+                            o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+                        }
+                        ++dbg_step;
+                    }
+                    wprev = nw;
+                    half ^= 1;
+                    tau += 2;
+                    if (tau >= 9) { tau -= 9; ++ch; ++gc; wstart = tau == 1; }      // tau == 1: the new chunk began at this interval's second K-step
+                }
+                if (epi_barrier) __builtin_amdgcn_s_barrier();
+                if (!hasnext) break;
+                idx = nidx;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         // vmcnt retires in issue order: B(t) was issued in step t - 2 BEFORE that step's window pieces; younger than it are those
         // window pieces and everything of step t - 1
         int w2 = 0, b1 = KB, w1 = 0;                   // window pieces of step t - 2, B and window pieces of step t - 1
@@ -1702,7 +1759,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
         for (int t = 0, tau = 0; t < nk; ++t) {
             unsigned long long st0 = 0, st1 = 0;
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
-            __builtin_amdgcn_s_barrier();
+            if (KS == 1 || (t & 1) == 0) __builtin_amdgcn_s_barrier();
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             if (t == nk - 1 && in16) {                  // (three K-steps ahead measured no better: 0.172 / 0.156 vs 0.171 / 0.154 ms)
 #pragma unroll
@@ -1779,16 +1836,16 @@ static bool launch16rw_ok(const IgemmParams& p, int BM, int wcap) {
     return (span + 7) / 8 <= wcap;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP>
+template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int KS = 1>
 hipError_t launch16rw(const IgemmParams& p, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
     IgemmParams q = p;
     q.ptiles = mt * nt;
     static const int dbg = getenv("FTE_IGEMM16_DBG") ? atoi(getenv("FTE_IGEMM16_DBG")) : 0;
     q.ptiles_dbg = dbg;
-    const size_t lds = (size_t)2 * WCAP * 1024 + (size_t)3 * BN * ROWB + (size_t)(4 * BN + 2 * WM * BN) * sizeof(float);
-    auto kern = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP>;
-    if (igemm_prof_on()) { const int ta[9] = {BM, BN, WM, WN, EPI, NLW, PFD, WCAP, 0}; igemm_note_symbol("igemm16rw_kernel", ta, 9); }
+    const size_t lds = (size_t)2 * WCAP * 1024 + (size_t)(KS == 1 ? 3 : 2 * KS) * BN * ROWB + (size_t)(4 * BN + 2 * WM * BN) * sizeof(float);
+    auto kern = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS>;
+    if (igemm_prof_on()) { const int ta[10] = {BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS, 0}; igemm_note_symbol("igemm16rw_kernel", ta, 10); }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1808,7 +1865,7 @@ hipError_t launch16rw(const IgemmParams& p, hipStream_t st) {
     constexpr int THREADS = 64 * (WM * WN + NLW);
     static const bool stamps = getenv("FTE_IGEMM16_STAMP") != nullptr;
     if (stamps) {
-        auto dk = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, 1>;
+        auto dk = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS, 1>;
         static unsigned long long* buf = nullptr;
         const size_t nb = 2 * 80 * 4 * sizeof(unsigned long long);
         if (!buf) {
@@ -1989,6 +2046,10 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
             // default (pers == 1): the window kernel where it applies -- every 3x3 / stride-1 layer, forward and data gradient (batch 512,
             // ms on one box, per-tile kernel -> igemm16rw: forward 28x28x128 0.220 -> 0.166, 14x14x256 0.161 -> 0.145; data gradient
             // 28x28x128 0.293 -> 0.229, 14x14x256 0.198 -> 0.178)
+            if ((pers == 1 || pers == 20) && (p.K / BK16) % 2 == 0 && launch16rw_ok(p, 256, 45)) {      // two K-steps per barrier
+                if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 45, 2>(p, st);
+                return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 45, 2>(p, st);
+            }
             if ((pers == 1 || (pers >= 20 && pers <= 22)) && launch16rw_ok(p, 256, 48)) {
                 if (pers == 21) {
                     if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 1, 48>(p, st);
