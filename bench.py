@@ -54,7 +54,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3                    # MI355X_MICROARCH.md, "Peak FP
 BF16_MFMA_PEAK_TFLOPS = 2500.0                   # same table, "Peak BF16/FP16 MFMA" (dense)
 HBM_PEAK_GBPS = 8000.0                           # same table, HBM3E peak (spec)
 LR = 1e-4
-TILES = {0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64', 4: '192,64', 5: '64,64 (1 wave)', 6: '64,64 (2 waves)'}   # igemm.h's TILE_* enum
+TILES = {0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64', 4: '192,64', 5: '64,64 (1 wave)', 6: '64,64 (2 waves)',   # igemm.h's TILE_* enum
+         7: '9 taps x 32|64 cin x 256|128 cout, resident (wgrad16.hip)'}
 
 
 def kernel_src_sha():

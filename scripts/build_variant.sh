@@ -12,5 +12,5 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 $HIPCC $FLAGS $EXTRA -c "$HERE/igemm.hip" -o "$OBJ/igemm.o" &
 $HIPCC $FLAGS $EXTRA -c "$HERE/igemm16.hip" -o "$OBJ/igemm16.o" &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfte_$NAME.so" "$OBJ/igemm.o" "$OBJ/igemm16.o" "$HERE/obj/kernels.o" "$HERE/obj/layers.o" "$HERE/obj/api.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfte_$NAME.so" "$OBJ/igemm.o" "$OBJ/igemm16.o" "$HERE/obj/wgrad16.o" "$HERE/obj/kernels.o" "$HERE/obj/layers.o" "$HERE/obj/api.o"
 echo "built $OUT/libfte_$NAME.so"

@@ -174,7 +174,7 @@ def test_bf16_source_entry_points_equal_the_operand_mode(bf16_mode, n, h, w, cin
     assert torch.equal(dx16, _bf16_bits(dx1))
     dw1 = torch.empty_like(wt)
     _lib.call('fte_conv2d_wgrad16', x16, dz16, dw1, n, h, w, cin, cout, k, stride, buf, nb, st)
-    assert torch.equal(dw1, dw0)
+    _close(dw1, dw0, 'dw')        # same bf16 products, fp32 sums; the resident kernel (wgrad16.hip) takes them in another fixed order
 
 
 @pytest.mark.parametrize('mode', ['8', '1'])

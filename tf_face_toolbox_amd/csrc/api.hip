@@ -8,6 +8,7 @@
 
 #include "../../include/fte.h"
 #include "igemm.h"
+#include "wgrad16.h"
 #include "kernels.h"
 #include "layers.h"
 
@@ -586,7 +587,16 @@ size_t fte_conv2d_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
     if (n <= 0 || cin <= 0 || cin % 4 || cout <= 0 || cout % 64) return 0;
     int tile, splits, kchunk, K;
     wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
-    return (splits > 1 ? (size_t)splits * ksize * ksize * cin * cout * sizeof(float) : 0) + SCRATCH_BYTES;
+    size_t need = splits > 1 ? (size_t)splits * ksize * ksize * cin * cout * sizeof(float) : 0;
+    if (ksize == 3 && stride == 1) {                 // the resident kernel's slot-range slabs (bf16 sources; wgrad16.hip)
+        Wgrad16Params g;
+        int cfg = 0;
+        if (wgrad16_plan(n, h, wd, cin, cout, &g, &cfg) && g.S > 1) {
+            const size_t gneed = (size_t)g.S * g.slab * sizeof(float);
+            if (gneed > need) need = gneed;
+        }
+    }
+    return need + SCRATCH_BYTES;
 }
 size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
     return fte_conv2d_wgrad_ws_bytes(n, h, wd, cin, cout, 3, stride);
@@ -599,6 +609,30 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     int tile, splits, kchunk, K;
     wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
+    if (src16 && ksize == 3 && stride == 1) {       // the resident kernel (wgrad16.hip): all nine taps per block, LDS-DMA, slot-range splits
+        Wgrad16Params g;
+        int cfg = 0;
+        if (wgrad16_plan(n, h, wd, cin, cout, &g, &cfg)) {
+            const size_t gneed = g.S > 1 ? (size_t)g.S * g.slab * sizeof(float) : 0;
+            const size_t xb = (size_t)n * h * wd * cin * 2, db = (size_t)n * h * wd * cout * 2;
+            if ((!gneed || (ws && ws_bytes >= gneed)) && xb < (1ull << 31) && db < (1ull << 31)) {
+                g.x = (const unsigned short*)x; g.dz = (const unsigned short*)dz;
+                g.out = g.S > 1 ? (float*)ws : dw;
+                g.x_bytes = (unsigned)xb; g.dz_bytes = (unsigned)db;
+                for (int r = 0; r < 3; ++r)
+                    for (int s2 = 0; s2 < 3; ++s2) { g.dh[r * 3 + s2] = r - 1; g.dw[r * 3 + s2] = s2 - 1; }
+                const int sig[5] = {AL_KM, BL_KN, EPI_FWD, 7, g.S};              // tile id 7: the resident kernel (bench.py TILES)
+                const double rows = 9.0 * cin;
+                const int h = igemm_prof_begin(sig, (int)rows, cout, K, 2.0 * rows * cout * (double)K, (double)xb + (double)db + (double)g.S * g.slab * 4.0,
+                                               (hipStream_t)stream);
+                hipError_t e = wgrad16_launch(g, cfg, (hipStream_t)stream);
+                igemm_prof_end(h, cfg == 0 ? "wgrad16_kernel<32,256,3>" : "wgrad16_kernel<64,128,3>", (hipStream_t)stream);
+                if (e != hipSuccess) return (int)e;
+                if (g.S > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, g.S, g.slab, 1, 1.f, nullptr, (hipStream_t)stream));
+                return FTE_OK;
+            }
+        }
+    }
     const size_t need = splits > 1 ? (size_t)splits * ksize * ksize * cin * cout * sizeof(float) : 0;
     if (need && (!ws || ws_bytes < need)) return FTE_EWORKSPACE;
     IgemmParams p;

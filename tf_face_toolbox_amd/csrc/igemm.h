@@ -85,6 +85,9 @@ bool igemm_prof_on();
 // arguments, spelled as rocprofv3 --kernel-trace prints them (minus blanks), e.g. "igemm_kernel<128,128,2,2,1,0,0,0>"
 void igemm_note_symbol(const char* family, const int* targs, int ntargs);
 hipError_t igemm_prof_get_name(int i, char* buf, int buflen);
+// records for kernels launched outside igemm_launch (wgrad16.hip): sig5 = {al, bl, epi, tile id, splits}
+int igemm_prof_begin(const int* sig5, int rows, int n, int k, double flops, double bytes, hipStream_t st);
+void igemm_prof_end(int handle, const char* sym, hipStream_t st);
 int igemm_prof_count();
 hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms);
 hipError_t igemm_prof_get_shape(int i, int* mnk, double* bytes);      // GEMM shape {rows, N, K} and algorithmic bytes of record i

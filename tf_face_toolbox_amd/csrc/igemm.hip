@@ -1200,6 +1200,25 @@ hipError_t igemm_launch(const IgemmParams& p, int al, int bl, int epi, int tile,
     return e;
 }
 
+// launch records for kernels outside the family's dispatcher (wgrad16.hip): begin returns a handle (< 0: records are off)
+int igemm_prof_begin(const int* sig5, int rows, int n, int k, double flops, double bytes, hipStream_t st) {
+    if (!g_prof_on) return -1;
+    ProfRec r;
+    for (int i = 0; i < 5; ++i) r.sig[i] = sig5[i];
+    r.mnk[0] = rows; r.mnk[1] = n; r.mnk[2] = k;
+    r.flops = flops; r.bytes = bytes; r.sym[0] = 0;
+    if (hipEventCreate(&r.e0) != hipSuccess) return -1;
+    if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return -1; }
+    (void)hipEventRecord(r.e0, st);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+void igemm_prof_end(int handle, const char* sym, hipStream_t st) {
+    if (handle < 0 || handle >= (int)g_prof.size()) return;
+    (void)hipEventRecord(g_prof[handle].e1, st);
+    snprintf(g_prof[handle].sym, sizeof(g_prof[handle].sym), "%s", sym);
+}
+
 hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st) {
     if (epi == EPI_FWD) return fixup_tile<EPI_FWD>(p, tile, splits, st);
     return fixup_tile<EPI_DGRAD>(p, tile, splits, st);

@@ -1,0 +1,307 @@
+// wgrad16.hip -- filter gradient of a 3x3 / stride-1 conv from bf16 x and dz (bf16 storage mode), resident blocks, LDS-DMA staging.
+//
+//   dW[tap][cin][cout] = sum over output pixels p of  x[p + tap][cin] * dz[p][cout]                (fp32 accumulate)
+//
+// The register-staged filter gradient of igemm.hip (BF = 2) runs one (tap, 128 cin) x 128 cout tile per block: every tap of a layer
+// re-reads the same dz rows and the same x rows from L2 (64 FLOP per staged byte), global -> VGPR -> LDS, 0.25 of the bf16 peak.
+// Here a block owns (CT cin) x (BN cout) x ALL NINE TAPS for one range of the reduction, and the reduction index is the PADDED
+// SLOT of igemm16rw's window (slot(img, y, x) = img (H+1)(W+1) + (y+1)(W+1) + x + 1; pad slots are zero rows, LDS-DMA'd from an
+// out-of-range offset), so that tap (dh, dw) is the same dz rows against x rows shifted by dh (W+1) + dw:
+//   * a K-piece is 64 slots: dz tile [64 slots][BN] and x window [64 + 2 (W+1) + 2 slots][CT], both row-contiguous in memory and
+//     DMA'd to LDS AS THEY ARE (1-KiB pieces); the 32x32x16 operands (8 consecutive slots of one channel per lane) come back through
+//     ds_read_b64_tr_b16 (the lane map of igemm.hip's frag_tr); 9 * (CT / 32) + BN / 32 fragments feed 9 * (CT / 32) * (BN / 32)
+//     MFMAs per 16 slots -- 214 FLOP per staged byte;
+//   * twelve waves, each 3 taps x 2 column blocks (six 32x32 accumulators), 5 fragments per 6 MFMAs; every wave also issues its share
+//     of the next-but-one K-piece's DMA pieces (the traffic is light: ~40 pieces per 864 MFMAs); three stages, one barrier per K-piece;
+//   * split over the slot range (S ranges -> S partial slabs, summed in fixed order by the caller's reduction as before).
+// The zero rows cost (H+1)(W+1) / (H W) - 1 extra MFMA work (15 % at 14x14, 7 % at 28x28).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "igemm_dev.h"
+#include "wgrad16.h"
+
+#ifndef WG_INTERLEAVE
+#define WG_INTERLEAVE 0
+#endif
+#ifndef WG_PFD
+#define WG_PFD 1
+#endif
+
+namespace {
+
+using namespace igemm_dev;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef short s16x4t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    if (n >= 4) wait_vmcnt<4>(); else if (n >= 3) wait_vmcnt<3>(); else if (n >= 2) wait_vmcnt<2>(); else if (n >= 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+}
+
+constexpr int KP = 64;                 // slots per K-piece
+constexpr int NWAVES = 12;
+
+// CT = input channels per block (32 | 64), BN = output channels per block; (CT / 32) * (BN / 32) must be 8: 72 accumulator blocks
+template <int CT, int BN, int NST>
+__global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Params p) {
+    constexpr int NCB = CT / 32, NNB = BN / 32;
+    static_assert(NCB * NNB == 8 && NST >= 3, "72 accumulator blocks over twelve waves");
+    constexpr int DZROW = BN * 2, XROW = CT * 2;                 // bytes per row of the two LDS images
+    constexpr int DZ_RPP = 1024 / DZROW, X_RPP = 1024 / XROW;    // rows per 1-KiB DMA piece
+    constexpr int DZ_PIECES = KP / DZ_RPP;
+    constexpr int XCAP = 128;                                    // window rows (64 + 2 (W + 1) + 2 <= 128: W <= 30)
+    constexpr int X_PIECES = XCAP / X_RPP;
+    constexpr int PIECES = DZ_PIECES + X_PIECES;
+    constexpr int MAXP = (PIECES + NWAVES - 1) / NWAVES;         // DMA pieces per wave and K-piece
+    constexpr int STAGE = KP * DZROW + XCAP * XROW;
+    static_assert(MAXP <= KP / 16, "one DMA piece per 16-deep step");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wid >> 2, wq = wid & 3;                       // taps 3 tg .. 3 tg + 2
+    const int cb = wq / (4 / NCB), ng = wq % (4 / NCB);          // input-channel block, pair of output-channel blocks
+    const int nb0 = ng * 2;
+
+    // ---- block -> (channel tile pair, slot range); the blocks of one slot range share an XCD (b & 7) where S allows ----
+    const int npairs = (p.cin / CT) * (p.cout / BN);
+    int split, pair;
+    if (p.S >= 8) { split = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / npairs); pair = (blockIdx.x >> 3) % npairs; }
+    else { split = blockIdx.x % p.S; pair = blockIdx.x / p.S; }
+    const int c0 = (pair / (p.cout / BN)) * CT, n0 = (pair % (p.cout / BN)) * BN;
+    const int H = p.H, W = p.W, PW1 = W + 1, IS = (H + 1) * PW1, HW = H * W;
+    const int KT = p.n * IS;                                     // padded slots of the whole tensor
+    const int kbeg = split * p.kper;
+    const int kend = min(kbeg + p.kper, (KT + KP - 1) / KP * KP);
+    const int np = (kend - kbeg) / KP;
+    float* const out = p.out + (long)split * p.slab;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dz), 0, p.dz_bytes, 0x00020000);
+
+    // The slots of a DMA piece are consecutive and its first slot is wave-uniform: (image, padded row, padded column) of the first
+    // slot come from SCALAR divisions (host-made reciprocals), a lane adds its row offset d < 16 and wraps -- ~10 vector instructions
+    // per piece instead of two per-lane divisions (every VALU instruction of these waves costs the MFMA pipe issue cycles).
+    auto pixel_at = [&](int S0, int d) __attribute__((always_inline)) -> int {         // pixel of slot S0 + d (S0 wave-uniform, any sign; 0 <= d < 16), or -1
+        const int Su = __builtin_amdgcn_readfirstlane(S0);
+        const int neg = Su < 0 ? 1 : 0;                                  // a window that starts ahead of the tensor (> -IS): decode one image up
+        const int S = Su + neg * IS;
+        const int img = (int)(((unsigned long long)(unsigned)S * p.magic_is) >> 40) - neg;
+        const int rem = S - (img + neg) * IS;
+        const int r = (int)(((unsigned long long)(unsigned)rem * p.magic_pw1) >> 40);
+        const int c = rem - r * PW1;
+        int cc = c + d, rr = r, ii = img;
+        const int wraps = (cc >= PW1 ? 1 : 0) + (cc >= 2 * PW1 ? 1 : 0);   // d < 16 <= 2 (W + 1) for W >= 7
+        cc -= wraps * PW1; rr += wraps;
+        if (rr > H) { rr -= H + 1; ++ii; }
+        const int sl = Su + d;
+        return (sl >= 0 && sl < KT && rr >= 1 && cc >= 1) ? ii * HW + (rr - 1) * W + (cc - 1) : -1;
+    };
+    // this wave's DMA pieces of K-piece `t` into ring stage `st`: piece ids wid, wid + 12, ...; ids < DZ_PIECES are dz rows
+    // piece i of this wave for K-piece t: (source offset, destination inside the stage, which tensor); kind 0 = none
+    auto prepare = [&](int t, int i, unsigned& voff, int& dst, int& kind) __attribute__((always_inline)) {
+        const int s0 = kbeg + t * KP;
+        const int j = wid + NWAVES * i;
+        kind = 0; voff = OOB; dst = 0;
+        if (j < DZ_PIECES) {
+            const int d = lane / (DZROW / 16), pos = lane % (DZROW / 16);
+            const int k = j * DZ_RPP + d;
+            const int m = pixel_at(s0 + j * DZ_RPP, d);
+            const int chunk = pos ^ ((k & 3) << 2);
+            voff = m >= 0 ? (unsigned)(m * p.cout + n0 + chunk * 8) * 2u : OOB;
+            dst = j * 1024; kind = 1;
+        } else if (j < PIECES && (j - DZ_PIECES) * X_RPP < KP + 2 * PW1 + 2) {      // window rows actually read
+            const int jx = j - DZ_PIECES;
+            const int d = lane / (XROW / 16), pos = lane % (XROW / 16);
+            const int r = jx * X_RPP + d;
+            const int m = pixel_at(s0 - PW1 - 1 + jx * X_RPP, d);
+            const int chunk = NCB == 1 ? pos : pos ^ (((r >> 1) & 1) << 2);
+            voff = m >= 0 ? (unsigned)(m * p.cin + c0 + chunk * 8) * 2u : OOB;
+            dst = KP * DZROW + jx * 1024; kind = 2;
+        }
+    };
+    // every wave fires MAXP DMAs per K-piece, branch-free: a wave without an i-th piece sends zeros (out-of-range source) to a
+    // scratch KiB behind the ring -- the count a wave waits for is then a constant
+    auto fire = [&](int st, unsigned voff, int dst, int kind) __attribute__((always_inline)) -> int {
+        char* const d = kind ? smem + st * STAGE + dst : smem + NST * STAGE;
+        dma16(kind == 2 ? rsrcX : rsrcD, d, voff, 0);
+        return 1;
+    };
+    auto issue = [&](int t, int st) __attribute__((always_inline)) -> int {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            unsigned v; int d, k;
+            prepare(t, i, v, d, k);
+            n += fire(st, v, d, k);
+        }
+        return n;
+    };
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposing-read lane map (igemm.hip frag_tr): of each 16 lanes, lane 4 q + pp addresses k-row q, columns 4 pp .. 4 pp + 3
+    const int g4 = lane >> 4, idx = lane & 15;
+    const int kk = 8 * (g4 >> 1) + (idx >> 2);                   // k-row within a 16-deep step (second read: + 4)
+    const int mm = 16 * (g4 & 1) + 4 * (idx & 3);                // column within a 32-wide block
+    // byte offsets inside a stage, for sub-step 0: dz fragments of the two column blocks, x fragments of the three taps
+    unsigned dz_off[2], x_off[3];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = (nb0 + b) * 32 + mm;
+        dz_off[b] = (unsigned)(kk * DZROW + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + (col & 7) * 2);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int tap = 3 * tg + a;
+        // tap = 3 (dh + 1) + (dw + 1) (the HWIO order); NOT p.dh[tap]: a dynamically indexed kernel-argument array makes the compiler
+        // copy the whole parameter block to scratch and reload fields from there -- inside the K loop, each reload with a vmcnt(0)
+        const int r0 = (tap / 3) * PW1 + tap % 3 + kk;                       // window row of this lane's first k
+        const int col = cb * 32 + mm;
+        if constexpr (NCB == 1) x_off[a] = (unsigned)(KP * DZROW + r0 * XROW + col * 2);
+        else x_off[a] = (unsigned)(KP * DZROW + r0 * XROW + (((col >> 3) ^ (((r0 >> 1) & 1) << 2)) << 4) + (col & 7) * 2);
+    }
+    // (CT = 64: the x swizzle is keyed by bit 1 of the window row; rows r0 + 16 h keep it, row + 4 keeps it: one offset per tap)
+    auto tr8 = [&](unsigned off, int rowbytes) __attribute__((always_inline)) -> bf16x8 {
+        const s16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + off));
+        const s16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + off + 4 * rowbytes));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    // ---- ring: the DMAs of K-piece t + 2 go out after the barrier of K-piece t ----
+    int n1 = 0;                                                   // pieces this wave issued for the K-piece after the awaited one
+    if (np > 0) issue(0, 0);
+    if (np > 1) n1 = issue(1, 1);
+    int st = 0;
+    for (int t = 0; t < np; ++t) {
+        wait_vmcnt_upto(t + 1 < np ? n1 : 0);
+        __builtin_amdgcn_s_barrier();
+        const bool fill = t + 2 < np;
+        const int fst = st + 2 >= NST ? st + 2 - NST : st + 2;
+        int nfill = 0;
+#if WG_INTERLEAVE
+        unsigned pv[MAXP]; int pd[MAXP], pk[MAXP];          // the next-but-one K-piece's DMA pieces: addresses now, the DMAs between the MFMA groups
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) { pv[i] = OOB; pd[i] = 0; pk[i] = 0; if (fill) prepare(t + 2, i, pv[i], pd[i], pk[i]); }
+#else
+        if (fill && (p.dbg & 1)) nfill = issue(t + 2, fst);       // (experiment: the DMAs ahead of the K-piece's MFMAs: 0.172 vs 0.162 ms at 14x14x256)
+#endif
+        const unsigned sb = (unsigned)(st * STAGE);
+        // fragments single-buffered (the registers of a 16-deep step are free once its six MFMAs are issued; the two other waves of the
+        // SIMD cover the read latency): a second set does not fit beside six accumulators in 168 registers -- and a spill reloaded
+        // inside this loop brings a vmcnt(0) with it, i.e. a wait for every DMA in flight
+        constexpr int NB_ = WG_PFD + 1;
+        bf16x8 fx[NB_][3], fd[NB_][2];
+        auto ld = [&](int h, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fd[buf][b] = tr8(sb + dz_off[b] + h * 16 * DZROW, DZROW);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) fx[buf][a] = tr8(sb + x_off[a] + h * 16 * XROW, XROW);
+        };
+        if (WG_PFD) ld(0, 0);
+#pragma unroll
+        for (int h = 0; h < KP / 16; ++h) {
+            if (WG_PFD == 0) ld(h, 0);
+            else if (h + 1 < KP / 16) ld(h + 1, (h + 1) & 1);
+#if WG_INTERLEAVE
+            if (h < MAXP) nfill += fire(fst, pv[h < MAXP ? h : 0], pd[h < MAXP ? h : 0], pk[h < MAXP ? h : 0]);      // one DMA piece per 16-deep step
+#endif
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[WG_PFD ? (h & 1) : 0][a], fd[WG_PFD ? (h & 1) : 0][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if !WG_INTERLEAVE
+        if (fill && !(p.dbg & 1)) nfill = issue(t + 2, fst);      // after this K-piece's MFMAs: the waves reach this point spread out
+#endif
+        if (fill) n1 = nfill;
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+
+    // ---- partial slab: rows (tap, cin), 32 consecutive output channels per half-wave store ----
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int tap = 3 * tg + a;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[((long)tap * p.cin + c0 + cb * 32 + row) * p.cout + n0 + (nb0 + b) * 32 + li] = acc[a][b][r];
+            }
+    }
+}
+
+template <int CT, int BN>
+hipError_t launch(const Wgrad16Params& p, hipStream_t st) {
+    constexpr int NST = 3;
+    const size_t lds = (size_t)NST * (KP * BN * 2 + 128 * CT * 2) + 1024;
+    auto kern = wgrad16_kernel<CT, BN, NST>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int npairs = (p.cin / CT) * (p.cout / BN);
+    hipLaunchKernelGGL(kern, dim3(p.S * npairs), dim3(64 * NWAVES), lds, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int* cfg) {
+    static const bool on = !(getenv("FTE_WGRAD16_RESIDENT") && atoi(getenv("FTE_WGRAD16_RESIDENT")) == 0);
+    if (!on || w > 30 || w < 7 || h < 7) return false;
+    int ct, bn;
+    if (cout % 256 == 0 && cin % 32 == 0) { ct = 32; bn = 256; *cfg = 0; }
+    else if (cout % 128 == 0 && cin % 64 == 0) { ct = 64; bn = 128; *cfg = 1; }
+    else return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        cus = prop.multiProcessorCount;
+    }
+    const int npairs = (cin / ct) * (cout / bn);
+    int S = cus / npairs;
+    if (S >= 8) S &= ~7; else if (S >= 4) S = 4; else if (S >= 2) S = 2; else S = 1;
+    const long KT = (long)n * (h + 1) * (w + 1);
+    const long pieces = (KT + KP - 1) / KP;
+    if (pieces < 8L * S || KT >= (1L << 24)) return false;       // at least eight K-pieces per block: otherwise the per-tile kernel's plan
+    p->kper = (int)((pieces + S - 1) / S) * KP;
+    p->S = S;                                                    // (a last range may come out short or empty: it writes a zero slab)
+    p->n = n; p->H = h; p->W = w; p->cin = cin; p->cout = cout;
+    static const int dbg = getenv("FTE_WGRAD16_DBG") ? atoi(getenv("FTE_WGRAD16_DBG")) : 0;
+    p->dbg = dbg;
+    // q = (s * magic) >> 40 is floor(s / d) for s < 2^24, d < 2^16
+    p->magic_is = ((1ull << 40) / (unsigned long long)((h + 1) * (w + 1))) + 1;
+    p->magic_pw1 = ((1ull << 40) / (unsigned long long)(w + 1)) + 1;
+    p->slab = 9L * cin * cout;
+    return true;
+}
+
+hipError_t wgrad16_launch(const Wgrad16Params& p, int cfg, hipStream_t st) {
+    return cfg == 0 ? launch<32, 256>(p, st) : launch<64, 128>(p, st);
+}
