@@ -144,13 +144,14 @@ def test_persistent_bf16_kernels_at_the_sizes_that_select_them():
 def test_resident_filter_gradient_of_the_bf16_storage_mode():
     """wgrad16.hip: all nine taps per block, the reduction over PADDED slots (zero rows between image rows / images), x and dz through
     LDS-DMA and the transposing LDS read, slot-range splits summed by the slab reduction -- against the float64 oracle on the same
-    bf16 inputs, both instantiations (32 cin x 256 cout: 14x14x256, 7x7x512; 64 cin x 128 cout: 28x28x128), ragged last ranges, and a
+    bf16 inputs, the three instantiations (32 cin x 256 cout: 14x14x256, 7x7x512; 64 x 128: 28x28x128; 64 x 64: 56x56x64), ragged last ranges, and a
     shape the plan leaves to the per-tile kernel (too few K-pieces per block)."""
     cs = _run([['s16wgrad', 80, 14, 14, 256, 256, 1], ['s16wgrad', 70, 7, 7, 512, 512, 1], ['s16wgrad', 83, 28, 28, 128, 128, 1],
-               ['s16wgrad', 24, 14, 14, 256, 256, 1]], {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
-    _has(cs[0], 'wgrad16_kernel<32,256,3>')
-    _has(cs[1], 'wgrad16_kernel<32,256,3>')
-    _has(cs[2], 'wgrad16_kernel<64,128,3>')
+               ['s16wgrad', 24, 14, 14, 256, 256, 1], ['s16wgrad', 45, 56, 56, 64, 64, 1]], {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
+    _has(cs[4], 'wgrad16_kernel<64,64,3,192>')
+    _has(cs[0], 'wgrad16_kernel<32,256,3,128>')
+    _has(cs[1], 'wgrad16_kernel<32,256,3,128>')
+    _has(cs[2], 'wgrad16_kernel<64,128,3,128>')
     assert not any(s.startswith('wgrad16') for s in cs[3]['symbols']), cs[3]['symbols']
 
 

@@ -626,7 +626,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
                 const int h = igemm_prof_begin(sig, (int)rows, cout, K, 2.0 * rows * cout * (double)K, (double)xb + (double)db + (double)g.S * g.slab * 4.0,
                                                (hipStream_t)stream);
                 hipError_t e = wgrad16_launch(g, cfg, (hipStream_t)stream);
-                igemm_prof_end(h, cfg == 0 ? "wgrad16_kernel<32,256,3>" : "wgrad16_kernel<64,128,3>", (hipStream_t)stream);
+                igemm_prof_end(h, cfg == 0 ? "wgrad16_kernel<32,256,3,128>" : cfg == 1 ? "wgrad16_kernel<64,128,3,128>" : "wgrad16_kernel<64,64,3,192>", (hipStream_t)stream);
                 if (e != hipSuccess) return (int)e;
                 if (g.S > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, g.S, g.slab, 1, 1.f, nullptr, (hipStream_t)stream));
                 return FTE_OK;

@@ -51,15 +51,16 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 constexpr int KP = 64;                 // slots per K-piece
 constexpr int NWAVES = 12;
 
-// CT = input channels per block (32 | 64), BN = output channels per block; (CT / 32) * (BN / 32) must be 8: 72 accumulator blocks
-template <int CT, int BN, int NST>
+// CT = input channels per block (32 | 64), BN = output channels per block; (CT / 32) * (BN / 32) = 8 (72 accumulator blocks, six per
+// wave) or 4 (the 64 -> 64 layers: 36 blocks, three per wave); XCAP = window rows (>= 64 + 2 (W + 1) + 2)
+template <int CT, int BN, int NST, int XCAP>
 __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Params p) {
     constexpr int NCB = CT / 32, NNB = BN / 32;
-    static_assert(NCB * NNB == 8 && NST >= 3, "72 accumulator blocks over twelve waves");
+    constexpr int NB2 = NCB * NNB / 4;                           // output-channel blocks per wave
+    static_assert((NB2 == 1 || NB2 == 2) && NST >= 3, "36 or 72 accumulator blocks over twelve waves");
     constexpr int DZROW = BN * 2, XROW = CT * 2;                 // bytes per row of the two LDS images
     constexpr int DZ_RPP = 1024 / DZROW, X_RPP = 1024 / XROW;    // rows per 1-KiB DMA piece
     constexpr int DZ_PIECES = KP / DZ_RPP;
-    constexpr int XCAP = 128;                                    // window rows (64 + 2 (W + 1) + 2 <= 128: W <= 30)
     constexpr int X_PIECES = XCAP / X_RPP;
     constexpr int PIECES = DZ_PIECES + X_PIECES;
     constexpr int MAXP = (PIECES + NWAVES - 1) / NWAVES;         // DMA pieces per wave and K-piece
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tg = wid >> 2, wq = wid & 3;                       // taps 3 tg .. 3 tg + 2
     const int cb = wq / (4 / NCB), ng = wq % (4 / NCB);          // input-channel block, pair of output-channel blocks
-    const int nb0 = ng * 2;
+    const int nb0 = ng * NB2;
 
     // ---- block -> (channel tile pair, slot range); the blocks of one slot range share an XCD (b & 7) where S allows ----
     const int npairs = (p.cin / CT) * (p.cout / BN);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
             const int d = lane / (DZROW / 16), pos = lane % (DZROW / 16);
             const int k = j * DZ_RPP + d;
             const int m = pixel_at(s0 + j * DZ_RPP, d);
-            const int chunk = pos ^ ((k & 3) << 2);
+            const int chunk = NNB >= 4 ? pos ^ ((k & 3) << 2) : pos ^ (((k >> 1) & 1) << 2);      // 128-byte rows: two 64-byte segments
             voff = m >= 0 ? (unsigned)(m * p.cout + n0 + chunk * 8) * 2u : OOB;
             dst = j * 1024; kind = 1;
         } else if (j < PIECES && (j - DZ_PIECES) * X_RPP < KP + 2 * PW1 + 2) {      // window rows actually read
@@ -150,11 +151,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
         return n;
     };
 
-    f32x16 acc[3][2];
+    f32x16 acc[3][NB2];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -163,11 +164,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     const int kk = 8 * (g4 >> 1) + (idx >> 2);                   // k-row within a 16-deep step (second read: + 4)
     const int mm = 16 * (g4 & 1) + 4 * (idx & 3);                // column within a 32-wide block
     // byte offsets inside a stage, for sub-step 0: dz fragments of the two column blocks, x fragments of the three taps
-    unsigned dz_off[2], x_off[3];
+    unsigned dz_off[NB2], x_off[3];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NB2; ++b) {
         const int col = (nb0 + b) * 32 + mm;
-        dz_off[b] = (unsigned)(kk * DZROW + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + (col & 7) * 2);
+        dz_off[b] = (unsigned)(kk * DZROW + (((col >> 3) ^ (NNB >= 4 ? (kk & 3) << 2 : ((kk >> 1) & 1) << 2)) << 4) + (col & 7) * 2);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -209,10 +210,10 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
         // SIMD cover the read latency): a second set does not fit beside six accumulators in 168 registers -- and a spill reloaded
         // inside this loop brings a vmcnt(0) with it, i.e. a wait for every DMA in flight
         constexpr int NB_ = WG_PFD + 1;
-        bf16x8 fx[NB_][3], fd[NB_][2];
+        bf16x8 fx[NB_][3], fd[NB_][NB2];
         auto ld = [&](int h, int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fd[buf][b] = tr8(sb + dz_off[b] + h * 16 * DZROW, DZROW);
+            for (int b = 0; b < NB2; ++b) fd[buf][b] = tr8(sb + dz_off[b] + h * 16 * DZROW, DZROW);
 #pragma unroll
             for (int a = 0; a < 3; ++a) fx[buf][a] = tr8(sb + x_off[a] + h * 16 * XROW, XROW);
         };
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[WG_PFD ? (h & 1) : 0][a], fd[WG_PFD ? (h & 1) : 0][b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < NB2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[WG_PFD ? (h & 1) : 0][a], fd[WG_PFD ? (h & 1) : 0][b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #if !WG_INTERLEAVE
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     for (int a = 0; a < 3; ++a) {
         const int tap = 3 * tg + a;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -252,11 +253,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     }
 }
 
-template <int CT, int BN>
+template <int CT, int BN, int XCAP>
 hipError_t launch(const Wgrad16Params& p, hipStream_t st) {
     constexpr int NST = 3;
-    const size_t lds = (size_t)NST * (KP * BN * 2 + 128 * CT * 2) + 1024;
-    auto kern = wgrad16_kernel<CT, BN, NST>;
+    const size_t lds = (size_t)NST * (KP * BN * 2 + XCAP * CT * 2) + 1024;
+    auto kern = wgrad16_kernel<CT, BN, NST, XCAP>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -272,10 +273,11 @@ hipError_t launch(const Wgrad16Params& p, hipStream_t st) {
 
 bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int* cfg) {
     static const bool on = !(getenv("FTE_WGRAD16_RESIDENT") && atoi(getenv("FTE_WGRAD16_RESIDENT")) == 0);
-    if (!on || w > 30 || w < 7 || h < 7) return false;
+    if (!on || w > 62 || w < 7 || h < 7) return false;
     int ct, bn;
-    if (cout % 256 == 0 && cin % 32 == 0) { ct = 32; bn = 256; *cfg = 0; }
-    else if (cout % 128 == 0 && cin % 64 == 0) { ct = 64; bn = 128; *cfg = 1; }
+    if (w <= 30 && cout % 256 == 0 && cin % 32 == 0) { ct = 32; bn = 256; *cfg = 0; }
+    else if (w <= 30 && cout % 128 == 0 && cin % 64 == 0) { ct = 64; bn = 128; *cfg = 1; }
+    else if (cout % 64 == 0 && cin % 64 == 0) { ct = 64; bn = 64; *cfg = 2; }             // the 64 -> 64 layers (56x56): 192 window rows
     else return false;
     static int cus = 0;
     if (!cus) {
@@ -303,5 +305,5 @@ bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int*
 }
 
 hipError_t wgrad16_launch(const Wgrad16Params& p, int cfg, hipStream_t st) {
-    return cfg == 0 ? launch<32, 256>(p, st) : launch<64, 128>(p, st);
+    return cfg == 0 ? launch<32, 256, 128>(p, st) : cfg == 1 ? launch<64, 128, 128>(p, st) : launch<64, 64, 192>(p, st);
 }
