@@ -12,6 +12,7 @@ struct Wgrad16Params {
     unsigned x_bytes, dz_bytes;
     int dh[9], dw[9];
     int dbg;                     // diagnostic switches (FTE_WGRAD16_DBG; 0 in production)
+    unsigned long long* stamps;  // diagnostic build only
     unsigned long long magic_is, magic_pw1;      // 2^40 / ((H+1)(W+1)) + 1, 2^40 / (W+1) + 1: scalar divisions of slot indices
 };
 

@@ -29,6 +29,9 @@
 #ifndef WG_PFD
 #define WG_PFD 1
 #endif
+#ifndef WG_STAMP
+#define WG_STAMP 0          // diagnostic build (scripts/build_variant-style): s_memtime stamps per K-piece, table on stderr
+#endif
 
 namespace {
 
@@ -39,6 +42,11 @@ typedef short s16x4t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, char* lds, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -133,23 +141,28 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
             dst = KP * DZROW + jx * 1024; kind = 2;
         }
     };
-    // every wave fires MAXP DMAs per K-piece, branch-free: a wave without an i-th piece sends zeros (out-of-range source) to a
-    // scratch KiB behind the ring -- the count a wave waits for is then a constant
     auto fire = [&](int st, unsigned voff, int dst, int kind) __attribute__((always_inline)) -> int {
-        char* const d = kind ? smem + st * STAGE + dst : smem + NST * STAGE;
-        dma16(kind == 2 ? rsrcX : rsrcD, d, voff, 0);
+        if (kind == 0) return 0;                       // (wave-uniform: this wave has no i-th piece)
+        dma16(kind == 2 ? rsrcX : rsrcD, smem + st * STAGE + dst, voff, 0);
         return 1;
     };
-    auto issue = [&](int t, int st) __attribute__((always_inline)) -> int {
+    auto issue_range = [&](int t, int st, int i0, int i1) __attribute__((always_inline)) -> int {
         int n = 0;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
+            if (i < i0 || i >= i1) continue;
             unsigned v; int d, k;
             prepare(t, i, v, d, k);
             n += fire(st, v, d, k);
         }
         return n;
     };
+    auto issue = [&](int t, int st) __attribute__((always_inline)) -> int { return issue_range(t, st, 0, MAXP); };
+    // Stamped: a wave's DMA phase (address decode + up to four LDS-DMA instructions) is 1300-1800 cycles, its MFMAs 770 of pipe time;
+    // with every wave doing MFMAs first and DMAs last, the last of a SIMD's three waves exposed its whole DMA phase at the end of each
+    // K-piece (period 4900 for 2300 cycles of MFMA).  The three tap groups (one wave of each per SIMD) take turns instead: group 1
+    // issues its DMAs before its MFMAs, group 0 after, group 2 half and half.
+    const int npre = (p.dbg & 2) ? 0 : (tg == 1 ? MAXP : tg == 2 ? MAXP / 2 : 0);
 
     f32x16 acc[3][NB2];
 #pragma unroll
@@ -193,8 +206,17 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     if (np > 1) n1 = issue(1, 1);
     int st = 0;
     for (int t = 0; t < np; ++t) {
+#if WG_STAMP
+        unsigned long long s0_ = stamp_now();
+#endif
         wait_vmcnt_upto(t + 1 < np ? n1 : 0);
+#if WG_STAMP
+        unsigned long long s1_ = stamp_now();
+#endif
         __builtin_amdgcn_s_barrier();
+#if WG_STAMP
+        unsigned long long s2_ = stamp_now();
+#endif
         const bool fill = t + 2 < np;
         const int fst = st + 2 >= NST ? st + 2 - NST : st + 2;
         int nfill = 0;
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) { pv[i] = OOB; pd[i] = 0; pk[i] = 0; if (fill) prepare(t + 2, i, pv[i], pd[i], pk[i]); }
 #else
-        if (fill && (p.dbg & 1)) nfill = issue(t + 2, fst);       // (experiment: the DMAs ahead of the K-piece's MFMAs: 0.172 vs 0.162 ms at 14x14x256)
+        if (fill) nfill = issue_range(t + 2, fst, 0, npre);
 #endif
         const unsigned sb = (unsigned)(st * STAGE);
         // fragments single-buffered (the registers of a 16-deep step are free once its six MFMAs are issued; the two other waves of the
@@ -231,8 +253,20 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
                 for (int b = 0; b < NB2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[WG_PFD ? (h & 1) : 0][a], fd[WG_PFD ? (h & 1) : 0][b], acc[a][b], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#if WG_STAMP
+        unsigned long long s3_ = stamp_now();
+#endif
 #if !WG_INTERLEAVE
-        if (fill && !(p.dbg & 1)) nfill = issue(t + 2, fst);      // after this K-piece's MFMAs: the waves reach this point spread out
+        if (fill) nfill += issue_range(t + 2, fst, npre, MAXP);
+#endif
+#if WG_STAMP
+        {
+            unsigned long long s4_ = stamp_now();
+            if (blockIdx.x == 0 && (wid == 0 || wid == NWAVES - 1) && lane == 0 && t < 60) {
+                unsigned long long* o = p.stamps + ((wid ? 1 : 0) * 60 + t) * 5;
+                o[0] = s0_; o[1] = s1_; o[2] = s2_; o[3] = s3_; o[4] = s4_;
+            }
+        }
 #endif
         if (fill) n1 = nfill;
         st = st + 1 == NST ? 0 : st + 1;
@@ -265,6 +299,33 @@ hipError_t launch(const Wgrad16Params& p, hipStream_t st) {
         attr_done = true;
     }
     const int npairs = (p.cin / CT) * (p.cout / BN);
+#if WG_STAMP
+    {
+        static unsigned long long* buf = nullptr;
+        const size_t nb = 2 * 60 * 5 * sizeof(unsigned long long);
+        if (!buf && hipMalloc(&buf, nb) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(buf, 0, nb, st);
+        Wgrad16Params q = p;
+        q.stamps = buf;
+        hipLaunchKernelGGL(kern, dim3(p.S * npairs), dim3(64 * NWAVES), lds, st, q);
+        (void)hipStreamSynchronize(st);
+        static unsigned long long h[2 * 60 * 5];
+        (void)hipMemcpy(h, buf, nb, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[stamp] wgrad16<%d,%d> %dx%d cin %d cout %d S %d kper %d\n", CT, BN, p.H, p.W, p.cin, p.cout, p.S, p.kper);
+        for (int w = 0; w < 2; ++w) {
+            double a = 0, b = 0, c = 0, d = 0, per = 0; int n = 0;
+            for (int t = 4; t < 50; ++t) {
+                const unsigned long long* r = h + (w * 60 + t) * 5;
+                if (!r[0] || !h[(w * 60 + t - 1) * 5]) break;
+                a += (double)(r[1] - r[0]); b += (double)(r[2] - r[1]); c += (double)(r[3] - r[2]); d += (double)(r[4] - r[3]);
+                per += (double)(r[0] - h[(w * 60 + t - 1) * 5]); ++n;
+            }
+            if (n) fprintf(stderr, "[stamp]  wave %d: per K-piece period %.0f = vmcnt wait %.0f + barrier %.0f + reads and MFMAs %.0f + DMA issue %.0f + rest\n",
+                           w ? NWAVES - 1 : 0, per / n, a / n, b / n, c / n, d / n);
+        }
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(p.S * npairs), dim3(64 * NWAVES), lds, st, p);
     return hipGetLastError();
 }
