@@ -520,29 +520,37 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
 // colf = [alpha[BN], bias[BN]] of the tile's columns (LDS), red = [2][WM][BN] floats (LDS).  ein0 / ein1: the inputs fetched ahead.
 // With EPI_DGRAD and PA the function holds ONE block barrier (every wave of the block must call it, or match it).  Returns the number
 // of stores a wave issued (0 after the barrier form: count nothing).
+// (the pointers carry the GLOBAL address space explicitly: a pointer rebuilt from the pinned integer is generic to the compiler, and
+// generic means flat_load / flat_store -- which count on lgkmcnt as well, so that every wait for an LDS read also waits for the last
+// store's round trip to HBM: the first version of this struct ran the epilogue at ~1000 cycles per 16-byte piece)
+typedef __attribute__((address_space(1))) unsigned short g_u16;
+typedef __attribute__((address_space(1))) const unsigned short g_cu16;
+typedef __attribute__((address_space(1))) float g_f32;
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+typedef __attribute__((address_space(1))) const u32x4 g_cu32x4;
 struct EpiPtrs {
-    unsigned short* o0;          // EPI_FWD: Z16 (may be null)     EPI_DGRAD: RAW16 (may be null)
-    unsigned short* o1;          //          Y16                              DZ16
-    const unsigned short* i0;    //          R16 (may be null)                ADD16 (may be null)
-    const unsigned short* i1;    //          --                               Zin16 (null: no activation gradient)
-    float* PA; float* PB;        // EPI_DGRAD: column partials (may be null)
+    g_u16* o0;                   // EPI_FWD: Z16 (may be null)     EPI_DGRAD: RAW16 (may be null)
+    g_u16* o1;                   //          Y16                              DZ16
+    g_cu16* i0;                  //          R16 (may be null)                ADD16 (may be null)
+    g_cu16* i1;                  //          --                               Zin16 (null: no activation gradient)
+    g_f32* PA; g_f32* PB;        // EPI_DGRAD: column partials (may be null)
     int has_bias, act, N, prow0, m_base, M;
 };
-template <class T>
-__device__ __forceinline__ T* pin_sgpr(T* q) {                 // the pointer stays in scalar registers from here on
+template <class G, class T>
+__device__ __forceinline__ G* pin_sgpr(T* q) {                 // the pointer stays in scalar registers from here on
     unsigned long long v = reinterpret_cast<unsigned long long>(q);
     asm volatile("" : "+s"(v));
-    return reinterpret_cast<T*>(v);
+    return (G*)v;
 }
 template <int EPI>
 __device__ __forceinline__ EpiPtrs epi_ptrs(const IgemmParams& p) {
     EpiPtrs e;
     if constexpr (EPI == EPI_FWD) {
-        e.o0 = pin_sgpr(p.Z16); e.o1 = pin_sgpr(p.Y16); e.i0 = pin_sgpr(p.R16); e.i1 = nullptr; e.PA = nullptr; e.PB = nullptr;
+        e.o0 = pin_sgpr<g_u16>(p.Z16); e.o1 = pin_sgpr<g_u16>(p.Y16); e.i0 = pin_sgpr<g_cu16>(p.R16); e.i1 = nullptr; e.PA = nullptr; e.PB = nullptr;
         e.has_bias = p.bias != nullptr; e.act = p.alpha != nullptr;
     } else {
-        e.o0 = pin_sgpr(p.RAW16); e.o1 = pin_sgpr(p.DZ16); e.i0 = pin_sgpr(p.ADD16); e.i1 = pin_sgpr(p.Zin16);
-        e.PA = pin_sgpr(p.PA); e.PB = pin_sgpr(p.PB);
+        e.o0 = pin_sgpr<g_u16>(p.RAW16); e.o1 = pin_sgpr<g_u16>(p.DZ16); e.i0 = pin_sgpr<g_cu16>(p.ADD16); e.i1 = pin_sgpr<g_cu16>(p.Zin16);
+        e.PA = pin_sgpr<g_f32>(p.PA); e.PB = pin_sgpr<g_f32>(p.PB);
         e.has_bias = 0; e.act = p.Zin16 != nullptr;
     }
     e.N = p.N; e.prow0 = p.prow0; e.m_base = p.m_base; e.M = p.M;
@@ -604,8 +612,8 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { dst[2 * e] = __builtin_bit_cast(float, h[e] << 16); dst[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xffff0000u); }
                 };
-                auto st16 = [&](unsigned short* dst, const float (&x)[8]) {
-                    if (dst && off >= 0) *reinterpret_cast<u32x4*>(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
+                auto st16 = [&](g_u16* dst, const float (&x)[8]) {
+                    if (dst && off >= 0) *(g_u32x4*)(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
                 };
                 if constexpr (EPI == EPI_FWD) {
                     if (ep.has_bias) {
@@ -961,10 +969,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16p_kernel(const Igem
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                             if constexpr (EPI == EPI_FWD) {
-                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
+                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
                             } else {
-                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
-                                if (ep.i1) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i1 + o);
+                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
+                                if (ep.i1) ein1[i][j][q] = *(g_cu32x4*)(ep.i1 + o);
                             }
                         }
             }
@@ -1315,10 +1323,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16r_kernel(const
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                             if constexpr (EPI == EPI_FWD) {
-                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
+                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
                             } else {
-                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
-                                if (ep.i1) ein1[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i1 + o);
+                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
+                                if (ep.i1) ein1[i][j][q] = *(g_cu32x4*)(ep.i1 + o);
                             }
                         }
             }
@@ -1770,9 +1778,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                             if constexpr (EPI == EPI_FWD) {
-                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
+                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
                             } else {
-                                if (ep.i0) ein0[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i0 + o);
+                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
                             }
                         }
             }
@@ -1799,7 +1807,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
-                            ein1[i][j][q] = *reinterpret_cast<const u32x4*>(ep.i1 + o);
+                            ein1[i][j][q] = *(g_cu32x4*)(ep.i1 + o);
                         }
             }
         }
