@@ -511,6 +511,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16w_kernel(const Igem
 //   * dalpha / dbias column partials (EPI_DGRAD): a halving butterfly over the 32 row-lanes (16 shuffles per 16 columns), then the
 //     usual fixed-order sum over the row-waves through LDS.
 // Restrictions (launch16p_ok): no split-K, no merged stride-2 classes, alpha period a multiple of 8.
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
 // ---- epilogue of the swapped-operand kernels (igemm16p / igemm16r / igemm16rw): accumulator lane = output row, registers = columns ----
 // acc[i][j][r] of lane (li, lh): output row m0 + wm*TM*32 + i*32 + li (its offset: roff[i], < 0 beyond M), column n0 + wn*TN*32 + j*32 +
 // (r & 3) + 8 (r >> 2) + 4 lh.  v_permlane32_swap between the half-waves gives every lane 8 consecutive columns -- 16 bytes of a bf16 row
@@ -559,8 +564,10 @@ __device__ __forceinline__ EpiPtrs epi_ptrs(const IgemmParams& p) {
 template <int BM, int BN, int WM, int WN, int EPI>
 __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&roff)[BM / WM / 32],
                                              u32x4 (&ein0)[BM / WM / 32][BN / WN / 32][2], u32x4 (&ein1)[BM / WM / 32][BN / WN / 32][2],
-                                             const float* colf, float* red, int mt, int n0, int tid, int wm, int wn, int li, int lh) {
+                                             const float* colf, float* red, int mt, int n0, int tid, int wm, int wn, int li, int lh,
+                                             unsigned long long* est = nullptr) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    if (est) est[0] = stamp_now();
     // Every fetched-ahead input is "used" here, in straight-line code BEFORE the first store: the compiler then waits for the loads
     // once, now.  Left to the first real use inside the conditional blocks below, its wait-count pass cannot tell how many stores were
     // issued since and writes vmcnt(0) before each piece -- every piece then waits for the stores of the piece before it to drain
@@ -574,6 +581,7 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                 asm volatile("" : "+v"(ein0[i][j][q]));
                 if constexpr (EPI == EPI_DGRAD) asm volatile("" : "+v"(ein1[i][j][q]));
             }
+    if (est) est[1] = stamp_now();
     float csa[TN], csb[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) { csa[j] = 0.f; csb[j] = 0.f; }
@@ -598,9 +606,11 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                     a[8 * g + e] = x;
                     a[8 * g + 4 + e] = y;
                 }
+            if (est && i == 0 && j == 0) est[2] = stamp_now();
             float sa16[16], sb16[16];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+                if (est && i == 0 && j == 0 && q == 1) est[5] = stamp_now();
                 const int cl = wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                 const long o = (long)(off < 0 ? 0 : off) + n0 + cl;
                 float v[8];
@@ -621,7 +631,9 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
                     }
+                    if (est && i == 0 && j == 0 && q == 0) est[3] = stamp_now();
                     st16(ep.o0, v);
+                    if (est && i == 0 && j == 0 && q == 0) est[4] = stamp_now();
                     if (act) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : al[e] * v[e];
@@ -723,11 +735,6 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
 }
 
 // NST = ring stages (NST - 1 K-steps in flight, across tile boundaries)
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
-}
 // DBG = 1 (diagnostic launches only, FTE_IGEMM16_STAMP): s_memtime stamps around the wait / barrier / body of every K-step
 // PFD = sub-steps by which the fragment reads run ahead of their MFMAs (1..3; 3 = every fragment of the K-step is requested at
 // its start): with two MFMAs per sub-step (wave tile 32 x 64) one sub-step of lookahead is 64 cycles, less than an LDS read takes
@@ -1769,7 +1776,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             if (KS == 1 || (t & 1) == 0) __builtin_amdgcn_s_barrier();
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
-            if (t == nk - 1 && in16) {                  // (three K-steps ahead measured no better: 0.172 / 0.156 vs 0.171 / 0.154 ms)
+            if (t == nk - 1 && in16) {                  // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1813,8 +1820,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
         }
         unsigned long long se0 = 0;
         if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); se0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
-        epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh);
+        unsigned long long estv[6] = {0, 0, 0, 0, 0, 0};
+        epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh, DBG ? estv : nullptr);
         if constexpr (DBG) {
+            if (blockIdx.x == 0 && wid == 0 && lane == 0 && kt_dbg == 1) {
+                unsigned long long* o = stamps + (1 * 80 + 76) * 4;
+                o[0] = estv[1] - estv[0]; o[1] = estv[2] - estv[1]; o[2] = estv[3] - estv[2]; o[3] = estv[4] - estv[3];
+                o[4] = estv[5] - estv[4]; o[5] = 7;
+            }
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long se1 = stamp_now();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1911,6 +1924,11 @@ hipError_t launch16rw(const IgemmParams& p, hipStream_t st) {
                 const unsigned long long* e = host + (80 + 70 + k) * 4;
                 if (e[3] == 1) fprintf(stderr, "[stamp]  consumer wave 0, tile %d: epilogue_rows %.0f ticks, then %.0f until its stores have drained\n", k,
                                        (double)(e[1] - e[0]), (double)(e[2] - e[1]));
+            }
+            {
+                const unsigned long long* e = host + (80 + 76) * 4;
+                if (e[5] == 7) fprintf(stderr, "[stamp]   inside (tile 1): wait for the fetched-ahead inputs %.0f, to the first block %.0f, exchange + bias to the first store %.0f, "
+                                               "first store %.0f, activation + shortcut + second store %.0f\n", (double)e[0], (double)e[1], (double)e[2], (double)e[3], (double)e[4]);
             }
         }
         return hipGetLastError();
