@@ -1504,6 +1504,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
         int tapB = 0;
         if (lane < 9) tapB = p.b_tapoff[lane] * 2;
         unsigned w_off[KW], b_base[KB];
+        const int apix = (int)(p.a_bytes / (unsigned)(p.a_ld * 2));
         int npc = 0;                                    // pieces of the current window (whole launch: <= WCAP, the launcher checks)
         auto setup_w = [&](int tile) {                  // window piece k of this wave = piece lw + NLW k: slots lo + 8 (lw + NLW k) + (lane >> 3)
             const int mt = tile / ntn;
@@ -1520,7 +1521,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                     const int n = fdiv(S, IS, r_is), rem = S - n * IS;
                     const int r = fdiv(rem, PW1, r_pw1), c = rem - r * PW1;
                     const int m = n * HW + (r - 1) * W + (c - 1);
-                    if (r >= 1 && c >= 1 && m < p.M) {
+                    if (r >= 1 && c >= 1 && m < apix) {             // (the TENSOR's pixels: a main launch of a main + tail pair stops short of them)
                         const int chunk = (lane & 7) ^ ((srel >> 1) & 7);
                         off = (unsigned)(m * p.a_ld + (chunk << 3)) * 2u;
                     }
@@ -1849,7 +1850,7 @@ static bool launch16rw_ok(const IgemmParams& p, int BM, int wcap) {
     if (p.a_NT != 9 || p.a_stride != 1 || p.a_OH != p.a_IH || p.a_OW != p.a_IW || p.a_KC % BK16 || p.K != 9 * p.a_KC) return false;
     for (int t = 0; t < 9; ++t)
         if (p.a_dh[t] < -1 || p.a_dh[t] > 1 || p.a_dw[t] < -1 || p.a_dw[t] > 1) return false;
-    if (p.M != p.a_OH * p.a_OW * (p.M / (p.a_OH * p.a_OW)) || p.m_base != 0) return false;
+    if (p.m_base != 0) return false;
     // widest window: BM pixels spread over padded rows / images, plus a padded row and a slot on either side
     const long H = p.a_IH, W = p.a_IW, hw = H * W;
     const long imgx = (BM + hw - 1) / hw, rowx = (BM - 1) / W + 1;       // image / row boundaries BM consecutive pixels can cross
