@@ -2059,92 +2059,42 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         if (epi == EPI_FWD) return launch16w<128, 128, 2, 2, EPI_FWD, 2>(p, splits, st);
         return launch16w<128, 128, 2, 2, EPI_DGRAD, 2>(p, splits, st);
     }
-    static const int pers = getenv("FTE_IGEMM16_PERSIST") ? atoi(getenv("FTE_IGEMM16_PERSIST")) : 1;      // 0: the per-tile kernels
+    // Resident kernels for bf16-STORAGE launches.  FTE_IGEMM16_PERSIST: 1 (default) = the window kernel igemm16rw for
+    // every 3x3 / stride-1 layer, igemm16p for the other eligible forward launches and the N = 64 data gradients; 0 = the per-tile
+    // kernels below; 14 = igemm16p for every eligible launch; 22 = the window kernel with one K-step per barrier; 10 = igemm16r (loader
+    // waves, no window).  Measured and dropped (same table): igemm16p with a four-stage ring at one block per CU (0.234 vs 0.160 ms,
+    // 14x14x256 forward), a 256x128 tile without loader waves (0.209), fragment reads two / three sub-steps ahead at 128 registers
+    // (spills: 0.168 / 0.170), four waves of 64x64 (0.168); the 128x128 data gradient on igemm16p (0.214 vs 0.202 per-tile).
+    static const int pers = getenv("FTE_IGEMM16_PERSIST") ? atoi(getenv("FTE_IGEMM16_PERSIST")) : 1;
     if (pers && launch16p_ok(p, epi, tile, splits)) {
+        const bool win = pers == 1 || pers == 22;
         if (tile == TILE_128x128) {
-            if (pers == 2) {         // four-stage ring, one block per CU
-                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 4, 2, 1>(p, st);
-                return launch16p<128, 128, 4, 2, EPI_DGRAD, 4, 2, 1>(p, st);
-            }
-            if (pers == 3 && (p.M - p.m_base) >= 256) {         // 256 x 128 tile (wave tile 64 x 64), three-stage ring, one block per CU
-                if (epi == EPI_FWD) return launch16p<256, 128, 4, 2, EPI_FWD, 3, 2, 1>(p, st);
-                return launch16p<256, 128, 4, 2, EPI_DGRAD, 3, 2, 1>(p, st);
-            }
-            // default (pers == 1): the window kernel where it applies -- every 3x3 / stride-1 layer, forward and data gradient (batch 512,
-            // ms on one box, per-tile kernel -> igemm16rw: forward 28x28x128 0.220 -> 0.166, 14x14x256 0.161 -> 0.145; data gradient
-            // 28x28x128 0.293 -> 0.229, 14x14x256 0.198 -> 0.178)
-            if ((pers == 1 || pers == 20) && (p.K / BK16) % 2 == 0 && launch16rw_ok(p, 256, 45)) {      // two K-steps per barrier
+            // batch 512, ms on one box, per-tile kernel -> igemm16rw: forward 28x28x128 0.220 -> 0.155, 14x14x256 0.161 -> 0.138, 7x7x512
+            // 0.185 -> 0.126; data gradient 0.293 -> 0.225, 0.198 -> 0.177, 0.215 -> 0.146
+            if (pers == 1 && (p.K / BK16) % 2 == 0 && launch16rw_ok(p, 256, 45)) {      // two K-steps per barrier
                 if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 45, 2>(p, st);
                 return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 45, 2>(p, st);
             }
-            if ((pers == 1 || (pers >= 20 && pers <= 22)) && launch16rw_ok(p, 256, 48)) {
-                if (pers == 21) {
-                    if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 1, 48>(p, st);
-                    return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 1, 48>(p, st);
-                }
+            if (win && launch16rw_ok(p, 256, 48)) {
                 if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 48>(p, st);
                 return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 48>(p, st);
             }
-            if (pers >= 10 && pers <= 13 && (p.M - p.m_base) >= 256) {      // loader waves + 64 x 64 consumers, 256 x 128 tile, one block per CU
-                if (pers == 10) {
-                    if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 4, 2>(p, st);
-                    return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 4, 2>(p, st);
-                }
-                if (pers == 11) {
-                    if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 4, 1>(p, st);
-                    return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 4, 1>(p, st);
-                }
-                if (pers == 12) {
-                    if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 2, 2>(p, st);
-                    return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 2, 2>(p, st);
-                }
-                if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 8, 2>(p, st);
-                return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 8, 2>(p, st);
-            }
-            if (pers == 6 || pers == 7) {         // four waves (2 x 2, wave tile 64 x 64), two blocks per CU = two waves per SIMD
-                if (pers == 6) {
-                    if (epi == EPI_FWD) return launch16p<128, 128, 2, 2, EPI_FWD, 2, 2, 2, 2>(p, st);
-                    return launch16p<128, 128, 2, 2, EPI_DGRAD, 2, 2, 2, 2>(p, st);
-                }
-                if (epi == EPI_FWD) return launch16p<128, 128, 2, 2, EPI_FWD, 2, 2, 2, 3>(p, st);
-                return launch16p<128, 128, 2, 2, EPI_DGRAD, 2, 2, 2, 3>(p, st);
-            }
-            if (pers == 8) {         // 256 x 128, eight waves of 64 x 64, three stages, all fragments up front
-                if (epi == EPI_FWD) return launch16p<256, 128, 4, 2, EPI_FWD, 3, 2, 1, 3>(p, st);
-                return launch16p<256, 128, 4, 2, EPI_DGRAD, 3, 2, 1, 3>(p, st);
-            }
-            if (pers == 9) {         // 128 x 128, eight waves, four stages, one block per CU, all fragments up front
-                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 4, 2, 1, 3>(p, st);
-                return launch16p<128, 128, 4, 2, EPI_DGRAD, 4, 2, 1, 3>(p, st);
-            }
-            if (pers == 4) {
-                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 2, 4, 2, 2>(p, st);
-                return launch16p<128, 128, 4, 2, EPI_DGRAD, 2, 4, 2, 2>(p, st);
-            }
-            if (pers == 5) {
-                if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 2, 4, 2, 3>(p, st);
-                return launch16p<128, 128, 4, 2, EPI_DGRAD, 2, 4, 2, 3>(p, st);
+            if (pers == 10 && p.K / BK16 >= 4 && (p.M - p.m_base) >= 256) {      // loader waves + 64 x 64 consumers, no window
+                if (epi == EPI_FWD) return launch16r<256, 128, 4, 2, EPI_FWD, 3, 4, 2>(p, st);
+                return launch16r<256, 128, 4, 2, EPI_DGRAD, 3, 4, 2>(p, st);
             }
             if (epi == EPI_FWD) return launch16p<128, 128, 4, 2, EPI_FWD, 2, 4, 2>(p, st);
             if (pers == 14) return launch16p<128, 128, 4, 2, EPI_DGRAD, 2, 4, 2>(p, st);
-            // the 128 x 128 data gradient stays on the per-tile kernel (default): its persistent form (two bf16 inputs per output, column
-            // partials, 128 registers) measured 0.214 / 0.297 ms against 0.202 / 0.296 (14x14x256 / 28x28x128, batch 512)
+            // (a 128 x 128 data gradient the window kernel does not take -- stride 2, 1x1 -- stays on the per-tile kernel)
         } else {
-        // N = 64: 256 x 64 tile, consumers 64 x 32 (56x56x64 at batch 512: forward 0.42 -> 0.37 -> 0.24 ms, data gradient 0.62 -> 0.51 -> 0.44)
-        if ((pers == 1 || (pers >= 20 && pers <= 22)) && launch16rw_ok(p, 256, 56)) {
-            if (epi == EPI_FWD) return launch16rw<256, 64, 4, 2, EPI_FWD, 4, 2, 56>(p, st);
-            return launch16rw<256, 64, 4, 2, EPI_DGRAD, 4, 2, 56>(p, st);
-        }
-        if (pers == 4 || pers == 5) {
-            if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 2, 6, 3, 3>(p, st);
-            return launch16p<128, 64, 4, 2, EPI_DGRAD, 2, 6, 3, 3>(p, st);
-        }
-        if (pers == 2 || pers == 3) {     // three-stage ring, two blocks per CU
-            if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 3, 4, 2>(p, st);
-            return launch16p<128, 64, 4, 2, EPI_DGRAD, 3, 4, 2>(p, st);
-        }
-        if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 2, 6, 3>(p, st);
-        return launch16p<128, 64, 4, 2, EPI_DGRAD, 2, 6, 3>(p, st);
+            // N = 64: 256 x 64 tile, consumers 64 x 32 (56x56x64 at batch 512: forward 0.42 -> 0.37 (igemm16p) -> 0.24 ms, data
+            // gradient 0.62 -> 0.51 -> 0.42)
+            if (win && launch16rw_ok(p, 256, 56)) {
+                if (epi == EPI_FWD) return launch16rw<256, 64, 4, 2, EPI_FWD, 4, 2, 56>(p, st);
+                return launch16rw<256, 64, 4, 2, EPI_DGRAD, 4, 2, 56>(p, st);
+            }
+            if (epi == EPI_FWD) return launch16p<128, 64, 4, 2, EPI_FWD, 2, 6, 3>(p, st);
+            return launch16p<128, 64, 4, 2, EPI_DGRAD, 2, 6, 3>(p, st);
         }
     }
     // cfg 4 = cfg 1 with eight waves per block: SphereNet bf16 step 16.57 -> 15.77 ms (one stream), 16.0 -> 15.5 (two streams)
