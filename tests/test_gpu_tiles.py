@@ -114,24 +114,31 @@ def test_wgrad_128x128_hooked_ragged_splits():
 def test_persistent_bf16_kernels_at_the_sizes_that_select_them():
     """bf16 storage (fte_conv2d_{fwd,dgrad}_s16): at >= 768 tiles of 128 rows the planner takes the 128x128 / 128x64 tile and the 3x3 /
     stride-1 launches run on igemm16rw_kernel -- resident blocks (loader waves + consumer waves) that walk several tiles, the A operand
-    through a padded-slot window in LDS, swapped-operand MFMAs, the register epilogue with the half-wave exchange, column partials
-    through the lane butterfly -- or, by hook, on igemm16p_kernel.  Every stored bf16 value must be within half a bf16 step (+ fp32
+    through a padded-slot window in LDS, swapped-operand MFMAs, the register epilogue with the half-wave exchange (256 x 128) or the
+    row-coalesced epilogue through LDS (256 x 64), column partials carried across a block's tiles -- or, by hook, on igemm16p_kernel.  Every stored bf16 value must be within half a bf16 step (+ fp32
     noise) of the float64 result of the same bf16 inputs; dalpha / dbias as in the fp32 cases."""
     env = {'FTE_MFMA_DTYPE': 'bf16s'}
     cs = _run([['s16fwd', 64, 56, 56, 64, 64, 1], ['s16dgrad', 64, 56, 56, 64, 64, 1], ['s16fwd', 126, 28, 28, 128, 128, 1],
                ['s16dgrad', 126, 28, 28, 128, 128, 1], ['s16fwd', 262, 14, 14, 256, 256, 1]], env, timeout=1500)
-    _has(cs[0], 'igemm16rw_kernel<256,64,4,2,0,4,2,56,1,0>')           # K = 576: one barrier per K-step
-    _has(cs[1], 'igemm16rw_kernel<256,64,4,2,1,4,2,56,1,0>')
-    _has(cs[2], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0>')          # two K-steps per barrier
-    _has(cs[3], 'igemm16rw_kernel<256,128,4,2,1,4,2,45,2,0>')
-    _has(cs[4], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0>')
+    _has(cs[0], 'igemm16rw_kernel<256,64,8,1,0,4,2,56,1,8,0>')         # K = 576: one barrier per K-step; row-coalesced epilogue
+    _has(cs[1], 'igemm16rw_kernel<256,64,8,1,1,4,2,56,1,8,0>')
+    _has(cs[2], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0,0>')          # two K-steps per barrier
+    _has(cs[3], 'igemm16rw_kernel<256,128,4,2,1,4,2,45,2,0,0>')
+    _has(cs[4], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0,0>')
     # ... one barrier per K-step on the 256 x 128 tile as well (hook), and a 7x7x512 layer (the unsplit plan: 72 K-steps per tile)
     cs = _run([['s16fwd', 126, 28, 28, 128, 128, 1], ['s16dgrad', 126, 28, 28, 128, 128, 1]], dict(env, FTE_IGEMM16_PERSIST='22'), timeout=1500)
-    _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,2,48,1,0>')
-    _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,2,48,1,0>')
+    _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,2,48,1,0,0>')
+    _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,2,48,1,0,0>')
     cs = _run([['s16fwd', 336, 7, 7, 512, 512, 1], ['s16dgrad', 336, 7, 7, 512, 512, 1]], env, timeout=1500)
-    _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0>')
-    _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,2,45,2,0>')
+    _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0,0>')
+    _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,2,45,2,0,0>')
+    # the register epilogue on the 256 x 64 tile (FTE_IGEMM16_STG=0) and the row-coalesced one through the B ring on 256 x 128 (=2)
+    cs = _run([['s16fwd', 64, 56, 56, 64, 64, 1], ['s16dgrad', 64, 56, 56, 64, 64, 1]], dict(env, FTE_IGEMM16_STG='0'), timeout=1500)
+    _has(cs[0], 'igemm16rw_kernel<256,64,4,2,0,4,2,56,1,0,0>')
+    _has(cs[1], 'igemm16rw_kernel<256,64,4,2,1,4,2,56,1,0,0>')
+    cs = _run([['s16fwd', 126, 28, 28, 128, 128, 1], ['s16dgrad', 126, 28, 28, 128, 128, 1]], dict(env, FTE_IGEMM16_STG='2'), timeout=1500)
+    _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,16,0>')
+    _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,2,45,2,16,0>')
     # the same layers on the persistent kernel without loader waves / window (FTE_IGEMM16_PERSIST=14: every eligible launch)
     cs = _run([['s16fwd', 64, 56, 56, 64, 64, 1], ['s16dgrad', 64, 56, 56, 64, 64, 1], ['s16fwd', 126, 28, 28, 128, 128, 1],
                ['s16dgrad', 126, 28, 28, 128, 128, 1]], dict(env, FTE_IGEMM16_PERSIST='14'), timeout=1500)

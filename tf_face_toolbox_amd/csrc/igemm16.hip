@@ -565,7 +565,7 @@ template <int BM, int BN, int WM, int WN, int EPI>
 __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&roff)[BM / WM / 32],
                                              u32x4 (&ein0)[BM / WM / 32][BN / WN / 32][2], u32x4 (&ein1)[BM / WM / 32][BN / WN / 32][2],
                                              const float* colf, float* red, int mt, int n0, int tid, int wm, int wn, int li, int lh,
-                                             unsigned long long* est = nullptr) {
+                                             unsigned long long* est = nullptr, float* carry = nullptr, bool flush = true) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     if (est) est[0] = stamp_now();
     // Every fetched-ahead input is "used" here, in straight-line code BEFORE the first store: the compiler then waits for the loads
@@ -582,9 +582,11 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                 if constexpr (EPI == EPI_DGRAD) asm volatile("" : "+v"(ein1[i][j][q]));
             }
     if (est) est[1] = stamp_now();
+    // column partials of this wave (dalpha, dbias).  `carry` (2 TN floats of the caller, zero at the start): the sums run on across the
+    // tiles of a resident block and reach the partial rows only when `flush` is set
     float csa[TN], csb[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { csa[j] = 0.f; csb[j] = 0.f; }
+    for (int j = 0; j < TN; ++j) { csa[j] = carry ? carry[j] : 0.f; csb[j] = carry ? carry[TN + j] : 0.f; }
     const bool act = ep.act;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -688,7 +690,27 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
     }
     int nst = TM * TN * 2 * ((ep.o0 ? 1 : 0) + (ep.o1 ? 1 : 0));      // stores issued (per wave; wave-uniform)
     if constexpr (EPI == EPI_DGRAD) {
-        if (ep.PA) {    // column partials (dalpha, dbias) per 128 rows -- the planner's partial rows -- reduced later in a fixed order
+        if (ep.PA && !flush) {
+            // A resident block whose next tile has the same columns keeps its sums in registers: this tile's partial rows are ZERO
+            // (fire-and-forget stores; the rows' total is what the reduction reads).  The flush below costs a block barrier -- and
+            // hipcc's __syncthreads waits for every store of the tile to drain first, i.e. nothing of the epilogue overlapped the
+            // next tile's K loop (56x56x64 data gradient 0.306 ms against 0.203 for the forward of the same bytes).
+            constexpr int NH = BM / 128;
+            if (tid < BN * NH) {
+                const int h = tid / BN, c = tid - h * BN;
+                if (ep.m_base + (mt * NH + h) * 128 < ep.M) {
+                    const long o = (long)(ep.prow0 + mt * NH + h) * ep.N + n0 + c;
+                    ep.PA[o] = 0.f;
+                    if (ep.PB) ep.PB[o] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { carry[j] = csa[j]; carry[TN + j] = csb[j]; }
+        } else if (ep.PA) {    // column partials (dalpha, dbias) per 128 rows -- the planner's partial rows -- reduced later in a fixed order
+            if (carry) {
+#pragma unroll
+                for (int j = 0; j < 2 * TN; ++j) carry[j] = 0.f;
+            }
             if ((li & 1) == 0) {
                 const int c16 = li >> 1;
 #pragma unroll
@@ -718,6 +740,160 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
         }
     }
     return nst;
+}
+
+// ---- the same epilogue with ROW-COALESCED memory instructions (igemm16rw, STG > 0) ----------------------------------------------
+// In epilogue_rows a 16-byte load / store has its 64 lanes on 64 different rows.  scripts/probes/store_patterns.hip: such an
+// instruction costs a CU ~65 cycles (store) / ~73 (load) -- one per touched line -- against 19 / 44 when eight lanes share a 128-byte
+// row; the 192 (forward) / 256 (data gradient) instructions of a 256 x 128 tile are the 10-12k / 18-20k cycles the stamped builds
+// show for the epilogue of a 45-55k-cycle tile, with the MFMA pipe idle (every consumer wave is in its epilogue at the same time).
+// Here the fp32 accumulators of a wave (32 TM rows x 64 columns, lane = row) go through LDS STG rows at a time -- masked
+// ds_write_b128 of the 4-column register groups, 16-byte chunk ch of row r at chunk position ch ^ (r & 15): conflict-free both ways
+// -- and come back with lane = (row r = lane >> 3 of eight, column chunk c = lane & 7 of eight columns): every bf16 load / store of
+// the epilogue then covers 8 rows x 128 contiguous bytes, and the half-wave exchange is gone.  Unit k = rows 8k .. 8k + 7 of the wave.
+// dalpha / dbias: a lane sums its eight columns over every unit (and over the tiles of a resident block, `carry`); the lanes of a
+// column meet (xor 8, 16, 32) only when the partial rows are written.
+// stg: this wave's STG x 256 bytes.  With KS = 2 they lie in the half of the B ring the last interval read (free until the loaders
+// pass the next tile's first barrier; the caller holds a block barrier between the last K-step and this function).
+template <int BM, int BN, int WM, int WN, int EPI, int STG>
+__device__ __forceinline__ void epilogue_staged(const EpiPtrs& ep, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* stg, long base, int m_wave,
+                                                u32x4 (&ein0)[BM / WM / 8], u32x4 (&ein1)[BM / WM / 8], const float* colf, float* red,
+                                                int mt, int n0, int tid, int wm, int wn, int lane, float (&carry)[16], bool flush) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NU = TM * 4;
+    static_assert(TN == 2 && (STG == 8 || STG == 16), "64-column slabs: eight lanes x eight columns per row");
+    const int li = lane & 31, lh = lane >> 5, rr = lane >> 3, cq = lane & 7;
+    // every fetched-ahead input "used" once, before the first store (see epilogue_rows)
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        asm volatile("" : "+v"(ein0[k]));
+        if constexpr (EPI == EPI_DGRAD) asm volatile("" : "+v"(ein1[k]));
+    }
+    const int cl = wn * 64 + 8 * cq;                   // this lane's first column within the tile
+    const f32x4 al0 = *reinterpret_cast<const f32x4*>(colf + cl), al1 = *reinterpret_cast<const f32x4*>(colf + cl + 4);
+    const float al[8] = {al0[0], al0[1], al0[2], al0[3], al1[0], al1[1], al1[2], al1[3]};
+    float bi[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == EPI_FWD) {
+        if (ep.has_bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(colf + BN + cl), b1 = *reinterpret_cast<const f32x4*>(colf + BN + cl + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bi[e] = b0[e]; bi[4 + e] = b1[e]; }
+        }
+    }
+    const bool act = ep.act;
+    auto bf8 = [&](const u32x4& h, float (&dst)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dst[2 * e] = __builtin_bit_cast(float, h[e] << 16); dst[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xffff0000u); }
+    };
+#pragma unroll
+    for (int r0 = 0; r0 < TM * 32; r0 += STG) {
+        const int i = r0 / 32, lo = r0 % 32;
+        if (li >= lo && li < lo + STG) {               // the rows of this pass: lane = row
+            const int r = li - lo;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = j * 8 + 2 * g + lh;
+                    *reinterpret_cast<f32x4*>(stg + r * 256 + ((ch ^ (r & 15)) << 4)) =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                }
+        }
+        // lanes exchange data through LDS: without the fence the compiler may keep a lane that did not write in this pass on the
+        // value it read in the pass before (a thread's own view of memory it did not touch) -- it did, in the forward instantiation
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < STG / 8; ++u) {
+            const int k = r0 / 8 + u, r = 8 * u + rr;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(stg + r * 256 + (((2 * cq) ^ (r & 15)) << 4));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(stg + r * 256 + (((2 * cq + 1) ^ (r & 15)) << 4));
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            const bool in = m_wave + 8 * k + rr < ep.M;
+            const long o = base + (long)(8 * k) * ep.N;           // (c_ld = N for the layers this kernel takes)
+            auto st16 = [&](g_u16* dst, const float (&x)[8]) __attribute__((always_inline)) {
+                if (dst && in) *(g_u32x4*)(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
+            };
+            if constexpr (EPI == EPI_FWD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bi[e];
+                st16(ep.o0, v);
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : al[e] * v[e];
+                }
+                float rs[8];
+                bf8(ein0[k], rs);                        // zeros when there is no shortcut
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rs[e];
+                st16(ep.o1, v);
+            } else {
+                float ad[8], z[8];
+                bf8(ein0[k], ad);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ad[e];
+                st16(ep.o0, v);
+                if (act) {
+                    bf8(ein1[k], z);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        carry[e] += in ? v[e] * fminf(z[e], 0.f) : 0.f;
+                        v[e] *= prelu_slope(z[e], al[e]);
+                        carry[8 + e] += in ? v[e] : 0.f;
+                    }
+                }
+                st16(ep.o1, v);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one unit at a time: scheduled across units, the unpacked inputs of all eight are live at once (94 spilled registers)
+        }
+    }
+    if constexpr (EPI == EPI_DGRAD) {
+        constexpr int NH = BM / 128, WH = WM / NH;          // 128-row parts of the tile, row-waves per part
+        if (ep.PA && !flush) {
+            // the block's next tile has the same columns: the sums stay in registers, this tile's partial rows are zero
+            if (tid < BN * NH) {
+                const int h = tid / BN, c = tid - h * BN;
+                if (ep.m_base + (mt * NH + h) * 128 < ep.M) {
+                    const long o = (long)(ep.prow0 + mt * NH + h) * ep.N + n0 + c;
+                    ep.PA[o] = 0.f;
+                    if (ep.PB) ep.PB[o] = 0.f;
+                }
+            }
+        } else if (ep.PA) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float x = carry[e];
+                x += __shfl_xor(x, 8);
+                x += __shfl_xor(x, 16);
+                x += __shfl_xor(x, 32);
+                carry[e] = x;
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[wm * BN + cl + e] = carry[e];
+                    red[(WM + wm) * BN + cl + e] = carry[8 + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) carry[e] = 0.f;
+            __syncthreads();
+            if (tid < BN * NH) {
+                const int h = tid / BN, c = tid - h * BN;
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int w = 0; w < WH; ++w) {
+                    sa += red[(h * WH + w) * BN + c];
+                    sb += red[(WM + h * WH + w) * BN + c];
+                }
+                if (ep.m_base + (mt * NH + h) * 128 < ep.M) {
+                    const long o = (long)(ep.prow0 + mt * NH + h) * ep.N + n0 + c;
+                    ep.PA[o] = sa;
+                    if (ep.PB) ep.PB[o] = sb;
+                }
+            }
+        }
+    }
 }
 
 // a counted vmcnt whose count is only known at run time (wave-uniform): the largest listed count <= n (waiting for more is safe)
@@ -1444,7 +1620,8 @@ hipError_t launch16r(const IgemmParams& p, hipStream_t st) {
 // K-step the two consumer waves of a SIMD fill the MFMA pipe for ~1050, the rest is the barrier -- waiting for the slowest of twelve
 // waves -- and loop overhead): four B stages, consumers run two K-steps (32 MFMAs per wave) between barriers, loaders fill the
 // other two stages meanwhile; the window shrinks to the layers' real need (WCAP = 45) to make room in the 160 KB.
-template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int KS = 1, int DBG = 0>
+// STG = rows per pass of the row-coalesced epilogue (epilogue_staged; 0 = the register epilogue epilogue_rows)
+template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int KS = 1, int STG = 0, int DBG = 0>
 __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(const IgemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NCW = WM * WN, NSTB = KS == 1 ? 3 : 2 * KS;
     constexpr int KB = BN / 8 / NLW;                    // B pieces per loader wave and K-step
@@ -1456,6 +1633,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
     char* const bring = smem16 + 2 * WINB;
     float* const colf2 = reinterpret_cast<float*>(bring + NSTB * BSTAGE);  // [2][2][BN]
     float* const red = colf2 + 4 * BN;                                     // [2][WM][BN]
+    char* const stgfix = reinterpret_cast<char*>(red + 2 * WM * BN);       // STG > 0, KS = 1: [NCW][STG] rows of 256 bytes (KS = 2: in the B ring)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1614,7 +1792,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                     tau += 2;
                     if (tau >= 9) { tau -= 9; ++ch; ++gc; wstart = tau == 1; }      // tau == 1: the new chunk began at this interval's second K-step
                 }
-                if (epi_barrier) __builtin_amdgcn_s_barrier();
+                if constexpr (STG > 0) __builtin_amdgcn_s_barrier();      // the consumers stage their epilogue in the ring half the last interval read
+                if (epi_barrier && (!hasnext || (xbase + nidx) % ntn != (xbase + idx) % ntn || (p.ptiles_dbg & 16))) __builtin_amdgcn_s_barrier();      // the consumers' flush
                 if (!hasnext) break;
                 idx = nidx;
             }
@@ -1662,7 +1841,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                 stage = stage + 1 == NSTB ? 0 : stage + 1;
                 if (++tau == 9) { tau = 0; ++ch; ++gc; }
             }
-            if (epi_barrier) __builtin_amdgcn_s_barrier();           // the consumers' epilogue holds one block barrier
+            if (epi_barrier && (!hasnext || (xbase + nidx) % ntn != (xbase + idx) % ntn || (p.ptiles_dbg & 16))) __builtin_amdgcn_s_barrier();   // the consumers' flush holds one block barrier
             if (!hasnext) break;
             idx = nidx;
         }
@@ -1714,6 +1893,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
     const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
     const EpiPtrs ep = epi_ptrs<EPI>(p);
     int stage = 0, kt = 0, gc = 0, n0_colf = -1, kt_dbg = 0;
+    float carry[STG > 0 ? 16 : 2 * TN];                // dalpha / dbias column sums carried across this block's tiles (epilogue_rows / _staged)
+#pragma unroll
+    for (int j = 0; j < (STG > 0 ? 16 : 2 * TN); ++j) carry[j] = 0.f;
+    constexpr int NU = TM * 4;                         // STG > 0: units of eight rows per wave (lane = row lane >> 3, columns 8 (lane & 7) ..)
+    const int rr = lane >> 3, cq = lane & 7;
     for (;;) {
         const int tile = xbase + idx;
         const int mt = tile / ntn, nt_ = tile - mt * ntn;
@@ -1771,13 +1955,25 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { ein0[i][j][q] = u32x4{0u, 0u, 0u, 0u}; ein1[i][j][q] = u32x4{0u, 0u, 0u, 0u}; }
+        u32x4 es0[NU], es1[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) { es0[k] = u32x4{0u, 0u, 0u, 0u}; es1[k] = u32x4{0u, 0u, 0u, 0u}; }
+        const int m_wave = m0 + wm * (TM * 32);
+        const long sbase = (long)(m_wave + rr) * p.c_ld + n0 + wn * (TN * 32) + 8 * cq;      // element offset of this lane's unit 0
 
         for (int t = 0, tau = 0; t < nk; ++t) {
             unsigned long long st0 = 0, st1 = 0;
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             if (KS == 1 || (t & 1) == 0) __builtin_amdgcn_s_barrier();
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
-            if (t == nk - 1 && in16) {                  // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
+            if (STG > 0 && t == nk - 1 && in16) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k) {
+                    const long o = m_wave + 8 * k + rr < p.M ? sbase + (long)(8 * k) * p.c_ld : 8 * cq;
+                    if (ep.i0) es0[k] = *(g_cu32x4*)(ep.i0 + o);
+                }
+            }
+            if (STG == 0 && t == nk - 1 && in16) {      // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1806,7 +2002,16 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             stage = stage + 1 == NSTB ? 0 : stage + 1;
             if (++tau == 9) { tau = 0; ++gc; }
         }
-        if constexpr (EPI == EPI_DGRAD) {          // the second input (previous z) only now: 64 more registers under the last K-step would spill
+        if constexpr (EPI == EPI_DGRAD && STG > 0) {
+            if (ep.i1) {
+#pragma unroll
+                for (int k = 0; k < NU; ++k) {
+                    const long o = m_wave + 8 * k + rr < p.M ? sbase + (long)(8 * k) * p.c_ld : 8 * cq;
+                    es1[k] = *(g_cu32x4*)(ep.i1 + o);
+                }
+            }
+        }
+        if constexpr (EPI == EPI_DGRAD && STG == 0) {          // the second input (previous z) only now: 64 more registers under the last K-step would spill
             if (ep.i1) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -1822,7 +2027,22 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
         unsigned long long se0 = 0;
         if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); se0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
         unsigned long long estv[6] = {0, 0, 0, 0, 0, 0};
-        epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh, DBG ? estv : nullptr);
+        const bool flush = !hasnext || (xbase + nidx) % ntn != nt_ || (p.ptiles_dbg & 16);       // the block's next tile has other columns (or there is none)
+        if constexpr (STG > 0) {
+            char* stg;
+            if constexpr (KS == 2) {
+                // the ring half of the last interval (the loaders refill it after the NEXT tile's first barrier); every consumer must
+                // have read its last B fragments first: one block barrier, matched by the loaders
+                __builtin_amdgcn_s_barrier();
+                stg = bring + ((stage + 2) & 3) * BSTAGE + wid * (STG * 256);
+                static_assert(KS != 2 || NCW * STG * 256 <= 2 * BSTAGE, "staging fits the ring half");
+            } else {
+                stg = stgfix + wid * (STG * 256);
+            }
+            epilogue_staged<BM, BN, WM, WN, EPI, STG>(ep, acc, stg, sbase, m_wave, es0, es1, colf, red, mt, n0, tid, wm, wn, lane, carry, flush);
+        } else {
+            epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh, DBG ? estv : nullptr, carry, flush);
+        }
         if constexpr (DBG) {
             if (blockIdx.x == 0 && wid == 0 && lane == 0 && kt_dbg == 1) {
                 unsigned long long* o = stamps + (1 * 80 + 76) * 4;
@@ -1850,7 +2070,7 @@ static bool launch16rw_ok(const IgemmParams& p, int BM, int wcap) {
     if (p.a_NT != 9 || p.a_stride != 1 || p.a_OH != p.a_IH || p.a_OW != p.a_IW || p.a_KC % BK16 || p.K != 9 * p.a_KC) return false;
     for (int t = 0; t < 9; ++t)
         if (p.a_dh[t] < -1 || p.a_dh[t] > 1 || p.a_dw[t] < -1 || p.a_dw[t] > 1) return false;
-    if (p.m_base != 0) return false;
+    if (p.m_base != 0 || p.c_OH != 0 || p.c_ld != p.N) return false;      // (rows stored at m * N: what the row-coalesced epilogue assumes)
     // widest window: BM pixels spread over padded rows / images, plus a padded row and a slot on either side
     const long H = p.a_IH, W = p.a_IW, hw = H * W;
     const long imgx = (BM + hw - 1) / hw, rowx = (BM - 1) / W + 1;       // image / row boundaries BM consecutive pixels can cross
@@ -1858,16 +2078,18 @@ static bool launch16rw_ok(const IgemmParams& p, int BM, int wcap) {
     return (span + 7) / 8 <= wcap;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int KS = 1>
+template <int BM, int BN, int WM, int WN, int EPI, int NLW, int PFD, int WCAP, int KS = 1, int STG = 0>
 hipError_t launch16rw(const IgemmParams& p, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
     IgemmParams q = p;
     q.ptiles = mt * nt;
     static const int dbg = getenv("FTE_IGEMM16_DBG") ? atoi(getenv("FTE_IGEMM16_DBG")) : 0;
     q.ptiles_dbg = dbg;
-    const size_t lds = (size_t)2 * WCAP * 1024 + (size_t)(KS == 1 ? 3 : 2 * KS) * BN * ROWB + (size_t)(4 * BN + 2 * WM * BN) * sizeof(float);
-    auto kern = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS>;
-    if (igemm_prof_on()) { const int ta[10] = {BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS, 0}; igemm_note_symbol("igemm16rw_kernel", ta, 10); }
+    const size_t lds = (size_t)2 * WCAP * 1024 + (size_t)(KS == 1 ? 3 : 2 * KS) * BN * ROWB + (size_t)(4 * BN + 2 * WM * BN) * sizeof(float) +
+                       (size_t)(STG > 0 && KS == 1 ? WM * WN * STG * 256 : 0);
+    static_assert(2 * WCAP * 1024 + (KS == 1 ? 3 : 2 * KS) * BN * ROWB + (4 * BN + 2 * WM * BN) * 4 + (STG > 0 && KS == 1 ? WM * WN * STG * 256 : 0) <= 160 * 1024, "LDS");
+    auto kern = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS, STG>;
+    if (igemm_prof_on()) { const int ta[11] = {BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS, STG, 0}; igemm_note_symbol("igemm16rw_kernel", ta, 11); }
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1887,7 +2109,7 @@ hipError_t launch16rw(const IgemmParams& p, hipStream_t st) {
     constexpr int THREADS = 64 * (WM * WN + NLW);
     static const bool stamps = getenv("FTE_IGEMM16_STAMP") != nullptr;
     if (stamps) {
-        auto dk = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS, 1>;
+        auto dk = igemm16rw_kernel<BM, BN, WM, WN, EPI, NLW, PFD, WCAP, KS, STG, 1>;
         static unsigned long long* buf = nullptr;
         const size_t nb = 2 * 80 * 4 * sizeof(unsigned long long);
         if (!buf) {
@@ -2066,12 +2288,22 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
     // 14x14x256 forward), a 256x128 tile without loader waves (0.209), fragment reads two / three sub-steps ahead at 128 registers
     // (spills: 0.168 / 0.170), four waves of 64x64 (0.168); the 128x128 data gradient on igemm16p (0.214 vs 0.202 per-tile).
     static const int pers = getenv("FTE_IGEMM16_PERSIST") ? atoi(getenv("FTE_IGEMM16_PERSIST")) : 1;
+    static const int stg_env = getenv("FTE_IGEMM16_STG") ? atoi(getenv("FTE_IGEMM16_STG")) : 1;      // A/B hook: 0 = the register epilogue everywhere
+    const bool stg = stg_env != 0, stg2 = stg_env == 2;
     if (pers && launch16p_ok(p, epi, tile, splits)) {
         const bool win = pers == 1 || pers == 22;
         if (tile == TILE_128x128) {
             // batch 512, ms on one box, per-tile kernel -> igemm16rw: forward 28x28x128 0.220 -> 0.155, 14x14x256 0.161 -> 0.138, 7x7x512
             // 0.185 -> 0.126; data gradient 0.293 -> 0.225, 0.198 -> 0.177, 0.215 -> 0.146
             if (pers == 1 && (p.K / BK16) % 2 == 0 && launch16rw_ok(p, 256, 45)) {      // two K-steps per barrier
+                // (the row-coalesced epilogue through the free half of the B ring: SLOWER here -- 28x28x128 forward 0.157 -> 0.180 ms,
+                // data gradient 0.220 -> 0.294 (94 spilled registers beside 64 accumulators and two fetched-ahead inputs), 14x14x256
+                // 0.140 -> 0.146 / 0.175 -> 0.211; the stamped forward epilogue stays at 11-13k cycles: the wait for the inputs and
+                // ~600 VALU instructions per wave, two waves per SIMD, are what is left of it.  FTE_IGEMM16_STG=2 selects it)
+                if (stg2) {
+                    if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 45, 2, 16>(p, st);
+                    return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 45, 2, 16>(p, st);
+                }
                 if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 45, 2>(p, st);
                 return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 45, 2>(p, st);
             }
@@ -2090,6 +2322,12 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
             // N = 64: 256 x 64 tile, consumers 64 x 32 (56x56x64 at batch 512: forward 0.42 -> 0.37 (igemm16p) -> 0.24 ms, data
             // gradient 0.62 -> 0.51 -> 0.42)
             if (win && launch16rw_ok(p, 256, 56)) {
+                // eight row-waves of 32 x 64 (whole 128-byte rows per wave) and the row-coalesced epilogue (epilogue_staged): 56x56x64 at
+                // batch 512 forward 0.2415 -> 0.2250 ms, data gradient 0.381 -> 0.338
+                if (stg && pers == 1) {
+                    if (epi == EPI_FWD) return launch16rw<256, 64, 8, 1, EPI_FWD, 4, 2, 56, 1, 8>(p, st);
+                    return launch16rw<256, 64, 8, 1, EPI_DGRAD, 4, 2, 56, 1, 8>(p, st);
+                }
                 if (epi == EPI_FWD) return launch16rw<256, 64, 4, 2, EPI_FWD, 4, 2, 56>(p, st);
                 return launch16rw<256, 64, 4, 2, EPI_DGRAD, 4, 2, 56>(p, st);
             }

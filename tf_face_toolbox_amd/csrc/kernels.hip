@@ -3,6 +3,7 @@
 // center / triplet heads, flat-arena momentum and Adam.  Wave = 64 lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <math.h>
 
 #include "kernels.h"
@@ -223,6 +224,13 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     float s0 = 0.f, s1 = 0.f;
     if (j < cols) {
         long r = r0 + rl;
+        for (; r + 28 < r1; r += 32) {              // eight loads in flight (a row lane's rows are a dependent chain of round trips otherwise)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[(r + 4 * u) * cols + j];
+            s0 += (v[0] + v[2]) + (v[4] + v[6]);
+            s1 += (v[1] + v[3]) + (v[5] + v[7]);
+        }
         for (; r + 4 < r1; r += 8) {
             s0 += in[r * cols + j];
             s1 += in[(r + 4) * cols + j];
@@ -235,6 +243,39 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         float v = ((sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c])) * scale;
         if (bias) v += bias[j % bmod];
         out[(long)blockIdx.y * cols + j] = v;
+    }
+}
+
+// Split-K slabs: out[j] = sum_r in[r, j] for a few (8..256) rows of a long (>= 4096, multiple of 4) column range -- the filter-gradient
+// partials.  reduce_rows_kernel above reads them with 4-byte loads, two in flight per thread, one thread column per 64: 30-220 us per
+// filter gradient of the bf16-storage step (13 % of it).  Here a thread owns FOUR columns (16-byte loads), its row lane takes every
+// RL-th row with eight loads in flight, and the RL row lanes of a block meet in LDS in a fixed order.  QB = column quads per block:
+// 64 (a wave reads 1 KiB of a row) for long rows, 16 (16 row lanes) when the columns alone would not fill the chip.
+template <int QB>
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int rows, long quads) {
+    constexpr int RL = 256 / QB;
+    __shared__ f32x4 sh[RL][QB];
+    const int cq = threadIdx.x % QB, rl = threadIdx.x / QB;
+    const long q = (long)blockIdx.x * QB + cq;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (q < quads) {
+        const f32x4* src = in + q;
+        int r = rl;
+        for (; r + 7 * RL < rows; r += 8 * RL) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(long)(r + u * RL) * quads];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; r < rows; r += RL) s += src[(long)r * quads];
+    }
+    sh[rl][cq] = s;
+    __syncthreads();
+    if (rl == 0 && q < quads) {
+        f32x4 t = sh[0][cq];
+#pragma unroll
+        for (int w = 1; w < RL; ++w) t += sh[w][cq];
+        out[q] = t;
     }
 }
 
@@ -709,11 +750,29 @@ hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* 
     // [rows, fold, cols/fold] is the same memory as [rows*fold, cols/fold]: folding is a reshape
     rows *= fold;
     cols /= fold;
+    static const bool slabs_off = getenv("FTE_REDUCE_SLABS") && atoi(getenv("FTE_REDUCE_SLABS")) == 0;      // A/B hook
+    if (!slabs_off && !in2 && !bias && scale == 1.f && rows >= 2 && rows < (1 << 20) && cols >= 4096 && cols % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) {
+        const long quads = cols / 4;
+        if (quads / 64 >= 1024 || rows < 32)
+            hipLaunchKernelGGL(reduce_slabs_kernel<64>, dim3((unsigned)((quads + 63) / 64)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(in),
+                               reinterpret_cast<f32x4*>(out), (int)rows, quads);
+        else
+            hipLaunchKernelGGL(reduce_slabs_kernel<16>, dim3((unsigned)((quads + 15) / 16)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(in),
+                               reinterpret_cast<f32x4*>(out), (int)rows, quads);
+        return hipGetLastError();
+    }
     const unsigned nz = in2 ? 2 : 1;
     const long cb = (cols + 63) / 64;
     long rs = 1;
     if (scratch && cb < 512 && rows >= 64) {
-        rs = 1024 / cb;
+        // two passes: a row lane walks rows / (4 rs) rows in the first and rs / 4 in the second -- balanced at rs = sqrt(rows) (12544
+        // partial rows of a 64-column layer: 1024 / cb = 784 splits left the second pass 196 dependent loads per lane, 29 us), more
+        // splits only while the first pass has less than a block per CU
+        rs = 1;
+        while (rs * rs < rows) ++rs;
+        if (rs < 256 / cb) rs = 256 / cb;
+        if (rs > 1024 / cb) rs = 1024 / cb;
         if (rs > rows / 16) rs = rows / 16;
         if (rs * cols * nz > REDUCE_SCRATCH_FLOATS) rs = REDUCE_SCRATCH_FLOATS / (cols * nz);
         if (rs < 1) rs = 1;

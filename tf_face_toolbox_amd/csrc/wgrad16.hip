@@ -96,6 +96,11 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     const int np = (kend - kbeg) / KP;
     float* const out = p.out + (long)split * p.slab;
 
+    // everything the per-K-piece address decode reads, pinned in scalar registers: left to the compiler, kernel arguments used inside
+    // the loop are re-fetched with s_load + a wait every time (the decode was a quarter of the kernel: 0.175 ms with it, 0.122 without)
+    unsigned long long magic_is = p.magic_is, magic_pw1 = p.magic_pw1;
+    int cin_ = p.cin, cout_ = p.cout, dbg_ = p.dbg;
+    asm volatile("" : "+s"(magic_is), "+s"(magic_pw1), "+s"(cin_), "+s"(cout_), "+s"(dbg_));
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dz), 0, p.dz_bytes, 0x00020000);
@@ -103,20 +108,26 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     // The slots of a DMA piece are consecutive and its first slot is wave-uniform: (image, padded row, padded column) of the first
     // slot come from SCALAR divisions (host-made reciprocals), a lane adds its row offset d < 16 and wraps -- ~10 vector instructions
     // per piece instead of two per-lane divisions (every VALU instruction of these waves costs the MFMA pipe issue cycles).
+    // (all per-lane arithmetic in 24-bit multiplies and adds: v_mul_lo_u32 / 64-bit multiplies run at a quarter of the rate, and with
+    // them the decode was a quarter of the kernel -- 0.175 ms with it, 0.122 without, 14x14x256)
     auto pixel_at = [&](int S0, int d) __attribute__((always_inline)) -> int {         // pixel of slot S0 + d (S0 wave-uniform, any sign; 0 <= d < 16), or -1
         const int Su = __builtin_amdgcn_readfirstlane(S0);
         const int neg = Su < 0 ? 1 : 0;                                  // a window that starts ahead of the tensor (> -IS): decode one image up
         const int S = Su + neg * IS;
-        const int img = (int)(((unsigned long long)(unsigned)S * p.magic_is) >> 40) - neg;
+        const int img = (int)(((unsigned long long)(unsigned)S * magic_is) >> 40) - neg;          // scalar unit
         const int rem = S - (img + neg) * IS;
-        const int r = (int)(((unsigned long long)(unsigned)rem * p.magic_pw1) >> 40);
+        const int r = (int)(((unsigned long long)(unsigned)rem * magic_pw1) >> 40);
         const int c = rem - r * PW1;
-        int cc = c + d, rr = r, ii = img;
-        const int wraps = (cc >= PW1 ? 1 : 0) + (cc >= 2 * PW1 ? 1 : 0);   // d < 16 <= 2 (W + 1) for W >= 7
-        cc -= wraps * PW1; rr += wraps;
-        if (rr > H) { rr -= H + 1; ++ii; }
+        const int mbase = img * HW - W - 1;                              // pixel = mbase + rr W + cc (+ HW past the image's last row)
+        int cc = c + d;
+        const int w1 = cc >= PW1 ? 1 : 0, w2 = cc >= 2 * PW1 ? 1 : 0;    // d < 16 <= 2 (W + 1) for W >= 7
+        cc -= w1 ? PW1 : 0; cc -= w2 ? PW1 : 0;
+        int rr = r + w1 + w2;
+        const bool over = rr > H;
+        rr -= over ? H + 1 : 0;
         const int sl = Su + d;
-        return (sl >= 0 && sl < KT && rr >= 1 && cc >= 1) ? ii * HW + (rr - 1) * W + (cc - 1) : -1;
+        const int m = mbase + __mul24(rr, W) + cc + (over ? HW : 0);
+        return (sl >= 0 && sl < KT && rr >= 1 && cc >= 1) ? m : -1;
     };
     // this wave's DMA pieces of K-piece `t` into ring stage `st`: piece ids wid, wid + 12, ...; ids < DZ_PIECES are dz rows
     // piece i of this wave for K-piece t: (source offset, destination inside the stage, which tensor); kind 0 = none
@@ -129,7 +140,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
             const int k = j * DZ_RPP + d;
             const int m = pixel_at(s0 + j * DZ_RPP, d);
             const int chunk = NNB >= 4 ? pos ^ ((k & 3) << 2) : pos ^ (((k >> 1) & 1) << 2);      // 128-byte rows: two 64-byte segments
-            voff = m >= 0 ? (unsigned)(m * p.cout + n0 + chunk * 8) * 2u : OOB;
+            voff = m >= 0 ? (unsigned)(__mul24(m, cout_) + n0 + chunk * 8) * 2u : OOB;
             dst = j * 1024; kind = 1;
         } else if (j < PIECES && (j - DZ_PIECES) * X_RPP < KP + 2 * PW1 + 2) {      // window rows actually read
             const int jx = j - DZ_PIECES;
@@ -137,17 +148,20 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
             const int r = jx * X_RPP + d;
             const int m = pixel_at(s0 - PW1 - 1 + jx * X_RPP, d);
             const int chunk = NCB == 1 ? pos : pos ^ (((r >> 1) & 1) << 2);
-            voff = m >= 0 ? (unsigned)(m * p.cin + c0 + chunk * 8) * 2u : OOB;
+            voff = m >= 0 ? (unsigned)(__mul24(m, cin_) + c0 + chunk * 8) * 2u : OOB;
             dst = KP * DZROW + jx * 1024; kind = 2;
         }
     };
     auto fire = [&](int st, unsigned voff, int dst, int kind) __attribute__((always_inline)) -> int {
         if (kind == 0) return 0;                       // (wave-uniform: this wave has no i-th piece)
+        if ((dbg_ & 4) && kind == 2) return 0;        // timing experiments (wrong results): no x pieces / no dz pieces
+        if ((dbg_ & 8) && kind == 1) return 0;
         dma16(kind == 2 ? rsrcX : rsrcD, smem + st * STAGE + dst, voff, 0);
         return 1;
     };
     auto issue_range = [&](int t, int st, int i0, int i1) __attribute__((always_inline)) -> int {
         int n = 0;
+        if (dbg_ & 16) return 0;                      // timing experiment: no address decode, no DMA
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             if (i < i0 || i >= i1) continue;
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
     // with every wave doing MFMAs first and DMAs last, the last of a SIMD's three waves exposed its whole DMA phase at the end of each
     // K-piece (period 4900 for 2300 cycles of MFMA).  The three tap groups (one wave of each per SIMD) take turns instead: group 1
     // issues its DMAs before its MFMAs, group 0 after, group 2 half and half.
-    const int npre = (p.dbg & 2) ? 0 : (tg == 1 ? MAXP : tg == 2 ? MAXP / 2 : 0);
+    const int npre = (dbg_ & 2) ? 0 : (tg == 1 ? MAXP : tg == 2 ? MAXP / 2 : 0);
 
     f32x16 acc[3][NB2];
 #pragma unroll
