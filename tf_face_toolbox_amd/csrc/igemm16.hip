@@ -540,6 +540,7 @@ struct EpiPtrs {
     g_cu16* i1;                  //          --                               Zin16 (null: no activation gradient)
     g_f32* PA; g_f32* PB;        // EPI_DGRAD: column partials (may be null)
     int has_bias, act, N, prow0, m_base, M;
+    int dbg;                     // timing experiments (FTE_IGEMM16_DBG): 32 = no epilogue stores, 64 = no epilogue input loads, 128 = no epilogue
 };
 template <class G, class T>
 __device__ __forceinline__ G* pin_sgpr(T* q) {                 // the pointer stays in scalar registers from here on
@@ -558,7 +559,7 @@ __device__ __forceinline__ EpiPtrs epi_ptrs(const IgemmParams& p) {
         e.PA = pin_sgpr<g_f32>(p.PA); e.PB = pin_sgpr<g_f32>(p.PB);
         e.has_bias = 0; e.act = p.Zin16 != nullptr;
     }
-    e.N = p.N; e.prow0 = p.prow0; e.m_base = p.m_base; e.M = p.M;
+    e.N = p.N; e.prow0 = p.prow0; e.m_base = p.m_base; e.M = p.M; e.dbg = p.ptiles_dbg;
     return e;
 }
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -625,7 +626,13 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                     for (int e = 0; e < 4; ++e) { dst[2 * e] = __builtin_bit_cast(float, h[e] << 16); dst[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xffff0000u); }
                 };
                 auto st16 = [&](g_u16* dst, const float (&x)[8]) {
-                    if (dst && off >= 0) *(g_u32x4*)(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
+                    // (nontemporal stores measured: forward unchanged, data gradient 0.221 -> 0.243 ms at 28x28x128 -- its outputs are the
+                    // next kernels' inputs)
+                    // On the 256 x 128 tile the ADDRESS pattern of these stores is not what costs: the same pieces sent to 8 rows x 128
+                    // contiguous bytes (wrong placement, same bytes) ran no faster (28x28x128 forward 0.168 -> 0.179 ms), while no stores at
+                    // all (FTE_IGEMM16_DBG=32) gives 0.137, no input loads (=64) 0.143 of 0.158, no epilogue (=128) 0.127 -- the bytes of
+                    // a tile leave in a burst at the end of its K loop, and the next tile's operand DMAs queue behind them.
+                    if (dst && off >= 0 && !(ep.dbg & 32)) *(g_u32x4*)(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
                 };
                 if constexpr (EPI == EPI_FWD) {
                     if (ep.has_bias) {
@@ -1973,7 +1980,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                     if (ep.i0) es0[k] = *(g_cu32x4*)(ep.i0 + o);
                 }
             }
-            if (STG == 0 && t == nk - 1 && in16) {      // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
+            if (STG == 0 && t == nk - 1 && in16 && !(p.ptiles_dbg & 64)) {      // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2012,7 +2019,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             }
         }
         if constexpr (EPI == EPI_DGRAD && STG == 0) {          // the second input (previous z) only now: 64 more registers under the last K-step would spill
-            if (ep.i1) {
+            if (ep.i1 && !(p.ptiles_dbg & 64)) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -2041,7 +2048,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             }
             epilogue_staged<BM, BN, WM, WN, EPI, STG>(ep, acc, stg, sbase, m_wave, es0, es1, colf, red, mt, n0, tid, wm, wn, lane, carry, flush);
         } else {
-            epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh, DBG ? estv : nullptr, carry, flush);
+            if (!(p.ptiles_dbg & 128) || flush)
+                epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh, DBG ? estv : nullptr, carry, flush);
         }
         if constexpr (DBG) {
             if (blockIdx.x == 0 && wid == 0 && lane == 0 && kt_dbg == 1) {
