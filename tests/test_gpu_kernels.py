@@ -231,6 +231,18 @@ def test_optimizers_and_reductions():
     check_maxabs(host(o), 0.5 * a.reshape(37, 4, 24).sum((0, 1)) + b, 1e-5, 'reduce_rows fold')
 
 
+@pytest.mark.parametrize('rows,cols', [(2, 4096), (7, 36868), (33, 147456), (129, 4100), (300, 36864), (42, 589824)])
+def test_reduce_rows_of_split_k_slabs(rows, cols):
+    """column sums of a few long rows: the 16-byte slab reduction (reduce_slabs_kernel<64> for long rows, <16> when the columns alone
+    would not fill the chip; ragged last block; row counts that are no multiple of the eight loads in flight) against float64."""
+    r = _rng(rows)
+    a = r.standard_normal((rows, cols)).astype(np.float32)
+    o = torch.empty(cols, device='cuda')
+    call('fte_reduce_rows', dev(a), o, None, 1, rows, cols, 1, 1.0, stream())
+    ref = a.astype(np.float64).sum(0)
+    check_maxabs(host(o), ref, 4e-6 * np.sqrt(rows) * 4, 'reduce_rows slabs %dx%d' % (rows, cols))
+
+
 def test_bad_arguments_are_rejected_not_run():
     from tf_face_toolbox_amd._lib import FteError
     y = torch.empty(4, device='cuda')
