@@ -122,16 +122,16 @@ def test_persistent_bf16_kernels_at_the_sizes_that_select_them():
                ['s16dgrad', 126, 28, 28, 128, 128, 1], ['s16fwd', 262, 14, 14, 256, 256, 1]], env, timeout=1500)
     _has(cs[0], 'igemm16rw_kernel<256,64,8,1,0,4,2,56,1,8,0>')         # K = 576: one barrier per K-step; row-coalesced epilogue
     _has(cs[1], 'igemm16rw_kernel<256,64,8,1,1,4,2,56,1,8,0>')
-    _has(cs[2], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0,0>')          # two K-steps per barrier
-    _has(cs[3], 'igemm16rw_kernel<256,128,4,2,1,4,2,45,2,0,0>')
-    _has(cs[4], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0,0>')
+    _has(cs[2], 'igemm16rw_kernel<256,128,4,2,0,4,1,45,2,0,0>')          # two K-steps per barrier
+    _has(cs[3], 'igemm16rw_kernel<256,128,4,2,1,4,1,45,2,0,0>')
+    _has(cs[4], 'igemm16rw_kernel<256,128,4,2,0,4,1,45,2,0,0>')
     # ... one barrier per K-step on the 256 x 128 tile as well (hook), and a 7x7x512 layer (the unsplit plan: 72 K-steps per tile)
     cs = _run([['s16fwd', 126, 28, 28, 128, 128, 1], ['s16dgrad', 126, 28, 28, 128, 128, 1]], dict(env, FTE_IGEMM16_PERSIST='22'), timeout=1500)
     _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,2,48,1,0,0>')
     _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,2,48,1,0,0>')
     cs = _run([['s16fwd', 336, 7, 7, 512, 512, 1], ['s16dgrad', 336, 7, 7, 512, 512, 1]], env, timeout=1500)
-    _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,2,45,2,0,0>')
-    _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,2,45,2,0,0>')
+    _has(cs[0], 'igemm16rw_kernel<256,128,4,2,0,4,1,45,2,0,0>')
+    _has(cs[1], 'igemm16rw_kernel<256,128,4,2,1,4,1,45,2,0,0>')
     # the register epilogue on the 256 x 64 tile (FTE_IGEMM16_STG=0) and the row-coalesced one through the B ring on 256 x 128 (=2)
     cs = _run([['s16fwd', 64, 56, 56, 64, 64, 1], ['s16dgrad', 64, 56, 56, 64, 64, 1]], dict(env, FTE_IGEMM16_STG='0'), timeout=1500)
     _has(cs[0], 'igemm16rw_kernel<256,64,4,2,0,4,2,56,1,0,0>')

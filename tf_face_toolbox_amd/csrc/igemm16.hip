@@ -1897,6 +1897,44 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // KS = 2: the two K-steps of a barrier interval as ONE stream of eight 16-deep sub-steps -- the fragments of the second K-step are
+    // fetched under the last MFMAs of the first (its stage and window have been complete since the interval's barrier); with one
+    // kstep() per K-step every K-step began with the MFMA pipe waiting for its first fragment reads, both waves of a SIMD at once
+    auto kstep2 = [&](int st0, int wb0, int tap0, int st1, int wb1, int tap1) {
+        const char* Bs[2] = {bring + st0 * BSTAGE, bring + st1 * BSTAGE};
+        const int sh[2] = {__builtin_amdgcn_readlane(tshift, tap0), __builtin_amdgcn_readlane(tshift, tap1)};
+        const int wb[2] = {wb0, wb1};
+        unsigned a0[2][TM];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int s_ = sl[i] + sh[h];
+                a0[h][i] = (unsigned)(wb[h] * WINB + (s_ << 7) + (((lh ^ (s_ >> 1)) & 7) << 4));
+            }
+        constexpr int NB = PFD + 1, NSUB = 2 * (BK16 / 16);
+        bf16x8 fa[NB][TM], fb[NB][TN];
+        auto ld = [&](int u, int b) {
+            const int h = u / (BK16 / 16), ks = u % (BK16 / 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[b][i] = *reinterpret_cast<const bf16x8*>(smem16 + (a0[h][i] ^ (unsigned)(ks << 5)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[b][j] = *reinterpret_cast<const bf16x8*>(Bs[h] + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
+        };
+#pragma unroll
+        for (int k0 = 0; k0 < PFD; ++k0) ld(k0, k0);
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+            if (u + PFD < NSUB) ld(u + PFD, (u + PFD) % NB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[u % NB][j], fa[u % NB][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
     const EpiPtrs ep = epi_ptrs<EPI>(p);
     int stage = 0, kt = 0, gc = 0, n0_colf = -1, kt_dbg = 0;
@@ -1973,14 +2011,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
             if (KS == 1 || (t & 1) == 0) __builtin_amdgcn_s_barrier();
             if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); st1 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
-            if (STG > 0 && t == nk - 1 && in16) {
+            if (STG > 0 && t == nk - KS && in16) {
 #pragma unroll
                 for (int k = 0; k < NU; ++k) {
                     const long o = m_wave + 8 * k + rr < p.M ? sbase + (long)(8 * k) * p.c_ld : 8 * cq;
                     if (ep.i0) es0[k] = *(g_cu32x4*)(ep.i0 + o);
                 }
             }
-            if (STG == 0 && t == nk - 1 && in16 && !(p.ptiles_dbg & 64)) {      // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
+            if (STG == 0 && t == nk - KS && in16 && !(p.ptiles_dbg & 64)) {      // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1995,7 +2033,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                             }
                         }
             }
-            kstep(stage, gc & 1, tau);
+            if constexpr (KS == 2) {
+                if ((t & 1) == 0) {
+                    const int tau1 = tau + 1 == 9 ? 0 : tau + 1, gc1 = tau + 1 == 9 ? gc + 1 : gc;
+                    kstep2(stage, gc & 1, tau, stage + 1, gc1 & 1, tau1);       // (stage is even here: stage + 1 < NSTB)
+                }
+            } else {
+                kstep(stage, gc & 1, tau);
+            }
             if constexpr (DBG) {
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned long long st2 = stamp_now();
@@ -2303,7 +2348,10 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         if (tile == TILE_128x128) {
             // batch 512, ms on one box, per-tile kernel -> igemm16rw: forward 28x28x128 0.220 -> 0.155, 14x14x256 0.161 -> 0.138, 7x7x512
             // 0.185 -> 0.126; data gradient 0.293 -> 0.225, 0.198 -> 0.177, 0.215 -> 0.146
-            if (pers == 1 && (p.K / BK16) % 2 == 0 && launch16rw_ok(p, 256, 45)) {      // two K-steps per barrier
+            // two K-steps per barrier, their fragments one stream (kstep2) with one sub-step fetched ahead: on one box, four alternating
+            // runs each, the per-step totals of the 28x28 / 14x14 / 7x7 layers 2.163 -> 2.141 ms forward, 2.840 -> 2.793 data gradient
+            // (two sub-steps ahead spills 13 / 25 registers there)
+            if (pers == 1 && (p.K / BK16) % 2 == 0 && launch16rw_ok(p, 256, 45)) {
                 // (the row-coalesced epilogue through the free half of the B ring: SLOWER here -- 28x28x128 forward 0.157 -> 0.180 ms,
                 // data gradient 0.220 -> 0.294 (94 spilled registers beside 64 accumulators and two fetched-ahead inputs), 14x14x256
                 // 0.140 -> 0.146 / 0.175 -> 0.211; the stamped forward epilogue stays at 11-13k cycles: the wait for the inputs and
@@ -2312,8 +2360,8 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
                     if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 45, 2, 16>(p, st);
                     return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 45, 2, 16>(p, st);
                 }
-                if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 45, 2>(p, st);
-                return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 2, 45, 2>(p, st);
+                if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 1, 45, 2>(p, st);
+                return launch16rw<256, 128, 4, 2, EPI_DGRAD, 4, 1, 45, 2>(p, st);
             }
             if (win && launch16rw_ok(p, 256, 48)) {
                 if (epi == EPI_FWD) return launch16rw<256, 128, 4, 2, EPI_FWD, 4, 2, 48>(p, st);
