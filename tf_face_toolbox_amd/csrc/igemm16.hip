@@ -542,6 +542,19 @@ struct EpiPtrs {
     int has_bias, act, N, prow0, m_base, M;
     int dbg;                     // timing experiments (FTE_IGEMM16_DBG): 32 = no epilogue stores, 64 = no epilogue input loads, 128 = no epilogue
 };
+// The same tensors as buffer resources, built where they are used from the pinned pointers.  A null tensor or a row beyond M: offset
+// EPI_OOB -- the load returns zeros, the store is dropped: the epilogue's memory instructions need no branch and no exec mask, so the
+// wait-count pass counts them exactly, and inputs fetched AFTER earlier stores are waited for without draining those.
+constexpr unsigned EPI_OOB = 0x80000000u;      // the resources cover 2 GiB (every tensor of these launches is smaller: set_bytes); this offset and its 16 bytes lie beyond
+                                               // (0xfffffff0 with 2^32 - 1 records FAULTED on ragged last tiles: the range check's offset + size wraps)
+template <class G>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t epi_rsrc(G* q) {
+    // (constant record count: a `null ? 0 : ~0` select became a v_cndmask, the resource sat in vector registers and every load / store
+    // of the epilogue was wrapped in a waterfall loop -- nullness goes into the OFFSET instead)
+    const unsigned long long a = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x80000000u, 0x00020000);
+}
 template <class G, class T>
 __device__ __forceinline__ G* pin_sgpr(T* q) {                 // the pointer stays in scalar registers from here on
     unsigned long long v = reinterpret_cast<unsigned long long>(q);
@@ -562,7 +575,7 @@ __device__ __forceinline__ EpiPtrs epi_ptrs(const IgemmParams& p) {
     e.N = p.N; e.prow0 = p.prow0; e.m_base = p.m_base; e.M = p.M; e.dbg = p.ptiles_dbg;
     return e;
 }
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool WAITALL = true>
 __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const int (&roff)[BM / WM / 32],
                                              u32x4 (&ein0)[BM / WM / 32][BN / WN / 32][2], u32x4 (&ein1)[BM / WM / 32][BN / WN / 32][2],
                                              const float* colf, float* red, int mt, int n0, int tid, int wm, int wn, int li, int lh,
@@ -573,22 +586,29 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
     // once, now.  Left to the first real use inside the conditional blocks below, its wait-count pass cannot tell how many stores were
     // issued since and writes vmcnt(0) before each piece -- every piece then waits for the stores of the piece before it to drain
     // (stamped: 11k cycles per 256 x 128 tile even alone on the chip).
+    // (WAITALL = false: the caller fetched the inputs of the later row blocks AFTER the K loop; every memory instruction below is
+    // unconditional, the pass counts the stores issued since and waits for those inputs with an exact vmcnt)
+    if constexpr (WAITALL) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                asm volatile("" : "+v"(ein0[i][j][q]));
-                if constexpr (EPI == EPI_DGRAD) asm volatile("" : "+v"(ein1[i][j][q]));
-            }
+                for (int q = 0; q < 2; ++q) {
+                    asm volatile("" : "+v"(ein0[i][j][q]));
+                    if constexpr (EPI == EPI_DGRAD) asm volatile("" : "+v"(ein1[i][j][q]));
+                }
+    }
     if (est) est[1] = stamp_now();
-    // column partials of this wave (dalpha, dbias).  `carry` (2 TN floats of the caller, zero at the start): the sums run on across the
-    // tiles of a resident block and reach the partial rows only when `flush` is set
-    float csa[TN], csb[TN];
+    // column partials of this wave (dalpha, dbias), one per 8-column piece.  `carry` (4 TN floats of the caller, zero at the start): the
+    // sums run on across the tiles of a resident block and reach the partial rows only when `flush` is set
+    float csa[TN][2], csb[TN][2];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { csa[j] = carry ? carry[j] : 0.f; csb[j] = carry ? carry[TN + j] : 0.f; }
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { csa[j][q] = carry ? carry[2 * j + q] : 0.f; csb[j][q] = carry ? carry[2 * TN + 2 * j + q] : 0.f; }
     const bool act = ep.act;
+    const __amdgpu_buffer_rsrc_t r_o0 = epi_rsrc(ep.o0), r_o1 = epi_rsrc(ep.o1), r_i0 = epi_rsrc(ep.i0), r_i1 = epi_rsrc(ep.i1);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int off = roff[i];
@@ -610,9 +630,9 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                     a[8 * g + 4 + e] = y;
                 }
             if (est && i == 0 && j == 0) est[2] = stamp_now();
-            float sa16[16], sb16[16];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+                float sa8[8], sb8[8];
                 if (est && i == 0 && j == 0 && q == 1) est[5] = stamp_now();
                 const int cl = wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
                 const long o = (long)(off < 0 ? 0 : off) + n0 + cl;
@@ -625,14 +645,15 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { dst[2 * e] = __builtin_bit_cast(float, h[e] << 16); dst[2 * e + 1] = __builtin_bit_cast(float, h[e] & 0xffff0000u); }
                 };
-                auto st16 = [&](g_u16* dst, const float (&x)[8]) {
+                auto st16 = [&](const __amdgpu_buffer_rsrc_t& dst, bool there, const float (&x)[8]) {
                     // (nontemporal stores measured: forward unchanged, data gradient 0.221 -> 0.243 ms at 28x28x128 -- its outputs are the
                     // next kernels' inputs)
                     // On the 256 x 128 tile the ADDRESS pattern of these stores is not what costs: the same pieces sent to 8 rows x 128
                     // contiguous bytes (wrong placement, same bytes) ran no faster (28x28x128 forward 0.168 -> 0.179 ms), while no stores at
                     // all (FTE_IGEMM16_DBG=32) gives 0.137, no input loads (=64) 0.143 of 0.158, no epilogue (=128) 0.127 -- the bytes of
                     // a tile leave in a burst at the end of its K loop, and the next tile's operand DMAs queue behind them.
-                    if (dst && off >= 0 && !(ep.dbg & 32)) *(g_u32x4*)(dst + o) = u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])};
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pkbf(x[0], x[1]), pkbf(x[2], x[3]), pkbf(x[4], x[5]), pkbf(x[6], x[7])}, dst,
+                                                           (off >= 0 && there && !(ep.dbg & 32)) ? (unsigned)o * 2u : EPI_OOB, 0, 0);
                 };
                 if constexpr (EPI == EPI_FWD) {
                     if (ep.has_bias) {
@@ -641,7 +662,7 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                         for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
                     }
                     if (est && i == 0 && j == 0 && q == 0) est[3] = stamp_now();
-                    st16(ep.o0, v);
+                    st16(r_o0, ep.o0 != nullptr, v);
                     if (est && i == 0 && j == 0 && q == 0) est[4] = stamp_now();
                     if (act) {
 #pragma unroll
@@ -651,51 +672,49 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                     bf8(ein0[i][j][q], rs);                      // zeros when there is no shortcut
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rs[e];
-                    st16(ep.o1, v);
+                    st16(r_o1, ep.o1 != nullptr, v);
                 } else {
                     float ad[8], z[8];
                     bf8(ein0[i][j][q], ad);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ad[e];
-                    st16(ep.o0, v);
+                    st16(r_o0, ep.o0 != nullptr, v);
                     if (act) {
                         bf8(ein1[i][j][q], z);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const bool in = off >= 0;
-                            sa16[8 * q + e] = in ? v[e] * fminf(z[e], 0.f) : 0.f;
+                            sa8[e] = in ? v[e] * fminf(z[e], 0.f) : 0.f;
                             v[e] *= prelu_slope(z[e], al[e]);
-                            sb16[8 * q + e] = in ? v[e] : 0.f;
+                            sb8[e] = in ? v[e] : 0.f;
                         }
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { sa16[8 * q + e] = 0.f; sb16[8 * q + e] = 0.f; }
+                        for (int e = 0; e < 8; ++e) { sa8[e] = 0.f; sb8[e] = 0.f; }
                     }
-                    st16(ep.o1, v);
-                }
-            }
-            if constexpr (EPI == EPI_DGRAD) {
-                if (ep.PA && act) {
-                    // halving butterfly over the 32 row-lanes: lane li ends with the sum of column 8 (c >> 3) ... c = li >> 1
-                    auto fold = [&](float (&x)[16]) -> float {
-                        float w8[8], w4[4], w2[2], w1;
-                        const bool h16 = li & 16, h8 = li & 8, h4 = li & 4, h2 = li & 2;
+                    st16(r_o1, ep.o1 != nullptr, v);
+                    if (ep.PA && act) {
+                        // halving butterfly over the 32 row-lanes, per 8-column piece (16 values at a time cost 32 live registers beside
+                        // the accumulators and the fetched-ahead inputs): lane li ends with the sum of column (li >> 2) & 7 of the piece
+                        auto fold = [&](float (&x)[8]) -> float {
+                            float w4[4], w2[2], w1;
+                            const bool h16 = li & 16, h8 = li & 8, h4 = li & 4;
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) w8[c] = (h16 ? x[c + 8] : x[c]) + __shfl_xor(h16 ? x[c] : x[c + 8], 16);
+                            for (int c = 0; c < 4; ++c) w4[c] = (h16 ? x[c + 4] : x[c]) + __shfl_xor(h16 ? x[c] : x[c + 4], 16);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) w4[c] = (h8 ? w8[c + 4] : w8[c]) + __shfl_xor(h8 ? w8[c] : w8[c + 4], 8);
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) w2[c] = (h4 ? w4[c + 2] : w4[c]) + __shfl_xor(h4 ? w4[c] : w4[c + 2], 4);
-                        w1 = (h2 ? w2[1] : w2[0]) + __shfl_xor(h2 ? w2[0] : w2[1], 2);
-                        return w1 + __shfl_xor(w1, 1);
-                    };
-                    csa[j] += fold(sa16);
-                    csb[j] += fold(sb16);
+                            for (int c = 0; c < 2; ++c) w2[c] = (h8 ? w4[c + 2] : w4[c]) + __shfl_xor(h8 ? w4[c] : w4[c + 2], 8);
+                            w1 = (h4 ? w2[1] : w2[0]) + __shfl_xor(h4 ? w2[0] : w2[1], 4);
+                            w1 += __shfl_xor(w1, 2);
+                            return w1 + __shfl_xor(w1, 1);
+                        };
+                        csa[j][q] += fold(sa8);
+                        csb[j][q] += fold(sb8);
+                    }
                 }
             }
         }
     }
-    int nst = TM * TN * 2 * ((ep.o0 ? 1 : 0) + (ep.o1 ? 1 : 0));      // stores issued (per wave; wave-uniform)
+    int nst = TM * TN * 2 * 2;                                         // stores issued per wave (those of a null tensor are issued and dropped)
     if constexpr (EPI == EPI_DGRAD) {
         if (ep.PA && !flush) {
             // A resident block whose next tile has the same columns keeps its sums in registers: this tile's partial rows are ZERO
@@ -712,20 +731,24 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                 }
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) { carry[j] = csa[j]; carry[TN + j] = csb[j]; }
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { carry[2 * j + q] = csa[j][q]; carry[2 * TN + 2 * j + q] = csb[j][q]; }
         } else if (ep.PA) {    // column partials (dalpha, dbias) per 128 rows -- the planner's partial rows -- reduced later in a fixed order
             if (carry) {
 #pragma unroll
-                for (int j = 0; j < 2 * TN; ++j) carry[j] = 0.f;
+                for (int j = 0; j < 4 * TN; ++j) carry[j] = 0.f;
             }
-            if ((li & 1) == 0) {
-                const int c16 = li >> 1;
+            if ((li & 3) == 0) {
+                const int c8 = li >> 2;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int c = wn * (TN * 32) + j * 32 + 16 * (c16 >> 3) + 8 * lh + (c16 & 7);
-                    red[wm * BN + c] = csa[j];
-                    red[(WM + wm) * BN + c] = csb[j];
-                }
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int c = wn * (TN * 32) + j * 32 + 16 * q + 8 * lh + c8;
+                        red[wm * BN + c] = csa[j][q];
+                        red[(WM + wm) * BN + c] = csb[j][q];
+                    }
             }
             __syncthreads();
             constexpr int NH = BM / 128, WH = WM / NH;          // 128-row parts of the tile, row-waves per part
@@ -1938,9 +1961,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
     const bool in16 = EPI == EPI_FWD ? p.R16 != nullptr : (p.ADD16 != nullptr || p.Zin16 != nullptr);
     const EpiPtrs ep = epi_ptrs<EPI>(p);
     int stage = 0, kt = 0, gc = 0, n0_colf = -1, kt_dbg = 0;
-    float carry[STG > 0 ? 16 : 2 * TN];                // dalpha / dbias column sums carried across this block's tiles (epilogue_rows / _staged)
+    float carry[STG > 0 ? 16 : 4 * TN];                // dalpha / dbias column sums carried across this block's tiles (epilogue_rows / _staged)
 #pragma unroll
-    for (int j = 0; j < (STG > 0 ? 16 : 2 * TN); ++j) carry[j] = 0.f;
+    for (int j = 0; j < (STG > 0 ? 16 : 4 * TN); ++j) carry[j] = 0.f;
     constexpr int NU = TM * 4;                         // STG > 0: units of eight rows per wave (lane = row lane >> 3, columns 8 (lane & 7) ..)
     const int rr = lane >> 3, cq = lane & 7;
     for (;;) {
@@ -2018,20 +2041,18 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                     if (ep.i0) es0[k] = *(g_cu32x4*)(ep.i0 + o);
                 }
             }
-            if (STG == 0 && t == nk - KS && in16 && !(p.ptiles_dbg & 64)) {      // (three or five K-steps ahead measured no better, although the stamps show 1.3-3 k cycles of wait here)
+            // the inputs of row block 0 before the last barrier interval, those of the later row blocks right after the K loop: BOTH
+            // inputs of the data gradient's first block are then fetched ahead in the registers one of them took for the whole tile
+            if (STG == 0 && t == nk - KS && in16 && !(p.ptiles_dbg & 64)) {
+                const __amdgpu_buffer_rsrc_t r_i0 = epi_rsrc(ep.i0), r_i1 = epi_rsrc(ep.i1);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
-                            if constexpr (EPI == EPI_FWD) {
-                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
-                            } else {
-                                if (ep.i0) ein0[i][j][q] = *(g_cu32x4*)(ep.i0 + o);
-                            }
-                        }
+                    for (int q = 0; q < 2; ++q) {
+                        const unsigned o = roff[0] < 0 ? EPI_OOB : (unsigned)(roff[0] + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh) * 2u;
+                        ein0[0][j][q] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, ep.i0 ? o : EPI_OOB, 0, 0);
+                        if constexpr (EPI == EPI_DGRAD) ein1[0][j][q] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, ep.i1 ? o : EPI_OOB, 0, 0);
+                    }
             }
             if constexpr (KS == 2) {
                 if ((t & 1) == 0) {
@@ -2063,23 +2084,27 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
                 }
             }
         }
-        if constexpr (EPI == EPI_DGRAD && STG == 0) {          // the second input (previous z) only now: 64 more registers under the last K-step would spill
-            if (ep.i1 && !(p.ptiles_dbg & 64)) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const long o = (long)(roff[i] < 0 ? 0 : roff[i]) + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
-                            ein1[i][j][q] = *(g_cu32x4*)(ep.i1 + o);
-                        }
-            }
-        }
         unsigned long long se0 = 0;
         if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); se0 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
         unsigned long long estv[6] = {0, 0, 0, 0, 0, 0};
         const bool flush = !hasnext || (xbase + nidx) % ntn != nt_ || (p.ptiles_dbg & 16);       // the block's next tile has other columns (or there is none)
+        if constexpr (STG == 0) {
+            // (before any store: vmcnt retires in order, a load issued behind the stores of row block 0 would be waited for together with
+            // them -- measured: data gradients 3.23 -> 3.50 ms per step with the loads of block 1 between the stores)
+            if (in16 && !(p.ptiles_dbg & 64)) {
+                const __amdgpu_buffer_rsrc_t r_i0 = epi_rsrc(ep.i0), r_i1 = epi_rsrc(ep.i1);
+#pragma unroll
+                for (int i = 1; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const unsigned o = roff[i] < 0 ? EPI_OOB : (unsigned)(roff[i] + n0 + wn * (TN * 32) + j * 32 + 16 * q + 8 * lh) * 2u;
+                            ein0[i][j][q] = __builtin_amdgcn_raw_buffer_load_b128(r_i0, ep.i0 ? o : EPI_OOB, 0, 0);
+                            if constexpr (EPI == EPI_DGRAD) ein1[i][j][q] = __builtin_amdgcn_raw_buffer_load_b128(r_i1, ep.i1 ? o : EPI_OOB, 0, 0);
+                        }
+            }
+        }
         if constexpr (STG > 0) {
             char* stg;
             if constexpr (KS == 2) {
@@ -2094,7 +2119,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             epilogue_staged<BM, BN, WM, WN, EPI, STG>(ep, acc, stg, sbase, m_wave, es0, es1, colf, red, mt, n0, tid, wm, wn, lane, carry, flush);
         } else {
             if (!(p.ptiles_dbg & 128) || flush)
-                epilogue_rows<BM, BN, WM, WN, EPI>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh, DBG ? estv : nullptr, carry, flush);
+                epilogue_rows<BM, BN, WM, WN, EPI, false>(ep, acc, roff, ein0, ein1, colf, red, mt, n0, tid, wm, wn, li, lh, DBG ? estv : nullptr, carry, flush);
         }
         if constexpr (DBG) {
             if (blockIdx.x == 0 && wid == 0 && lane == 0 && kt_dbg == 1) {
