@@ -635,7 +635,7 @@ __device__ __forceinline__ int epilogue_rows(const EpiPtrs& ep, f32x16 (&acc)[BM
                 float sa8[8], sb8[8];
                 if (est && i == 0 && j == 0 && q == 1) est[5] = stamp_now();
                 const int cl = wn * (TN * 32) + j * 32 + 16 * q + 8 * lh;
-                const long o = (long)(off < 0 ? 0 : off) + n0 + cl;
+                const int o = (off < 0 ? 0 : off) + n0 + cl;            // (32-bit: the resources cover 2 GiB)
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = a[8 * q + e];
