@@ -23,9 +23,6 @@
 #include "igemm_dev.h"
 #include "wgrad16.h"
 
-#ifndef WG_INTERLEAVE
-#define WG_INTERLEAVE 0
-#endif
 #ifndef WG_PFD
 #define WG_PFD 1
 #endif
@@ -98,76 +95,88 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
 
     // everything the per-K-piece address decode reads, pinned in scalar registers: left to the compiler, kernel arguments used inside
     // the loop are re-fetched with s_load + a wait every time (the decode was a quarter of the kernel: 0.175 ms with it, 0.122 without)
-    unsigned long long magic_is = p.magic_is, magic_pw1 = p.magic_pw1;
+    unsigned long long magic_is = p.magic_is;
     int cin_ = p.cin, cout_ = p.cout, dbg_ = p.dbg;
-    asm volatile("" : "+s"(magic_is), "+s"(magic_pw1), "+s"(cin_), "+s"(cout_), "+s"(dbg_));
+    asm volatile("" : "+s"(magic_is), "+s"(cin_), "+s"(cout_), "+s"(dbg_));
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dz), 0, p.dz_bytes, 0x00020000);
 
-    // The slots of a DMA piece are consecutive and its first slot is wave-uniform: (image, padded row, padded column) of the first
-    // slot come from SCALAR divisions (host-made reciprocals), a lane adds its row offset d < 16 and wraps -- ~10 vector instructions
-    // per piece instead of two per-lane divisions (every VALU instruction of these waves costs the MFMA pipe issue cycles).
-    // (all per-lane arithmetic in 24-bit multiplies and adds: v_mul_lo_u32 / 64-bit multiplies run at a quarter of the rate, and with
-    // them the decode was a quarter of the kernel -- 0.175 ms with it, 0.122 without, 14x14x256)
-    auto pixel_at = [&](int S0, int d) __attribute__((always_inline)) -> int {         // pixel of slot S0 + d (S0 wave-uniform, any sign; 0 <= d < 16), or -1
-        const int Su = __builtin_amdgcn_readfirstlane(S0);
-        const int neg = Su < 0 ? 1 : 0;                                  // a window that starts ahead of the tensor (> -IS): decode one image up
-        const int S = Su + neg * IS;
-        const int img = (int)(((unsigned long long)(unsigned)S * magic_is) >> 40) - neg;          // scalar unit
-        const int rem = S - (img + neg) * IS;
-        const int r = (int)(((unsigned long long)(unsigned)rem * magic_pw1) >> 40);
-        const int c = rem - r * PW1;
-        const int mbase = img * HW - W - 1;                              // pixel = mbase + rr W + cc (+ HW past the image's last row)
-        int cc = c + d;
-        const int w1 = cc >= PW1 ? 1 : 0, w2 = cc >= 2 * PW1 ? 1 : 0;    // d < 16 <= 2 (W + 1) for W >= 7
-        cc -= w1 ? PW1 : 0; cc -= w2 ? PW1 : 0;
-        int rr = r + w1 + w2;
-        const bool over = rr > H;
-        rr -= over ? H + 1 : 0;
-        const int sl = Su + d;
-        const int m = mbase + __mul24(rr, W) + cc + (over ? HW : 0);
-        return (sl >= 0 && sl < KT && rr >= 1 && cc >= 1) ? m : -1;
-    };
-    // this wave's DMA pieces of K-piece `t` into ring stage `st`: piece ids wid, wid + 12, ...; ids < DZ_PIECES are dz rows
-    // piece i of this wave for K-piece t: (source offset, destination inside the stage, which tensor); kind 0 = none
-    auto prepare = [&](int t, int i, unsigned& voff, int& dst, int& kind) __attribute__((always_inline)) {
-        const int s0 = kbeg + t * KP;
+    // Address decode of a DMA piece.  Its slots are consecutive and its first slot S0 is wave-uniform: (image, slot within the image)
+    // of S0 come from ONE scalar division (host-made reciprocal); a lane adds its row d < 16 and looks the pixel up in an LDS table --
+    // tab[s], s < IS + 16: pixel (within the image; + HW beyond it, i.e. in the next image) of padded slot s, a large negative number
+    // for a pad slot -- so a piece costs a lane ~9 vector instructions.  (Before the table: two divisions' worth of wraps and compares
+    // per lane, ~25 instructions per piece; every vector instruction of these waves costs the MFMA pipe issue cycles, and the decode
+    // was a quarter of the kernel: 0.167 ms with it, 0.122 without, 14x14x256.)  The table reads are inline assembly: the compiler
+    // writes vmcnt(0) in front of an LDS read that follows an LDS-DMA it cannot tell apart -- a wait for every DMA in flight.
+    int* const tab = reinterpret_cast<int*>(smem + NST * STAGE);
+    for (int s_ = tid; s_ < IS + 16; s_ += 64 * NWAVES) {
+        const int rem = s_ >= IS ? s_ - IS : s_;
+        const int r = rem / PW1, c = rem - r * PW1;
+        tab[s_] = (r >= 1 && c >= 1) ? (r - 1) * W + (c - 1) + (s_ >= IS ? HW : 0) : -(1 << 30);
+    }
+    __syncthreads();
+    // this wave's pieces of a K-piece: piece ids wid, wid + 12, ...; ids < DZ_PIECES are dz rows, then the x window rows actually read.
+    // Per piece, constant over the K-pieces: kind (0 none, 1 dz, 2 x), first slot relative to the K-piece's, destination inside the
+    // stage, this lane's row within the piece and its channel offset (source chunk swizzle included)
+    int pkind[MAXP], prel[MAXP], pdst[MAXP], pd[MAXP], pcst[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
         const int j = wid + NWAVES * i;
-        kind = 0; voff = OOB; dst = 0;
+        pkind[i] = 0; prel[i] = 0; pdst[i] = 0; pd[i] = 0; pcst[i] = 0;
         if (j < DZ_PIECES) {
             const int d = lane / (DZROW / 16), pos = lane % (DZROW / 16);
             const int k = j * DZ_RPP + d;
-            const int m = pixel_at(s0 + j * DZ_RPP, d);
             const int chunk = NNB >= 4 ? pos ^ ((k & 3) << 2) : pos ^ (((k >> 1) & 1) << 2);      // 128-byte rows: two 64-byte segments
-            voff = m >= 0 ? (unsigned)(__mul24(m, cout_) + n0 + chunk * 8) * 2u : OOB;
-            dst = j * 1024; kind = 1;
-        } else if (j < PIECES && (j - DZ_PIECES) * X_RPP < KP + 2 * PW1 + 2) {      // window rows actually read
+            pkind[i] = 1; prel[i] = j * DZ_RPP; pdst[i] = j * 1024; pd[i] = d; pcst[i] = n0 + chunk * 8;
+        } else if (j < PIECES && (j - DZ_PIECES) * X_RPP < KP + 2 * PW1 + 2) {
             const int jx = j - DZ_PIECES;
             const int d = lane / (XROW / 16), pos = lane % (XROW / 16);
             const int r = jx * X_RPP + d;
-            const int m = pixel_at(s0 - PW1 - 1 + jx * X_RPP, d);
             const int chunk = NCB == 1 ? pos : pos ^ (((r >> 1) & 1) << 2);
-            voff = m >= 0 ? (unsigned)(__mul24(m, cin_) + c0 + chunk * 8) * 2u : OOB;
-            dst = KP * DZROW + jx * 1024; kind = 2;
+            pkind[i] = 2; prel[i] = jx * X_RPP - PW1 - 1; pdst[i] = KP * DZROW + jx * 1024; pd[i] = d; pcst[i] = c0 + chunk * 8;
         }
-    };
-    auto fire = [&](int st, unsigned voff, int dst, int kind) __attribute__((always_inline)) -> int {
-        if (kind == 0) return 0;                       // (wave-uniform: this wave has no i-th piece)
-        if ((dbg_ & 4) && kind == 2) return 0;        // timing experiments (wrong results): no x pieces / no dz pieces
-        if ((dbg_ & 8) && kind == 1) return 0;
-        dma16(kind == 2 ? rsrcX : rsrcD, smem + st * STAGE + dst, voff, 0);
-        return 1;
-    };
+    }
     auto issue_range = [&](int t, int st, int i0, int i1) __attribute__((always_inline)) -> int {
         int n = 0;
         if (dbg_ & 16) return 0;                      // timing experiment: no address decode, no DMA
+        int tv[MAXP], mb[MAXP], su[MAXP];
+        unsigned ta[MAXP];
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            if (i < i0 || i >= i1) continue;
-            unsigned v; int d, k;
-            prepare(t, i, v, d, k);
-            n += fire(st, v, d, k);
+            tv[i] = 0; mb[i] = 0; su[i] = 0; ta[i] = (unsigned)(NST * STAGE);
+            if (i < i0 || i >= i1 || pkind[i] == 0) continue;
+            const int Su = __builtin_amdgcn_readfirstlane(kbeg + t * KP + prel[i]);
+            const int neg = Su < 0 ? 1 : 0;                                  // a window that starts ahead of the tensor (> -IS): one image up
+            const int S = Su + neg * IS;
+            const int img = (int)(((unsigned long long)(unsigned)S * magic_is) >> 40) - neg;          // scalar unit
+            const int rem0 = S - (img + neg) * IS;
+            mb[i] = img * HW; su[i] = Su;
+            ta[i] = (unsigned)(NST * STAGE) + (unsigned)(rem0 + pd[i]) * 4u;
+        }
+        // reads and their wait in ONE statement: the compiler takes an asm's outputs for complete and copied them to other registers
+        // right behind a lone ds_read (an absent piece reads tab[0])
+        static_assert(MAXP >= 1 && MAXP <= 4, "table reads");
+        if constexpr (MAXP == 4)
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(tv[0]), "=&v"(tv[1]), "=&v"(tv[2]), "=&v"(tv[3]) : "v"(ta[0]), "v"(ta[1]), "v"(ta[2]), "v"(ta[3]) : "memory");
+        else if constexpr (MAXP == 3)
+            asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(tv[0]), "=&v"(tv[1]), "=&v"(tv[2]) : "v"(ta[0]), "v"(ta[1]), "v"(ta[2]) : "memory");
+        else if constexpr (MAXP == 2)
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tv[0]), "=&v"(tv[1]) : "v"(ta[0]), "v"(ta[1]) : "memory");
+        else
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(tv[0]) : "v"(ta[0]) : "memory");
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            if (i < i0 || i >= i1 || pkind[i] == 0) continue;
+            if ((dbg_ & 4) && pkind[i] == 2) continue;      // timing experiments (wrong results): no x pieces / no dz pieces
+            if ((dbg_ & 8) && pkind[i] == 1) continue;
+            const int m = mb[i] + tv[i];                                    // pixel; negative for a pad slot or a slot ahead of the tensor
+            const bool ok = m >= 0 && su[i] + pd[i] < KT;
+            const unsigned voff = ok ? (unsigned)(__mul24(m, pkind[i] == 2 ? cin_ : cout_) + pcst[i]) * 2u : OOB;
+            dma16(pkind[i] == 2 ? rsrcX : rsrcD, smem + st * STAGE + pdst[i], voff, 0);
+            ++n;
         }
         return n;
     };
@@ -234,13 +243,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
         const bool fill = t + 2 < np;
         const int fst = st + 2 >= NST ? st + 2 - NST : st + 2;
         int nfill = 0;
-#if WG_INTERLEAVE
-        unsigned pv[MAXP]; int pd[MAXP], pk[MAXP];          // the next-but-one K-piece's DMA pieces: addresses now, the DMAs between the MFMA groups
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) { pv[i] = OOB; pd[i] = 0; pk[i] = 0; if (fill) prepare(t + 2, i, pv[i], pd[i], pk[i]); }
-#else
         if (fill) nfill = issue_range(t + 2, fst, 0, npre);
-#endif
         const unsigned sb = (unsigned)(st * STAGE);
         // fragments single-buffered (the registers of a 16-deep step are free once its six MFMAs are issued; the two other waves of the
         // SIMD cover the read latency): a second set does not fit beside six accumulators in 168 registers -- and a spill reloaded
@@ -258,9 +261,6 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
         for (int h = 0; h < KP / 16; ++h) {
             if (WG_PFD == 0) ld(h, 0);
             else if (h + 1 < KP / 16) ld(h + 1, (h + 1) & 1);
-#if WG_INTERLEAVE
-            if (h < MAXP) nfill += fire(fst, pv[h < MAXP ? h : 0], pd[h < MAXP ? h : 0], pk[h < MAXP ? h : 0]);      // one DMA piece per 16-deep step
-#endif
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -270,9 +270,7 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
 #if WG_STAMP
         unsigned long long s3_ = stamp_now();
 #endif
-#if !WG_INTERLEAVE
         if (fill) nfill += issue_range(t + 2, fst, npre, MAXP);
-#endif
 #if WG_STAMP
         {
             unsigned long long s4_ = stamp_now();
@@ -304,7 +302,9 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
 template <int CT, int BN, int XCAP>
 hipError_t launch(const Wgrad16Params& p, hipStream_t st) {
     constexpr int NST = 3;
-    const size_t lds = (size_t)NST * (KP * BN * 2 + XCAP * CT * 2) + 1024;
+    constexpr int TABCAP = (XCAP >= 192 ? 57 * 57 : 31 * 31) + 16;      // slot table: the widest layer of this configuration (wgrad16_plan)
+    if ((p.H + 1) * (p.W + 1) + 16 > TABCAP) return hipErrorInvalidValue;
+    const size_t lds = (size_t)NST * (KP * BN * 2 + XCAP * CT * 2) + 1024 + (size_t)TABCAP * sizeof(int);
     auto kern = wgrad16_kernel<CT, BN, NST, XCAP>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -354,6 +354,7 @@ bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int*
     else if (w <= 30 && cout % 128 == 0 && cin % 64 == 0) { ct = 64; bn = 128; *cfg = 1; }
     else if (cout % 64 == 0 && cin % 64 == 0) { ct = 64; bn = 64; *cfg = 2; }             // the 64 -> 64 layers (56x56): 192 window rows
     else return false;
+    if ((long)(h + 1) * (w + 1) > (*cfg == 2 ? 57 * 57 : 31 * 31)) return false;      // the kernel's slot table (launch: TABCAP)
     static int cus = 0;
     if (!cus) {
         int dev = 0;
