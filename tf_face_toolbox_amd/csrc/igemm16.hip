@@ -1923,8 +1923,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
     // KS = 2: the two K-steps of a barrier interval as ONE stream of eight 16-deep sub-steps -- the fragments of the second K-step are
     // fetched under the last MFMAs of the first (its stage and window have been complete since the interval's barrier); with one
     // kstep() per K-step every K-step began with the MFMA pipe waiting for its first fragment reads, both waves of a SIMD at once
+    // (tried: B fragment addresses as lane constants with the stage as the read's immediate offset, the two stage pairs as two
+    // instantiations of this lambda behind a uniform branch -- the 64 accumulators then live across the branch and 179 / 356 registers spill)
     auto kstep2 = [&](int st0, int wb0, int tap0, int st1, int wb1, int tap1) {
         const char* Bs[2] = {bring + st0 * BSTAGE, bring + st1 * BSTAGE};
+        // (window addresses as integers of the LDS address space, base included once: with `smem16 + (a0 ^ ..)` every fragment read paid a
+        // vector add for the base -- 16 of the 55 vector instructions beside the 32 MFMAs of an interval, and each costs the pipe issue
+        // cycles; the dynamic LDS of this kernel starts at a multiple of 128, so the XOR of bits 5-6 commutes with the base)
+        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem16;
         const int sh[2] = {__builtin_amdgcn_readlane(tshift, tap0), __builtin_amdgcn_readlane(tshift, tap1)};
         const int wb[2] = {wb0, wb1};
         unsigned a0[2][TM];
@@ -1933,7 +1939,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int s_ = sl[i] + sh[h];
-                a0[h][i] = (unsigned)(wb[h] * WINB + (s_ << 7) + (((lh ^ (s_ >> 1)) & 7) << 4));
+                a0[h][i] = lds0 + (unsigned)(wb[h] * WINB + (s_ << 7) + (((lh ^ (s_ >> 1)) & 7) << 4));      // an LDS ADDRESS: the reads below add nothing
             }
         constexpr int NB = PFD + 1, NSUB = 2 * (BK16 / 16);
         bf16x8 fa[NB][TM], fb[NB][TN];
@@ -1941,7 +1947,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
             const int h = u / (BK16 / 16), ks = u % (BK16 / 16);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[b][i] = *reinterpret_cast<const bf16x8*>(smem16 + (a0[h][i] ^ (unsigned)(ks << 5)));
+                fa[b][i] = *(const __attribute__((address_space(3))) bf16x8*)(a0[h][i] ^ (unsigned)(ks << 5));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 fb[b][j] = *reinterpret_cast<const bf16x8*>(Bs[h] + b_row[j] * ROWB + (((2 * ks + lh) ^ ((b_row[j] >> 1) & 7)) << 4));
