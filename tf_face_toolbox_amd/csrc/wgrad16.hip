@@ -217,9 +217,13 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
         else x_off[a] = (unsigned)(KP * DZROW + r0 * XROW + (((col >> 3) ^ (((r0 >> 1) & 1) << 2)) << 4) + (col & 7) * 2);
     }
     // (CT = 64: the x swizzle is keyed by bit 1 of the window row; rows r0 + 16 h keep it, row + 4 keeps it: one offset per tap)
-    auto tr8 = [&](unsigned off, int rowbytes) __attribute__((always_inline)) -> bf16x8 {
-        const s16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + off));
-        const s16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(smem + off + 4 * rowbytes));
+    // (addresses as integers of the LDS address space: `base` = stage + this lane's fragment offset, once per K-piece; the sub-step and
+    // the second k-half are compile-time and end in the read's immediate offset -- through `smem + off` every read paid a vector add,
+    // 33 beside the 24 MFMAs of a K-piece, and each vector instruction of these waves costs the MFMA pipe issue cycles)
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    auto tr8 = [&](unsigned base, int imm, int rowbytes) __attribute__((always_inline)) -> bf16x8 {
+        const s16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(base + (unsigned)imm));
+        const s16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(base + (unsigned)(imm + 4 * rowbytes)));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
@@ -250,11 +254,16 @@ __global__ __launch_bounds__(64 * NWAVES, 1) void wgrad16_kernel(const Wgrad16Pa
         // inside this loop brings a vmcnt(0) with it, i.e. a wait for every DMA in flight
         constexpr int NB_ = WG_PFD + 1;
         bf16x8 fx[NB_][3], fd[NB_][NB2];
+        unsigned vd[NB2], vx[3];
+#pragma unroll
+        for (int b = 0; b < NB2; ++b) vd[b] = lds0 + sb + dz_off[b];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vx[a] = lds0 + sb + x_off[a];
         auto ld = [&](int h, int buf) __attribute__((always_inline)) {
 #pragma unroll
-            for (int b = 0; b < NB2; ++b) fd[buf][b] = tr8(sb + dz_off[b] + h * 16 * DZROW, DZROW);
+            for (int b = 0; b < NB2; ++b) fd[buf][b] = tr8(vd[b], h * 16 * DZROW, DZROW);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) fx[buf][a] = tr8(sb + x_off[a] + h * 16 * XROW, XROW);
+            for (int a = 0; a < 3; ++a) fx[buf][a] = tr8(vx[a], h * 16 * XROW, XROW);
         };
         if (WG_PFD) ld(0, 0);
 #pragma unroll
