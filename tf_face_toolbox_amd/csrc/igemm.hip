@@ -364,16 +364,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
             if constexpr (AL == AL_MK) {
                 fa[i] = *reinterpret_cast<const f32x4*>(As + row * BK + swz(row, 2 * u + lh));
             } else {
+                // (integer addresses of the LDS address space: lane part + stage once, the k index in the read's immediate offset --
+                // through `As[...]` on the generic pointer every read pair paid a vector add: 29 of the 73 vector instructions beside
+                // the 64 MFMAs of a filter-gradient K-step, and each costs the matrix pipe issue cycles)
+                const unsigned ab = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)As + (unsigned)((4 * lh * BM + row) * 4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) fa[i][t] = As[(8 * u + 4 * lh + t) * BM + row];
+                for (int t = 0; t < 4; ++t) fa[i][t] = *(const __attribute__((address_space(3))) float*)(ab + (unsigned)((8 * u + t) * BM * 4));
             }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = wn * (TN * 32) + j * 32 + li;
             if constexpr (BL == BL_KN) {
+                const unsigned bb = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)Bs + (unsigned)((4 * lh * BN + col) * 4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) fb[j][t] = Bs[(8 * u + 4 * lh + t) * BN + col];
+                for (int t = 0; t < 4; ++t) fb[j][t] = *(const __attribute__((address_space(3))) float*)(bb + (unsigned)((8 * u + t) * BN * 4));
             } else {
                 fb[j] = *reinterpret_cast<const f32x4*>(Bs + col * BK + swz(col, 2 * u + lh));
             }
@@ -727,6 +732,36 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                 kow_ = rem - koh_ * p.a_OW;
             }
         }
+        // KMF, hoisted out of the K loop (round 3: the loop had 73 vector instructions beside its 64 MFMAs, nine of them quarter-rate
+        // multiplies -- the tap of a load's 32-wide m group was re-derived by a division EVERY step and the source offset rebuilt from
+        // (n, oh, ow) with three multiplies; each vector instruction costs the matrix pipe issue cycles):
+        //   * per load i, wave-uniform and constant over the loop: its tap's (dh, dw), source offset and validity;
+        //   * the thread's source offset is ADVANCED: a step moves the pixel by 32 = q32 rows + r32 columns plus at most one row carry
+        //     and one image carry, i.e. by kd0 + (carry ? kdA : 0) + (image carry ? kdB : 0) bytes.
+        int kq_dh[A_CH], kq_dw[A_CH], kq_off[A_CH];
+        bool kq_ok[A_CH];
+        unsigned kbase = 0;
+        int kd0 = 0, kdA = 0, kdB = 0;
+        if constexpr (AL == AL_KM && BF == 0) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int mg = m0 + 32 * i;                         // wave-uniform: first m of this load's 32-wide group
+                const int t = mg / p.a_KC, c0 = mg - t * p.a_KC;
+                const int tt = t < p.a_NT ? t : 0;
+                kq_dh[i] = p.a_dh[tt]; kq_dw[i] = p.a_dw[tt];
+                kq_ok[i] = mg < p.M;
+                kq_off[i] = ((kq_dh[i] * p.a_IW + kq_dw[i]) * p.a_ld + c0) * 4;
+            }
+            kbase = (unsigned)(((kn_ * p.a_IH + koh_ * p.a_stride) * p.a_IW + kow_ * p.a_stride) * p.a_ld + ((tid & 7) << 2)) * 4u;
+            if (p.a_OH * p.a_OW == 1) {
+                kd0 = BK * p.a_IH * p.a_IW * p.a_ld * 4;            // 1 x 1 image: the pixel index IS n
+            } else {
+                const int q32 = BK / p.a_OW, r32 = BK - q32 * p.a_OW;
+                kd0 = (q32 * p.a_stride * p.a_IW + r32 * p.a_stride) * p.a_ld * 4;
+                kdA = (p.a_stride * p.a_IW - p.a_OW * p.a_stride) * p.a_ld * 4;
+                kdB = (p.a_IH - p.a_OH * p.a_stride) * p.a_IW * p.a_ld * 4;
+            }
+        }
         auto run_loop = [&](auto KMF_) {
         constexpr bool KMF = decltype(KMF_)::value;
         for (int s = 0; s < nsteps; ++s) {
@@ -771,26 +806,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
                 if (adv && !(p.a_OH * p.a_OW == 1)) {
                     const int q32 = BK / p.a_OW, r32 = BK - q32 * p.a_OW;              // scalars
                     kow_ += r32;
-                    const int c1 = kow_ >= p.a_OW ? 1 : 0;
+                    const bool c1 = kow_ >= p.a_OW;
                     kow_ -= c1 ? p.a_OW : 0;
-                    koh_ += q32 + c1;
-                    const int c2 = koh_ >= p.a_OH ? 1 : 0;
+                    koh_ += q32 + (c1 ? 1 : 0);
+                    const bool c2 = koh_ >= p.a_OH;
                     koh_ -= c2 ? p.a_OH : 0;
-                    kn_ += c2;
+                    kbase += (unsigned)(kd0 + (c1 ? kdA : 0) + (c2 ? kdB : 0));
                 } else if (adv) {
-                    kn_ += BK;                                                          // 1 x 1 image: the pixel index IS n
+                    kbase += (unsigned)kd0;
                 }
-                kih0 = koh_ * p.a_stride;
-                kiw0 = kow_ * p.a_stride;
-                const unsigned base = (unsigned)(((kn_ * p.a_IH + kih0) * p.a_IW + kiw0) * p.a_ld + ((tid & 7) << 2)) * 4u;
+                kih0 = __mul24(koh_, p.a_stride);
+                kiw0 = __mul24(kow_, p.a_stride);
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
-                    const int mg = m0 + 32 * i;                                         // wave-uniform: first m of this load's 32-wide group
-                    const int t = mg / p.a_KC, c0 = mg - t * p.a_KC;
-                    const int tt = t < p.a_NT ? t : 0;
-                    const int dh = p.a_dh[tt], dw = p.a_dw[tt];                         // scalars
-                    const bool ok = mg < p.M && (unsigned)(kih0 + dh) < (unsigned)p.a_IH && (unsigned)(kiw0 + dw) < (unsigned)p.a_IW;
-                    vk[i] = ok ? base + (unsigned)(((dh * p.a_IW + dw) * p.a_ld + c0) * 4) : OOB;
+                    const bool ok = kq_ok[i] && (unsigned)(kih0 + kq_dh[i]) < (unsigned)p.a_IH && (unsigned)(kiw0 + kq_dw[i]) < (unsigned)p.a_IW;
+                    vk[i] = ok ? kbase + (unsigned)kq_off[i] : OOB;
                 }
             } else {
                 const int pix = k0 + (tid >> 3);
