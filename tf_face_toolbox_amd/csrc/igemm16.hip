@@ -1938,8 +1938,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NLW), 1) void igemm16rw_kernel(cons
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int s_ = sl[i] + sh[h];
-                a0[h][i] = lds0 + (unsigned)(wb[h] * WINB + (s_ << 7) + (((lh ^ (s_ >> 1)) & 7) << 4));      // an LDS ADDRESS: the reads below add nothing
+                // row s_ at s_ << 7, its chunk lh at position (lh ^ (s_ >> 1)) & 7 -- written as shift, and, shift-or, xor-add (five
+                // vector instructions per fragment row and K-step instead of seven); an LDS ADDRESS: the reads below add nothing
+                const unsigned t1 = (unsigned)(sl[i] + sh[h]) << 3;
+                a0[h][i] = (((t1 << 4) | (t1 & 0x70u)) ^ (unsigned)(lh << 4)) + (lds0 + (unsigned)(wb[h] * WINB));
             }
         constexpr int NB = PFD + 1, NSUB = 2 * (BK16 / 16);
         bf16x8 fa[NB][TM], fb[NB][TN];
