@@ -208,6 +208,21 @@ def run_s16dgrad(n, h, w, cin, cout, stride, r):
     return syms, splits, errs, ok
 
 
+def run_s16wgrad1(n, h, w, cin, cout, stride, r):
+    """fte_conv2d_wgrad16 of a 1x1 conv: the pointwise resident kernel (wgrad16p_kernel) against the float64 product of the same bf16 inputs"""
+    x, x16 = _bf(r.standard_normal((n, h, w, cin), dtype=np.float32))
+    dz, dz16 = _bf(r.standard_normal((n, h, w, cout), dtype=np.float32))
+    dw = torch.empty(1, 1, cin, cout, device='cuda')
+    wsb, nb = ws(query('fte_conv2d_wgrad_ws_bytes', n, h, w, cin, cout, 1, stride))
+    _lib.query('fte_prof_enable', 1)
+    call('fte_conv2d_wgrad16', x16, dz16, dw, n, h, w, cin, cout, 1, stride, wsb, nb, stream())
+    _lib.query('fte_prof_enable', 0)
+    syms, splits = _records()
+    ref = x.reshape(-1, cin).astype(np.float64).T @ dz.reshape(-1, cout).astype(np.float64)
+    e, s = _maxabs(dw.cpu().numpy().astype(np.float64).reshape(cin, cout), ref)
+    return syms, splits, {'dw_maxabs_rel': e / s}, e / s <= TOL_MAXABS
+
+
 def run_s16wgrad(n, h, w, cin, cout, stride, r):
     """fte_conv2d_wgrad16 (bf16 x and dz in, fp32 dw out): the resident kernel of wgrad16.hip at the sizes that select it"""
     x, x16 = _bf(r.standard_normal((n, h, w, cin), dtype=np.float32))
@@ -234,7 +249,7 @@ def main():
     for ci, c in enumerate(cases):
         op, dims = c[0], [int(v) for v in c[1:]]
         r = np.random.default_rng(100 + ci)
-        syms, splits, errs, ok = {'fwd': run_fwd, 'dgrad': run_dgrad, 'wgrad': run_wgrad, 's16fwd': run_s16fwd, 's16dgrad': run_s16dgrad, 's16wgrad': run_s16wgrad}[op](*dims, r)
+        syms, splits, errs, ok = {'fwd': run_fwd, 'dgrad': run_dgrad, 'wgrad': run_wgrad, 's16fwd': run_s16fwd, 's16dgrad': run_s16dgrad, 's16wgrad': run_s16wgrad, 's16wgrad1': run_s16wgrad1}[op](*dims, r)
         out.append({'case': c, 'symbols': syms, 'splits': splits, 'errors': errs, 'ok': bool(ok)})
         ok_all = ok_all and ok
         torch.cuda.empty_cache()

@@ -596,6 +596,14 @@ size_t fte_conv2d_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
             if (gneed > need) need = gneed;
         }
     }
+    if (ksize == 1 && stride == 1) {                 // ... and the pointwise kernel's pixel-range slabs
+        Wgrad16Params g;
+        int cfg = 0;
+        if (wgrad16p_plan(n, h, wd, cin, cout, &g, &cfg) && g.S > 1) {
+            const size_t gneed = (size_t)g.S * g.slab * sizeof(float);
+            if (gneed > need) need = gneed;
+        }
+    }
     return need + SCRATCH_BYTES;
 }
 size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -627,6 +635,27 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
                                                (hipStream_t)stream);
                 hipError_t e = wgrad16_launch(g, cfg, (hipStream_t)stream);
                 igemm_prof_end(h, cfg == 0 ? "wgrad16_kernel<32,256,3,128>" : cfg == 1 ? "wgrad16_kernel<64,128,3,128>" : "wgrad16_kernel<64,64,3,192>", (hipStream_t)stream);
+                if (e != hipSuccess) return (int)e;
+                if (g.S > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, g.S, g.slab, 1, 1.f, nullptr, (hipStream_t)stream));
+                return FTE_OK;
+            }
+        }
+    }
+    if (src16 && ksize == 1 && stride == 1) {       // 1x1 convs: the pointwise resident kernel (wgrad16.hip: wgrad16p_kernel)
+        Wgrad16Params g;
+        int cfg = 0;
+        if (wgrad16p_plan(n, h, wd, cin, cout, &g, &cfg)) {
+            const size_t gneed = g.S > 1 ? (size_t)g.S * g.slab * sizeof(float) : 0;
+            const size_t xb = (size_t)n * h * wd * cin * 2, db = (size_t)n * h * wd * cout * 2;
+            if ((!gneed || (ws && ws_bytes >= gneed)) && xb < (1ull << 31) && db < (1ull << 31)) {
+                g.x = (const unsigned short*)x; g.dz = (const unsigned short*)dz;
+                g.out = g.S > 1 ? (float*)ws : dw;
+                g.x_bytes = (unsigned)xb; g.dz_bytes = (unsigned)db;
+                const int sig[5] = {AL_KM, BL_KN, EPI_FWD, 7, g.S};
+                const int hr = igemm_prof_begin(sig, cin, cout, K, 2.0 * cin * cout * (double)K, (double)xb + (double)db + (double)g.S * g.slab * 4.0,
+                                                (hipStream_t)stream);
+                hipError_t e = wgrad16p_launch(g, cfg, (hipStream_t)stream);
+                igemm_prof_end(hr, cfg == 0 ? "wgrad16p_kernel<128,256,2,4>" : cfg == 1 ? "wgrad16p_kernel<256,128,4,2>" : "wgrad16p_kernel<128,128,2,4>", (hipStream_t)stream);
                 if (e != hipSuccess) return (int)e;
                 if (g.S > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, g.S, g.slab, 1, 1.f, nullptr, (hipStream_t)stream));
                 return FTE_OK;

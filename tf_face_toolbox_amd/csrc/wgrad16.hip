@@ -50,6 +50,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    if (n >= 6) wait_vmcnt<6>(); else if (n >= 5) wait_vmcnt<5>(); else
     if (n >= 4) wait_vmcnt<4>(); else if (n >= 3) wait_vmcnt<3>(); else if (n >= 2) wait_vmcnt<2>(); else if (n >= 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
 }
 
@@ -353,6 +354,160 @@ hipError_t launch(const Wgrad16Params& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+
+// ---- 1x1 convs, stride 1 (the BN nets' bottlenecks): dW[cin][cout] = sum over pixels p of x[p][cin] dz[p][cout] -------------------
+// The same staging without taps, slots or address decode: a K-piece is 64 PIXELS, x tile [64][CT] and dz tile [64][BN] LDS-DMA'd as they
+// lie in memory (rows of 256 or 512 bytes; 16-byte chunk c of row k at c ^ ((k & 3) << 2), the swizzle on the DMA's source chunk), the
+// operands back through ds_read_b64_tr_b16, eight waves of (CT / WM) x (BN / WN) accumulators, three stages, one barrier per K-piece,
+// ranges of the pixel axis -> partial slabs.  The per-tile kernel (igemm.hip, BF = 2) ran these at ~6 % of the bf16 peak (46 us for a
+// launch whose operands are 77 MB): 17 vector instructions per MFMA in its loop.
+template <int CT, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 1) void wgrad16p_kernel(const Wgrad16Params p) {
+    constexpr int TM = CT / WM / 32, TN = BN / WN / 32, NST = 3, NW = 8;
+    static_assert(WM * WN == NW && CT >= 128 && BN >= 128 && TM >= 1 && TN >= 1, "eight waves; rows of at least 256 bytes");
+    constexpr int XROW = CT * 2, DROW = BN * 2;
+    constexpr int X_RPP = 1024 / XROW, D_RPP = 1024 / DROW;       // rows per 1-KiB DMA piece
+    constexpr int X_PIECES = KP / X_RPP, D_PIECES = KP / D_RPP, PIECES = X_PIECES + D_PIECES;
+    constexpr int MAXP = (PIECES + NW - 1) / NW;
+    static_assert(MAXP <= 6, "wait_vmcnt_upto");
+    constexpr int STAGE = KP * (XROW + DROW);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int npairs = (p.cin / CT) * (p.cout / BN);
+    int split, pair;
+    if (p.S >= 8) { split = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / npairs); pair = (blockIdx.x >> 3) % npairs; }
+    else { split = blockIdx.x % p.S; pair = blockIdx.x / p.S; }
+    const int c0 = (pair / (p.cout / BN)) * CT, n0 = (pair % (p.cout / BN)) * BN;
+    const int KT = p.n * p.H * p.W;                              // pixels
+    const int kbeg = split * p.kper;
+    const int kend = min(kbeg + p.kper, (KT + KP - 1) / KP * KP);
+    const int np = kend > kbeg ? (kend - kbeg) / KP : 0;
+    float* const out = p.out + (long)split * p.slab;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcD = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.dz), 0, p.dz_bytes, 0x00020000);
+    // this wave's DMA pieces of a K-piece (ids wid, wid + 8, ...; the first X_PIECES are x rows): constant over the K-pieces are the
+    // destination, this lane's row within the K-piece and its source offset at K-piece 0; a K-piece later the source is KP rows on
+    int pkind[MAXP], pdst[MAXP], prow[MAXP];
+    unsigned pv0[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int j = wid + NW * i;
+        pkind[i] = 0; pdst[i] = 0; prow[i] = 0; pv0[i] = 0;
+        if (j < X_PIECES) {
+            const int row = j * X_RPP + lane / (XROW / 16), pos = lane % (XROW / 16);
+            pkind[i] = 2; pdst[i] = j * 1024; prow[i] = row;
+            pv0[i] = (unsigned)((kbeg + row) * p.cin + c0 + ((pos ^ ((row & 3) << 2)) << 3)) * 2u;
+        } else if (j < PIECES) {
+            const int jd = j - X_PIECES;
+            const int row = jd * D_RPP + lane / (DROW / 16), pos = lane % (DROW / 16);
+            pkind[i] = 1; pdst[i] = KP * XROW + jd * 1024; prow[i] = row;
+            pv0[i] = (unsigned)((kbeg + row) * p.cout + n0 + ((pos ^ ((row & 3) << 2)) << 3)) * 2u;
+        }
+    }
+    const unsigned xstep = (unsigned)(KP * p.cin) * 2u, dstep = (unsigned)(KP * p.cout) * 2u;
+    auto issue = [&](int t, int st) __attribute__((always_inline)) -> int {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            if (pkind[i] == 0) continue;
+            const bool ok = kbeg + t * KP + prow[i] < KT;
+            const unsigned voff = ok ? pv0[i] + (unsigned)t * (pkind[i] == 2 ? xstep : dstep) : OOB;
+            dma16(pkind[i] == 2 ? rsrcX : rsrcD, smem + st * STAGE + pdst[i], voff, 0);
+            ++n;
+        }
+        return n;
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // transposing-read lane map (see wgrad16_kernel)
+    const int g4 = lane >> 4, idx = lane & 15;
+    const int kk = 8 * (g4 >> 1) + (idx >> 2);
+    const int mm = 16 * (g4 & 1) + 4 * (idx & 3);
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    unsigned x_off[TM], d_off[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int col = wm * (TM * 32) + a * 32 + mm;
+        x_off[a] = lds0 + (unsigned)(kk * XROW + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + (col & 7) * 2);
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = wn * (TN * 32) + b * 32 + mm;
+        d_off[b] = lds0 + (unsigned)(KP * XROW + kk * DROW + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + (col & 7) * 2);
+    }
+    auto tr8 = [&](unsigned base, int imm, int rowbytes) __attribute__((always_inline)) -> bf16x8 {
+        const s16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(base + (unsigned)imm));
+        const s16x4t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(base + (unsigned)(imm + 4 * rowbytes)));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    int n1 = 0;
+    if (np > 0) issue(0, 0);
+    if (np > 1) n1 = issue(1, 1);
+    int st = 0;
+    for (int t = 0; t < np; ++t) {
+        wait_vmcnt_upto(t + 1 < np ? n1 : 0);
+        __builtin_amdgcn_s_barrier();
+        const unsigned sb = (unsigned)(st * STAGE);
+        unsigned vx[TM], vd[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) vx[a] = sb + x_off[a];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) vd[b] = sb + d_off[b];
+        bf16x8 fx[2][TM], fd[2][TN];
+        auto ld = [&](int h, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fx[buf][a] = tr8(vx[a], h * 16 * XROW, XROW);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fd[buf][b] = tr8(vd[b], h * 16 * DROW, DROW);
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int h = 0; h < KP / 16; ++h) {
+            if (h + 1 < KP / 16) ld(h + 1, (h + 1) & 1);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[h & 1][a], fd[h & 1][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 2 < np) n1 = issue(t + 2, st + 2 >= NST ? st + 2 - NST : st + 2);
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[(long)(c0 + wm * (TM * 32) + a * 32 + row) * p.cout + n0 + wn * (TN * 32) + b * 32 + li] = acc[a][b][r];
+            }
+}
+
+template <int CT, int BN, int WM, int WN>
+hipError_t launch_p(const Wgrad16Params& p, hipStream_t st) {
+    const size_t lds = (size_t)3 * KP * (CT * 2 + BN * 2);
+    auto kern = wgrad16p_kernel<CT, BN, WM, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int npairs = (p.cin / CT) * (p.cout / BN);
+    hipLaunchKernelGGL(kern, dim3(p.S * npairs), dim3(512), lds, st, p);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int* cfg) {
@@ -391,4 +546,39 @@ bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int*
 
 hipError_t wgrad16_launch(const Wgrad16Params& p, int cfg, hipStream_t st) {
     return cfg == 0 ? launch<32, 256, 128>(p, st) : cfg == 1 ? launch<64, 128, 128>(p, st) : launch<64, 64, 192>(p, st);
+}
+
+// 1x1 / stride 1: cfg 0: 128 cin x 256 cout per block, 1: 256 x 128, 2: 128 x 128
+bool wgrad16p_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int* cfg) {
+    static const bool on = !(getenv("FTE_WGRAD16_POINTWISE") && atoi(getenv("FTE_WGRAD16_POINTWISE")) == 0);
+    if (!on) return false;
+    int ct, bn;
+    if (cin % 128 == 0 && cout % 256 == 0) { ct = 128; bn = 256; *cfg = 0; }
+    else if (cin % 256 == 0 && cout % 128 == 0) { ct = 256; bn = 128; *cfg = 1; }
+    else if (cin % 128 == 0 && cout % 128 == 0) { ct = 128; bn = 128; *cfg = 2; }
+    else return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        cus = prop.multiProcessorCount;
+    }
+    const int npairs = (cin / ct) * (cout / bn);
+    const long KT = (long)n * h * w;
+    const long pieces = (KT + KP - 1) / KP;
+    int S = cus / npairs;
+    if (S >= 8) S &= ~7; else if (S >= 4) S = 4; else if (S >= 2) S = 2; else S = 1;
+    while (S > 1 && pieces < 4L * S) S >>= 1;                    // at least four K-pieces per block
+    if (pieces < 4 || KT * (cin > cout ? cin : cout) * 2 >= (1L << 31)) return false;
+    p->kper = (int)((pieces + S - 1) / S) * KP;
+    p->S = S;
+    p->n = n; p->H = h; p->W = w; p->cin = cin; p->cout = cout;
+    p->slab = (long)cin * cout;
+    p->dbg = 0; p->stamps = nullptr; p->magic_is = 0; p->magic_pw1 = 0;
+    return true;
+}
+
+hipError_t wgrad16p_launch(const Wgrad16Params& p, int cfg, hipStream_t st) {
+    return cfg == 0 ? launch_p<128, 256, 2, 4>(p, st) : cfg == 1 ? launch_p<256, 128, 4, 2>(p, st) : launch_p<128, 128, 2, 4>(p, st);
 }
