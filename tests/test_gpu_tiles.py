@@ -167,12 +167,19 @@ def test_pointwise_resident_filter_gradient():
     ranges summed by the slab reduction -- the three channel tiles (128 x 256, 256 x 128, 128 x 128), a ragged last K-piece (pixel count
     no multiple of 64), few pixels (fewer ranges than CUs), and channel counts it leaves to the per-tile kernel."""
     cs = _run([['s16wgrad1', 37, 28, 28, 128, 256, 1], ['s16wgrad1', 128, 14, 14, 512, 128, 1], ['s16wgrad1', 9, 27, 29, 128, 128, 1],
-               ['s16wgrad1', 12, 7, 7, 1024, 2048, 1], ['s16wgrad1', 16, 14, 14, 64, 128, 1]], {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
+               ['s16wgrad1', 12, 7, 7, 1024, 2048, 1], ['s16wgrad1', 16, 14, 14, 64, 64, 1]], {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
     _has(cs[0], 'wgrad16p_kernel<128,256,2,4>')
     _has(cs[1], 'wgrad16p_kernel<256,128,4,2>')
     _has(cs[2], 'wgrad16p_kernel<128,128,2,4>')
     _has(cs[3], 'wgrad16p_kernel<128,256,2,4>')
     assert not any(s.startswith('wgrad16p') for s in cs[4]['symbols']), cs[4]['symbols']
+    # ... and the tiles with a 64-channel side (128-byte rows: the other swizzle key)
+    cs = _run([['s16wgrad1', 21, 28, 28, 64, 256, 1], ['s16wgrad1', 21, 28, 28, 256, 64, 1], ['s16wgrad1', 33, 14, 14, 64, 128, 1],
+               ['s16wgrad1', 33, 13, 15, 128, 64, 1]], {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
+    _has(cs[0], 'wgrad16p_kernel<64,256,1,8>')
+    _has(cs[1], 'wgrad16p_kernel<256,64,8,1>')
+    _has(cs[2], 'wgrad16p_kernel<64,128,2,4>')
+    _has(cs[3], 'wgrad16p_kernel<128,64,4,2>')
 
 
 def test_every_conv_symbol_of_the_headline_run_was_checked():

@@ -655,7 +655,9 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
                 const int hr = igemm_prof_begin(sig, cin, cout, K, 2.0 * cin * cout * (double)K, (double)xb + (double)db + (double)g.S * g.slab * 4.0,
                                                 (hipStream_t)stream);
                 hipError_t e = wgrad16p_launch(g, cfg, (hipStream_t)stream);
-                igemm_prof_end(hr, cfg == 0 ? "wgrad16p_kernel<128,256,2,4>" : cfg == 1 ? "wgrad16p_kernel<256,128,4,2>" : "wgrad16p_kernel<128,128,2,4>", (hipStream_t)stream);
+                static const char* const psym[7] = {"wgrad16p_kernel<128,256,2,4>", "wgrad16p_kernel<256,128,4,2>", "wgrad16p_kernel<128,128,2,4>", "wgrad16p_kernel<64,256,1,8>",
+                                                   "wgrad16p_kernel<256,64,8,1>", "wgrad16p_kernel<64,128,2,4>", "wgrad16p_kernel<128,64,4,2>"};
+                igemm_prof_end(hr, psym[cfg], (hipStream_t)stream);
                 if (e != hipSuccess) return (int)e;
                 if (g.S > 1) return rc(k_reduce_rows((const float*)ws, dw, nullptr, 1, g.S, g.slab, 1, 1.f, nullptr, (hipStream_t)stream));
                 return FTE_OK;

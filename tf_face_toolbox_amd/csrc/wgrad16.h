@@ -20,6 +20,6 @@ struct Wgrad16Params {
 // block); cfg selects the instantiation
 bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int* cfg);
 hipError_t wgrad16_launch(const Wgrad16Params& p, int cfg, hipStream_t st);
-// the same for 1x1 / stride-1 convs (wgrad16p_kernel): slabs of cin * cout floats; cfg 0 / 1 / 2 = 128x256 / 256x128 / 128x128 channel tiles
+// the same for 1x1 / stride-1 convs (wgrad16p_kernel): slabs of cin * cout floats; cfg = channel tile (128x256, 256x128, 128x128, 64x256, 256x64, 64x128, 128x64)
 bool wgrad16p_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int* cfg);
 hipError_t wgrad16p_launch(const Wgrad16Params& p, int cfg, hipStream_t st);

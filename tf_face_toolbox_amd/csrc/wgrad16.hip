@@ -364,13 +364,17 @@ hipError_t launch(const Wgrad16Params& p, hipStream_t st) {
 template <int CT, int BN, int WM, int WN>
 __global__ __launch_bounds__(512, 1) void wgrad16p_kernel(const Wgrad16Params p) {
     constexpr int TM = CT / WM / 32, TN = BN / WN / 32, NST = 3, NW = 8;
-    static_assert(WM * WN == NW && CT >= 128 && BN >= 128 && TM >= 1 && TN >= 1, "eight waves; rows of at least 256 bytes");
+    static_assert(WM * WN == NW && CT >= 64 && BN >= 64 && TM >= 1 && TN >= 1, "eight waves; rows of 128 bytes or more");
     constexpr int XROW = CT * 2, DROW = BN * 2;
     constexpr int X_RPP = 1024 / XROW, D_RPP = 1024 / DROW;       // rows per 1-KiB DMA piece
     constexpr int X_PIECES = KP / X_RPP, D_PIECES = KP / D_RPP, PIECES = X_PIECES + D_PIECES;
     constexpr int MAXP = (PIECES + NW - 1) / NW;
     static_assert(MAXP <= 6, "wait_vmcnt_upto");
     constexpr int STAGE = KP * (XROW + DROW);
+    // swizzle key of row k (XOR-ed into the 16-byte chunk index): four consecutive rows of >= 256 bytes share their banks -> two bits of
+    // k move the chunk by 64 bytes; rows of 128 bytes pair up -> one bit (the transposing read takes rows k, k+1, k+2, k+3 of 16 lanes)
+    auto xkey = [](int k) { return XROW >= 256 ? (k & 3) << 2 : ((k >> 1) & 1) << 2; };
+    auto dkey = [](int k) { return DROW >= 256 ? (k & 3) << 2 : ((k >> 1) & 1) << 2; };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -399,12 +403,12 @@ __global__ __launch_bounds__(512, 1) void wgrad16p_kernel(const Wgrad16Params p)
         if (j < X_PIECES) {
             const int row = j * X_RPP + lane / (XROW / 16), pos = lane % (XROW / 16);
             pkind[i] = 2; pdst[i] = j * 1024; prow[i] = row;
-            pv0[i] = (unsigned)((kbeg + row) * p.cin + c0 + ((pos ^ ((row & 3) << 2)) << 3)) * 2u;
+            pv0[i] = (unsigned)((kbeg + row) * p.cin + c0 + ((pos ^ xkey(row)) << 3)) * 2u;
         } else if (j < PIECES) {
             const int jd = j - X_PIECES;
             const int row = jd * D_RPP + lane / (DROW / 16), pos = lane % (DROW / 16);
             pkind[i] = 1; pdst[i] = KP * XROW + jd * 1024; prow[i] = row;
-            pv0[i] = (unsigned)((kbeg + row) * p.cout + n0 + ((pos ^ ((row & 3) << 2)) << 3)) * 2u;
+            pv0[i] = (unsigned)((kbeg + row) * p.cout + n0 + ((pos ^ dkey(row)) << 3)) * 2u;
         }
     }
     const unsigned xstep = (unsigned)(KP * p.cin) * 2u, dstep = (unsigned)(KP * p.cout) * 2u;
@@ -436,12 +440,12 @@ __global__ __launch_bounds__(512, 1) void wgrad16p_kernel(const Wgrad16Params p)
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const int col = wm * (TM * 32) + a * 32 + mm;
-        x_off[a] = lds0 + (unsigned)(kk * XROW + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + (col & 7) * 2);
+        x_off[a] = lds0 + (unsigned)(kk * XROW + (((col >> 3) ^ xkey(kk)) << 4) + (col & 7) * 2);
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = wn * (TN * 32) + b * 32 + mm;
-        d_off[b] = lds0 + (unsigned)(KP * XROW + kk * DROW + (((col >> 3) ^ ((kk & 3) << 2)) << 4) + (col & 7) * 2);
+        d_off[b] = lds0 + (unsigned)(KP * XROW + kk * DROW + (((col >> 3) ^ dkey(kk)) << 4) + (col & 7) * 2);
     }
     auto tr8 = [&](unsigned base, int imm, int rowbytes) __attribute__((always_inline)) -> bf16x8 {
         const s16x4t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4t*)(base + (unsigned)imm));
@@ -556,6 +560,10 @@ bool wgrad16p_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int
     if (cin % 128 == 0 && cout % 256 == 0) { ct = 128; bn = 256; *cfg = 0; }
     else if (cin % 256 == 0 && cout % 128 == 0) { ct = 256; bn = 128; *cfg = 1; }
     else if (cin % 128 == 0 && cout % 128 == 0) { ct = 128; bn = 128; *cfg = 2; }
+    else if (cin % 64 == 0 && cout % 256 == 0) { ct = 64; bn = 256; *cfg = 3; }
+    else if (cin % 256 == 0 && cout % 64 == 0) { ct = 256; bn = 64; *cfg = 4; }
+    else if (cin % 64 == 0 && cout % 128 == 0) { ct = 64; bn = 128; *cfg = 5; }
+    else if (cin % 128 == 0 && cout % 64 == 0) { ct = 128; bn = 64; *cfg = 6; }
     else return false;
     static int cus = 0;
     if (!cus) {
@@ -580,5 +588,13 @@ bool wgrad16p_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int
 }
 
 hipError_t wgrad16p_launch(const Wgrad16Params& p, int cfg, hipStream_t st) {
-    return cfg == 0 ? launch_p<128, 256, 2, 4>(p, st) : cfg == 1 ? launch_p<256, 128, 4, 2>(p, st) : launch_p<128, 128, 2, 4>(p, st);
+    switch (cfg) {
+    case 0: return launch_p<128, 256, 2, 4>(p, st);
+    case 1: return launch_p<256, 128, 4, 2>(p, st);
+    case 2: return launch_p<128, 128, 2, 4>(p, st);
+    case 3: return launch_p<64, 256, 1, 8>(p, st);
+    case 4: return launch_p<256, 64, 8, 1>(p, st);
+    case 5: return launch_p<64, 128, 2, 4>(p, st);
+    default: return launch_p<128, 64, 4, 2>(p, st);
+    }
 }
