@@ -55,7 +55,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                   # same table, "Peak BF16/FP16 M
 HBM_PEAK_GBPS = 8000.0                           # same table, HBM3E peak (spec)
 LR = 1e-4
 TILES = {0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64', 4: '192,64', 5: '64,64 (1 wave)', 6: '64,64 (2 waves)',   # igemm.h's TILE_* enum
-         7: '9 taps x 32|64 cin x 256|128 cout, resident (wgrad16.hip)'}
+         7: 'resident filter gradient (wgrad16.hip): 9 taps x 32|64 cin x 256|128 cout, or a 1x1 channel tile'}
 
 
 def kernel_src_sha():

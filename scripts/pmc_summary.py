@@ -38,7 +38,7 @@ def avg_by_kernel(rows, counter):
 
 def short(kernel_name):
     """'void (anonymous namespace)::igemm_kernel<64, 64, 2, 2, 0, 0, 0, 0>(IgemmParams)' -> bench.py's 'igemm_kernel<64,64,2,2,0,0,0,0>'."""
-    m = re.search(r'((?:igemm(?:16(?:rw|w|p|r)?)?|wgrad16)_kernel)<([^>]*)>', kernel_name)
+    m = re.search(r'((?:igemm(?:16(?:rw|w|p|r)?)?|wgrad16p?)_kernel)<([^>]*)>', kernel_name)
     return '%s<%s>' % (m.group(1), m.group(2).replace(' ', '')) if m else None
 
 
