@@ -323,6 +323,47 @@ int fte_gap_bwd_s16(const float* dy, uint16_t* dx16, int n, int hw, int c, void*
 int fte_gconv3x3_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* y16, int n, int h, int wd, int c, int stride, int dgrad, void* stream);
 int fte_gconv3x3_wgrad_bf16_s16(const uint16_t* x16, const uint16_t* dz16, float* dw, int n, int h, int wd, int c, int groups, int stride,
                                 void* ws, size_t ws_bytes, void* stream);
+/* ---------------------------------------------------------------------------
+ * BN FUSION: the conv -> batch_norm (-> ReLU) pairs of nets/resnet.py:47-61 (`conv_bn_relu`), nets/resnext.py:34-67,
+ * nets/shufflenet_v2.py:120-135.  TF runs Conv2D, FusedBatchNorm (statistics pass + normalise pass) and Relu as separate
+ * kernels, and FusedBatchNormGrad re-reads dy and x for its two sums; here the PRODUCING kernel leaves those per-channel
+ * sums behind, so each BN tensor makes one HBM round trip less in each direction:
+ *   forward   the conv epilogue keeps (n, mean, M2) of the values it stores -- per tile row and channel, Chan-merged, no
+ *             E[x^2] - E[x]^2 -- in `ws`; one finalize launch merges the tile rows in a fixed order -> mean, rstd (biased batch
+ *             variance, eps inside the root), scale = gamma * rstd, shift = beta - mean * scale, moving statistics (decay, unbiased
+ *             variance) exactly as fte_bn_train_stats.  The caller normalises with fte_bn_apply (or the consumer folds it in).
+ *   backward  the data gradient that lands on the BN layer's OUTPUT applies the ReLU mask in its epilogue, stores the masked gradient
+ *             g and leaves sum g, sum g * xhat per tile row; one finalize launch -> dgamma, dbeta and coef[3 c] = (A, B, C0) of
+ *             dz = A g + B z + C0, which fte_bn_bwd_apply evaluates (one read of g and z, one write of dz).
+ *             mask:  bn_scale / bn_shift given -> fma(zbn, scale, shift) > 0, the expression the forward pass evaluated (BN + ReLU);
+ *                    ybn given -> ybn > 0, ybn = the stored output of BN + add + ReLU (g is then also the shortcut's gradient);
+ *                    neither -> no mask (BN without activation).
+ * s16 = 0: fp32 tensors (w: HWIO fp32);  s16 = 1: bf16 storage -- x / dz / addin / zbn / ybn / z / g are bf16, w is the bf16 pack
+ * (forward: [tap][cout][cin], data gradient: HWIO; fte_pack_weights_bf16), and statistics / sums are taken of the ROUNDED values that
+ * are stored.  Sums are fp32, deterministic (fixed merge order, no atomics).  Shapes as fte_conv2d_fwd / fte_conv2d_dgrad.
+ * The grouped 3x3 twins run on the bf16 MFMA with bf16 tensors (4 / 8 / 16 / 32 channels per group, c % 32 == 0).
+ * ------------------------------------------------------------------------- */
+size_t fte_conv2d_bn_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma, const float* beta, float* mean, float* rstd,
+                      float* scale, float* shift, float* moving_mean, float* moving_var, float eps, float decay,
+                      int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream);
+size_t fte_conv2d_dgrad_bn_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int fte_conv2d_dgrad_bn(const void* dz, const void* w, const void* addin, const void* zbn, const void* ybn,
+                        const float* gamma, const float* mean, const float* rstd, const float* bn_scale, const float* bn_shift,
+                        void* g, float* dgamma, float* dbeta, float* coef,
+                        int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream);
+/* y = [relu](scale[c] * z + shift[c] [+ res]) with given coefficients; flags: FTE_S16_Z (z bf16), FTE_S16_A (res, y bf16) */
+int fte_bn_apply(const void* z, const float* scale, const float* shift, const void* res, void* y, long rows, int c, int relu, int flags, void* stream);
+/* dz = coef[c] * g + coef[C + c] * z + coef[2C + c], g already masked; flags: FTE_S16_Z (z, dz bf16), FTE_S16_A (g bf16) */
+int fte_bn_bwd_apply(const void* g, const void* z, const float* coef, void* dz, long rows, int c, int flags, void* stream);
+size_t fte_gconv3x3_bn_ws_bytes(int n, int h, int wd, int c, int stride);
+int fte_gconv3x3_bn_fwd_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* z16, const float* gamma, const float* beta,
+                                 float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                                 float eps, float decay, int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream);
+int fte_gconv3x3_dgrad_bn_bf16_s16(const uint16_t* dz16, const uint16_t* wpk_dgrad, const uint16_t* zbn16, const float* gamma, const float* mean,
+                                   const float* rstd, const float* bn_scale, const float* bn_shift, uint16_t* g16, float* dgamma, float* dbeta,
+                                   float* coef, int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream);
+
 /* ShuffleNet-v2's layers on bf16 tensors (nets/shufflenet_v2.py): depthwise 3x3 forward / data gradient / filter gradient (fp32 filter
  * and dw), the channel gather and the gather with batch norm folded in (sources and results bf16, tables / scale / shift unchanged),
  * and the statistics-only pass of a folded batch norm (`flags` as above: FTE_S16_Z = z is bf16). */

@@ -68,9 +68,15 @@ inline bool plan_bf16() { return g_plan16 || igemm_get_bf16(); }
 bool g_plan_s16 = false;
 struct PlanS16 { bool prev; explicit PlanS16(bool on) : prev(g_plan_s16) { g_plan_s16 = on; } ~PlanS16() { g_plan_s16 = prev; } };
 
+// ... and the "BN fusion" launches (fte_conv2d_bn_fwd, fte_conv2d_dgrad_bn): no split-K (the statistics / BN sums come from the
+// epilogue of the launch that holds the whole reduction) and the per-tile kernels, whose shared epilogue carries them
+bool g_plan_bn = false;
+struct PlanBn { bool prev; PlanBn() : prev(g_plan_bn) { g_plan_bn = true; } ~PlanBn() { g_plan_bn = prev; } };
+
 inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only = false) {
     RowPlan r;
     memset(&r, 0, sizeof(r));
+    if (g_plan_bn) allow_pw = false;
     static const int narrow_tile = getenv("FTE_NARROW_TILE") ? atoi(getenv("FTE_NARROW_TILE")) : TILE_64x64;   // N = 64: measured on MI355X
     // 64x64 beats 128x64 beats 256x64 (fwd 83 / 82 / 75 TF, dgrad 80 / 76 / 65): with only 18 K-steps per tile the
     // layer lives on co-resident blocks hiding each other's prologue / epilogue, not on operand reuse.
@@ -286,7 +292,8 @@ size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksiz
 // x / w are bf16 copies (x16 [n,h,wd,cin]; w16t [k*k][cout][cin], fte_pack_weights_bf16) when `src16`
 static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float* bias, const float* alpha, const float* res,
                            float* z, float* y, uint16_t* y16, int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                           void* ws, size_t ws_bytes, void* stream, const uint16_t* res16 = nullptr, uint16_t* z16 = nullptr) {
+                           void* ws, size_t ws_bytes, void* stream, const uint16_t* res16 = nullptr, uint16_t* z16 = nullptr,
+                           float* stat_part = nullptr, int* stat_rows = nullptr) {
     if (!x || !w || (!y && !(src16 && y16)) || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3))
         return FTE_EINVAL;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
@@ -312,6 +319,11 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
     if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
     RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr);
     if (rp.tail_mode == 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
+    if (stat_part) {                                 // "BN fusion": one statistics partial row per tile row of the launch(es)
+        if (rp.tail_mode == 2) return FTE_EINVAL;    // (plan_rows never splits under PlanBn)
+        p.SP = stat_part;
+        *stat_rows = (int)(rp.main_mtiles + rp.tail_mtiles);
+    }
     return rc(launch_rows(p, rp, AL_MK, bl, EPI_FWD, 0, (float*)ws, (hipStream_t)stream));
 }
 int fte_conv2d_fwd(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
@@ -421,11 +433,28 @@ size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
     });
 }
 
+// the BN layer a "BN fusion" data gradient lands on (fte_conv2d_dgrad_bn): see igemm.h
+struct DgradBn {
+    const void* zbn; const void* ybn;                 // the BN's input z; its (add + ReLU'd) output when the mask comes from there
+    const float* gamma; const float* mean; const float* rstd; const float* scale; const float* shift;
+    float* dgamma; float* dbeta; float* coef;
+};
 // dz / w are bf16 copies (dz16 [n,ho,wo,cout]; w16 [k*k][cin][cout], the HWIO layout) when `src16`
 static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const float* addin, const float* zprev,
                              const float* alpha_prev, float* raw, float* dzprev, uint16_t* dzprev16, float* dalpha_prev, float* dbias_prev,
                              int n, int h, int wd, int cin, int cout, int ksize, int stride, void* ws, size_t ws_bytes, void* stream,
-                             const uint16_t* addin16 = nullptr, const uint16_t* zprev16 = nullptr, uint16_t* raw16 = nullptr) {
+                             const uint16_t* addin16 = nullptr, const uint16_t* zprev16 = nullptr, uint16_t* raw16 = nullptr,
+                             const DgradBn* bn = nullptr) {
+    const float* zx = nullptr;
+    const uint16_t* zx16 = nullptr;
+    if (bn) {          // mask tensor -> the Zin slot, the BN input -> Zx when the mask comes from the output
+        const void* msk = (!bn->scale && bn->ybn) ? bn->ybn : bn->zbn;
+        const void* zb = (!bn->scale && bn->ybn) ? bn->zbn : nullptr;
+        if (src16) { zprev16 = (const uint16_t*)msk; zx16 = (const uint16_t*)zb; }
+        else { zprev = (const float*)msk; zx = (const float*)zb; }
+        alpha_prev = bn->gamma;                       // (never read by the BN epilogue; keeps the PReLU argument check below quiet)
+        dalpha_prev = bn->dgamma; dbias_prev = bn->dbeta;
+    }
     if (zprev16 && !zprev) zprev = reinterpret_cast<const float*>(zprev16);      // "has a PReLU mask" below; the kernels read p.Zin16
     const bool z16only = zprev16 != nullptr;
     if (!dz || !w || (!dzprev && !(src16 && dzprev16)) || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
@@ -471,6 +500,7 @@ static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const fl
         p.ADD = addin; p.RAW = raw; p.Zin = z16only ? nullptr : zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
         p.ADD16 = addin16; p.Zin16 = zprev16; p.RAW16 = raw16;
         p.PA = PA; p.PB = PB; p.prow0 = 0;
+        if (bn) { p.bn_mu = bn->mean; p.bn_rs = bn->rstd; p.bn_sc = bn->scale; p.bn_sh = bn->shift; p.Zx = zx; p.Zx16 = zx16; }
         p.src16 = src16 ? 1 : 0; p.DZ16 = dzprev16;
         if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
         hipError_t e = igemm_launch(p, AL_MK, BL_NK, EPI_DGRAD, tile, 1, (hipStream_t)stream);
@@ -496,12 +526,16 @@ static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const fl
         p.ADD = addin; p.RAW = raw; p.Zin = z16only ? nullptr : zprev; p.alpha = alpha_prev; p.amod = cin; p.DZ = dzprev;
         p.ADD16 = addin16; p.Zin16 = zprev16; p.RAW16 = raw16;
         p.PA = PA; p.PB = PB;
+        if (bn) { p.bn_mu = bn->mean; p.bn_rs = bn->rstd; p.bn_sc = bn->scale; p.bn_sh = bn->shift; p.Zx = zx; p.Zx16 = zx16; }
         if (!set_bytes(&p, (size_t)n * pho.out * pwo.out * cout, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
         hipError_t e = launch_rows(p, c.rp, AL_MK, BL_NK, EPI_DGRAD, prow, pwbuf, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
         prow += c.mtiles;
     }
     }
+    if (bn)            // PA = sum g * xhat, PB = sum g per partial row -> dgamma, dbeta, the coefficients of dz = A g + B z + C0
+        return rc(l_bn_bwd_finalize(PB, PA, cin, (int)rows, (long)n * h * wd, cin, bn->gamma, bn->mean, bn->rstd, bn->dgamma, bn->dbeta,
+                                    bn->coef, (hipStream_t)stream));
     if (want_part) {
         if (dalpha_prev && dbias_prev) {
             hipError_t e = k_reduce_rows2(PA, dalpha_prev, PB, dbias_prev, nullptr, 1, rows, cin, 1, 1.f, scratch, (hipStream_t)stream);
@@ -1042,6 +1076,110 @@ int fte_bn_train_bwd_s16(const void* dy, const void* y, const void* z, const flo
     return rc(l_bn_bwd(f32p(dy), f32p(y), f32p(z), gamma, mean, rstd, scale, shift, f32p(g_out), f32p(dz), dgamma, dbeta, rows, c,
                        (float*)ws, (hipStream_t)stream, flags));
 }
+// ---- "BN fusion": conv -> BN pairs of the graph nets (fte.h) -----------------------------------------------------------------------
+size_t fte_conv2d_bn_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+    if (n <= 0 || cin <= 0 || cout <= 0 || (stride != 1 && stride != 2)) return 0;
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
+    const size_t rows = ((size_t)n * ph.out * pw.out + 63) / 64 + 2;      // at most one partial row per 64 output rows
+    return align_up(rows * 3 * cout * sizeof(float));
+}
+int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma, const float* beta, float* mean, float* rstd,
+                      float* scale, float* shift, float* moving_mean, float* moving_var, float eps, float decay,
+                      int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream) {
+    if (!z || !gamma || !beta || !mean || !rstd || !scale || !shift || (s16 & ~1) || ((moving_mean == nullptr) != (moving_var == nullptr)))
+        return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_conv2d_bn_fwd_ws_bytes(n, h, wd, cin, cout, ksize, stride)) return FTE_EWORKSPACE;
+    PlanBn bnplan;
+    int rows = 0, e;
+    if (s16) {
+        Plan16 guard;
+        PlanS16 storage(true);
+        e = conv2d_fwd_impl(x, w, true, nullptr, nullptr, nullptr, nullptr, nullptr, (uint16_t*)z, n, h, wd, cin, cout, ksize, stride,
+                            nullptr, 0, stream, nullptr, nullptr, (float*)ws, &rows);
+    } else {
+        e = conv2d_fwd_impl(x, w, false, nullptr, nullptr, nullptr, nullptr, (float*)z, nullptr, n, h, wd, cin, cout, ksize, stride,
+                            nullptr, 0, stream, nullptr, nullptr, (float*)ws, &rows);
+    }
+    if (e != FTE_OK) return e;
+    return rc(l_bn_finalize((const float*)ws, rows, gamma, beta, cout, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
+                            (hipStream_t)stream));
+}
+size_t fte_conv2d_dgrad_bn_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+    PlanBn bnplan;
+    return fte_conv2d_dgrad_ws_bytes(n, h, wd, cin, cout, ksize, stride);
+}
+int fte_conv2d_dgrad_bn(const void* dz, const void* w, const void* addin, const void* zbn, const void* ybn,
+                        const float* gamma, const float* mean, const float* rstd, const float* bn_scale, const float* bn_shift,
+                        void* g, float* dgamma, float* dbeta, float* coef,
+                        int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream) {
+    if (!zbn || !gamma || !mean || !rstd || !g || !dgamma || !dbeta || !coef || (s16 & ~1) || ((bn_scale == nullptr) != (bn_shift == nullptr)) ||
+        (bn_scale && ybn))
+        return FTE_EINVAL;
+    const DgradBn bn = {zbn, ybn, gamma, mean, rstd, bn_scale, bn_shift, dgamma, dbeta, coef};
+    PlanBn bnplan;
+    if (s16) {
+        Plan16 guard;
+        PlanS16 storage(true);
+        return conv2d_dgrad_impl(dz, w, true, nullptr, nullptr, nullptr, nullptr, nullptr, (uint16_t*)g, nullptr, nullptr,
+                                 n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream, (const uint16_t*)addin, nullptr, nullptr, &bn);
+    }
+    return conv2d_dgrad_impl(dz, w, false, (const float*)addin, nullptr, nullptr, nullptr, (float*)g, nullptr, nullptr, nullptr,
+                             n, h, wd, cin, cout, ksize, stride, ws, ws_bytes, stream, nullptr, nullptr, nullptr, &bn);
+}
+int fte_bn_apply(const void* z, const float* scale, const float* shift, const void* res, void* y, long rows, int c, int relu, int flags, void* stream) {
+    if (!z || !scale || !shift || !y || rows <= 0 || c % 4 || (flags & ~3) || (flags && c < 32)) return FTE_EINVAL;
+    return rc(l_bn_apply(f32p(z), scale, shift, f32p(res), f32p(y), rows, c, relu, (hipStream_t)stream, flags));
+}
+int fte_bn_bwd_apply(const void* g, const void* z, const float* coef, void* dz, long rows, int c, int flags, void* stream) {
+    if (!g || !z || !coef || !dz || rows <= 0 || c % 4 || (flags & ~3) || (flags && c < 32)) return FTE_EINVAL;
+    return rc(l_bn_bwd_apply(f32p(g), f32p(z), coef, f32p(dz), rows, c, (hipStream_t)stream, flags));
+}
+size_t fte_gconv3x3_bn_ws_bytes(int n, int h, int wd, int c, int stride) {
+    if (n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32 || (stride != 1 && stride != 2)) return 0;
+    return align_up((size_t)l_gconv_bn_rows(n, h, wd, c) * 3 * c * sizeof(float));      // (h, wd: the input's side -- the larger grid)
+}
+int fte_gconv3x3_bn_fwd_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* z16, const float* gamma, const float* beta,
+                                 float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                                 float eps, float decay, int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream) {
+    if (!x16 || !wpk || !z16 || !gamma || !beta || !mean || !rstd || !scale || !shift || n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32 ||
+        (stride != 1 && stride != 2) || (long)n * h * wd >= ((long)1 << 31) || ((moving_mean == nullptr) != (moving_var == nullptr)))
+        return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_gconv3x3_bn_ws_bytes(n, h, wd, c, stride)) return FTE_EWORKSPACE;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    hipError_t e;
+    int rows;
+    if (stride == 1) {
+        rows = l_gconv_bn_rows(n, h, wd, c);
+        e = l_gconv_mfma16_bn(f32p(x16), wpk, f32p(z16), n, h, wd, c, h, wd, 0, 1, 1, 1, (float*)ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    } else {
+        rows = l_gconv_bn_rows(n, ph.out, pw.out, c);
+        e = l_gconv_mfma16_bn(f32p(x16), wpk, f32p(z16), n, ph.out, pw.out, c, h, wd, 1, ph.before, pw.before, 1, (float*)ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              (hipStream_t)stream);
+    }
+    if (e != hipSuccess) return (int)e;
+    return rc(l_bn_finalize((const float*)ws, rows, gamma, beta, c, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var, (hipStream_t)stream));
+}
+int fte_gconv3x3_dgrad_bn_bf16_s16(const uint16_t* dz16, const uint16_t* wpk_dgrad, const uint16_t* zbn16, const float* gamma, const float* mean,
+                                   const float* rstd, const float* bn_scale, const float* bn_shift, uint16_t* g16, float* dgamma, float* dbeta,
+                                   float* coef, int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream) {
+    if (!dz16 || !wpk_dgrad || !zbn16 || !gamma || !mean || !rstd || !g16 || !dgamma || !dbeta || !coef || n <= 0 || h <= 0 || wd <= 0 || c <= 0 ||
+        c % 32 || (stride != 1 && stride != 2) || (long)n * h * wd >= ((long)1 << 31) || ((bn_scale == nullptr) != (bn_shift == nullptr)))
+        return FTE_EINVAL;
+    if (!ws || ws_bytes < fte_gconv3x3_bn_ws_bytes(n, h, wd, c, stride)) return FTE_EWORKSPACE;
+    const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
+    const int rows = l_gconv_bn_rows(n, h, wd, c);
+    float* pg = (float*)ws;
+    float* pgx = pg + (size_t)rows * c;
+    hipError_t e;
+    if (stride == 1)
+        e = l_gconv_mfma16_bn(f32p(dz16), wpk_dgrad, f32p(g16), n, h, wd, c, h, wd, 0, 1, 1, 2, pg, pgx, zbn16, mean, rstd, bn_scale, bn_shift, (hipStream_t)stream);
+    else
+        e = l_gconv_mfma16_bn(f32p(dz16), wpk_dgrad, f32p(g16), n, h, wd, c, ph.out, pw.out, 2, ph.before, pw.before, 2, pg, pgx, zbn16, mean, rstd, bn_scale, bn_shift,
+                              (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return rc(l_bn_bwd_finalize(pg, pgx, c, rows, (long)n * h * wd, c, gamma, mean, rstd, dgamma, dbeta, coef, (hipStream_t)stream));
+}
+
 int fte_relu_bwd_s16(const uint16_t* dy16, const uint16_t* y16, uint16_t* g16, long n, void* stream) {
     if (!dy16 || !y16 || !g16 || n <= 0 || n % 4) return FTE_EINVAL;
     return rc(l_relu_bwd(f32p(dy16), f32p(y16), f32p(g16), n, (hipStream_t)stream, 2));

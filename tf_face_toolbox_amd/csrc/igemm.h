@@ -56,6 +56,17 @@ struct IgemmParams {
     // outputs Y / DZ may then be NULL
     const unsigned short* R16; const unsigned short* ADD16; const unsigned short* Zin16;
     unsigned short* Z16; unsigned short* RAW16;
+    // ---- BN fusion (the graph nets' conv -> BN pairs; only the BNM = 1 instantiations of the kernels read these) ----------------
+    // EPI_FWD, SP != NULL: per-tile column statistics of the STORED output (no activation, no shortcut): n, mean, M2 of the tile's
+    //   valid rows -> SP[((prow0 + mt) * 3 + {0, 1, 2}) * N + col] = bn_finalize_kernel's partial layout, one partial row per tile row
+    float* SP;
+    // EPI_DGRAD, bn_mu != NULL: the data gradient lands on the output of a BN (+ ReLU) layer; its mask and reduction pass run here:
+    //   v = stored(acc + ADD);  g = mask ? v : 0;  DZ = g;  PA[row][n] = sum_rows g * (zb - mu[n]) * rs[n];  PB[row][n] = sum_rows g
+    //   mask / zb:  bn_sc != NULL: fma(Zin, sc, sh) > 0, zb = Zin (BN + ReLU, mask recomputed from z -- bn_affine's expression)
+    //               Zx / Zx16 != NULL: Zin > 0 with Zin = the stored block output, zb = Zx (BN + add + ReLU)
+    //               neither: no mask, zb = Zin (BN without activation)
+    const float* bn_mu; const float* bn_rs; const float* bn_sc; const float* bn_sh;
+    const float* Zx; const unsigned short* Zx16;
     int ptiles;           // igemm16p_kernel (persistent blocks): tiles of the launch; set by its launcher
     int ptiles_dbg;       // diagnostic switches of that kernel (FTE_IGEMM16_DBG; 0 in production)
 };

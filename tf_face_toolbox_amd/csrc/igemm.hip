@@ -91,8 +91,9 @@ using namespace igemm_dev;
 // BF = 1: the same gathers, epilogues and fp32 accumulators, but the operand tiles are rounded to bf16 (RNE) on their way
 // into LDS and multiplied by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): storage stays fp32 in HBM, the kernel
 // turns from MFMA-bound into staging / HBM-bound.  See the BF branch of the main loop.
-template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && BM <= 192) ? 3 : 2)) void igemm_kernel(const IgemmParams p) {
+// (the body is shared by two kernel symbols: igemm_kernel, and igemm_bn_kernel = the same with the BN-fusion epilogue compiled in)
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF, bool BNM>
+__device__ __forceinline__ void igemm_body(const IgemmParams& p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     // NTH threads = WM x WN waves.  4 waves is the general case; 1 or 2 waves per block (fp32, k-contiguous A only) trade
     // operand reuse across waves for fewer waves coupled by each barrier: with ONE wave per block there is no barrier at all
@@ -922,7 +923,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
     }
 
     if (FTE_PRIO_EPILOGUE && BF == 0) __builtin_amdgcn_s_setprio(FTE_PRIO_EPILOGUE);      // drain quickly, free the slot
-    igemm_epilogue<BM, BN, WM, WN, EPI, BF == 2>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow);
+    igemm_epilogue<BM, BN, WM, WN, EPI, BF == 2, BNM>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow);
 #ifdef FTE_STAMP
     if constexpr (BF == 0) {
         __syncthreads();
@@ -934,6 +935,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
         }
     }
 #endif
+}
+
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && BM <= 192) ? 3 : 2)) void igemm_kernel(const IgemmParams p) {
+    igemm_body<BM, BN, WM, WN, AL, BL, EPI, BF, false>(p);
+}
+// conv -> BN pairs of the graph nets (igemm.h "BN fusion"): forward with tile statistics, data gradient with the BN mask / sums
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF = 0>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && BM <= 192) ? 3 : 2)) void igemm_bn_kernel(const IgemmParams p) {
+    igemm_body<BM, BN, WM, WN, AL, BL, EPI, BF, true>(p);
 }
 
 // ---- fix-up: sum the split-K partial tiles of one output tile and apply the fused epilogue -------------
@@ -1088,14 +1099,19 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     const size_t lds = BF == 2 ? (loop16 > epi ? loop16 : epi) : (BF ? (loop > epi ? loop : epi) : (epi > loop32 ? epi : loop32));
     static const size_t lds_pad = getenv("FTE_LDS_PAD") ? (size_t)atoi(getenv("FTE_LDS_PAD")) : 0;      // tuning hook: fewer blocks per CU
     const size_t lds_x = lds + lds_pad;
+    // the BN-fusion symbol exists for the 4-wave forward / data-gradient kernels only (k-contiguous A)
+    constexpr bool BN_OK = AL == AL_MK && WM * WN == 4;
+    const bool bnm = p.SP != nullptr || p.bn_mu != nullptr;
+    if (bnm && !BN_OK) return hipErrorInvalidValue;
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>;
-    if (igemm_prof_on()) { const int ta[8] = {BM, BN, WM, WN, AL, BL, EPI, BF}; igemm_note_symbol("igemm_kernel", ta, 8); }
-    static bool attr_done = false;
-    if (!attr_done) {
+    if constexpr (BN_OK) { if (bnm) kern = igemm_bn_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>; }
+    if (igemm_prof_on()) { const int ta[8] = {BM, BN, WM, WN, AL, BL, EPI, BF}; igemm_note_symbol(bnm ? "igemm_bn_kernel" : "igemm_kernel", ta, 8); }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[bnm]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 65536 > 160 * 1024 ? lds : lds + 65536));
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[bnm] = true;
     }
     if (p.ncls > 1) {                       // merged parity classes: every class has the same M x N tile grid
         IgemmParams q = p;

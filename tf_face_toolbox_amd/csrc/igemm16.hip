@@ -58,8 +58,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // fragment reads (MFMAs on whatever the registers hold)
 // PF = 1: the fragments of sub-step ks + 1 are read while the MFMAs of sub-step ks run (register double buffer), and the scalar
 // loads of the next tile's tap offsets are taken before the barrier instead of between the fragment reads
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0, int PF = 0>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const IgemmParams p) {
+// (body shared by two kernel symbols: igemm16_kernel, and igemm16_bn_kernel = the same with the BN-fusion epilogue compiled in)
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL, int PF, bool BNM>
+__device__ __forceinline__ void igemm16_body(const IgemmParams& p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1 && NST >= 2, "4 or 8 waves");
     constexpr int NW = WM * WN, RP = 8 * NW;          // a pass of the block's DMA instructions covers RP rows x 128 B
@@ -291,7 +292,16 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const Igemm
                 for (int r = 0; r < 16; ++r) keep_alive(acc[i][j][r]);
         return;
     }
-    igemm_epilogue<BM, BN, WM, WN, EPI, true>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, c_ph, c_pw, prow);
+    igemm_epilogue<BM, BN, WM, WN, EPI, true, BNM>(p, acc, reinterpret_cast<float*>(smem16), bid, split, m0, n0, mt, c_ph, c_pw, prow);
+}
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW, int ABL = 0, int PF = 0>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_kernel(const IgemmParams p) {
+    igemm16_body<BM, BN, WM, WN, EPI, NST, MINW, ABL, PF, false>(p);
+}
+// conv -> BN pairs of the graph nets (igemm.h "BN fusion")
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void igemm16_bn_kernel(const IgemmParams p) {
+    igemm16_body<BM, BN, WM, WN, EPI, NST, MINW, 0, 0, true>(p);
 }
 
 // ---- window variant (3x3, stride 1, TF-SAME; W <= 30): the A operand of a 64-channel chunk is fetched ONCE per tile -------------
@@ -2302,6 +2312,30 @@ hipError_t launch16(const IgemmParams& p, int splits, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int MINW>
+hipError_t launch16bn(const IgemmParams& p, hipStream_t st) {
+    const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
+    const size_t ring = (size_t)NST * (BM + BN) * ROWB;
+    const size_t epi = (size_t)(BM + WM * WN * 32 * 36 + 2 * WM * BN) * sizeof(float);
+    const size_t lds = ring > epi ? ring : epi;
+    auto kern = igemm16_bn_kernel<BM, BN, WM, WN, EPI, NST, MINW>;
+    if (igemm_prof_on()) { const int ta[7] = {BM, BN, WM, WN, EPI, NST, MINW}; igemm_note_symbol("igemm16_bn_kernel", ta, 7); }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (p.ncls > 1) {
+        IgemmParams q = p;
+        q.cls_tiles = mt * nt; q.cls_mtiles = mt;
+        hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(64 * WM * WN), lds, st, q);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(mt * nt, 1), dim3(64 * WM * WN), lds, st, p);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace
 
 bool igemm16_handles(const IgemmParams& p, int al, int bl, int tile) {
@@ -2315,6 +2349,17 @@ bool igemm16_handles(const IgemmParams& p, int al, int bl, int tile) {
 }
 
 hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st) {
+    if (p.SP || p.bn_mu) {
+        // conv -> BN pairs: the per-tile kernel with the shared (LDS-transposed) epilogue, whose BNM form carries the statistics /
+        // the BN mask and sums; the resident kernels' register epilogues do not (yet)
+        if (splits != 1 || p.PW) return hipErrorInvalidValue;
+        if (tile == TILE_128x128) {
+            if (epi == EPI_FWD) return launch16bn<128, 128, 4, 2, EPI_FWD, 2, 4>(p, st);
+            return launch16bn<128, 128, 4, 2, EPI_DGRAD, 2, 4>(p, st);
+        }
+        if (epi == EPI_FWD) return launch16bn<128, 64, 4, 2, EPI_FWD, 2, 6>(p, st);
+        return launch16bn<128, 64, 4, 2, EPI_DGRAD, 2, 4>(p, st);      // (four waves per SIMD: at six the BN inputs spill 63 registers)
+    }
     static const int abl = getenv("FTE_IGEMM16_ABL") ? atoi(getenv("FTE_IGEMM16_ABL")) : 0;      // diagnostic: see the kernel's ABL
     if (abl && tile == TILE_128x128 && epi == EPI_FWD) {
         if (abl == 1) return launch16<128, 128, 2, 2, EPI_FWD, 4, 1, 1>(p, splits, st);

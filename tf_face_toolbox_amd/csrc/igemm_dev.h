@@ -57,6 +57,7 @@ __device__ __forceinline__ void st_bf4(unsigned short* q, const f32x4 v) {
     *reinterpret_cast<u32x2*>(q) = u32x2{pkbf(v[0], v[1]), pkbf(v[2], v[3])};
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ float rbf(float a) { return bf2f(tobf(a)); }      // the value a bf16 store of `a` leaves in memory
 
 __device__ __forceinline__ float prelu_slope(float z, float a) {
     // d/dz [relu(z) + a*(z-|z|)/2]; TF's grad of relu(0) and sign(0) are 0 -> a/2 at exactly 0.
@@ -70,7 +71,10 @@ __device__ __forceinline__ float prelu_slope(float z, float a) {
 // CAP16 (the bf16-source kernels): the tensors of the epilogue may live in HBM as bf16 ("bf16 storage", fte_conv2d_*_s16): R16 /
 // ADD16 / Zin16 replace the fp32 inputs when set, Z16 / RAW16 (and Y16 / DZ16) are written, and the fp32 outputs Y / DZ are
 // optional.  The arithmetic stays fp32; every stored value is rounded once, to nearest even, where it is written.
-template <int BM, int BN, int WM, int WN, int EPI, bool CAP16 = false>
+// BNM (the graph nets' conv -> BN pairs, igemm.h "BN fusion"): the forward epilogue also leaves per-tile column statistics of the
+// stored output (SP), the data-gradient epilogue applies the ReLU mask of the BN layer below and leaves the two sums of its
+// backward pass as column partials (bn_mu).  Separate instantiations: the kernels of the BN-free nets compile to the code they had.
+template <int BM, int BN, int WM, int WN, int EPI, bool CAP16 = false, bool BNM = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
                                                int bid, int split, int m0, int n0, int mt, int c_ph, int c_pw, int prow) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = 64 * WM * WN;
@@ -114,6 +118,67 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
     }
     __syncthreads();
 
+    if constexpr (BNM && EPI == EPI_FWD) {
+        if (p.SP) {
+            // ---- batch-norm statistics of this tile's stored values, straight from the accumulators (lane = column, registers =
+            // rows): two passes over the registers per column -- mean of the wave's valid rows, then the squared deviations from
+            // it -- the two half-waves meet through one shuffle, the WM row-waves through LDS with Chan's merge in wave order.
+            // No E[x^2] - E[x]^2 anywhere; the value counted is the one the store below leaves in memory (bf16-rounded when the
+            // output tensor is bf16).
+            float* red = smem + BM + (WM * WN) * (32 * 36);      // [2][WM][BN], past the patches
+            bool rnd = false;
+            if constexpr (CAP16) rnd = p.Y16 != nullptr && p.Y == nullptr;
+            const int lim = p.M - m0 - wm * (TM * 32) - 4 * lh;            // valid: i * 32 + (r & 3) + 8 * (r >> 2) < lim
+            const int cntw = min(max(p.M - m0 - wm * (TM * 32), 0), TM * 32);
+            const float rcnt = cntw > 0 ? 1.f / (float)cntw : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cl = wn * (TN * 32) + j * 32 + li;
+                const float b = p.bias ? p.bias[n0 + cl] : 0.f;
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r] + b;
+                        if (rnd) v = rbf(v);
+                        s1 += (i * 32 + (r & 3) + 8 * (r >> 2) < lim) ? v : 0.f;
+                    }
+                s1 += __shfl_xor(s1, 32);
+                const float mw = s1 * rcnt;
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r] + b;
+                        if (rnd) v = rbf(v);
+                        const float d = v - mw;
+                        s2 += (i * 32 + (r & 3) + 8 * (r >> 2) < lim) ? d * d : 0.f;
+                    }
+                s2 += __shfl_xor(s2, 32);
+                if (lh == 0) { red[wm * BN + cl] = mw; red[(WM + wm) * BN + cl] = s2; }
+            }
+            __syncthreads();
+            for (int c = tid; c < BN; c += NTH) {
+                float n = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {
+                    const float nb = (float)min(max(p.M - m0 - w * (TM * 32), 0), TM * 32);
+                    if (nb > 0.f) {
+                        const float mb = red[w * BN + c], qb = red[(WM + w) * BN + c];
+                        const float tot = n + nb, d = mb - mean;
+                        mean += d * (nb / tot);
+                        m2 += qb + d * d * (n * nb / tot);
+                        n = tot;
+                    }
+                }
+                float* sp = p.SP + (long)(prow + mt) * 3 * p.N + n0 + c;
+                sp[0] = n; sp[p.N] = mean; sp[2 * (long)p.N] = m2;
+            }
+        }
+    }
+
     {
         // ---- LDS-staged epilogue, 16 bytes per lane --------------------------------------------------------------
         // The accumulator layout (lane = column) gives 4-byte global accesses, 256 B per wave instruction -- a quarter
@@ -132,6 +197,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (TN * 32) + j * 32 + 4 * pc4;
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f};
+            f32x4 mu4 = bias4, rs4 = bias4, sh4 = bias4;      // BNM: mean, rstd, shift of the BN layer below (its scale rides in al4)
             bool act = false;
             if constexpr (EPI == EPI_FWD) {
                 if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
@@ -140,6 +206,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
             } else {
                 act = p.Zin != nullptr;
                 if constexpr (CAP16) act = act || p.Zin16 != nullptr;
+                if constexpr (BNM) {
+                    if (p.bn_mu) {           // BN mode: the mask comes from z (or the stored output), never from PReLU
+                        act = false;
+                        mu4 = *reinterpret_cast<const f32x4*>(p.bn_mu + col);
+                        rs4 = *reinterpret_cast<const f32x4*>(p.bn_rs + col);
+                        if (p.bn_sc) { al4 = *reinterpret_cast<const f32x4*>(p.bn_sc + col); sh4 = *reinterpret_cast<const f32x4*>(p.bn_sh + col); }
+                    }
+                }
                 if (act) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) al4[e] = p.alpha[(col + e) % p.amod];
@@ -151,12 +225,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                 // memory round trip per 32x32 block instead of one per pass
                 int offs[4];
                 f32x4 in0[4], in1[4];
+                f32x4 in2[BNM ? 4 : 1];
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
                     offs[ps] = rowoff[wm * (TM * 32) + i * 32 + prw + 8 * ps];
                     const long o = (long)(offs[ps] < 0 ? 0 : offs[ps]) + col;
                     in0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
                     in1[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (BNM && EPI == EPI_DGRAD) {
+                        in2[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (CAP16) { if (p.Zx16 && offs[ps] >= 0) in2[ps] = ld_bf4(p.Zx16 + o); }
+                        if (p.Zx && offs[ps] >= 0) in2[ps] = *reinterpret_cast<const f32x4*>(p.Zx + o);
+                    }
                     if constexpr (EPI == EPI_FWD) {
                         if constexpr (CAP16) { if (p.R16 && offs[ps] >= 0) in0[ps] = ld_bf4(p.R16 + o); }
                         if (p.R && offs[ps] >= 0) in0[ps] = *reinterpret_cast<const f32x4*>(p.R + o);
@@ -204,6 +284,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&ac
                                 sa4[j][e] += v[e] * fminf(z[e], 0.f);
                                 v[e] *= prelu_slope(z[e], al4[e]);
                                 sb4[j][e] += v[e];
+                            }
+                        }
+                        if constexpr (BNM) {
+                            if (p.bn_mu) {
+                                bool rnd = false, two = p.Zx != nullptr;
+                                if constexpr (CAP16) { rnd = p.DZ16 != nullptr && p.DZ == nullptr; two = two || p.Zx16 != nullptr; }
+                                const f32x4 z = in1[ps], zb = two ? in2[ps] : in1[ps];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float g = rnd ? rbf(v[e]) : v[e];
+                                    const bool on = p.bn_sc ? __builtin_fmaf(z[e], al4[e], sh4[e]) > 0.f : (two ? z[e] > 0.f : true);
+                                    g = on ? g : 0.f;
+                                    v[e] = g;
+                                    sb4[j][e] += g;
+                                    sa4[j][e] += g * ((zb[e] - mu4[e]) * rs4[e]);
+                                }
                             }
                         }
                         if constexpr (CAP16) { if (p.DZ) *reinterpret_cast<f32x4*>(p.DZ + o) = v; }

@@ -16,6 +16,11 @@ hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStre
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
                     const float* rstd, const float* zsc, const float* zsf, float* gout, float* dz, float* dgamma, float* dbeta,
                     long rows, int C, float* part, hipStream_t st, int flags = 0);
+hipError_t l_bn_finalize(const float* part, int splits, const float* gamma, const float* beta, int C, float eps, float decay,
+                         float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var, hipStream_t st);
+hipError_t l_bn_bwd_finalize(const float* pg, const float* pgx, long ld, int splits, long rows, int C, const float* gamma, const float* mean,
+                             const float* rstd, float* dgamma, float* dbeta, float* coef, hipStream_t st);
+hipError_t l_bn_bwd_apply(const float* g, const float* z, const float* coef, float* dz, long rows, int C, hipStream_t st, int flags = 0);
 hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st, int flags = 0);
 hipError_t l_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st, int flags = 0);
 hipError_t l_gap_fwd(const float* x, float* y, int n, int hw, int c, hipStream_t st, int flags = 0);
@@ -31,6 +36,10 @@ hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int 
 hipError_t l_gconv_pack16(const float* w, unsigned short* wf, unsigned short* wd, int c, int groups, hipStream_t st);
 hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
                           int mode, int pt, int pl, hipStream_t st, int h16 = 0);
+int l_gconv_bn_rows(int n, int h, int wd, int c);
+hipError_t l_gconv_mfma16_bn(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
+                             int mode, int pt, int pl, int bnf, float* part, float* pgx, const unsigned short* zbn, const float* mu,
+                             const float* rs, const float* sc, const float* sh, hipStream_t st);
 int l_gconv_wgrad16_chunks(long npix, int c);
 hipError_t l_gconv_wgrad16(const float* x, const float* dz, float* part, float* dw, int n, int h, int wd, int c, int groups,
                            int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st, int h16 = 0);

@@ -401,6 +401,69 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
+// The same merge for MANY partial rows (the conv epilogues of the "BN fusion" path leave one per tile row: up to M / 64 of them):
+// block = ONE channel quad x 256 split lanes, 16-byte loads, four rows in flight per lane; wave shuffles, then the four waves
+// through LDS.  Same sums around the first split's mean as above.
+__device__ __forceinline__ f32x4 wave_sum4(f32x4 v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+        v[e] = x;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void bn_finalize_wide_kernel(const float* __restrict__ part, int splits, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float decay, float* __restrict__ mean_out,
+                                                               float* __restrict__ rstd_out, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float* __restrict__ mov_mean,
+                                                               float* __restrict__ mov_var) {
+    __shared__ f32x4 sh[3][4];
+    const int ch = blockIdx.x * 4, lane = threadIdx.x;
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(part + C + ch);
+    f32x4 n = {0.f, 0.f, 0.f, 0.f}, d1 = n, q = n;
+    for (int s0 = lane; s0 < splits; s0 += 1024) {
+        f32x4 nb[4], mb[4], qb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 256 * u;
+            const bool in = s < splits;
+            const float* pp = part + (long)(in ? s : 0) * 3 * C + ch;
+            nb[u] = *reinterpret_cast<const f32x4*>(pp); mb[u] = *reinterpret_cast<const f32x4*>(pp + C); qb[u] = *reinterpret_cast<const f32x4*>(pp + 2 * C);
+            if (!in) { nb[u] = f32x4{0.f, 0.f, 0.f, 0.f}; qb[u] = nb[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 d = mb[u] - m0;
+            n += nb[u];
+            d1 += nb[u] * d;
+            q += qb[u] + nb[u] * d * d;
+        }
+    }
+    n = wave_sum4(n); d1 = wave_sum4(d1); q = wave_sum4(q);
+    if ((lane & 63) == 0) { sh[0][lane >> 6] = n; sh[1][lane >> 6] = d1; sh[2][lane >> 6] = q; }
+    __syncthreads();
+    if (lane >= 4) return;
+    float N = 0.f, D = 0.f, Q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { N += sh[0][w][lane]; D += sh[1][w][lane]; Q += sh[2][w][lane]; }
+    const int c = ch + lane;
+    const float mean = m0[lane] + D / N;
+    const float m2 = fmaxf(Q - D * D / N, 0.f);
+    const float rstd = 1.f / sqrtf(m2 / N + eps);
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (mov_mean) {
+        mov_mean[c] = decay * mov_mean[c] + (1.f - decay) * mean;
+        mov_var[c] = decay * mov_var[c] + (1.f - decay) * (m2 / fmaxf(N - 1.f, 1.f));
+    }
+}
+
 // inference-mode scale/shift from the moving statistics
 __global__ __launch_bounds__(256) void bn_infer_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mm, const float* __restrict__ mv,
@@ -487,7 +550,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // dgamma, dbeta and the coefficients of dz = A*g + B*z + C0
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int splits, int C, float count,
+// (pg / pgx: the two partial-sum arrays, `ld` floats apart from split to split: [s][2][C] of the reduce kernels is (part, part + C,
+// 2 C); the conv epilogues of the "BN fusion" path write two separate [rows][C] arrays)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ pg, const float* __restrict__ pgx, long ld,
+                                                              int splits, int C, float count,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
@@ -498,8 +564,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     if (ch < C) {
 #pragma unroll 4
         for (int s = lane; s < splits; s += 16) {
-            sg += part[(long)s * 2 * C + ch];
-            sgx += part[(long)s * 2 * C + C + ch];
+            sg += pg[(long)s * ld + ch];
+            sgx += pgx[(long)s * ld + ch];
         }
     }
     sh[0][lane][cl] = sg; sh[1][lane][cl] = sgx;
@@ -514,6 +580,45 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     coef[ch] = gr;
     coef[C + ch] = b;
     coef[2 * C + ch] = -gr * sg / count - b * mean[ch];
+}
+
+// many partial rows (conv epilogues): one channel quad x 256 split lanes per block, as bn_finalize_wide_kernel
+__global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(const float* __restrict__ pg, const float* __restrict__ pgx, long ld,
+                                                                   int splits, int C, float count,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ f32x4 sh[2][4];
+    const int ch = blockIdx.x * 4, lane = threadIdx.x;
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg;
+    for (int s0 = lane; s0 < splits; s0 += 1024) {
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + 256 * u;
+            const bool in = s < splits;
+            a[u] = *reinterpret_cast<const f32x4*>(pg + (long)(in ? s : 0) * ld + ch);
+            b[u] = *reinterpret_cast<const f32x4*>(pgx + (long)(in ? s : 0) * ld + ch);
+            if (!in) { a[u] = f32x4{0.f, 0.f, 0.f, 0.f}; b[u] = a[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sg += a[u]; sgx += b[u]; }
+    }
+    sg = wave_sum4(sg); sgx = wave_sum4(sgx);
+    if ((lane & 63) == 0) { sh[0][lane >> 6] = sg; sh[1][lane >> 6] = sgx; }
+    __syncthreads();
+    if (lane >= 4) return;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += sh[0][w][lane]; b += sh[1][w][lane]; }
+    const int c = ch + lane;
+    dbeta[c] = a;
+    dgamma[c] = b;
+    const float gr = gamma[c] * rstd[c];
+    const float bb = -gr * rstd[c] * b / count;
+    coef[c] = gr;
+    coef[C + c] = bb;
+    coef[2 * C + c] = -gr * a / count - bb * mean[c];
 }
 
 template <bool ZH = false, bool AH = false>
@@ -868,13 +973,40 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
     }
 #undef FTE_BR
     if (!tail.cnt)
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, (float)rows, gamma, mean, rstd,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, part + C, 2L * C, splits, C, (float)rows, gamma, mean, rstd,
                            dgamma, dbeta, coef);
     const long n4 = rows * C / 4;
     if (gout) FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
     else FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C));
     return hipGetLastError();
 }
+// ---- the pieces of the "BN fusion" path (conv epilogues leave the partials; fte_conv2d_bn_fwd / fte_conv2d_dgrad_bn) ------------------
+// statistics partials [splits][3][C] (n, mean, M2) -> mean, rstd, scale, shift, moving statistics
+hipError_t l_bn_finalize(const float* part, int splits, const float* gamma, const float* beta, int C, float eps, float decay,
+                         float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var, hipStream_t st) {
+    if (splits > 512 && C % 4 == 0)
+        hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C / 4), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay, mean, rstd, scale, shift, mov_mean, mov_var);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay, mean, rstd, scale, shift, mov_mean, mov_var);
+    return hipGetLastError();
+}
+// backward partials pg / pgx [splits][ld] (sum g, sum g * xhat) -> dgamma, dbeta, coef[3][C] of dz = A g + B z + C0
+hipError_t l_bn_bwd_finalize(const float* pg, const float* pgx, long ld, int splits, long rows, int C, const float* gamma, const float* mean,
+                             const float* rstd, float* dgamma, float* dbeta, float* coef, hipStream_t st) {
+    if (splits > 512 && C % 4 == 0 && ld % 4 == 0)
+        hipLaunchKernelGGL(bn_bwd_finalize_wide_kernel, dim3(C / 4), dim3(256), 0, st, pg, pgx, ld, splits, C, (float)rows, gamma, mean, rstd, dgamma, dbeta, coef);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pg, pgx, ld, splits, C, (float)rows, gamma, mean, rstd, dgamma, dbeta, coef);
+    return hipGetLastError();
+}
+// dz = A g + B z + C0 with g ALREADY masked (the producing data gradient's epilogue did that)
+hipError_t l_bn_bwd_apply(const float* g, const float* z, const float* coef, float* dz, long rows, int C, hipStream_t st, int flags) {
+    if (C % 4 || (flags && !quads_per_block(C))) return hipErrorInvalidValue;
+    const long n4 = rows * C / 4;
+    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, g, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
+    return hipGetLastError();
+}
+
 hipError_t l_maxpool_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int ho, int wo, int pt, int pl, hipStream_t st, int flags) {
     const dim3 grid(grid_for((long)n * ho * wo * (c / 4)));
     if (flags & 2) hipLaunchKernelGGL(maxpool_fwd_kernel<true>, grid, dim3(256), 0, st, x, y, idx, n, h, w, c, ho, wo, pt, pl);
@@ -1047,13 +1179,75 @@ __global__ __launch_bounds__(256) void gconv_pack16_kernel(const float* __restri
     }
 }
 
+// "BN fusion" of the grouped 3x3 (bf16 storage only).  BNF = 1 (forward): every wave keeps shifted sums of the values it STORES
+// (lane = channel, shift = the first value the lane sees) over its whole walk and leaves one (n, mean, M2) partial row per wave --
+// bn_finalize's layout, part[((block * 4 + wave) * 3 + k) * c + channel].  BNF = 2 (data gradient landing on a BN + ReLU output):
+// g = stored(dx) where fma(zbn, sc, sh) > 0 (sc == NULL: everywhere), else 0; g is what is stored, and the wave leaves
+// sum g -> pg[row][channel], sum g * (zbn - mu) * rs -> pgx[row][channel] for bn_bwd_finalize.
+struct GconvBn {
+    float* part;                       // BNF 1: statistics partials; BNF 2: pg
+    float* pgx;                        // BNF 2
+    const unsigned short* zbn;         // BNF 2: the BN layer's input z (bf16), same shape as the gradient written
+    const float* mu; const float* rs; const float* sc; const float* sh;
+};
+struct GconvAcc { float a, b, c, shift; };      // BNF 1: n, sum d, sum d^2, shift;  BNF 2: sum g, sum g xhat
+template <int BNF>
+__device__ __forceinline__ void gconv_bn_tile(const GconvBn& bn, GconvAcc& st, f32x16_l& acc, long tile, long npix, int c, int ch, int lh,
+                                              float mu, float rs, float sc, float sh) {
+    if constexpr (BNF == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (pr < npix) {
+                const float v = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, (__bf16)acc[i]) << 16);
+                if (st.a == 0.f) st.shift = v;
+                const float d = v - st.shift;
+                st.a += 1.f; st.b += d; st.c += d * d;
+            }
+        }
+    } else if constexpr (BNF == 2) {
+        float z[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            z[i] = pr < npix ? __builtin_bit_cast(float, (unsigned)bn.zbn[pr * c + ch] << 16) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            float g = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, (__bf16)acc[i]) << 16);
+            const bool on = pr < npix && (bn.sc == nullptr || __builtin_fmaf(z[i], sc, sh) > 0.f);
+            g = on ? g : 0.f;
+            acc[i] = g;
+            st.a += g;
+            st.b += g * ((z[i] - mu) * rs);
+        }
+    }
+}
+template <int BNF>
+__device__ __forceinline__ void gconv_bn_flush(const GconvBn& bn, const GconvAcc& st, int row, int c, int ch, int lh) {
+    if constexpr (BNF == 1) {
+        float n = st.a, mean = 0.f, m2 = 0.f;
+        if (n > 0.f) { mean = st.shift + st.b / n; m2 = fmaxf(st.c - st.b * st.b / n, 0.f); }
+        const float nb = __shfl_xor(n, 32), mb = __shfl_xor(mean, 32), qb = __shfl_xor(m2, 32);
+        if (lh == 0) {
+            chan_merge(n, mean, m2, nb, mb, qb);
+            float* pp = bn.part + (long)row * 3 * c + ch;
+            pp[0] = n; pp[c] = mean; pp[2 * (long)c] = m2;
+        }
+    } else if constexpr (BNF == 2) {
+        const float a = st.a + __shfl_xor(st.a, 32), b = st.b + __shfl_xor(st.b, 32);
+        if (lh == 0) { bn.part[(long)row * c + ch] = a; bn.pgx[(long)row * c + ch] = b; }
+    }
+}
+
 // MODE 0: stride 1 (forward, or data gradient with the mirrored filter: the same index map); 1: forward at stride 2 (x is
 // [n, hs, ws], y [n, h, wd] = the walked grid); 2: data gradient at stride 2 (x is dz [n, hs, ws], y is dx [n, h, wd]; tap (r, q) of
 // the mirrored filter reads dz[(iy + pt - (2 - r)) / 2] when that is whole).  pt, pl = the TF-SAME pads before.
-template <int MODE, bool H = false>      // H: x and y are bf16 in HBM (bf16 storage)
+template <int MODE, bool H = false, int BNF = 0>      // H: x and y are bf16 in HBM (bf16 storage)
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                               float* __restrict__ y, int n, int h, int wd, int c,
-                                                              int hs, int ws, int pt, int pl) {
+                                                              int hs, int ws, int pt, int pl, GconvBn bn) {
     // the slice's 9 x [32][32] bf16 filter (18 KB) sits in LDS; a fragment is one ds_read_b128 right before its MFMA
     __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
     // per wave: the 32 pixels x 128 B of one tap, twice (the next tap lands while this one multiplies).  A lane FETCHES 16-byte
@@ -1076,6 +1270,12 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
     const long xs = slice * 32 + ((lane & 7) << 2);
     const int fr = lane >> 3;                         // fetch row inside a group of 8 pixels
     float* st = &stage[wv][0][0];
+    GconvAcc bst = {0.f, 0.f, 0.f, 0.f};
+    float bmu = 0.f, brs = 0.f, bsc = 0.f, bsh = 0.f;
+    if constexpr (BNF == 2) {
+        bmu = bn.mu[slice * 32 + li]; brs = bn.rs[slice * 32 + li];
+        if (bn.sc) { bsc = bn.sc[slice * 32 + li]; bsh = bn.sh[slice * 32 + li]; }
+    }
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
         // the four pixels this lane fetches for: coordinates once per tile
         int foy[4], fox[4];
@@ -1144,12 +1344,14 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
         }
         // C layout: column (channel) = lane & 31, row (pixel) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5): 32 lanes write one pixel's 128 B
         const long yo = slice * 32 + li;
+        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
             if (pr < npix) st1<H>(y, yo + pr * c, acc[i]);
         }
     }
+    if constexpr (BNF != 0) gconv_bn_flush<BNF>(bn, bst, blockIdx.x * 4 + wv, c, slice * 32 + li, lh);
 }
 
 // Stride 1 (forward and data gradient), second formulation: the taps of one kernel ROW are shifted views of the same 34
@@ -1158,9 +1360,9 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
 // ONCE (coalesced 128-byte rows, rounded to bf16, 80-byte LDS rows), and the three taps q read window rows li + q; the image /
 // row edges are a 9-bit mask per lane that zeroes the fragment.  gconv3x3_mfma16_kernel<0> fetched every tap on its own: 9 x the
 // tensor through L2 -> L1 (461 MB for the 28x28x128 layer at 128 images, 52 us = the L2 rate); this one moves 3.2 x.
-template <bool H = false>
+template <bool H = false, int BNF = 0>
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
-                                                                  float* __restrict__ y, int n, int h, int wd, int c) {
+                                                                  float* __restrict__ y, int n, int h, int wd, int c, GconvBn bn) {
     __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
     constexpr int WROW = 40, WBUF = 34 * WROW;                    // bf16 per window row (32 + 8 pad: conflict-free b128 reads), per buffer
     __shared__ __attribute__((aligned(16))) unsigned short win[4][2][WBUF];
@@ -1201,6 +1403,12 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
     f32x4 va[5], vb[5];
     if (tile < ntiles) fetch(tile, 0, va);
     int sb = 0;
+    GconvAcc bst = {0.f, 0.f, 0.f, 0.f};
+    float bmu = 0.f, brs = 0.f, bsc = 0.f, bsh = 0.f;
+    if constexpr (BNF == 2) {
+        bmu = bn.mu[slice * 32 + li]; brs = bn.rs[slice * 32 + li];
+        if (bn.sc) { bsc = bn.sc[slice * 32 + li]; bsh = bn.sh[slice * 32 + li]; }
+    }
     for (; tile < ntiles; tile += stride_t) {
         const long p = tile * 32 + li;
         const bool pok = p < npix;
@@ -1245,12 +1453,14 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
         row(2, sb);
         sb ^= 1;
         const long yo = slice * 32 + li;
+        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
             if (pr < npix) st1<H>(y, yo + pr * c, acc[i]);
         }
     }
+    if constexpr (BNF != 0) gconv_bn_flush<BNF>(bn, bst, blockIdx.x * 4 + wv, c, slice * 32 + li, lh);
 }
 
 // Filter gradient of the same layers on the bf16 MFMA: per 32-channel slice and tap a dense [32 ic] x [32 oc] product over the
@@ -1548,25 +1758,46 @@ hipError_t l_gconv_pack16(const float* w, unsigned short* wf, unsigned short* wd
     return hipGetLastError();
 }
 // y [n, h, wd] is the walked grid, x [n, hs, ws] the source; mode as gconv3x3_mfma16_kernel's MODE
+// blocks along x of a launch over [n, h, wd] output pixels (4 waves of 32-pixel tiles each); the "BN fusion" forms leave one partial
+// row per wave, so their grid is capped at 512 blocks (2048 partial rows, still >= 8192 waves)
+static long gconv16_blocks(long npix, int c, bool bn) {
+    const long ntiles = (npix + 31) / 32;
+    long bx = (ntiles + 3) / 4;
+    long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
+    if (bn && cap > 512) cap = 512;
+    return bx > cap ? cap : bx;
+}
+int l_gconv_bn_rows(int n, int h, int wd, int c) { return (int)gconv16_blocks((long)n * h * wd, c, true) * 4; }
 hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
                           int mode, int pt, int pl, hipStream_t st, int h16) {
-    const long ntiles = ((long)n * h * wd + 31) / 32;
-    long bx = (ntiles + 3) / 4;
-    const long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
-    if (bx > cap) bx = cap;
-    const dim3 grid((unsigned)bx, c / 32);
+    const dim3 grid((unsigned)gconv16_blocks((long)n * h * wd, c, false), c / 32);
     static const bool win = !(getenv("FTE_GCONV_WIN") && atoi(getenv("FTE_GCONV_WIN")) == 0);     // A/B hook: 0 = a fetch per tap
+    const GconvBn nobn = {};
     if (h16) {
-        if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel<true>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c);
-        else if (mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<0, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
-        else if (mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
-        else hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+        if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel<true>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, nobn);
+        else if (mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<0, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, nobn);
+        else if (mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, nobn);
+        else hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, nobn);
         return hipGetLastError();
     }
-    if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel<false>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c);
-    else if (mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<0, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
-    else if (mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
-    else hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl);
+    if (mode == 0 && win) hipLaunchKernelGGL(gconv3x3_mfma16_win_kernel<false>, grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, nobn);
+    else if (mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<0, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, nobn);
+    else if (mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, nobn);
+    else hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, false>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, nobn);
+    return hipGetLastError();
+}
+// the same launches (bf16 storage) with the BN work in the epilogue: bnf = 1 forward statistics (mode 0 / 1), bnf = 2 data gradient
+// landing on a BN (+ ReLU) output (mode 0 / 2).  part (and pgx): l_gconv_bn_rows(n, h, wd, c) partial rows.
+hipError_t l_gconv_mfma16_bn(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
+                             int mode, int pt, int pl, int bnf, float* part, float* pgx, const unsigned short* zbn, const float* mu,
+                             const float* rs, const float* sc, const float* sh, hipStream_t st) {
+    const dim3 grid((unsigned)gconv16_blocks((long)n * h * wd, c, true), c / 32);
+    const GconvBn bn = {part, pgx, zbn, mu, rs, sc, sh};
+    if (bnf == 1 && mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_win_kernel<true, 1>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, bn);
+    else if (bnf == 1 && mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, true, 1>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, bn);
+    else if (bnf == 2 && mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_win_kernel<true, 2>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, bn);
+    else if (bnf == 2 && mode == 2) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, true, 2>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, bn);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 int l_gconv_wgrad16_chunks(long npix, int c) {

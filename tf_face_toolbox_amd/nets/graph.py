@@ -426,23 +426,43 @@ class GraphNet(Network):
         # pass only ('bnstats'), the gather applies scale / shift / ReLU to that source on the way
         # (fte_channel_gather_affine), and the normalised tensor is never written (FTE_BN_GATHER=0: off, A/B hook).
         self.folded = {}
+        pusers = {}
+        for j, op in enumerate(plan):
+            if op[0] == 'gather':
+                ins = [x for x in op[2]['ins'] if x is not None]
+            elif op[0] in ('bn', 'addrelu'):
+                ins = [op[2]] + ([op[4]] if op[0] == 'bn' and op[4] is not None else []) + ([op[3]] if op[0] == 'addrelu' else [])
+            else:
+                ins = self._inputs(op)
+            for x in ins:
+                pusers.setdefault(x, []).append(j)
         if os.environ.get('FTE_BN_GATHER', '1') != '0':
-            pusers = {}
-            for j, op in enumerate(plan):
-                if op[0] == 'gather':
-                    ins = [x for x in op[2]['ins'] if x is not None]
-                elif op[0] in ('bn', 'addrelu'):
-                    ins = [op[2]] + ([op[4]] if op[0] == 'bn' and op[4] is not None else []) + ([op[3]] if op[0] == 'addrelu' else [])
-                else:
-                    ins = self._inputs(op)
-                for x in ins:
-                    pusers.setdefault(x, []).append(j)
             for j, op in enumerate(plan):
                 if op[0] == 'bn' and op[4] is None:
                     u = pusers.get(op[1], [])
                     if len(u) == 1 and plan[u[0]][0] == 'gather' and op[1] != self.feature_name:
                         plan[j] = ('bnstats',) + op[1:]
                         self.folded[op[1]] = (op[2], op[5])          # name -> (z, relu)
+        # "BN fusion" (fte.h): a conv / grouped conv whose output feeds ONE batch norm leaves that layer's batch statistics in its
+        # epilogue (fuse_fwd: plan index of the conv -> plan index of the BN), and the data gradient that completes the gradient of
+        # a BN layer's OUTPUT -- the dgrad of its first consumer in plan order, which runs last in the backward walk and takes the
+        # other consumer's contribution through `addin` -- applies the ReLU mask and leaves the two sums of the BN backward
+        # (fuse_bwd: name of the BN output -> plan index of the BN).  Which of them can run fused (MFMA conv path, storage
+        # mode, grouped conv on the bf16 MFMA) is decided where they run.  FTE_BN_FUSE=0: off (A/B hook).
+        self.fuse_fwd, self.fuse_bwd = {}, {}
+        if os.environ.get('FTE_BN_FUSE', '1') != '0':
+            producer = {op[1]: j for j, op in enumerate(plan) if op[0] in ('conv', 'gconv')}
+            for j, op in enumerate(plan):
+                if op[0] not in ('bn', 'bnstats'):
+                    continue
+                i = producer.get(op[2])
+                if i is not None and pusers.get(op[2], []) == [j]:
+                    self.fuse_fwd[i] = j
+                us = pusers.get(op[1], [])
+                if op[0] == 'bn' and us and op[1] != self.feature_name:
+                    first = plan[us[0]]
+                    if (first[0] == 'conv' and len(us) <= 2) or (first[0] == 'gconv' and len(us) == 1):
+                        self.fuse_bwd[op[1]] = j
         self.plan = plan
         self.has_classifier = plan[-1][0] == 'fc'
 
@@ -522,7 +542,7 @@ class GraphNet(Network):
             if kind in ('bn', 'bnstats'):
                 c = shape[-1]
                 self.bn[out] = dict(mean=torch.empty(c, **f32), rstd=torch.empty(c, **f32), scale=torch.empty(c, **f32),
-                                    shift=torch.empty(c, **f32))
+                                    shift=torch.empty(c, **f32), coef=torch.empty(3 * c, **f32))
                 need = max(need, q('fte_bn_ws_bytes', c))
             elif kind == 'conv':
                 ih, iw, cin = self.shapes[op[2]]
@@ -531,7 +551,9 @@ class GraphNet(Network):
                 if cin >= 32:
                     need = max(need, q('fte_conv2d_fwd_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
                                q('fte_conv2d_dgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
-                               q('fte_conv2d_wgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]))
+                               q('fte_conv2d_wgrad_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
+                               q('fte_conv2d_bn_fwd_ws_bytes', n, ih, iw, cin, cout, k, op[4]),
+                               q('fte_conv2d_dgrad_bn_ws_bytes', n, ih, iw, cin, cout, k, op[4]))
                     if s16:          # bf16 packs of the filter: HWIO (data gradient) and [tap][cout][cin] (forward), refreshed every step
                         self._pack_entries.append((op[3], self.variables[op[3]].offset, k, cin, cout))
                 elif self._direct_stem(k, cin, cout):
@@ -548,7 +570,8 @@ class GraphNet(Network):
                 ih, iw, cc = self.shapes[op[2]]
                 need = max(need, q('fte_gconv3x3_wgrad_ws_bytes', n, ih, iw, cc, op[5], op[4]))
                 if cc % 32 == 0 and cc // op[5] in (4, 8, 16, 32):
-                    need = max(need, q('fte_gconv3x3_wgrad_bf16_ws_bytes', n, ih, iw, cc, op[5], op[4]))
+                    need = max(need, q('fte_gconv3x3_wgrad_bf16_ws_bytes', n, ih, iw, cc, op[5], op[4]),
+                               q('fte_gconv3x3_bn_ws_bytes', n, ih, iw, cc, op[4]))
             elif kind == 'se':
                 cc = shape[-1]
                 hd = self._se_names(op)[4]
@@ -606,14 +629,26 @@ class GraphNet(Network):
         h16 = self.h16
         if s16:
             self.packs.refresh(self.params, st)          # every filter's bf16 packs, two launches
-        for op in self.plan:
+        stats_done = set()                               # BN plan ops whose statistics came out of the producing conv's epilogue
+        upd = self.update_moving_stats
+
+        def bn_args(j):
+            bop = self.plan[j]
+            b, pre = self.bn[bop[1]], bop[3]
+            return (self.view(pre + '/gamma'), self.view(pre + '/beta'), b['mean'], b['rstd'], b['scale'], b['shift'],
+                    self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None, BN_EPS, BN_DECAY)
+        for j, op in enumerate(self.plan):
             kind, out = op[0], op[1]
             if kind == 'conv':
                 _, _, inp, wname, stride = op
                 ih, iw, cin = self.shapes[inp]
                 k = self.spec[wname][0][0]
                 cout = self.shapes[out][-1]
-                if cin >= 32 and s16:          # bf16 storage: bf16 x in, bf16 z out, filters packed once per step
+                if cin >= 32 and is_training and j in self.fuse_fwd:          # conv + the batch statistics of its output ("BN fusion")
+                    call('fte_conv2d_bn_fwd', T[inp], self.w16t[wname] if s16 else self.view(wname), T[out], *bn_args(self.fuse_fwd[j]),
+                         n, ih, iw, cin, cout, k, stride, 1 if s16 else 0, self.ws, self.ws_bytes, st)
+                    stats_done.add(self.fuse_fwd[j])
+                elif cin >= 32 and s16:          # bf16 storage: bf16 x in, bf16 z out, filters packed once per step
                     call('fte_conv2d_fwd_s16', T[inp], self.w16t[wname], None, None, None, None, T[out], None, None,
                          n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 elif cin >= 32:
@@ -655,7 +690,9 @@ class GraphNet(Network):
                 b = self.bn[out]
                 c = self.shapes[out][-1]
                 rows = T[inp].numel() // c
-                if is_training and s16:
+                if j in stats_done:
+                    pass
+                elif is_training and s16:
                     upd = self.update_moving_stats
                     call('fte_bn_train_stats_s16', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
                          b['mean'], b['rstd'], b['scale'], b['shift'],
@@ -676,7 +713,10 @@ class GraphNet(Network):
                 c = self.shapes[out][-1]
                 rows = T[out].numel() // c
                 resbuf = T[res] if res is not None else None
-                if s16:
+                if j in stats_done:              # scale / shift are there already: the normalise pass alone
+                    assert res is None or not s16 or res in h16, 'bf16 storage: the shortcut of %s is an fp32 tensor' % out
+                    call('fte_bn_apply', T[inp], b['scale'], b['shift'], resbuf, T[out], rows, c, relu, ((1 if inp in h16 else 0) | 2) if s16 else 0, st)
+                elif s16:
                     assert res is None or res in h16, 'bf16 storage: the shortcut of %s is an fp32 tensor' % out
                     fl = (1 if inp in h16 else 0) | 2
                     if is_training:
@@ -704,7 +744,12 @@ class GraphNet(Network):
                 pk = self._gconv_pack(op)
                 if pk is not None:                             # bf16 MFMA mode: block-diagonal slices on the matrix cores
                     call('fte_gconv3x3_pack_bf16', self.view(op[3]), pk[0], pk[1], c, op[5], st)
-                    call('fte_gconv3x3_bf16_s16' if s16 else 'fte_gconv3x3_bf16', T[op[2]], pk[0], T[out], n, ih, iw, c, op[4], 0, st)
+                    if s16 and is_training and j in self.fuse_fwd:
+                        call('fte_gconv3x3_bn_fwd_bf16_s16', T[op[2]], pk[0], T[out], *bn_args(self.fuse_fwd[j]), n, ih, iw, c, op[4],
+                             self.ws, self.ws_bytes, st)
+                        stats_done.add(self.fuse_fwd[j])
+                    else:
+                        call('fte_gconv3x3_bf16_s16' if s16 else 'fte_gconv3x3_bf16', T[op[2]], pk[0], T[out], n, ih, iw, c, op[4], 0, st)
                 else:
                     call('fte_gconv3x3_fwd', T[op[2]], self.view(op[3]), T[out], n, ih, iw, c, op[5], op[4], st)
             elif kind == 'se':
@@ -920,6 +965,21 @@ class GraphNet(Network):
         main, side = torch.cuda.current_stream(), self.side
         wst, wws = (side.cuda_stream, self.ws_side) if side is not None else (st, self.ws)
         pending = []
+        reduced = set()          # BN outputs whose mask / reduction pass ran in the epilogue of the data gradient that produced G[name]
+
+        def bn_below(name):
+            """arguments of the BN layer whose output `name` a fused data gradient lands on, or None"""
+            bj = self.fuse_bwd.get(name)
+            if bj is None:
+                return None
+            _, bout, binp, pre, res, relu = self.plan[bj]
+            if s16 and not (binp in h16 and bout in h16):
+                return None
+            b = self.bn[bout]
+            zmask = relu and res is None
+            return (T[binp], T[bout] if res is not None else None, self.view(pre + '/gamma'), b['mean'], b['rstd'],
+                    b['scale'] if zmask else None, b['shift'] if zmask else None), \
+                   (self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads), b['coef'])
 
         def wgrad(name, dy, *args):
             if side is None:
@@ -1024,7 +1084,13 @@ class GraphNet(Network):
                     wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
                 pk = self._gconv_pack(op)
-                if pk is not None:                       # packed by this step's forward pass (the weights have not changed since)
+                bnb = bn_below(inp) if (pk is not None and s16) else None
+                if bnb is not None:                      # ... with the mask / sums of the BN layer below in the epilogue
+                    (zbn, _, gam, mean, rstd, sc, sh), outs = bnb
+                    call('fte_gconv3x3_dgrad_bn_bf16_s16', dy, pk[1], zbn, gam, mean, rstd, sc, sh, dx, *outs, n, ih, iw, c, stride,
+                         self.ws, self.ws_bytes, st)
+                    reduced.add(inp)
+                elif pk is not None:                     # packed by this step's forward pass (the weights have not changed since)
                     call('fte_gconv3x3_bf16_s16' if s16 else 'fte_gconv3x3_bf16', dy, pk[1], dx, n, ih, iw, c, stride, 1, st)
                 else:
                     call('fte_gconv3x3_dgrad', dy, self.view(wname), dx, n, ih, iw, c, groups, stride, st)
@@ -1035,7 +1101,11 @@ class GraphNet(Network):
                 c = self.shapes[out][-1]
                 rows = dy.numel() // c
                 dz = torch.empty_like(T[inp])
-                if s16:
+                if out in reduced:               # dy is the masked gradient already, dgamma / dbeta / coef are there: the apply pass alone
+                    call('fte_bn_bwd_apply', dy, T[inp], b['coef'], dz, rows, c, 3 if s16 else 0, st)
+                    if res is not None:
+                        self._put(res, dy)               # the shortcut sees the same (read-only) masked gradient
+                elif s16:
                     fl = (1 if inp in h16 else 0) | 2
                     gam, dgam, dbet = self.view(pre + '/gamma'), self.view(pre + '/gamma', self.grads), self.view(pre + '/beta', self.grads)
                     if res is not None:
@@ -1081,7 +1151,13 @@ class GraphNet(Network):
                 flush(self.side_batch)
                 prev = G.pop(inp, None)                  # accumulate into an existing contribution through `addin`
                 dx = self._new(inp)
-                if s16:          # bf16 dz in, bf16 dx out (+ the bf16 contribution already there); the HWIO pack is this step's
+                bnb = bn_below(inp)
+                if bnb is not None:          # the last contribution to the gradient of a BN output: mask + BN sums in the epilogue
+                    ins, outs = bnb
+                    call('fte_conv2d_dgrad_bn', dy, self.w16[wname] if s16 else self.view(wname), prev, *ins, dx, *outs,
+                         n, ih, iw, cin, cout, k, stride, 1 if s16 else 0, self.ws, self.ws_bytes, st)
+                    reduced.add(inp)
+                elif s16:          # bf16 dz in, bf16 dx out (+ the bf16 contribution already there); the HWIO pack is this step's
                     call('fte_conv2d_dgrad_s16', dy, self.w16[wname], prev, None, None, None, dx, None, None,
                          n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
                 else:
