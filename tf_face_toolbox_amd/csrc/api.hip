@@ -9,6 +9,7 @@
 #include "../../include/fte.h"
 #include "igemm.h"
 #include "wgrad16.h"
+#include "pw16.h"
 #include "kernels.h"
 #include "layers.h"
 
@@ -1091,6 +1092,16 @@ int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma,
     if (!ws || ws_bytes < fte_conv2d_bn_fwd_ws_bytes(n, h, wd, cin, cout, ksize, stride)) return FTE_EWORKSPACE;
     PlanBn bnplan;
     int rows = 0, e;
+    Pw16Params pw;
+    memset(&pw, 0, sizeof(pw));
+    if (s16 && ksize == 1 && stride == 1 && pw16_plan((long)n * h * wd, cin, cout, PW_EPI_STATS, &pw)) {
+        // the streaming pointwise kernel (pw16.hip): filter slice resident in LDS, statistics of the stored rows from its epilogue
+        pw.A = (const unsigned short*)x; pw.W = (const unsigned short*)w; pw.OUT = (unsigned short*)z; pw.part = (float*)ws;
+        hipError_t he = pw16_launch(pw, PW_PRO_NONE, PW_EPI_STATS, (hipStream_t)stream);
+        if (he != hipSuccess) return (int)he;
+        return rc(l_bn_finalize((const float*)ws, pw.nrb, gamma, beta, cout, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
+                                (hipStream_t)stream));
+    }
     if (s16) {
         Plan16 guard;
         PlanS16 storage(true);
@@ -1117,6 +1128,26 @@ int fte_conv2d_dgrad_bn(const void* dz, const void* w, const void* addin, const 
         return FTE_EINVAL;
     const DgradBn bn = {zbn, ybn, gamma, mean, rstd, bn_scale, bn_shift, dgamma, dbeta, coef};
     PlanBn bnplan;
+    Pw16Params pw;
+    memset(&pw, 0, sizeof(pw));
+    // (opt-in, FTE_PW16_DGRAD=1: measured SLOWER than the tile kernel's BN epilogue at 128 images -- 28x28 128<-256 69 vs 46 us, 14x14
+    // 512<-256 87 vs 58: the K = 256 form runs four waves per CU, too few to hide the row pass's three input loads)
+    static const bool pw_dgrad = getenv("FTE_PW16_DGRAD") && atoi(getenv("FTE_PW16_DGRAD")) == 1;
+    if (pw_dgrad && s16 && ksize == 1 && stride == 1 && n > 0 && pw16_plan((long)n * h * wd, cout, cin, PW_EPI_BN, &pw)) {
+        // the streaming pointwise kernel (pw16.hip): OUT[M, cin] = dz[M, cout] * W[cin, cout]^T (the HWIO pack's rows are its k-contiguous
+        // filter rows), mask and sums in its row-coalesced epilogue, one partial row per block
+        const size_t need = 2 * (size_t)pw.nrb * cin * sizeof(float);
+        if (!ws || ws_bytes < need) return FTE_EWORKSPACE;
+        pw.A = (const unsigned short*)dz; pw.W = (const unsigned short*)w; pw.OUT = (unsigned short*)g;
+        pw.ADD = (const unsigned short*)addin;
+        pw.Zm = (const unsigned short*)((!bn_scale && ybn) ? ybn : zbn);
+        pw.Zx = (const unsigned short*)((!bn_scale && ybn) ? zbn : nullptr);
+        pw.mu = mean; pw.rs = rstd; pw.sc = bn_scale; pw.sh = bn_shift;
+        pw.part = (float*)ws; pw.pgx = (float*)ws + (size_t)pw.nrb * cin;
+        hipError_t he = pw16_launch(pw, PW_PRO_NONE, PW_EPI_BN, (hipStream_t)stream);
+        if (he != hipSuccess) return (int)he;
+        return rc(l_bn_bwd_finalize(pw.part, pw.pgx, cin, pw.nrb, (long)n * h * wd, cin, gamma, mean, rstd, dgamma, dbeta, coef, (hipStream_t)stream));
+    }
     if (s16) {
         Plan16 guard;
         PlanS16 storage(true);

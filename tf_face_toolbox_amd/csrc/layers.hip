@@ -1191,9 +1191,22 @@ struct GconvBn {
     const float* mu; const float* rs; const float* sc; const float* sh;
 };
 struct GconvAcc { float a, b, c, shift; };      // BNF 1: n, sum d, sum d^2, shift;  BNF 2: sum g, sum g xhat
+// BNF 2: this lane's 16 z values of a tile (pixel rows (i & 3) + 8 (i >> 2) + 4 lh, its channel), requested at the TOP of the tile's
+// iteration so that they land under its matrix work (fetched where they are used, every tile stalled on 16 two-byte loads: 65 vs
+// 28 us for the 28x28x128 data gradient)
+template <int BNF>
+__device__ __forceinline__ void gconv_bn_prefetch(const GconvBn& bn, unsigned short (&zr)[16], long tile, long npix, int c, int ch, int lh) {
+    if constexpr (BNF == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            zr[i] = pr < npix ? bn.zbn[pr * c + ch] : (unsigned short)0;
+        }
+    }
+}
 template <int BNF>
 __device__ __forceinline__ void gconv_bn_tile(const GconvBn& bn, GconvAcc& st, f32x16_l& acc, long tile, long npix, int c, int ch, int lh,
-                                              float mu, float rs, float sc, float sh) {
+                                              float mu, float rs, float sc, float sh, const unsigned short (&zr)[16]) {
     if constexpr (BNF == 1) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1206,21 +1219,16 @@ __device__ __forceinline__ void gconv_bn_tile(const GconvBn& bn, GconvAcc& st, f
             }
         }
     } else if constexpr (BNF == 2) {
-        float z[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            z[i] = pr < npix ? __builtin_bit_cast(float, (unsigned)bn.zbn[pr * c + ch] << 16) : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            const float z = __builtin_bit_cast(float, (unsigned)zr[i] << 16);
             float g = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, (__bf16)acc[i]) << 16);
-            const bool on = pr < npix && (bn.sc == nullptr || __builtin_fmaf(z[i], sc, sh) > 0.f);
+            const bool on = pr < npix && (bn.sc == nullptr || __builtin_fmaf(z, sc, sh) > 0.f);
             g = on ? g : 0.f;
             acc[i] = g;
             st.a += g;
-            st.b += g * ((z[i] - mu) * rs);
+            st.b += g * ((z - mu) * rs);
         }
     }
 }
@@ -1277,6 +1285,8 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
         if (bn.sc) { bsc = bn.sc[slice * 32 + li]; bsh = bn.sh[slice * 32 + li]; }
     }
     for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        unsigned short zr[16];
+        gconv_bn_prefetch<BNF>(bn, zr, tile, npix, c, slice * 32 + li, lh);
         // the four pixels this lane fetches for: coordinates once per tile
         int foy[4], fox[4];
         long fbase[4];
@@ -1344,7 +1354,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
         }
         // C layout: column (channel) = lane & 31, row (pixel) = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5): 32 lanes write one pixel's 128 B
         const long yo = slice * 32 + li;
-        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh);
+        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh, zr);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
@@ -1410,6 +1420,8 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
         if (bn.sc) { bsc = bn.sc[slice * 32 + li]; bsh = bn.sh[slice * 32 + li]; }
     }
     for (; tile < ntiles; tile += stride_t) {
+        unsigned short zr[16];
+        gconv_bn_prefetch<BNF>(bn, zr, tile, npix, c, slice * 32 + li, lh);
         const long p = tile * 32 + li;
         const bool pok = p < npix;
         const unsigned pu = (unsigned)(pok ? p : 0);
@@ -1453,7 +1465,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
         row(2, sb);
         sb ^= 1;
         const long yo = slice * 32 + li;
-        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh);
+        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh, zr);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;

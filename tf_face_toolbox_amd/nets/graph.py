@@ -450,6 +450,12 @@ class GraphNet(Network):
         # (fuse_bwd: name of the BN output -> plan index of the BN).  Which of them can run fused (MFMA conv path, storage
         # mode, grouped conv on the bf16 MFMA) is decided where they run.  FTE_BN_FUSE=0: off (A/B hook).
         self.fuse_fwd, self.fuse_bwd = {}, {}
+        # The backward half is OPT-IN (FTE_BN_FUSE_BWD=1 / FTE_BN_FUSE_GBWD=1).  Measured on MI355X at 128 images per GPU, ms per step,
+        # forward only / + conv data gradients / + grouped-conv data gradients / no fusion: ResNeXt-50 7.84 / 7.91 / 8.17 / 8.23, ResNet-50
+        # 7.27 / 7.38 / - / 7.66, SE-ResNet-50 9.52 / 9.40 / - / 9.87, ShuffleNet-v2 (fp32, 256) 8.10 / 8.11 / - / 8.60: the tile kernels'
+        # epilogue waits for its three extra inputs with 3 blocks per CU, which costs what the separate reduce pass cost.
+        self.fuse_bwd_conv = os.environ.get('FTE_BN_FUSE_BWD', '0') == '1'
+        self.fuse_bwd_gconv = os.environ.get('FTE_BN_FUSE_GBWD', '0') == '1'
         if os.environ.get('FTE_BN_FUSE', '1') != '0':
             producer = {op[1]: j for j, op in enumerate(plan) if op[0] in ('conv', 'gconv')}
             for j, op in enumerate(plan):
@@ -1084,7 +1090,7 @@ class GraphNet(Network):
                     wgrad('fte_gconv3x3_wgrad', dy, T[inp], dy, self.view(wname, self.grads), n, ih, iw, c, groups, stride, wws, self.ws_bytes, wst)
                 dx = self._new(inp)
                 pk = self._gconv_pack(op)
-                bnb = bn_below(inp) if (pk is not None and s16) else None
+                bnb = bn_below(inp) if (pk is not None and s16 and self.fuse_bwd_gconv) else None
                 if bnb is not None:                      # ... with the mask / sums of the BN layer below in the epilogue
                     (zbn, _, gam, mean, rstd, sc, sh), outs = bnb
                     call('fte_gconv3x3_dgrad_bn_bf16_s16', dy, pk[1], zbn, gam, mean, rstd, sc, sh, dx, *outs, n, ih, iw, c, stride,
@@ -1151,7 +1157,7 @@ class GraphNet(Network):
                 flush(self.side_batch)
                 prev = G.pop(inp, None)                  # accumulate into an existing contribution through `addin`
                 dx = self._new(inp)
-                bnb = bn_below(inp)
+                bnb = bn_below(inp) if self.fuse_bwd_conv else None
                 if bnb is not None:          # the last contribution to the gradient of a BN output: mask + BN sums in the epilogue
                     ins, outs = bnb
                     call('fte_conv2d_dgrad_bn', dy, self.w16[wname] if s16 else self.view(wname), prev, *ins, dx, *outs,
