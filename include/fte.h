@@ -344,8 +344,15 @@ int fte_gconv3x3_wgrad_bf16_s16(const uint16_t* x16, const uint16_t* dz16, float
  * The grouped 3x3 twins run on the bf16 MFMA with bf16 tensors (4 / 8 / 16 / 32 channels per group, c % 32 == 0).
  * ------------------------------------------------------------------------- */
 size_t fte_conv2d_bn_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+/* in_scale / in_shift / y_side (all three or none): `x` is then the PRE-normalisation tensor of the batch norm IN FRONT of this conv
+ * (conv -> BN -> ReLU -> conv chains); the operand loader applies y = relu(in_scale[k] * x + in_shift[k]) -- the expression and the
+ * bf16 rounding of fte_bn_apply -- on the way to the matrix cores and writes the normalised rows to y_side, which only the filter
+ * gradient reads: the fte_bn_apply launch between the two convs and its pass over the tensor disappear.  Taken by the streaming
+ * pointwise kernel only: fte_conv2d_bn_fwd_folds() says whether a shape qualifies (bf16 storage, 1x1, stride 1, cin 64 / 128 / 256). */
+int fte_conv2d_bn_fwd_folds(int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16);
 int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma, const float* beta, float* mean, float* rstd,
                       float* scale, float* shift, float* moving_mean, float* moving_var, float eps, float decay,
+                      const float* in_scale, const float* in_shift, void* y_side,
                       int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream);
 size_t fte_conv2d_dgrad_bn_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 int fte_conv2d_dgrad_bn(const void* dz, const void* w, const void* addin, const void* zbn, const void* ybn,
@@ -357,9 +364,11 @@ int fte_bn_apply(const void* z, const float* scale, const float* shift, const vo
 /* dz = coef[c] * g + coef[C + c] * z + coef[2C + c], g already masked; flags: FTE_S16_Z (z, dz bf16), FTE_S16_A (g bf16) */
 int fte_bn_bwd_apply(const void* g, const void* z, const float* coef, void* dz, long rows, int c, int flags, void* stream);
 size_t fte_gconv3x3_bn_ws_bytes(int n, int h, int wd, int c, int stride);
+/* (in_scale / in_shift / y_side as above; stride 1 only) */
 int fte_gconv3x3_bn_fwd_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* z16, const float* gamma, const float* beta,
                                  float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
-                                 float eps, float decay, int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream);
+                                 float eps, float decay, const float* in_scale, const float* in_shift, uint16_t* y_side,
+                                 int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream);
 int fte_gconv3x3_dgrad_bn_bf16_s16(const uint16_t* dz16, const uint16_t* wpk_dgrad, const uint16_t* zbn16, const float* gamma, const float* mean,
                                    const float* rstd, const float* bn_scale, const float* bn_shift, uint16_t* g16, float* dgamma, float* dbeta,
                                    float* coef, int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream);

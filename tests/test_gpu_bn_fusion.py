@@ -81,7 +81,7 @@ def test_conv_bn_fwd_fp32_tensors(n, h, w, cin, cout, ks, stride, mode):
     _lib.set_mfma_dtype(mode)
     try:
         call('fte_conv2d_bn_fwd', dev(x), dev(wt), z, dev(gamma), dev(beta), mean, rstd, scale, shift, mmd, mvd, EPS, DECAY,
-             n, h, w, cin, cout, ks, stride, 0, wsb, nb, stream())
+             None, None, None, n, h, w, cin, cout, ks, stride, 0, wsb, nb, stream())
     finally:
         _lib.set_mfma_dtype('f32')
     check_maxabs(host(z), z_ref, what='z')
@@ -109,7 +109,7 @@ def test_conv_bn_fwd_bf16_storage(n, h, w, cin, cout, ks, stride):
     _lib.set_mfma_dtype('bf16s')
     try:
         call('fte_conv2d_bn_fwd', _dev16(x), w16t, z16, dev(gamma), dev(beta), mean, rstd, scale, shift, mmd, mvd, EPS, DECAY,
-             n, h, w, cin, cout, ks, stride, 1, wsb, nb, stream())
+             None, None, None, n, h, w, cin, cout, ks, stride, 1, wsb, nb, stream())
     finally:
         _lib.set_mfma_dtype('f32')
     zs = _host16(z16)
@@ -244,7 +244,7 @@ def test_gconv_bn_fwd_and_dgrad_bf16_storage(n, h, w, c, groups, stride):
     mmd, mvd = dev(mm), dev(mv)
     wsb, nb = ws(query('fte_gconv3x3_bn_ws_bytes', n, h, w, c, stride))
     call('fte_gconv3x3_bn_fwd_bf16_s16', x16, wf, z16, dev(gamma), dev(beta), mean, rstd, scale, shift, mmd, mvd, EPS, DECAY,
-         n, h, w, c, stride, wsb, nb, stream())
+         None, None, None, n, h, w, c, stride, wsb, nb, stream())
     assert torch.equal(z16, z_plain)
     zs = _host16(z16)
     cache, sc_ref, sh_ref, mm_ref, mv_ref = _stats_ref(zs, gamma, beta, mm, mv)
@@ -298,3 +298,78 @@ def test_bn_apply_matches_the_train_forward():
     call('fte_bn_train_fwd_s16', z16, dev(gamma), dev(beta), r16, y3, mean, rstd, scale, shift, None, None, rows, c, EPS, DECAY, 1, 3, wsb, nb, stream())
     call('fte_bn_apply', z16, scale, shift, r16, y4, rows, c, 1, 3, stream())
     assert torch.equal(y3, y4)
+
+
+FOLD_SHAPES = [(3, 14, 14, 64, 256), (2, 9, 7, 128, 128), (64, 28, 28, 128, 256), (131, 7, 7, 256, 512), (5, 3, 3, 256, 64), (33, 28, 28, 64, 64)]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout', FOLD_SHAPES)
+def test_conv_bn_fwd_folds_the_normalise_pass_of_the_bn_in_front(n, h, w, cin, cout):
+    """conv -> BN -> ReLU -> conv (nets/resnet.py:47-61): the second conv takes the first BN's PRE-normalisation tensor and its scale /
+    shift; z, the statistics and the side-stored y must equal, bit for bit, fte_bn_apply followed by the plain fused conv"""
+    r = _rng(27)
+    assert query('fte_conv2d_bn_fwd_folds', n, h, w, cin, cout, 1, 1, 1) == 1
+    zp = _bf(r.standard_normal((n, h, w, cin)) * 1.5 + 0.3)
+    isc = (1 + 0.2 * r.standard_normal(cin)).astype(np.float32); ish = (0.3 * r.standard_normal(cin)).astype(np.float32)
+    wt = _bf(r.standard_normal((1, 1, cin, cout)) * 0.05)
+    gamma = 1 + 0.2 * r.standard_normal(cout); beta = 0.3 * r.standard_normal(cout)
+    _, w16t = _pack16(wt)
+    zp16 = _dev16(zp)
+    rows = n * h * w
+    y_ref = torch.empty((n, h, w, cin), dtype=torch.int16, device='cuda')
+    call('fte_bn_apply', zp16, dev(isc), dev(ish), None, y_ref, rows, cin, 1, 3, stream())
+    wsb, nb = ws(query('fte_conv2d_bn_fwd_ws_bytes', n, h, w, cin, cout, 1, 1))
+    outs = []
+    _lib.set_mfma_dtype('bf16s')
+    try:
+        for fold in (False, True):
+            z16 = torch.full((n, h, w, cout), 0x4100, dtype=torch.int16, device='cuda')
+            st = [torch.empty(cout, device='cuda') for _ in range(4)]
+            mm, mv = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+            ys = torch.full((n, h, w, cin), 0x4100, dtype=torch.int16, device='cuda')
+            if fold:
+                call('fte_conv2d_bn_fwd', zp16, w16t, z16, dev(gamma), dev(beta), st[0], st[1], st[2], st[3], mm, mv, EPS, DECAY,
+                     dev(isc), dev(ish), ys, n, h, w, cin, cout, 1, 1, 1, wsb, nb, stream())
+            else:
+                call('fte_conv2d_bn_fwd', y_ref, w16t, z16, dev(gamma), dev(beta), st[0], st[1], st[2], st[3], mm, mv, EPS, DECAY,
+                     None, None, None, n, h, w, cin, cout, 1, 1, 1, wsb, nb, stream())
+            outs.append((z16, st, mm, mv, ys))
+    finally:
+        _lib.set_mfma_dtype('f32')
+    assert torch.equal(outs[1][4], y_ref), 'side-stored y differs from fte_bn_apply'
+    assert torch.equal(outs[0][0], outs[1][0]), 'z differs'
+    for a, b in zip(outs[0][1] + [outs[0][2], outs[0][3]], outs[1][1] + [outs[1][2], outs[1][3]]):
+        assert torch.equal(a, b)
+    # and against the oracle: y = relu(isc * zp + ish) rounded, z = y * w
+    y64 = _bf(np.maximum(zp * isc.astype(np.float64) + ish.astype(np.float64), 0))
+    check_rell2(_host16(outs[1][4]), y64, 2e-3, 'y vs the oracle')
+    check_rell2(_host16(outs[1][0]), _bf(ops.conv2d_fwd(_host16(outs[1][4]), wt, 1)), 2e-3, 'z vs the oracle')
+
+
+@pytest.mark.parametrize('n,h,w,c,groups', [(3, 14, 14, 128, 32), (2, 9, 7, 256, 32), (16, 28, 28, 128, 32), (1, 5, 5, 1024, 32)])
+def test_gconv_bn_fwd_folds_the_normalise_pass_of_the_bn_in_front(n, h, w, c, groups):
+    r = _rng(28)
+    gw = c // groups
+    zp = _bf(r.standard_normal((n, h, w, c)) * 1.5 + 0.3)
+    isc = (1 + 0.2 * r.standard_normal(c)).astype(np.float32); ish = (0.3 * r.standard_normal(c)).astype(np.float32)
+    wg = r.standard_normal((groups, 3, 3, gw, gw)) * 0.1
+    wf = torch.empty((c // 32) * 9 * 1024, dtype=torch.int16, device='cuda'); wd_ = torch.empty_like(wf)
+    call('fte_gconv3x3_pack_bf16', dev(wg), wf, wd_, c, groups, stream())
+    gamma = 1 + 0.2 * r.standard_normal(c); beta = 0.3 * r.standard_normal(c)
+    zp16 = _dev16(zp)
+    rows = n * h * w
+    y_ref = torch.empty((n, h, w, c), dtype=torch.int16, device='cuda')
+    call('fte_bn_apply', zp16, dev(isc), dev(ish), None, y_ref, rows, c, 1, 3, stream())
+    wsb, nb = ws(query('fte_gconv3x3_bn_ws_bytes', n, h, w, c, 1))
+    outs = []
+    for fold in (False, True):
+        z16 = torch.full((n, h, w, c), 0x4100, dtype=torch.int16, device='cuda')
+        st = [torch.empty(c, device='cuda') for _ in range(4)]
+        ys = torch.full((n, h, w, c), 0x4100, dtype=torch.int16, device='cuda')
+        call('fte_gconv3x3_bn_fwd_bf16_s16', zp16 if fold else y_ref, wf, z16, dev(gamma), dev(beta), st[0], st[1], st[2], st[3], None, None,
+             EPS, DECAY, dev(isc) if fold else None, dev(ish) if fold else None, ys if fold else None, n, h, w, c, 1, wsb, nb, stream())
+        outs.append((z16, st, ys))
+    assert torch.equal(outs[1][2], y_ref), 'side-stored y differs from fte_bn_apply'
+    assert torch.equal(outs[0][0], outs[1][0]), 'z differs'
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

@@ -92,13 +92,14 @@ _SIGS = {
     'fte_channel_gather_affine_s16': (c_int, [_P] * 4 + [c_int, _P, _P, c_int, c_long, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P]),
     'fte_bn_train_stats_s16': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
     'fte_conv2d_bn_fwd_ws_bytes': (c_size_t, [c_int] * 7),
-    'fte_conv2d_bn_fwd': (c_int, [_P] * 11 + [c_float, c_float] + [c_int] * 8 + [_P, c_size_t, _P]),
+    'fte_conv2d_bn_fwd': (c_int, [_P] * 11 + [c_float, c_float] + [_P] * 3 + [c_int] * 8 + [_P, c_size_t, _P]),
+    'fte_conv2d_bn_fwd_folds': (c_int, [c_int] * 8),
     'fte_conv2d_dgrad_bn_ws_bytes': (c_size_t, [c_int] * 7),
     'fte_conv2d_dgrad_bn': (c_int, [_P] * 14 + [c_int] * 8 + [_P, c_size_t, _P]),
     'fte_bn_apply': (c_int, [_P] * 5 + [c_long, c_int, c_int, c_int, _P]),
     'fte_bn_bwd_apply': (c_int, [_P] * 4 + [c_long, c_int, c_int, _P]),
     'fte_gconv3x3_bn_ws_bytes': (c_size_t, [c_int] * 5),
-    'fte_gconv3x3_bn_fwd_bf16_s16': (c_int, [_P] * 11 + [c_float, c_float] + [c_int] * 5 + [_P, c_size_t, _P]),
+    'fte_gconv3x3_bn_fwd_bf16_s16': (c_int, [_P] * 11 + [c_float, c_float] + [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),
     'fte_gconv3x3_dgrad_bn_bf16_s16': (c_int, [_P] * 12 + [c_int] * 5 + [_P, c_size_t, _P]),
     'fte_set_mfma_dtype': (c_int, [c_int]),
     'fte_get_mfma_dtype': (c_int, []),

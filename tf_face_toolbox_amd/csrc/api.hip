@@ -1084,11 +1084,18 @@ size_t fte_conv2d_bn_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int k
     const size_t rows = ((size_t)n * ph.out * pw.out + 63) / 64 + 2;      // at most one partial row per 64 output rows
     return align_up(rows * 3 * cout * sizeof(float));
 }
+int fte_conv2d_bn_fwd_folds(int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16) {
+    Pw16Params pw;
+    return s16 == 1 && ksize == 1 && stride == 1 && n > 0 && h > 0 && wd > 0 && pw16_plan((long)n * h * wd, cin, cout, PW_EPI_STATS, &pw) ? 1 : 0;
+}
 int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma, const float* beta, float* mean, float* rstd,
                       float* scale, float* shift, float* moving_mean, float* moving_var, float eps, float decay,
+                      const float* in_scale, const float* in_shift, void* y_side,
                       int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream) {
     if (!z || !gamma || !beta || !mean || !rstd || !scale || !shift || (s16 & ~1) || ((moving_mean == nullptr) != (moving_var == nullptr)))
         return FTE_EINVAL;
+    if (((in_scale == nullptr) != (in_shift == nullptr)) || (in_scale && !y_side) ||
+        (in_scale && !fte_conv2d_bn_fwd_folds(n, h, wd, cin, cout, ksize, stride, s16))) return FTE_EINVAL;
     if (!ws || ws_bytes < fte_conv2d_bn_fwd_ws_bytes(n, h, wd, cin, cout, ksize, stride)) return FTE_EWORKSPACE;
     PlanBn bnplan;
     int rows = 0, e;
@@ -1097,7 +1104,8 @@ int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma,
     if (s16 && ksize == 1 && stride == 1 && pw16_plan((long)n * h * wd, cin, cout, PW_EPI_STATS, &pw)) {
         // the streaming pointwise kernel (pw16.hip): filter slice resident in LDS, statistics of the stored rows from its epilogue
         pw.A = (const unsigned short*)x; pw.W = (const unsigned short*)w; pw.OUT = (unsigned short*)z; pw.part = (float*)ws;
-        hipError_t he = pw16_launch(pw, PW_PRO_NONE, PW_EPI_STATS, (hipStream_t)stream);
+        pw.c0 = in_scale; pw.c1 = in_shift; pw.SIDE = (unsigned short*)y_side;
+        hipError_t he = pw16_launch(pw, in_scale ? PW_PRO_FWD : PW_PRO_NONE, PW_EPI_STATS, (hipStream_t)stream);
         if (he != hipSuccess) return (int)he;
         return rc(l_bn_finalize((const float*)ws, pw.nrb, gamma, beta, cout, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
                                 (hipStream_t)stream));
@@ -1171,17 +1179,20 @@ size_t fte_gconv3x3_bn_ws_bytes(int n, int h, int wd, int c, int stride) {
 }
 int fte_gconv3x3_bn_fwd_bf16_s16(const uint16_t* x16, const uint16_t* wpk, uint16_t* z16, const float* gamma, const float* beta,
                                  float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
-                                 float eps, float decay, int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream) {
+                                 float eps, float decay, const float* in_scale, const float* in_shift, uint16_t* y_side,
+                                 int n, int h, int wd, int c, int stride, void* ws, size_t ws_bytes, void* stream) {
     if (!x16 || !wpk || !z16 || !gamma || !beta || !mean || !rstd || !scale || !shift || n <= 0 || h <= 0 || wd <= 0 || c <= 0 || c % 32 ||
         (stride != 1 && stride != 2) || (long)n * h * wd >= ((long)1 << 31) || ((moving_mean == nullptr) != (moving_var == nullptr)))
         return FTE_EINVAL;
+    if (((in_scale == nullptr) != (in_shift == nullptr)) || (in_scale && (!y_side || stride != 1))) return FTE_EINVAL;
     if (!ws || ws_bytes < fte_gconv3x3_bn_ws_bytes(n, h, wd, c, stride)) return FTE_EWORKSPACE;
     const Pads ph = same_pads(h, 3, stride), pw = same_pads(wd, 3, stride);
     hipError_t e;
     int rows;
     if (stride == 1) {
         rows = l_gconv_bn_rows(n, h, wd, c);
-        e = l_gconv_mfma16_bn(f32p(x16), wpk, f32p(z16), n, h, wd, c, h, wd, 0, 1, 1, 1, (float*)ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+        e = l_gconv_mfma16_bn(f32p(x16), wpk, f32p(z16), n, h, wd, c, h, wd, 0, 1, 1, 1, (float*)ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream,
+                              in_scale, in_shift, y_side);
     } else {
         rows = l_gconv_bn_rows(n, ph.out, pw.out, c);
         e = l_gconv_mfma16_bn(f32p(x16), wpk, f32p(z16), n, ph.out, pw.out, c, h, wd, 1, ph.before, pw.before, 1, (float*)ws, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,

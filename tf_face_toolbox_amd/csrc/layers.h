@@ -39,7 +39,8 @@ hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, i
 int l_gconv_bn_rows(int n, int h, int wd, int c);
 hipError_t l_gconv_mfma16_bn(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
                              int mode, int pt, int pl, int bnf, float* part, float* pgx, const unsigned short* zbn, const float* mu,
-                             const float* rs, const float* sc, const float* sh, hipStream_t st);
+                             const float* rs, const float* sc, const float* sh, hipStream_t st, const float* isc = nullptr,
+                             const float* ish = nullptr, unsigned short* yside = nullptr);
 int l_gconv_wgrad16_chunks(long npix, int c);
 hipError_t l_gconv_wgrad16(const float* x, const float* dz, float* part, float* dw, int n, int h, int wd, int c, int groups,
                            int ho, int wo, int stride, int pt, int pl, int chunks, hipStream_t st, int h16 = 0);

@@ -1189,6 +1189,10 @@ struct GconvBn {
     float* pgx;                        // BNF 2
     const unsigned short* zbn;         // BNF 2: the BN layer's input z (bf16), same shape as the gradient written
     const float* mu; const float* rs; const float* sc; const float* sh;
+    // PRO (window kernel, forward): x is the PRE-normalisation tensor of the batch norm in front of the layer; the loader applies
+    // y = relu(isc[c] * x + ish[c]) -- bn_apply's expression, rounded to bf16 as its store would -- and writes the tile's own pixels
+    // back to yside (the filter gradient's operand; nothing else reads y): the bn_apply launch in front of the layer disappears
+    const float* isc; const float* ish; unsigned short* yside;
 };
 struct GconvAcc { float a, b, c, shift; };      // BNF 1: n, sum d, sum d^2, shift;  BNF 2: sum g, sum g xhat
 // BNF 2: this lane's 16 z values of a tile (pixel rows (i & 3) + 8 (i >> 2) + 4 lh, its channel), requested at the TOP of the tile's
@@ -1370,7 +1374,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
 // ONCE (coalesced 128-byte rows, rounded to bf16, 80-byte LDS rows), and the three taps q read window rows li + q; the image /
 // row edges are a 9-bit mask per lane that zeroes the fragment.  gconv3x3_mfma16_kernel<0> fetched every tap on its own: 9 x the
 // tensor through L2 -> L1 (461 MB for the 28x28x128 layer at 128 images, 52 us = the L2 rate); this one moves 3.2 x.
-template <bool H = false, int BNF = 0>
+template <bool H = false, int BNF = 0, bool PRO = false>
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                                   float* __restrict__ y, int n, int h, int wd, int c, GconvBn bn) {
     __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
@@ -1390,13 +1394,22 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
     const int fr = lane >> 3, fp = lane & 7;
     const long xs = slice * 32 + (fp << 2);
     unsigned short* wb = &win[wv][0][0];
+    f32x4 isc4 = {0.f, 0.f, 0.f, 0.f}, ish4 = isc4;
+    if constexpr (PRO) { isc4 = *reinterpret_cast<const f32x4*>(bn.isc + xs); ish4 = *reinterpret_cast<const f32x4*>(bn.ish + xs); }
     auto fetch = [&](long tile, int r, f32x4 (&v)[5]) {
         const long s0 = tile * 32 - 1 + (long)(r - 1) * wd + fr;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const long sp = s0 + 8 * i;
             const bool ok = fr + 8 * i < 34 && sp >= 0 && sp < npix;
-            const f32x4 val = ldq<H>(x, xs + (ok ? sp : 0) * c);
+            f32x4 val = ldq<H>(x, xs + (ok ? sp : 0) * c);
+            if constexpr (PRO) {
+                val = bn_affine(val, isc4, ish4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+                // the centre row's window entries 1 .. 32 are the tile's own pixels: each pixel of the tensor exactly once
+                if (r == 1 && ok && fr + 8 * i >= 1 && fr + 8 * i <= 32) stq<true>(reinterpret_cast<float*>(bn.yside), xs + sp * c, val);
+            }
             v[i] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -1802,10 +1815,13 @@ hipError_t l_gconv_mfma16(const float* x, const unsigned short* wpk, float* y, i
 // landing on a BN (+ ReLU) output (mode 0 / 2).  part (and pgx): l_gconv_bn_rows(n, h, wd, c) partial rows.
 hipError_t l_gconv_mfma16_bn(const float* x, const unsigned short* wpk, float* y, int n, int h, int wd, int c, int hs, int ws,
                              int mode, int pt, int pl, int bnf, float* part, float* pgx, const unsigned short* zbn, const float* mu,
-                             const float* rs, const float* sc, const float* sh, hipStream_t st) {
+                             const float* rs, const float* sc, const float* sh, hipStream_t st, const float* isc, const float* ish,
+                             unsigned short* yside) {
     const dim3 grid((unsigned)gconv16_blocks((long)n * h * wd, c, true), c / 32);
-    const GconvBn bn = {part, pgx, zbn, mu, rs, sc, sh};
-    if (bnf == 1 && mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_win_kernel<true, 1>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, bn);
+    const GconvBn bn = {part, pgx, zbn, mu, rs, sc, sh, isc, ish, yside};
+    if (isc && !(bnf == 1 && mode == 0)) return hipErrorInvalidValue;
+    if (bnf == 1 && mode == 0 && isc) hipLaunchKernelGGL((gconv3x3_mfma16_win_kernel<true, 1, true>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, bn);
+    else if (bnf == 1 && mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_win_kernel<true, 1>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, bn);
     else if (bnf == 1 && mode == 1) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<1, true, 1>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, bn);
     else if (bnf == 2 && mode == 0) hipLaunchKernelGGL((gconv3x3_mfma16_win_kernel<true, 2>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, bn);
     else if (bnf == 2 && mode == 2) hipLaunchKernelGGL((gconv3x3_mfma16_kernel<2, true, 2>), grid, dim3(256), 0, st, x, wpk, y, n, h, wd, c, hs, ws, pt, pl, bn);

@@ -469,6 +469,19 @@ class GraphNet(Network):
                     first = plan[us[0]]
                     if (first[0] == 'conv' and len(us) <= 2) or (first[0] == 'gconv' and len(us) == 1):
                         self.fuse_bwd[op[1]] = j
+        # ... and the normalise pass of a BN + ReLU whose output feeds ONE conv / grouped conv that itself runs fused can move into
+        # that consumer's operand loader (fold_apply: plan index of the BN -> plan index of the consumer): the consumer reads the
+        # BN's input z, applies scale / shift / ReLU on the way to the matrix cores and writes the normalised tensor back for the
+        # filter gradient; the bn_apply launch and its pass over the tensor disappear (fte.h, fte_conv2d_bn_fwd's in_scale).
+        # Whether the consumer's kernel takes it (bf16 storage, pointwise stride-1 conv of 64 / 128 / 256 channels, or a
+        # stride-1 grouped conv on the bf16 MFMA) is decided where it runs.  FTE_BN_FOLD=0: off (A/B hook).
+        self.fold_apply = {}
+        if self.fuse_fwd and os.environ.get('FTE_BN_FOLD', '1') != '0':
+            for j, op in enumerate(plan):
+                if op[0] == 'bn' and op[4] is None and op[5] and op[1] != self.feature_name and j in self.fuse_fwd.values():
+                    us = pusers.get(op[1], [])
+                    if len(us) == 1 and us[0] in self.fuse_fwd and plan[us[0]][0] in ('conv', 'gconv') and plan[us[0]][2] == op[1]:
+                        self.fold_apply[j] = us[0]
         self.plan = plan
         self.has_classifier = plan[-1][0] == 'fc'
 
@@ -636,7 +649,28 @@ class GraphNet(Network):
         if s16:
             self.packs.refresh(self.params, st)          # every filter's bf16 packs, two launches
         stats_done = set()                               # BN plan ops whose statistics came out of the producing conv's epilogue
+        folded_in = {}                                   # consumer plan op -> BN plan op whose normalise pass its loader applies
         upd = self.update_moving_stats
+
+        def folds(bj):
+            """does the consumer of BN plan op bj take the normalise pass into its loader? (bf16 storage, training, statistics fused)"""
+            cj = self.fold_apply.get(bj)
+            if cj is None or not (s16 and is_training and bj in stats_done):
+                return False
+            cop = self.plan[cj]
+            ih_, iw_, cin_ = self.shapes[cop[2]]
+            if cop[0] == 'gconv':
+                return cop[4] == 1 and self._gconv_pack(cop) is not None
+            return bool(_lib.query('fte_conv2d_bn_fwd_folds', n, ih_, iw_, cin_, self.shapes[cop[1]][-1], self.spec[cop[3]][0][0], cop[4], 1))
+
+        def fold_args(j):
+            """(x, in_scale, in_shift, y_side) of consumer plan op j"""
+            bj = folded_in.get(j)
+            if bj is None:
+                return T[self.plan[j][2]], None, None, None
+            bop = self.plan[bj]
+            b = self.bn[bop[1]]
+            return T[bop[2]], b['scale'], b['shift'], T[bop[1]]
 
         def bn_args(j):
             bop = self.plan[j]
@@ -651,8 +685,9 @@ class GraphNet(Network):
                 k = self.spec[wname][0][0]
                 cout = self.shapes[out][-1]
                 if cin >= 32 and is_training and j in self.fuse_fwd:          # conv + the batch statistics of its output ("BN fusion")
-                    call('fte_conv2d_bn_fwd', T[inp], self.w16t[wname] if s16 else self.view(wname), T[out], *bn_args(self.fuse_fwd[j]),
-                         n, ih, iw, cin, cout, k, stride, 1 if s16 else 0, self.ws, self.ws_bytes, st)
+                    xin, isc, ish, yside = fold_args(j)
+                    call('fte_conv2d_bn_fwd', xin, self.w16t[wname] if s16 else self.view(wname), T[out], *bn_args(self.fuse_fwd[j]),
+                         isc, ish, yside, n, ih, iw, cin, cout, k, stride, 1 if s16 else 0, self.ws, self.ws_bytes, st)
                     stats_done.add(self.fuse_fwd[j])
                 elif cin >= 32 and s16:          # bf16 storage: bf16 x in, bf16 z out, filters packed once per step
                     call('fte_conv2d_fwd_s16', T[inp], self.w16t[wname], None, None, None, None, T[out], None, None,
@@ -719,7 +754,9 @@ class GraphNet(Network):
                 c = self.shapes[out][-1]
                 rows = T[out].numel() // c
                 resbuf = T[res] if res is not None else None
-                if j in stats_done:              # scale / shift are there already: the normalise pass alone
+                if j in stats_done and folds(j):  # ... which the consumer's operand loader takes over (it also writes T[out])
+                    folded_in[self.fold_apply[j]] = j
+                elif j in stats_done:            # scale / shift are there already: the normalise pass alone
                     assert res is None or not s16 or res in h16, 'bf16 storage: the shortcut of %s is an fp32 tensor' % out
                     call('fte_bn_apply', T[inp], b['scale'], b['shift'], resbuf, T[out], rows, c, relu, ((1 if inp in h16 else 0) | 2) if s16 else 0, st)
                 elif s16:
@@ -751,7 +788,8 @@ class GraphNet(Network):
                 if pk is not None:                             # bf16 MFMA mode: block-diagonal slices on the matrix cores
                     call('fte_gconv3x3_pack_bf16', self.view(op[3]), pk[0], pk[1], c, op[5], st)
                     if s16 and is_training and j in self.fuse_fwd:
-                        call('fte_gconv3x3_bn_fwd_bf16_s16', T[op[2]], pk[0], T[out], *bn_args(self.fuse_fwd[j]), n, ih, iw, c, op[4],
+                        xin, isc, ish, yside = fold_args(j)
+                        call('fte_gconv3x3_bn_fwd_bf16_s16', xin, pk[0], T[out], *bn_args(self.fuse_fwd[j]), isc, ish, yside, n, ih, iw, c, op[4],
                              self.ws, self.ws_bytes, st)
                         stats_done.add(self.fuse_fwd[j])
                     else:
