@@ -62,7 +62,8 @@ def test_single_rank_rccl_data_parallel_equals_singular(name):
 
 @pytest.mark.parametrize('name', ['ResNeXt-26', 'ShuffleNet-v2-small'])
 def test_single_rank_rccl_bn_nets_equal_singular(name):
-    """The graph-engine nets (two all-reduce buckets: classifier, then the body; filter gradients on a second stream) through the
+    """The graph-engine nets (one all-reduce bucket per backward segment: classifier, then the body from its last layers to its first;
+    filter gradients on a second stream, joined at every segment's end) through the
     same world-size-1 RCCL run: async all-reduce per backward stage, per-bucket optimizer after each wait -- bit-identical to
     Singular (same seeds: one replica's dropout seed is base * 1 + 0)."""
     n, h, w, ch, ncls = 8, 64, 64, 3, 10
@@ -87,7 +88,7 @@ def test_single_rank_rccl_bn_nets_equal_singular(name):
         net = make()
         model = DataParallel_margin(net, 0.05, 'Momentum', num_gpus=2)
         model.num_gpus = 1
-        assert len(net.grad_buckets()) == 2 == len(net.backward_stages())
+        assert len(net.grad_buckets()) == len(net.backward_stages()) >= 4      # classifier + the body's backward segments
         step, losses, names, others = model(inputs)
         for _ in range(3):
             step()

@@ -229,3 +229,23 @@ def test_two_ranks_center_loss_reconciled_tables(tmp_path):
     err = np.abs(c0 - newc).max()
     assert err <= 5e-4 * np.abs(newc).max(), err
     assert np.abs(c0[[3, 4, 6, 8, 9]]).max() == 0 and np.abs(c0[0]).max() > 0
+
+
+@pytest.mark.parametrize('name,b', [('ResNeXt-26-center', 8), ('SENet-50-triplet', 8)])
+def test_bench_net_runs_a_bn_net_with_two_ranks(tmp_path, name, b):
+    """scripts/bench_net.py --gpus 2 (its own ranks, as bench.py): a graph net as two DataParallel replicas, gradients reduced in the
+    buckets of its backward segments (classifier-less nets included) -- the line carries the allreduce block."""
+    import re
+    shared = torch.cuda.device_count() < 2
+    env = dict(os.environ, PYTHONPATH=ROOT, FTE_MFMA_DTYPE='bf16s')
+    if shared:
+        env['FTE_BENCH_SHARED_GPU'] = '1'
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'bench_net.py'), name, str(b), '3', '--gpus', '2']
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    m = re.search(r'x 2 GPUs: ([0-9.]+) ms/step', r.stdout)
+    assert m and float(m.group(1)) > 0, r.stdout
+    m = re.search(r'allreduce: backend (\w+), (\d+) buckets', r.stdout)
+    assert m and m.group(1) == ('gloo' if shared else 'nccl') and int(m.group(2)) >= 4, r.stdout

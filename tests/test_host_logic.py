@@ -232,3 +232,28 @@ def test_cli_leaves_with_the_real_status(tmp_path, body, code):
     src = 'import sys; sys.path.insert(0, %r)\nimport train\ndef f():\n    %s\ntrain._run_and_leave(f)\n' % (root, body)
     r = subprocess.run([sys.executable, '-c', src], capture_output=True, text=True, timeout=120)
     assert r.returncode == code, (r.returncode, r.stderr[-500:])
+
+
+@pytest.mark.parametrize('name', ['ResNet-50', 'ResNeXt-50-center', 'SENet-50-triplet', 'ShuffleNet-v2-small', 'ShuffleNet-v2-large', 'ResNet-26'])
+def test_graph_net_gradient_buckets_follow_the_backward_walk(name):
+    """data_parallel.py:88-113 reduces every gradient as it becomes ready; the graph nets hand DataParallel one bucket per backward
+    segment (classifier, then the body from its last layers to its first): the buckets tile the arena once, line up with the
+    backward stages, and every layer's filters lie in the bucket of the segment that computes their gradient."""
+    net = net_select(name)
+    net.build(112, 112, 3, 100, 'cpu')
+    b, stages, segs = net.grad_buckets(), net.backward_stages(), net._segments()
+    assert len(b) == len(stages) == len(segs) + (1 if net.has_classifier else 0)
+    assert len(segs) >= 3, 'the body of %s is one all-reduce bucket' % name
+    assert sum(e - a for a, e in b) == net.arena_size + 4
+    assert sorted(b)[0][0] == 0 and all(x[1] == y[0] for x, y in zip(sorted(b), sorted(b)[1:]))      # disjoint, gap-free
+    body = b[1:] if net.has_classifier else b
+    assert [x[0] for x in body] == sorted((x[0] for x in body), reverse=True)                          # completion order: from the end
+    nops = len(net.plan) - (1 if net.has_classifier else 0)
+    assert segs[0][0] == 0 and segs[-1][1] == nops and all(x[1] == y[0] for x, y in zip(segs, segs[1:]))
+    for lo, hi, a, e in segs:
+        for j in range(lo, hi):
+            for w in net._op_weight_names(net.plan[j]):
+                v = net.variables[w]
+                assert a <= v.offset and v.offset + v.size <= e, (name, w)
+    sizes = [e - a for _, _, a, e in segs]
+    assert max(sizes) <= 0.6 * sum(sizes)                                # no segment holds most of the body

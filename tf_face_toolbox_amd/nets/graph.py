@@ -967,13 +967,61 @@ class GraphNet(Network):
 
     # ---- backward ---------------------------------------------------------------------------------------
     def backward(self):
-        for stage in self.backward_stages():
-            stage()
+        if self.has_classifier:
+            self.backward_head()
+        self.backward_body()
 
     def backward_stages(self):
-        if self.has_classifier:
-            return [self.backward_head, self.backward_body]
-        return [self.backward_body]
+        """One callable per all-reduce bucket of grad_buckets(), in the order the backward walk completes them: the classifier, then
+        the body in segments from the last layers to the first (data_parallel.py:88-113 issues one nccl.all_sum per variable, which TF
+        schedules as each gradient becomes ready; here every segment's filter gradients are final -- side stream joined -- when its
+        callable returns, and DataParallel enqueues that bucket's all-reduce while the next segment still runs)."""
+        segs = self._segments()
+        body = [(lambda lo=lo, hi=hi: self.backward_body(lo, hi)) for lo, hi, _, _ in reversed(segs)]
+        return ([self.backward_head] if self.has_classifier else []) + body
+
+    def _op_weight_names(self, op):
+        if op[0] in ('conv', 'gconv', 'dwconv'):
+            return [op[3]]
+        if op[0] == 'se':
+            w1, _, w2, _, _ = self._se_names(op)
+            return [w1, w2]
+        return []
+
+    def _segments(self):
+        """[(plan lo, plan hi, arena a, arena b)] in forward order: the body's plan split into FTE_GRAD_BUCKETS (default 4) runs of
+        about equal filter bytes.  The filters lie in the arena in the order the plan uses them, so a run of ops owns a contiguous
+        arena range; the first segment's range starts at 0 and so carries gamma / beta / biases of the whole net (0.1 - 0.4 MB: final
+        early, reduced last, at no cost).  A net whose filters are not in plan order keeps ONE body segment."""
+        if getattr(self, '_segs', None) is not None:
+            return self._segs
+        nops = len(self.plan) - (1 if self.has_classifier else 0)
+        one = [(0, nops, 0, self.cls_start)]
+        want = int(os.environ.get('FTE_GRAD_BUCKETS', '4'))
+        offs = []                                        # (plan index, first arena offset, end offset) of every op with filters
+        for j in range(nops):
+            names = self._op_weight_names(self.plan[j])
+            if names:
+                vs = [self.variables[w] for w in names]
+                offs.append((j, min(v.offset for v in vs), max(v.offset + v.size for v in vs)))
+        mono = all(offs[i][2] <= offs[i + 1][1] for i in range(len(offs) - 1)) and (not offs or offs[0][1] >= self.small_end)
+        if want <= 1 or not mono or len(offs) < want:
+            self._segs = one
+            return one
+        total = offs[-1][2] - offs[0][1]
+        cuts, acc, k = [], 0, 1                          # cut BEFORE the op at which the running size passes k / want of the total
+        for i, (j, a, b) in enumerate(offs):
+            if k < want and i > 0 and acc >= total * k / want:
+                cuts.append((j, a))
+                k += 1
+            acc += b - a
+        segs, lo, a0 = [], 0, 0
+        for j, a in cuts:
+            segs.append((lo, j, a0, a))
+            lo, a0 = j, a
+        segs.append((lo, nops, a0, self.cls_start))
+        self._segs = segs
+        return segs
 
     def backward_head(self):
         """Classifier gradient (first all-reduce bucket) and the gradient wrt its input."""
@@ -990,18 +1038,22 @@ class GraphNet(Network):
     def _new(self, name):
         return torch.empty_like(self.t[name])
 
-    def backward_body(self):
+    def backward_body(self, lo=0, hi=None):
+        """The backward walk over plan ops [lo, hi) (default: the whole body), last op first.  Segments are walked from the end of
+        the plan: the gradients in flight between two calls stay in self._grad; when a call returns its filter gradients are final."""
         n = self._act_n
         st = _stream()
         call = _lib.call
         T = self.t
         s16 = self._act_s16
         h16 = self.h16
-        if not self.has_classifier:
+        nops = len(self.plan) - (1 if self.has_classifier else 0)
+        hi = nops if hi is None else hi
+        if hi == nops and not self.has_classifier:
             self._grad = {self.feature_name: self._dfeat}
             self._dfeat = None
         G = self._grad
-        ops = self.plan[:-1] if self.has_classifier else self.plan
+        ops = self.plan[lo:hi]
         # Filter gradients (conv / depthwise / grouped wgrad + their slab reductions) depend only on the layer's dz and its
         # stored input, and nothing but the optimizer reads them: they go to a second stream and overlap the dgrad -> BN
         # backward chain (these nets' kernels are 5-60 us long and leave CUs idle at their ramps and tails).  An event on
@@ -1009,7 +1061,9 @@ class GraphNet(Network):
         main, side = torch.cuda.current_stream(), self.side
         wst, wws = (side.cuda_stream, self.ws_side) if side is not None else (st, self.ws)
         pending = []
-        reduced = set()          # BN outputs whose mask / reduction pass ran in the epilogue of the data gradient that produced G[name]
+        if hi == nops:
+            self._reduced = set()
+        reduced = self._reduced  # BN outputs whose mask / reduction pass ran in the epilogue of the data gradient that produced G[name]
 
         def bn_below(name):
             """arguments of the BN layer whose output `name` a fused data gradient lands on, or None"""
@@ -1213,7 +1267,8 @@ class GraphNet(Network):
         if side is not None:
             flush()
             main.wait_stream(side)
-        self._grad = {}
+        if lo == 0:
+            self._grad = {}
 
     def _put(self, name, g):
         if name in self._grad:
@@ -1243,6 +1298,11 @@ class GraphNet(Network):
         return groups
 
     def grad_buckets(self):
+        """arena ranges of backward_stages()'s callables, in the same order; the four loss slots behind the arena ride on the bucket
+        that ends at the arena's end"""
+        segs = self._segments()
+        body = [(a, b) for _, _, a, b in reversed(segs)]
         if self.has_classifier:
-            return [(self.cls_start, self.arena_size + 4), (0, self.cls_start)]
-        return [(0, self.arena_size + 4)]
+            return [(self.cls_start, self.arena_size + 4)] + body
+        body[0] = (body[0][0], self.arena_size + 4)          # (cls_start == arena_size: the last segment ends the arena)
+        return body
