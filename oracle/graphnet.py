@@ -112,6 +112,19 @@ def noise_bands(graph, params, images, masks=None, state=None):
     return out
 
 
+BF16_NOISE_MULT = 4  # mixed-precision checks: band = this many times the oracle's OWN bf16-vs-exact discrepancy on that tensor (noise_bands16)
+
+
+def noise_bands16(graph, params, images, masks=None, state=None, stored=None):
+    """rms(oracle with bf16 operand rounding (+ the ambient storage rounding) - exact oracle) of every ReLU / max-pool output on THIS
+    input: what bf16 operands do to the decision tensors, from the oracle alone -- the mixed-precision counterpart of noise_bands()."""
+    with ops.operand_rounding('bf16'):
+        ea, _, _ = forward(graph, params, images, train=True, masks=masks, state=state, stored=stored)
+    with ops.no_rounding():
+        eb, _, _ = forward(graph, params, images, train=True, masks=masks, state=state)
+    return {op[1]: float(np.sqrt(((ea[op[1]] - eb[op[1]]) ** 2).mean())) for op in graph if op[0] in ('relu', 'maxpool')}
+
+
 def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='fp32', bands=None, stored=None, stored_grad=None):
     """dout: {tensor name: gradient}.  Returns (param grads, tensor grads).
     `kink` (optional): tensors of the implementation under test.  ReLU's derivative jumps at 0 and a
@@ -119,16 +132,18 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
     closer than the band to such a decision boundary either choice is valid for a float32
     evaluation, and the oracle adopts the choice the checked implementation made (there and only there):
     kink[relu_out] = its ReLU output, kink[pool_out + '/idx'] = its arg-max window positions.
-    The band: kink_mode 'fp32' -> max(KINK_BAND*rms, NOISE_MULT*bands[out]) with `bands` = noise_bands() of the
-    ORACLE (never a function of the implementation's tensors); kink_mode 'bf16' (mixed-precision checks only) ->
-    max(KINK_BAND*rms, 4x the forward discrepancy observed on that tensor)."""
+    The band is never a function of the implementation's tensors: kink_mode 'fp32' -> max(KINK_BAND*rms, NOISE_MULT*bands[out])
+    with `bands` = noise_bands() of the ORACLE; kink_mode 'bf16' (mixed-precision checks only) -> max(KINK_BAND*rms,
+    BF16_NOISE_MULT*bands[out]) with `bands` = noise_bands16() of the ORACLE (loss_and_grads computes it when not given)."""
     if kink_mode not in ('fp32', 'bf16'):
         raise ValueError(kink_mode)
+    if kink_mode == 'bf16' and kink is not None:
+        assert bands is not None, "the bf16 kink band needs the oracle's own noise figures (noise_bands16)"
 
-    def band_of(out, ref_rms, observed):
+    def band_of(out, ref_rms):
         thr = KINK_BAND * ref_rms
         if kink_mode == 'bf16':
-            return max(thr, 4 * observed())
+            return max(thr, BF16_NOISE_MULT * (bands or {}).get(out, 0.0))
         return max(thr, NOISE_MULT * (bands or {}).get(out, 0.0))
     gt = dict(dout)
     gp = OrderedDict()
@@ -163,7 +178,7 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
             pre = env[op[2]]
             on = pre > 0
             if kink is not None and out in kink:
-                thr = band_of(out, np.sqrt((pre * pre).mean()), lambda: np.sqrt(((kink[out] - np.maximum(pre, 0)) ** 2).mean()))
+                thr = band_of(out, np.sqrt((pre * pre).mean()))
                 band = np.abs(pre) < thr
                 on = np.where(band, kink[out] > 0, on)
             acc(gt, op[2], dy * on)
@@ -185,8 +200,12 @@ def backward(graph, params, env, cache, dout, masks=None, kink=None, kink_mode='
                     ok = (ih >= 0) & (ih < x.shape[1]) & (iw >= 0) & (iw < x.shape[2])
                     assert ok.all(), 'arg-max outside the image'
                     gap = env[out][diff] - x[ii[:, 0], ih, iw, ii[:, 3]]
-                    tie = band_of(out, np.sqrt((x * x).mean()), lambda: np.sqrt(((kink.get(out, env[out]) - env[out]) ** 2).mean()))
-                    assert (np.abs(gap) <= tie).all(), 'arg-max differs beyond the tie band'
+                    tie = band_of(out, np.sqrt((x * x).mean()))
+                    if kink_mode == 'bf16':          # candidates that are ONE value in the implementation's bf16 tensor differ here by at
+                        tie = tie + 2.0 ** -7 * np.abs(env[out][diff])      # most one bf16 ulp (<= 2^-7 |x|: the rounding) plus the noise band
+                    assert (np.abs(gap) <= tie).all(), 'arg-max differs beyond the tie band: %d of %d, worst gap %.3e at value %.3e, band %.3e' % (
+                        int((np.abs(gap) > tie).sum()), gap.size, float(np.abs(gap).max()), float(np.abs(env[out][diff])[np.argmax(np.abs(gap))]),
+                        float(band_of(out, np.sqrt((x * x).mean()))))
                     c = dict(c, arg=their)
             acc(gt, op[2], ops.maxpool3x3s2_bwd(dy, c))
         elif kind == 'gap':
@@ -510,6 +529,8 @@ def loss_and_grads(graph, params, images, labels, weight_decay=5e-4, masks=None,
             scale = center['weight'] * (1.0 if grad_scale is None else grad_scale * n)
             dout['features'] = dfe * scale
             extra['centers'] = newc
+    if kink is not None and kink_mode == 'bf16' and bands is None:
+        bands = noise_bands16(graph, params, images, masks=masks, state=state, stored=stored)
     gp, _ = backward(graph, params, env, cache, dout, masks=masks, kink=kink, kink_mode=kink_mode, bands=bands, stored=stored, stored_grad=stored_grad)
     reg_names = [k for k in params if k.endswith('weights')]      # weights, depthwise_weights, pointwise_weights
     reg = ops.l2_reg([params[k] for k in reg_names], weight_decay)

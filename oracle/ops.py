@@ -69,6 +69,19 @@ def storage_rounding(mode):
         _STORAGE_ROUND = prev
 
 
+@contextlib.contextmanager
+def no_rounding():
+    """Both rounding modes off inside the block (the exact float64 evaluation beside a rounded one: the oracles' own bf16 noise
+    figures, oracle/spherenet.py bf16_noise, oracle/graphnet.py noise_bands16)."""
+    global _OPERAND_ROUND, _STORAGE_ROUND
+    prev = (_OPERAND_ROUND, _STORAGE_ROUND)
+    _OPERAND_ROUND = _STORAGE_ROUND = None
+    try:
+        yield
+    finally:
+        _OPERAND_ROUND, _STORAGE_ROUND = prev
+
+
 def stored(a):
     """`a` as its consumers see it after a round trip through HBM in the active storage precision."""
     return a if _STORAGE_ROUND is None else _STORAGE_ROUND(a)

@@ -14,6 +14,11 @@ from tf_face_toolbox_amd import _lib
 # path's z to the oracle, which adopts its side inside the kink band only (oracle.spherenet.kink_resolved).
 TOL_MAXABS = 2e-5
 TOL_RELL2 = 2e-5
+# Mixed-precision checks ('bf16' / 'bf16s' modes): the band inside which the oracle adopts the implementation's side of a ReLU /
+# PReLU kink is BF16_KINK_MULT x the ORACLE's OWN bf16 noise on that tensor -- rms(oracle with bf16-rounded operands - exact oracle)
+# on the same input (oracle.spherenet.bf16_noise, oracle.graphnet.noise_bands16; per operand the unit roundoff is 2^-9, per layer
+# ~1.6e-3 * rms(z), compounding with depth) -- never a function of the tensors under test.
+BF16_KINK_MULT = 4
 
 
 def dev(a, dtype=torch.float32):
