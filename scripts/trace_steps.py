@@ -6,6 +6,11 @@ marker = sys.argv[2] if len(sys.argv) > 2 else 'softmax_ce'
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+for alt in ('triplet_dist', 'im2col_first_kernel', 'softmax'):          # nets without the default marker (no classifier: the triplet head)
+    if len(idx) > nsteps:
+        break
+    idx = [i for i, r in enumerate(rows) if alt in r['Kernel_Name']]
+nsteps = min(nsteps, len(idx) - 1)
 a, b = idx[-nsteps - 1], idx[-1]
 seg = rows[a:b]
 wall = (max(int(r['End_Timestamp']) for r in seg) - int(seg[0]['Start_Timestamp'])) / nsteps / 1e6

@@ -3,6 +3,7 @@
 // family, tile / split-K selection, ordered reductions.  Never allocates, never
 // synchronises; every launch goes to the caller's stream.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1105,7 +1106,13 @@ int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma,
         // the streaming pointwise kernel (pw16.hip): filter slice resident in LDS, statistics of the stored rows from its epilogue
         pw.A = (const unsigned short*)x; pw.W = (const unsigned short*)w; pw.OUT = (unsigned short*)z; pw.part = (float*)ws;
         pw.c0 = in_scale; pw.c1 = in_shift; pw.SIDE = (unsigned short*)y_side;
+        const long M = (long)n * h * wd;
+        const int sig[5] = {AL_MK, BL_NK, EPI_FWD, 8, 1};                         // tile id 8: the streaming pointwise kernel
+        const int hr = igemm_prof_begin(sig, (int)M, cout, cin, 2.0 * M * cout * (double)cin, 2.0 * M * (cin + cout) + 2.0 * cin * cout, (hipStream_t)stream);
         hipError_t he = pw16_launch(pw, in_scale ? PW_PRO_FWD : PW_PRO_NONE, PW_EPI_STATS, (hipStream_t)stream);
+        char sym[64];
+        snprintf(sym, sizeof(sym), "pw16_kernel<%d,%d,%d,%d,%d>", cin, cout / pw.nct, cin == 256 ? 4 : 8, in_scale ? PW_PRO_FWD : PW_PRO_NONE, PW_EPI_STATS);
+        igemm_prof_end(hr, sym, (hipStream_t)stream);
         if (he != hipSuccess) return (int)he;
         return rc(l_bn_finalize((const float*)ws, pw.nrb, gamma, beta, cout, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,
                                 (hipStream_t)stream));
