@@ -304,8 +304,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_v4_kernel(const float* __re
             sgx += g * ((zz - mu) * rs);
         };
         long r = r0 + rl;
-        for (; r + RL < r1; r += 2 * RL) { one(r); one(r + RL); }
-        if (r < r1) one(r);
+        // four rows in flight per lane (two were: 16 KB in flight per CU at 2 blocks of 256 threads -- the pass ran at 2.5-3.5 TB/s on
+        // the 25-50 MB tensors of a 128-image shard)
+        for (; r + 3 * RL < r1; r += 4 * RL) {
+            f32x4 g4[4], z4[4], m4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g4[u] = ldq<AH>(dy, (r + u * RL) * C + ch);
+                z4[u] = ldq<ZH>(z, (r + u * RL) * C + ch);
+                if (!zsc && ymask) m4[u] = ldq<AH>(ymask, (r + u * RL) * C + ch);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 g = g4[u];
+                if (zsc) {
+                    const f32x4 m = bn_affine(z4[u], sc, sf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+                } else if (ymask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = m4[u][e] > 0.f ? g[e] : 0.f;
+                }
+                if (gout) stq<AH>(gout, (r + u * RL) * C + ch, g);
+                sg += g;
+                sgx += g * ((z4[u] - mu) * rs);
+            }
+        }
+        for (; r < r1; r += RL) one(r);
     }
     sh[0][rl][q] = sg; sh[1][rl][q] = sgx;
     __syncthreads();
@@ -489,6 +514,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     int c = (int)((unsigned)(i % q) << 2);
     f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sf = *reinterpret_cast<const f32x4*>(shift + c);
+    if (inv) {
+        // four 16-byte (8-byte) pieces in flight per thread: the walk is a latency-bound stream at the 25-50 MB of a 128-image shard
+        for (; i + 3 * step < n4; i += 4 * step) {
+            f32x4 zv[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                zv[u] = ldq<ZH>(z, (i + u * step) * 4);
+                if (res) rv[u] = ldq<AH>(res, (i + u * step) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 v = bn_affine(zv[u], sc, sf);
+                if (res) v += rv[u];
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                stq<AH>(y, (i + u * step) * 4, v);
+            }
+        }
+    }
     for (; i < n4; i += step) {
         if (!inv) {
             c = (int)((unsigned)(i % q) << 2);
@@ -638,6 +684,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         if (zsc) { msc = *reinterpret_cast<const f32x4*>(zsc + c); msf = *reinterpret_cast<const f32x4*>(zsf + c); }
     };
     coefs(i);
+    if (inv) {
+        for (; i + 3 * step < n4; i += 4 * step) {          // four pieces of each input in flight per thread (see bn_apply_kernel)
+            f32x4 gv[4], zv[4], mv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gv[u] = ldq<AH>(dy, (i + u * step) * 4);
+                zv[u] = ldq<ZH>(z, (i + u * step) * 4);
+                if (!zsc && ymask) mv[u] = ldq<AH>(ymask, (i + u * step) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 g = gv[u];
+                if (zsc) {
+                    const f32x4 m = bn_affine(zv[u], msc, msf);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+                } else if (ymask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = mv[u][e] > 0.f ? g[e] : 0.f;
+                }
+                stq<ZH>(dz, (i + u * step) * 4, A * g + B * zv[u] + C0);
+            }
+        }
+    }
     for (; i < n4; i += step) {
         if (!inv) coefs(i);
         f32x4 g = ldq<AH>(dy, i * 4);
@@ -857,6 +927,11 @@ inline int grid_for_c(long n4, int C) {
     while (b) { const long t = a % b; a = b; b = t; }
     const long m = q / a;                                       // blocks must be a multiple of m
     long blocks = grid_for(n4);
+    // about 4 resident blocks per CU (measured at 128 images, ms per ResNeXt-50 / SE-ResNet-50 / ResNet-50 step: 512 blocks 7.53 / 9.33 / 7.13,
+    // 768: 7.52 / 9.26 / 7.10, 1024: 7.56 / 9.27 / 7.08, 2048: 7.68 / 9.44 / 7.22, one piece per thread: 7.70 / 9.44 / 7.24), each thread walking >= 4 pieces with all of them in flight (bn_apply_kernel's unrolled walk):
+    // one piece per thread on 6000+ blocks left 32 KB in flight per CU
+    static const long cap = getenv("FTE_BN_APPLY_BLOCKS") ? atol(getenv("FTE_BN_APPLY_BLOCKS")) : 1024;      // tuning hook
+    if (blocks > cap && n4 >= 4 * cap * 256) blocks = cap;
     blocks = (blocks + m - 1) / m * m;
     return (int)blocks;
 }
@@ -931,8 +1006,7 @@ hipError_t l_bn_train_stats(const float* z, const float* gamma, const float* bet
     }
 #undef FTE_ST
     if (!tail.cnt)      // scalar-channel layouts (C % 4 != 0, C < 32) and FTE_BN_TAIL unset: the splits are merged by a second launch
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay,
-                           mean, rstd, scale, shift, mov_mean, mov_var);
+        return l_bn_finalize(part, splits, gamma, beta, C, eps, decay, mean, rstd, scale, shift, mov_mean, mov_var, st);
     return hipGetLastError();
 }
 hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* mm, const float* mv, float eps, int C,
@@ -972,19 +1046,26 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
         default: hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 63) / 64, splits), dim3(256), 0, st, dy, ymask, z, mean, rstd, zsc, zsf, gout, part, rows, C, rps);
     }
 #undef FTE_BR
-    if (!tail.cnt)
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, part + C, 2L * C, splits, C, (float)rows, gamma, mean, rstd,
-                           dgamma, dbeta, coef);
+    if (!tail.cnt) {
+        hipError_t fe = l_bn_bwd_finalize(part, part + C, 2L * C, splits, rows, C, gamma, mean, rstd, dgamma, dbeta, coef, st);
+        if (fe != hipSuccess) return fe;
+    }
     const long n4 = rows * C / 4;
     if (gout) FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
     else FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C));
     return hipGetLastError();
 }
+// partial rows from which the finalize kernels take the wide form (one channel quad x 256 split lanes per block) instead of 16 channels x
+// 16 split lanes: FTE_BN_FIN_WIDE tunes it
+static int fin_wide_from() {
+    static const int v = getenv("FTE_BN_FIN_WIDE") ? atoi(getenv("FTE_BN_FIN_WIDE")) : 512;
+    return v;
+}
 // ---- the pieces of the "BN fusion" path (conv epilogues leave the partials; fte_conv2d_bn_fwd / fte_conv2d_dgrad_bn) ------------------
 // statistics partials [splits][3][C] (n, mean, M2) -> mean, rstd, scale, shift, moving statistics
 hipError_t l_bn_finalize(const float* part, int splits, const float* gamma, const float* beta, int C, float eps, float decay,
                          float* mean, float* rstd, float* scale, float* shift, float* mov_mean, float* mov_var, hipStream_t st) {
-    if (splits > 512 && C % 4 == 0)
+    if (splits > fin_wide_from() && C % 4 == 0)
         hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C / 4), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay, mean, rstd, scale, shift, mov_mean, mov_var);
     else
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, splits, C, gamma, beta, eps, decay, mean, rstd, scale, shift, mov_mean, mov_var);
@@ -993,7 +1074,7 @@ hipError_t l_bn_finalize(const float* part, int splits, const float* gamma, cons
 // backward partials pg / pgx [splits][ld] (sum g, sum g * xhat) -> dgamma, dbeta, coef[3][C] of dz = A g + B z + C0
 hipError_t l_bn_bwd_finalize(const float* pg, const float* pgx, long ld, int splits, long rows, int C, const float* gamma, const float* mean,
                              const float* rstd, float* dgamma, float* dbeta, float* coef, hipStream_t st) {
-    if (splits > 512 && C % 4 == 0 && ld % 4 == 0)
+    if (splits > fin_wide_from() && C % 4 == 0 && ld % 4 == 0)
         hipLaunchKernelGGL(bn_bwd_finalize_wide_kernel, dim3(C / 4), dim3(256), 0, st, pg, pgx, ld, splits, C, (float)rows, gamma, mean, rstd, dgamma, dbeta, coef);
     else
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, pg, pgx, ld, splits, C, (float)rows, gamma, mean, rstd, dgamma, dbeta, coef);
