@@ -72,8 +72,13 @@ def evaluate(FLAGS):
                                                                 (time.time() - start_time) * 1000))
     finally:
         # orderly shutdown: producer thread joined, decode workers reaped, device drained (see train.py _run_and_leave)
-        if not next_images.close():
-            raise SystemExit('evaluate.py: the input pipeline thread did not stop')
+        try:                                    # never raise from a finally block: a checkpoint / device error on its way out must stay the one reported
+            if not next_images.close():
+                print('evaluate.py: the input pipeline did not shut down cleanly', file=sys.stderr)
+                FLAGS._shutdown_failed = True
+        except Exception as e:
+            print('evaluate.py: closing the input pipeline failed: %s' % e, file=sys.stderr)
+            FLAGS._shutdown_failed = True
         try:
             torch.cuda.synchronize()
         except Exception as e:
@@ -85,6 +90,7 @@ def evaluate(FLAGS):
     os.makedirs(out_dir, exist_ok=True)
     savemat(os.path.join(out_dir, FLAGS.fea_name + '_' + step + '.mat'), {'wfea': wfea})
     print('Done.')
+    return FLAGS                               # (_run_and_leave reads _shutdown_failed from it)
 
 
 if __name__ == '__main__':

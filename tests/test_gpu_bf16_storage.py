@@ -19,7 +19,7 @@ from oracle import ops, spherenet as osn
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from util_gpu import dev, host, stream, ws, check_rell2
+    from util_gpu import dev, host, stream, ws, check_rell2, call, query
     from tf_face_toolbox_amd import _lib, net_select, Singular
 
 
@@ -546,3 +546,34 @@ def test_se_gate_s16():
     ok = (dx16 == _bits(ref))
     assert float(ok.float().mean()) > 0.999          # fused multiply-add vs two roundings in the torch expression: a bf16 tie now and then
     assert (_f(dx16) - ref).abs().max() <= 2 ** -7 * ref.abs().max()
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,stride', [(100, 28, 28, 128, 128, 3, 1), (37, 14, 14, 256, 256, 3, 1), (128, 28, 28, 256, 512, 1, 1),
+                                                        (64, 56, 56, 64, 64, 3, 1), (9, 7, 7, 512, 512, 3, 1), (128, 14, 14, 512, 1024, 1, 2)])
+def test_workspace_sized_exactly_by_the_queries_serves_the_s16_entry_points(bf16s_mode, n, h, w, cin, cout, k, stride):
+    """fte_conv2d_{fwd,dgrad}_s16 plan with the bf16-STORAGE rules (one unsplit launch of 128-row tiles inside a window of tile counts,
+    csrc/api.hip plan_rows); the *_ws_bytes queries must cover that plan too: a workspace of EXACTLY the queried size -- no slack --
+    serves every entry point, dalpha / dbias partial rows included."""
+    r = np.random.default_rng(5)
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    x16 = torch.randn(n, h, w, cin, device='cuda').bfloat16().view(torch.int16)
+    wt = (torch.randn(k, k, cin, cout, device='cuda') * 0.05)
+    w16 = torch.empty(k * k * cin * cout, dtype=torch.int16, device='cuda'); w16t = torch.empty_like(w16)
+    call('fte_pack_weights_bf16', wt, w16, w16t, k, cin, cout, stream())
+    z16 = torch.empty(n, ho, wo, cout, dtype=torch.int16, device='cuda'); y16 = torch.empty_like(z16)
+    bias = torch.zeros(cout, device='cuda'); alpha = torch.full((cout,), 0.25, device='cuda')
+
+    def exact(nbytes):
+        return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device='cuda'), int(nbytes)
+    wsb, nb = exact(query('fte_conv2d_fwd_ws_bytes', n, h, w, cin, cout, k, stride))
+    call('fte_conv2d_fwd_s16', x16, w16t, bias, alpha, None, z16, y16, None, None, n, h, w, cin, cout, k, stride, wsb if nb else None, nb, stream())
+    wsb, nb = exact(query('fte_conv2d_dgrad_ws_bytes', n, h, w, cin, cout, k, stride))
+    dz16 = torch.randn(n, ho, wo, cout, device='cuda').bfloat16().view(torch.int16)
+    raw16 = torch.empty(n, h, w, cin, dtype=torch.int16, device='cuda'); dx16 = torch.empty_like(raw16)
+    da, db = torch.empty(cin, device='cuda'), torch.empty(cin, device='cuda')
+    call('fte_conv2d_dgrad_s16', dz16, w16, None, x16, torch.full((cin,), 0.25, device='cuda'), raw16, dx16, da, db, n, h, w, cin, cout, k, stride, wsb, nb, stream())
+    wsb, nb = exact(query('fte_conv2d_wgrad_ws_bytes', n, h, w, cin, cout, k, stride))
+    dw = torch.empty(k, k, cin, cout, device='cuda')
+    call('fte_conv2d_wgrad16', x16, dz16, dw, n, h, w, cin, cout, k, stride, wsb, nb, stream())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(da).all()) and bool(torch.isfinite(dw).all())

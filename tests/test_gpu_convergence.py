@@ -55,3 +55,29 @@ def test_identities_become_separable(dtype):
         assert acc >= 0.95, acc
     finally:
         _lib.set_mfma_dtype('f32')
+
+
+def test_reference_learning_rate_trains_a_labelled_task():
+    """train.py:70-72's default init_lr = 0.1 with Momentum 0.9 on a task that HAS structure (ten identities, the softmax head of
+    nets/sphere.py:84-95): the loss falls and stays finite.  bench.py runs lr = 1e-4 because ITS batch -- one fixed set of 512 images
+    with uniformly random labels over 10,575 classes, nothing to learn but memorisation -- diverges at 0.1 within a dozen steps
+    (DESIGN.md 6); this test shows that to be the task's doing, not the kernels'."""
+    rng = np.random.default_rng(1)
+    ncls, h, w, bs = 10, 32, 32, 64
+    templates = rng.uniform(-0.7, 0.7, (ncls, h, w, 3))
+    net = net_select('SphereNet', 'NCHW', 5e-4)
+    state = {}
+
+    def images():
+        state['y'] = rng.integers(0, ncls, bs)
+        return _samples(templates, state['y'], rng)
+
+    def labels():
+        return torch.tensor(state['y'], dtype=torch.int32, device='cuda')
+    step, losses, names, _ = Singular(net, 0.1, 'Momentum')({'images': images, 'labels': labels, 'num_classes': ncls, 'num_examples': 10000})
+    trace = []
+    for i in range(150):
+        step()
+        trace.append(float(losses[0]))
+    assert all(np.isfinite(v) for v in trace), trace[:20]
+    assert np.mean(trace[-10:]) < 0.25 * np.mean(trace[:5]), (trace[:5], trace[-10:])

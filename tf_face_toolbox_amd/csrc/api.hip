@@ -63,16 +63,16 @@ struct RowPlan {
     int tail_mode, tail_tile; long tail_mtiles; int tail_splits, tail_kchunk; size_t pw_bytes;
 };
 // the bf16 tile preferences apply in the bf16-operand mode and inside the bf16-source (fte_*16) entry points
-bool g_plan16 = false;
+thread_local bool g_plan16 = false;      // (thread_local: a query on one host thread must not re-plan a launch on another)
 struct Plan16 { bool prev; Plan16() : prev(g_plan16) { g_plan16 = true; } ~Plan16() { g_plan16 = prev; } };
 inline bool plan_bf16() { return g_plan16 || igemm_get_bf16(); }
 // ... and a storage-only launch (bf16 tensors in the epilogue, no fp32 outputs): the persistent kernels of igemm16.hip take it
-bool g_plan_s16 = false;
+thread_local bool g_plan_s16 = false;
 struct PlanS16 { bool prev; explicit PlanS16(bool on) : prev(g_plan_s16) { g_plan_s16 = on; } ~PlanS16() { g_plan_s16 = prev; } };
 
 // ... and the "BN fusion" launches (fte_conv2d_bn_fwd, fte_conv2d_dgrad_bn): no split-K (the statistics / BN sums come from the
 // epilogue of the launch that holds the whole reduction) and the per-tile kernels, whose shared epilogue carries them
-bool g_plan_bn = false;
+thread_local bool g_plan_bn = false;
 struct PlanBn { bool prev; PlanBn() : prev(g_plan_bn) { g_plan_bn = true; } ~PlanBn() { g_plan_bn = prev; } };
 
 inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only = false) {
@@ -239,8 +239,14 @@ size_t both_modes(F f) {
     const size_t a = f();
     igemm_set_bf16(true);
     const size_t b = f();
+    size_t c;
+    {                      // ... and the bf16-STORAGE plan of the *_s16 entry points (one unsplit launch of 128-row tiles where it applies)
+        Plan16 guard;
+        PlanS16 storage(true);
+        c = f();
+    }
     igemm_set_bf16(cur);
-    return a > b ? a : b;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 }  // namespace
 

@@ -564,10 +564,12 @@ __global__ __launch_bounds__(256) void center_loss_kernel(const float* __restric
 // of all samples with the same label in sample order; the other blocks of that label leave.  Replicas that apply the same
 // (labels, diff) list therefore produce bit-identical tables (the opt-in reconciliation of data_parallel.py), and a repeated
 // step repeats bit for bit.  Labels are staged in LDS (n <= CENTER_LDS_LABELS), else read from global memory.
+// (dynamic LDS: n ints when n <= CENTER_LDS_LABELS -- 512 bytes for a 128-image shard, not a fixed 32 KiB per block -- and the
+// "does an earlier sample own this row" scan is shared by the block's threads instead of run serially by each of them)
 constexpr int CENTER_LDS_LABELS = 8192;
 __global__ __launch_bounds__(256) void center_update_kernel(const float* __restrict__ diff, const int32_t* __restrict__ labels,
                                                             float* __restrict__ centers, int n, int d, int num_classes, float alpha) {
-    __shared__ int lab[CENTER_LDS_LABELS];
+    extern __shared__ int lab[];
     const int i = blockIdx.x, y = labels[i];
     if ((unsigned)y >= (unsigned)num_classes) return;
     const bool staged = n <= CENTER_LDS_LABELS;
@@ -576,8 +578,9 @@ __global__ __launch_bounds__(256) void center_update_kernel(const float* __restr
         __syncthreads();
     }
     const int* L = staged ? lab : labels;
-    for (int k = 0; k < i; ++k)
-        if (L[k] == y) return;                       // an earlier sample owns this row (block-uniform)
+    int dup = 0;
+    for (int k = threadIdx.x; k < i; k += 256) dup |= (L[k] == y) ? 1 : 0;
+    if (__syncthreads_or(dup)) return;               // an earlier sample owns this row (block-uniform)
     for (int j0 = threadIdx.x; j0 < d; j0 += 256 * 4) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = i; k < n; ++k) {
@@ -916,11 +919,11 @@ hipError_t k_center_loss(const float* feat, const int32_t* labels, float* center
                          int n, int d, int num_classes, float alpha, float gs, float* ws, hipStream_t st) {
     hipLaunchKernelGGL(center_loss_kernel, dim3(n), dim3(256), 0, st, feat, labels, centers, ws, loss_rows, dfeat, d, num_classes, gs);
     if (alpha != 1.f)      // alpha == 1: loss and gradient only (graph construction, or the update is applied later by k_center_update)
-        hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), 0, st, ws, labels, centers, n, d, num_classes, alpha);
+        hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), n <= CENTER_LDS_LABELS ? (size_t)n * sizeof(int) : 0, st, ws, labels, centers, n, d, num_classes, alpha);
     return hipGetLastError();
 }
 hipError_t k_center_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes, float alpha, hipStream_t st) {
-    hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), 0, st, diff, labels, centers, n, d, num_classes, alpha);
+    hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), n <= CENTER_LDS_LABELS ? (size_t)n * sizeof(int) : 0, st, diff, labels, centers, n, d, num_classes, alpha);
     return hipGetLastError();
 }
 hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, float lw, float* loss_rows, float* dfeat,

@@ -9,6 +9,7 @@ Reference: data.py:30-56 (list parsers), :77-96 (PxK dict), :153-191 (eval_input
 :195-281 (train_inputs)."""
 import copy
 import os
+import sys
 import queue
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -139,7 +140,11 @@ class _Prefetcher(object):
         self._t.join(timeout)
         ended = not self._t.is_alive()
         if self.device.type == 'cuda':
-            torch.cuda.synchronize()                          # host-to-device copies still reading the ring / the workers' buffers
+            try:
+                torch.cuda.synchronize()                      # host-to-device copies still reading the ring / the workers' buffers
+            except Exception as e:                            # after a device fault: the callers' finally blocks must still run to their end
+                print('input pipeline: device synchronise failed during close: %s' % e, file=sys.stderr)
+                ended = False
         if self.pool is not None and ended:
             self.pool.close()
         if self._dead is None:
@@ -224,6 +229,7 @@ class _WorkerPool(object):
         self.shape = tuple(shape)
         self.pin = bool(pin)
         self.procs, self.fds, self.mms, self.maps, self.tensors = [], [], [], [], None
+        self.pin_failed = False
         atexit.register(self.close)                # registered before anything below can raise: a half-built pool is torn down too
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), OMP_NUM_THREADS='1',
@@ -243,7 +249,13 @@ class _WorkerPool(object):
         # that holds the descriptor -- and the size of the /dev/shm mount (64 MB by default in containers) does not matter.
         nbytes = int(np.prod(self.shape)) * 4
         for k in range(self.RING):
-            fd = os.memfd_create('fte_batch_%d' % k)
+            try:
+                fd = os.memfd_create('fte_batch_%d' % k)
+            except (AttributeError, OSError):          # no memfd_create (non-Linux / old kernel / seccomp): an UNLINKED temporary file --
+                import tempfile                        # just as nameless once it exists, freed with the last descriptor, but backed by
+                tfd, tpath = tempfile.mkstemp(prefix='fte_batch_')      # the temporary directory's file system instead of anonymous memory
+                os.unlink(tpath)
+                fd = tfd
             self.fds.append(fd)
             os.ftruncate(fd, nbytes)
             mm = mmap.mmap(fd, nbytes)
@@ -272,8 +284,9 @@ class _WorkerPool(object):
                 for t in done:
                     rt.cudaHostUnregister(t.data_ptr())
                 self.pin = False
+                self.pin_failed = True             # (train_inputs() passes it on as inputs['pin_fallback']: benchmarks can notice)
                 print('tf_face_toolbox_amd.data: hipHostRegister of the shared batch buffers failed -- batches are staged through '
-                      'pinned host buffers instead')
+                      'pinned host buffers instead (a large loader slowdown)', file=sys.stderr)
 
     def close(self):
         for p in self.procs:
@@ -456,7 +469,8 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
             pool.shutdown(wait=True)
         return ended
     return {'images': src.images, 'labels': src.labels, 'num_classes': num_classes_total,
-            'num_examples': num_examples_total, 'batch_size': batch_size, 'close': close}
+            'num_examples': num_examples_total, 'batch_size': batch_size, 'close': close,
+            'pin_fallback': bool(procs is not None and procs.pin_failed)}
 
 
 def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width, device='cuda', num_workers=None):

@@ -533,8 +533,8 @@ class GraphNet(Network):
         self.h16 = set()
         if s16:
             for op in self.plan:
-                if op[0] in ('bn', 'gconv', 'dwconv', 'se', 'maxpool', 'addrelu'):
-                    self.h16.add(op[1])
+                if op[0] in ('gconv', 'dwconv', 'se', 'maxpool', 'addrelu') or (op[0] == 'bn' and len(self.shapes[op[1]]) == 3):
+                    self.h16.add(op[1])          # (a batch norm behind the pooling has a rank-1 output: the features stay fp32)
                 elif op[0] == 'conv':          # the MFMA convs and the direct 3x3 stem write bf16; the im2col stem is an fp32 GEMM
                     cin = self.shapes[op[2]][-1]
                     if cin >= 32 or self._direct_stem(self.spec[op[3]][0][0], cin, self.shapes[op[1]][-1]):
@@ -544,6 +544,15 @@ class GraphNet(Network):
             self._pack_entries = []
         # tensors whose GRADIENT is stored as bf16: the stored ones and the BN outputs folded into a gather (never stored themselves)
         self.g16 = set(self.h16) | (set(self.folded) if s16 else set())
+        if s16:          # every bf16-storage entry point reads its tensor input as bf16: an fp32 input would be misread silently
+            for op in self.plan:
+                ins = []
+                if op[0] == 'conv' and self.shapes[op[2]][-1] >= 32:
+                    ins = [op[2]]
+                elif op[0] in ('gconv', 'dwconv', 'maxpool', 'se'):
+                    ins = [op[2]]
+                for x in ins:
+                    assert x in self.h16, 'bf16 storage: %s reads %s, which is stored as fp32' % (op[0] + ' ' + op[1], x)
         self.t = _Activations(self)
         self.bn = {}
         self.ident = {}
@@ -1036,6 +1045,10 @@ class GraphNet(Network):
         self._grad[op[2]] = gin
 
     def _new(self, name):
+        """a gradient buffer for tensor `name`: bf16 where the tensor (or, for a BN output folded into a gather, its gradient) is"""
+        if name in self.folded:                  # never stored: no tensor to take the layout from
+            z = self.t[self.folded[name][0]]
+            return torch.empty(z.shape, dtype=torch.int16 if name in self.g16 else torch.float32, device=self.device)
         return torch.empty_like(self.t[name])
 
     def backward_body(self, lo=0, hi=None):

@@ -224,8 +224,12 @@ def train(FLAGS):
         # orderly shutdown, whatever happened above: stop the input pipeline's producer thread and wait for it, end the decode
         # workers and release their shared buffers, drain the device, leave the process group
         close = inputs.get('close')
-        if close is not None and not close():
-            print('train.py: the input pipeline thread did not stop', file=sys.stderr)
+        try:
+            if close is not None and not close():
+                print('train.py: the input pipeline did not shut down cleanly', file=sys.stderr)
+                FLAGS._shutdown_failed = True
+        except Exception as e:                 # never raise from here: the error that brought us here (if any) must stay the one reported
+            print('train.py: closing the input pipeline failed: %s' % e, file=sys.stderr)
             FLAGS._shutdown_failed = True
         try:
             torch.cuda.synchronize()
