@@ -11,8 +11,12 @@ class FilterPacks(object):
 
     CHUNK = 64          # rows per table launch (the kernel keeps the table in LDS)
 
-    def __init__(self, entries, device):
+    def __init__(self, entries, device, head=0):
+        """`head` > 0: the first `head` entries form launches of their own (refresh_head / refresh_rest): a net whose forward walk
+        starts with them can pack those on its main stream and the rest -- and every HWIO pack, which only the backward pass reads --
+        on a side stream, under its first layers (nets/graph.py)."""
         i16 = dict(dtype=torch.int16, device=device)
+        self.head = int(head)
         off = 0
         rows = []
         for name, src, k, cin, cout in entries:
@@ -27,18 +31,38 @@ class FilterPacks(object):
         for src, dst, taps, cin, cout, _, name, k in rows:
             self.w16[name] = self.a16[dst:dst + taps * cin * cout].view(k, k, cin, cout)
             self.w16t[name] = self.a16t[dst:dst + taps * cin * cout].view(k, k, cout, cin)
-        self.launches = []          # (device table, rows, elements, destination base offset)
-        for c0 in range(0, len(rows), self.CHUNK):
-            chunk = rows[c0:c0 + self.CHUNK]
+        self.launches = []          # (device table, rows, elements, destination base offset, all rows inside the head)
+        starts = list(range(0, len(rows), self.CHUNK))
+        if 0 < self.head < len(rows):
+            starts = [0] + list(range(self.head, len(rows), self.CHUNK))
+        bounds = starts[1:] + [len(rows)]
+        for c0, c1 in zip(starts, bounds):
+            chunk = rows[c0:c1]
             base = chunk[0][1]
             start = 0
             tab = []
             for src, dst, taps, cin, cout, _, name, k in chunk:
                 tab.append([src, dst - base, taps, cin, cout, start // 4])
                 start += taps * cin * cout
-            self.launches.append((torch.tensor(tab, dtype=torch.int32, device=device).contiguous(), len(chunk), start, base))
+            self.launches.append((torch.tensor(tab, dtype=torch.int32, device=device).contiguous(), len(chunk), start, base,
+                                  0 < self.head < len(rows) and c1 <= self.head))
+        self.head_names = set(r[6] for r in rows[:self.head]) if 0 < self.head < len(rows) else set(r[6] for r in rows)
 
     def refresh(self, params, st):
-        for tab, n, total, base in self.launches:
+        for tab, n, total, base, _ in self.launches:
             _lib.call('fte_pack_weights_bf16_table', params, self.a16[base:], tab, n, total, 0, st)
             _lib.call('fte_pack_weights_bf16_table', params, self.a16t[base:], tab, n, total, 1, st)
+
+    def refresh_head(self, params, st):
+        """the forward ([cout][cin]) packs of the head entries"""
+        for tab, n, total, base, is_head in self.launches:
+            if is_head:
+                _lib.call('fte_pack_weights_bf16_table', params, self.a16t[base:], tab, n, total, 1, st)
+
+    def refresh_rest(self, params, st):
+        """everything refresh_head left: the forward packs of the other entries, the HWIO packs of all"""
+        for tab, n, total, base, is_head in self.launches:
+            if not is_head:
+                _lib.call('fte_pack_weights_bf16_table', params, self.a16t[base:], tab, n, total, 1, st)
+        for tab, n, total, base, _ in self.launches:
+            _lib.call('fte_pack_weights_bf16_table', params, self.a16[base:], tab, n, total, 0, st)
