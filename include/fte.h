@@ -141,6 +141,9 @@ size_t fte_conv2d_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
  * stem is then fte_gemm_nn / fte_gemm_tn on cols. */
 int fte_im2col_first(const float* x, float* cols, int n, int h, int wd, int cin, int ksize, int stride,
                      int kpad, void* stream);
+/* the same with bf16 columns (bf16 STORAGE: the stem then runs as a 1x1 conv of `kpad` input channels on the bf16-source kernels --
+ * fte_conv2d_bn_fwd / fte_conv2d_fwd_s16 / fte_conv2d_wgrad16 with cin = kpad, ksize = 1 -- and its output is stored as bf16) */
+int fte_im2col_first_s16(const float* x, uint16_t* cols16, int n, int h, int wd, int cin, int ksize, int stride, int kpad, void* stream);
 
 /* ---------------------------------------------------------------------------
  * layers.batch_norm(scale=True, center=True, fused=True, decay=0.999, epsilon=1e-3) in TRAINING mode

@@ -1271,6 +1271,12 @@ int fte_im2col_first(const float* x, float* cols, int n, int h, int wd, int cin,
     return rc(l_im2col_first(x, cols, n, h, wd, cin, ksize, stride, ph.out, pw.out, ph.before, pw.before, kpad, (hipStream_t)stream));
 }
 
+int fte_im2col_first_s16(const float* x, uint16_t* cols16, int n, int h, int wd, int cin, int ksize, int stride, int kpad, void* stream) {
+    if (!x || !cols16 || n <= 0 || kpad % 32 || kpad < ksize * ksize * cin) return FTE_EINVAL;
+    const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
+    return rc(l_im2col_first(x, f32p(cols16), n, h, wd, cin, ksize, stride, ph.out, pw.out, ph.before, pw.before, kpad, (hipStream_t)stream, 1));
+}
+
 // ------------------------------------------------------------------------------------------------
 // grouped 3x3 conv, SE-gate pieces
 int fte_gconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int stride, void* stream) {

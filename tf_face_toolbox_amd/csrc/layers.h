@@ -28,7 +28,7 @@ hipError_t l_gap_bwd(const float* dy, float* dx, int n, int hw, int c, hipStream
 hipError_t l_dropout_fwd(const float* x, float* mask, float* y, long n, float keep, uint64_t seed, hipStream_t st);
 hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, float inv_keep, hipStream_t st);
 hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
-                          int pt, int pl, int kpad, hipStream_t st);
+                          int pt, int pl, int kpad, hipStream_t st, int h16 = 0);
 hipError_t l_gconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int ho, int wo,
                        int stride, int pt, int pl, hipStream_t st);
 hipError_t l_gconv_dgrad(const float* dz, const float* w, float* dx, int n, int h, int wd, int c, int groups, int ho, int wo,

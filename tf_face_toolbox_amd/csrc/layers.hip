@@ -893,6 +893,7 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict
 // im2col of the first layer (Cin = 1 or 3, any k): cols[m, kpad], k ordered (r, s, c) like HWIO rows,
 // columns >= k*k*cin are zero.  Turns the 7x7-s2 stem of nets/resnet.py:109 into a dense MFMA GEMM.
 // ---------------------------------------------------------------------------------------------------
+template <bool H = false>      // H: cols are bf16 (bf16 storage: the stem GEMM then reads half the bytes and runs on the bf16-source kernels)
 __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restrict__ x, float* __restrict__ cols,
                                                            int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
                                                            int pt, int pl, int kpad) {
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
                 if (ih >= 0 && ih < h && iw >= 0 && iw < w) v[e] = x[((long)(img * h + ih) * w + iw) * cin + cch];
             }
         }
-        *reinterpret_cast<f32x4*>(cols + i * 4) = v;
+        stq<H>(cols, i * 4, v);
     }
 }
 
@@ -1126,9 +1127,11 @@ hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, f
     return hipGetLastError();
 }
 hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
-                          int pt, int pl, int kpad, hipStream_t st) {
-    hipLaunchKernelGGL(im2col_first_kernel, dim3(grid_for((long)n * ho * wo * (kpad / 4))), dim3(256), 0, st, x, cols, n, h, w, cin, ks,
-                       stride, ho, wo, pt, pl, kpad);
+                          int pt, int pl, int kpad, hipStream_t st, int h16) {
+    if (h16) hipLaunchKernelGGL(im2col_first_kernel<true>, dim3(grid_for((long)n * ho * wo * (kpad / 4))), dim3(256), 0, st, x, cols, n, h, w, cin, ks,
+                                stride, ho, wo, pt, pl, kpad);
+    else hipLaunchKernelGGL(im2col_first_kernel<false>, dim3(grid_for((long)n * ho * wo * (kpad / 4))), dim3(256), 0, st, x, cols, n, h, w, cin, ks,
+                            stride, ho, wo, pt, pl, kpad);
     return hipGetLastError();
 }
 

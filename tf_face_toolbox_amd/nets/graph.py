@@ -535,10 +535,8 @@ class GraphNet(Network):
             for op in self.plan:
                 if op[0] in ('gconv', 'dwconv', 'se', 'maxpool', 'addrelu') or (op[0] == 'bn' and len(self.shapes[op[1]]) == 3):
                     self.h16.add(op[1])          # (a batch norm behind the pooling has a rank-1 output: the features stay fp32)
-                elif op[0] == 'conv':          # the MFMA convs and the direct 3x3 stem write bf16; the im2col stem is an fp32 GEMM
-                    cin = self.shapes[op[2]][-1]
-                    if cin >= 32 or self._direct_stem(self.spec[op[3]][0][0], cin, self.shapes[op[1]][-1]):
-                        self.h16.add(op[1])
+                elif op[0] == 'conv':          # every conv writes bf16: the MFMA convs, the direct 3x3 stem, and the im2col stem (a 1x1 conv
+                    self.h16.add(op[1])        # of `kpad` bf16 columns on the bf16-source kernels)
                 elif op[0] == 'gather':
                     self.h16.update(name for name, _ in op[2]['outs'])
             self._pack_entries = []
@@ -589,8 +587,12 @@ class GraphNet(Network):
                 else:
                     oh, ow, _ = self.shapes[out]
                     kpad = stem_kpad(k, cin)
-                    self.cols = torch.empty(n * oh * ow, kpad, **f32)
+                    self.cols = torch.empty(n * oh * ow, kpad, **(i16 if s16 else f32))
                     need = max(need, q('fte_gemm_ws_bytes', n * oh * ow, cout, kpad))
+                    if s16:          # the stem as a 1x1 conv of kpad bf16 columns: packs like any other conv's, [1, 1, kpad, cout]
+                        self._pack_entries.append((op[3], self.variables[op[3]].offset, 1, kpad, cout))
+                        need = max(need, q('fte_conv2d_fwd_ws_bytes', n, oh, ow, kpad, cout, 1, 1), q('fte_conv2d_bn_fwd_ws_bytes', n, oh, ow, kpad, cout, 1, 1),
+                                   q('fte_conv2d_wgrad_ws_bytes', n, oh, ow, kpad, cout, 1, 1))
             elif kind == 'dwconv':
                 ih, iw, cc = self.shapes[op[2]]
                 need = max(need, q('fte_dwconv3x3_wgrad_ws_bytes', n, ih, iw, cc, op[4]))
@@ -731,6 +733,17 @@ class GraphNet(Network):
                         call('fte_conv3x3_first_fwd_s16', T[inp], self.view(wname), None, None, None, T[out], n, ih, iw, cin, cout, stride, st)
                     else:
                         call('fte_conv3x3_first_fwd', T[inp], self.view(wname), None, None, None, T[out], n, ih, iw, cin, cout, stride, st)
+                elif s16:                                      # other stems (7x7), bf16 storage: bf16 columns, then a 1x1 conv of kpad channels
+                    oh, ow, _ = self.shapes[out]
+                    kpad = stem_kpad(k, cin)
+                    call('fte_im2col_first_s16', T[inp], self.cols, n, ih, iw, cin, k, stride, kpad, st)
+                    if is_training and j in self.fuse_fwd:
+                        call('fte_conv2d_bn_fwd', self.cols, self.w16t[wname], T[out], *bn_args(self.fuse_fwd[j]), None, None, None,
+                             n, oh, ow, kpad, cout, 1, 1, 1, self.ws, self.ws_bytes, st)
+                        stats_done.add(self.fuse_fwd[j])
+                    else:
+                        call('fte_conv2d_fwd_s16', self.cols, self.w16t[wname], None, None, None, None, T[out], None, None,
+                             n, oh, ow, kpad, cout, 1, 1, self.ws, self.ws_bytes, st)
                 else:                                          # other stems (7x7): im2col + dense MFMA GEMM
                     oh, ow, _ = self.shapes[out]
                     kpad = stem_kpad(k, cin)
@@ -1282,7 +1295,10 @@ class GraphNet(Network):
                     continue
                 if cin < 32:                             # stem: filter gradient only
                     oh, ow, _ = self.shapes[out]
-                    call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, stem_kpad(k, cin), self.ws, self.ws_bytes, st)
+                    if s16:
+                        call('fte_conv2d_wgrad16', self.cols, dy, gw, n, oh, ow, stem_kpad(k, cin), cout, 1, 1, self.ws, self.ws_bytes, st)
+                    else:
+                        call('fte_gemm_tn', self.cols, dy, gw, n * oh * ow, cout, stem_kpad(k, cin), self.ws, self.ws_bytes, st)
                     continue
                 wgrad('fte_conv2d_wgrad16' if s16 else 'fte_conv2d_wgrad', dy, T[inp], dy, gw, n, ih, iw, cin, cout, k, stride, wws, self.ws_bytes, wst)
                 flush(self.side_batch)
