@@ -893,19 +893,33 @@ __global__ __launch_bounds__(256) void scale_mask_kernel(const float* __restrict
 // im2col of the first layer (Cin = 1 or 3, any k): cols[m, kpad], k ordered (r, s, c) like HWIO rows,
 // columns >= k*k*cin are zero.  Turns the 7x7-s2 stem of nets/resnet.py:109 into a dense MFMA GEMM.
 // ---------------------------------------------------------------------------------------------------
-template <bool H = false>      // H: cols are bf16 (bf16 storage: the stem GEMM then reads half the bytes and runs on the bf16-source kernels)
+// KS / CIN > 0: compile-time filter size and channel count (the 7x7x3 stem: every index decomposition below becomes multiplies and
+// shifts; with run-time divisors the bf16 form of this kernel -- 8-byte stores, twice the index work per byte -- took 204 us for
+// 128 images against 123 us for the fp32 form)
+template <bool H = false, int KS = 0, int CIN = 0>      // H: cols are bf16 (bf16 storage: the stem GEMM then reads half the bytes and runs on the bf16-source kernels)
 __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restrict__ x, float* __restrict__ cols,
-                                                           int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
+                                                           int n, int h, int w, int cin_, int ks_, int stride, int ho, int wo,
                                                            int pt, int pl, int kpad) {
-    const int k4 = kpad >> 2;
+    const int cin = CIN > 0 ? CIN : cin_, ks = KS > 0 ? KS : ks_;
+    const unsigned k4 = (unsigned)kpad >> 2;
     const long total = (long)n * ho * wo * k4;
     const int kreal = ks * ks * cin;
+    const bool small = total <= 0xffffffffL;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int kc = (int)(i % k4) * 4;
-        long t = i / k4;
-        const int ow = (int)(t % wo); t /= wo;
-        const int oh = (int)(t % ho);
-        const int img = (int)(t / ho);
+        int kc, ow, oh, img;
+        if (small) {
+            unsigned u = (unsigned)i;
+            kc = (int)(u % k4) * 4; u /= k4;
+            ow = (int)(u % (unsigned)wo); u /= (unsigned)wo;
+            oh = (int)(u % (unsigned)ho);
+            img = (int)(u / (unsigned)ho);
+        } else {
+            kc = (int)(i % k4) * 4;
+            long t = i / k4;
+            ow = (int)(t % wo); t /= wo;
+            oh = (int)(t % ho);
+            img = (int)(t / ho);
+        }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1128,10 +1142,13 @@ hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, f
 }
 hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
                           int pt, int pl, int kpad, hipStream_t st, int h16) {
-    if (h16) hipLaunchKernelGGL(im2col_first_kernel<true>, dim3(grid_for((long)n * ho * wo * (kpad / 4))), dim3(256), 0, st, x, cols, n, h, w, cin, ks,
-                                stride, ho, wo, pt, pl, kpad);
-    else hipLaunchKernelGGL(im2col_first_kernel<false>, dim3(grid_for((long)n * ho * wo * (kpad / 4))), dim3(256), 0, st, x, cols, n, h, w, cin, ks,
-                            stride, ho, wo, pt, pl, kpad);
+    const dim3 grid(grid_for((long)n * ho * wo * (kpad / 4)));
+#define FTE_I2C(...) do { if (h16) hipLaunchKernelGGL((im2col_first_kernel<true, __VA_ARGS__>), grid, dim3(256), 0, st, x, cols, n, h, w, cin, ks, stride, ho, wo, pt, pl, kpad); \
+                          else hipLaunchKernelGGL((im2col_first_kernel<false, __VA_ARGS__>), grid, dim3(256), 0, st, x, cols, n, h, w, cin, ks, stride, ho, wo, pt, pl, kpad); } while (0)
+    if (ks == 7 && cin == 3) FTE_I2C(7, 3);
+    else if (ks == 7 && cin == 1) FTE_I2C(7, 1);
+    else FTE_I2C(0, 0);
+#undef FTE_I2C
     return hipGetLastError();
 }
 

@@ -450,6 +450,7 @@ class GraphNet(Network):
         # (fuse_bwd: name of the BN output -> plan index of the BN).  Which of them can run fused (MFMA conv path, storage
         # mode, grouped conv on the bf16 MFMA) is decided where they run.  FTE_BN_FUSE=0: off (A/B hook).
         self.fuse_fwd, self.fuse_bwd = {}, {}
+        self.fuse_3x3 = os.environ.get('FTE_BN_FUSE_3X3', '1') != '0'
         # The backward half is OPT-IN (FTE_BN_FUSE_BWD=1 / FTE_BN_FUSE_GBWD=1).  Measured on MI355X at 128 images per GPU, ms per step,
         # forward only / + conv data gradients / + grouped-conv data gradients / no fusion: ResNeXt-50 7.84 / 7.91 / 8.17 / 8.23, ResNet-50
         # 7.27 / 7.38 / - / 7.66, SE-ResNet-50 9.52 / 9.40 / - / 9.87, ShuffleNet-v2 (fp32, 256) 8.10 / 8.11 / - / 8.60: the tile kernels'
@@ -717,7 +718,7 @@ class GraphNet(Network):
                 if pack_ev is not None and cin >= 32 and wname not in self.packs.head_names:
                     torch.cuda.current_stream().wait_event(pack_ev)          # the side stream's packs (once: every later layer is behind this wait)
                     pack_ev = None
-                if cin >= 32 and is_training and j in self.fuse_fwd:          # conv + the batch statistics of its output ("BN fusion")
+                if cin >= 32 and is_training and j in self.fuse_fwd and (k == 1 or not s16 or self.fuse_3x3):          # conv + the batch statistics of its output ("BN fusion")
                     xin, isc, ish, yside = fold_args(j)
                     call('fte_conv2d_bn_fwd', xin, self.w16t[wname] if s16 else self.view(wname), T[out], *bn_args(self.fuse_fwd[j]),
                          isc, ish, yside, n, ih, iw, cin, cout, k, stride, 1 if s16 else 0, self.ws, self.ws_bytes, st)
