@@ -145,6 +145,16 @@ int fte_im2col_first(const float* x, float* cols, int n, int h, int wd, int cin,
  * fte_conv2d_bn_fwd / fte_conv2d_fwd_s16 / fte_conv2d_wgrad16 with cin = kpad, ksize = 1 -- and its output is stored as bf16) */
 int fte_im2col_first_s16(const float* x, uint16_t* cols16, int n, int h, int wd, int cin, int ksize, int stride, int kpad, void* stream);
 
+/* The loader's image transform on DECODED uint8 images (data.py:206-223 of the reference: convert_image_dtype, resize_images
+ * to in_h x in_w -- TF-1.x bilinear, align_corners = False --, random_crop to crop_h x crop_w, random_flip_left_right,
+ * (x - 0.5) / 0.5; the evaluation transform of data.py:153-191 is the same with the full window and no flip).  `slots` holds
+ * n slots of slot_stride bytes (a multiple of 64): a 64-byte header of int32 {mode, h0, w0, y0, x0, flip, 0...} followed by
+ * the h0 x w0 x channels bytes of the image (mode 0; y0 / x0 = the crop's corner in the RESIZED image) or by the finished
+ * float32 crop (mode 1).  out is [n, crop_h, crop_w, channels] float32; every value is bit-equal to the host transform
+ * (tf_face_toolbox_amd/_decode_worker.py).  The random draws stay on the host (they are the workers' seeded draws). */
+int fte_preprocess_u8(const uint8_t* slots, float* out, int n, long slot_stride, int channels, int in_h, int in_w, int crop_h, int crop_w,
+                      void* stream);
+
 /* ---------------------------------------------------------------------------
  * layers.batch_norm(scale=True, center=True, fused=True, decay=0.999, epsilon=1e-3) in TRAINING mode
  * (nets/resnet.py:97-99; FusedBatchNorm / FusedBatchNormGrad).  z is [rows, c] (NHWC flattened).

@@ -43,7 +43,7 @@ def main():
                '--max_epoches', '1000', '--lr_decay_epoch', '400,800', '--max_steps', str(a.steps), '--display_interval', '20', '--save_interval', '100000',
                '--mfma_dtype', a.mfma_dtype]
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
-        tail = [ln for ln in out.stdout.splitlines() if 'throughput' in ln or 'Error' in ln or 'error' in ln]
+        tail = [ln for ln in out.stdout.splitlines() if 'mean throughput' in ln or 'sustained' in ln or 'Error' in ln or 'error' in ln]
         print('\n'.join(tail[-4:]) if tail else out.stdout[-2000:])
         return out.returncode
 

@@ -168,3 +168,60 @@ def test_worker_pool_leaves_nothing_behind_even_when_killed(tmp_path):
     finally:
         if p.poll() is None:
             p.kill()
+
+
+def _host_transform_of_slot(slot, ch, in_h, in_w, out_h, out_w):
+    """what fte_preprocess_u8 computes from one raw slot, with the host's own resize (the GPU kernel is checked against the
+    same thing bit for bit in tests/test_gpu_loader.py)"""
+    from tf_face_toolbox_amd import _decode_worker as dw
+    mode, h0, w0, y0, x0, flip = (int(v) for v in slot[:dw.HEADER_BYTES].view(np.int32)[:6])
+    if mode == 1:
+        return slot[dw.HEADER_BYTES:dw.HEADER_BYTES + out_h * out_w * ch * 4].view(np.float32).reshape(out_h, out_w, ch).copy()
+    raw = slot[dw.HEADER_BYTES:dw.HEADER_BYTES + h0 * w0 * ch].reshape(h0, w0, ch)
+    img = dw.resize_window(raw, in_h, in_w, y0, out_h, x0, out_w)
+    if flip:
+        img = img[:, ::-1, :]
+    return (np.ascontiguousarray(img, dtype=np.float32) - np.float32(0.5)) / np.float32(0.5)
+
+
+@pytest.mark.parametrize('ch', [3, 1])
+def test_raw_slots_carry_the_image_and_the_draws_of_train_example(ch):
+    """The GPU-transform form of a batch (a decoded uint8 image + {h0, w0, y0, x0, flip} per slot) reproduces train_example()
+    and the evaluation transform exactly: same seeds, same draws in the same order; an image larger than its slot arrives
+    finished (mode 1)."""
+    from tf_face_toolbox_amd import _decode_worker as dw
+    big = dw.HEADER_BYTES + 256 * 256 * ch
+    small = dw.HEADER_BYTES + 112 * 112 * ch * 4              # fits the finished crop but not the larger images
+    modes = set()
+    for seed, name in enumerate(NAMES * 2):
+        path = os.path.join(IMG, name)
+        for nbytes in (big, small):
+            slot = np.zeros(nbytes, dtype=np.uint8)
+            dw.raw_example(slot, path, ch, 120, 116, 112, 112, np.random.default_rng(seed))
+            modes.add(int(slot[:4].view(np.int32)[0]))
+            want = dw.train_example(path, ch, 120, 116, 112, 112, 0, np.random.default_rng(seed))
+            assert np.array_equal(_host_transform_of_slot(slot, ch, 120, 116, 112, 112), want)
+        slot = np.zeros(big, dtype=np.uint8)
+        dw.raw_example(slot, path, ch, 64, 48, -1, -1, None)
+        want = (dw.decode(path, ch, 64, 48) - np.float32(0.5)) / np.float32(0.5)
+        assert np.array_equal(_host_transform_of_slot(slot, ch, 64, 48, 64, 48), want)
+    assert modes == {0, 1}
+
+
+def test_worker_processes_fill_raw_slots(tmp_path):
+    """_WorkerPool with uint8 slot buffers (what train_inputs uses on a GPU): every slot of every batch, transformed on the host,
+    equals the row the float32 pool produces for the same seed."""
+    from tf_face_toolbox_amd import _decode_worker as dw
+    slot = dw.HEADER_BYTES + 256 * 256 * 3
+    rows = [(i, os.path.join(IMG, NAMES[i % len(NAMES)]), 100 + i) for i in range(12)]
+    pf = data._WorkerPool(3, (12, 112, 112, 3))
+    pr = data._WorkerPool(3, (12, slot), dtype=np.uint8)
+    try:
+        params = (3, 120, 116, 112, 112, 0)
+        a = pf.fill(rows, params).copy()
+        b = pr.fill(rows, params + (1,))
+        assert b.dtype == np.uint8 and b.shape == (12, slot)
+        for i in range(12):
+            assert np.array_equal(_host_transform_of_slot(b[i], 3, 120, 116, 112, 112), a[i])
+    finally:
+        pf.close(); pr.close()

@@ -81,8 +81,7 @@ def decode(path, num_channels, height, width):
     return resize_window(_load(path, num_channels), height, width)
 
 
-def train_example(path, num_channels, input_height, input_width, crop_height, crop_width, augmentation, rng):
-    raw = _load(path, num_channels)
+def _finish(raw, input_height, input_width, crop_height, crop_width, augmentation, rng):
     if crop_height != -1 and crop_width != -1:                      # tf.random_crop: only the cropped window is resized
         y0 = rng.integers(0, input_height - crop_height + 1)
         x0 = rng.integers(0, input_width - crop_width + 1)
@@ -97,20 +96,70 @@ def train_example(path, num_channels, input_height, input_width, crop_height, cr
     return (np.ascontiguousarray(image, dtype=np.float32) - 0.5) / 0.5
 
 
-def fill_rows(task):
-    """(buffer, batch shape, [(row, path, seed), ...], num_channels, in_h, in_w, crop_h, crop_w, augmentation): decode the
-    listed images (seed None: the evaluation transform) into rows of the shared batch buffer -- a float32 array in anonymous shared
-    memory named by the file DESCRIPTOR this process inherited from the parent (data._WorkerPool: memfd_create + pass_fds), or by a
-    file path.  Returns the number of rows written (errors propagate)."""
-    name, shape, rows, num_channels, in_h, in_w, crop_h, crop_w, augmentation = task
+def train_example(path, num_channels, input_height, input_width, crop_height, crop_width, augmentation, rng):
+    return _finish(_load(path, num_channels), input_height, input_width, crop_height, crop_width, augmentation, rng)
+
+
+HEADER_BYTES = 64            # per raw slot: int32 {mode, h0, w0, y0, x0, flip} + padding (include/fte.h: fte_preprocess_u8)
+
+
+def raw_example(slot, path, num_channels, input_height, input_width, crop_height, crop_width, rng):
+    """The DECODED image and the draws of train_example() (seeded the same way, drawn in the same order) into one slot of a raw
+    batch buffer -- resize / crop / flip / normalise then run on the GPU (fte_preprocess_u8) and give the bits train_example()
+    gives.  rng None: the evaluation transform (full window, no flip).  An image too large for its slot is transformed here
+    and stored finished (mode 1)."""
+    raw = _load(path, num_channels)
+    h0, w0 = raw.shape[:2]
+    cropped = crop_height != -1 and crop_width != -1
+    out_h, out_w = (crop_height, crop_width) if cropped else (input_height, input_width)
+    hd = slot[:HEADER_BYTES].view(np.int32)
+    if raw.size > slot.size - HEADER_BYTES:
+        if rng is None:
+            image = (resize_window(raw, input_height, input_width) - np.float32(0.5)) / np.float32(0.5)
+        else:
+            image = _finish(raw, input_height, input_width, crop_height, crop_width, 0, rng)
+        slot[HEADER_BYTES:HEADER_BYTES + image.size * 4] = np.ascontiguousarray(image, dtype=np.float32).reshape(-1).view(np.uint8)
+        hd[:6] = (1, out_h, out_w, 0, 0, 0)
+        return
+    y0 = x0 = flip = 0
+    if rng is not None:
+        if cropped:
+            y0 = int(rng.integers(0, input_height - crop_height + 1))
+            x0 = int(rng.integers(0, input_width - crop_width + 1))
+        flip = int(rng.random() < 0.5)
+    slot[HEADER_BYTES:HEADER_BYTES + raw.size] = raw.reshape(-1)
+    hd[:6] = (0, h0, w0, y0, x0, flip)
+
+
+def _buffer(name, shape, dtype):
+    """The shared batch buffer a task names: anonymous shared memory behind the file DESCRIPTOR this process inherited from the
+    parent (data._WorkerPool: memfd_create + pass_fds), or a file path."""
     batch = _SHM.get(name)
-    if batch is None or batch.shape != tuple(shape):
+    if batch is None or batch.shape != tuple(shape) or batch.dtype != dtype:
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         if isinstance(name, int):
             import mmap
-            mm = mmap.mmap(name, int(np.prod(shape)) * 4)
-            batch = _SHM[name] = np.frombuffer(mm, dtype=np.float32).reshape(tuple(shape))
+            mm = mmap.mmap(name, nbytes)
+            batch = _SHM[name] = np.frombuffer(mm, dtype=dtype).reshape(tuple(shape))
         else:
-            batch = _SHM[name] = np.memmap(name, dtype=np.float32, mode='r+', shape=tuple(shape))
+            batch = _SHM[name] = np.memmap(name, dtype=dtype, mode='r+', shape=tuple(shape))
+    return batch
+
+
+def fill_rows(task):
+    """(buffer, batch shape, [(row, path, seed), ...], num_channels, in_h, in_w, crop_h, crop_w, augmentation[, raw]): decode the
+    listed images (seed None: the evaluation transform) into rows of the shared batch buffer -- a float32 array of finished
+    examples, or with raw = 1 a uint8 array [rows, slot bytes] of decoded images + draws for the GPU transform.  Returns the
+    number of rows written (errors propagate)."""
+    name, shape, rows, num_channels, in_h, in_w, crop_h, crop_w, augmentation = task[:9]
+    raw = len(task) > 9 and task[9]
+    if raw:
+        assert not augmentation, 'the colour augmentation runs on the host: no raw slots'
+        batch = _buffer(name, shape, np.uint8)
+        for row, path, seed in rows:
+            raw_example(batch[row], path, num_channels, in_h, in_w, crop_h, crop_w, None if seed is None else np.random.default_rng(seed))
+        return len(rows)
+    batch = _buffer(name, shape, np.float32)
     for row, path, seed in rows:
         if seed is None:                          # evaluation: decode + resize + normalise, nothing random (data.py:153-191)
             batch[row] = (decode(path, num_channels, in_h, in_w) - np.float32(0.5)) / np.float32(0.5)

@@ -35,6 +35,7 @@ _SIGS = {
     'fte_conv2d_wgrad_ws_bytes': (c_size_t, [c_int] * 7),
     'fte_im2col_first': (c_int, [_P] * 2 + [c_int] * 7 + [_P]),
     'fte_im2col_first_s16': (c_int, [_P] * 2 + [c_int] * 7 + [_P]),
+    'fte_preprocess_u8': (c_int, [_P] * 2 + [c_int, c_long] + [c_int] * 5 + [_P]),
     'fte_bn_ws_bytes': (c_size_t, [c_int]),
     'fte_bn_train_fwd': (c_int, [_P] * 11 + [c_long, c_int, c_float, c_float, c_int, _P, c_size_t, _P]),
     'fte_bn_infer_fwd': (c_int, [_P] * 9 + [c_long, c_int, c_float, c_int, _P]),

@@ -1277,6 +1277,13 @@ int fte_im2col_first_s16(const float* x, uint16_t* cols16, int n, int h, int wd,
     return rc(l_im2col_first(x, f32p(cols16), n, h, wd, cin, ksize, stride, ph.out, pw.out, ph.before, pw.before, kpad, (hipStream_t)stream, 1));
 }
 
+int fte_preprocess_u8(const uint8_t* slots, float* out, int n, long slot_stride, int channels, int in_h, int in_w, int crop_h, int crop_w,
+                      void* stream) {
+    if (!slots || !out || n <= 0 || (channels != 1 && channels != 3) || in_h <= 0 || in_w <= 0 || crop_h <= 0 || crop_w <= 0 ||
+        crop_h > in_h || crop_w > in_w || slot_stride < 64 || slot_stride % 64 || n > 65535) return FTE_EINVAL;
+    return rc(k_preprocess_u8(slots, out, n, slot_stride, channels, in_h, in_w, crop_h, crop_w, (hipStream_t)stream));
+}
+
 // ------------------------------------------------------------------------------------------------
 // grouped 3x3 conv, SE-gate pieces
 int fte_gconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int groups, int stride, void* stream) {

@@ -34,3 +34,5 @@ hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, flo
                      int n, int d, float* ws, hipStream_t st);
 hipError_t k_momentum(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gs, hipStream_t st);
 hipError_t k_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps, float wd, float gs, hipStream_t st);
+hipError_t k_preprocess_u8(const unsigned char* slots, float* out, int n, long slot_stride, int channels, int in_h, int in_w,
+                           int crop_h, int crop_w, hipStream_t st);

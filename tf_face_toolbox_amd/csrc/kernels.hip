@@ -943,3 +943,61 @@ hipError_t k_adam(float* w, float* m, float* v, const float* g, long n, float lr
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, w, m, v, g, n, lr_t, b1, b2, eps, wd, gs);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// input transform of the loader (data.py:206-223 of the reference: convert_image_dtype + resize_images + random_crop +
+// random_flip_left_right + (x - 0.5) / 0.5) on DECODED uint8 images.  One slot per image: a 64-byte header of int32
+// {mode, h0, w0, y0, x0, flip} and then the h0 x w0 x C bytes of the decoded image (mode 0) or the finished float32 crop
+// (mode 1: an image that did not fit its slot was transformed by the worker).  TF-1.x ResizeBilinear, align_corners = False:
+// in = out * (n_in / n_out), low = floor(in), high = min(low + 1, n_in - 1); the two neighbours of a row are blended along x,
+// then the two rows along y, every operation rounded to float32 on its own (no contraction): the results are the BITS
+// tf_face_toolbox_amd/_decode_worker.py computes on the host.  One thread per output pixel.
+template <int C>
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ slots, float* __restrict__ out, long slot_stride,
+                                                             int in_h, int in_w, int crop_h, int crop_w) {
+#pragma clang fp contract(off)     // every product and sum below rounds on its own, as numpy's do (hipcc's default would fuse them into FMAs;
+    // the __fmul_rn / __fadd_rn intrinsics are inline operators that carry the translation unit's contraction flag with them)
+    const int img = blockIdx.y;
+    const unsigned char* slot = slots + (long)img * slot_stride;
+    const int* hd = reinterpret_cast<const int*>(slot);
+    const int mode = hd[0], h0 = hd[1], w0 = hd[2], y0 = hd[3], x0 = hd[4], flip = hd[5];
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= crop_h * crop_w) return;
+    float* o = out + ((long)img * crop_h * crop_w + px) * C;
+    if (mode == 1) {
+        const float* f = reinterpret_cast<const float*>(slot + 64) + (long)px * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = f[c];
+        return;
+    }
+    const int r = px / crop_w, cc = px - r * crop_w;
+    const int col = flip ? crop_w - 1 - cc : cc;
+    const float s = (float)(1.0 / 255.0);
+    const float py = (float)(y0 + r) * ((float)h0 / (float)in_h);
+    const float pxs = (float)(x0 + col) * ((float)w0 / (float)in_w);
+    const int ylo = (int)floorf(py), xlo = (int)floorf(pxs);
+    const int yhi = min(ylo + 1, h0 - 1), xhi = min(xlo + 1, w0 - 1);
+    const float yw = py - (float)ylo, xw = pxs - (float)xlo;
+    const unsigned char* img0 = slot + 64;
+    const unsigned char* tl = img0 + ((long)ylo * w0 + xlo) * C;
+    const unsigned char* tr = img0 + ((long)ylo * w0 + xhi) * C;
+    const unsigned char* bl = img0 + ((long)yhi * w0 + xlo) * C;
+    const unsigned char* br = img0 + ((long)yhi * w0 + xhi) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float a = (float)tl[c] * s, b = (float)tr[c] * s;
+        const float d = (float)bl[c] * s, e = (float)br[c] * s;
+        const float top = (b - a) * xw + a;
+        const float bot = (e - d) * xw + d;
+        const float v = (bot - top) * yw + top;
+        o[c] = (v - 0.5f) / 0.5f;
+    }
+}
+
+hipError_t k_preprocess_u8(const unsigned char* slots, float* out, int n, long slot_stride, int channels, int in_h, int in_w,
+                           int crop_h, int crop_w, hipStream_t st) {
+    const dim3 grid((crop_h * crop_w + 255) / 256, n);
+    if (channels == 3) preprocess_u8_kernel<3><<<grid, 256, 0, st>>>(slots, out, slot_stride, in_h, in_w, crop_h, crop_w);
+    else preprocess_u8_kernel<1><<<grid, 256, 0, st>>>(slots, out, slot_stride, in_h, in_w, crop_h, crop_w);
+    return hipGetLastError();
+}

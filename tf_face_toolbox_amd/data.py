@@ -99,8 +99,9 @@ class _Prefetcher(object):
 
     POLL_SECONDS = 5.0
 
-    def __init__(self, make_batch, device, depth=2, num_classes=None, pool=None):
+    def __init__(self, make_batch, device, depth=2, num_classes=None, pool=None, transform=None):
         self.q = queue.Queue(maxsize=depth)
+        self.transform = transform                                # raw uint8 slots on the device -> the float32 batch (fte_preprocess_u8)
         self.pool = pool                                          # a _WorkerPool with page-locked buffers, or None
         self.device = device
         self.make_batch = make_batch
@@ -156,7 +157,7 @@ class _Prefetcher(object):
         if not self._ring or tuple(self._ring[0]['buf'].shape) != tuple(x.shape):
             self._ring = []
             for _ in range(self._nslots):
-                b = torch.empty(tuple(x.shape), dtype=torch.float32)
+                b = torch.from_numpy(np.empty(x.shape, dtype=x.dtype))
                 self._ring.append({'buf': b.pin_memory() if self.device.type == 'cuda' else b, 'ev': None})
             self._slot = 0
         e = self._ring[self._slot]
@@ -180,7 +181,7 @@ class _Prefetcher(object):
                 if d is not None:                                 # page-locked worker buffer: no staging copy at all
                     self._put(({'buf': d[0], 'ev': None, 'release': d[1]}, yt))
                 else:
-                    self._put((self._stage(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x), yt))
+                    self._put((self._stage(x if isinstance(x, np.ndarray) else np.asarray(x, dtype=np.float32)), yt))
         except BaseException as e:                            # noqa: B902 -- everything goes to the consumer
             self._put(e)
 
@@ -207,6 +208,8 @@ class _Prefetcher(object):
                 slot['release'](ev)                           # worker buffer: the pool waits for it before the next refill
             else:
                 slot['ev'] = ev                               # the producer waits for it before it overwrites the buffer
+            if self.transform is not None:
+                xd = self.transform(xd)
         else:
             xd = slot['buf'].clone()                          # CPU consumers (tests) may keep a batch: hand out a copy, not the ring buffer
         self._cur = (xd, yt.to(self.device, non_blocking=True) if yt is not None else None)
@@ -221,12 +224,13 @@ class _WorkerPool(object):
     GROUP = 16       # workers that share one batch: with 128 workers on one 512-image batch each has ~5 ms of work per batch and is
     # asleep most of the time (wake-ups dominate) -- so the pool is cut into groups and every group works on a DIFFERENT batch.
 
-    def __init__(self, workers, shape, pin=False):
+    def __init__(self, workers, shape, pin=False, dtype=np.float32):
         import atexit
         import mmap
         import subprocess
         import sys
         self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
         self.pin = bool(pin)
         self.procs, self.fds, self.mms, self.maps, self.tensors = [], [], [], [], None
         self.pin_failed = False
@@ -247,7 +251,7 @@ class _WorkerPool(object):
         # name under /dev/shm, so a rank that is SIGTERMed / SIGKILLed (torch.distributed.run does that to the survivors of a
         # failed rank; so do schedulers and `timeout`) leaves nothing behind -- the kernel frees the pages with the last process
         # that holds the descriptor -- and the size of the /dev/shm mount (64 MB by default in containers) does not matter.
-        nbytes = int(np.prod(self.shape)) * 4
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
         for k in range(self.RING):
             try:
                 fd = os.memfd_create('fte_batch_%d' % k)
@@ -260,7 +264,7 @@ class _WorkerPool(object):
             os.ftruncate(fd, nbytes)
             mm = mmap.mmap(fd, nbytes)
             self.mms.append(mm)
-            self.maps.append(np.frombuffer(mm, dtype=np.float32).reshape(self.shape))
+            self.maps.append(np.frombuffer(mm, dtype=self.dtype).reshape(self.shape))
         self.procs = [subprocess.Popen([sys.executable, '-m', 'tf_face_toolbox_amd._decode_worker'], stdin=subprocess.PIPE,
                                        stdout=subprocess.PIPE, env=env, pass_fds=self.fds) for _ in range(workers)]
         self.groups = [self.procs[i:i + gs] for i in range(0, workers - gs + 1, gs)]
@@ -275,7 +279,7 @@ class _WorkerPool(object):
             tensors = [torch.from_numpy(m) for m in self.maps]
             done = []
             for t in tensors:
-                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 4, 0)) != 0 or not t.is_pinned():
+                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) != 0 or not t.is_pinned():
                     break
                 done.append(t)
             if len(done) == len(tensors):
@@ -388,6 +392,28 @@ class _BatchSource(object):
         return self.p._cur[1]
 
 
+def _raw_slots(num_workers, rows, num_channels, in_h, in_w, out_h, out_w, augmentation, device):
+    """(slot bytes, transform) when the decode workers hand over DECODED uint8 images and the resize / crop / flip / normalise
+    runs on the GPU (fte_preprocess_u8: the same bits as the host transform, tests/test_gpu_loader.py), else (0, None).  The
+    host transform is 0.6 of the 1.7 ms a 250 x 250 JPEG costs a worker; the decode stays.  FTE_LOADER_GPU=0 keeps everything on
+    the host; the colour augmentation (preprocessing.py) always does.  A slot holds an image of FTE_LOADER_RAW_SIDE^2 pixels
+    (default 256; CASIA-WebFace crops are 250 x 250) -- a larger image is transformed by its worker and handed over finished."""
+    if num_workers <= 0 or augmentation or torch.device(device).type != 'cuda' or os.environ.get('FTE_LOADER_GPU', '1') == '0':
+        return 0, None
+    from . import _lib
+    from ._decode_worker import HEADER_BYTES
+    side = int(os.environ.get('FTE_LOADER_RAW_SIDE', '256'))
+    slot = HEADER_BYTES + max(side * side * num_channels, out_h * out_w * num_channels * 4)
+    slot = (slot + 63) // 64 * 64
+
+    def transform(raw):
+        out = torch.empty((rows, out_h, out_w, num_channels), dtype=torch.float32, device=raw.device)
+        _lib.call('fte_preprocess_u8', raw.data_ptr(), out.data_ptr(), rows, slot, num_channels, in_h, in_w, out_h, out_w,
+                  torch.cuda.current_stream().cuda_stream)
+        return out
+    return slot, transform
+
+
 # ------------------------------------------------------------------ public input builders
 def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop_width=-1, is_color=1,
                  augmentation=0, batch_size=-1, num_classes=-1, num_per_class=-1, device='cuda', seed=None,
@@ -435,9 +461,13 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
             # 32 workers 23.8 k, 48 workers 27.1 k images/s (through a staging copy: 24.5 k at 48)
             num_workers = min(max(1, cpu_count() // 2 // max(1, world_size)), 48, shard // 4) if shard >= 64 else 0
     on_gpu = torch.device(device).type == 'cuda'
-    procs = _WorkerPool(num_workers, (shard, out_h, out_w, num_channels), pin=on_gpu) if num_workers > 0 else None
+    slot, transform = _raw_slots(num_workers, shard, num_channels, input_height, input_width, out_h, out_w, augmentation, device)
+    if slot:
+        procs = _WorkerPool(num_workers, (shard, slot), pin=on_gpu, dtype=np.uint8)
+    else:
+        procs = _WorkerPool(num_workers, (shard, out_h, out_w, num_channels), pin=on_gpu) if num_workers > 0 else None
     pool = None if procs else ThreadPoolExecutor(max(1, cpu_count() // 2))
-    params = (num_channels, input_height, input_width, crop_height, crop_width, augmentation)
+    params = (num_channels, input_height, input_width, crop_height, crop_width, augmentation) + ((1,) if slot else ())
 
     def draw():
         items = [next(gen) for _ in range(batch_size)][rank * shard:(rank + 1) * shard]
@@ -460,7 +490,7 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
         x = np.stack(imgs).reshape(shard, out_h, out_w, num_channels)
         return x, labels
 
-    pf = _Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total, pool=procs)
+    pf = _Prefetcher(make_batch, torch.device(device), num_classes=num_classes_total, pool=procs, transform=transform)
     src = _BatchSource(pf)
 
     def close():
@@ -470,7 +500,7 @@ def train_inputs(data_list_path, input_height, input_width, crop_height=-1, crop
         return ended
     return {'images': src.images, 'labels': src.labels, 'num_classes': num_classes_total,
             'num_examples': num_examples_total, 'batch_size': batch_size, 'close': close,
-            'pin_fallback': bool(procs is not None and procs.pin_failed)}
+            'pin_fallback': bool(procs is not None and procs.pin_failed), 'gpu_transform': bool(slot)}
 
 
 def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width, device='cuda', num_workers=None):
@@ -483,10 +513,15 @@ def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width,
         num_workers = int(os.environ.get('FTE_LOADER_WORKERS', '-1'))
         if num_workers < 0:
             num_workers = min(max(1, cpu_count() // 2), 32, batch_size // 4) if batch_size >= 64 else 0
-    procs = _WorkerPool(num_workers, (batch_size, input_height, input_width, num_channels), pin=torch.device(device).type == 'cuda') if num_workers > 0 else None
+    on_gpu = torch.device(device).type == 'cuda'
+    slot, transform = _raw_slots(num_workers, batch_size, num_channels, input_height, input_width, input_height, input_width, 0, device)
+    if slot:
+        procs = _WorkerPool(num_workers, (batch_size, slot), pin=on_gpu, dtype=np.uint8)
+    else:
+        procs = _WorkerPool(num_workers, (batch_size, input_height, input_width, num_channels), pin=on_gpu) if num_workers > 0 else None
     pool = None if procs else ThreadPoolExecutor(8)
     state = {'pos': 0}
-    params = (num_channels, input_height, input_width, -1, -1, 0)
+    params = (num_channels, input_height, input_width, -1, -1, 0) + ((1,) if slot else ())
     pending = []
 
     def draw():
@@ -502,7 +537,7 @@ def eval_inputs(data_list_path, batch_size, is_color, input_height, input_width,
         imgs = list(pool.map(lambda q: (_decode(q, num_channels, input_height, input_width) - 0.5) / 0.5, draw()))
         return np.stack(imgs).astype(np.float32), None
 
-    pf = _Prefetcher(make_batch, torch.device(device), pool=procs)
+    pf = _Prefetcher(make_batch, torch.device(device), pool=procs, transform=transform)
 
     def next_batch():
         return pf.advance()[0]

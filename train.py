@@ -190,13 +190,18 @@ def train(FLAGS):
         print('%s training start...' % tag)
         step, epoch = 0, 1
         time_sim, image_sim = 0.0, 0.0
+        first_step, settled = None, None                          # (step, wall clock) 20 steps after the start: the sustained rate printed at the end
         while epoch <= FLAGS.max_epoches:                                                             # train.py:223-250
             step = model.global_step
             epoch = step // batches_per_epoch + 1
             start_time = time.time()
+            first_step = step if first_step is None else first_step
+            if settled is None and step - first_step >= 20:
+                settled = (step, start_time)
             train_ops()
             losses_value = [float(l) for l in losses]            # reading the losses synchronises, like sess.run
-            duration = time.time() - start_time
+            last_done = time.time()
+            duration = last_done - start_time
             if not all(math.isfinite(v) for v in losses_value):
                 raise SystemExit('Model diverged with losses = %s' % losses_value)
             if step % FLAGS.display_interval == 0 and rank == 0:
@@ -218,6 +223,8 @@ def train(FLAGS):
                 break
         if rank == 0 and step > 0:
             print('mean batch_time=%.2f, mean throughput=%.2f' % (time_sim / step * 1000, image_sim / step))
+            if settled is not None and step + 1 > settled[0]:      # not in the reference: images / wall clock once the pipeline has settled
+                print('sustained throughput=%.2f images/s over steps %d..%d' % ((step + 1 - settled[0]) * batch_size / (last_done - settled[1]), settled[0], step))
         if world > 1:
             dist.barrier()
     finally:
