@@ -32,9 +32,18 @@ inline long tiles_of(int tile, long M, long N) {
     return ((M + bm - 1) / bm) * (N / bn);
 }
 
+// the bf16 tile preferences apply in the bf16-operand mode and inside the bf16-source (fte_*16) entry points
+thread_local bool g_plan16 = false;      // (thread_local: a query on one host thread must not re-plan a launch on another)
+struct Plan16 { bool prev; Plan16() : prev(g_plan16) { g_plan16 = true; } ~Plan16() { g_plan16 = prev; } };
+inline bool plan_bf16() { return g_plan16 || igemm_get_bf16(); }
 // Largest tile that still gives the chip >= 1.5 blocks per CU; else the smallest legal one.
 inline int pick_tile(long M, long N) {
-    const long want = 384;      // (measured again in round 2 on the BN nets: 384 / 800 / 1200 / always-smallest are within 0.5 %)
+    const bool b16 = plan_bf16();
+    static const long want32 = getenv("FTE_PICK_WANT") ? atol(getenv("FTE_PICK_WANT")) : 384;      // (measured again in round 2 on the BN nets: 384 / 800 / 1200 / always-smallest are within 0.5 %)
+    // bf16 operands: the 128-row tiles run on the LDS-DMA kernels (igemm16.hip), the 64 x 64 tile on the register-staged one, which is
+    // the slower kernel by more than the half-empty chip costs the larger tiles (FTE_PICK_WANT16 sweep in DESIGN.md)
+    static const long want16 = getenv("FTE_PICK_WANT16") ? atol(getenv("FTE_PICK_WANT16")) : 120;
+    const long want = b16 ? want16 : want32;
     int cands[3];
     int nc = 0;
     if (N % 128 == 0) { cands[nc++] = TILE_128x128; cands[nc++] = TILE_128x64; cands[nc++] = TILE_64x64; }
@@ -62,10 +71,6 @@ struct RowPlan {
     int main_tile; long main_rows, main_mtiles;
     int tail_mode, tail_tile; long tail_mtiles; int tail_splits, tail_kchunk; size_t pw_bytes;
 };
-// the bf16 tile preferences apply in the bf16-operand mode and inside the bf16-source (fte_*16) entry points
-thread_local bool g_plan16 = false;      // (thread_local: a query on one host thread must not re-plan a launch on another)
-struct Plan16 { bool prev; Plan16() : prev(g_plan16) { g_plan16 = true; } ~Plan16() { g_plan16 = prev; } };
-inline bool plan_bf16() { return g_plan16 || igemm_get_bf16(); }
 // ... and a storage-only launch (bf16 tensors in the epilogue, no fp32 outputs): the persistent kernels of igemm16.hip take it
 thread_local bool g_plan_s16 = false;
 struct PlanS16 { bool prev; explicit PlanS16(bool on) : prev(g_plan_s16) { g_plan_s16 = on; } ~PlanS16() { g_plan_s16 = prev; } };
@@ -88,10 +93,11 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     // 6.8 -> 5.8 ms, dgrad 8.1 -> 7.5 ms per step; at batch 64 the big tile loses: 3.7 -> 4.7 ms);
     // the short-K stride-2 dgrad classes stay on 64x64 (`small_only`)
     static const bool wide_env = getenv("FTE_WIDE_TILE") != nullptr;
-    const bool fills = ((M + 127) / 128) * (N / 128) >= SLOTS_BIG;      // at least one round of the big tile's slots
+    static const long fills16 = getenv("FTE_FILLS16") ? atol(getenv("FTE_FILLS16")) : 384;       // half a round: measured 768 / 384 / 190 / 120 on the bf16s nets
+    const bool fills = ((M + 127) / 128) * (N / 128) >= fills16;        // at least one round of the big tile's slots
     const int wide = (!wide_env && plan_bf16() && !small_only && fills) ? TILE_128x128 : wide_tile;
     static const bool narrow_env = getenv("FTE_NARROW_TILE") != nullptr;
-    const bool fills_n = ((M + 127) / 128) * (N / 64) >= SLOTS_BIG;
+    const bool fills_n = ((M + 127) / 128) * (N / 64) >= fills16;
     const int narrow = (!narrow_env && plan_bf16() && !small_only && fills_n) ? TILE_128x64 : narrow_tile;   // N = 64 layers: +3 %
     // fp32, very tall outputs (>= 4096 tiles of 128 x 64: the 56x56 and 28x28 layers at batch 512): 128 x 64 tiles -- two
     // accumulator blocks per wave, 32 MFMAs per barrier instead of 16 -- measured after the K-order / priority work of round 2:
@@ -390,7 +396,9 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int ksize, int stride
                 }
             }
             const long M = (long)n * c.hq * c.wq;
-            c.rp = plan_rows(M, cin, (long)c.ntap * cout, true, stride != 1);
+            // FTE_DGRAD_CLS_BIG=1 (A/B hook): let the bf16 plans give the parity classes the 128-row tiles of the LDS-DMA kernels
+            static const bool cls_big = getenv("FTE_DGRAD_CLS_BIG") && atoi(getenv("FTE_DGRAD_CLS_BIG")) == 1;
+            c.rp = plan_rows(M, cin, (long)c.ntap * cout, true, stride != 1 && !cls_big);
             c.mtiles = c.rp.main_mtiles + c.rp.tail_mtiles;
             ++nc;
         }

@@ -2353,9 +2353,24 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         // conv -> BN pairs: the per-tile kernel with the shared (LDS-transposed) epilogue, whose BNM form carries the statistics /
         // the BN mask and sums; the resident kernels' register epilogues do not (yet)
         if (splits != 1 || p.PW) return hipErrorInvalidValue;
+        // Launches with at most a block or two per CU (the 14x14 / 7x7 / 4x4 layers of a 128-image shard) are paced by the bytes their K
+        // loop keeps in flight: one K-step per block on the two-stage ring = 24-32 KB per block, 1.5 us per step.  A three-stage ring
+        // (two steps in flight, still two blocks per CU) runs them in 0.6x the time.  FTE_BN16_NST=2 restores the two-stage ring.
+        static const int nst_env = getenv("FTE_BN16_NST") ? atoi(getenv("FTE_BN16_NST")) : 3;
+        static const int nst_tiles = getenv("FTE_BN16_NST_TILES") ? atoi(getenv("FTE_BN16_NST_TILES")) : 768;
+        const long ntl = (long)((p.M - p.m_base + 127) / 128) * (p.N / (tile == TILE_128x128 ? 128 : 64)) * (p.ncls > 1 ? p.ncls : 1);
+        const bool deep = nst_env >= 3 && ntl <= nst_tiles && p.K / BK16 >= 6;
         if (tile == TILE_128x128) {
+            if (deep) {
+                if (epi == EPI_FWD) return launch16bn<128, 128, 4, 2, EPI_FWD, 3, 2>(p, st);
+                return launch16bn<128, 128, 4, 2, EPI_DGRAD, 3, 2>(p, st);
+            }
             if (epi == EPI_FWD) return launch16bn<128, 128, 4, 2, EPI_FWD, 2, 4>(p, st);
             return launch16bn<128, 128, 4, 2, EPI_DGRAD, 2, 4>(p, st);
+        }
+        if (deep) {
+            if (epi == EPI_FWD) return launch16bn<128, 64, 4, 2, EPI_FWD, 3, 4>(p, st);
+            return launch16bn<128, 64, 4, 2, EPI_DGRAD, 3, 4>(p, st);
         }
         if (epi == EPI_FWD) return launch16bn<128, 64, 4, 2, EPI_FWD, 2, 6>(p, st);
         return launch16bn<128, 64, 4, 2, EPI_DGRAD, 2, 4>(p, st);      // (four waves per SIMD: at six the BN inputs spill 63 registers)
@@ -2418,6 +2433,23 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
     // waves, no window).  Measured and dropped (same table): igemm16p with a four-stage ring at one block per CU (0.234 vs 0.160 ms,
     // 14x14x256 forward), a 256x128 tile without loader waves (0.209), fragment reads two / three sub-steps ahead at 128 registers
     // (spills: 0.168 / 0.170), four waves of 64x64 (0.168); the 128x128 data gradient on igemm16p (0.214 vs 0.202 per-tile).
+    // Pointwise launches with at most a block or two per CU (the 1x1 data gradients of the 14x14 / 7x7 / 4x4 stages at a 128-image
+    // shard): the three-stage ring, as for the conv -> BN launches above.  FTE_IGEMM16_DEEP=0 turns it off.
+    {
+        static const int deep_env = getenv("FTE_IGEMM16_DEEP") ? atoi(getenv("FTE_IGEMM16_DEEP")) : 1;
+        static const int deep_tiles = getenv("FTE_IGEMM16_DEEP_TILES") ? atoi(getenv("FTE_IGEMM16_DEEP_TILES")) : 768;
+        const long ntl = (long)((p.M - p.m_base + 127) / 128) * (p.N / (tile == TILE_128x128 ? 128 : 64)) * (p.ncls > 1 ? p.ncls : 1);
+        if (deep_env && splits == 1 && !p.PW && p.a_NT == 1 && ntl <= deep_tiles && p.kchunk >= p.K && p.K / BK16 >= 6) {
+            if (tile == TILE_128x128) {
+                if (epi == EPI_FWD) return launch16<128, 128, 4, 2, EPI_FWD, 3, 2>(p, splits, st);
+                return launch16<128, 128, 4, 2, EPI_DGRAD, 3, 2>(p, splits, st);
+            }
+            if (tile == TILE_128x64) {
+                if (epi == EPI_FWD) return launch16<128, 64, 4, 2, EPI_FWD, 3, 4>(p, splits, st);
+                return launch16<128, 64, 4, 2, EPI_DGRAD, 3, 4>(p, splits, st);
+            }
+        }
+    }
     static const int pers = getenv("FTE_IGEMM16_PERSIST") ? atoi(getenv("FTE_IGEMM16_PERSIST")) : 1;
     static const int stg_env = getenv("FTE_IGEMM16_STG") ? atoi(getenv("FTE_IGEMM16_STG")) : 1;      // A/B hook: 0 = the register epilogue everywhere
     const bool stg = stg_env != 0, stg2 = stg_env == 2;
