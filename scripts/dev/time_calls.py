@@ -44,6 +44,25 @@ for _ in range(4):
     step()
     runs.append(cur)
 _lib.call = real_call
+# one more step with the library's own launch records on: the conv / GEMM symbol(s) each call dispatched
+syms = []
+
+
+def sym_call(fn, *args):
+    n0 = _lib.query('fte_prof_count')
+    r = real_call(fn, *args)
+    syms.append((n0, _lib.query('fte_prof_count')))
+    return r
+
+
+_lib.query('fte_prof_enable', 1)
+_lib.call = sym_call
+step()
+torch.cuda.synchronize()
+_lib.call = real_call
+_lib.query('fte_prof_enable', 0)
+recs = _lib.prof_records(shapes=True)
+names = [' + '.join(sorted({recs[k][5].replace('_kernel', '') for k in range(a, b) if recs[k][5]})) for a, b in syms]
 base = runs[0]
 tot = 0.0
 agg = {}
@@ -53,7 +72,8 @@ for i, (fn, ints, nb, _) in enumerate(base):
     a = agg.setdefault(fn, [0, 0.0, 0])
     a[0] += 1; a[1] += us; a[2] += nb
     if flt in fn:
-        print('%4d %-34s %-44s %8.1f MB %7.1f us %6.0f GB/s' % (i, fn, ','.join(map(str, ints[:9])), nb / 1e6, us, nb / us / 1e3))
+        print('%4d %-34s %-44s %8.1f MB %7.1f us %6.0f GB/s  %s' % (i, fn, ','.join(map(str, ints[:9])), nb / 1e6, us, nb / us / 1e3,
+                                                                     names[i] if i < len(names) and len(names) == len(base) else ''))
 print('--- per entry point (serialised, one stream): total %.2f ms' % (tot / 1e3))
 for fn, (cnt, us, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print('%-36s %4d calls %8.3f ms %9.1f MB %6.0f GB/s' % (fn, cnt, us / 1e3, nb / 1e6, nb / us / 1e3 if us else 0))

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include "layers.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1480,7 +1481,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
                                                                   float* __restrict__ y, int n, int h, int wd, int c, GconvBn bn) {
     __shared__ __attribute__((aligned(16))) unsigned short wsh[9 * 32 * 32];
     constexpr int WROW = 40, WBUF = 34 * WROW;                    // bf16 per window row (32 + 8 pad: conflict-free b128 reads), per buffer
-    __shared__ __attribute__((aligned(16))) unsigned short win[4][2][WBUF];
+    __shared__ __attribute__((aligned(16))) unsigned short win[4][3][WBUF];    // one buffer per kernel row: a tile's three rows are fetched together
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int slice = blockIdx.y;
@@ -1497,36 +1498,53 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
     unsigned short* wb = &win[wv][0][0];
     f32x4 isc4 = {0.f, 0.f, 0.f, 0.f}, ish4 = isc4;
     if constexpr (PRO) { isc4 = *reinterpret_cast<const f32x4*>(bn.isc + xs); ish4 = *reinterpret_cast<const f32x4*>(bn.ish + xs); }
-    auto fetch = [&](long tile, int r, f32x4 (&v)[5]) {
+    // a fetched window row stays in its memory format until it is stashed (bf16 storage: 2 registers per piece instead of 4)
+    using raw_t = typename std::conditional<H, u32x2_l, f32x4>::type;
+    auto fetch = [&](long tile, int r, raw_t (&v)[5]) {
         const long s0 = tile * 32 - 1 + (long)(r - 1) * wd + fr;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const long sp = s0 + 8 * i;
             const bool ok = fr + 8 * i < 34 && sp >= 0 && sp < npix;
-            f32x4 val = ldq<H>(x, xs + (ok ? sp : 0) * c);
-            if constexpr (PRO) {
-                val = bn_affine(val, isc4, ish4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
-                // the centre row's window entries 1 .. 32 are the tile's own pixels: each pixel of the tensor exactly once
-                if (r == 1 && ok && fr + 8 * i >= 1 && fr + 8 * i <= 32) stq<true>(reinterpret_cast<float*>(bn.yside), xs + sp * c, val);
-            }
-            v[i] = ok ? val : f32x4{0.f, 0.f, 0.f, 0.f};
+            const long off = xs + (ok ? sp : 0) * c;
+            if constexpr (H) v[i] = *reinterpret_cast<const u32x2_l*>(reinterpret_cast<const unsigned short*>(x) + off);
+            else v[i] = *reinterpret_cast<const f32x4*>(x + off);
         }
     };
-    auto stash = [&](int buf, const f32x4 (&v)[5]) {
+    auto stash = [&](int buf, long tile, int r, const raw_t (&v)[5]) {
+        const long s0 = tile * 32 - 1 + (long)(r - 1) * wd + fr;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int j = fr + 8 * i;
-            if (j < 34)
-                *reinterpret_cast<s16x4_l*>(wb + buf * WBUF + j * WROW + (fp << 2)) = __builtin_bit_cast(s16x4_l, __builtin_convertvector(v[i], bf16x4_l));
+            const long sp = s0 + 8 * i;
+            const bool ok = j < 34 && sp >= 0 && sp < npix;
+            if (j >= 34) continue;
+            unsigned short* dst = wb + buf * WBUF + j * WROW + (fp << 2);
+            if constexpr (H && !PRO) {
+                *reinterpret_cast<u32x2_l*>(dst) = ok ? v[i] : u32x2_l{0u, 0u};
+            } else {
+                f32x4 val;
+                if constexpr (H) val = f32x4{__builtin_bit_cast(float, v[i][0] << 16), __builtin_bit_cast(float, v[i][0] & 0xffff0000u),
+                                             __builtin_bit_cast(float, v[i][1] << 16), __builtin_bit_cast(float, v[i][1] & 0xffff0000u)};
+                else val = v[i];
+                if constexpr (PRO) {
+                    val = bn_affine(val, isc4, ish4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+                    // the centre row's window entries 1 .. 32 are the tile's own pixels: each pixel of the tensor exactly once
+                    if (r == 1 && ok && j >= 1 && j <= 32) stq<true>(reinterpret_cast<float*>(bn.yside), xs + sp * c, val);
+                }
+                if (!ok) val = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<s16x4_l*>(dst) = __builtin_bit_cast(s16x4_l, __builtin_convertvector(val, bf16x4_l));
+            }
         }
     };
     const long stride_t = (long)gridDim.x * 4;
     long tile = (long)blockIdx.x * 4 + wv;
-    f32x4 va[5], vb[5];
-    if (tile < ntiles) fetch(tile, 0, va);
-    int sb = 0;
+    // all three window rows of a tile are in flight at once, and the NEXT tile's go out before this tile's MFMAs (one row at a time
+    // left 2.5 KB in flight per wave: the launches ran at 0.6-1.2 TB/s on a chain of dependent round trips)
+    raw_t va[5], vb[5], vc[5];
+    if (tile < ntiles) { fetch(tile, 0, va); fetch(tile, 1, vb); fetch(tile, 2, vc); }
     GconvAcc bst = {0.f, 0.f, 0.f, 0.f};
     float bmu = 0.f, brs = 0.f, bsc = 0.f, bsh = 0.f;
     if constexpr (BNF == 2) {
@@ -1567,17 +1585,13 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
                 }
             }
         };
-        // rows alternate between the two window buffers; the next row (or the next tile's first row) is in flight while this one multiplies
-        stash(sb, va);
-        fetch(tile, 1, vb);
-        row(0, sb);
-        stash(sb ^ 1, vb);
-        fetch(tile, 2, va);
-        row(1, sb ^ 1);
-        stash(sb, va);
-        if (tile + stride_t < ntiles) fetch(tile + stride_t, 0, va);
-        row(2, sb);
-        sb ^= 1;
+        stash(0, tile, 0, va);
+        stash(1, tile, 1, vb);
+        stash(2, tile, 2, vc);
+        if (tile + stride_t < ntiles) { fetch(tile + stride_t, 0, va); fetch(tile + stride_t, 1, vb); fetch(tile + stride_t, 2, vc); }
+        row(0, 0);
+        row(1, 1);
+        row(2, 2);
         const long yo = slice * 32 + li;
         if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh, zr);
 #pragma unroll
@@ -1891,6 +1905,8 @@ static long gconv16_blocks(long npix, int c, bool bn) {
     long bx = (ntiles + 3) / 4;
     long cap = 8192 / (c / 32) > 1 ? 8192 / (c / 32) : 1;
     if (bn && cap > 512) cap = 512;
+    static const long total = getenv("FTE_GCONV_BLOCKS") ? atol(getenv("FTE_GCONV_BLOCKS")) : 512;    // blocks of the whole launch: two per CU, several tiles per wave (measured 2048 / 1024 / 768 / 512 / 384 / 256: DESIGN.md)
+    if (total > 0 && cap > total / (c / 32)) cap = total / (c / 32) > 1 ? total / (c / 32) : 1;
     return bx > cap ? cap : bx;
 }
 int l_gconv_bn_rows(int n, int h, int wd, int c) { return (int)gconv16_blocks((long)n * h * wd, c, true) * 4; }
