@@ -1314,6 +1314,17 @@ template <int BNF>
 __device__ __forceinline__ void gconv_bn_tile(const GconvBn& bn, GconvAcc& st, f32x16_l& acc, long tile, long npix, int c, int ch, int lh,
                                               float mu, float rs, float sc, float sh, const unsigned short (&zr)[16]) {
     if constexpr (BNF == 1) {
+        if (tile * 32 + 32 <= npix) {                   // (wave-uniform) a whole tile: no row checks, the shift is set once
+            if (st.a == 0.f) st.shift = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, (__bf16)acc[0]) << 16);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, (__bf16)acc[i]) << 16);
+                const float d = v - st.shift;
+                st.b += d; st.c += d * d;
+            }
+            st.a += 16.f;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
@@ -1476,6 +1487,14 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_kernel(const float* __res
 // ONCE (coalesced 128-byte rows, rounded to bf16, 80-byte LDS rows), and the three taps q read window rows li + q; the image /
 // row edges are a 9-bit mask per lane that zeroes the fragment.  gconv3x3_mfma16_kernel<0> fetched every tap on its own: 9 x the
 // tensor through L2 -> L1 (461 MB for the 28x28x128 layer at 128 images, 52 us = the L2 rate); this one moves 3.2 x.
+// a / d for 0 <= a < 2^24 with rd = 1 / d (one multiply and a correction instead of the integer division sequence)
+__device__ __forceinline__ int gdiv(int a, int d, float rd) {
+    int q = (int)((float)a * rd);
+    const int r = a - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
 template <bool H = false, int BNF = 0, bool PRO = false>
 __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                                   float* __restrict__ y, int n, int h, int wd, int c, GconvBn bn) {
@@ -1491,56 +1510,64 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
         for (int i = threadIdx.x; i < 9 * 1024 / 8; i += 256) dst[i] = src[i];
     }
     __syncthreads();
-    const long npix = (long)n * h * wd;
-    const long ntiles = (npix + 31) / 32;
+    // 32-bit pixel / byte offsets and buffer addressing (the launcher checks npix * c * element size < 2^31): an out-of-range window
+    // entry is an out-of-range OFFSET, which the buffer load answers with zeros -- the kernel was bound by its own address arithmetic
+    // (~1000 VALU instructions per 18 MFMAs with 64-bit offsets, range checks and the / and % of the edge masks)
+    constexpr unsigned ES = H ? 2u : 4u, OOB = 0x80000000u;
+    const int npix = n * h * wd;
+    const int ntiles = (npix + 31) / 32;
     const int fr = lane >> 3, fp = lane & 7;
-    const long xs = slice * 32 + (fp << 2);
+    const int xs = slice * 32 + (fp << 2);
+    const unsigned cb = (unsigned)c * ES, xsb = (unsigned)xs * ES;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (unsigned)npix * cb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, (unsigned)npix * cb, 0x00020000);
     unsigned short* wb = &win[wv][0][0];
     f32x4 isc4 = {0.f, 0.f, 0.f, 0.f}, ish4 = isc4;
     if constexpr (PRO) { isc4 = *reinterpret_cast<const f32x4*>(bn.isc + xs); ish4 = *reinterpret_cast<const f32x4*>(bn.ish + xs); }
     // a fetched window row stays in its memory format until it is stashed (bf16 storage: 2 registers per piece instead of 4)
     using raw_t = typename std::conditional<H, u32x2_l, f32x4>::type;
-    auto fetch = [&](long tile, int r, raw_t (&v)[5]) {
-        const long s0 = tile * 32 - 1 + (long)(r - 1) * wd + fr;
+    auto fetch = [&](int tile, int r, raw_t (&v)[5]) {
+        const int s0 = tile * 32 - 1 + (r - 1) * wd + fr;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const long sp = s0 + 8 * i;
-            const bool ok = fr + 8 * i < 34 && sp >= 0 && sp < npix;
-            const long off = xs + (ok ? sp : 0) * c;
-            if constexpr (H) v[i] = *reinterpret_cast<const u32x2_l*>(reinterpret_cast<const unsigned short*>(x) + off);
-            else v[i] = *reinterpret_cast<const f32x4*>(x + off);
+            const int sp = s0 + 8 * i;
+            const bool ok = fr + 8 * i < 34 && (unsigned)sp < (unsigned)npix;
+            const unsigned voff = ok ? (unsigned)sp * cb + xsb : OOB;
+            if constexpr (H) v[i] = __builtin_bit_cast(u32x2_l, __builtin_amdgcn_raw_buffer_load_b64(rx, voff, 0, 0));
+            else v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff, 0, 0));
         }
     };
-    auto stash = [&](int buf, long tile, int r, const raw_t (&v)[5]) {
-        const long s0 = tile * 32 - 1 + (long)(r - 1) * wd + fr;
+    auto stash = [&](int buf, int tile, int r, const raw_t (&v)[5]) {
+        const int s0 = tile * 32 - 1 + (r - 1) * wd + fr;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int j = fr + 8 * i;
-            const long sp = s0 + 8 * i;
-            const bool ok = j < 34 && sp >= 0 && sp < npix;
             if (j >= 34) continue;
             unsigned short* dst = wb + buf * WBUF + j * WROW + (fp << 2);
             if constexpr (H && !PRO) {
-                *reinterpret_cast<u32x2_l*>(dst) = ok ? v[i] : u32x2_l{0u, 0u};
+                *reinterpret_cast<u32x2_l*>(dst) = v[i];                  // (zeros where the entry lies outside the tensor)
             } else {
                 f32x4 val;
                 if constexpr (H) val = f32x4{__builtin_bit_cast(float, v[i][0] << 16), __builtin_bit_cast(float, v[i][0] & 0xffff0000u),
                                              __builtin_bit_cast(float, v[i][1] << 16), __builtin_bit_cast(float, v[i][1] & 0xffff0000u)};
                 else val = v[i];
                 if constexpr (PRO) {
+                    const int sp = s0 + 8 * i;
+                    const bool ok = (unsigned)sp < (unsigned)npix;
                     val = bn_affine(val, isc4, ish4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+                    for (int e = 0; e < 4; ++e) val[e] = ok ? fmaxf(val[e], 0.f) : 0.f;
                     // the centre row's window entries 1 .. 32 are the tile's own pixels: each pixel of the tensor exactly once
-                    if (r == 1 && ok && j >= 1 && j <= 32) stq<true>(reinterpret_cast<float*>(bn.yside), xs + sp * c, val);
+                    if (r == 1 && ok && j >= 1 && j <= 32) stq<true>(reinterpret_cast<float*>(bn.yside), xs + (long)sp * c, val);
                 }
-                if (!ok) val = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<s16x4_l*>(dst) = __builtin_bit_cast(s16x4_l, __builtin_convertvector(val, bf16x4_l));
             }
         }
     };
-    const long stride_t = (long)gridDim.x * 4;
-    long tile = (long)blockIdx.x * 4 + wv;
+    const bool fast_div = npix < (1 << 24);
+    const float r_wd = 1.f / (float)wd, r_h = 1.f / (float)h;
+    const int stride_t = (int)gridDim.x * 4;
+    int tile = (int)blockIdx.x * 4 + wv;
     // all three window rows of a tile are in flight at once, and the NEXT tile's go out before this tile's MFMAs (one row at a time
     // left 2.5 KB in flight per wave: the launches ran at 0.6-1.2 TB/s on a chain of dependent round trips)
     raw_t va[5], vb[5], vc[5];
@@ -1554,11 +1581,17 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
     for (; tile < ntiles; tile += stride_t) {
         unsigned short zr[16];
         gconv_bn_prefetch<BNF>(bn, zr, tile, npix, c, slice * 32 + li, lh);
-        const long p = tile * 32 + li;
+        const int p = tile * 32 + li;
         const bool pok = p < npix;
-        const unsigned pu = (unsigned)(pok ? p : 0);
-        const int ox = (int)(pu % (unsigned)wd);
-        const int oy = (int)((pu / (unsigned)wd) % (unsigned)h);
+        const int pu = pok ? p : 0;
+        int ox, oy;
+        if (fast_div) {                                            // (wave-uniform)
+            const int q1 = gdiv(pu, wd, r_wd), q2 = gdiv(q1, h, r_h);
+            ox = pu - q1 * wd; oy = q1 - q2 * h;
+        } else {
+            ox = (int)((unsigned)pu % (unsigned)wd);
+            oy = (int)(((unsigned)pu / (unsigned)wd) % (unsigned)h);
+        }
         unsigned vm = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -1592,12 +1625,16 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
         row(0, 0);
         row(1, 1);
         row(2, 2);
-        const long yo = slice * 32 + li;
-        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, (int)yo, lh, bmu, brs, bsc, bsh, zr);
+        const int yo = slice * 32 + li;
+        if constexpr (BNF != 0) gconv_bn_tile<BNF>(bn, bst, acc, tile, npix, c, yo, lh, bmu, brs, bsc, bsh, zr);
+        const unsigned ybase = (unsigned)(tile * 32 + 4 * lh) * cb + (unsigned)yo * ES;
+        const int prow = tile * 32 + 4 * lh;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const long pr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-            if (pr < npix) st1<H>(y, yo + pr * c, acc[i]);
+            const int d = (i & 3) + 8 * (i >> 2);
+            const unsigned voff = prow + d < npix ? ybase + (unsigned)d * cb : OOB;      // (a store to an out-of-range offset is dropped)
+            if constexpr (H) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)acc[i]), ry, voff, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i]), ry, voff, 0, 0);
         }
     }
     if constexpr (BNF != 0) gconv_bn_flush<BNF>(bn, bst, blockIdx.x * 4 + wv, c, slice * 32 + li, lh);
