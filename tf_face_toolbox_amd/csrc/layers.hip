@@ -1634,7 +1634,7 @@ __global__ __launch_bounds__(256) void gconv3x3_mfma16_win_kernel(const float* _
             const int d = (i & 3) + 8 * (i >> 2);
             const unsigned voff = prow + d < npix ? ybase + (unsigned)d * cb : OOB;      // (a store to an out-of-range offset is dropped)
             if constexpr (H) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)acc[i]), ry, voff, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i]), ry, voff, 0, 0);
+            else { const float av = acc[i]; __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), ry, voff, 0, 0); }
         }
     }
     if constexpr (BNF != 0) gconv_bn_flush<BNF>(bn, bst, blockIdx.x * 4 + wv, c, slice * 32 + li, lh);
