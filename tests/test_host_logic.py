@@ -208,7 +208,7 @@ def test_filter_pack_table_layout():
     packs = FilterPacks(entries, 'cpu')
     assert [l[1] for l in packs.launches] == [64, 6]
     off = 0
-    for li, (tab, n, total, base) in enumerate(packs.launches):
+    for li, (tab, n, total, base, _head) in enumerate(packs.launches):
         t = tab.tolist()
         start = 0
         for row, (name, src, k, cin, cout) in zip(t, entries[li * 64:li * 64 + n]):
