@@ -610,9 +610,12 @@ class GraphNet(Network):
                 self.t[out + '/hid'] = torch.empty(n, hd, **f32)
                 self.t[out + '/gate'] = torch.empty(n, cc, **f32)
                 need = max(need, q('fte_gemm_ws_bytes', n, cc, hd), q('fte_gemm_ws_bytes', n, hd, cc))
-                for nm, wdt in (('dgate', cc), ('dhid', hd), ('dsq', cc)):           # backward scratch, shared by all SE blocks of a width
-                    if ('se', nm, wdt) not in self.ident:
-                        self.ident[('se', nm, wdt)] = torch.empty(n, wdt, **f32)
+                # backward scratch: dsq is shared by all SE blocks of a width; dgate / dhid are per block -- the gate's weight gradients
+                # read them on the side stream while the walk has moved on to the next block
+                if ('se', 'dsq', cc) not in self.ident:
+                    self.ident[('se', 'dsq', cc)] = torch.empty(n, cc, **f32)
+                self.ident[('se', out, 'dgate')] = torch.empty(n, cc, **f32)
+                self.ident[('se', out, 'dhid')] = torch.empty(n, hd, **f32)
             elif kind == 'addrelu':
                 cc = shape[-1]
                 if cc not in self.ident:
@@ -1209,17 +1212,18 @@ class GraphNet(Network):
                 f32 = dict(dtype=torch.float32, device=self.device)
                 dx = self._new(inp)
                 # scratch preallocated in _alloc (three allocator calls per SE block and step otherwise)
-                dgate, dhid, dsq = (self.ident[('se', nm, wdt)] for nm, wdt in (('dgate', c), ('dhid', hd), ('dsq', c)))
+                dgate, dhid, dsq = self.ident[('se', out, 'dgate')], self.ident[('se', out, 'dhid')], self.ident[('se', 'dsq', c)]
                 if s16:          # reduction only; dx is written once by the apply pass below
                     call('fte_channel_scale_bwd_s16', dy, T[inp], gate, dgate, n, hw, c, 1, st)
                 else:
                     call('fte_channel_scale_bwd', dy, T[inp], gate, dx, dgate, n, hw, c, 1, st)         # dgate = d(pre-sigmoid)
-                call('fte_gemm_tn', hid, dgate, self.view(w2, self.grads), n, c, hd, self.ws, self.ws_bytes, st)
-                call('fte_reduce_rows', dgate, self.view(b2, self.grads), None, 1, n, c, 1, 1.0, st)
+                # the gate's four parameter gradients feed nothing but the optimizer: side stream, like every filter gradient
+                wgrad('fte_gemm_tn', dgate, hid, dgate, self.view(w2, self.grads), n, c, hd, wws, self.ws_bytes, wst)
+                wgrad('fte_reduce_rows', dgate, dgate, self.view(b2, self.grads), None, 1, n, c, 1, 1.0, wst)
                 call('fte_gemm_nt', dgate, self.view(w2), None, None, 0, None, dhid, None, n, c, hd, self.ws, self.ws_bytes, st)
                 call('fte_act_bwd', dhid, hid, dhid, dhid.numel(), 0, st)                            # -> d(pre-ReLU)
-                call('fte_gemm_tn', sq, dhid, self.view(w1, self.grads), n, hd, c, self.ws, self.ws_bytes, st)
-                call('fte_reduce_rows', dhid, self.view(b1, self.grads), None, 1, n, hd, 1, 1.0, st)
+                wgrad('fte_gemm_tn', dhid, sq, dhid, self.view(w1, self.grads), n, hd, c, wws, self.ws_bytes, wst)
+                wgrad('fte_reduce_rows', dhid, dhid, self.view(b1, self.grads), None, 1, n, hd, 1, 1.0, wst)
                 call('fte_gemm_nt', dhid, self.view(w1), None, None, 0, None, dsq, None, n, hd, c, self.ws, self.ws_bytes, st)
                 if s16:
                     call('fte_channel_scale_bwd_apply_s16', dy, gate, dsq, dx, n, hw, c, 1.0 / hw, st)
