@@ -154,6 +154,18 @@ inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only 
     // P = 2 already pays (batch 64, 14x14x256: 96 -> 101 TFLOP/s forward, 89 -> 95
     // dgrad; batch 128, 7x7x512: 100 -> 111); P = 1 means the tiles fill the chip on their own.
     static const int min_p = getenv("FTE_MIN_SPLITP") ? atoi(getenv("FTE_MIN_SPLITP")) : 2;     // tuning hook
+    // bf16 plans: an unsplit launch on the LDS-DMA kernels (three-stage ring below 768 tiles) instead of split-K + fix-up on the
+    // register-staged 64x64 kernel, whenever the 128-row tiles give pick_tile's minimum.  FTE_PLAN16_NOSPLIT=0: the split plan.
+    static const bool nosplit16 = !(getenv("FTE_PLAN16_NOSPLIT") && atoi(getenv("FTE_PLAN16_NOSPLIT")) == 0);
+    if (nosplit16 && plan_bf16() && !small_only && T < SLOTS) {
+        const int t16 = pick_tile(M, N);
+        if (t16 == TILE_128x128 || t16 == TILE_128x64) {
+            int tbm, tbn;
+            igemm_tile_dims(t16, &tbm, &tbn);
+            r.main_tile = t16; r.main_rows = M; r.main_mtiles = (M + tbm - 1) / tbm;
+            return r;
+        }
+    }
     if (allow_pw && P >= min_p && T < SLOTS) {
         r.tail_mode = 2; r.tail_tile = big; r.tail_mtiles = tmt * FIXUP_CHUNKS;   // partial rows: one per (tile row, chunk)
         r.tail_kchunk = (int)((ksteps + P - 1) / P * 32);
