@@ -420,19 +420,30 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int ksize, int stride
 // ... and only while one class alone cannot fill the chip (fewer 64x64 tiles than resident slots: the small per-GPU
 // shards).  Measured on MI355X, 28x28x128 <- 256 at batch 512: four launches 0.55 ms, the merged one 0.75 ms with the SAME
 // instruction counts but half the resident waves (PMC); at batch 64 the merged launch is the faster one (36 -> 50 TFLOP/s).
+// FTE_DGRAD_MERGED16=1 (A/B hook): in the bf16 plans the four classes always share ONE launch on the LDS-DMA kernels' 128-row tiles
+static bool dgrad_merged16() {
+    static const bool on = getenv("FTE_DGRAD_MERGED16") && atoi(getenv("FTE_DGRAD_MERGED16")) == 1;
+    return on && plan_bf16();
+}
 bool dgrad_mergeable(const DgradClass* cls, int nc, int n, int cin) {
     static const char* mode = getenv("FTE_DGRAD_CLASSES");      // tuning hook: "split" | "merged"
     if (nc != 4 || (mode && mode[0] == 's')) return false;
     for (int i = 0; i < nc; ++i)
         if (cls[i].hq != cls[0].hq || cls[i].wq != cls[0].wq || cls[i].ntap < 1) return false;
-    if (mode && mode[0] == 'm') return true;
+    if ((mode && mode[0] == 'm') || dgrad_merged16()) return true;
     const long tiles = (((long)n * cls[0].hq * cls[0].wq + 63) / 64) * (cin / 64);
     return tiles < SLOTS;
+}
+static int dgrad_merged_tile(int cin) {
+    if (!dgrad_merged16()) return TILE_64x64;
+    return cin % 128 == 0 ? TILE_128x128 : TILE_128x64;
 }
 // partial rows (one per tile row and class) the merged launch writes for dalpha / dbias
 long dgrad_merged_rows(const DgradClass* cls, int nc, int n, int cin) {
     if (!dgrad_mergeable(cls, nc, n, cin)) return 0;
-    return (long)nc * (((long)n * cls[0].hq * cls[0].wq + 63) / 64);
+    int bm, bn;
+    igemm_tile_dims(dgrad_merged_tile(cin), &bm, &bn);
+    return (long)nc * (((long)n * cls[0].hq * cls[0].wq + bm - 1) / bm);
 }
 // tile of the merged launch and the class order (most taps first)
 int dgrad_merged_plan(const DgradClass* cls, int nc, int n, int cin, int* order) {
@@ -440,8 +451,8 @@ int dgrad_merged_plan(const DgradClass* cls, int nc, int n, int cin, int* order)
     for (int i = 0; i < nc; ++i)
         for (int j = i + 1; j < nc; ++j)
             if (cls[order[j]].ntap > cls[order[i]].ntap) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    (void)n; (void)cin;
-    return TILE_64x64;
+    (void)n;
+    return dgrad_merged_tile(cin);
 }
 }  // namespace
 
