@@ -19,6 +19,14 @@ def _check(t, dtype, what):
     return t.contiguous()
 
 
+def _scaled_sum(rows, scale):
+    """0-d tensor scale * sum(rows) on the library's ordered two-stage reduction (no ATen kernel on the step)"""
+    out = torch.empty(1, dtype=torch.float32, device=rows.device)
+    ws = torch.empty(2048, dtype=torch.float32, device=rows.device)
+    _lib.call('fte_sum', rows, rows.numel(), float(scale), out, ws, ws.numel() * 4, _stream())
+    return out[0]
+
+
 def focal_loss(logits, labels, gamma=1.0, alpha=2.0, num_classes=None):
     """mean_i gamma * (1 - p_y)^alpha * CE_i (loss.py:18-27; the reference's parameter names are kept as written).
     -> (loss [0-d], dlogits [N, ld])"""
@@ -28,7 +36,7 @@ def focal_loss(logits, labels, gamma=1.0, alpha=2.0, num_classes=None):
     rows = torch.empty(n, dtype=torch.float32, device=logits.device)
     d = torch.empty_like(logits)
     _lib.call('fte_focal_loss_fwd_bwd', logits, labels, rows, d, n, c, ld, float(gamma), float(alpha), 1.0 / n, _stream())
-    return rows.mean(), d
+    return _scaled_sum(rows, 1.0 / n), d
 
 
 def center_loss(features, labels, num_classes, alpha=0.99, weight=1.0, centers=None):
@@ -45,7 +53,7 @@ def center_loss(features, labels, num_classes, alpha=0.99, weight=1.0, centers=N
     ws = torch.empty(max(n * d, 1024) + 1024, dtype=torch.float32, device=features.device)
     _lib.call('fte_center_loss_fwd_bwd_update', features, labels, centers, rows, df, n, d, int(centers.shape[0]), float(alpha),
               float(weight) / (n * d), ws, ws.numel() * 4, _stream())
-    return rows.sum() / (n * d), centers, df
+    return _scaled_sum(rows, 1.0 / (n * d)), centers, df
 
 
 def batch_hard_triplet_loss(features, labels, margin=None, metric='euclidean'):
