@@ -483,6 +483,24 @@ class GraphNet(Network):
                     us = pusers.get(op[1], [])
                     if len(us) == 1 and us[0] in self.fuse_fwd and plan[us[0]][0] in ('conv', 'gconv') and plan[us[0]][2] == op[1]:
                         self.fold_apply[j] = us[0]
+        # Shortcut branches of the residual blocks (conv 1x1 -> BN without activation, consumed only as the `res` of the block's last
+        # BN or by its add + ReLU): independent of the block's main branch, so the forward walk queues them on the side stream and the
+        # consumer waits for their event (shortcut_fwd: plan index -> True for the conv and the BN).  FTE_SHORTCUT_SIDE=0: off (A/B hook).
+        self.shortcut_fwd = {}
+        if os.environ.get('FTE_SHORTCUT_SIDE', '1') != '0':
+            producer = {op[1]: j for j, op in enumerate(plan) if op[0] == 'conv'}
+            for j, op in enumerate(plan):
+                if op[0] != 'bn' or op[4] is not None or op[5]:
+                    continue
+                us = pusers.get(op[1], [])
+                if len(us) != 1 or op[1] == self.feature_name:
+                    continue
+                cons = plan[us[0]]
+                as_res = (cons[0] == 'bn' and cons[4] == op[1] and cons[2] != op[1]) or (cons[0] == 'addrelu' and op[1] in (cons[2], cons[3]))
+                i = producer.get(op[2])
+                if as_res and i is not None and pusers.get(op[2], []) == [j] and i == j - 1:
+                    self.shortcut_fwd[i] = True
+                    self.shortcut_fwd[j] = True
         self.plan = plan
         self.has_classifier = plan[-1][0] == 'fc'
 
@@ -711,27 +729,35 @@ class GraphNet(Network):
             b, pre = self.bn[bop[1]], bop[3]
             return (self.view(pre + '/gamma'), self.view(pre + '/beta'), b['mean'], b['rstd'], b['scale'], b['shift'],
                     self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None, BN_EPS, BN_DECAY)
+        main_s = torch.cuda.current_stream()
+        sc_side = self.side if (self.side is not None and is_training and self.shortcut_fwd) else None
+        sc_ev = {}                                       # shortcut tensor -> event of the side stream that completes it
+        st_main, ws_main = st, self.ws
         for j, op in enumerate(self.plan):
             kind, out = op[0], op[1]
+            on_side = sc_side is not None and j in self.shortcut_fwd
+            st, ws_j = (sc_side.cuda_stream, self.ws_side) if on_side else (st_main, ws_main)
             if kind == 'conv':
                 _, _, inp, wname, stride = op
                 ih, iw, cin = self.shapes[inp]
                 k = self.spec[wname][0][0]
                 cout = self.shapes[out][-1]
-                if pack_ev is not None and cin >= 32 and wname not in self.packs.head_names:
+                if on_side:
+                    sc_side.wait_event(main_s.record_event())          # the block's input is complete (the packs were made on this stream)
+                if not on_side and pack_ev is not None and cin >= 32 and wname not in self.packs.head_names:
                     torch.cuda.current_stream().wait_event(pack_ev)          # the side stream's packs (once: every later layer is behind this wait)
                     pack_ev = None
                 if cin >= 32 and is_training and j in self.fuse_fwd and (k == 1 or not s16 or self.fuse_3x3):          # conv + the batch statistics of its output ("BN fusion")
                     xin, isc, ish, yside = fold_args(j)
                     call('fte_conv2d_bn_fwd', xin, self.w16t[wname] if s16 else self.view(wname), T[out], *bn_args(self.fuse_fwd[j]),
-                         isc, ish, yside, n, ih, iw, cin, cout, k, stride, 1 if s16 else 0, self.ws, self.ws_bytes, st)
+                         isc, ish, yside, n, ih, iw, cin, cout, k, stride, 1 if s16 else 0, ws_j, self.ws_bytes, st)
                     stats_done.add(self.fuse_fwd[j])
                 elif cin >= 32 and s16:          # bf16 storage: bf16 x in, bf16 z out, filters packed once per step
                     call('fte_conv2d_fwd_s16', T[inp], self.w16t[wname], None, None, None, None, T[out], None, None,
-                         n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                         n, ih, iw, cin, cout, k, stride, ws_j, self.ws_bytes, st)
                 elif cin >= 32:
                     call('fte_conv2d_fwd', T[inp], self.view(wname), None, None, None, None, T[out],
-                         n, ih, iw, cin, cout, k, stride, self.ws, self.ws_bytes, st)
+                         n, ih, iw, cin, cout, k, stride, ws_j, self.ws_bytes, st)
                 elif self._direct_stem(k, cin, cout):          # 3x3 stem of 32 / 64 stored filters: the direct MFMA kernel
                     if s16:
                         call('fte_conv3x3_first_fwd_s16', T[inp], self.view(wname), None, None, None, T[out], n, ih, iw, cin, cout, stride, st)
@@ -802,6 +828,8 @@ class GraphNet(Network):
                 c = self.shapes[out][-1]
                 rows = T[out].numel() // c
                 resbuf = T[res] if res is not None else None
+                if res is not None and res in sc_ev:
+                    main_s.wait_event(sc_ev.pop(res))                  # the shortcut branch (side stream) has written it
                 if j in stats_done and folds(j):  # ... which the consumer's operand loader takes over (it also writes T[out])
                     folded_in[self.fold_apply[j]] = j
                 elif j in stats_done:            # scale / shift are there already: the normalise pass alone
@@ -815,7 +843,7 @@ class GraphNet(Network):
                         call('fte_bn_train_fwd_s16', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'), resbuf, T[out],
                              b['mean'], b['rstd'], b['scale'], b['shift'],
                              self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None,
-                             rows, c, BN_EPS, BN_DECAY, relu, fl, self.ws, self.ws_bytes, st)
+                             rows, c, BN_EPS, BN_DECAY, relu, fl, ws_j, self.ws_bytes, st)
                     else:
                         call('fte_bn_infer_fwd_s16', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
                              self.state[pre + '/moving_mean'], self.state[pre + '/moving_variance'], resbuf, T[out],
@@ -825,11 +853,13 @@ class GraphNet(Network):
                     call('fte_bn_train_fwd', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'), resbuf, T[out],
                          b['mean'], b['rstd'], b['scale'], b['shift'],
                          self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None,
-                         rows, c, BN_EPS, BN_DECAY, relu, self.ws, self.ws_bytes, st)
+                         rows, c, BN_EPS, BN_DECAY, relu, ws_j, self.ws_bytes, st)
                 else:
                     call('fte_bn_infer_fwd', T[inp], self.view(pre + '/gamma'), self.view(pre + '/beta'),
                          self.state[pre + '/moving_mean'], self.state[pre + '/moving_variance'], resbuf, T[out],
                          b['scale'], b['shift'], rows, c, BN_EPS, relu, st)
+                if on_side:
+                    sc_ev[out] = sc_side.record_event()
             elif kind == 'gconv':
                 ih, iw, c = self.shapes[op[2]]
                 pk = self._gconv_pack(op)
@@ -862,6 +892,9 @@ class GraphNet(Network):
             elif kind == 'addrelu':
                 c = self.shapes[out][-1]
                 one, zero = self.ident[c]
+                for nm in (op[2], op[3]):
+                    if nm in sc_ev:
+                        main_s.wait_event(sc_ev.pop(nm))
                 if s16:
                     assert op[2] in h16 and op[3] in h16
                     call('fte_bn_infer_fwd_s16', T[op[2]], one, zero, zero, one, T[op[3]], T[out], self._scr(c, 0), self._scr(c, 1),
