@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
 inline int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 // grid for a walk over [rows][C] in 16-byte steps whose stride (blocks * 256 threads) is a multiple of C / 4: every thread keeps
 // its channel quad (bn_apply_kernel).  blocks is rounded UP to a multiple of (C/4) / gcd(C/4, 256).
-inline int grid_for_c(long n4, int C) {
+inline int grid_for_c(long n4, int C, bool wide = false) {      // wide: fp32 tensors (16 bytes per lane and piece)
     long q = C / 4, a = q, b = 256;
     while (b) { const long t = a % b; a = b; b = t; }
     const long m = q / a;                                       // blocks must be a multiple of m
@@ -1108,7 +1108,10 @@ inline int grid_for_c(long n4, int C) {
     // about 4 resident blocks per CU (measured at 128 images, ms per ResNeXt-50 / SE-ResNet-50 / ResNet-50 step: 512 blocks 7.53 / 9.33 / 7.13,
     // 768: 7.52 / 9.26 / 7.10, 1024: 7.56 / 9.27 / 7.08, 2048: 7.68 / 9.44 / 7.22, one piece per thread: 7.70 / 9.44 / 7.24), each thread walking >= 4 pieces with all of them in flight (bn_apply_kernel's unrolled walk):
     // one piece per thread on 6000+ blocks left 32 KB in flight per CU
-    static const long cap = getenv("FTE_BN_APPLY_BLOCKS") ? atol(getenv("FTE_BN_APPLY_BLOCKS")) : 1024;      // tuning hook
+    // fp32 tensors put twice the bytes in flight per lane: two blocks per CU there (ShuffleNet-v2 fp32 @256, ms per step: 256 blocks 8.08,
+    // 384: 8.05, 512: 8.02, 1024: 8.11, 2048: 8.14; the bf16-storage nets: 512 -> 1024 6.73 -> 6.71 / 6.35 -> 6.32 / 8.11 -> 8.07)
+    static const long cap_env = getenv("FTE_BN_APPLY_BLOCKS") ? atol(getenv("FTE_BN_APPLY_BLOCKS")) : 0;      // tuning hook
+    const long cap = cap_env > 0 ? cap_env : (wide ? 512 : 1024);
     if (blocks > cap && n4 >= 4 * cap * 256) blocks = cap;
     blocks = (blocks + m - 1) / m * m;
     return (int)blocks;
@@ -1195,7 +1198,7 @@ hipError_t l_bn_infer_coef(const float* gamma, const float* beta, const float* m
 hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, const float* res, float* y, long rows, int C,
                       int relu, hipStream_t st, int flags) {
     const long n4 = rows * C / 4;
-    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, z, scale, shift, res, y, n4, C, relu));
+    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C, !flags)), dim3(256), 0, st, z, scale, shift, res, y, n4, C, relu));
     return hipGetLastError();
 }
 hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st, int flags) {
@@ -1255,8 +1258,8 @@ hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const f
         if (fe != hipSuccess) return fe;
     }
     const long n4 = rows * C / 4;
-    if (gout) FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
-    else FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C));
+    if (gout) FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C, !flags)), dim3(256), 0, st, gout, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
+    else FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C, !flags)), dim3(256), 0, st, dy, ymask, z, coef, zsc, zsf, dz, n4, C));
     return hipGetLastError();
 }
 // partial rows from which the finalize kernels take the wide form (one channel quad x 256 split lanes per block) instead of 16 channels x
@@ -1288,7 +1291,7 @@ hipError_t l_bn_bwd_finalize(const float* pg, const float* pgx, long ld, int spl
 hipError_t l_bn_bwd_apply(const float* g, const float* z, const float* coef, float* dz, long rows, int C, hipStream_t st, int flags) {
     if (C % 4 || (flags && !quads_per_block(C))) return hipErrorInvalidValue;
     const long n4 = rows * C / 4;
-    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C)), dim3(256), 0, st, g, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
+    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_apply_kernel<ZH, AH>), dim3(grid_for_c(n4, C, !flags)), dim3(256), 0, st, g, nullptr, z, coef, nullptr, nullptr, dz, n4, C));
     return hipGetLastError();
 }
 
