@@ -1148,7 +1148,8 @@ inline void stat_split(long rows, int C, int* splits, long* rps) {
     const int Q = quads_per_block(C);
     const long cb = Q ? (C / 4 + Q - 1) / Q : (C + 63) / 64;
     const long lanes = Q ? 256 / Q : 4;
-    long rs = 2048 / cb;
+    static const long target = getenv("FTE_BN_SPLIT_BLOCKS") ? atol(getenv("FTE_BN_SPLIT_BLOCKS")) : 2048;      // tuning hook: blocks of a reduce pass
+    long rs = target / cb;
     if (rs > rows / (lanes * 8)) rs = rows / (lanes * 8);
     if (rs > BN_MAX_SPLITS) rs = BN_MAX_SPLITS;
     if (rs < 1) rs = 1;
