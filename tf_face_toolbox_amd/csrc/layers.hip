@@ -555,7 +555,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 template <bool AH = false>
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                        float* __restrict__ g, long n4) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long step = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < n4; i += 4 * step) {              // four pieces of both inputs in flight per thread (l_relu_bwd caps the grid)
+        f32x4 d[4], yy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { d[u] = ldq<AH>(dy, (i + u * step) * 4); yy[u] = ldq<AH>(y, (i + u * step) * 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[u][e] = yy[u][e] > 0.f ? d[u][e] : 0.f;
+            stq<AH>(g, (i + u * step) * 4, d[u]);
+        }
+    }
+    for (; i < n4; i += step) {
         f32x4 d = ldq<AH>(dy, i * 4);
         const f32x4 yy = ldq<AH>(y, i * 4);
 #pragma unroll
@@ -1203,8 +1216,12 @@ hipError_t l_bn_apply(const float* z, const float* scale, const float* shift, co
     return hipGetLastError();
 }
 hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStream_t st, int flags) {
-    if (flags & 2) hipLaunchKernelGGL(relu_bwd_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, st, dy, y, g, n / 4);
-    else hipLaunchKernelGGL(relu_bwd_kernel<false>, dim3(grid_for(n / 4)), dim3(256), 0, st, dy, y, g, n / 4);
+    const long n4 = n / 4;
+    long blocks = grid_for(n4);
+    const long cap = flags ? 1024 : 512;                     // as grid_for_c: ~4 (bf16 storage) / ~2 (fp32) blocks per CU, four pieces per thread
+    if (blocks > cap && n4 >= 4 * cap * 256) blocks = cap;
+    if (flags & 2) hipLaunchKernelGGL(relu_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, g, n4);
+    else hipLaunchKernelGGL(relu_bwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, g, n4);
     return hipGetLastError();
 }
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
@@ -2034,13 +2051,22 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // y[n,hw,c] = x * gate[n,c]
 template <bool H = false>      // H: x / y (and dy / dx below) are bf16 in HBM; gate, dgate, dsq are [n, c] fp32
 __global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gate,
-                                                          float* __restrict__ y, long n4, int hw, int c) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const long e = i * 4;
-        const int ch = (int)(e % c);
-        const long img = e / ((long)hw * c);
-        stq<H>(y, e, ldq<H>(x, e) * *reinterpret_cast<const f32x4*>(gate + img * c + ch));
+                                                          float* __restrict__ y, int hwq, int cq) {
+    // grid = (blocks over one image's hw * c / 4 quads, image); the stride is a multiple of c / 4 (chscale_grid), so a thread keeps its
+    // gate quad and has four pieces in flight (a flat walk with a 64-bit / and % per piece ran the SE blocks' passes at 2.5-3 TB/s)
+    const int step = (int)gridDim.x * 256;
+    const long base = (long)blockIdx.y * hwq;
+    int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hwq) return;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gate + ((long)blockIdx.y * cq + i % cq) * 4);
+    for (; i + 3 * step < hwq; i += 4 * step) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ldq<H>(x, (base + i + u * step) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stq<H>(y, (base + i + u * step) * 4, v[u] * g);
     }
+    for (; i < hwq; i += step) stq<H>(y, (base + i) * 4, ldq<H>(x, (base + i) * 4) * g);
 }
 // dx = dy * gate + dsq * scale: the whole gradient of an SE block's input in one pass (the gate path's dy * gate and the squeeze
 // path's broadcast), after chscale_bwd_kernel's reduction has gone through the two dense layers.  With bf16 storage dx is written
@@ -2048,14 +2074,21 @@ __global__ __launch_bounds__(256) void chscale_fwd_kernel(const float* __restric
 template <bool H = false>
 __global__ __launch_bounds__(256) void chscale_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ gate,
                                                                 const float* __restrict__ dsq, float* __restrict__ dx,
-                                                                long n4, int hw, int c, float scale) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const long e = i * 4;
-        const int ch = (int)(e % c);
-        const long img = e / ((long)hw * c);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gate + img * c + ch), q = *reinterpret_cast<const f32x4*>(dsq + img * c + ch);
-        stq<H>(dx, e, ldq<H>(dy, e) * g + q * scale);
+                                                                int hwq, int cq, float scale) {
+    const int step = (int)gridDim.x * 256;                   // (grid and walk as chscale_fwd_kernel)
+    const long base = (long)blockIdx.y * hwq;
+    int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hwq) return;
+    const long go = ((long)blockIdx.y * cq + i % cq) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gate + go), q = *reinterpret_cast<const f32x4*>(dsq + go) * scale;
+    for (; i + 3 * step < hwq; i += 4 * step) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ldq<H>(dy, (base + i + u * step) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stq<H>(dx, (base + i + u * step) * 4, v[u] * g + q);
     }
+    for (; i < hwq; i += step) stq<H>(dx, (base + i) * 4, ldq<H>(dy, (base + i) * 4) * g + q);
 }
 // dx = dy * gate ; dgate[n,c] = sum_hw dy * x   (block = one image x 16 channel quads x 16 row lanes, float4, fixed-order LDS sum)
 template <bool H = false>      // dx may be NULL: reduction only
@@ -2069,7 +2102,21 @@ __global__ __launch_bounds__(256) void chscale_bwd_kernel(const float* __restric
     f32x4 gt = {0.f, 0.f, 0.f, 0.f};
     if (ch < c) {
         gt = *reinterpret_cast<const f32x4*>(gate + (long)img * c + ch);
-        for (int r = rl; r < hw; r += 16) {
+        int r = rl;
+        for (; r + 48 < hw; r += 64) {                          // four rows of both inputs in flight per lane
+            f32x4 d[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long o = ((long)img * hw + r + 16 * u) * c + ch;
+                d[u] = ldq<H>(dy, o); xv[u] = ldq<H>(x, o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += d[u] * xv[u];
+                if (dx) stq<H>(dx, ((long)img * hw + r + 16 * u) * c + ch, d[u] * gt);
+            }
+        }
+        for (; r < hw; r += 16) {
             const long o = ((long)img * hw + r) * c + ch;
             const f32x4 d = ldq<H>(dy, o);
             s += d * ldq<H>(x, o);
@@ -2228,11 +2275,25 @@ hipError_t l_act_bwd(const float* dy, const float* y, float* dx, long n, int kin
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, dy, y, dx, n, kind);
     return hipGetLastError();
 }
+// grid of the channel-scale passes: (blocks over one image's quads, images), ~1024 blocks in all, the stride (blocks.x * 256) a
+// multiple of c / 4 so that a thread keeps its gate quad
+static dim3 chscale_grid(int n, int hw, int c) {
+    const long hwq = (long)hw * (c / 4), cq = c / 4;
+    long a = cq, b = 256;
+    while (b) { const long t = a % b; a = b; b = t; }
+    const long m = cq / a;                                       // blocks.x must be a multiple of m
+    long gx = (hwq + 1023) / 1024;                               // four pieces per thread
+    const long want = (1024 + n - 1) / n;
+    if (gx > want) gx = want;
+    if (gx < 1) gx = 1;
+    gx = (gx + m - 1) / m * m;
+    return dim3((unsigned)gx, (unsigned)n);
+}
 hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st, int h16) {
-    const long n4 = (long)n * hw * c / 4;
-    const dim3 grid((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256));
-    if (h16) hipLaunchKernelGGL(chscale_fwd_kernel<true>, grid, dim3(256), 0, st, x, gate, y, n4, hw, c);
-    else hipLaunchKernelGGL(chscale_fwd_kernel<false>, grid, dim3(256), 0, st, x, gate, y, n4, hw, c);
+    if (c % 4 || (long)hw * c / 4 >= (1L << 30)) return hipErrorInvalidValue;
+    const dim3 grid = chscale_grid(n, hw, c);
+    if (h16) hipLaunchKernelGGL(chscale_fwd_kernel<true>, grid, dim3(256), 0, st, x, gate, y, hw * (c / 4), c / 4);
+    else hipLaunchKernelGGL(chscale_fwd_kernel<false>, grid, dim3(256), 0, st, x, gate, y, hw * (c / 4), c / 4);
     return hipGetLastError();
 }
 hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c,
@@ -2242,10 +2303,10 @@ hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, flo
     return hipGetLastError();
 }
 hipError_t l_chscale_bwd_apply(const float* dy, const float* gate, const float* dsq, float* dx, int n, int hw, int c, float scale, hipStream_t st, int h16) {
-    const long n4 = (long)n * hw * c / 4;
-    const dim3 grid((unsigned)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256));
-    if (h16) hipLaunchKernelGGL(chscale_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, gate, dsq, dx, n4, hw, c, scale);
-    else hipLaunchKernelGGL(chscale_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, gate, dsq, dx, n4, hw, c, scale);
+    if (c % 4 || (long)hw * c / 4 >= (1L << 30)) return hipErrorInvalidValue;
+    const dim3 grid = chscale_grid(n, hw, c);
+    if (h16) hipLaunchKernelGGL(chscale_bwd_apply_kernel<true>, grid, dim3(256), 0, st, dy, gate, dsq, dx, hw * (c / 4), c / 4, scale);
+    else hipLaunchKernelGGL(chscale_bwd_apply_kernel<false>, grid, dim3(256), 0, st, dy, gate, dsq, dx, hw * (c / 4), c / 4, scale);
     return hipGetLastError();
 }
 
