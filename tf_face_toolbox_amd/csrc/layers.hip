@@ -987,12 +987,18 @@ __global__ __launch_bounds__(256) void maxpool_bwd_even_kernel(const float* __re
             if (k.z == pos) acc[2] += d[2];
             if (k.w == pos) acc[3] += d[3];
         };
-        uchar4 k; f32x4 d;
-        if (a > 0 && b > 0) { window(a - 1, b - 1, k, d); take(p00, k, d, 8); }
-        if (a > 0) { window(a - 1, b, k, d); take(p00, k, d, 6); take(p01, k, d, 7); }
-        if (b > 0) { window(a, b - 1, k, d); take(p00, k, d, 2); take(p10, k, d, 5); }
-        window(a, b, k, d);
-        take(p00, k, d, 0); take(p01, k, d, 1); take(p10, k, d, 3); take(p11, k, d, 4);
+        // the four windows' loads go out together (clamped coordinates, results discarded where the window does not exist); the sums
+        // keep their order
+        uchar4 k0, k1, k2, k3; f32x4 d0, d1, d2, d3;
+        const int am = a > 0 ? a - 1 : 0, bm = b > 0 ? b - 1 : 0;
+        window(am, bm, k0, d0);
+        window(am, b, k1, d1);
+        window(a, bm, k2, d2);
+        window(a, b, k3, d3);
+        if (a > 0 && b > 0) take(p00, k0, d0, 8);
+        if (a > 0) { take(p00, k1, d1, 6); take(p01, k1, d1, 7); }
+        if (b > 0) { take(p00, k2, d2, 2); take(p10, k2, d2, 5); }
+        take(p00, k3, d3, 0); take(p01, k3, d3, 1); take(p10, k3, d3, 3); take(p11, k3, d3, 4);
         const long o = (((long)(img * h + 2 * a) * w + 2 * b) * c) + c4 * 4;
         stq<AH>(dx, o, p00);
         stq<AH>(dx, o + c, p01);
@@ -1081,7 +1087,7 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
     const long total = (long)n * ho * wo * k4;
     const int kreal = ks * ks * cin;
     const bool small = total <= 0xffffffffL;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    auto gather = [&](long i) {
         int kc, ow, oh, img;
         if (small) {
             unsigned u = (unsigned)i;
@@ -1106,7 +1112,67 @@ __global__ __launch_bounds__(256) void im2col_first_kernel(const float* __restri
                 if (ih >= 0 && ih < h && iw >= 0 && iw < w) v[e] = x[((long)(img * h + ih) * w + iw) * cin + cch];
             }
         }
-        stq<H>(cols, i * 4, v);
+        return v;
+    };
+    const long step = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < total; i += 4 * step) {              // four quads' gathers in flight per thread
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gather(i + u * step);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stq<H>(cols, (i + u * step) * 4, v[u]);
+    }
+    for (; i < total; i += step) stq<H>(cols, i * 4, gather(i));
+}
+
+// the same columns from LDS: block = one output row (img, oh); its KS input rows (w * CIN floats each, contiguous) are copied in with
+// coalesced loads, and a thread that KEEPS its eight columns -- (r, s, channel) decoded once -- picks them out of LDS for every PX-th
+// pixel: one 16-byte store of bf16 columns per thread and pixel.  (The flat walk above gathers every column with its own 4-byte global
+// load behind ~40 instructions of index arithmetic: 81 us for the 7x7x3 stem at 128 images, neither its bytes nor its stores.)
+template <bool H, int KS, int CIN, int K4, int PX>
+__global__ __launch_bounds__(K4 / 2 * PX) void im2col_first_rows_kernel(const float* __restrict__ x, float* __restrict__ cols,
+                                                                        int h, int w, int stride, int ho, int wo, int pt, int pl) {
+    extern __shared__ float xs[];                                   // [KS][w * CIN]
+    constexpr int KREAL = KS * KS * CIN, K8 = K4 / 2, NT = K8 * PX;
+    const int row = blockIdx.x, img = row / ho, oh = row - img * ho;
+    const int wc = w * CIN;
+    for (int r = 0; r < KS; ++r) {
+        const int ih = oh * stride + r - pt;
+        const bool ok = ih >= 0 && ih < h;
+        const float* src = x + ((long)(img * h + (ok ? ih : 0)) * w) * CIN;
+        for (int t = threadIdx.x; t < wc; t += NT) xs[r * wc + t] = ok ? src[t] : 0.f;
+    }
+    __syncthreads();
+    const int ko = threadIdx.x % K8, p0 = threadIdx.x / K8;
+    int loff[8], sx[8];
+    bool kok[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = ko * 8 + e;
+        const int cch = k % CIN, rs = k / CIN, s_ = rs % KS, r = rs / KS;
+        kok[e] = k < KREAL;
+        loff[e] = (kok[e] ? r : 0) * wc + cch;
+        sx[e] = s_ - pl;
+    }
+    for (int ow = p0; ow < wo; ow += PX) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int iw = ow * stride + sx[e];
+            const bool ok = kok[e] && iw >= 0 && iw < w;
+            const float t = xs[loff[e] + (ok ? iw : 0) * CIN];
+            if (e < 4) v0[e] = ok ? t : 0.f; else v1[e - 4] = ok ? t : 0.f;
+        }
+        const long o = ((long)row * wo + ow) * (K4 * 4) + ko * 8;
+        if constexpr (H) {
+            typedef unsigned u32x4_i __attribute__((ext_vector_type(4)));
+            const u32x2_l a = __builtin_bit_cast(u32x2_l, __builtin_convertvector(v0, bf16x4_s)), b = __builtin_bit_cast(u32x2_l, __builtin_convertvector(v1, bf16x4_s));
+            *reinterpret_cast<u32x4_i*>(reinterpret_cast<unsigned short*>(cols) + o) = u32x4_i{a[0], a[1], b[0], b[1]};
+        } else {
+            stq<false>(cols, o, v0);
+            stq<false>(cols, o + 4, v1);
+        }
     }
 }
 
@@ -1352,6 +1418,12 @@ hipError_t l_scale_mask(const float* dy, const float* mask, float* dx, long n, f
 }
 hipError_t l_im2col_first(const float* x, float* cols, int n, int h, int w, int cin, int ks, int stride, int ho, int wo,
                           int pt, int pl, int kpad, hipStream_t st, int h16) {
+    static const bool rows_form = !(getenv("FTE_IM2COL_ROWS") && atoi(getenv("FTE_IM2COL_ROWS")) == 0);      // A/B hook
+    if (rows_form && ks == 7 && cin == 3 && kpad == 160 && w <= 1024 && (long)n * h * w * cin < (1L << 31) && (long)n * ho < (1L << 31)) {
+        if (h16) hipLaunchKernelGGL((im2col_first_rows_kernel<true, 7, 3, 40, 14>), dim3((unsigned)(n * ho)), dim3(280), (size_t)7 * w * 3 * sizeof(float), st, x, cols, h, w, stride, ho, wo, pt, pl);
+        else hipLaunchKernelGGL((im2col_first_rows_kernel<false, 7, 3, 40, 14>), dim3((unsigned)(n * ho)), dim3(280), (size_t)7 * w * 3 * sizeof(float), st, x, cols, h, w, stride, ho, wo, pt, pl);
+        return hipGetLastError();
+    }
     const dim3 grid(grid_for((long)n * ho * wo * (kpad / 4)));
 #define FTE_I2C(...) do { if (h16) hipLaunchKernelGGL((im2col_first_kernel<true, __VA_ARGS__>), grid, dim3(256), 0, st, x, cols, n, h, w, cin, ks, stride, ho, wo, pt, pl, kpad); \
                           else hipLaunchKernelGGL((im2col_first_kernel<false, __VA_ARGS__>), grid, dim3(256), 0, st, x, cols, n, h, w, cin, ks, stride, ho, wo, pt, pl, kpad); } while (0)
