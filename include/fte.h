@@ -455,6 +455,10 @@ size_t fte_conv3x3_first_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout,
 /* y[m,n] = x[m,k] @ w[k,n] (+ bias[n]) */
 int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y,
                 int m, int n, int k, void* ws, size_t ws_bytes, void* stream);
+/* the same followed by an activation in the same pass over y: act 0 none, 1 ReLU, 2 sigmoid (the squeeze-excitation gate's two dense
+ * layers, nets/shufflenet_v2.py:79-85; y = act(x @ w + bias)) */
+int fte_gemm_nn_act(const float* x, const float* w, const float* bias, float* y,
+                    int m, int n, int k, int act, void* ws, size_t ws_bytes, void* stream);
 /* dx[m,k] = dy[m,n] @ w[k,n]^T, with the same fused PReLU-gradient epilogue as
  * fte_conv3x3_dgrad (zprev has dx's shape; alpha_prev has `amod` entries and
  * column j uses alpha_prev[j % amod] -- the flattened H*W*C feature map that

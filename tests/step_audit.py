@@ -307,6 +307,16 @@ class Audit(object):
             ref = ref + _h(bias)
         self._ok('fte_gemm_nn', 'y', _h(y).reshape(m, n), ref)
 
+    def _chk_fte_gemm_nn_act(self, x, w, bias, y, m, n, k, act, ws, wsb, st):
+        ref = self._w(_h(x).reshape(m, k)) @ self._w(_h(w).reshape(k, n))
+        if bias is not None:
+            ref = ref + _h(bias)
+        if act == 1:
+            ref = np.maximum(ref, 0.0)
+        elif act == 2:
+            ref = 1.0 / (1.0 + np.exp(-ref))
+        self._ok('fte_gemm_nn_act', 'y', _h(y).reshape(m, n), ref)
+
     def _chk_fte_gemm_nt(self, dy, w, zprev, alpha, amod, raw, dx, dalpha, m, n, k, ws, wsb, st):
         assert zprev is None and raw is None
         ref = self._w(_h(dy).reshape(m, n)) @ self._w(_h(w).reshape(k, n)).T

@@ -108,6 +108,21 @@ def test_first_conv_fwd_and_wgrad(n, h, w, cin, cout, stride):
     check_maxabs(host(dw), dw_ref, what='dw')
 
 
+@pytest.mark.parametrize('m,n,k', [(128, 128, 256), (128, 1024, 2048), (7, 64, 96), (2048, 4096, 64)])
+def test_dense_with_activation(m, n, k):
+    """fte_gemm_nn_act: y = act(x @ w + bias) with the activation in the pass that writes y (the slab reduction of the split plan,
+    or a pass of its own behind an unsplit launch): the squeeze-excitation gate's two dense layers."""
+    r = _rng(9)
+    x = r.standard_normal((m, k)); w = r.standard_normal((k, n)) * 0.1; b = r.standard_normal(n)
+    wsb, nb = ws(query('fte_gemm_ws_bytes', m, n, k))
+    lin = x @ w + b
+    for act, ref in ((0, lin), (1, np.maximum(lin, 0.0)), (2, 1.0 / (1.0 + np.exp(-lin)))):
+        y = torch.full((m, n), 7.0, device='cuda')
+        call('fte_gemm_nn_act', dev(x), dev(w), dev(b), y, m, n, k, act, wsb, nb, stream())
+        check_maxabs(host(y), ref, what='act %d' % act)
+    assert query('fte_gemm_nn_act', dev(x).data_ptr(), dev(w).data_ptr(), 0, y.data_ptr(), m, n, k, 3, wsb.data_ptr(), nb, 0) != 0
+
+
 @pytest.mark.parametrize('m,n,k', [(4, 512, 2048), (64, 512, 25088), (3, 128, 512), (70, 10624, 512), (512, 512, 512)])
 def test_dense_nn_nt_tn(m, n, k):
     r = _rng(5)

@@ -115,6 +115,7 @@ _SIGS = {
     'fte_conv3x3_first_wgrad': (c_int, [_P] * 3 + [c_int] * 6 + [_P, c_size_t, _P]),
     'fte_conv3x3_first_wgrad_ws_bytes': (c_size_t, [c_int] * 6),
     'fte_gemm_nn': (c_int, [_P] * 4 + [c_int] * 3 + [_P, c_size_t, _P]),
+    'fte_gemm_nn_act': (c_int, [_P] * 4 + [c_int] * 4 + [_P, c_size_t, _P]),
     'fte_gemm_nt': (c_int, [_P] * 4 + [c_int] + [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     'fte_gemm_tn': (c_int, [_P] * 3 + [c_int] * 3 + [_P, c_size_t, _P]),
     'fte_gemm_ws_bytes': (c_size_t, [c_int] * 3),

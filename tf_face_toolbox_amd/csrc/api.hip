@@ -836,9 +836,9 @@ size_t fte_gemm_ws_bytes(int m, int n, int k) {
     return need;
 }
 
-int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y, int m, int n, int k,
-                void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !y || m <= 0 || n % 64 || k % 32) return FTE_EINVAL;
+static int gemm_nn_impl(const float* x, const float* w, const float* bias, float* y, int m, int n, int k, int act,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || m <= 0 || n % 64 || k % 32 || act < 0 || act > 2) return FTE_EINVAL;
     IgemmParams p;
     zero_params(&p);
     p.M = m; p.N = n; p.K = k;
@@ -855,10 +855,21 @@ int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y, int
         p.Y = (float*)ws;
         hipError_t e = igemm_launch(p, AL_MK, BL_KN, EPI_FWD, tile, splits, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
-        return rc(k_reduce_rows((const float*)ws, y, bias, n, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream));
+        // (the activation rides in the slab reduction's epilogue: no separate pass over y)
+        return rc(k_reduce_rows((const float*)ws, y, bias, n, splits, p.slab, 1, 1.f, nullptr, (hipStream_t)stream, act));
     }
     p.Y = y; p.bias = bias;
-    return rc(igemm_launch(p, AL_MK, BL_KN, EPI_FWD, tile, 1, (hipStream_t)stream));
+    hipError_t e = igemm_launch(p, AL_MK, BL_KN, EPI_FWD, tile, 1, (hipStream_t)stream);
+    if (e != hipSuccess || !act) return rc(e);
+    return rc(l_act_fwd(y, y, (long)m * n, act - 1, (hipStream_t)stream));
+}
+int fte_gemm_nn(const float* x, const float* w, const float* bias, float* y, int m, int n, int k,
+                void* ws, size_t ws_bytes, void* stream) {
+    return gemm_nn_impl(x, w, bias, y, m, n, k, 0, ws, ws_bytes, stream);
+}
+int fte_gemm_nn_act(const float* x, const float* w, const float* bias, float* y, int m, int n, int k, int act,
+                    void* ws, size_t ws_bytes, void* stream) {
+    return gemm_nn_impl(x, w, bias, y, m, n, k, act, ws, ws_bytes, stream);
 }
 
 int fte_gemm_nt(const float* dy, const float* w, const float* zprev, const float* alpha_prev, int amod,

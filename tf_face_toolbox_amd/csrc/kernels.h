@@ -11,10 +11,10 @@ hipError_t k_conv_first_wgrad(const float* x, const float* dz, const unsigned sh
                               int stride, int pt, int pl, int blocks, hipStream_t st);
 constexpr long REDUCE_SCRATCH_FLOATS = 1 << 18;      // 1 MiB of scratch for the tall-and-narrow case of k_reduce_rows
 hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale,
-                         float* scratch, hipStream_t st);
+                         float* scratch, hipStream_t st, int act = 0);
 // the same for two matrices of one shape in one launch (out2 may not alias out)
 hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* out2, const float* bias, int bmod, long rows, long cols,
-                          int fold, float scale, float* scratch, hipStream_t st);
+                          int fold, float scale, float* scratch, hipStream_t st, int act = 0);
 hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, bool sq, hipStream_t st);
 hipError_t k_softmax_ce(const float* logits, const int32_t* labels, float* loss_rows, float* dlogits, int n, int c, int ld, float gs, hipStream_t st);
 hipError_t k_to_bf16(const float* x, unsigned short* y, long n, hipStream_t st);

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           const float* __restrict__ bias, int bmod, long rows,
                                                           long cols, long rows_per_split, float scale,
-                                                          const float* __restrict__ in2, float* __restrict__ out2) {
+                                                          const float* __restrict__ in2, float* __restrict__ out2, int act) {
     __shared__ float sh[4][64];
     if (blockIdx.z == 1) { in = in2; out = out2; }
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     if (rl == 0 && j < cols) {
         float v = ((sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c])) * scale;
         if (bias) v += bias[j % bmod];
+        if (act == 1) v = fmaxf(v, 0.f);                         // (act_fwd_kernel's two activations, for fte_gemm_nn_act)
+        else if (act == 2) v = 1.f / (1.f + expf(-v));
         out[(long)blockIdx.y * cols + j] = v;
     }
 }
@@ -802,12 +804,12 @@ hipError_t k_conv_first_wgrad(const float* x, const float* dz, const unsigned sh
 }
 // scratch: REDUCE_SCRATCH_FLOATS floats, only touched when the matrix is tall and narrow
 hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* out2, const float* bias, int bmod, long rows, long cols,
-                          int fold, float scale, float* scratch, hipStream_t st) {
+                          int fold, float scale, float* scratch, hipStream_t st, int act) {
     // [rows, fold, cols/fold] is the same memory as [rows*fold, cols/fold]: folding is a reshape
     rows *= fold;
     cols /= fold;
     static const bool slabs_off = getenv("FTE_REDUCE_SLABS") && atoi(getenv("FTE_REDUCE_SLABS")) == 0;      // A/B hook
-    if (!slabs_off && !in2 && !bias && scale == 1.f && rows >= 2 && rows < (1 << 20) && cols >= 4096 && cols % 4 == 0 &&
+    if (!slabs_off && !act && !in2 && !bias && scale == 1.f && rows >= 2 && rows < (1 << 20) && cols >= 4096 && cols % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) {
         const long quads = cols / 4;
         if (quads / 64 >= 1024 || rows < 32)
@@ -820,7 +822,7 @@ hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* 
     }
     const unsigned nz = in2 ? 2 : 1;
     static const bool rq_off = getenv("FTE_REDUCE_ROWS_Q") && atoi(getenv("FTE_REDUCE_ROWS_Q")) == 0;      // A/B hook
-    if (!rq_off && scratch && !bias && scale == 1.f && rows >= 256 && cols % 4 == 0 && cols <= 1024 &&
+    if (!rq_off && !act && scratch && !bias && scale == 1.f && rows >= 256 && cols % 4 == 0 && cols <= 1024 &&
         (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in2) | reinterpret_cast<uintptr_t>(out2) |
          reinterpret_cast<uintptr_t>(scratch)) % 16 == 0) {
         const long quads = cols / 4;
@@ -860,22 +862,22 @@ hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* 
         if (rs < 1) rs = 1;
     }
     if (rs == 1) {
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1, nz), dim3(256), 0, st, in, out, bias, bmod, rows, cols, rows, scale, in2, out2);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1, nz), dim3(256), 0, st, in, out, bias, bmod, rows, cols, rows, scale, in2, out2, act);
         return hipGetLastError();
     }
     const long rps = (rows + rs - 1) / rs;
     rs = (rows + rps - 1) / rps;
     float* scratch2 = scratch + rs * cols;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, (unsigned)rs, nz), dim3(256), 0, st, in, scratch, (const float*)nullptr, 1, rows, cols, rps, 1.f,
-                       in2, scratch2);
+                       in2, scratch2, 0);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cb, 1, nz), dim3(256), 0, st, (const float*)scratch, out, bias, bmod, rs, cols, rs, scale,
-                       (const float*)scratch2, out2);
+                       (const float*)scratch2, out2, act);
     return hipGetLastError();
 }
 // scratch: REDUCE_SCRATCH_FLOATS floats, only touched when the matrix is tall and narrow
 hipError_t k_reduce_rows(const float* in, float* out, const float* bias, int bmod, long rows, long cols, int fold, float scale,
-                         float* scratch, hipStream_t st) {
-    return k_reduce_rows2(in, out, nullptr, nullptr, bias, bmod, rows, cols, fold, scale, scratch, st);
+                         float* scratch, hipStream_t st, int act) {
+    return k_reduce_rows2(in, out, nullptr, nullptr, bias, bmod, rows, cols, fold, scale, scratch, st, act);
 }
 hipError_t k_sum(const float* a, long n, float scale, float* out, float* ws, bool sq, hipStream_t st) {
     const int nb = grid_for(n, 256 * 4 * 8) > 1024 ? 1024 : grid_for(n, 256 * 4 * 8);

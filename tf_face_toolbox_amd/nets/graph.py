@@ -884,10 +884,15 @@ class GraphNet(Network):
                 ih, iw, c = self.shapes[inp]
                 sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
                 call('fte_gap_fwd_s16' if s16 else 'fte_gap_fwd', T[inp], sq, n, ih * iw, c, st)
-                call('fte_gemm_nn', sq, self.view(w1), self.view(b1), hid, n, hd, c, self.ws, self.ws_bytes, st)
-                call('fte_act_fwd', hid, hid, hid.numel(), 0, st)
-                call('fte_gemm_nn', hid, self.view(w2), self.view(b2), gate, n, c, hd, self.ws, self.ws_bytes, st)
-                call('fte_act_fwd', gate, gate, gate.numel(), 1, st)
+                if os.environ.get('FTE_SE_ACT_FUSE', '1') != '0':
+                    # the gate's two dense layers with their activation (ReLU, sigmoid) in the same pass over the output
+                    call('fte_gemm_nn_act', sq, self.view(w1), self.view(b1), hid, n, hd, c, 1, self.ws, self.ws_bytes, st)
+                    call('fte_gemm_nn_act', hid, self.view(w2), self.view(b2), gate, n, c, hd, 2, self.ws, self.ws_bytes, st)
+                else:                                          # (A/B hook: the activations as launches of their own)
+                    call('fte_gemm_nn', sq, self.view(w1), self.view(b1), hid, n, hd, c, self.ws, self.ws_bytes, st)
+                    call('fte_act_fwd', hid, hid, hid.numel(), 0, st)
+                    call('fte_gemm_nn', hid, self.view(w2), self.view(b2), gate, n, c, hd, self.ws, self.ws_bytes, st)
+                    call('fte_act_fwd', gate, gate, gate.numel(), 1, st)
                 call('fte_channel_scale_fwd_s16' if s16 else 'fte_channel_scale_fwd', T[inp], gate, T[out], n, ih * iw, c, st)
             elif kind == 'addrelu':
                 c = self.shapes[out][-1]
