@@ -28,6 +28,6 @@ for hw, cin, cout, stride, count in cases:
     t2 = T(lambda: _lib.call('fte_conv3x3_dgrad', dz, w, add, zp, alp, raw, dzp, da, db, B, hw, hw, cin, cout, stride, ws, wsb, st))
     t3 = T(lambda: _lib.call('fte_conv3x3_wgrad', x, dz, dw, B, hw, hw, cin, cout, stride, ws, wsb, st))
     tot['fwd'] += t1 * count; tot['dgrad'] += t2 * count; tot['wgrad'] += t3 * count
-    print('%3dx%-3d %3d->%-3d s%d x%d | fwd %.3f ms %5.1f TF | dgrad %.3f ms %5.1f TF | wgrad %.3f ms %5.1f TF' % (
+    print('%3dx%-3d %3d->%-3d s%d x%d | fwd %.4f ms %5.1f TF | dgrad %.4f ms %5.1f TF | wgrad %.4f ms %5.1f TF' % (
         hw, hw, cin, cout, stride, count, t1, fl / t1 / 1e9, t2, fl / t2 / 1e9, t3, fl / t3 / 1e9))
 print('per-step conv totals (ms):', {k: round(v, 2) for k, v in tot.items()}, 'sum %.2f' % sum(tot.values()))

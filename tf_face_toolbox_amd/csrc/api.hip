@@ -67,10 +67,14 @@ constexpr long SLOTS = 1536;
 //   mode 2 (needs workspace): the same big tiles with split-K, P = SLOTS / tiles splits, raw partial
 //          tiles to the workspace, then igemm_fixup sums them and applies the epilogue;
 //   mode 1 (no workspace / P < 2): 64x64 tiles (4x the blocks, 1/4 of the work each).
+//   mode 3 (needs workspace): STREAM-K -- one launch of resident workers that share the (tile, K-step) space equally (igemm.hip
+//          "stream-K"); main_tile / main_mtiles describe its tile grid (the partial rows of dalpha / dbias are per tile row as ever).
 struct RowPlan {
     int main_tile; long main_rows, main_mtiles;
     int tail_mode, tail_tile; long tail_mtiles; int tail_splits, tail_kchunk; size_t pw_bytes;
+    int sk_workers;
 };
+constexpr long NUM_CU = 256;
 // ... and a storage-only launch (bf16 tensors in the epilogue, no fp32 outputs): the persistent kernels of igemm16.hip take it
 thread_local bool g_plan_s16 = false;
 struct PlanS16 { bool prev; explicit PlanS16(bool on) : prev(g_plan_s16) { g_plan_s16 = on; } ~PlanS16() { g_plan_s16 = prev; } };
@@ -80,10 +84,51 @@ struct PlanS16 { bool prev; explicit PlanS16(bool on) : prev(g_plan_s16) { g_pla
 thread_local bool g_plan_bn = false;
 struct PlanBn { bool prev; PlanBn() : prev(g_plan_bn) { g_plan_bn = true; } ~PlanBn() { g_plan_bn = prev; } };
 
-inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only = false) {
+// Stream-K plan of an fp32 forward / data-gradient launch, or false.  The one-block-per-tile schedule finishes a launch of T tiles on
+// S = CUs x blocks-per-CU slots in ceil-ish rounds: what the chip loses is (rounds up - rounds) of the LAST round, which matters when
+// there are only one or two (the 64- and 128-image shards of SphereNet: 14x14x256 at 64 images is 1.53 tiles of 128x64 per CU).
+inline bool plan_sk(long M, long N, long K, int epi, RowPlan* out) {
+    static const int mode = getenv("FTE_SK") ? atoi(getenv("FTE_SK")) : 1;          // 0: off; 1: the rule below; 2: every eligible launch (tests, A/B)
+    static const int env_tile = getenv("FTE_SK_TILE") ? atoi(getenv("FTE_SK_TILE")) : -1;
+    static const int env_tile_d = getenv("FTE_SK_TILE_DGRAD") ? atoi(getenv("FTE_SK_TILE_DGRAD")) : env_tile;
+    if (!mode || K % 32 || N % 64) return false;
+    const long ksteps = K / 32;
+    // measured on MI355X (profiles/r5_notes.md): forward -- 64x64 tiles, six workers per CU; data gradient (more registers: the
+    // PReLU / partial-sum epilogue) -- 128x64 tiles, four per CU
+    const int want = epi == EPI_FWD ? env_tile : env_tile_d;
+    int tile = want >= 0 ? want : (epi == EPI_FWD ? TILE_64x64 : TILE_128x64);
+    if (tile == TILE_128x128 && N % 128) tile = TILE_128x64;
+    const int bpc = igemm_sk_blocks_per_cu(tile, epi);
+    if (bpc <= 0) return false;
+    int bm, bn;
+    igemm_tile_dims(tile, &bm, &bn);
+    const long MT = (M + bm - 1) / bm, T = MT * (N / bn), iters = T * ksteps;
+    long W = NUM_CU * bpc;
+    if (iters >= (1L << 31)) return false;
+    if (mode == 1) {
+        // The rule, in units of 128x64 tiles per CU (the one-block-per-tile plans' tile at these sizes): stream-K wins up to ~3 tiles
+        // per CU (14x14x256 at 64 images, 1.53 per CU: forward 152 -> 127 us, data gradient 160 -> 138; at 128 images, 3.06: 248 ->
+        // 228 / 255 -> 245), is even at ~6 (28x28x128 at 128 images) and loses at 12 (56x56x64: 304 -> 321); and every worker should
+        // have a few K-steps of its own.
+        const double per_cu = (double)(((M + 127) / 128) * (N / 64)) / NUM_CU;
+        static const double max_per_cu = getenv("FTE_SK_MAX_PER_CU") ? atof(getenv("FTE_SK_MAX_PER_CU")) : 4.0;
+        static const long min_steps = getenv("FTE_SK_MIN_STEPS") ? atol(getenv("FTE_SK_MIN_STEPS")) : 12;      // K-steps per worker
+        if (per_cu > max_per_cu) return false;
+        if (iters / W < min_steps) return false;
+    }
+    if (W > iters) W = iters;
+    memset(out, 0, sizeof(*out));
+    out->main_tile = tile; out->main_rows = M; out->main_mtiles = MT;
+    out->tail_mode = 3; out->sk_workers = (int)W;
+    out->pw_bytes = igemm_sk_ws_bytes(tile, (int)W);
+    return true;
+}
+
+inline RowPlan plan_rows(long M, long N, long K, bool allow_pw, bool small_only = false, int epi = -1) {
     RowPlan r;
     memset(&r, 0, sizeof(r));
     if (g_plan_bn) allow_pw = false;
+    if (epi >= 0 && allow_pw && !small_only && !plan_bf16() && plan_sk(M, N, K, epi, &r)) return r;
     static const int narrow_tile = getenv("FTE_NARROW_TILE") ? atoi(getenv("FTE_NARROW_TILE")) : TILE_64x64;   // N = 64: measured on MI355X
     // 64x64 beats 128x64 beats 256x64 (fwd 83 / 82 / 75 TF, dgrad 80 / 76 / 65): with only 18 K-steps per tile the
     // layer lives on co-resident blocks hiding each other's prologue / epilogue, not on operand reuse.
@@ -234,6 +279,15 @@ inline bool set_bytes(IgemmParams* p, size_t a_elems, size_t b_elems, size_t esi
 inline hipError_t launch_rows(IgemmParams p, const RowPlan& rp, int al, int bl, int epi, long prow0, float* pw, hipStream_t st) {
     const int M = p.M;
     hipError_t e = hipSuccess;
+    if (rp.tail_mode == 3) {                      // stream-K: slabs first, the flag words behind them
+        int bm, bn;
+        igemm_tile_dims(rp.main_tile, &bm, &bn);
+        const long T = rp.main_mtiles * (p.N / bn), iters = T * (p.K / 32);
+        p.m_base = 0; p.prow0 = (int)prow0;
+        p.sk_workers = rp.sk_workers; p.sk_base = (int)(iters / rp.sk_workers); p.sk_rem = (int)(iters % rp.sk_workers);
+        p.SKW = pw; p.SKF = reinterpret_cast<unsigned*>(pw + (size_t)rp.sk_workers * bm * bn);
+        return igemm_launch(p, al, bl, epi, rp.main_tile, 1, st);
+    }
     if (rp.main_rows > 0) {
         p.m_base = 0; p.M = (int)rp.main_rows; p.prow0 = (int)prow0;
         e = igemm_launch(p, al, bl, epi, rp.main_tile, 1, st);
@@ -312,7 +366,7 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms) {
 size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     if (n <= 0 || cin <= 0 || cin % 32 || cout <= 0 || cout % 64) return 0;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
-    return both_modes([&] { return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true).pw_bytes; });
+    return both_modes([&] { return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true, false, EPI_FWD).pw_bytes; });
 }
 
 // x / w are bf16 copies (x16 [n,h,wd,cin]; w16t [k*k][cout][cin], fte_pack_weights_bf16) when `src16`
@@ -343,8 +397,8 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
         p.b_ld = cout;
     }
     if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
-    RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr);
-    if (rp.tail_mode == 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
+    RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr, false, EPI_FWD);
+    if (rp.tail_mode >= 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
     if (stat_part) {                                 // "BN fusion": one statistics partial row per tile row of the launch(es)
         if (rp.tail_mode == 2) return FTE_EINVAL;    // (plan_rows never splits under PlanBn)
         p.SP = stat_part;
@@ -410,7 +464,7 @@ int dgrad_classes(int n, int h, int wd, int cin, int cout, int ksize, int stride
             const long M = (long)n * c.hq * c.wq;
             // FTE_DGRAD_CLS_BIG=1 (A/B hook): let the bf16 plans give the parity classes the 128-row tiles of the LDS-DMA kernels
             static const bool cls_big = getenv("FTE_DGRAD_CLS_BIG") && atoi(getenv("FTE_DGRAD_CLS_BIG")) == 1;
-            c.rp = plan_rows(M, cin, (long)c.ntap * cout, true, stride != 1 && !cls_big);
+            c.rp = plan_rows(M, cin, (long)c.ntap * cout, true, stride != 1 && !cls_big, EPI_DGRAD);
             c.mtiles = c.rp.main_mtiles + c.rp.tail_mtiles;
             ++nc;
         }

@@ -45,7 +45,7 @@ struct IgemmParams {
     const float* ADD; float* RAW; const float* Zin; float* DZ; float* PA; float* PB;
     int amod, prow0;
     // EPI_DGRAD, stride 2: ncls > 1 merges the output-parity classes into one launch (see igemm_kernel)
-    int ncls, cls_tiles, cls_mtiles;
+    int ncls, cls_tiles, cls_mtiles, cls_rot;      // cls_rot: set by the launcher (class rotation, see the kernel)
     int cls_tap0[5], cls_ph[4], cls_pw[4];
     // bf16 operand copies: src16 != 0 -> A and B point at bf16 data (a_bytes / b_bytes count 2-byte elements' bytes) and the
     // BF = 2 kernels run; Y16 / DZ16 != NULL -> the epilogue also writes a bf16 copy of Y / DZ for the next consumer
@@ -67,6 +67,14 @@ struct IgemmParams {
     //               neither: no mask, zb = Zin (BN without activation)
     const float* bn_mu; const float* bn_rs; const float* bn_sc; const float* bn_sh;
     const float* Zx; const unsigned short* Zx16;
+    // ---- stream-K (igemm_sk_kernel, fp32 forward / data gradient; see igemm.hip "stream-K") -------------------------------------
+    // sk_workers > 0: the launch is ONE grid of sk_workers resident blocks; worker w takes iterations [w*sk_base + min(w, sk_rem), ...)
+    // of the linear (tile, K-step) space, sk_base (+1 for the first sk_rem workers) each.  A worker that starts inside a tile leaves its
+    // raw accumulators in slab w of SKW (BM*BN floats each) and raises SKF[w]; the worker that holds K-step 0 of the tile adds the
+    // slabs of its successors in worker order and runs the fused epilogue.  SKF: the caller passes sk_workers words behind the slabs; the
+    // launcher normally replaces them by the library's per-stream words (igemm.hip sk_flags) and zeroes the caller's only as a fallback.
+    int sk_workers, sk_base, sk_rem, sk_epoch;      // sk_epoch: the value a raised flag word holds (set by the launcher)
+    float* SKW; unsigned* SKF;
     int ptiles;           // igemm16p_kernel (persistent blocks): tiles of the launch; set by its launcher
     int ptiles_dbg;       // diagnostic switches of that kernel (FTE_IGEMM16_DBG; 0 in production)
 };
@@ -78,6 +86,10 @@ constexpr int FIXUP_CHUNKS = 4;
 // sums `splits` partial tiles written through PW and applies the EPI_FWD / EPI_DGRAD epilogue of the same params
 hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipStream_t st);
 void igemm_tile_dims(int tile, int* bm, int* bn);
+// stream-K: resident blocks per CU the planner assumes for a tile shape (0: no stream-K instantiation of that shape), and the
+// workspace (slabs + flag words) a launch of `workers` blocks needs
+int igemm_sk_blocks_per_cu(int tile, int epi);
+size_t igemm_sk_ws_bytes(int tile, int workers);
 
 // igemm16.hip: the bf16 LDS-DMA kernel (k-contiguous bf16 A and B: conv forward / dgrad on the bf16 operand copies).  igemm_launch
 // routes a launch there when igemm16_handles() says so; everything else runs on igemm.hip's kernels.

@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -92,8 +93,9 @@ using namespace igemm_dev;
 // into LDS and multiplied by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): storage stays fp32 in HBM, the kernel
 // turns from MFMA-bound into staging / HBM-bound.  See the BF branch of the main loop.
 // (the body is shared by two kernel symbols: igemm_kernel, and igemm_bn_kernel = the same with the BN-fusion epilogue compiled in)
-template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF, bool BNM>
-__device__ __forceinline__ void igemm_body(const IgemmParams& p) {
+// SK (stream-K, see below the kernels): the body computes K-steps [sk_k0, sk_k1) of tile sk_tile for worker sk_worker
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF, bool BNM, bool SK = false>
+__device__ __forceinline__ void igemm_body(const IgemmParams& p, int sk_tile = 0, int sk_k0 = 0, int sk_k1 = 0, int sk_worker = 0) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     // NTH threads = WM x WN waves.  4 waves is the general case; 1 or 2 waves per block (fp32, k-contiguous A only) trade
     // operand reuse across waves for fewer waves coupled by each barrier: with ONE wave per block there is no barrier at all
@@ -108,7 +110,12 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p) {
     const unsigned long long st_entry = g_stamp_buf ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
 
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    // stream-K: the body sits in a loop over the worker's parts.  Everything derived from the thread id is loop-invariant there and
+    // the compiler would keep it all in registers across the parts (+30 VGPRs: 6 -> 4 blocks per CU on the 64x64 tile); an opaque
+    // copy of the id per part makes it recompute them (a few dozen instructions per part).
+    if constexpr (SK) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, lh = lane >> 5;
@@ -122,7 +129,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p) {
     // ---- tile coordinates: XCD-aware bijective remap, n-tiles fastest --------
     const int ntn = p.N / BN;
     int bid = blockIdx.x, split = blockIdx.y;
-    if (p.split_major > 0) {
+    if constexpr (SK) {
+        bid = sk_tile; split = 0;             // tiles in natural order (n-tiles fastest); the WORKER ids carry the XCD remap
+    } else if (p.split_major > 0) {
         // Split-K filter gradients: every tile of one K range (pixel range) reads the SAME x and dz rows.  Blocks are dealt
         // round-robin over the 8 XCDs, each with its own L2: ids are laid out in groups of 8 splits x all tiles, the split
         // fastest, so that the tiles of one split are 8 ids apart -- same XCD, dispatched together -- and x / dz leave HBM
@@ -146,8 +155,12 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p) {
             // class = fastest index of the remapped id: the XCD remap hands each XCD a CONTIGUOUS range of ids, so
             // "class c owns ids [c*T, (c+1)*T)" put the whole 4-tap class on two XCDs and the 1-tap class on two others
             // (merged launch 25 % slower than four separate ones); interleaved, every XCD gets 1/8 of every class
-            const int cls = bid % p.ncls;
-            bid /= p.ncls;
+            // ... and ROTATED by the group index: blocks go to an XCD's 32 CUs round-robin, so with class = id % 4 alone a CU received
+            // tiles of ONE class only (the CUs of the 4-tap class 4x the K-steps of the 1-tap class's: 28x28x128 <- 256 at 64 images ran
+            // 127 us for 46 us of MFMA work); rotating the class by (group / 8) deals every CU the classes in turn
+            const int grp = bid / p.ncls;
+            const int cls = (bid - grp * p.ncls + ((grp >> p.cls_rot) & 3)) % p.ncls;
+            bid = grp;
             tap0 = p.cls_tap0[cls];
             NT = p.cls_tap0[cls + 1] - tap0;
             Kc = NT * p.a_KC;
@@ -157,8 +170,8 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p) {
     }
     const int mt = bid / ntn, nt_ = bid - mt * ntn;
     const int m0 = p.m_base + mt * BM, n0 = nt_ * BN;
-    const int kbeg = split * p.kchunk;
-    const int kend = min(Kc, kbeg + p.kchunk);
+    const int kbeg = SK ? sk_k0 * BK : split * p.kchunk;
+    const int kend = SK ? sk_k1 * BK : min(Kc, kbeg + p.kchunk);
     const int nsteps = (kend - kbeg + BK - 1) / BK;
     // index decompositions use fdiv(): every decomposed index (GEMM row m < M, pixel < K) is below 2^24 for the tensors
     // the 2-GiB buffer range admits with >= 32 channels; the launcher checks it (igemm_launch)
@@ -923,7 +936,62 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p) {
     }
 
     if (FTE_PRIO_EPILOGUE && BF == 0) __builtin_amdgcn_s_setprio(FTE_PRIO_EPILOGUE);      // drain quickly, free the slot
-    igemm_epilogue<BM, BN, WM, WN, EPI, BF == 2, BNM>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow);
+    if constexpr (SK) {
+        // ---- stream-K hand-over (MI355X guide, "inter-workgroup communication": write-through payload + drained flag) ----------
+        // slab layout [TM*TN*4 quads][NTH lanes] of 16 bytes: every store / load instruction of a wave covers 1 KiB contiguous
+        constexpr int NQ = TM * TN * 4;
+        constexpr unsigned SLAB_BYTES = (unsigned)NQ * NTH * 16u;
+        if (sk_k0 > 0) {
+            // PRODUCER: this worker started inside the tile.  Raw accumulators -> its slab with sc1 (write-through) stores, every wave
+            // drains its stores, the workgroup meets, ONE lane raises the flag with an agent-scope store.
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.SKW + (size_t)sk_worker * (BM * BN), 0, SLAB_BYTES, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (unsigned)((((i * TN + j) * 4 + q) * NTH + tid) * 16), 0, 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.SKF + sk_worker, (unsigned)p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (FTE_PRIO_EPILOGUE) __builtin_amdgcn_s_setprio(0);
+            return;
+        }
+        const int ksteps = Kc / BK;
+        if (sk_k1 < ksteps) {
+            // FINISHER: holds K-steps [0, sk_k1) of the tile; the following workers hold the rest, in worker order (each published its
+            // part as the FIRST thing it did).  One lane polls the flag (relaxed, agent scope), the workgroup meets, then every lane
+            // reads its quads with sc1 loads (they bypass this CU's L1; the slab was stored write-through) and adds them IN WORKER
+            // ORDER: the sum does not depend on timing or placement.
+            const int tile_end = (bid + 1) * ksteps;
+            for (int w2 = sk_worker + 1; w2 < p.sk_workers; ++w2) {
+                const int it0 = w2 * p.sk_base + min(w2, p.sk_rem);
+                if (it0 >= tile_end) break;
+                if (tid == 0) {
+                    while (__hip_atomic_load(p.SKF + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.sk_epoch) __builtin_amdgcn_s_sleep(1);
+                }
+                __syncthreads();
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.SKW + (size_t)w2 * (BM * BN), 0, SLAB_BYTES, 0x00020000);
+                constexpr int QC = NQ < 8 ? NQ : 8;        // quads in flight per lane
+#pragma unroll
+                for (int q0 = 0; q0 < NQ; q0 += QC) {
+                    f32x4 part[QC];
+#pragma unroll
+                    for (int q = 0; q < QC; ++q)
+                        part[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(((q0 + q) * NTH + tid) * 16), 0, 16));
+#pragma unroll
+                    for (int q = 0; q < QC; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[(q0 + q) / 4 / TN][((q0 + q) / 4) % TN][4 * ((q0 + q) & 3) + e] += part[q][e];
+                }
+            }
+        }
+    }
+    igemm_epilogue<BM, BN, WM, WN, EPI, BF == 2, BNM>(p, acc, smem, bid, split, m0, n0, mt, c_ph, c_pw, prow, SK ? tid : -1);
+    if constexpr (SK) { if (FTE_PRIO_EPILOGUE) __builtin_amdgcn_s_setprio(0); }
 #ifdef FTE_STAMP
     if constexpr (BF == 0) {
         __syncthreads();
@@ -945,6 +1013,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && B
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN < 4) ? 2 : ((FTE_SINGLE && BM <= 192) ? 3 : 2)) void igemm_bn_kernel(const IgemmParams p) {
     igemm_body<BM, BN, WM, WN, AL, BL, EPI, BF, true>(p);
+}
+
+// ---- stream-K -----------------------------------------------------------------------------------------------------------------
+// A launch whose tiles make 1-2.5 rounds of the chip quantises: 392 tiles of 128x64 on 256 CUs run for two tiles' time and do 1.53
+// tiles' work per CU (the 14x14 layers of SphereNet at a 64-image shard: 77 %).  Here the launch is ONE grid of resident workers
+// (p.sk_workers = CUs x blocks per CU) and the linear space of (tile, K-step) iterations is dealt out in equal contiguous shares.  A
+// share that starts inside a tile leaves a raw partial tile (producer), the share that holds the tile's first K-step collects the
+// partials and runs the fused epilogue (finisher): a producer part is always the FIRST thing its worker does and a finisher part the
+// LAST, so a finisher never waits for work that has not started, whatever the dispatch order.  The partials are added in worker order:
+// results are bit-identical run to run (they differ from the one-block-per-tile schedule by the summation order of the split tiles only).
+// Worker ids are the XCD-aware remap of the block id: consecutive workers -- consecutive tiles, the same A rows -- share an XCD.
+// blocks per CU the stream-K symbols are compiled for (= igemm_sk_blocks_per_cu(): the planner's worker count per CU)
+#define SK_MINB(BM, BN, EPI) ((BM) * (BN) <= 64 * 64 ? ((EPI) == EPI_FWD ? 6 : 5) : ((BM) * (BN) <= 128 * 64 ? 4 : 3))
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, bool BNM>
+__device__ __forceinline__ void igemm_sk_body(const IgemmParams& p) {
+    const int W = gridDim.x;
+    const int q = W >> 3, r = W & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int ksteps = p.K / BK;
+    const int it0 = w * p.sk_base + min(w, p.sk_rem);
+    const int it1 = it0 + p.sk_base + (w < p.sk_rem ? 1 : 0);
+    for (int it = it0; it < it1;) {
+        const int tile = it / ksteps, k0 = it - tile * ksteps;
+        const int k1 = min(ksteps, k0 + (it1 - it));
+        if (it != it0) __syncthreads();            // the previous part's epilogue is done with the LDS
+        igemm_body<BM, BN, WM, WN, AL, BL, EPI, 0, BNM, true>(p, tile, k0, k1, w);
+        it += k1 - k0;
+    }
+}
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
+__global__ __launch_bounds__(256, SK_MINB(BM, BN, EPI)) void igemm_sk_kernel(const IgemmParams p) {
+    igemm_sk_body<BM, BN, WM, WN, AL, BL, EPI, false>(p);
+}
+template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI>
+__global__ __launch_bounds__(256, SK_MINB(BM, BN, EPI)) void igemm_bn_sk_kernel(const IgemmParams p) {
+    igemm_sk_body<BM, BN, WM, WN, AL, BL, EPI, true>(p);
 }
 
 // ---- fix-up: sum the split-K partial tiles of one output tile and apply the fused epilogue -------------
@@ -1086,6 +1190,39 @@ hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st
     return hipGetLastError();
 }
 
+// Flag words of the stream-K hand-over.  A launch needs its workers' words to differ from its epoch when it starts; zeroing words in the
+// caller's workspace is a fill kernel of ~6 us in front of EVERY stream-K launch (measured: 31 per SphereNet step at 64 images).
+// Instead the library owns one row of words per STREAM (launches of one stream never overlap, so a row has one user at a time) and
+// tags them with a per-row launch counter: a word equals the current epoch only after this launch's producer has stored it.  Rows are
+// handed out to stream handles first come, first served; a 17th concurrent stream falls back to words in the workspace + a memset.
+constexpr int SK_ROWS = 16, SK_ROW_WORDS = 2048;
+__device__ unsigned g_sk_words[SK_ROWS][SK_ROW_WORDS];
+struct SkRow { hipStream_t st; unsigned epoch; bool used; };
+SkRow g_sk_rows[SK_ROWS];
+std::mutex g_sk_mu;
+unsigned* g_sk_base = nullptr;
+hipError_t sk_flags(IgemmParams* q, hipStream_t st) {
+    static const bool force_ws = getenv("FTE_SK_WS_FLAGS") != nullptr;      // A/B hook: the memset form
+    if (!force_ws && q->sk_workers <= SK_ROW_WORDS) {
+        std::lock_guard<std::mutex> lock(g_sk_mu);
+        if (!g_sk_base) {
+            hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&g_sk_base), HIP_SYMBOL(g_sk_words));
+            if (e != hipSuccess) return e;
+        }
+        int row = -1;
+        for (int i = 0; i < SK_ROWS; ++i) if (g_sk_rows[i].used && g_sk_rows[i].st == st) { row = i; break; }
+        if (row < 0) for (int i = 0; i < SK_ROWS; ++i) if (!g_sk_rows[i].used) { row = i; g_sk_rows[i].used = true; g_sk_rows[i].st = st; g_sk_rows[i].epoch = 0; break; }
+        if (row >= 0) {
+            if (++g_sk_rows[row].epoch == 0u) g_sk_rows[row].epoch = 1u;      // 0 is the value the words are loaded with
+            q->SKF = g_sk_base + (size_t)row * SK_ROW_WORDS;
+            q->sk_epoch = (int)g_sk_rows[row].epoch;
+            return hipSuccess;
+        }
+    }
+    q->sk_epoch = 1;
+    return hipMemsetAsync(q->SKF, 0, ((size_t)q->sk_workers * 4 + 15) & ~(size_t)15, st);
+}
+
 template <int BM, int BN, int WM, int WN, int AL, int BL, int EPI, int BF>
 hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     const int mt = (p.M - p.m_base + BM - 1) / BM, nt = p.N / BN;
@@ -1103,6 +1240,35 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     constexpr bool BN_OK = AL == AL_MK && WM * WN == 4;
     const bool bnm = p.SP != nullptr || p.bn_mu != nullptr;
     if (bnm && !BN_OK) return hipErrorInvalidValue;
+    if (p.sk_workers > 0) {
+        // stream-K: fp32, k-contiguous A, four waves, the three square-ish tiles
+        if constexpr (AL == AL_MK && BF == 0 && WM * WN == 4 && BM <= 128) {
+            if (p.ncls > 1 || p.split_major > 0 || splits != 1 || p.PW || !p.SKW || !p.SKF || p.m_base != 0) return hipErrorInvalidValue;
+            auto sk = igemm_sk_kernel<BM, BN, WM, WN, AL, BL, EPI>;
+            if (bnm) sk = igemm_bn_sk_kernel<BM, BN, WM, WN, AL, BL, EPI>;
+            if (igemm_prof_on()) { const int ta[7] = {BM, BN, WM, WN, AL, BL, EPI}; igemm_note_symbol(bnm ? "igemm_bn_sk_kernel" : "igemm_sk_kernel", ta, 7); }
+            static bool sk_attr[2] = {false, false};
+            if (!sk_attr[bnm]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 65536));
+                if (e != hipSuccess) return e;
+                sk_attr[bnm] = true;
+            }
+            static const bool sk_dbg = getenv("FTE_SK_DEBUG") != nullptr;
+            if (sk_dbg) {
+                int nb = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(sk), 256, lds_x);
+                fprintf(stderr, "[sk] %dx%d epi %d bn %d: workers %d (base %d rem %d), M %d N %d K %d, occupancy %d blocks/CU, lds %zu\n", BM, BN, EPI, (int)bnm,
+                        p.sk_workers, p.sk_base, p.sk_rem, p.M, p.N, p.K, nb, lds_x);
+            }
+            IgemmParams q = p;
+            hipError_t e = sk_flags(&q, st);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(sk, dim3(q.sk_workers), dim3(256), lds_x, st, q);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     auto kern = igemm_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>;
     if constexpr (BN_OK) { if (bnm) kern = igemm_bn_kernel<BM, BN, WM, WN, AL, BL, EPI, BF>; }
     if (igemm_prof_on()) { const int ta[8] = {BM, BN, WM, WN, AL, BL, EPI, BF}; igemm_note_symbol(bnm ? "igemm_bn_kernel" : "igemm_kernel", ta, 8); }
@@ -1116,6 +1282,8 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
     if (p.ncls > 1) {                       // merged parity classes: every class has the same M x N tile grid
         IgemmParams q = p;
         q.cls_tiles = mt * nt; q.cls_mtiles = mt;
+        static const int cls_rot = getenv("FTE_CLS_ROT") ? atoi(getenv("FTE_CLS_ROT")) : 3;      // tuning hook: 31 = no rotation
+        q.cls_rot = cls_rot;
         hipLaunchKernelGGL(kern, dim3(mt * nt * p.ncls, 1), dim3(64 * WM * WN), lds_x, st, q);
     } else if (p.split_major > 0) hipLaunchKernelGGL(kern, dim3(mt * nt * splits), dim3(64 * WM * WN), lds_x, st, p);
     else hipLaunchKernelGGL(kern, dim3(mt * nt, splits), dim3(64 * WM * WN), lds_x, st, p);
@@ -1301,6 +1469,24 @@ hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms) {
     for (int k = 0; k < 5; ++k) sig[k] = r.sig[k];
     *flops = r.flops;
     return hipEventElapsedTime(ms, r.e0, r.e1);
+}
+
+int igemm_sk_blocks_per_cu(int tile, int epi) {
+    // co-resident blocks per CU the stream-K symbols are compiled for (SK_MINB; FTE_SK_DEBUG=1 prints what the runtime reports)
+    static const int env = getenv("FTE_SK_BPC") ? atoi(getenv("FTE_SK_BPC")) : 0;      // tuning hook: fewer workers per CU
+    int v = 0;
+    switch (tile) {
+        case TILE_64x64:   v = SK_MINB(64, 64, epi); break;
+        case TILE_128x64:  v = SK_MINB(128, 64, epi); break;
+        case TILE_128x128: v = SK_MINB(128, 128, epi); break;
+        default: return 0;
+    }
+    return env > 0 && env < v ? env : v;
+}
+size_t igemm_sk_ws_bytes(int tile, int workers) {
+    int bm, bn;
+    igemm_tile_dims(tile, &bm, &bn);
+    return (size_t)workers * bm * bn * sizeof(float) + (((size_t)workers * 4 + 255) & ~(size_t)255);
 }
 
 void igemm_tile_dims(int tile, int* bm, int* bn) {

@@ -76,9 +76,9 @@ __device__ __forceinline__ float prelu_slope(float z, float a) {
 // backward pass as column partials (bn_mu).  Separate instantiations: the kernels of the BN-free nets compile to the code they had.
 template <int BM, int BN, int WM, int WN, int EPI, bool CAP16 = false, bool BNM = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* smem,
-                                               int bid, int split, int m0, int n0, int mt, int c_ph, int c_pw, int prow) {
+                                               int bid, int split, int m0, int n0, int mt, int c_ph, int c_pw, int prow, int tid_in = -1) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32, NTH = 64 * WM * WN;
-    const int tid = threadIdx.x;
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;      // (the stream-K loop passes its opaque copy of the id: igemm.hip)
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 31, lh = lane >> 5;
