@@ -68,6 +68,22 @@ def kernel_src_sha():
     return h.hexdigest()[:16]
 
 
+def library_src_sha():
+    """The hash the LOADED libfte.so was built from (csrc/build.sh stamps it into fte_version())."""
+    from tf_face_toolbox_amd import _lib
+    return _lib.source_stamp()
+
+
+def check_library_stamp():
+    """A stale libfte.so must not report numbers under the current sources' name: refuse to run (FTE_BENCH_ALLOW_STALE=1 overrides,
+    for A/B variants loaded through FTE_LIB)."""
+    lib, src = library_src_sha(), kernel_src_sha()
+    if lib != src and os.environ.get('FTE_BENCH_ALLOW_STALE') != '1' and not os.environ.get('FTE_LIB'):
+        raise SystemExit('bench.py: libfte.so was built from other kernel sources (library src:%s, csrc/ is %s): run '
+                         'tf_face_toolbox_amd/csrc/build.sh (python -c "import __graft_entry__ as g; g.build()")' % (lib or 'unstamped', src))
+    return lib
+
+
 def cpu_model():
     try:
         for line in open('/proc/cpuinfo'):
@@ -260,6 +276,7 @@ def main():
     g = torch.Generator().manual_seed(1)
     labels = torch.randint(0, NUM_CLASSES, (gb,), generator=g, dtype=torch.int32)[rank * shard:(rank + 1) * shard].to(dev)
     from tf_face_toolbox_amd import _lib
+    check_library_stamp()                         # libfte.so is the build of THESE sources, or no numbers
     _lib.set_mfma_dtype(args.mfma_dtype)          # before the wrapper's construction pass: every launch of this process runs in this mode
     net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
     net.seed = 2
@@ -396,9 +413,9 @@ def main():
         if world == 1 and tpath and gb == GLOBAL_BATCH:
             tinfo = json.load(open(tpath))
             ent = (tinfo.get('symbols') or {}).get(DOM)
-            if tinfo.get('kernel_src_sha') != kernel_src_sha():
-                tnote = 'profiles/%s was measured on other kernel sources (%s != %s): traffic nulled' % (
-                    os.path.basename(tpath), tinfo.get('kernel_src_sha'), kernel_src_sha())
+            if tinfo.get('kernel_src_sha') != library_src_sha():
+                tnote = 'profiles/%s was measured on other kernel sources (%s != library %s): traffic nulled' % (
+                    os.path.basename(tpath), tinfo.get('kernel_src_sha'), library_src_sha())
             elif ent and tinfo.get('mfma_dtype', 'f32') == args.mfma_dtype:
                 traffic = ent['hbm_bytes_per_launch']
                 tsrc = 'profiles/' + os.path.basename(tpath)
@@ -446,7 +463,7 @@ def main():
                                                              'algorithmic_bytes_per_launch': round(v[3] / v[0])}
                                         for k, v in sorted(table.items(), key=lambda kv: -kv[1][2])},
                          'per_shape': per_shape},
-            'kernel_src_sha': kernel_src_sha(),
+            'kernel_src_sha': library_src_sha(),          # the LIBRARY's stamp (= the sources': check_library_stamp())
         }
         if allreduce is not None:
             out['allreduce'] = allreduce

@@ -526,8 +526,9 @@ int fte_center_scatter_update(const float* diff, const int32_t* labels, float* c
                               float alpha, void* stream);
 
 /* batch-hard triplet (loss.py:47-78): per-sample loss [n] and d(sum w_i*loss_i)/dfeat.
- * margin < 0 selects softplus (margin=None in the reference).  ws >= 3*n*n floats. */
-int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, float margin,
+ * soft_margin != 0 selects softplus(pos - neg) (margin=None in the reference, loss.py:74-75) and `margin` is ignored; otherwise
+ * max(0, pos - neg + margin) for ANY margin, negative ones included (loss.py:76-77).  ws >= 3*n*n floats. */
+int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, float margin, int soft_margin,
                                    float loss_weight, float* loss_rows, float* dfeat,
                                    int n, int d, void* ws, size_t ws_bytes, void* stream);
 

@@ -40,3 +40,14 @@ def test_kernel_source_stamp_is_stable_and_traffic_file_is_found():
     assert a == b and len(a) == 16
     p = bench.latest_traffic_file()
     assert p is None or os.path.basename(p).endswith('_traffic.json')
+
+
+def test_library_carries_the_hash_of_the_kernel_sources():
+    """csrc/build.sh stamps libfte.so with the hash of csrc/*.hip, *.h; bench.py prints the LIBRARY's stamp as kernel_src_sha and
+    refuses to run when it differs from the sources' (the tie between binary and sources was mtime only)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tf_face_toolbox_amd import _lib
+    assert _lib.version().endswith('src:' + bench.kernel_src_sha()), (_lib.version(), bench.kernel_src_sha())
+    assert bench.library_src_sha() == bench.kernel_src_sha()
+    assert bench.check_library_stamp() == bench.kernel_src_sha()

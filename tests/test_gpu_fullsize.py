@@ -3,7 +3,12 @@ size-independent properties -- the float64 oracle needs minutes per image batch 
   * batch independence (no BN in SphereNet): the embeddings of images 0..3 inside the 512-batch equal those of the same
     images run alone, and THOSE are compared with the oracle;
   * tower-split additivity (data_parallel.py:37,179): gradient(512) == gradient(first 256) + gradient(last 256) with the
-    1/2 pre-scale -- the identity the multi-GPU path rests on, here across different tile plans / split-K factors;
+    1/2 pre-scale -- the identity the multi-GPU path rests on, here across different tile plans / split-K factors.  Round 5: the
+    256-image shard's 7x7 layers run on the stream-K schedule (csrc/igemm.hip), whose partial tiles change the ORDER of a K sum: z
+    differs in its last bits from the 512-image run, a handful of the 10^8 pre-activations change sign and with it their PReLU slope
+    (0.25 <-> 1).  Checked twice: in a child process with FTE_SK=0 (same per-element K order in both runs -> the strict 2e-5), and
+    with the default plans, where the sign changes are counted, must lie inside the oracle's kink band (1e-5 rms(z))
+    and bound what the gradients may differ by;
   * determinism: the same step twice gives bit-identical gradients (ordered reductions, no float atomics)."""
 import numpy as np
 import pytest
@@ -30,7 +35,19 @@ def _step(net, x, y, scale):
     return [float(v) for v in losses], net.grads[:net.arena_size].clone(), net.emb.clone()
 
 
+def test_full_size_split_additivity_is_exact_under_one_k_order():
+    """FTE_SK=0 (read once per process, hence a child): every output element sums its K range in the same order at 512 and at 256
+    images, z is bit-identical and gradient(512) == gradient(256) + gradient(256) to 2e-5 per variable."""
+    import os, subprocess, sys
+    env = dict(os.environ, FTE_SK='0', FTE_TEST_STRICT_SPLIT='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'step_properties', '-p', 'no:cacheprovider'],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_full_size_step_properties():
+    import os
+    strict = os.environ.get('FTE_TEST_STRICT_SPLIT') == '1'
     g = torch.Generator().manual_seed(0)
     x = (torch.rand(B, H, W, CH, generator=g) * 2 - 1).cuda()
     y = torch.randint(0, NCLS, (B,), generator=g, dtype=torch.int32).cuda()
@@ -40,14 +57,33 @@ def test_full_size_step_properties():
     l_full, g_full, e_full = _step(net, x, y, 1.0)
     l_again, g_again, _ = _step(net, x, y, 1.0)
     assert l_again == l_full and torch.equal(g_again, g_full)                       # determinism
+    z_full = [z[:B // 2].clone() for z in net.z]                                      # pre-activations of the first half inside the 512-batch
     l_a, g_a, _ = _step(net, x[:B // 2], y[:B // 2], 0.5)
+    flips, total, worst_band = 0, 0, 0.0
+    for zf, za in zip(z_full, net.z):
+        za = za[:B // 2]
+        d = (zf > 0) != (za > 0)
+        k = int(d.sum())
+        total += zf.numel()
+        if k:
+            flips += k
+            rms = float(zf.float().pow(2).mean().sqrt())
+            worst_band = max(worst_band, float(torch.maximum(zf[d].abs(), za[d].abs()).max()) / rms)
+    del z_full
     l_b, g_b, _ = _step(net, x[B // 2:], y[B // 2:], 0.5)
     assert abs((l_a[0] + l_b[0]) - l_full[0]) <= 1e-5 * l_full[0]                    # displayed CE: mean of the shard means
     assert abs((l_a[1] + l_b[1]) - l_full[1]) <= 1e-6 * l_full[1]                    # reg loss: wd*|w|^2/2 scaled 1/2 per tower
     gs, gf = host(g_a + g_b), host(g_full)
+    if strict:
+        assert flips == 0, 'FTE_SK=0: %d of %d pre-activations changed sign between the 512- and the 256-image run' % (flips, total)
+    else:
+        # PReLU kinks: the few z whose sign differs between the two K orders must be AT the kink (inside the band the oracle
+        # comparisons use) and few -- each changes one element of one dz by a factor <= 4
+        assert flips <= 2e-6 * total and worst_band <= 1e-5, (flips, total, worst_band)
+    tol = 2e-5 if (strict or flips == 0) else 5e-3
     for name, v in net.variables.items():                                           # tower-split additivity, per variable
         a, b = gs[v.offset:v.offset + v.size], gf[v.offset:v.offset + v.size]
-        check_rell2(a, b, 2e-5, 'split-sum gradient of ' + name)
+        check_rell2(a, b, tol, 'split-sum gradient of ' + name)
     _, _, e_small = _step(net, x[:4], y[:4], 1.0)                                    # batch independence
     check_maxabs(host(e_small), host(e_full[:4]), 2e-5, 'embeddings of images 0..3: alone vs inside the 512-batch')
     p = {k: host(net.get_variable(k)) for k in net.variables}

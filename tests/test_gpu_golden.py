@@ -75,7 +75,7 @@ def test_head_goldens():
     for m in (None, 0.3):
         tl = torch.empty(n, device='cuda'); tg = torch.empty(n, d, device='cuda')
         wsb, nb = ws(3 * n * n * 4)
-        call('fte_batch_hard_triplet_fwd_bwd', dev(x), dev(g['tri_labels'], torch.int32), -1.0 if m is None else m, 1.0,
+        call('fte_batch_hard_triplet_fwd_bwd', dev(x), dev(g['tri_labels'], torch.int32), 0.0 if m is None else m, int(m is None), 1.0,
              tl, tg, n, d, wsb, nb, stream())
         check_maxabs(host(tl), g['tri_loss_%s' % m], what='triplet loss'); check_maxabs(host(tg), g['tri_grad_%s' % m], what='triplet grad')
 

@@ -211,12 +211,12 @@ def test_center_loss_and_triplet():
     call('fte_center_loss_fwd_bwd_update', dev(f), dev(y, torch.int32), cd, lrows, df, n, d, c, 0.99, 1.0 / (n * d), wsb, nb, stream())
     assert abs(host(lrows).sum() / (n * d) - loss_ref) <= 1e-5 * loss_ref
     check_maxabs(host(df), df_ref, 1e-5, 'dfeat'); check_maxabs(host(cd), newc_ref, 1e-5, 'centers')
-    for margin in (None, 0.3):
+    for margin in (None, 0.3, -1.0):
         yk = np.repeat(np.arange(8), 4); yk[-1] = 99                    # P x K with one singleton identity
         l_ref, g_ref = ops.batch_hard_triplet(f, yk, margin)
         lr_ = torch.empty(n, device='cuda'); g = torch.empty(n, d, device='cuda')
         wsb, nb = ws(3 * n * n * 4)
-        call('fte_batch_hard_triplet_fwd_bwd', dev(f), dev(yk, torch.int32), -1.0 if margin is None else margin, 1.0,
+        call('fte_batch_hard_triplet_fwd_bwd', dev(f), dev(yk, torch.int32), 0.0 if margin is None else margin, int(margin is None), 1.0,
              lr_, g, n, d, wsb, nb, stream())
         check_maxabs(host(lr_), l_ref, 1e-5, 'triplet loss'); check_rell2(host(g), g_ref, 1e-5, 'triplet grad')
 

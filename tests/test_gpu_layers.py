@@ -221,19 +221,7 @@ def test_batch_norm_with_the_in_launch_finalize_option():
     is read once per process)."""
     import os, subprocess, sys
     env = dict(os.environ, FTE_BN_TAIL='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'batch_norm and not in_launch and not one_launch',
-                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-def test_batch_norm_backward_with_the_one_launch_option():
-    """FTE_BN_COOP=1 (off by default: measured slower, profiles/r4_notes.md): reduce, coefficients and apply of the BN backward in ONE launch
-    whose blocks wait for each other on device-global counters (bounded spin).  Same oracle, same tolerances: the batch-norm cases of
-    this file re-run in a child process with the option on."""
-    import os, subprocess, sys
-    env = dict(os.environ, FTE_BN_COOP='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'batch_norm and not in_launch and not one_launch',
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'batch_norm and not in_launch',
                         '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

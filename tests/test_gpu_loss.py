@@ -36,7 +36,7 @@ def test_center_loss_and_triplet_functions():
     check_rell2(host(df), 0.5 * ref_df, 2e-5, 'd(weight*center_loss)/dfeatures')
     check_maxabs(host(cd), ref_c, 1e-5, 'centers after scatter_sub')
     labels = np.repeat(np.arange(4), 3)
-    for margin in (None, 0.3):
+    for margin in (None, 0.3, -1.0, -0.25):          # negative margins are hinges (loss.py:76-77), only None is the softplus
         per, dfe = ops.batch_hard_triplet(f, labels, margin)
         rows, dft = L.batch_hard_triplet_loss(dev(f), dev(labels, torch.int32), margin)
         check_maxabs(host(rows), per, 2e-5, 'per-sample triplet loss')

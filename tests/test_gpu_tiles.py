@@ -24,7 +24,7 @@ SEEN = set()          # kernel symbols the cases of this module ran (filled in f
 
 def _run(cases, env=None, timeout=900):
     e = dict(os.environ)
-    for k in ('FTE_WGRAD_TILE', 'FTE_NARROW_TILE', 'FTE_WIDE_TILE', 'FTE_WGRAD_SPLIT_MAJOR', 'FTE_SPLIT_MINK'):
+    for k in ('FTE_WGRAD_TILE', 'FTE_NARROW_TILE', 'FTE_WIDE_TILE', 'FTE_WGRAD_SPLIT_MAJOR', 'FTE_SPLIT_MINK', 'FTE_SK', 'FTE_SK_TILE', 'FTE_SK_WS_FLAGS'):
         e.pop(k, None)
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(HERE, 'tile_worker.py'), json.dumps(cases)], env=e, cwd=ROOT,
@@ -79,8 +79,8 @@ def test_tall_128x64_fwd_dgrad_n128_natural():
 def test_default_64x64_fwd_dgrad_at_many_rounds():
     """stages 3 and 4 stay on the 64x64 tile; sizes with several rounds of blocks and a ragged last round, and the stride-2 data
     gradient's four parity classes as separate launches (>= one round of tiles per class)."""
-    cs = _run([['fwd', 130, 14, 14, 256, 256, 1], ['dgrad', 130, 14, 14, 256, 256, 1], ['dgrad', 256, 28, 28, 128, 256, 2],
-               ['fwd', 256, 7, 7, 512, 512, 1], ['dgrad', 256, 7, 7, 512, 512, 1]])
+    cs = _run([['fwd', 176, 14, 14, 256, 256, 1], ['dgrad', 176, 14, 14, 256, 256, 1], ['dgrad', 256, 28, 28, 128, 256, 2],
+               ['fwd', 344, 7, 7, 512, 512, 1], ['dgrad', 344, 7, 7, 512, 512, 1]])      # (> 4 tiles of 128x64 per CU: below that, stream-K)
     _has(cs[0], 'igemm_kernel<64,64,2,2,0,0,0,0>')
     _has(cs[1], 'igemm_kernel<64,64,2,2,0,1,1,0>')
     _has(cs[2], 'igemm_kernel<64,64,2,2,0,1,1,0>')
@@ -180,6 +180,41 @@ def test_pointwise_resident_filter_gradient():
     _has(cs[1], 'wgrad16p_kernel<256,64,8,1>')
     _has(cs[2], 'wgrad16p_kernel<64,128,2,4>')
     _has(cs[3], 'wgrad16p_kernel<128,64,4,2>')
+
+
+def test_stream_k_natural_at_the_small_shards():
+    """Round 5: launches of < 4 tiles (128x64) per CU run on igemm_sk_kernel (csrc/igemm.hip "stream-K"; planner: api.hip plan_sk) --
+    forward on 64x64 tiles, data gradient on 128x64.  The 8-GPU shard of the headline (64 images) NATURALLY: 14x14x256 (1.53 tiles per
+    CU, every tile split over 2-3 workers), 7x7x512 (0.78 per CU: was split-K + fix-up), 28x28x128 (3.06), the stride-2 entry of
+    stage 3 (forward); the 128-image shard's 14x14 layer; and 56x56x64 must stay on the one-block-per-tile kernel (6 tiles per CU).
+    reference: /root/reference/data_parallel.py:206-207 (the shard), nets/sphere.py:61-70 (the layers)."""
+    cs = _run([['fwd', 64, 14, 14, 256, 256, 1], ['dgrad', 64, 14, 14, 256, 256, 1], ['fwd', 64, 7, 7, 512, 512, 1], ['dgrad', 64, 7, 7, 512, 512, 1],
+               ['fwd', 64, 28, 28, 128, 128, 1], ['dgrad', 64, 28, 28, 128, 128, 1], ['fwd', 64, 28, 28, 128, 256, 2],
+               ['fwd', 128, 14, 14, 256, 256, 1], ['dgrad', 128, 14, 14, 256, 256, 1], ['fwd', 64, 56, 56, 64, 64, 1]])
+    for i in (0, 2, 4, 6, 7):
+        _has(cs[i], 'igemm_sk_kernel<64,64,2,2,0,0,0>')
+    for i in (1, 3, 5, 8):
+        _has(cs[i], 'igemm_sk_kernel<128,64,2,2,0,1,1>')
+    assert not any(s.startswith('igemm_sk') for s in cs[9]['symbols']), cs[9]
+
+
+@pytest.mark.parametrize('tile', ['0', '2', '3'])
+def test_stream_k_hooked_every_tile_and_ragged_shapes(tile):
+    """FTE_SK=2 puts every eligible launch on stream-K, FTE_SK_TILE picks the tile (0: 128x128, 2: 128x64, 3: 64x64): ragged M (189,
+    5291 rows), N = 192 (128x128 falls back to 128x64), fewer iterations than workers (3x9x7: 36-54 one-step workers), K = 576 with
+    two K-steps per worker, and the shapes of the natural test on the other tiles."""
+    cases = json.load(open(os.path.join(HERE, 'golden', 'sk_cases.json')))
+    cs = _run(cases, {'FTE_SK': '2', 'FTE_SK_TILE': tile})
+    for c in cs:
+        assert any(s.startswith('igemm_sk_kernel<') for s in c['symbols']), c
+
+
+def test_stream_k_flag_words_in_the_workspace():
+    """FTE_SK_WS_FLAGS=1: the fallback form of the hand-over flags (words behind the slabs in the caller's workspace, zeroed by a
+    memset in front of the launch) instead of the library's per-stream epoch words."""
+    cs = _run([['fwd', 64, 14, 14, 256, 256, 1], ['dgrad', 64, 14, 14, 256, 256, 1]], {'FTE_SK_WS_FLAGS': '1'})
+    _has(cs[0], 'igemm_sk_kernel<64,64,2,2,0,0,0>')
+    _has(cs[1], 'igemm_sk_kernel<128,64,2,2,0,1,1>')
 
 
 def test_every_conv_symbol_of_the_headline_run_was_checked():

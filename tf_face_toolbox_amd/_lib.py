@@ -128,7 +128,7 @@ _SIGS = {
     'fte_add_scaled_rows_cols': (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
     'fte_center_loss_fwd_bwd_update': (c_int, [_P] * 5 + [c_int] * 3 + [c_float] * 2 + [_P, c_size_t, _P]),
     'fte_center_scatter_update': (c_int, [_P] * 3 + [c_int] * 3 + [c_float, _P]),
-    'fte_batch_hard_triplet_fwd_bwd': (c_int, [_P] * 2 + [c_float] * 2 + [_P] * 2 + [c_int] * 2 + [_P, c_size_t, _P]),
+    'fte_batch_hard_triplet_fwd_bwd': (c_int, [_P] * 2 + [c_float, c_int, c_float] + [_P] * 2 + [c_int] * 2 + [_P, c_size_t, _P]),
     'fte_reduce_rows': (c_int, [_P] * 3 + [c_int, c_long, c_long, c_int, c_float, _P]),
     'fte_sumsq': (c_int, [_P, c_long, c_float, _P, _P, c_size_t, _P]),
     'fte_sum': (c_int, [_P, c_long, c_float, _P, _P, c_size_t, _P]),
@@ -212,6 +212,12 @@ def query(name, *args):
 
 def version():
     return load().fte_version().decode()
+
+
+def source_stamp():
+    """the hash of csrc/*.hip, *.h the loaded library was built from (csrc/build.sh); '' for an unstamped build"""
+    v = version()
+    return v.split('src:', 1)[1] if 'src:' in v else ''
 
 
 def set_mfma_dtype(name):

@@ -35,7 +35,11 @@ inline long tiles_of(int tile, long M, long N) {
 // the bf16 tile preferences apply in the bf16-operand mode and inside the bf16-source (fte_*16) entry points
 thread_local bool g_plan16 = false;      // (thread_local: a query on one host thread must not re-plan a launch on another)
 struct Plan16 { bool prev; Plan16() : prev(g_plan16) { g_plan16 = true; } ~Plan16() { g_plan16 = prev; } };
-inline bool plan_bf16() { return g_plan16 || igemm_get_bf16(); }
+// workspace queries plan for BOTH operand modes (both_modes): a thread-local override, never a flip of the process-global mode that a
+// launch on another host thread is reading (-1: follow fte_set_mfma_dtype)
+thread_local int g_plan_mode = -1;
+struct PlanMode { int prev; explicit PlanMode(bool bf16) : prev(g_plan_mode) { g_plan_mode = bf16 ? 1 : 0; } ~PlanMode() { g_plan_mode = prev; } };
+inline bool plan_bf16() { return g_plan16 || (g_plan_mode >= 0 ? g_plan_mode == 1 : igemm_get_bf16()); }
 // Largest tile that still gives the chip >= 1.5 blocks per CU; else the smallest legal one.
 inline int pick_tile(long M, long N) {
     const bool b16 = plan_bf16();
@@ -91,7 +95,8 @@ inline bool plan_sk(long M, long N, long K, int epi, RowPlan* out) {
     static const int mode = getenv("FTE_SK") ? atoi(getenv("FTE_SK")) : 1;          // 0: off; 1: the rule below; 2: every eligible launch (tests, A/B)
     static const int env_tile = getenv("FTE_SK_TILE") ? atoi(getenv("FTE_SK_TILE")) : -1;
     static const int env_tile_d = getenv("FTE_SK_TILE_DGRAD") ? atoi(getenv("FTE_SK_TILE_DGRAD")) : env_tile;
-    if (!mode || K % 32 || N % 64) return false;
+    static const int ops = getenv("FTE_SK_OPS") ? atoi(getenv("FTE_SK_OPS")) : 3;      // A/B hook: 1 = forward only, 2 = data gradient only
+    if (!mode || K % 32 || N % 64 || !(ops & (epi == EPI_FWD ? 1 : 2))) return false;
     const long ksteps = K / 32;
     // measured on MI355X (profiles/r5_notes.md): forward -- 64x64 tiles, six workers per CU; data gradient (more registers: the
     // PReLU / partial-sum epilogue) -- 128x64 tiles, four per CU
@@ -306,25 +311,25 @@ inline hipError_t launch_rows(IgemmParams p, const RowPlan& rp, int al, int bl, 
 // sized once stays valid when the mode is switched
 template <class F>
 size_t both_modes(F f) {
-    const bool cur = igemm_get_bf16();
-    igemm_set_bf16(false);
-    const size_t a = f();
-    igemm_set_bf16(true);
-    const size_t b = f();
-    size_t c;
+    size_t a, b, c;
+    { PlanMode m(false); a = f(); }
+    { PlanMode m(true); b = f(); }
     {                      // ... and the bf16-STORAGE plan of the *_s16 entry points (one unsplit launch of 128-row tiles where it applies)
         Plan16 guard;
         PlanS16 storage(true);
         c = f();
     }
-    igemm_set_bf16(cur);
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 }  // namespace
 
 extern "C" {
 
-const char* fte_version(void) { return "fte 0.1 gfx950 fp32-mfma"; }
+#ifndef FTE_SRC_SHA
+#define FTE_SRC_SHA "unstamped"
+#endif
+// "... src:<hash of csrc/*.hip, *.h at build time>" (csrc/build.sh): bench.py and __graft_entry__.build() compare it with the sources'
+const char* fte_version(void) { return "fte 0.2 gfx950 fp32-mfma src:" FTE_SRC_SHA; }
 
 int fte_to_bf16(const float* x, uint16_t* y, long n, void* stream) {
     if (!x || !y || n <= 0 || n % 4) return FTE_EINVAL;
@@ -1038,11 +1043,11 @@ int fte_center_scatter_update(const float* diff, const int32_t* labels, float* c
     if (!diff || !labels || !centers || n <= 0 || d <= 0 || num_classes <= 0) return FTE_EINVAL;
     return rc(k_center_update(diff, labels, centers, n, d, num_classes, alpha, (hipStream_t)stream));
 }
-int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, float margin, float loss_weight,
+int fte_batch_hard_triplet_fwd_bwd(const float* feat, const int32_t* labels, float margin, int soft_margin, float loss_weight,
                                    float* loss_rows, float* dfeat, int n, int d, void* ws, size_t ws_bytes, void* stream) {
     if (!feat || !labels || !loss_rows || !dfeat || n <= 0) return FTE_EINVAL;
     if (!ws || ws_bytes < (size_t)2 * n * n * sizeof(float)) return FTE_EWORKSPACE;
-    return rc(k_triplet(feat, labels, margin, loss_weight, loss_rows, dfeat, n, d, (float*)ws, (hipStream_t)stream));
+    return rc(k_triplet(feat, labels, margin, soft_margin != 0, loss_weight, loss_rows, dfeat, n, d, (float*)ws, (hipStream_t)stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1195,8 +1200,8 @@ int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma,
                       float* scale, float* shift, float* moving_mean, float* moving_var, float eps, float decay,
                       const float* in_scale, const float* in_shift, void* y_side,
                       int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream) {
-    if (!z || !gamma || !beta || !mean || !rstd || !scale || !shift || (s16 & ~1) || ((moving_mean == nullptr) != (moving_var == nullptr)))
-        return FTE_EINVAL;
+    if (!x || !w || !z || !gamma || !beta || !mean || !rstd || !scale || !shift || (s16 & ~1) || ((moving_mean == nullptr) != (moving_var == nullptr)))
+        return FTE_EINVAL;      // (x / w here: the streaming pointwise path below does not go through conv2d_fwd_impl's checks)
     if (((in_scale == nullptr) != (in_shift == nullptr)) || (in_scale && !y_side) ||
         (in_scale && !fte_conv2d_bn_fwd_folds(n, h, wd, cin, cout, ksize, stride, s16))) return FTE_EINVAL;
     if (!ws || ws_bytes < fte_conv2d_bn_fwd_ws_bytes(n, h, wd, cin, cout, ksize, stride)) return FTE_EWORKSPACE;
@@ -1240,7 +1245,7 @@ int fte_conv2d_dgrad_bn(const void* dz, const void* w, const void* addin, const 
                         const float* gamma, const float* mean, const float* rstd, const float* bn_scale, const float* bn_shift,
                         void* g, float* dgamma, float* dbeta, float* coef,
                         int n, int h, int wd, int cin, int cout, int ksize, int stride, int s16, void* ws, size_t ws_bytes, void* stream) {
-    if (!zbn || !gamma || !mean || !rstd || !g || !dgamma || !dbeta || !coef || (s16 & ~1) || ((bn_scale == nullptr) != (bn_shift == nullptr)) ||
+    if (!dz || !w || !zbn || !gamma || !mean || !rstd || !g || !dgamma || !dbeta || !coef || (s16 & ~1) || ((bn_scale == nullptr) != (bn_shift == nullptr)) ||
         (bn_scale && ybn))
         return FTE_EINVAL;
     const DgradBn bn = {zbn, ybn, gamma, mean, rstd, bn_scale, bn_shift, dgamma, dbeta, coef};

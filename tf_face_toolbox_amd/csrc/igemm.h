@@ -73,7 +73,7 @@ struct IgemmParams {
     // raw accumulators in slab w of SKW (BM*BN floats each) and raises SKF[w]; the worker that holds K-step 0 of the tile adds the
     // slabs of its successors in worker order and runs the fused epilogue.  SKF: the caller passes sk_workers words behind the slabs; the
     // launcher normally replaces them by the library's per-stream words (igemm.hip sk_flags) and zeroes the caller's only as a fallback.
-    int sk_workers, sk_base, sk_rem, sk_epoch;      // sk_epoch: the value a raised flag word holds (set by the launcher)
+    int sk_workers, sk_base, sk_rem, sk_epoch, sk_acq;      // sk_epoch: the value a raised flag word holds (set by the launcher)
     float* SKW; unsigned* SKF;
     int ptiles;           // igemm16p_kernel (persistent blocks): tiles of the launch; set by its launcher
     int ptiles_dbg;       // diagnostic switches of that kernel (FTE_IGEMM16_DBG; 0 in production)

@@ -973,6 +973,10 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, int sk_tile = 0
                 if (tid == 0) {
                     while (__hip_atomic_load(p.SKF + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.sk_epoch) __builtin_amdgcn_s_sleep(1);
                 }
+                if (p.sk_acq) {
+                    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __syncthreads();
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.SKW + (size_t)w2 * (BM * BN), 0, SLAB_BYTES, 0x00020000);
                 constexpr int QC = NQ < 8 ? NQ : 8;        // quads in flight per lane
@@ -1261,6 +1265,8 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
                         p.sk_workers, p.sk_base, p.sk_rem, p.M, p.N, p.K, nb, lds_x);
             }
             IgemmParams q = p;
+            static const int sk_acq = getenv("FTE_SK_ACQ") ? atoi(getenv("FTE_SK_ACQ")) : 0;
+            q.sk_acq = sk_acq;
             hipError_t e = sk_flags(&q, st);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(sk, dim3(q.sk_workers), dim3(256), lds_x, st, q);

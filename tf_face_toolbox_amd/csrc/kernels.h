@@ -30,7 +30,7 @@ hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* 
 hipError_t k_center_loss(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
                          int n, int d, int num_classes, float alpha, float gs, float* ws, hipStream_t st);
 hipError_t k_center_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes, float alpha, hipStream_t st);
-hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, float lw, float* loss_rows, float* dfeat,
+hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, bool soft, float lw, float* loss_rows, float* dfeat,
                      int n, int d, float* ws, hipStream_t st);
 hipError_t k_momentum(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gs, hipStream_t st);
 hipError_t k_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps, float wd, float gs, hipStream_t st);

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void triplet_dist_kernel(const float* __restri
 // one wave-sized block per anchor: hardest positive (max) / hardest negative (min), loss, and the
 // coefficient matrix coef[i][j] such that dfeat_a = sum_b (coef[a][b] + coef[b][a]) (f_a - f_b)
 __global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restrict__ dist, const int32_t* __restrict__ labels,
-                                                          float margin, float lw, float* __restrict__ loss_rows,
+                                                          float margin, bool soft, float lw, float* __restrict__ loss_rows,
                                                           float* __restrict__ coef, int n) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const int yi = labels[i];
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restric
     if (lane == 0) {
         const float v = bp - bn;
         float loss, dv;
-        if (margin < 0.f) {
+        if (soft) {
             loss = v > 20.f ? v : log1pf(expf(v));
             dv = 1.f / (1.f + expf(-v));
         } else {
@@ -822,7 +822,8 @@ hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* 
     }
     const unsigned nz = in2 ? 2 : 1;
     static const bool rq_off = getenv("FTE_REDUCE_ROWS_Q") && atoi(getenv("FTE_REDUCE_ROWS_Q")) == 0;      // A/B hook
-    if (!rq_off && !act && scratch && !bias && scale == 1.f && rows >= 256 && cols % 4 == 0 && cols <= 1024 &&
+    // (rows < 256: ONE launch, a row lane walks <= 64 rows -- the partial rows of a small shard's 128-row tiles: two 4-us passes before)
+    if (!rq_off && !act && scratch && !bias && scale == 1.f && rows >= 32 && cols % 4 == 0 && cols <= 1024 &&
         (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in2) | reinterpret_cast<uintptr_t>(out2) |
          reinterpret_cast<uintptr_t>(scratch)) % 16 == 0) {
         const long quads = cols / 4;
@@ -831,7 +832,7 @@ hipError_t k_reduce_rows2(const float* in, float* out, const float* in2, float* 
         long rs = 1024 / (qb * nz);                            // ~4 blocks per CU in the first pass ...
         if (rs > rows / (8L * RL)) rs = rows / (8L * RL);      // ... each with at least one round of eight loads per lane
         if (rs * cols * nz > REDUCE_SCRATCH_FLOATS) rs = REDUCE_SCRATCH_FLOATS / (cols * nz);
-        if (rs < 1) rs = 1;
+        if (rs < 1 || rows < 256) rs = 1;
         const long rps = (rows + rs - 1) / rs;
         rs = (rows + rps - 1) / rps;
         f32x4* s1 = reinterpret_cast<f32x4*>(scratch);
@@ -1007,12 +1008,12 @@ hipError_t k_center_update(const float* diff, const int32_t* labels, float* cent
     hipLaunchKernelGGL(center_update_kernel, dim3(n), dim3(256), n <= CENTER_LDS_LABELS ? (size_t)n * sizeof(int) : 0, st, diff, labels, centers, n, d, num_classes, alpha);
     return hipGetLastError();
 }
-hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, float lw, float* loss_rows, float* dfeat,
+hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, bool soft, float lw, float* loss_rows, float* dfeat,
                      int n, int d, float* ws, hipStream_t st) {
     float* dist = ws;
     float* coef = ws + (long)n * n;
     hipLaunchKernelGGL(triplet_dist_kernel, dim3(n * n), dim3(256), 0, st, feat, dist, n, d);
-    hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(64), 0, st, dist, labels, margin, lw, loss_rows, coef, n);
+    hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(64), 0, st, dist, labels, margin, soft, lw, loss_rows, coef, n);
     hipLaunchKernelGGL(triplet_grad_kernel, dim3(n), dim3(256), 0, st, feat, coef, dfeat, n, d);
     return hipGetLastError();
 }

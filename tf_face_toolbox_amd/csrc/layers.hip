@@ -681,168 +681,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_wide_kernel(const float* 
     coef[2 * C + c] = -gr * a / count - bb * mean[c];
 }
 
-// arrival / departure counters of bn_bwd_coop_kernel: a zero-initialised device global (no allocation in the library), used as a ring --
-// a launch takes the next slot of 64 words (two per column group) and its last block to leave zeroes what it used
-constexpr int COOP_SLOTS = 1024, COOP_WORDS = 64;
-__device__ unsigned g_coop_cnt[COOP_SLOTS * COOP_WORDS];
-// ---------------------------------------------------------------------------------------------------
-// BN backward in ONE launch for the tensors of a small shard (round 4; FTE_BN_COOP): reduce, the column's coefficients, apply.
-// Grid = (C / 64 column groups) x (row splits), at most 512 blocks = two per CU, so that every block is resident (or becomes so as
-// soon as another stream's blocks retire) while the column's blocks wait for each other:
-//   phase 1  block (g, s) sums g and g * xhat over its rows for its 64 channels (four rows in flight per lane) and hands the partial
-//            over with write-through stores;
-//   barrier  one lane per block: agent-scope fetch_add on the column's arrival counter, then a BOUNDED spin on it (a launch that
-//            cannot get its blocks resident degrades to wrong coefficients, never to a hung device; tests compare with the
-//            three-launch path); the last block to LEAVE puts both counters back to zero (ring slots, as the in-launch finalize);
-//   phase 2  every block of the column sums the column's partials itself (gy x 512 B of L2-resident words, in split order: the same
-//            value in every block), derives dz = A g + B z + C0 and applies it to ITS rows -- which it read a few microseconds ago.
-// The three launches it replaces are 9-15 + 5-6 + 9-12 us on 8-50 MB tensors, most of it launch and first-byte latency.
-template <bool ZH, bool AH>
-__global__ __launch_bounds__(256, 2) void bn_bwd_coop_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
-                                                             const float* __restrict__ z, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, const float* __restrict__ zsc,
-                                                             const float* __restrict__ zsf, const float* __restrict__ gamma,
-                                                             float* __restrict__ gout, float* __restrict__ dz, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, float* __restrict__ part, unsigned slot,
-                                                             long rows, int C, long rows_per_split, float count) {
-    constexpr int Q = 16, RL = 16;
-    __shared__ f32x4 sh[2][RL][Q];
-    __shared__ float cs[2][128];
-    __shared__ float tot[128];
-    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
-    const int ch = (blockIdx.x * Q + q) * 4;
-    const int gy = gridDim.y, sp = blockIdx.y;
-    const long r0 = (long)sp * rows_per_split, r1 = min(rows, r0 + rows_per_split);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), rs = *reinterpret_cast<const f32x4*>(rstd + ch);
-    f32x4 sc = mu, sf = mu;
-    if (zsc) { sc = *reinterpret_cast<const f32x4*>(zsc + ch); sf = *reinterpret_cast<const f32x4*>(zsf + ch); }
-    auto masked = [&](f32x4 g, const f32x4 zz, const f32x4 mv) {
-        if (zsc) {                                       // ReLU mask recomputed from z (bn_affine: the forward's own expression)
-            const f32x4 m = bn_affine(zz, sc, sf);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
-        } else if (ymask) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = mv[e] > 0.f ? g[e] : 0.f;
-        }
-        return g;
-    };
-    // ---- phase 1
-    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg;
-    {
-        long r = r0 + rl;
-        for (; r + 3 * RL < r1; r += 4 * RL) {
-            f32x4 g4[4], z4[4], m4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                g4[u] = ldq<AH>(dy, (r + u * RL) * C + ch);
-                z4[u] = ldq<ZH>(z, (r + u * RL) * C + ch);
-                if (!zsc && ymask) m4[u] = ldq<AH>(ymask, (r + u * RL) * C + ch); else m4[u] = g4[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 g = masked(g4[u], z4[u], m4[u]);
-                if (gout) stq<AH>(gout, (r + u * RL) * C + ch, g);
-                sg += g;
-                sgx += g * ((z4[u] - mu) * rs);
-            }
-        }
-        for (; r < r1; r += RL) {
-            const f32x4 gr = ldq<AH>(dy, r * C + ch), zz = ldq<ZH>(z, r * C + ch);
-            const f32x4 mv = (!zsc && ymask) ? ldq<AH>(ymask, r * C + ch) : gr;
-            const f32x4 g = masked(gr, zz, mv);
-            if (gout) stq<AH>(gout, r * C + ch, g);
-            sg += g;
-            sgx += g * ((zz - mu) * rs);
-        }
-    }
-    sh[0][rl][q] = sg; sh[1][rl][q] = sgx;
-    __syncthreads();
-    if (rl == 0) {
-        f32x4 a = sg, b = sgx;
-        for (int l = 1; l < RL; ++l) { a += sh[0][l][q]; b += sh[1][l][q]; }
-        float* pp = part + (long)sp * 2 * C;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { st_wt(pp + ch + e, a[e]); st_wt(pp + C + ch + e, b[e]); }
-    }
-    // ---- the column's blocks wait for each other
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned* arrive = g_coop_cnt + slot * COOP_WORDS + 2 * blockIdx.x;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int it = 0; it < (1 << 20); ++it) {            // ~1 s at most: see the header
-            if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)gy) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- the column's sums: thread t -> value t & 127 (= which * 64 + channel), split parity t >> 7; eight loads in flight
-    {
-        const int v = threadIdx.x & 127, grp = threadIdx.x >> 7;
-        const float* src = part + (long)(v >> 6) * C + blockIdx.x * 64 + (v & 63);
-        float acc = 0.f;
-        for (int j0 = grp; j0 < gy; j0 += 16) {
-            float w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = j0 + 2 * u < gy ? ld_wt(src + (long)(j0 + 2 * u) * 2 * C) : 0.f;
-            acc += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
-        }
-        cs[grp][v] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) tot[threadIdx.x] = cs[0][threadIdx.x] + cs[1][threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {                                  // leave: the last one out zeroes the slot for its next user
-        const unsigned t = __hip_atomic_fetch_add(arrive + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t + 1 == (unsigned)gy) {
-            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(arrive + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    f32x4 tg, tgx;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { tg[e] = tot[q * 4 + e]; tgx[e] = tot[64 + q * 4 + e]; }
-    const f32x4 gam = *reinterpret_cast<const f32x4*>(gamma + ch);
-    f32x4 A, B, C0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float gr = gam[e] * rs[e];
-        const float b = -gr * rs[e] * tgx[e] / count;
-        A[e] = gr; B[e] = b; C0[e] = -gr * tg[e] / count - b * mu[e];
-    }
-    if (sp == 0 && rl == 0) {
-        *reinterpret_cast<f32x4*>(dbeta + ch) = tg;
-        *reinterpret_cast<f32x4*>(dgamma + ch) = tgx;
-    }
-    // ---- phase 2: this block's rows again
-    {
-        const float* gsrc = gout ? gout : dy;
-        long r = r0 + rl;
-        for (; r + 3 * RL < r1; r += 4 * RL) {
-            f32x4 g4[4], z4[4], m4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                g4[u] = ldq<AH>(gsrc, (r + u * RL) * C + ch);
-                z4[u] = ldq<ZH>(z, (r + u * RL) * C + ch);
-                if (!gout && !zsc && ymask) m4[u] = ldq<AH>(ymask, (r + u * RL) * C + ch); else m4[u] = g4[u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 g = gout ? g4[u] : masked(g4[u], z4[u], m4[u]);
-                stq<ZH>(dz, (r + u * RL) * C + ch, A * g + B * z4[u] + C0);
-            }
-        }
-        for (; r < r1; r += RL) {
-            const f32x4 gr = ldq<AH>(gsrc, r * C + ch), zz = ldq<ZH>(z, r * C + ch);
-            const f32x4 mv = (!gout && !zsc && ymask) ? ldq<AH>(ymask, r * C + ch) : gr;
-            const f32x4 g = gout ? gr : masked(gr, zz, mv);
-            stq<ZH>(dz, r * C + ch, A * g + B * zz + C0);
-        }
-    }
-}
-
+// (round 4's one-launch cooperative BN backward -- reduce, wait for the column's blocks on device-global counters, apply -- was measured
+// 2x slower per call than the three launches and 15 % slower per step (profiles/r4_notes.md 7) and relied on a bounded spin that could fall
+// through with incomplete partials; it was removed in round 5)
 template <bool ZH = false, bool AH = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                            const float* __restrict__ z, const float* __restrict__ coef,
@@ -1293,32 +1134,6 @@ hipError_t l_relu_bwd(const float* dy, const float* y, float* g, long n, hipStre
 hipError_t l_bn_bwd(const float* dy, const float* ymask, const float* z, const float* gamma, const float* mean,
                     const float* rstd, const float* zsc, const float* zsf, float* gout, float* dz, float* dgamma, float* dbeta,
                     long rows, int C, float* part, hipStream_t st, int flags) {
-    {
-        // one cooperative launch (see bn_bwd_coop_kernel): OFF by default, FTE_BN_COOP=1 turns it on, FTE_BN_COOP_MB bounds the tensor
-        // (dy + z bytes) it takes.  Measured (ResNeXt-50 bf16s @128, per call, one stream): 100352 x 128: 31 us in three launches, 62 us in
-        // one; 2048 x 1024: 14.7 against 22.9; steps 6.73 -> 7.79 ms, ResNet-50 6.36 -> 7.28, ShuffleNet fp32 @256 8.10 -> 8.93 -- the
-        // three launches already move the large tensors at 4 TB/s, and two blocks per CU that wait for each other do not
-        static const int coop = getenv("FTE_BN_COOP") ? atoi(getenv("FTE_BN_COOP")) : 0;
-        static const long coop_mb = getenv("FTE_BN_COOP_MB") ? atol(getenv("FTE_BN_COOP_MB")) : 256;
-        static unsigned coop_pos[16];
-        const long bytes = rows * C * ((flags & 1 ? 2 : 4) + (flags & 2 ? 2 : 4));
-        int dev = 0;
-        if (coop && C % 64 == 0 && C / 64 <= COOP_WORDS / 2 && rows >= 256 && bytes <= (coop_mb << 20) &&
-            hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
-            const int gx = C / 64;
-            long gy = 512 / gx;
-            if (gy > 256) gy = 256;
-            if (gy > rows / 64) gy = rows / 64;
-            if (gy >= 2) {
-                const long rps2 = (rows + gy - 1) / gy;
-                gy = (rows + rps2 - 1) / rps2;
-                const unsigned slot = coop_pos[dev]++ % COOP_SLOTS;
-                FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((bn_bwd_coop_kernel<ZH, AH>), dim3(gx, (unsigned)gy), dim3(256), 0, st, dy, ymask, z, mean, rstd,
-                                                                 zsc, zsf, gamma, gout, dz, dgamma, dbeta, part, slot, rows, C, rps2, (float)rows));
-                return hipGetLastError();
-            }
-        }
-    }
     int splits; long rps;
     stat_split(rows, C, &splits, &rps);
     float* coef = part + (long)splits * 2 * C;

@@ -66,6 +66,6 @@ def batch_hard_triplet_loss(features, labels, margin=None, metric='euclidean'):
     rows = torch.empty(n, dtype=torch.float32, device=features.device)
     df = torch.empty_like(features)
     ws = torch.empty(max(4 * n * n, 1024) + 1024, dtype=torch.float32, device=features.device)
-    _lib.call('fte_batch_hard_triplet_fwd_bwd', features, labels, -1.0 if margin is None else float(margin), 1.0 / n,
+    _lib.call('fte_batch_hard_triplet_fwd_bwd', features, labels, 0.0 if margin is None else float(margin), int(margin is None), 1.0 / n,
               rows, df, n, d, ws, ws.numel() * 4, _stream())
     return rows, df

@@ -711,8 +711,8 @@ class GraphNet(Network):
                 return False
             cop = self.plan[cj]
             ih_, iw_, cin_ = self.shapes[cop[2]]
-            if cop[0] == 'gconv':
-                return cop[4] == 1 and self._gconv_pack(cop) is not None
+            if cop[0] == 'gconv':                       # (its fused launch carries the fold: FTE_BN_FUSE_3X3=0 takes both away)
+                return cop[4] == 1 and self._gconv_pack(cop) is not None and self.fuse_3x3
             return bool(_lib.query('fte_conv2d_bn_fwd_folds', n, ih_, iw_, cin_, self.shapes[cop[1]][-1], self.spec[cop[3]][0][0], cop[4], 1))
 
         def fold_args(j):
@@ -869,7 +869,7 @@ class GraphNet(Network):
                     elif pack_ev is not None:                  # (packed on the side stream at the start of the walk)
                         torch.cuda.current_stream().wait_event(pack_ev)
                         pack_ev = None
-                    if s16 and is_training and j in self.fuse_fwd:
+                    if s16 and is_training and j in self.fuse_fwd and self.fuse_3x3:
                         xin, isc, ish, yside = fold_args(j)
                         call('fte_gconv3x3_bn_fwd_bf16_s16', xin, pk[0], T[out], *bn_args(self.fuse_fwd[j]), isc, ish, yside, n, ih, iw, c, op[4],
                              self.ws, self.ws_bytes, st)
@@ -1024,8 +1024,8 @@ class GraphNet(Network):
         losses, names = [], []
         self._dfeat = None
         if self.head == 'triplet':
-            margin = -1.0 if self.triplet_margin is None else float(self.triplet_margin)
-            call('fte_batch_hard_triplet_fwd_bwd', feat, labels, margin, self.tower_scale / n, self.loss_rows, self.dfeat,
+            soft = self.triplet_margin is None                                  # loss.py:74-77: None -> softplus, any number -> hinge
+            call('fte_batch_hard_triplet_fwd_bwd', feat, labels, 0.0 if soft else float(self.triplet_margin), int(soft), self.tower_scale / n, self.loss_rows, self.dfeat,
                  n, d, self.ws, self.ws_bytes, st)
             call('fte_sum', self.loss_rows, n, self.tower_scale / n, slots[0:1], self.ws, self.ws_bytes, st)
             self._dfeat = self.dfeat
@@ -1089,13 +1089,20 @@ class GraphNet(Network):
         one = [(0, nops, 0, self.cls_start)]
         want = int(os.environ.get('FTE_GRAD_BUCKETS', '4'))
         offs = []                                        # (plan index, first arena offset, end offset) of every op with filters
+        owned = set()
         for j in range(nops):
             names = self._op_weight_names(self.plan[j])
             if names:
                 vs = [self.variables[w] for w in names]
+                owned.update(names)
                 offs.append((j, min(v.offset for v in vs), max(v.offset + v.size for v in vs)))
         mono = all(offs[i][2] <= offs[i + 1][1] for i in range(len(offs) - 1)) and (not offs or offs[0][1] >= self.small_end)
-        if want <= 1 or not mono or len(offs) < want:
+        # every variable of the body range that SOME plan op names must belong to an op seen above: a bucket's all-reduce is issued when
+        # the ops of its plan range have been walked, so a variable of another kind of op (none today; e.g. a mid-plan fc) could land in a
+        # bucket reduced before its gradient is final.  (Variables no op names -- ShuffleNet-v2-large's dead convs -- have no gradient.)
+        named = {x for op in self.plan[:nops] for x in op if isinstance(x, str) and x in self.variables}
+        stray = [k for k in named if self.small_end <= self.variables[k].offset < self.cls_start and k not in owned]
+        if want <= 1 or not mono or stray or len(offs) < want:
             self._segs = one
             return one
         total = offs[-1][2] - offs[0][1]
