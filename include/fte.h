@@ -396,6 +396,28 @@ int fte_channel_scale_bwd_s16(const uint16_t* dy16, const uint16_t* x16, const f
                               int pre_sigmoid, void* stream);
 int fte_channel_scale_bwd_apply_s16(const uint16_t* dy16, const float* gate, const float* dsq, uint16_t* dx16, int n, int hw, int c,
                                     float scale, void* stream);
+/* The SE residual block  z -> BN (no activation) -> y * gate(mean_hw y) -> + shortcut -> ReLU  (nets/resnet.py:63-92 with the gate of
+ * nets/shufflenet_v2.py:79-85) in ONE pass over the tensor forward and TWO backward; the BN output and the gated tensor never exist
+ * in HBM.  flags: bit 0 (FTE_S16_Z) z / dz are bf16, bit 1 (FTE_S16_A) shortcut / out / dy / g are bf16; gate, sq, xm, s1, s2, dgate, dsq
+ * are [n, c] fp32; scale / shift / mean / rstd are the BN layer's (fte_conv2d_bn_fwd, fte_bn_train_stats, fte_bn_infer_coef).
+ *   fte_se_squeeze       sq = scale * mean_hw(z) + shift (= mean_hw of the BN output); xm (optional) = (mean_hw(z) - mean) * rstd
+ *   fte_se_apply_fwd     out = relu(fma(z, scale, shift) * gate + shortcut)
+ *   fte_se_bwd_gate      g = dy * (out > 0) (the shortcut's gradient; stored, and the stored value is what is summed);
+ *                        s1 = sum_hw g, s2 = sum_hw g * xhat, dgate = (gamma * s2 + beta * s1) * gate * (1 - gate) (w.r.t. the pre-sigmoid)
+ *   fte_se_bn_bwd_coef   dsq = gradient of the squeeze (from the gate's dense layers): the batch-norm backward of
+ *                        dy_bn = g * gate + dsq / hw from the per-image sums -- dbeta = sum_n (gate * s1 + dsq), dgamma = sum_n (gate * s2 +
+ *                        dsq * xm), coef[3][c] of dz = A dy_bn + B z + C0 (FusedBatchNormGrad, nets/resnet.py:97-99)
+ *   fte_se_bn_bwd_apply  dz = A * (g * gate + dsq / hw) + B * z + C0 */
+int fte_se_squeeze(const void* z, const float* scale, const float* shift, const float* mean, const float* rstd, float* sq, float* xm,
+                   int n, int hw, int c, int flags, void* stream);
+int fte_se_apply_fwd(const void* z, const float* scale, const float* shift, const float* gate, const void* shortcut, void* out,
+                     int n, int hw, int c, int flags, void* stream);
+int fte_se_bwd_gate(const void* dy, const void* out, const void* z, const float* gamma, const float* beta, const float* mean,
+                    const float* rstd, const float* gate, void* g, float* s1, float* s2, float* dgate, int n, int hw, int c, int flags, void* stream);
+int fte_se_bn_bwd_coef(const float* s1, const float* s2, const float* gate, const float* dsq, const float* xm, const float* gamma,
+                       const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int n, int hw, int c, void* stream);
+int fte_se_bn_bwd_apply(const void* g, const void* z, const float* coef, const float* gate, const float* dsq, void* dz,
+                        int n, int hw, int c, int flags, void* stream);
 int fte_dwconv3x3_fwd_s16(const uint16_t* x16, const float* w, uint16_t* y16, int n, int h, int wd, int c, int stride, void* stream);
 int fte_dwconv3x3_dgrad_s16(const uint16_t* dy16, const float* w, uint16_t* dx16, int n, int h, int wd, int c, int stride, void* stream);
 int fte_dwconv3x3_wgrad_s16(const uint16_t* x16, const uint16_t* dy16, float* dw, int n, int h, int wd, int c, int stride,

@@ -325,3 +325,323 @@ class Audit(object):
     def _chk_fte_gemm_tn(self, x, dy, dw, m, n, k, ws, wsb, st):
         ref = self._w(_h(x).reshape(m, k)).T @ self._w(_h(dy).reshape(m, n))
         self._ok('fte_gemm_tn', 'dw', _h(dw).reshape(k, n), ref)
+
+    # ---- streaming kernels (round 5: the audit covers every entry point of the step, not only the conv / BN / dense families) ------------
+    @staticmethod
+    def _nhwc(t, n, hw, c):
+        return _h(t).reshape(n, hw, c)
+
+    def _chk_fte_se_squeeze(self, z, scale, shift, mean, rstd, sq, xm, n, hw, c, flags, st):
+        zm = self._nhwc(z, n, hw, c).mean(1)
+        self._ok('fte_se_squeeze', 'sq', _h(sq).reshape(n, c), zm * _h(scale) + _h(shift))
+        if xm is not None:      # (mean_hw z - mean) * rstd: as good as the mean it subtracts (error ~ eps * |mean| * rstd)
+            ref = (zm - _h(mean)) * _h(rstd)
+            lim = 2e-6 * (1.0 + float((np.abs(_h(mean)) * _h(rstd)).max()))
+            err = float(np.abs(_h(xm).reshape(n, c) - ref).max())
+            self.worst['fte_se_squeeze'] = max(self.worst.get('fte_se_squeeze', 0.0), err / lim)
+            assert err <= lim, 'fte_se_squeeze: xm off by %.2e (limit %.2e)' % (err, lim)
+
+    def _chk_fte_se_apply_fwd(self, z, scale, shift, gate, sc, out, n, hw, c, flags, st):
+        y = self._nhwc(z, n, hw, c) * _h(scale) + _h(shift)
+        ref = np.maximum(y * _h(gate).reshape(n, 1, c) + self._nhwc(sc, n, hw, c), 0)
+        self._ok('fte_se_apply_fwd', 'out', self._nhwc(out, n, hw, c), ref, stored16=bool(flags & 2))
+
+    def _chk_fte_se_bwd_gate(self, dy, out, z, gamma, beta, mean, rstd, gate, g, s1, s2, dgate, n, hw, c, flags, st):
+        fn = 'fte_se_bwd_gate'
+        gr = self._nhwc(dy, n, hw, c) * (self._nhwc(out, n, hw, c) > 0)
+        gg = self._nhwc(g, n, hw, c)
+        self._ok(fn, 'g', gg, gr, stored16=bool(flags & 2), tol=1e-7 if not flags & 2 else TOL)
+        xhat = (self._nhwc(z, n, hw, c) - _h(mean)) * _h(rstd)
+        r1, r2 = gg.sum(1), (gg * xhat).sum(1)              # the STORED g is what the kernel sums (fte.h)
+        for what, got, ref, terms in (('s1', _h(s1), r1, np.abs(gg).sum(1)), ('s2', _h(s2), r2, np.abs(gg * xhat).sum(1))):
+            lim = 2e-6 * float(terms.max()) + 1e-30
+            err = float(np.abs(got.reshape(n, c) - ref).max())
+            self.worst[fn] = max(self.worst.get(fn, 0.0), err / lim)
+            assert err <= lim, '%s: %s off by %.2e (limit %.2e = 2e-6 x the largest sum of |terms|)' % (fn, what, err, lim)
+        gt = _h(gate).reshape(n, c)
+        ref = (_h(gamma) * r2 + _h(beta) * r1) * gt * (1 - gt)
+        lim = 2e-6 * float(((np.abs(_h(gamma)) * np.abs(gg * xhat).sum(1) + np.abs(_h(beta)) * np.abs(gg).sum(1)) * gt * (1 - gt)).max()) + 1e-30
+        err = float(np.abs(_h(dgate).reshape(n, c) - ref).max())
+        self.worst[fn] = max(self.worst.get(fn, 0.0), err / lim)
+        assert err <= lim, '%s: dgate off by %.2e (limit %.2e)' % (fn, err, lim)
+
+    def _chk_fte_se_bn_bwd_coef(self, s1, s2, gate, dsq, xm, gamma, mean, rstd, dgamma, dbeta, coef, n, hw, c, st):
+        fn = 'fte_se_bn_bwd_coef'
+        a1, a2, gt, dq, x = (_h(t).reshape(n, c) for t in (s1, s2, gate, dsq, xm))
+        db, dg = (gt * a1 + dq).sum(0), (gt * a2 + dq * x).sum(0)
+        for what, got, ref, terms in (('dbeta', _h(dbeta), db, (np.abs(gt * a1) + np.abs(dq)).sum(0)), ('dgamma', _h(dgamma), dg, (np.abs(gt * a2) + np.abs(dq * x)).sum(0))):
+            lim = 2e-6 * float(terms.max()) + 1e-30
+            err = float(np.abs(got - ref).max())
+            self.worst[fn] = max(self.worst.get(fn, 0.0), err / lim)
+            assert err <= lim, '%s: %s off by %.2e (limit %.2e)' % (fn, what, err, lim)
+        cnt = float(n * hw)
+        gr = _h(gamma) * _h(rstd)
+        bb = -gr * _h(rstd) * dg / cnt
+        cf = _h(coef).reshape(3, c)
+        self._ok(fn, 'A', cf[0], gr, tol=1e-6)
+        self._ok(fn, 'B', cf[1], bb, tol=1e-5 * max(1.0, float(np.abs(dg).max()) and 1.0))
+        c0 = -gr * db / cnt - bb * _h(mean)
+        lim = 1e-5 * float((np.abs(gr * db / cnt) + np.abs(bb * _h(mean))).max()) + 1e-30
+        assert float(np.abs(cf[2] - c0).max()) <= lim, '%s: C0 off by %.2e (limit %.2e)' % (fn, float(np.abs(cf[2] - c0).max()), lim)
+
+    def _chk_fte_se_bn_bwd_apply(self, g, z, coef, gate, dsq, dz, n, hw, c, flags, st):
+        cf = _h(coef).reshape(3, c)
+        dyb = self._nhwc(g, n, hw, c) * _h(gate).reshape(n, 1, c) + _h(dsq).reshape(n, 1, c) / hw
+        ref = cf[0] * dyb + cf[1] * self._nhwc(z, n, hw, c) + cf[2]
+        self._ok('fte_se_bn_bwd_apply', 'dz', self._nhwc(dz, n, hw, c), ref, stored16=bool(flags & 1))
+
+    def _chscale_fwd(self, fn, x, gate, y, n, hw, c, s16):
+        self._ok(fn, 'y', self._nhwc(y, n, hw, c), self._nhwc(x, n, hw, c) * _h(gate).reshape(n, 1, c), stored16=s16)
+
+    def _chk_fte_channel_scale_fwd(self, x, gate, y, n, hw, c, st):
+        self._chscale_fwd('fte_channel_scale_fwd', x, gate, y, n, hw, c, False)
+
+    def _chk_fte_channel_scale_fwd_s16(self, x, gate, y, n, hw, c, st):
+        self._chscale_fwd('fte_channel_scale_fwd_s16', x, gate, y, n, hw, c, True)
+
+    def _dgate(self, fn, dy, x, gate, dgate, n, hw, c, pre_sigmoid):
+        d, xx, gt = self._nhwc(dy, n, hw, c), self._nhwc(x, n, hw, c), _h(gate).reshape(n, c)
+        ref = (d * xx).sum(1)
+        terms = np.abs(d * xx).sum(1)
+        if pre_sigmoid:
+            ref, terms = ref * gt * (1 - gt), terms * gt * (1 - gt)
+        lim = 2e-6 * float(terms.max()) + 1e-30
+        err = float(np.abs(_h(dgate).reshape(n, c) - ref).max())
+        self.worst[fn] = max(self.worst.get(fn, 0.0), err / lim)
+        assert err <= lim, '%s: dgate off by %.2e (limit %.2e)' % (fn, err, lim)
+
+    def _chk_fte_channel_scale_bwd(self, dy, x, gate, dx, dgate, n, hw, c, pre_sigmoid, st):
+        self._dgate('fte_channel_scale_bwd', dy, x, gate, dgate, n, hw, c, pre_sigmoid)
+        if dx is not None:
+            self._ok('fte_channel_scale_bwd', 'dx', self._nhwc(dx, n, hw, c), self._nhwc(dy, n, hw, c) * _h(gate).reshape(n, 1, c))
+
+    def _chk_fte_channel_scale_bwd_s16(self, dy, x, gate, dgate, n, hw, c, pre_sigmoid, st):
+        self._dgate('fte_channel_scale_bwd_s16', dy, x, gate, dgate, n, hw, c, pre_sigmoid)
+
+    def _chk_fte_channel_scale_bwd_apply_s16(self, dy, gate, dsq, dx, n, hw, c, scale, st):
+        ref = self._nhwc(dy, n, hw, c) * _h(gate).reshape(n, 1, c) + _h(dsq).reshape(n, 1, c) * scale
+        self._ok('fte_channel_scale_bwd_apply_s16', 'dx', self._nhwc(dx, n, hw, c), ref, stored16=True)
+
+    def _chk_fte_bcast_add(self, dx, v, n, hw, c, scale, st):
+        pass        # in place: checked through fte_channel_scale_bwd's dx and the block's BN backward (the input is gone)
+
+    def _relu_bwd(self, fn, dy, y, g):
+        ref = _h(dy) * (_h(y) > 0)
+        assert np.array_equal(_h(g).reshape(ref.shape), ref), '%s: g != dy * (y > 0) exactly' % fn      # a product with 0 / 1: no rounding
+        self.worst[fn] = max(self.worst.get(fn, 0.0), 0.0)
+
+    def _chk_fte_relu_bwd(self, dy, y, g, n, st):
+        self._relu_bwd('fte_relu_bwd', dy, y, g)
+
+    def _chk_fte_relu_bwd_s16(self, dy, y, g, n, st):
+        self._relu_bwd('fte_relu_bwd_s16', dy, y, g)
+
+    def _bn_infer(self, fn, z, gamma, beta, mm, mv, res, y, scale, shift, rows, c, eps, relu, out16):
+        sc = _h(gamma) / np.sqrt(_h(mv) + eps)
+        sh = _h(beta) - _h(mm) * sc
+        self._ok(fn, 'scale', _h(scale), sc, tol=1e-6)
+        self._ok(fn, 'shift', _h(shift), sh, tol=1e-6) if float(np.abs(sh).max()) > 0 else None
+        v = _h(z).reshape(rows, c) * sc + sh
+        if res is not None:
+            v = v + _h(res).reshape(rows, c)
+        if relu:
+            v = np.maximum(v, 0)
+        self._ok(fn, 'y', _h(y).reshape(rows, c), v, stored16=out16)
+
+    def _chk_fte_bn_infer_fwd(self, z, gamma, beta, mm, mv, res, y, scale, shift, rows, c, eps, relu, st):
+        self._bn_infer('fte_bn_infer_fwd', z, gamma, beta, mm, mv, res, y, scale, shift, rows, c, eps, relu, False)
+
+    def _chk_fte_bn_infer_fwd_s16(self, z, gamma, beta, mm, mv, res, y, scale, shift, rows, c, eps, relu, flags, st):
+        self._bn_infer('fte_bn_infer_fwd_s16', z, gamma, beta, mm, mv, res, y, scale, shift, rows, c, eps, relu, bool(flags & 2))
+
+    @staticmethod
+    def _gather(a, b, table, rows, ca, cb, sa=None, sb=None):
+        """out[row, k] = table[k] < 0 ? 0 : (table[k] >> 16 ? b : a)[row, table[k] & 0xffff], a source with (scale, shift, relu) normalised on the way"""
+        t = table.cpu().numpy().astype(np.int64)
+        srcs = []
+        for src, cs, aff in ((a, ca, sa), (b, cb, sb)):
+            if src is None:
+                srcs.append(None)
+                continue
+            v = _h(src).reshape(rows, cs)
+            if aff is not None and aff[0] is not None:
+                v = v * _h(aff[0]) + _h(aff[1])
+                if aff[2]:
+                    v = np.maximum(v, 0)
+            srcs.append(v)
+        out = np.zeros((rows, len(t)))
+        for k, e in enumerate(t):
+            if e >= 0:
+                out[:, k] = srcs[e >> 16][:, e & 0xffff]
+        return out
+
+    def _chk_fte_channel_gather(self, a, b, out, table, rows, ca, cb, co, st):
+        ref = self._gather(a, b, table, rows, ca, cb)
+        assert np.array_equal(_h(out).reshape(rows, co), ref), 'fte_channel_gather: not the table\'s permutation'
+        self.worst['fte_channel_gather'] = 0.0
+
+    def _chk_fte_channel_gather_s16(self, a, b, out, table, rows, ca, cb, co, st):
+        ref = self._gather(a, b, table, rows, ca, cb)
+        assert np.array_equal(_h(out).reshape(rows, co), ref), 'fte_channel_gather_s16: not the table\'s permutation'
+        self.worst['fte_channel_gather_s16'] = 0.0
+
+    def _gather_affine(self, fn, a, b, out, table, co, out1, table1, co1, rows, ca, cb, sca, sha, ra, scb, shb, rb, s16):
+        for o, t, cw in ((out, table, co), (out1, table1, co1)):
+            if o is None:
+                continue
+            ref = self._gather(a, b, t, rows, ca, cb, (sca, sha, ra), (scb, shb, rb))
+            self._ok(fn, 'out', _h(o).reshape(rows, cw), ref, stored16=s16)
+
+    def _chk_fte_channel_gather_affine(self, a, b, out, table, co, out1, table1, co1, rows, ca, cb, sca, sha, ra, scb, shb, rb, st):
+        self._gather_affine('fte_channel_gather_affine', a, b, out, table, co, out1, table1, co1, rows, ca, cb, sca, sha, ra, scb, shb, rb, False)
+
+    def _chk_fte_channel_gather_affine_s16(self, a, b, out, table, co, out1, table1, co1, rows, ca, cb, sca, sha, ra, scb, shb, rb, st):
+        self._gather_affine('fte_channel_gather_affine_s16', a, b, out, table, co, out1, table1, co1, rows, ca, cb, sca, sha, ra, scb, shb, rb, True)
+
+    def _maxpool_fwd(self, fn, x, y, idx, n, h, wd, c):
+        xx = _h(x).reshape(n, h, wd, c)
+        for i in range(0, n, IMG_BLOCK):
+            ref, cache = ops.maxpool3x3s2_fwd(xx[i:i + IMG_BLOCK])
+            assert np.array_equal(_h(y).reshape((n,) + ref.shape[1:])[i:i + IMG_BLOCK], ref), '%s: y is not the window maximum' % fn      # a selection: exact
+            assert np.array_equal(idx.reshape((n,) + ref.shape[1:])[i:i + IMG_BLOCK].cpu().numpy(), cache['arg']), '%s: idx is not the FIRST maximum' % fn
+        self.worst[fn] = 0.0
+
+    def _chk_fte_maxpool3x3s2_fwd(self, x, y, idx, n, h, wd, c, st):
+        self._maxpool_fwd('fte_maxpool3x3s2_fwd', x, y, idx, n, h, wd, c)
+
+    def _chk_fte_maxpool3x3s2_fwd_s16(self, x, y, idx, n, h, wd, c, st):
+        self._maxpool_fwd('fte_maxpool3x3s2_fwd_s16', x, y, idx, n, h, wd, c)
+
+    def _maxpool_bwd(self, fn, dy, idx, dx, n, h, wd, c, s16):
+        ho, wo = ops.same_pads(h, 3, 2)[0], ops.same_pads(wd, 3, 2)[0]
+        d, ii = _h(dy).reshape(n, ho, wo, c), idx.reshape(n, ho, wo, c).cpu().numpy().astype(np.int64)
+        pt, pl = ops.same_pads(h, 3, 2)[1], ops.same_pads(wd, 3, 2)[1]
+        for i in range(0, n, IMG_BLOCK):
+            m = min(IMG_BLOCK, n - i)
+            ref = ops.maxpool3x3s2_bwd(d[i:i + m], dict(arg=ii[i:i + m], shape=(m, h, wd, c), pads=(pt, pl)))
+            self._ok(fn, 'dx', _h(dx).reshape(n, h, wd, c)[i:i + m], ref, stored16=s16)
+
+    def _chk_fte_maxpool3x3s2_bwd(self, dy, idx, dx, n, h, wd, c, st):
+        self._maxpool_bwd('fte_maxpool3x3s2_bwd', dy, idx, dx, n, h, wd, c, False)
+
+    def _chk_fte_maxpool3x3s2_bwd_s16(self, dy, idx, dx, n, h, wd, c, st):
+        self._maxpool_bwd('fte_maxpool3x3s2_bwd_s16', dy, idx, dx, n, h, wd, c, True)
+
+    def _chk_fte_gap_fwd(self, x, y, n, hw, c, st):
+        self._ok('fte_gap_fwd', 'y', _h(y).reshape(n, c), self._nhwc(x, n, hw, c).mean(1))
+
+    def _chk_fte_gap_fwd_s16(self, x, y, n, hw, c, st):
+        self._ok('fte_gap_fwd_s16', 'y', _h(y).reshape(n, c), self._nhwc(x, n, hw, c).mean(1))
+
+    def _chk_fte_gap_bwd(self, dy, dx, n, hw, c, st):
+        self._ok('fte_gap_bwd', 'dx', self._nhwc(dx, n, hw, c), np.broadcast_to(_h(dy).reshape(n, 1, c) / hw, (n, hw, c)))
+
+    def _chk_fte_gap_bwd_s16(self, dy, dx, n, hw, c, st):
+        self._ok('fte_gap_bwd_s16', 'dx', self._nhwc(dx, n, hw, c), np.broadcast_to(_h(dy).reshape(n, 1, c) / hw, (n, hw, c)), stored16=True)
+
+    def _im2col(self, fn, x, cols, n, h, wd, cin, k, stride, kpad, s16):
+        """cols[n*ho*wo, kpad]: k ordered (r, s, c) like the HWIO weight rows, zero columns behind k*k*cin (fte.h)"""
+        xx = _h(x).reshape(n, h, wd, cin)
+        ho, pt, _ = ops.same_pads(h, k, stride)
+        wo, pl, _ = ops.same_pads(wd, k, stride)
+        got = _h(cols).reshape(n, ho, wo, kpad)
+        assert not got[..., k * k * cin:].any(), '%s: padding columns are not zero' % fn
+        xp = np.zeros((n, h + k, wd + k, cin))
+        xp[:, pt:pt + h, pl:pl + wd] = xx
+        for r in range(k):
+            for s in range(k):
+                ref = xp[:, r:r + (ho - 1) * stride + 1:stride, s:s + (wo - 1) * stride + 1:stride, :]
+                self._ok(fn, 'tap (%d, %d)' % (r, s), got[..., (r * k + s) * cin:(r * k + s + 1) * cin], ref, stored16=s16, tol=1e-7 if not s16 else TOL)
+
+    def _chk_fte_im2col_first(self, x, cols, n, h, wd, cin, k, stride, kpad, st):
+        self._im2col('fte_im2col_first', x, cols, n, h, wd, cin, k, stride, kpad, False)
+
+    def _chk_fte_im2col_first_s16(self, x, cols, n, h, wd, cin, k, stride, kpad, st):
+        self._im2col('fte_im2col_first_s16', x, cols, n, h, wd, cin, k, stride, kpad, True)
+
+    def _chk_fte_dropout_fwd(self, x, mask, y, n, keep, seed, st):
+        m = _h(mask)
+        assert np.isin(m, (0.0, 1.0)).all() and abs(float(m.mean()) - keep) < 0.02, 'fte_dropout_fwd: the mask is not a Bernoulli(keep) 0 / 1 field'
+        self._ok('fte_dropout_fwd', 'y', _h(y), ops.dropout_fwd(_h(x), m, keep), tol=1e-6)
+
+    def _chk_fte_dropout_bwd(self, dy, mask, dx, n, keep, st):
+        self._ok('fte_dropout_bwd', 'dx', _h(dx), _h(dy) * _h(mask) / keep, tol=1e-6)
+
+    def _chk_fte_pack_weights_bf16_table(self, params, dst, table, nconv, total, transposed, st):
+        """rows {source offset (floats), destination offset (bf16 elements), taps, cin, cout, ...}: HWIO packs, or [tap][cout][cin]"""
+        t = table.cpu().numpy().reshape(nconv, -1)
+        p, d = _h(params), _h(dst)
+        for src, off, taps, cin, cout in t[:, :5]:
+            w = _bf(p[src:src + taps * cin * cout]).reshape(taps, cin, cout)
+            ref = w.transpose(0, 2, 1) if transposed else w
+            assert np.array_equal(d[off:off + taps * cin * cout].reshape(ref.shape), ref), 'fte_pack_weights_bf16_table: pack at %d is not bf16(w)' % off
+        self.worst['fte_pack_weights_bf16_table'] = 0.0
+
+    def _chk_fte_act_fwd(self, x, y, n, kind, st):
+        pass        # in place on the gate's [n, c] vectors: covered by fte_gemm_nn_act where fused; the unfused form is an A/B hook
+
+    def _chk_fte_act_bwd(self, dy, y, dx, n, kind, st):
+        pass        # in place (dx is dy): checked through the dense product that follows it
+
+    def _chk_fte_batch_hard_triplet_fwd_bwd(self, feat, labels, margin, soft, lw, rows, dfeat, n, d, ws, wsb, st):
+        per, df = ops.batch_hard_triplet(_h(feat).reshape(n, d), labels.cpu().numpy().astype(np.int64), None if soft else margin)
+        self._ok('fte_batch_hard_triplet_fwd_bwd', 'loss rows', _h(rows), per, tol=1e-5)
+        self._ok('fte_batch_hard_triplet_fwd_bwd', 'dfeat', _h(dfeat).reshape(n, d), df * lw, tol=2e-5, rell2=True)
+
+    def _chk_fte_center_loss_fwd_bwd_update(self, feat, labels, centers, rows, dfeat, n, d, ncls, alpha, lw, ws, wsb, st):
+        pass        # updates `centers` in place: the input table is gone after the call (tests/test_gpu_configs34.py checks it at this shard)
+
+    def _chk_fte_softmax_ce_fwd_bwd(self, logits, labels, rows, dlogits, n, c, ld, gs, st):
+        lg = _h(logits).reshape(n, ld)[:, :c]
+        y = labels.cpu().numpy().astype(np.int64)
+        m = lg.max(1, keepdims=True)
+        lse = m[:, 0] + np.log(np.exp(lg - m).sum(1))
+        self._ok('fte_softmax_ce_fwd_bwd', 'loss rows', _h(rows), lse - lg[np.arange(n), y], tol=1e-5)
+        p = np.exp(lg - lse[:, None])
+        p[np.arange(n), y] -= 1
+        self._ok('fte_softmax_ce_fwd_bwd', 'dlogits', _h(dlogits).reshape(n, ld)[:, :c], p * gs, tol=2e-5, rell2=True)
+
+
+# kernel FAMILIES (symbol names without template arguments, as rocprofv3 prints them) that each entry point's checked call ran, for
+# the kernels that leave no launch record (everything outside the MFMA families): read off the launchers in csrc/layers.hip /
+# kernels.hip.  tests/test_gpu_fullshard.py requires every symbol with >= 1 % of a profiled step's kernel time to be covered by a
+# launch record of a checked call or by this table.
+ENTRY_KERNELS = {
+    'fte_conv2d_bn_fwd': ['bn_finalize_kernel', 'bn_finalize_wide_kernel'],
+    'fte_gconv3x3_bn_fwd_bf16_s16': ['gconv3x3_mfma16_win_kernel', 'gconv3x3_mfma16_kernel', 'bn_finalize_kernel', 'bn_finalize_wide_kernel'],
+    'fte_gconv3x3_bf16_s16': ['gconv3x3_mfma16_win_kernel', 'gconv3x3_mfma16_kernel'],
+    'fte_gconv3x3_wgrad_bf16_s16': ['gconv3x3_wgrad_mfma16_kernel', 'gconv_wgrad16_reduce_kernel'],
+    'fte_bn_apply': ['bn_apply_kernel'],
+    'fte_bn_train_fwd': ['bn_stats_v4_kernel', 'bn_stats_kernel', 'bn_finalize_kernel', 'bn_apply_kernel'],
+    'fte_bn_train_fwd_s16': ['bn_stats_v4_kernel', 'bn_finalize_kernel', 'bn_apply_kernel'],
+    'fte_bn_train_stats': ['bn_stats_v4_kernel', 'bn_stats_kernel', 'bn_finalize_kernel'],
+    'fte_bn_train_bwd': ['bn_bwd_reduce_v4_kernel', 'bn_bwd_reduce_kernel', 'bn_bwd_finalize_kernel', 'bn_bwd_finalize_wide_kernel', 'bn_bwd_apply_kernel'],
+    'fte_bn_train_bwd_s16': ['bn_bwd_reduce_v4_kernel', 'bn_bwd_finalize_kernel', 'bn_bwd_finalize_wide_kernel', 'bn_bwd_apply_kernel'],
+    'fte_bn_train_bwd_res': ['bn_bwd_reduce_v4_kernel', 'bn_bwd_reduce_kernel', 'bn_bwd_finalize_kernel', 'bn_bwd_apply_kernel'],
+    'fte_bn_train_bwd_zmask': ['bn_bwd_reduce_v4_kernel', 'bn_bwd_reduce_kernel', 'bn_bwd_finalize_kernel', 'bn_bwd_apply_kernel'],
+    'fte_bn_infer_fwd': ['bn_infer_coef_kernel', 'bn_apply_kernel'], 'fte_bn_infer_fwd_s16': ['bn_infer_coef_kernel', 'bn_apply_kernel'],
+    'fte_conv2d_wgrad': ['reduce_slabs_kernel', 'reduce_rows_kernel', 'reduce_rows_q_kernel'],
+    'fte_conv2d_wgrad16': ['reduce_slabs_kernel', 'reduce_rows_kernel', 'reduce_rows_q_kernel'],
+    'fte_conv2d_dgrad': ['reduce_rows_kernel', 'reduce_rows_q_kernel'], 'fte_conv2d_dgrad_s16': ['reduce_rows_kernel', 'reduce_rows_q_kernel'],
+    'fte_gemm_nn': ['reduce_slabs_kernel', 'reduce_rows_kernel'], 'fte_gemm_nn_act': ['reduce_slabs_kernel', 'reduce_rows_kernel'],
+    'fte_gemm_nt': ['reduce_slabs_kernel', 'reduce_rows_kernel'], 'fte_gemm_tn': ['reduce_slabs_kernel', 'reduce_rows_kernel'],
+    'fte_dwconv3x3_fwd': ['dwconv3x3_win_kernel', 'dwconv3x3_kernel'],
+    'fte_dwconv3x3_dgrad': ['dwconv3x3_win_kernel', 'dwconv3x3_kernel', 'dwconv3x3_dgrad_s2_kernel'],
+    'fte_dwconv3x3_wgrad': ['dwconv3x3_wgrad_kernel', 'reduce_rows_kernel', 'reduce_rows_q_kernel', 'reduce_slabs_kernel'],
+    'fte_se_squeeze': ['se_squeeze_kernel'], 'fte_se_apply_fwd': ['se_apply_kernel'], 'fte_se_bwd_gate': ['se_bwd_gate_kernel'],
+    'fte_se_bn_bwd_coef': ['se_bn_coef_kernel'], 'fte_se_bn_bwd_apply': ['se_bn_apply_kernel'],
+    'fte_channel_scale_fwd': ['chscale_fwd_kernel'], 'fte_channel_scale_fwd_s16': ['chscale_fwd_kernel'],
+    'fte_channel_scale_bwd': ['chscale_bwd_kernel'], 'fte_channel_scale_bwd_s16': ['chscale_bwd_kernel'],
+    'fte_channel_scale_bwd_apply_s16': ['chscale_bwd_apply_kernel'],
+    'fte_relu_bwd': ['relu_bwd_kernel'], 'fte_relu_bwd_s16': ['relu_bwd_kernel'],
+    'fte_channel_gather': ['channel_gather_kernel'], 'fte_channel_gather_s16': ['channel_gather_kernel'],
+    'fte_channel_gather_affine': ['channel_gather_affine_kernel'], 'fte_channel_gather_affine_s16': ['channel_gather_affine_kernel'],
+    'fte_maxpool3x3s2_fwd': ['maxpool_fwd_kernel'], 'fte_maxpool3x3s2_fwd_s16': ['maxpool_fwd_kernel'],
+    'fte_maxpool3x3s2_bwd': ['maxpool_bwd_kernel', 'maxpool_bwd_even_kernel'], 'fte_maxpool3x3s2_bwd_s16': ['maxpool_bwd_kernel', 'maxpool_bwd_even_kernel'],
+    'fte_gap_fwd': ['gap_fwd_kernel'], 'fte_gap_fwd_s16': ['gap_fwd_kernel'], 'fte_gap_bwd': ['gap_bwd_kernel'], 'fte_gap_bwd_s16': ['gap_bwd_kernel'],
+    'fte_im2col_first': ['im2col_first_kernel', 'im2col_first_rows_kernel'], 'fte_im2col_first_s16': ['im2col_first_kernel', 'im2col_first_rows_kernel'],
+    'fte_dropout_fwd': ['dropout_fwd_kernel'], 'fte_dropout_bwd': ['scale_mask_kernel'],
+    'fte_pack_weights_bf16_table': ['pack_weights_table_kernel'],
+    'fte_batch_hard_triplet_fwd_bwd': ['triplet_dist_kernel', 'triplet_mine_kernel', 'triplet_grad_kernel'],
+    'fte_softmax_ce_fwd_bwd': ['softmax_ce_reg_kernel', 'softmax_ce_kernel'],
+}

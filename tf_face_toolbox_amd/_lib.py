@@ -87,6 +87,11 @@ _SIGS = {
     'fte_channel_scale_fwd_s16': (c_int, [_P] * 3 + [c_int] * 3 + [_P]),
     'fte_channel_scale_bwd_s16': (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
     'fte_channel_scale_bwd_apply_s16': (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P]),
+    'fte_se_squeeze': (c_int, [_P] * 7 + [c_int] * 4 + [_P]),
+    'fte_se_apply_fwd': (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
+    'fte_se_bwd_gate': (c_int, [_P] * 12 + [c_int] * 4 + [_P]),
+    'fte_se_bn_bwd_coef': (c_int, [_P] * 11 + [c_int] * 3 + [_P]),
+    'fte_se_bn_bwd_apply': (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
     'fte_dwconv3x3_fwd_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_dgrad_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_wgrad_s16': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),

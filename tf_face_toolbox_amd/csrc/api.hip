@@ -1503,6 +1503,34 @@ int fte_channel_scale_bwd_apply_s16(const uint16_t* dy16, const float* gate, con
     return rc(l_chscale_bwd_apply(f32p(dy16), gate, dsq, f32p(dx16), n, hw, c, scale, (hipStream_t)stream, 1));
 }
 
+// the SE residual block, fused (layers.hip "SE residual block")
+static bool se_args_ok(int n, int hw, int c, int flags) { return n > 0 && hw > 0 && c > 0 && c % 4 == 0 && !(flags & ~3) && (!flags || c >= 32); }
+int fte_se_squeeze(const void* z, const float* scale, const float* shift, const float* mean, const float* rstd, float* sq, float* xm,
+                   int n, int hw, int c, int flags, void* stream) {
+    if (!z || !scale || !shift || !sq || (xm && (!mean || !rstd)) || !se_args_ok(n, hw, c, flags)) return FTE_EINVAL;
+    return rc(l_se_squeeze(f32p(z), scale, shift, mean, rstd, sq, xm, n, hw, c, (hipStream_t)stream, flags));
+}
+int fte_se_apply_fwd(const void* z, const float* scale, const float* shift, const float* gate, const void* shortcut, void* out,
+                     int n, int hw, int c, int flags, void* stream) {
+    if (!z || !scale || !shift || !gate || !shortcut || !out || !se_args_ok(n, hw, c, flags)) return FTE_EINVAL;
+    return rc(l_se_apply(f32p(z), scale, shift, gate, f32p(shortcut), f32p(out), n, hw, c, (hipStream_t)stream, flags));
+}
+int fte_se_bwd_gate(const void* dy, const void* out, const void* z, const float* gamma, const float* beta, const float* mean,
+                    const float* rstd, const float* gate, void* g, float* s1, float* s2, float* dgate, int n, int hw, int c, int flags, void* stream) {
+    if (!dy || !out || !z || !gamma || !beta || !mean || !rstd || !gate || !g || !s1 || !s2 || !dgate || !se_args_ok(n, hw, c, flags)) return FTE_EINVAL;
+    return rc(l_se_bwd_gate(f32p(dy), f32p(out), f32p(z), gamma, beta, mean, rstd, gate, f32p(g), s1, s2, dgate, n, hw, c, (hipStream_t)stream, flags));
+}
+int fte_se_bn_bwd_coef(const float* s1, const float* s2, const float* gate, const float* dsq, const float* xm, const float* gamma,
+                       const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int n, int hw, int c, void* stream) {
+    if (!s1 || !s2 || !gate || !dsq || !xm || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef || !se_args_ok(n, hw, c, 0)) return FTE_EINVAL;
+    return rc(l_se_bn_coef(s1, s2, gate, dsq, xm, gamma, mean, rstd, dgamma, dbeta, coef, n, hw, c, (hipStream_t)stream));
+}
+int fte_se_bn_bwd_apply(const void* g, const void* z, const float* coef, const float* gate, const float* dsq, void* dz,
+                        int n, int hw, int c, int flags, void* stream) {
+    if (!g || !z || !coef || !gate || !dsq || !dz || !se_args_ok(n, hw, c, flags)) return FTE_EINVAL;
+    return rc(l_se_bn_apply(f32p(g), f32p(z), coef, gate, dsq, f32p(dz), n, hw, c, (hipStream_t)stream, flags));
+}
+
 // ------------------------------------------------------------------------------------------------
 // ShuffleNet-v2: depthwise 3x3, channel gather
 int fte_dwconv3x3_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int stride, void* stream) {

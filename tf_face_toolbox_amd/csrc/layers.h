@@ -49,6 +49,18 @@ hipError_t l_gconv_wgrad(const float* x, const float* dz, float* part, int n, in
                          int stride, int pt, int pl, int chunks, hipStream_t st);
 hipError_t l_act_fwd(const float* x, float* y, long n, int kind, hipStream_t st);
 hipError_t l_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, hipStream_t st);
+// the SE residual block in one forward and two backward passes (layers.hip "SE residual block"); flags: bit 0 z / dz bf16, bit 1 activations bf16
+hipError_t l_se_squeeze(const float* z, const float* scale, const float* shift, const float* mean, const float* rstd, float* sq, float* xm,
+                        int n, int hw, int c, hipStream_t st, int flags);
+hipError_t l_se_apply(const float* z, const float* scale, const float* shift, const float* gate, const float* res, float* out,
+                      int n, int hw, int c, hipStream_t st, int flags);
+hipError_t l_se_bwd_gate(const float* dy, const float* out, const float* z, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, const float* gate, float* g, float* s1, float* s2, float* dgate, int n, int hw, int c,
+                         hipStream_t st, int flags);
+hipError_t l_se_bn_coef(const float* s1, const float* s2, const float* gate, const float* dsq, const float* xm, const float* gamma,
+                        const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int n, int hw, int c, hipStream_t st);
+hipError_t l_se_bn_apply(const float* g, const float* z, const float* coef, const float* gate, const float* dsq, float* dz,
+                         int n, int hw, int c, hipStream_t st, int flags);
 hipError_t l_chscale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, hipStream_t st, int h16 = 0);
 hipError_t l_chscale_bwd_apply(const float* dy, const float* gate, const float* dsq, float* dx, int n, int hw, int c, float scale, hipStream_t st, int h16 = 0);
 hipError_t l_chscale_bwd(const float* dy, const float* x, const float* gate, float* dx, float* dgate, int n, int hw, int c,

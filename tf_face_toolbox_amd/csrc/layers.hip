@@ -2197,6 +2197,231 @@ hipError_t l_chscale_bwd_apply(const float* dy, const float* gate, const float* 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// SE residual block in one forward pass over the tensor and two backward passes (round 5).  The block of nets/resnet.py:63-92 with the
+// gate of nets/shufflenet_v2.py:79-85 is  z -> y = BN(z) (no activation) -> s = y * gate(mean_hw y) -> out = relu(s + shortcut).  As
+// separate ops that was bn_apply (R z, W y), gap (R y), channel_scale (R y, W s), add + ReLU (R s, R shortcut, W out) forward and
+// relu_bwd, channel_scale_bwd, channel_scale_bwd_apply, BN reduce, BN apply backward: 7 + 12 passes over the block's tensor.  Here y and
+// s never exist in HBM:
+//   forward   se_squeeze   R z            sq[n,c] = scale * mean_hw(z) + shift  (= mean_hw(y): BN without activation is affine per
+//                                         channel), xm[n,c] = mean_hw(xhat) for the backward sums
+//             (the gate's two dense layers on sq, as before)
+//             se_apply     R z, R sc, W out     out = relu(fma(z, scale, shift) * gate + shortcut)
+//   backward  se_bwd_gate  R dy, R out, R z, W g   g = dy * (out > 0) (the shortcut's gradient too); per image and channel
+//                                         S1 = sum_hw g, S2 = sum_hw g * xhat; dgate_pre = (gamma * S2 + beta * S1) * gate * (1 - gate)
+//                                         (sum_hw g * y with y = gamma * xhat + beta)
+//             (the gate's dense layers backward -> dsq[n,c], the gradient of the squeeze)
+//             se_bn_coef   [n,c] only     the BN backward sums of dy_bn = g * gate + dsq / hw from the per-image sums:
+//                                         sum dy_bn = sum_n (gate * S1 + dsq), sum dy_bn * xhat = sum_n (gate * S2 + dsq * xm)
+//                                         -> dgamma, dbeta, the coefficients of dz = A dy_bn + B z + C0 -- the BN reduce pass over the
+//                                         tensor is gone
+//             se_bn_apply  R g, R z, W dz   dz = (A * gate) g + B z + (A * dsq / hw + C0)
+// 4 + 7 passes.  Sums in a fixed order (block-local, then over the images in order): bit-identical run to run.
+// ---------------------------------------------------------------------------------------------------
+template <bool ZH>
+__global__ __launch_bounds__(256) void se_squeeze_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ sq, float* __restrict__ xm,
+                                                         int hw, int c) {
+    __shared__ f32x4 sh[16][16];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = (blockIdx.x * 16 + q) * 4, img = blockIdx.y;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (ch < c) {
+        const long px = (long)img * hw * c + ch;
+        int r = rl;
+        for (; r + 48 < hw; r += 64) {                          // four rows in flight per lane
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ldq<ZH>(z, px + (long)(r + 16 * u) * c);
+            s0 += v[0] + v[2]; s1 += v[1] + v[3];
+        }
+        for (; r < hw; r += 16) s0 += ldq<ZH>(z, px + (long)r * c);
+    }
+    sh[rl][q] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        f32x4 s = sh[0][q];
+#pragma unroll
+        for (int l = 1; l < 16; ++l) s += sh[l][q];
+        const f32x4 zm = s / (float)hw;
+        const long o = (long)img * c + ch;
+        *reinterpret_cast<f32x4*>(sq + o) = bn_affine(zm, *reinterpret_cast<const f32x4*>(scale + ch), *reinterpret_cast<const f32x4*>(shift + ch));
+        if (xm) *reinterpret_cast<f32x4*>(xm + o) = (zm - *reinterpret_cast<const f32x4*>(mean + ch)) * *reinterpret_cast<const f32x4*>(rstd + ch);
+    }
+}
+// out = relu(fma(z, scale, shift) * gate[n,c] + shortcut)      (grid and walk as chscale_fwd_kernel: a thread keeps its channel quad)
+template <bool ZH, bool AH>
+__global__ __launch_bounds__(256) void se_apply_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ gate,
+                                                       const float* __restrict__ res, float* __restrict__ out, int hwq, int cq) {
+    const int step = (int)gridDim.x * 256;
+    const long base = (long)blockIdx.y * hwq;
+    int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hwq) return;
+    const int cqi = i % cq;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gate + ((long)blockIdx.y * cq + cqi) * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + cqi * 4), sf = *reinterpret_cast<const f32x4*>(shift + cqi * 4);
+    auto f = [&](const f32x4 zz, const f32x4 rr) {
+        f32x4 v = bn_affine(zz, sc, sf) * g + rr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        return v;
+    };
+    for (; i + 3 * step < hwq; i += 4 * step) {
+        f32x4 zv[4], rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { zv[u] = ldq<ZH>(z, (base + i + u * step) * 4); rv[u] = ldq<AH>(res, (base + i + u * step) * 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stq<AH>(out, (base + i + u * step) * 4, f(zv[u], rv[u]));
+    }
+    for (; i < hwq; i += step) stq<AH>(out, (base + i) * 4, f(ldq<ZH>(z, (base + i) * 4), ldq<AH>(res, (base + i) * 4)));
+}
+// g = dy * (out > 0) (stored: with bf16 storage the STORED value is what every sum below and the apply pass see);
+// S1[n,c] = sum_hw g, S2[n,c] = sum_hw g * xhat, dgate[n,c] = (gamma * S2 + beta * S1) * gate * (1 - gate)
+template <bool ZH, bool AH>
+__global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                                                          const float* __restrict__ z, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gate,
+                                                          float* __restrict__ g, float* __restrict__ s1, float* __restrict__ s2,
+                                                          float* __restrict__ dgate, int hw, int c) {
+    __shared__ f32x4 sh[2][16][16];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = (blockIdx.x * 16 + q) * 4, img = blockIdx.y;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (ch < c) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), rs = *reinterpret_cast<const f32x4*>(rstd + ch);
+        auto one = [&](const long o, f32x4 d, const f32x4 ov, const f32x4 zz) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = ov[e] > 0.f ? d[e] : 0.f;
+            if constexpr (AH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, (__bf16)d[e]) << 16);
+            }
+            stq<AH>(g, o, d);
+            a += d;
+            b += d * ((zz - mu) * rs);
+        };
+        int r = rl;
+        for (; r + 48 < hw; r += 64) {                          // four rows of the three inputs in flight per lane
+            f32x4 d[4], ov[4], zv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long o = ((long)img * hw + r + 16 * u) * c + ch;
+                d[u] = ldq<AH>(dy, o); ov[u] = ldq<AH>(out, o); zv[u] = ldq<ZH>(z, o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(((long)img * hw + r + 16 * u) * c + ch, d[u], ov[u], zv[u]);
+        }
+        for (; r < hw; r += 16) {
+            const long o = ((long)img * hw + r) * c + ch;
+            one(o, ldq<AH>(dy, o), ldq<AH>(out, o), ldq<ZH>(z, o));
+        }
+    }
+    sh[0][rl][q] = a; sh[1][rl][q] = b;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        f32x4 t1 = sh[0][0][q], t2 = sh[1][0][q];
+#pragma unroll
+        for (int l = 1; l < 16; ++l) { t1 += sh[0][l][q]; t2 += sh[1][l][q]; }
+        const long o = (long)img * c + ch;
+        *reinterpret_cast<f32x4*>(s1 + o) = t1;
+        *reinterpret_cast<f32x4*>(s2 + o) = t2;
+        const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + o);
+        const f32x4 gy = *reinterpret_cast<const f32x4*>(gamma + ch) * t2 + *reinterpret_cast<const f32x4*>(beta + ch) * t1;      // sum_hw g * y
+        *reinterpret_cast<f32x4*>(dgate + o) = gy * gt * (1.f - gt);
+    }
+}
+// one thread per channel, the images in order: the two sums of the BN backward, then bn_bwd_finalize_channel's arithmetic
+__global__ __launch_bounds__(64) void se_bn_coef_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                        const float* __restrict__ gate, const float* __restrict__ dsq,
+                                                        const float* __restrict__ xm, const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                                        int n, int C, float count) {
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int i0 = 0; i0 < n; i0 += 8) {                         // eight images' five words in flight
+        float v1[8], v2[8], vg[8], vd[8], vx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long o = (long)min(i0 + u, n - 1) * C + ch;
+            v1[u] = s1[o]; v2[u] = s2[o]; vg[u] = gate[o]; vd[u] = dsq[o]; vx[u] = xm[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u < n) { a += vg[u] * v1[u] + vd[u]; b += vg[u] * v2[u] + vd[u] * vx[u]; }
+    }
+    dbeta[ch] = a;
+    dgamma[ch] = b;
+    const float gr = gamma[ch] * rstd[ch];
+    const float bb = -gr * rstd[ch] * b / count;
+    coef[ch] = gr;
+    coef[C + ch] = bb;
+    coef[2 * C + ch] = -gr * a / count - bb * mean[ch];
+}
+// dz = A * (g * gate + dsq / hw) + B * z + C0      (grid and walk as chscale_fwd_kernel)
+template <bool ZH, bool AH>
+__global__ __launch_bounds__(256) void se_bn_apply_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                          const float* __restrict__ coef, const float* __restrict__ gate,
+                                                          const float* __restrict__ dsq, float* __restrict__ dz, int hwq, int cq, float inv_hw) {
+    const int step = (int)gridDim.x * 256;
+    const long base = (long)blockIdx.y * hwq;
+    int i = (int)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hwq) return;
+    const int cqi = i % cq, C = cq * 4;
+    const long go = ((long)blockIdx.y * cq + cqi) * 4;
+    const f32x4 A = *reinterpret_cast<const f32x4*>(coef + cqi * 4), B = *reinterpret_cast<const f32x4*>(coef + C + cqi * 4);
+    const f32x4 ag = A * *reinterpret_cast<const f32x4*>(gate + go);
+    const f32x4 k0 = A * (*reinterpret_cast<const f32x4*>(dsq + go) * inv_hw) + *reinterpret_cast<const f32x4*>(coef + 2 * C + cqi * 4);
+    for (; i + 3 * step < hwq; i += 4 * step) {
+        f32x4 gv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { gv[u] = ldq<AH>(g, (base + i + u * step) * 4); zv[u] = ldq<ZH>(z, (base + i + u * step) * 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) stq<ZH>(dz, (base + i + u * step) * 4, ag * gv[u] + B * zv[u] + k0);
+    }
+    for (; i < hwq; i += step) stq<ZH>(dz, (base + i) * 4, ag * ldq<AH>(g, (base + i) * 4) + B * ldq<ZH>(z, (base + i) * 4) + k0);
+}
+hipError_t l_se_squeeze(const float* z, const float* scale, const float* shift, const float* mean, const float* rstd, float* sq, float* xm,
+                        int n, int hw, int c, hipStream_t st, int flags) {
+    if (c % 4) return hipErrorInvalidValue;
+    const dim3 grid((c / 4 + 15) / 16, n);
+    if (flags & 1) hipLaunchKernelGGL(se_squeeze_kernel<true>, grid, dim3(256), 0, st, z, scale, shift, mean, rstd, sq, xm, hw, c);
+    else hipLaunchKernelGGL(se_squeeze_kernel<false>, grid, dim3(256), 0, st, z, scale, shift, mean, rstd, sq, xm, hw, c);
+    return hipGetLastError();
+}
+hipError_t l_se_apply(const float* z, const float* scale, const float* shift, const float* gate, const float* res, float* out,
+                      int n, int hw, int c, hipStream_t st, int flags) {
+    if (c % 4 || (long)hw * c / 4 >= (1L << 30)) return hipErrorInvalidValue;
+    const dim3 grid = chscale_grid(n, hw, c);
+    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((se_apply_kernel<ZH, AH>), grid, dim3(256), 0, st, z, scale, shift, gate, res, out, hw * (c / 4), c / 4));
+    return hipGetLastError();
+}
+hipError_t l_se_bwd_gate(const float* dy, const float* out, const float* z, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, const float* gate, float* g, float* s1, float* s2, float* dgate, int n, int hw, int c,
+                         hipStream_t st, int flags) {
+    if (c % 4) return hipErrorInvalidValue;
+    const dim3 grid((c / 4 + 15) / 16, n);
+    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((se_bwd_gate_kernel<ZH, AH>), grid, dim3(256), 0, st, dy, out, z, gamma, beta, mean, rstd, gate, g, s1, s2, dgate, hw, c));
+    return hipGetLastError();
+}
+hipError_t l_se_bn_coef(const float* s1, const float* s2, const float* gate, const float* dsq, const float* xm, const float* gamma,
+                        const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int n, int hw, int c, hipStream_t st) {
+    hipLaunchKernelGGL(se_bn_coef_kernel, dim3((c + 63) / 64), dim3(64), 0, st, s1, s2, gate, dsq, xm, gamma, mean, rstd, dgamma, dbeta, coef,
+                       n, c, (float)((long)n * hw));
+    return hipGetLastError();
+}
+hipError_t l_se_bn_apply(const float* g, const float* z, const float* coef, const float* gate, const float* dsq, float* dz,
+                         int n, int hw, int c, hipStream_t st, int flags) {
+    if (c % 4 || (long)hw * c / 4 >= (1L << 30)) return hipErrorInvalidValue;
+    const dim3 grid = chscale_grid(n, hw, c);
+    FTE_ZA(flags & 1, flags & 2, hipLaunchKernelGGL((se_bn_apply_kernel<ZH, AH>), grid, dim3(256), 0, st, g, z, coef, gate, dsq, dz, hw * (c / 4), c / 4, 1.f / (float)hw));
+    return hipGetLastError();
+}
+
 // dx[n,hw,c] += v[n,c] * scale   (gradient of the SE squeeze: d(mean over hw) broadcast back)
 namespace {
 __global__ __launch_bounds__(256) void bcast_add_kernel(float* __restrict__ dx, const float* __restrict__ v, long n4, int hw, int c, float scale) {

@@ -51,6 +51,14 @@ class _Activations(dict):
 
     def __missing__(self, name):
         net = self.net
+        if name in getattr(net, 'se_fused', {}):         # the BN output / gated tensor of a fused SE block (never stored)
+            which, out, z = net.se_fused[name]
+            b = net.bn[out]
+            zz = self[z]
+            if zz.dtype == torch.int16:
+                zz = zz.view(torch.bfloat16).float()
+            y = torch.addcmul(b['shift'], zz, b['scale'])
+            return y if which == 'y' else y * self[out + '/gate'][:, None, None, :]
         if name not in net.folded:
             raise KeyError(name)
         z, relu = net.folded[name]
@@ -425,16 +433,16 @@ class GraphNet(Network):
         # ShuffleNet block, nets/shufflenet_v2.py:96-113) is normalised INSIDE the gather: the BN op keeps its statistics
         # pass only ('bnstats'), the gather applies scale / shift / ReLU to that source on the way
         # (fte_channel_gather_affine), and the normalised tensor is never written (FTE_BN_GATHER=0: off, A/B hook).
+        # SE residual block: BN (no activation) -> SE gate -> add shortcut -> ReLU becomes ONE plan op whose kernels read the BN's input z
+        # and write the block's output; the BN output and the gated tensor never exist (csrc/layers.hip "SE residual block",
+        # fte_se_*).  FTE_SE_FUSE=0: the separate ops (A/B hook).
+        self.se_fused = {}
+        if os.environ.get('FTE_SE_FUSE', '1') != '0':
+            plan = self._fuse_se_blocks(plan)
         self.folded = {}
         pusers = {}
         for j, op in enumerate(plan):
-            if op[0] == 'gather':
-                ins = [x for x in op[2]['ins'] if x is not None]
-            elif op[0] in ('bn', 'addrelu'):
-                ins = [op[2]] + ([op[4]] if op[0] == 'bn' and op[4] is not None else []) + ([op[3]] if op[0] == 'addrelu' else [])
-            else:
-                ins = self._inputs(op)
-            for x in ins:
+            for x in self._plan_inputs(op):
                 pusers.setdefault(x, []).append(j)
         if os.environ.get('FTE_BN_GATHER', '1') != '0':
             for j, op in enumerate(plan):
@@ -460,7 +468,7 @@ class GraphNet(Network):
         if os.environ.get('FTE_BN_FUSE', '1') != '0':
             producer = {op[1]: j for j, op in enumerate(plan) if op[0] in ('conv', 'gconv')}
             for j, op in enumerate(plan):
-                if op[0] not in ('bn', 'bnstats'):
+                if op[0] not in ('bn', 'bnstats', 'seblock'):
                     continue
                 i = producer.get(op[2])
                 if i is not None and pusers.get(op[2], []) == [j]:
@@ -496,7 +504,8 @@ class GraphNet(Network):
                 if len(us) != 1 or op[1] == self.feature_name:
                     continue
                 cons = plan[us[0]]
-                as_res = (cons[0] == 'bn' and cons[4] == op[1] and cons[2] != op[1]) or (cons[0] == 'addrelu' and op[1] in (cons[2], cons[3]))
+                as_res = (cons[0] == 'bn' and cons[4] == op[1] and cons[2] != op[1]) or (cons[0] == 'addrelu' and op[1] in (cons[2], cons[3])) or \
+                    (cons[0] == 'seblock' and cons[4] == op[1] and cons[2] != op[1])
                 i = producer.get(op[2])
                 if as_res and i is not None and pusers.get(op[2], []) == [j] and i == j - 1:
                     self.shortcut_fwd[i] = True
@@ -510,6 +519,46 @@ class GraphNet(Network):
             return [op[2], op[3]]
         return [op[2]]
 
+    def _plan_inputs(self, op):
+        """tensors a PLAN op reads"""
+        if op[0] == 'gather':
+            return [x for x in op[2]['ins'] if x is not None]
+        if op[0] == 'bn':
+            return [op[2]] + ([op[4]] if op[4] is not None else [])
+        if op[0] == 'addrelu':
+            return [op[2], op[3]]
+        if op[0] == 'seblock':
+            return [op[2], op[4]]
+        return self._inputs(op)
+
+    def _fuse_se_blocks(self, plan):
+        """('bn', y, z, pre, None, 0) -> ('se', s, y, ...) -> ('addrelu', out, s, shortcut), each the only user of its input, becomes
+        ('seblock', out, z, pre, shortcut, se op, y, s) at the add's place (nets/resnet.py:63-92 with use_se)."""
+        users = {}
+        for j, op in enumerate(plan):
+            for x in self._plan_inputs(op):
+                users.setdefault(x, []).append(j)
+        drop, repl = set(), {}
+        for j, op in enumerate(plan):
+            if op[0] != 'bn' or op[4] is not None or op[5] or len(self.shapes[op[1]]) != 3 or op[1] == self.feature_name:
+                continue
+            u = users.get(op[1], [])
+            if len(u) != 1 or plan[u[0]][0] != 'se' or plan[u[0]][2] != op[1]:
+                continue
+            se = plan[u[0]]
+            u2 = users.get(se[1], [])
+            if len(u2) != 1 or plan[u2[0]][0] != 'addrelu' or se[1] == self.feature_name:
+                continue
+            ar = plan[u2[0]]
+            sc = ar[3] if ar[2] == se[1] else ar[2]
+            if sc == se[1] or self.shapes[sc] != self.shapes[op[1]] or self.shapes[op[1]][-1] % 4:
+                continue
+            repl[u2[0]] = ('seblock', ar[1], op[2], op[3], sc, se, op[1], se[1])
+            drop.update([j, u[0]])
+            self.se_fused[op[1]] = ('y', ar[1], op[2])
+            self.se_fused[se[1]] = ('s', ar[1], op[2])
+        return [repl.get(j, op) for j, op in enumerate(plan) if j not in drop]
+
     def _defined_before(self, name, idx):
         if name == 'images':
             return True
@@ -520,7 +569,7 @@ class GraphNet(Network):
         return False
 
     # ---- buffers --------------------------------------------------------------------------------------
-    S16_OPS = ('conv', 'bn', 'bnstats', 'gconv', 'dwconv', 'gather', 'se', 'maxpool', 'addrelu', 'gap', 'dropout', 'fc')
+    S16_OPS = ('conv', 'bn', 'bnstats', 'gconv', 'dwconv', 'gather', 'se', 'seblock', 'maxpool', 'addrelu', 'gap', 'dropout', 'fc')
 
     def _storage16(self):
         """bf16 STORAGE ('bf16s', fte.h): the tensors between the layers live in HBM as bf16 -- implemented for the op sets of the ResNet
@@ -552,7 +601,7 @@ class GraphNet(Network):
         self.h16 = set()
         if s16:
             for op in self.plan:
-                if op[0] in ('gconv', 'dwconv', 'se', 'maxpool', 'addrelu') or (op[0] == 'bn' and len(self.shapes[op[1]]) == 3):
+                if op[0] in ('gconv', 'dwconv', 'se', 'seblock', 'maxpool', 'addrelu') or (op[0] == 'bn' and len(self.shapes[op[1]]) == 3):
                     self.h16.add(op[1])          # (a batch norm behind the pooling has a rank-1 output: the features stay fp32)
                 elif op[0] == 'conv':          # every conv writes bf16: the MFMA convs, the direct 3x3 stem, and the im2col stem (a 1x1 conv
                     self.h16.add(op[1])        # of `kpad` bf16 columns on the bf16-source kernels)
@@ -561,6 +610,8 @@ class GraphNet(Network):
             self._pack_entries = []
         # tensors whose GRADIENT is stored as bf16: the stored ones and the BN outputs folded into a gather (never stored themselves)
         self.g16 = set(self.h16) | (set(self.folded) if s16 else set())
+        if s16:          # ... and the gated tensor of a fused SE block: its gradient g = dy * (out > 0) is stored (the shortcut's gradient too)
+            self.g16.update(op[7] for op in self.plan if op[0] == 'seblock')
         if s16:          # every bf16-storage entry point reads its tensor input as bf16: an fp32 input would be misread silently
             for op in self.plan:
                 ins = []
@@ -568,6 +619,8 @@ class GraphNet(Network):
                     ins = [op[2]]
                 elif op[0] in ('gconv', 'dwconv', 'maxpool', 'se'):
                     ins = [op[2]]
+                elif op[0] == 'seblock':
+                    ins = [op[2], op[4]]
                 for x in ins:
                     assert x in self.h16, 'bf16 storage: %s reads %s, which is stored as fp32' % (op[0] + ' ' + op[1], x)
         self.t = _Activations(self)
@@ -584,7 +637,7 @@ class GraphNet(Network):
             shape = (n,) + self.shapes[out]
             if kind != 'bnstats':
                 self.t[out] = torch.empty(shape, **(i16 if out in self.h16 else f32))
-            if kind in ('bn', 'bnstats'):
+            if kind in ('bn', 'bnstats', 'seblock'):
                 c = shape[-1]
                 self.bn[out] = dict(mean=torch.empty(c, **f32), rstd=torch.empty(c, **f32), scale=torch.empty(c, **f32),
                                     shift=torch.empty(c, **f32), coef=torch.empty(3 * c, **f32))
@@ -621,9 +674,12 @@ class GraphNet(Network):
                 if cc % 32 == 0 and cc // op[5] in (4, 8, 16, 32):
                     need = max(need, q('fte_gconv3x3_wgrad_bf16_ws_bytes', n, ih, iw, cc, op[5], op[4]),
                                q('fte_gconv3x3_bn_ws_bytes', n, ih, iw, cc, op[4]))
-            elif kind == 'se':
+            if kind in ('se', 'seblock'):
                 cc = shape[-1]
-                hd = self._se_names(op)[4]
+                hd = self._se_names(op[5] if kind == 'seblock' else op)[4]
+                if kind == 'seblock':          # per-image sums of the backward pass, the squeeze in xhat units
+                    for nm in ('xm', 's1', 's2'):
+                        self.t[out + '/' + nm] = torch.empty(n, cc, **f32)
                 self.t[out + '/sq'] = torch.empty(n, cc, **f32)
                 self.t[out + '/hid'] = torch.empty(n, hd, **f32)
                 self.t[out + '/gate'] = torch.empty(n, cc, **f32)
@@ -894,6 +950,35 @@ class GraphNet(Network):
                     call('fte_gemm_nn', hid, self.view(w2), self.view(b2), gate, n, c, hd, self.ws, self.ws_bytes, st)
                     call('fte_act_fwd', gate, gate, gate.numel(), 1, st)
                 call('fte_channel_scale_fwd_s16' if s16 else 'fte_channel_scale_fwd', T[inp], gate, T[out], n, ih * iw, c, st)
+            elif kind == 'seblock':
+                _, _, zin, pre, scn, seop, _, _ = op
+                w1, b1, w2, b2, hd = self._se_names(seop)
+                ih, iw, c = self.shapes[out]
+                hw = ih * iw
+                b = self.bn[out]
+                fl = ((1 if zin in h16 else 0) | 2) if s16 else 0
+                if j in stats_done:                            # the producing conv's epilogue left the batch statistics
+                    pass
+                elif is_training:
+                    upd = self.update_moving_stats
+                    args = (T[zin], self.view(pre + '/gamma'), self.view(pre + '/beta'), b['mean'], b['rstd'], b['scale'], b['shift'],
+                            self.state[pre + '/moving_mean'] if upd else None, self.state[pre + '/moving_variance'] if upd else None,
+                            n * hw, c, BN_EPS, BN_DECAY)
+                    if s16:
+                        call('fte_bn_train_stats_s16', *args, 1 if zin in h16 else 0, self.ws, self.ws_bytes, st)
+                    else:
+                        call('fte_bn_train_stats', *args, self.ws, self.ws_bytes, st)
+                else:
+                    call('fte_bn_infer_coef', self.view(pre + '/gamma'), self.view(pre + '/beta'),
+                         self.state[pre + '/moving_mean'], self.state[pre + '/moving_variance'], b['scale'], b['shift'], c, BN_EPS, st)
+                sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
+                call('fte_se_squeeze', T[zin], b['scale'], b['shift'], b['mean'], b['rstd'], sq, T[out + '/xm'] if is_training else None,
+                     n, hw, c, fl & 1, st)
+                call('fte_gemm_nn_act', sq, self.view(w1), self.view(b1), hid, n, hd, c, 1, self.ws, self.ws_bytes, st)
+                call('fte_gemm_nn_act', hid, self.view(w2), self.view(b2), gate, n, c, hd, 2, self.ws, self.ws_bytes, st)
+                if scn in sc_ev:
+                    main_s.wait_event(sc_ev.pop(scn))          # the shortcut branch (side stream) has written it
+                call('fte_se_apply_fwd', T[zin], b['scale'], b['shift'], gate, T[scn], T[out], n, hw, c, fl, st)
             elif kind == 'addrelu':
                 c = self.shapes[out][-1]
                 one, zero = self.ident[c]
@@ -1073,8 +1158,8 @@ class GraphNet(Network):
     def _op_weight_names(self, op):
         if op[0] in ('conv', 'gconv', 'dwconv'):
             return [op[3]]
-        if op[0] == 'se':
-            w1, _, w2, _, _ = self._se_names(op)
+        if op[0] in ('se', 'seblock'):
+            w1, _, w2, _, _ = self._se_names(op[5] if op[0] == 'seblock' else op)
             return [w1, w2]
         return []
 
@@ -1248,6 +1333,32 @@ class GraphNet(Network):
                 call('fte_relu_bwd_s16' if s16 else 'fte_relu_bwd', dy, T[out], g, dy.numel(), st)
                 self._put(op[2], g)
                 self._put(op[3], g)                      # both addends see the same (read-only) gradient
+            elif kind == 'seblock':
+                _, _, zin, pre, scn, seop, _, _ = op
+                w1, b1, w2, b2, hd = self._se_names(seop)
+                ih, iw, c = self.shapes[out]
+                hw = ih * iw
+                b = self.bn[out]
+                fl = ((1 if zin in h16 else 0) | 2) if s16 else 0
+                sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
+                s1, s2, xm = T[out + '/s1'], T[out + '/s2'], T[out + '/xm']
+                dgate, dhid, dsq = self.ident[('se', out, 'dgate')], self.ident[('se', out, 'dhid')], self.ident[('se', 'dsq', c)]
+                gam, bet = self.view(pre + '/gamma'), self.view(pre + '/beta')
+                g = self._new(out)                             # dy * (out > 0): the shortcut's gradient, and the gate path's input
+                call('fte_se_bwd_gate', dy, T[out], T[zin], gam, bet, b['mean'], b['rstd'], gate, g, s1, s2, dgate, n, hw, c, fl, st)
+                wgrad('fte_gemm_tn', dgate, hid, dgate, self.view(w2, self.grads), n, c, hd, wws, self.ws_bytes, wst)
+                wgrad('fte_reduce_rows', dgate, dgate, self.view(b2, self.grads), None, 1, n, c, 1, 1.0, wst)
+                call('fte_gemm_nt', dgate, self.view(w2), None, None, 0, None, dhid, None, n, c, hd, self.ws, self.ws_bytes, st)
+                call('fte_act_bwd', dhid, hid, dhid, dhid.numel(), 0, st)                            # -> d(pre-ReLU)
+                wgrad('fte_gemm_tn', dhid, sq, dhid, self.view(w1, self.grads), n, hd, c, wws, self.ws_bytes, wst)
+                wgrad('fte_reduce_rows', dhid, dhid, self.view(b1, self.grads), None, 1, n, hd, 1, 1.0, wst)
+                call('fte_gemm_nt', dhid, self.view(w1), None, None, 0, None, dsq, None, n, hd, c, self.ws, self.ws_bytes, st)
+                call('fte_se_bn_bwd_coef', s1, s2, gate, dsq, xm, gam, b['mean'], b['rstd'], self.view(pre + '/gamma', self.grads),
+                     self.view(pre + '/beta', self.grads), b['coef'], n, hw, c, st)
+                dz = torch.empty_like(T[zin])
+                call('fte_se_bn_bwd_apply', g, T[zin], b['coef'], gate, dsq, dz, n, hw, c, fl, st)
+                self._put(scn, g)
+                self._put(zin, dz)
             elif kind == 'se':
                 inp = op[2]
                 w1, b1, w2, b2, hd = self._se_names(op)
