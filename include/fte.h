@@ -241,6 +241,12 @@ size_t fte_gconv3x3_wgrad_ws_bytes(int n, int h, int wd, int c, int groups, int 
  * dx = dy*gate, dgate[n,c] = sum_hw dy*x.  The two 1x1 convs on the pooled vector are fte_gemm_*. */
 /* dx[n,hw,c] += v[n,c]*scale: the squeeze (spatial mean) gradient broadcast back over the map */
 int fte_bcast_add(float* dx, const float* v, int n, int hw, int c, float scale, void* stream);
+/* The gate's dense layers in ONE launch each (fte_gemm_* make two: split-K + reduction, 12-15 us for these sizes):
+ * out[m, n] = act(a[m, k] * op(w) + bias) [* (mask > 0)], op(w) = w[k][n] (trans_w = 0: layers.fully_connected forward) or w[n][k]^T
+ * (trans_w = 1: the gradient w.r.t. the layer's input); act 0 none, 1 ReLU, 2 sigmoid; bias [n] and mask [m, n] optional (mask: the ReLU
+ * gradient of the layer below, tf.nn.relu's grad).  n % 32 == 0, k % 128 == 0.  Operand precision follows fte_set_mfma_dtype. */
+int fte_dense_small(const float* a, const float* w, const float* bias, const float* mask, float* out, int m, int n, int k,
+                    int trans_w, int act, void* stream);
 int fte_act_fwd(const float* x, float* y, long n, int kind, void* stream);
 int fte_act_bwd(const float* dy, const float* y, float* dx, long n, int kind, void* stream);
 int fte_channel_scale_fwd(const float* x, const float* gate, float* y, int n, int hw, int c, void* stream);

@@ -317,6 +317,19 @@ class Audit(object):
             ref = 1.0 / (1.0 + np.exp(-ref))
         self._ok('fte_gemm_nn_act', 'y', _h(y).reshape(m, n), ref)
 
+    def _chk_fte_dense_small(self, a, w, bias, mask, out, m, n, k, trans_w, act, st):
+        ww = self._w(_h(w).reshape(n, k)).T if trans_w else self._w(_h(w).reshape(k, n))
+        ref = self._w(_h(a).reshape(m, k)) @ ww
+        if bias is not None:
+            ref = ref + _h(bias)
+        if act == 1:
+            ref = np.maximum(ref, 0.0)
+        elif act == 2:
+            ref = 1.0 / (1.0 + np.exp(-ref))
+        if mask is not None:
+            ref = ref * (_h(mask).reshape(m, n) > 0)
+        self._ok('fte_dense_small', 'out', _h(out).reshape(m, n), ref)
+
     def _chk_fte_gemm_nt(self, dy, w, zprev, alpha, amod, raw, dx, dalpha, m, n, k, ws, wsb, st):
         assert zprev is None and raw is None
         ref = self._w(_h(dy).reshape(m, n)) @ self._w(_h(w).reshape(k, n)).T
@@ -628,6 +641,7 @@ ENTRY_KERNELS = {
     'fte_dwconv3x3_fwd': ['dwconv3x3_win_kernel', 'dwconv3x3_kernel'],
     'fte_dwconv3x3_dgrad': ['dwconv3x3_win_kernel', 'dwconv3x3_kernel', 'dwconv3x3_dgrad_s2_kernel'],
     'fte_dwconv3x3_wgrad': ['dwconv3x3_wgrad_kernel', 'reduce_rows_kernel', 'reduce_rows_q_kernel', 'reduce_slabs_kernel'],
+    'fte_dense_small': ['dense_small_kernel'],
     'fte_se_squeeze': ['se_squeeze_kernel'], 'fte_se_apply_fwd': ['se_apply_kernel'], 'fte_se_bwd_gate': ['se_bwd_gate_kernel'],
     'fte_se_bn_bwd_coef': ['se_bn_coef_kernel'], 'fte_se_bn_bwd_apply': ['se_bn_apply_kernel'],
     'fte_channel_scale_fwd': ['chscale_fwd_kernel'], 'fte_channel_scale_fwd_s16': ['chscale_fwd_kernel'],

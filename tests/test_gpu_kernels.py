@@ -151,6 +151,40 @@ def test_dense_nn_nt_tn(m, n, k):
     check_maxabs(host(dw), x.T @ dy, what='tn')
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('m,n,k', [(128, 128, 256), (128, 256, 128), (37, 64, 128), (128, 1024, 2048), (5, 32, 384), (256, 2048, 1024)])
+def test_dense_small_one_launch_layers(m, n, k, mode):
+    """fte_dense_small: the squeeze-excitation gate's dense layers (nets/shufflenet_v2.py:79-85) in one launch -- forward with bias and
+    ReLU / sigmoid, the gradient w.r.t. the input through w^T with the ReLU mask; ragged m (37, 5 rows: part of a 32-row tile); fp32
+    operands, and bf16 operands against the oracle evaluated on the bf16-rounded operands (fp32 accumulation both ways)."""
+    from tf_face_toolbox_amd import _lib
+    r = _rng(31)
+    a = r.standard_normal((m, k)); w = r.standard_normal((k, n)) * 0.05; b = r.standard_normal(n)
+    wt = r.standard_normal((n, k)) * 0.05; msk = r.standard_normal((m, n))
+    rd = ops.bf16_round if mode == 'bf16' else (lambda v: v)
+    a32, w32, wt32 = (np.asarray(v, np.float32).astype(np.float64) for v in (a, w, wt))
+    _lib.set_mfma_dtype(mode)
+    try:
+        for act in (0, 1, 2):
+            out = torch.empty(m, n, device='cuda')
+            call('fte_dense_small', dev(a), dev(w), dev(b), None, out, m, n, k, 0, act, stream())
+            ref = rd(a32) @ rd(w32) + np.asarray(b, np.float32)
+            ref = np.maximum(ref, 0) if act == 1 else (1 / (1 + np.exp(-ref)) if act == 2 else ref)
+            check_maxabs(host(out), ref, 2e-5, 'dense_small nn act %d' % act)
+        out = torch.empty(m, n, device='cuda')
+        call('fte_dense_small', dev(a), dev(wt), None, dev(msk), out, m, n, k, 1, 0, stream())
+        ref = (rd(a32) @ rd(wt32).T) * (np.asarray(msk, np.float32) > 0)
+        check_maxabs(host(out), ref, 2e-5, 'dense_small nt with the ReLU mask')
+        out2 = torch.empty(m, n, device='cuda')
+        call('fte_dense_small', dev(a), dev(wt), None, dev(msk), out2, m, n, k, 1, 0, stream())
+        assert torch.equal(out, out2)                                        # fixed summation order
+    finally:
+        _lib.set_mfma_dtype('f32')
+    from tf_face_toolbox_amd._lib import FteError
+    with pytest.raises(FteError):
+        call('fte_dense_small', dev(a), dev(w), None, None, out, m, n, k + 64, 0, 0, stream())      # k % 128 != 0
+
+
 @pytest.mark.parametrize('n,c', [(5, 10), (64, 10575), (3, 129)])
 def test_softmax_ce(n, c):
     r = _rng(6)

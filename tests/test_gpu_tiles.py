@@ -154,12 +154,25 @@ def test_resident_filter_gradient_of_the_bf16_storage_mode():
     bf16 inputs, the three instantiations (32 cin x 256 cout: 14x14x256, 7x7x512; 64 x 128: 28x28x128; 64 x 64: 56x56x64), ragged last ranges, and a
     shape the plan leaves to the per-tile kernel (too few K-pieces per block)."""
     cs = _run([['s16wgrad', 80, 14, 14, 256, 256, 1], ['s16wgrad', 70, 7, 7, 512, 512, 1], ['s16wgrad', 83, 28, 28, 128, 128, 1],
-               ['s16wgrad', 24, 14, 14, 256, 256, 1], ['s16wgrad', 45, 56, 56, 64, 64, 1]], {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
+               ['s16wgrad', 24, 14, 14, 256, 256, 1], ['s16wgrad', 45, 56, 56, 64, 64, 1], ['s16wgrad', 1, 7, 7, 256, 256, 1]],
+              {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
     _has(cs[4], 'wgrad16_kernel<64,64,3,192>')
     _has(cs[0], 'wgrad16_kernel<32,256,3,128>')
     _has(cs[1], 'wgrad16_kernel<32,256,3,128>')
     _has(cs[2], 'wgrad16_kernel<64,128,3,128>')
-    assert not any(s.startswith('wgrad16') for s in cs[3]['symbols']), cs[3]['symbols']
+    _has(cs[3], 'wgrad16_kernel<32,256,3,128>')          # round 5: fewer slot ranges (S lowered to 8 K-pieces per block) instead of the per-tile plan
+    assert not any(s.startswith('wgrad16') for s in cs[5]['symbols']), cs[5]['symbols']      # one K-piece in all: the per-tile kernel
+
+
+def test_resident_filter_gradient_at_the_bn_nets_128_image_shard():
+    """Round 5: the 3x3 layers of ResNet-50 / SE-ResNet-50 at 128 images -- 28x28x64, 14x14x128, 7x7x256
+    (nets/resnet.py:63-92) -- have 225-1000 K-pieces, fewer than eight per block at one block per CU: wgrad16_plan lowers the number of
+    slot ranges instead of handing them to the register-staged 64x64 kernel (44-49 us -> 30-44 us per layer)."""
+    cs = _run([['s16wgrad', 128, 28, 28, 64, 64, 1], ['s16wgrad', 128, 14, 14, 128, 128, 1], ['s16wgrad', 128, 7, 7, 256, 256, 1]],
+              {'FTE_MFMA_DTYPE': 'bf16s'}, timeout=1500)
+    _has(cs[0], 'wgrad16_kernel<64,64,3,192>')
+    _has(cs[1], 'wgrad16_kernel<64,128,3,128>')
+    _has(cs[2], 'wgrad16_kernel<32,256,3,128>')
 
 
 def test_pointwise_resident_filter_gradient():

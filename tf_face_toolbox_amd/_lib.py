@@ -87,6 +87,7 @@ _SIGS = {
     'fte_channel_scale_fwd_s16': (c_int, [_P] * 3 + [c_int] * 3 + [_P]),
     'fte_channel_scale_bwd_s16': (c_int, [_P] * 4 + [c_int] * 4 + [_P]),
     'fte_channel_scale_bwd_apply_s16': (c_int, [_P] * 4 + [c_int] * 3 + [c_float, _P]),
+    'fte_dense_small': (c_int, [_P] * 5 + [c_int] * 5 + [_P]),
     'fte_se_squeeze': (c_int, [_P] * 7 + [c_int] * 4 + [_P]),
     'fte_se_apply_fwd': (c_int, [_P] * 6 + [c_int] * 4 + [_P]),
     'fte_se_bwd_gate': (c_int, [_P] * 12 + [c_int] * 4 + [_P]),

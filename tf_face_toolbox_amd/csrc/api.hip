@@ -931,6 +931,12 @@ int fte_gemm_nn_act(const float* x, const float* w, const float* bias, float* y,
     return gemm_nn_impl(x, w, bias, y, m, n, k, act, ws, ws_bytes, stream);
 }
 
+int fte_dense_small(const float* a, const float* w, const float* bias, const float* mask, float* out, int m, int n, int k,
+                    int trans_w, int act, void* stream) {
+    if (!a || !w || !out || m <= 0 || n <= 0 || n % 32 || k <= 0 || k % 128 || act < 0 || act > 2 || (trans_w & ~1)) return FTE_EINVAL;
+    return rc(k_dense_small(a, w, bias, mask, out, m, n, k, trans_w != 0, act, plan_bf16(), (hipStream_t)stream));
+}
+
 int fte_gemm_nt(const float* dy, const float* w, const float* zprev, const float* alpha_prev, int amod,
                 float* raw, float* dx, float* dalpha_prev, int m, int n, int k, void* ws, size_t ws_bytes, void* stream) {
     // dx[m,k] = dy[m,n] @ w[k,n]^T : GEMM with rows m, cols k, reduction n

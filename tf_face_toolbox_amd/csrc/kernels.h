@@ -32,6 +32,9 @@ hipError_t k_center_loss(const float* feat, const int32_t* labels, float* center
 hipError_t k_center_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes, float alpha, hipStream_t st);
 hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, bool soft, float lw, float* loss_rows, float* dfeat,
                      int n, int d, float* ws, hipStream_t st);
+// out[m, n] = act(a[m, k] * (trans_w ? w[n][k]^T : w[k][n]) + bias) [* (mask > 0)] in one launch (kernels.hip "Small dense products")
+hipError_t k_dense_small(const float* a, const float* w, const float* bias, const float* mask, float* out, int m, int n, int k,
+                         bool trans_w, int act, bool bf16, hipStream_t st);
 hipError_t k_momentum(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gs, hipStream_t st);
 hipError_t k_adam(float* w, float* m, float* v, const float* g, long n, float lr_t, float b1, float b2, float eps, float wd, float gs, hipStream_t st);
 hipError_t k_preprocess_u8(const unsigned char* slots, float* out, int n, long slot_stride, int channels, int in_h, int in_w,

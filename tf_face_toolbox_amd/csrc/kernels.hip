@@ -716,12 +716,18 @@ __global__ __launch_bounds__(64) void triplet_mine_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void triplet_grad_kernel(const float* __restrict__ feat, const float* __restrict__ coef,
                                                            float* __restrict__ dfeat, int n, int d) {
+    // the anchor's coefficient row (its own choices + the anchors that chose it) goes to LDS once -- every thread walked the two global
+    // rows itself before: 2 n dependent-latency loads per thread, 128 us for 128 x 2048 -- and is almost all zeros (<= 2 entries per
+    // anchor): the walk below reads LDS and touches feat only for the non-zero ones, in the same order b = 0 .. n - 1
+    extern __shared__ float cfs[];
     const int a = blockIdx.x;
+    for (int b = threadIdx.x; b < n; b += 256) cfs[b] = coef[(long)a * n + b] + coef[(long)b * n + a];
+    __syncthreads();
     for (int k = threadIdx.x; k < d; k += 256) {
         float g = 0.f;
         const float fa = feat[(long)a * d + k];
         for (int b = 0; b < n; ++b) {
-            const float cf = coef[(long)a * n + b] + coef[(long)b * n + a];
+            const float cf = cfs[b];
             if (cf != 0.f) g += cf * (fa - feat[(long)b * d + k]);
         }
         dfeat[(long)a * d + k] = g;
@@ -1010,11 +1016,114 @@ hipError_t k_center_update(const float* diff, const int32_t* labels, float* cent
 }
 hipError_t k_triplet(const float* feat, const int32_t* labels, float margin, bool soft, float lw, float* loss_rows, float* dfeat,
                      int n, int d, float* ws, hipStream_t st) {
+    if (n > 8192) return hipErrorInvalidValue;              // triplet_grad_kernel keeps a coefficient row of n floats in LDS
     float* dist = ws;
     float* coef = ws + (long)n * n;
     hipLaunchKernelGGL(triplet_dist_kernel, dim3(n * n), dim3(256), 0, st, feat, dist, n, d);
     hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(64), 0, st, dist, labels, margin, soft, lw, loss_rows, coef, n);
-    hipLaunchKernelGGL(triplet_grad_kernel, dim3(n), dim3(256), 0, st, feat, coef, dfeat, n, d);
+    hipLaunchKernelGGL(triplet_grad_kernel, dim3(n), dim3(256), (size_t)n * sizeof(float), st, feat, coef, dfeat, n, d);
+    return hipGetLastError();
+}
+// ---------------------------------------------------------------------------------------------------
+// Small dense products in ONE launch (round 5): out[m, n] = act(a[m, k] * op(w) + bias) [* (mask > 0)] for the squeeze-excitation
+// gate's layers (nets/shufflenet_v2.py:79-85: [images, c] x [c, c / 2] and back; m = the shard's images).  Through fte_gemm_* these
+// were a split-K launch of the tile kernel plus a reduction launch, 12-15 us per layer whatever its size -- four of them per SE
+// block and step on the critical path.  Here a block of four waves owns one 32 x 32 output tile: wave v multiplies the tile's rows by
+// the v-th quarter of K straight from global memory (no LDS staging: every operand element is used once per block), the four
+// partial tiles meet in LDS and are added in wave order (fixed: bit-identical run to run), bias / activation / mask in the same pass.
+// BF: operands rounded to bf16 (v_mfma_f32_32x32x16_bf16; the precision of every other product in the bf16 modes); else fp32
+// (v_mfma_f32_32x32x2_f32).  TW: w is [n][k] (out = a * w^T: the data gradient through a layer).  The k index inside a K-step is
+// permuted (lane half lh takes k0 + 8 lh .. + 7, resp. k0 + 4 lh .. + 3) identically for both operands: a sum's order, nothing else.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+typedef float f32x16d __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8d __attribute__((ext_vector_type(8)));
+template <bool BF, bool TW, int NW>
+__global__ __launch_bounds__(64 * NW) void dense_small_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const float* __restrict__ mask, float* __restrict__ out, int m, int n, int k, int act) {
+    __shared__ float part[NW][32][33];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int col0 = blockIdx.x * 32, row0 = blockIdx.y * 32;
+    const int kw = k / NW, kb = wv * kw;                       // this wave's K range (whole 64-deep trips: the launcher checks)
+    const int arow = min(row0 + li, m - 1);                    // (rows past m are computed and dropped)
+    const float* pa = a + (long)arow * k;
+    const float* pw = TW ? w + (long)(col0 + li) * k : w + col0 + li;
+    f32x16d acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if constexpr (BF) {
+        auto cvt = [](const f32x4 lo, const f32x4 hi) -> bf16x8d {
+            bf16x8d v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (__bf16)lo[e]; v[4 + e] = (__bf16)hi[e]; }
+            return v;
+        };
+        for (int k0 = kb; k0 < kb + kw; k0 += 64) {            // four K-steps' loads in flight
+            f32x4 al[4], ah[4], bl[4], bh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k0 + 16 * u + 8 * lh;
+                al[u] = *reinterpret_cast<const f32x4*>(pa + kk); ah[u] = *reinterpret_cast<const f32x4*>(pa + kk + 4);
+                if constexpr (TW) { bl[u] = *reinterpret_cast<const f32x4*>(pw + kk); bh[u] = *reinterpret_cast<const f32x4*>(pw + kk + 4); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bl[u][e] = pw[(long)(kk + e) * n]; bh[u][e] = pw[(long)(kk + 4 + e) * n]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt(al[u], ah[u]), cvt(bl[u], bh[u]), acc, 0, 0, 0);
+        }
+    } else {
+        for (int k0 = kb; k0 < kb + kw; k0 += 32) {            // four 8-deep steps in flight, four MFMAs each
+            f32x4 av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = k0 + 8 * u + 4 * lh;
+                av[u] = *reinterpret_cast<const f32x4*>(pa + kk);
+                if constexpr (TW) bv[u] = *reinterpret_cast<const f32x4*>(pw + kk);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[u][e] = pw[(long)(kk + e) * n];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][e], bv[u][e], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wv][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16 / NW; ++i) {
+        const int idx = threadIdx.x + 64 * NW * i, r = idx >> 5, c = idx & 31;
+        if (row0 + r >= m) continue;
+        float v = part[0][r][c];
+#pragma unroll
+        for (int wq = 1; wq < NW; ++wq) v += part[wq][r][c];      // wave order
+        if (bias) v += bias[col0 + c];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = 1.f / (1.f + expf(-v));
+        const long o = (long)(row0 + r) * n + col0 + c;
+        if (mask) v = mask[o] > 0.f ? v : 0.f;
+        out[o] = v;
+    }
+}
+}  // namespace
+hipError_t k_dense_small(const float* a, const float* w, const float* bias, const float* mask, float* out, int m, int n, int k,
+                         bool trans_w, int act, bool bf16, hipStream_t st) {
+    if (m <= 0 || n <= 0 || n % 32 || k <= 0 || k % 128) return hipErrorInvalidValue;
+    const dim3 grid(n / 32, (m + 31) / 32);
+    // waves per tile: each takes k / NW in whole 64-deep trips (bf16) / 32-deep (fp32); eight from K = 1024 on (a wave's loop is a
+    // chain of ~1-us trips: 128 x 1024 <- 2048 ran 21 us with four waves)
+    const int nw = (k % 512 == 0 && k >= 1024) ? 8 : (k % 256 == 0 ? 4 : 2);
+#define FTE_DS(BF_, TW_) do { if (nw == 8) hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 8>), grid, dim3(512), 0, st, a, w, bias, mask, out, m, n, k, act); \
+                              else if (nw == 4) hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 4>), grid, dim3(256), 0, st, a, w, bias, mask, out, m, n, k, act); \
+                              else hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 2>), grid, dim3(128), 0, st, a, w, bias, mask, out, m, n, k, act); } while (0)
+    if (bf16) { if (trans_w) FTE_DS(true, true); else FTE_DS(true, false); }
+    else { if (trans_w) FTE_DS(false, true); else FTE_DS(false, false); }
+#undef FTE_DS
     return hipGetLastError();
 }
 hipError_t k_momentum(float* w, float* acc, const float* g, long n, float lr, float mom, float wd, float gs, hipStream_t st) {

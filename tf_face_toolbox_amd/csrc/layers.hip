@@ -2229,14 +2229,14 @@ __global__ __launch_bounds__(256) void se_squeeze_kernel(const float* __restrict
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     if (ch < c) {
         const long px = (long)img * hw * c + ch;
-        int r = rl;
-        for (; r + 48 < hw; r += 64) {                          // four rows in flight per lane
+        for (int r = rl; r < hw; r += 64) {                     // four rows in flight per lane (rows past the image: re-read row r, not added)
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = ldq<ZH>(z, px + (long)(r + 16 * u) * c);
+            for (int u = 0; u < 4; ++u) v[u] = ldq<ZH>(z, px + (long)(r + 16 * u < hw ? r + 16 * u : r) * c);
+#pragma unroll
+            for (int u = 1; u < 4; ++u) if (r + 16 * u >= hw) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             s0 += v[0] + v[2]; s1 += v[1] + v[3];
         }
-        for (; r < hw; r += 16) s0 += ldq<ZH>(z, px + (long)r * c);
     }
     sh[rl][q] = s0 + s1;
     __syncthreads();
@@ -2303,20 +2303,16 @@ __global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restric
             a += d;
             b += d * ((zz - mu) * rs);
         };
-        int r = rl;
-        for (; r + 48 < hw; r += 64) {                          // four rows of the three inputs in flight per lane
+        for (int r = rl; r < hw; r += 64) {                     // four rows of the three inputs in flight per lane, also in the last trip
             f32x4 d[4], ov[4], zv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long o = ((long)img * hw + r + 16 * u) * c + ch;
+                const long o = ((long)img * hw + (r + 16 * u < hw ? r + 16 * u : r)) * c + ch;
                 d[u] = ldq<AH>(dy, o); ov[u] = ldq<AH>(out, o); zv[u] = ldq<ZH>(z, o);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) one(((long)img * hw + r + 16 * u) * c + ch, d[u], ov[u], zv[u]);
-        }
-        for (; r < hw; r += 16) {
-            const long o = ((long)img * hw + r) * c + ch;
-            one(o, ldq<AH>(dy, o), ldq<AH>(out, o), ldq<ZH>(z, o));
+            for (int u = 0; u < 4; ++u)
+                if (r + 16 * u < hw) one(((long)img * hw + r + 16 * u) * c + ch, d[u], ov[u], zv[u]);
         }
     }
     sh[0][rl][q] = a; sh[1][rl][q] = b;
@@ -2333,34 +2329,49 @@ __global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restric
         *reinterpret_cast<f32x4*>(dgate + o) = gy * gt * (1.f - gt);
     }
 }
-// one thread per channel, the images in order: the two sums of the BN backward, then bn_bwd_finalize_channel's arithmetic
-__global__ __launch_bounds__(64) void se_bn_coef_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
-                                                        const float* __restrict__ gate, const float* __restrict__ dsq,
-                                                        const float* __restrict__ xm, const float* __restrict__ gamma,
-                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
-                                                        int n, int C, float count) {
-    const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int i0 = 0; i0 < n; i0 += 8) {                         // eight images' five words in flight
-        float v1[8], v2[8], vg[8], vd[8], vx[8];
+// block = 16 channel quads x 16 image lanes (image i on lane i % 16, every lane's loads independent), the lanes' sums added in lane
+// order: the two sums of the BN backward, then bn_bwd_finalize_channel's arithmetic
+__global__ __launch_bounds__(256) void se_bn_coef_kernel(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                         const float* __restrict__ gate, const float* __restrict__ dsq,
+                                                         const float* __restrict__ xm, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                                         int n, int C, float count) {
+    __shared__ f32x4 sh[2][16][16];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = (blockIdx.x * 16 + q) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (ch < C) {
+        for (int i0 = rl; i0 < n; i0 += 64) {                   // four images' five quads in flight per lane
+            f32x4 v1[4], v2[4], vg[4], vd[4], vx[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long o = (long)min(i0 + u, n - 1) * C + ch;
-            v1[u] = s1[o]; v2[u] = s2[o]; vg[u] = gate[o]; vd[u] = dsq[o]; vx[u] = xm[o];
+            for (int u = 0; u < 4; ++u) {
+                const long o = (long)(i0 + 16 * u < n ? i0 + 16 * u : i0) * C + ch;
+                v1[u] = *reinterpret_cast<const f32x4*>(s1 + o); v2[u] = *reinterpret_cast<const f32x4*>(s2 + o);
+                vg[u] = *reinterpret_cast<const f32x4*>(gate + o); vd[u] = *reinterpret_cast<const f32x4*>(dsq + o);
+                vx[u] = *reinterpret_cast<const f32x4*>(xm + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 16 * u < n) { a += vg[u] * v1[u] + vd[u]; b += vg[u] * v2[u] + vd[u] * vx[u]; }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + u < n) { a += vg[u] * v1[u] + vd[u]; b += vg[u] * v2[u] + vd[u] * vx[u]; }
     }
-    dbeta[ch] = a;
-    dgamma[ch] = b;
-    const float gr = gamma[ch] * rstd[ch];
-    const float bb = -gr * rstd[ch] * b / count;
-    coef[ch] = gr;
-    coef[C + ch] = bb;
-    coef[2 * C + ch] = -gr * a / count - bb * mean[ch];
+    sh[0][rl][q] = a; sh[1][rl][q] = b;
+    __syncthreads();
+    if (rl != 0 || ch >= C) return;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { a += sh[0][l][q]; b += sh[1][l][q]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c1 = ch + e;
+        dbeta[c1] = a[e];
+        dgamma[c1] = b[e];
+        const float gr = gamma[c1] * rstd[c1];
+        const float bb = -gr * rstd[c1] * b[e] / count;
+        coef[c1] = gr;
+        coef[C + c1] = bb;
+        coef[2 * C + c1] = -gr * a[e] / count - bb * mean[c1];
+    }
 }
 // dz = A * (g * gate + dsq / hw) + B * z + C0      (grid and walk as chscale_fwd_kernel)
 template <bool ZH, bool AH>
@@ -2410,7 +2421,7 @@ hipError_t l_se_bwd_gate(const float* dy, const float* out, const float* z, cons
 }
 hipError_t l_se_bn_coef(const float* s1, const float* s2, const float* gate, const float* dsq, const float* xm, const float* gamma,
                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef, int n, int hw, int c, hipStream_t st) {
-    hipLaunchKernelGGL(se_bn_coef_kernel, dim3((c + 63) / 64), dim3(64), 0, st, s1, s2, gate, dsq, xm, gamma, mean, rstd, dgamma, dbeta, coef,
+    hipLaunchKernelGGL(se_bn_coef_kernel, dim3((c / 4 + 15) / 16), dim3(256), 0, st, s1, s2, gate, dsq, xm, gamma, mean, rstd, dgamma, dbeta, coef,
                        n, c, (float)((long)n * hw));
     return hipGetLastError();
 }

@@ -535,7 +535,17 @@ bool wgrad16_plan(int n, int h, int w, int cin, int cout, Wgrad16Params* p, int*
     if (S >= 8) S &= ~7; else if (S >= 4) S = 4; else if (S >= 2) S = 2; else S = 1;
     const long KT = (long)n * (h + 1) * (w + 1);
     const long pieces = (KT + KP - 1) / KP;
-    if (pieces < 8L * S || KT >= (1L << 24)) return false;       // at least eight K-pieces per block: otherwise the per-tile kernel's plan
+    // at least `minp` K-pieces per block: S is LOWERED until that holds (round 4 returned to the per-tile kernel's plan instead, which put
+    // the BN nets' 14x14 / 7x7 3x3 layers at a 128-image shard -- 225 / 64 pieces -- on the register-staged 64x64 kernel: 44-46 us each)
+    static const long minp = getenv("FTE_WGRAD16_MINP") ? atol(getenv("FTE_WGRAD16_MINP")) : 8;
+    static const bool lower = !(getenv("FTE_WGRAD16_LOWER_S") && atoi(getenv("FTE_WGRAD16_LOWER_S")) == 0);
+    if (KT >= (1L << 24)) return false;
+    if (pieces < minp * S) {
+        if (!lower) return false;
+        S = (int)(pieces / minp);
+        if (S >= 8) S &= ~7; else if (S >= 4) S = 4; else if (S >= 2) S = 2; else S = 1;
+        if (pieces < 2) return false;
+    }
     p->kper = (int)((pieces + S - 1) / S) * KP;
     p->S = S;                                                    // (a last range may come out short or empty: it writes a zero slab)
     p->n = n; p->H = h; p->W = w; p->cin = cin; p->cout = cout;

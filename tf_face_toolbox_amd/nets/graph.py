@@ -974,8 +974,12 @@ class GraphNet(Network):
                 sq, hid, gate = T[out + '/sq'], T[out + '/hid'], T[out + '/gate']
                 call('fte_se_squeeze', T[zin], b['scale'], b['shift'], b['mean'], b['rstd'], sq, T[out + '/xm'] if is_training else None,
                      n, hw, c, fl & 1, st)
-                call('fte_gemm_nn_act', sq, self.view(w1), self.view(b1), hid, n, hd, c, 1, self.ws, self.ws_bytes, st)
-                call('fte_gemm_nn_act', hid, self.view(w2), self.view(b2), gate, n, c, hd, 2, self.ws, self.ws_bytes, st)
+                if self._se_small(c, hd):                      # the gate's dense layers, one launch each
+                    call('fte_dense_small', sq, self.view(w1), self.view(b1), None, hid, n, hd, c, 0, 1, st)
+                    call('fte_dense_small', hid, self.view(w2), self.view(b2), None, gate, n, c, hd, 0, 2, st)
+                else:
+                    call('fte_gemm_nn_act', sq, self.view(w1), self.view(b1), hid, n, hd, c, 1, self.ws, self.ws_bytes, st)
+                    call('fte_gemm_nn_act', hid, self.view(w2), self.view(b2), gate, n, c, hd, 2, self.ws, self.ws_bytes, st)
                 if scn in sc_ev:
                     main_s.wait_event(sc_ev.pop(scn))          # the shortcut branch (side stream) has written it
                 call('fte_se_apply_fwd', T[zin], b['scale'], b['shift'], gate, T[scn], T[out], n, hw, c, fl, st)
@@ -1037,6 +1041,11 @@ class GraphNet(Network):
         s1, s2 = (op[4], op[5]) if len(op) > 4 else ('fc1', 'fc2')
         w1 = pre + '/%s/weights' % s1
         return w1, pre + '/%s/biases' % s1, pre + '/%s/weights' % s2, pre + '/%s/biases' % s2, self.ishape[w1][1]
+
+    @staticmethod
+    def _se_small(c, hd):
+        """the SE gate's dense layers through fte_dense_small (one launch each)?  FTE_SE_DENSE=0: fte_gemm_* (A/B hook)"""
+        return c % 128 == 0 and hd % 128 == 0 and os.environ.get('FTE_SE_DENSE', '1') != '0'
 
     def _scr(self, c, i):
         key = ('scr', c, i)
@@ -1348,11 +1357,18 @@ class GraphNet(Network):
                 call('fte_se_bwd_gate', dy, T[out], T[zin], gam, bet, b['mean'], b['rstd'], gate, g, s1, s2, dgate, n, hw, c, fl, st)
                 wgrad('fte_gemm_tn', dgate, hid, dgate, self.view(w2, self.grads), n, c, hd, wws, self.ws_bytes, wst)
                 wgrad('fte_reduce_rows', dgate, dgate, self.view(b2, self.grads), None, 1, n, c, 1, 1.0, wst)
-                call('fte_gemm_nt', dgate, self.view(w2), None, None, 0, None, dhid, None, n, c, hd, self.ws, self.ws_bytes, st)
-                call('fte_act_bwd', dhid, hid, dhid, dhid.numel(), 0, st)                            # -> d(pre-ReLU)
+                small = self._se_small(c, hd)
+                if small:                                      # d(pre-ReLU) = (dgate W2^T) * (hid > 0) in one launch
+                    call('fte_dense_small', dgate, self.view(w2), None, hid, dhid, n, hd, c, 1, 0, st)
+                else:
+                    call('fte_gemm_nt', dgate, self.view(w2), None, None, 0, None, dhid, None, n, c, hd, self.ws, self.ws_bytes, st)
+                    call('fte_act_bwd', dhid, hid, dhid, dhid.numel(), 0, st)                        # -> d(pre-ReLU)
                 wgrad('fte_gemm_tn', dhid, sq, dhid, self.view(w1, self.grads), n, hd, c, wws, self.ws_bytes, wst)
                 wgrad('fte_reduce_rows', dhid, dhid, self.view(b1, self.grads), None, 1, n, hd, 1, 1.0, wst)
-                call('fte_gemm_nt', dhid, self.view(w1), None, None, 0, None, dsq, None, n, hd, c, self.ws, self.ws_bytes, st)
+                if small:
+                    call('fte_dense_small', dhid, self.view(w1), None, None, dsq, n, c, hd, 1, 0, st)
+                else:
+                    call('fte_gemm_nt', dhid, self.view(w1), None, None, 0, None, dsq, None, n, hd, c, self.ws, self.ws_bytes, st)
                 call('fte_se_bn_bwd_coef', s1, s2, gate, dsq, xm, gam, b['mean'], b['rstd'], self.view(pre + '/gamma', self.grads),
                      self.view(pre + '/beta', self.grads), b['coef'], n, hw, c, st)
                 dz = torch.empty_like(T[zin])
