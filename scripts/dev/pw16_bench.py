@@ -17,7 +17,7 @@ for hw, cin, cout in shapes:
     nb = q('fte_conv2d_bn_fwd_ws_bytes', n, hw, hw, cin, cout, 1, 1)
     ws = torch.empty(nb // 4 + 1024, device='cuda')
     def run():
-        call('fte_conv2d_bn_fwd', x, w, z, v[0], v[1], v[2], v[3], v[4], v[5], None, None, 1e-3, 0.999, n, hw, hw, cin, cout, 1, 1, 1, ws, ws.numel() * 4, st)
+        call('fte_conv2d_bn_fwd', x, w, z, v[0], v[1], v[2], v[3], v[4], v[5], None, None, 1e-3, 0.999, None, None, None, n, hw, hw, cin, cout, 1, 1, 1, ws, ws.numel() * 4, st)
     for _ in range(5): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

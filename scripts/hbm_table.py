@@ -30,7 +30,14 @@ REASONS = [
     (r'gconv3x3_wgrad', '32-channel slices through the transposing LDS read; VALU-bound on address and conversion work (side stream: overlapped)'),
     (r'gconv3x3_mfma16', 'VALU-bound, not byte-bound: ~600 VALU instructions per 18 MFMAs (edge masks of 28-wide images inside 32-pixel tiles, '
                          'bf16 <-> fp32 of the BN fold, 2-byte stores); two waves per SIMD at 208-228 registers'),
-    (r'pw16_kernel', 'one streaming pass over the input with the filter resident in LDS; 256 blocks, the output tile stores are 2 bytes per lane'),
+    (r'pw16_kernel', 'instruction-issue bound beside its memory waits, not byte-bound: SQ counters of the kernel alone (profiles/r5_pw16_sq_counters.csv) -- of a wave\'s '
+                     'cycles 37-41 % issue instructions (0.3-0.7 G VALU per 55 launches: bf16 <-> fp32 of the loader transform and the statistics, the '
+                     '2-byte writes into the LDS result stage), 38-43 % are parked on s_waitcnt / barriers, 18-24 % are issue stalls (LDS: 5-10 %); at the '
+                     'two waves per SIMD the LDS allows (filter slice + a stage per wave) nothing covers the parked share'),
+    (r'se_squeeze|se_bwd_gate', 'per-image column sums (one block per image and 64 channels): the 28x28 / 14x14 tensors stream at 3.6-4.2 TB/s with four rows in flight '
+                                'per lane; the 7x7 / 4x4 ones are 10-50 MB in 7-12 us -- launch-latency floor'),
+    (r'se_apply|se_bn_apply', 'streams at 4.4-5.7 TB/s on the 28x28 / 14x14 tensors; 7x7 / 4x4: 26-40 MB in 9-11 us -- launch-latency floor'),
+    (r'se_bn_coef|dense_small', 'not streaming kernels: [images, channels] vectors and the gate\'s 0.1-8 MB dense layers, 6-10 us = launch + one dependent chain'),
     (r'channel_gather', 'gathers 4-byte elements at a channel permutation: a 128-byte line serves 32 lanes of one pixel only when the permutation '
                         'keeps neighbours together (ShuffleNet\'s shuffle does not)'),
     (r'dwconv3x3', 'nine taps of a 4-byte element per output, served from L1 / L2; the 14x14 / 7x7 layers are 10-25 MB = launch-latency floor'),

@@ -194,6 +194,70 @@ def test_se_gate_pieces():
         check_maxabs(host(d), v * df(f(v)), 1e-5, 'act bwd')
 
 
+@pytest.mark.parametrize('flags', [0, 3])
+@pytest.mark.parametrize('n,hw,c', [(3, 49, 64), (2, 10, 96), (5, 196, 128), (4, 16, 2048), (2, 784, 256), (1, 67, 32)])
+def test_se_residual_block_fused_kernels(n, hw, c, flags):
+    """fte_se_squeeze / _apply_fwd / _bwd_gate / _bn_bwd_coef / _bn_bwd_apply (csrc/layers.hip "SE residual block"; nets/resnet.py:63-92 +
+    the gate of nets/shufflenet_v2.py:79-85) against float64 on the same inputs: fp32 tensors (flags 0) and bf16 storage (flags 3: the
+    inputs ARE bf16 values, stored results within half a bf16 step), spatial sizes that are not multiples of the 16 row lanes or of
+    the 64-row trip, 4x4 images, one image."""
+    r = _rng(41)
+    s16 = flags == 3
+    rd = (lambda a: ops.bf16_round(np.asarray(a, np.float64))) if s16 else (lambda a: np.asarray(a, np.float32).astype(np.float64))
+
+    def tdev(a):          # host values -> device tensor in the storage the flags say
+        t = dev(a)
+        return t.bfloat16().view(torch.int16) if s16 else t
+
+    def thost(t):
+        return host(t.view(torch.bfloat16).float()) if s16 else host(t)
+    z = rd(r.standard_normal((n, hw, c)) * 1.5 + 0.3); sc_ = rd(r.standard_normal((n, hw, c)))
+    gamma = 1 + 0.2 * r.standard_normal(c); beta = 0.1 * r.standard_normal(c)
+    gamma, beta = np.asarray(gamma, np.float32).astype(np.float64), np.asarray(beta, np.float32).astype(np.float64)
+    mean = z.reshape(-1, c).mean(0); rstd = 1 / np.sqrt(z.reshape(-1, c).var(0) + 1e-3)
+    mean, rstd = np.asarray(mean, np.float32).astype(np.float64), np.asarray(rstd, np.float32).astype(np.float64)
+    scale = np.asarray(gamma * rstd, np.float32).astype(np.float64); shift = np.asarray(beta - mean * scale, np.float32).astype(np.float64)
+    gate = np.asarray(1 / (1 + np.exp(-r.standard_normal((n, c)))), np.float32).astype(np.float64)
+    # forward
+    sq = torch.empty(n, c, device='cuda'); xm = torch.empty(n, c, device='cuda')
+    call('fte_se_squeeze', tdev(z), dev(scale), dev(shift), dev(mean), dev(rstd), sq, xm, n, hw, c, flags & 1, stream())
+    zm = z.mean(1)
+    check_maxabs(host(sq), zm * scale + shift, 2e-5, 'sq')
+    assert np.abs(host(xm) - (zm - mean) * rstd).max() <= 2e-6 * (1 + (np.abs(mean) * rstd).max())
+    out = torch.empty(n, hw, c, dtype=torch.int16 if s16 else torch.float32, device='cuda')
+    call('fte_se_apply_fwd', tdev(z), dev(scale), dev(shift), dev(gate), tdev(sc_), out, n, hw, c, flags, stream())
+    y = z * scale + shift
+    out_ref = np.maximum(y * gate[:, None, :] + sc_, 0)
+    lim = np.abs(out_ref) * (2.0 ** -8 if s16 else 0) + 2e-5 * np.abs(out_ref).max()
+    assert (np.abs(thost(out) - out_ref) <= lim).all(), 'se_apply_fwd'
+    # backward, on the STORED out
+    outv = thost(out)
+    dy = rd(r.standard_normal((n, hw, c)))
+    g = torch.empty_like(out); s1 = torch.empty(n, c, device='cuda'); s2 = torch.empty_like(s1); dgate = torch.empty_like(s1)
+    call('fte_se_bwd_gate', tdev(dy), out, tdev(z), dev(gamma), dev(beta), dev(mean), dev(rstd), dev(gate), g, s1, s2, dgate, n, hw, c, flags, stream())
+    g_ref = dy * (outv > 0)
+    gv = thost(g)
+    assert np.array_equal(gv, rd(g_ref)), 'g = dy * (out > 0), rounded once where stored'
+    xhat = (z - mean) * rstd
+    check_maxabs(host(s1), gv.sum(1), 2e-6 * max(1.0, np.abs(gv).sum(1).max() / max(np.abs(gv.sum(1)).max(), 1e-30)), 's1')
+    check_maxabs(host(s2), (gv * xhat).sum(1), 2e-6 * max(1.0, np.abs(gv * xhat).sum(1).max() / max(np.abs((gv * xhat).sum(1)).max(), 1e-30)), 's2')
+    dg_ref = (gamma * (gv * xhat).sum(1) + beta * gv.sum(1)) * gate * (1 - gate)
+    check_maxabs(host(dgate), dg_ref, 2e-5 * max(1.0, (np.abs(gamma) * np.abs(gv * xhat).sum(1) + np.abs(beta) * np.abs(gv).sum(1)).max() / max(np.abs(dg_ref).max(), 1e-30)), 'dgate')
+    dsq = np.asarray(0.1 * r.standard_normal((n, c)), np.float32).astype(np.float64)
+    dgam = torch.empty(c, device='cuda'); dbet = torch.empty(c, device='cuda'); coef = torch.empty(3 * c, device='cuda')
+    call('fte_se_bn_bwd_coef', s1, s2, dev(gate), dev(dsq), xm, dev(gamma), dev(mean), dev(rstd), dgam, dbet, coef, n, hw, c, stream())
+    dyb = gv * gate[:, None, :] + dsq[:, None, :] / hw                       # gradient w.r.t. the BN output
+    db_ref, dg2_ref = dyb.reshape(-1, c).sum(0), (dyb * xhat).reshape(-1, c).sum(0)
+    tb, tg = np.abs(dyb).reshape(-1, c).sum(0).max(), np.abs(dyb * xhat).reshape(-1, c).sum(0).max()
+    assert np.abs(host(dbet) - db_ref).max() <= 4e-6 * tb and np.abs(host(dgam) - dg2_ref).max() <= 4e-6 * tg + 2e-6 * np.abs(dsq).sum(0).max() * (1 + (np.abs(mean) * rstd).max())
+    dz = torch.empty_like(out)
+    call('fte_se_bn_bwd_apply', g, tdev(z), coef, dev(gate), dev(dsq), dz, n, hw, c, flags, stream())
+    cnt = n * hw
+    dz_ref = gamma * rstd * (dyb - db_ref / cnt - xhat * (dg2_ref / cnt))         # FusedBatchNormGrad
+    lim = np.abs(dz_ref) * (2.0 ** -8 if s16 else 0) + 5e-5 * np.abs(dz_ref).max()
+    assert (np.abs(thost(dz) - dz_ref) <= lim).all(), 'se_bn_bwd_apply vs the batch-norm gradient of g * gate + dsq / hw'
+
+
 @pytest.mark.parametrize('rows,c', [(3 * 14 * 14, 256), (128 * 7 * 7, 1024), (50, 64), (37, 8)])
 def test_residual_bn_backward_writes_the_masked_gradient_as_a_by_product(rows, c):
     """fte_bn_train_bwd_res == fte_relu_bwd followed by fte_bn_train_bwd without a mask, bit for bit: g = dy * (y > 0) for the
