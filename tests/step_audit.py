@@ -583,7 +583,8 @@ class Audit(object):
     def _chk_fte_pack_weights_bf16_table(self, params, dst, table, nconv, total, transposed, st):
         """rows {source offset (floats), destination offset (bf16 elements), taps, cin, cout, ...}: HWIO packs, or [tap][cout][cin]"""
         t = table.cpu().numpy().reshape(nconv, -1)
-        p, d = _h(params), _h(dst)
+        with np.errstate(invalid='ignore'):      # the pack arena behind the table's ranges holds whatever bits were there
+            p, d = _h(params), _h(dst)
         for src, off, taps, cin, cout in t[:, :5]:
             w = _bf(p[src:src + taps * cin * cout]).reshape(taps, cin, cout)
             ref = w.transpose(0, 2, 1) if transposed else w

@@ -260,7 +260,7 @@ def test_graph_net_gradient_buckets_follow_the_backward_walk(name):
 
 
 def test_profile_tables_regenerate_from_the_committed_profiles(capsys):
-    """scripts/hbm_table.py and scripts/make_symbol_lists.py read the committed round-4 profiles: the HBM table lists the BN kernels of
+    """scripts/hbm_table.py and scripts/make_symbol_lists.py read the committed round-5 profiles: the HBM table lists the BN kernels of
     every BN config with a share of 8 TB/s, and the symbol lists the GPU tests check are the ones these profiles produce."""
     import importlib.util
     import json
@@ -271,17 +271,17 @@ def test_profile_tables_regenerate_from_the_committed_profiles(capsys):
     spec.loader.exec_module(mod)
     import sys
     argv = sys.argv
-    sys.argv = ['hbm_table.py', 'r4']
+    sys.argv = ['hbm_table.py', 'r5']
     try:
         mod.main()
     finally:
         sys.argv = argv
     out = capsys.readouterr().out
-    assert out == open(os.path.join(root, 'profiles', 'r4_hbm_bound_kernels.md')).read()
+    assert out == open(os.path.join(root, 'profiles', 'r5_hbm_bound_kernels.md')).read()
     for section in ('config 3: ResNeXt-50', 'config 4: SE-ResNet-50', 'config 5: ShuffleNet-v2', 'SphereNet-20, bf16 storage'):
         assert section in out
     assert out.count('bn_bwd_apply_kernel') >= 3 and 'at::native' not in out.split('### config 3')[1]
     for name, key in (('headline_symbols.json', 'conv_symbols'), ('symbols_resnext50_bf16s_b128.json', None)):
         d = json.load(open(os.path.join(root, 'tests', 'golden', name)))
-        assert 'r4_' in d['source'], name
+        assert 'r5_' in d['source'], name
         assert (d[key] if key else [v for k, v in d.items() if isinstance(v, list)][0])
