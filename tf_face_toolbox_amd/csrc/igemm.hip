@@ -1201,24 +1201,30 @@ hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st
 // handed out to stream handles first come, first served; a 17th concurrent stream falls back to words in the workspace + a memset.
 constexpr int SK_ROWS = 16, SK_ROW_WORDS = 2048;
 __device__ unsigned g_sk_words[SK_ROWS][SK_ROW_WORDS];
-struct SkRow { hipStream_t st; unsigned epoch; bool used; };
+struct SkRow { hipStream_t st; int dev; unsigned epoch; bool used; };
 SkRow g_sk_rows[SK_ROWS];
 std::mutex g_sk_mu;
-unsigned* g_sk_base = nullptr;
+constexpr int SK_DEVS = 16;
+unsigned* g_sk_base[SK_DEVS];      // the words' address on each device of this process (one process per GPU is the design; this keeps two honest)
 hipError_t sk_flags(IgemmParams* q, hipStream_t st) {
     static const bool force_ws = getenv("FTE_SK_WS_FLAGS") != nullptr;      // A/B hook: the memset form
-    if (!force_ws && q->sk_workers <= SK_ROW_WORDS) {
+    // A stream being CAPTURED into a graph replays this launch with its arguments frozen -- the epoch too, which would then equal what
+    // the previous replay left in the words: captured launches take the workspace words and a memset node (replayed every time).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    int dev = -1;
+    if (!force_ws && !capturing && q->sk_workers <= SK_ROW_WORDS && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < SK_DEVS) {
         std::lock_guard<std::mutex> lock(g_sk_mu);
-        if (!g_sk_base) {
-            hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&g_sk_base), HIP_SYMBOL(g_sk_words));
+        if (!g_sk_base[dev]) {
+            hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&g_sk_base[dev]), HIP_SYMBOL(g_sk_words));
             if (e != hipSuccess) return e;
         }
         int row = -1;
-        for (int i = 0; i < SK_ROWS; ++i) if (g_sk_rows[i].used && g_sk_rows[i].st == st) { row = i; break; }
-        if (row < 0) for (int i = 0; i < SK_ROWS; ++i) if (!g_sk_rows[i].used) { row = i; g_sk_rows[i].used = true; g_sk_rows[i].st = st; g_sk_rows[i].epoch = 0; break; }
+        for (int i = 0; i < SK_ROWS; ++i) if (g_sk_rows[i].used && g_sk_rows[i].st == st && g_sk_rows[i].dev == dev) { row = i; break; }
+        if (row < 0) for (int i = 0; i < SK_ROWS; ++i) if (!g_sk_rows[i].used) { row = i; g_sk_rows[i].used = true; g_sk_rows[i].st = st; g_sk_rows[i].dev = dev; g_sk_rows[i].epoch = 0; break; }
         if (row >= 0) {
             if (++g_sk_rows[row].epoch == 0u) g_sk_rows[row].epoch = 1u;      // 0 is the value the words are loaded with
-            q->SKF = g_sk_base + (size_t)row * SK_ROW_WORDS;
+            q->SKF = g_sk_base[dev] + (size_t)row * SK_ROW_WORDS;
             q->sk_epoch = (int)g_sk_rows[row].epoch;
             return hipSuccess;
         }
