@@ -736,6 +736,7 @@ class GraphNet(Network):
         s16 = self._act_s16
         h16 = self.h16
         pack_ev = None
+        side_packs = None
         if s16:
             # every filter's bf16 packs, refreshed once per step.  The walk's first layers need only THEIR forward packs: those are
             # made here; the rest -- the other layers' forward packs, every HWIO pack (read by the backward pass only) and the
@@ -744,16 +745,26 @@ class GraphNet(Network):
             side = self.side
             if side is not None and self.packs.head_names != set(self.w16t):
                 self.packs.refresh_head(self.params, st)
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)
-                sst = side.cuda_stream
-                self.packs.refresh_rest(self.params, sst)
-                for op in self.plan:
-                    if op[0] == 'gconv':
-                        pk = self._gconv_pack(op)
-                        if pk is not None:
-                            call('fte_gconv3x3_pack_bf16', self.view(op[3]), pk[0], pk[1], self.shapes[op[2]][-1], op[5], sst)
-                pack_ev = side.record_event()
+
+                def side_packs():
+                    main = torch.cuda.current_stream()
+                    side.wait_stream(main)
+                    sst = side.cuda_stream
+                    self.packs.refresh_rest(self.params, sst)
+                    for op in self.plan:
+                        if op[0] == 'gconv':
+                            pk = self._gconv_pack(op)
+                            if pk is not None:
+                                call('fte_gconv3x3_pack_bf16', self.view(op[3]), pk[0], pk[1], self.shapes[op[2]][-1], op[5], sst)
+                    return side.record_event()
+                # A 7x7 stem's im2col (150-200 MB of strided traffic) and the packs (the same again) choke each other when they run
+                # side by side: im2col 74 -> 240-260 us beside ResNet-50's 47 MB of packs (profiles/r5_resnet50_*).  The packs start
+                # behind the im2col instead, under the stem's GEMM (FTE_PACK_AFTER_STEM=0: at the start of the walk, as before).
+                first = self.plan[0]
+                stem_cols = first[0] == 'conv' and self.shapes[first[2]][-1] < 32 and not self._direct_stem(self.spec[first[3]][0][0], self.shapes[first[2]][-1], self.shapes[first[1]][-1])
+                if not (stem_cols and os.environ.get('FTE_PACK_AFTER_STEM', '1') != '0'):
+                    pack_ev = side_packs()
+                    side_packs = None
             else:
                 self.packs.refresh(self.params, st)
         stats_done = set()                               # BN plan ops whose statistics came out of the producing conv's epilogue
@@ -823,6 +834,9 @@ class GraphNet(Network):
                     oh, ow, _ = self.shapes[out]
                     kpad = stem_kpad(k, cin)
                     call('fte_im2col_first_s16', T[inp], self.cols, n, ih, iw, cin, k, stride, kpad, st)
+                    if side_packs is not None:                 # the rest of the filter packs, from here on (see above)
+                        pack_ev = side_packs()
+                        side_packs = None
                     if is_training and j in self.fuse_fwd:
                         call('fte_conv2d_bn_fwd', self.cols, self.w16t[wname], T[out], *bn_args(self.fuse_fwd[j]), None, None, None,
                              n, oh, ow, kpad, cout, 1, 1, 1, self.ws, self.ws_bytes, st)
