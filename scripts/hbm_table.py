@@ -38,6 +38,8 @@ REASONS = [
                                 'per lane; the 7x7 / 4x4 ones are 10-50 MB in 7-12 us -- launch-latency floor'),
     (r'se_apply|se_bn_apply', 'streams at 4.4-5.7 TB/s on the 28x28 / 14x14 tensors; 7x7 / 4x4: 26-40 MB in 9-11 us -- launch-latency floor'),
     (r'se_bn_coef|dense_small', 'not streaming kernels: [images, channels] vectors and the gate\'s 0.1-8 MB dense layers, 6-10 us = launch + one dependent chain'),
+    (r'channel_gather_lds', 'whole rows in as 16-byte pieces, the permutation applied by LDS reads, 16-byte stores (round 5; the element gather ran '
+                            'at 37 %): 20-100 MB per launch, two barriers per group of rows'),
     (r'channel_gather', 'gathers 4-byte elements at a channel permutation: a 128-byte line serves 32 lanes of one pixel only when the permutation '
                         'keeps neighbours together (ShuffleNet\'s shuffle does not)'),
     (r'dwconv3x3', 'nine taps of a 4-byte element per output, served from L1 / L2; the 14x14 / 7x7 layers are 10-25 MB = launch-latency floor'),

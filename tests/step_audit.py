@@ -591,6 +591,21 @@ class Audit(object):
             assert np.array_equal(d[off:off + taps * cin * cout].reshape(ref.shape), ref), 'fte_pack_weights_bf16_table: pack at %d is not bf16(w)' % off
         self.worst['fte_pack_weights_bf16_table'] = 0.0
 
+    def _chk_fte_gconv3x3_pack_bf16(self, w, wf, wd, c, groups, st):
+        """block-diagonal 32-channel slices [slice][tap][col][k] of the grouped filter [group][tap][ic][oc]: forward col = oc, k = ic;
+        data gradient col = ic, k = oc, taps mirrored (fte.h:220)"""
+        gw, nsl = c // groups, c // 32
+        W = _bf(_h(w).ravel()[:groups * 9 * gw * gw]).reshape(groups, 9, gw, gw)
+        f = np.zeros((nsl, 9, 32, 32)); d = np.zeros_like(f)
+        for sl in range(nsl):
+            for j in range(32 // gw):
+                q = slice(j * gw, (j + 1) * gw)
+                f[sl, :, q, q] = W[sl * (32 // gw) + j].transpose(0, 2, 1)
+                d[sl, :, q, q] = W[sl * (32 // gw) + j][::-1]
+        assert np.array_equal(_h(wf).ravel()[:f.size].reshape(f.shape), f), 'fte_gconv3x3_pack_bf16: forward pack'
+        assert np.array_equal(_h(wd).ravel()[:d.size].reshape(d.shape), d), 'fte_gconv3x3_pack_bf16: data-gradient pack'
+        self.worst['fte_gconv3x3_pack_bf16'] = 0.0
+
     def _chk_fte_act_fwd(self, x, y, n, kind, st):
         pass        # in place on the gate's [n, c] vectors: covered by fte_gemm_nn_act where fused; the unfused form is an A/B hook
 
@@ -649,14 +664,15 @@ ENTRY_KERNELS = {
     'fte_channel_scale_bwd': ['chscale_bwd_kernel'], 'fte_channel_scale_bwd_s16': ['chscale_bwd_kernel'],
     'fte_channel_scale_bwd_apply_s16': ['chscale_bwd_apply_kernel'],
     'fte_relu_bwd': ['relu_bwd_kernel'], 'fte_relu_bwd_s16': ['relu_bwd_kernel'],
-    'fte_channel_gather': ['channel_gather_kernel'], 'fte_channel_gather_s16': ['channel_gather_kernel'],
-    'fte_channel_gather_affine': ['channel_gather_affine_kernel'], 'fte_channel_gather_affine_s16': ['channel_gather_affine_kernel'],
+    'fte_channel_gather': ['channel_gather_kernel', 'channel_gather_lds_kernel'], 'fte_channel_gather_s16': ['channel_gather_kernel', 'channel_gather_lds_kernel'],
+    'fte_channel_gather_affine': ['channel_gather_affine_kernel', 'channel_gather_lds_kernel'],
+    'fte_channel_gather_affine_s16': ['channel_gather_affine_kernel', 'channel_gather_lds_kernel'],
     'fte_maxpool3x3s2_fwd': ['maxpool_fwd_kernel'], 'fte_maxpool3x3s2_fwd_s16': ['maxpool_fwd_kernel'],
     'fte_maxpool3x3s2_bwd': ['maxpool_bwd_kernel', 'maxpool_bwd_even_kernel'], 'fte_maxpool3x3s2_bwd_s16': ['maxpool_bwd_kernel', 'maxpool_bwd_even_kernel'],
     'fte_gap_fwd': ['gap_fwd_kernel'], 'fte_gap_fwd_s16': ['gap_fwd_kernel'], 'fte_gap_bwd': ['gap_bwd_kernel'], 'fte_gap_bwd_s16': ['gap_bwd_kernel'],
     'fte_im2col_first': ['im2col_first_kernel', 'im2col_first_rows_kernel'], 'fte_im2col_first_s16': ['im2col_first_kernel', 'im2col_first_rows_kernel'],
     'fte_dropout_fwd': ['dropout_fwd_kernel'], 'fte_dropout_bwd': ['scale_mask_kernel'],
-    'fte_pack_weights_bf16_table': ['pack_weights_table_kernel'],
+    'fte_pack_weights_bf16_table': ['pack_weights_table_kernel'], 'fte_gconv3x3_pack_bf16': ['gconv_pack16_kernel'],
     'fte_batch_hard_triplet_fwd_bwd': ['triplet_dist_kernel', 'triplet_mine_kernel', 'triplet_grad_kernel'],
     'fte_softmax_ce_fwd_bwd': ['softmax_ce_reg_kernel', 'softmax_ce_kernel'],
 }

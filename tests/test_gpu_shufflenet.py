@@ -81,6 +81,57 @@ def test_channel_gather_is_concat_shuffle_split(ca, fmt):
     assert torch.equal(run(ts['bwd'][0][1], h0, h1, pc(2 * ca)), cd)
 
 
+@pytest.mark.parametrize('s16', [0, 1])
+@pytest.mark.parametrize('rows,ca,cb,co0,co1', [(256 * 28 * 28 // 8 + 3, 128, 128, 128, 128), (9001, 256, 256, 256, 256), (777, 512, 512, 512, 512),
+                                             (5003, 256, 0, 128, 128), (4099, 128, 128, 256, 0), (1234, 32, 32, 32, 0), (3001, 64, 192, 64, 64),
+                                             (2050, 40, 24, 32, 32), (2051, 40, 32, 40, 32)])
+def test_channel_gather_row_groups_through_lds(rows, ca, cb, co0, co1, s16):
+    """The LDS form of the gather (power-of-two quads per row; csrc/layers.hip channel_gather_lds_kernel) and the element form
+    (the last case: 10 + 8 quads) against plain indexing: random tables with zero entries, row counts that end inside a row
+    group, one and two sources / outputs; bit-exact without the affine, and the affine = fma + max of the source's scale / shift."""
+    g = torch.Generator(device='cuda').manual_seed(rows + ca)
+    a = torch.randn(rows, ca, device='cuda', generator=g)
+    b = torch.randn(rows, cb, device='cuda', generator=g) if cb else None
+    if s16:
+        a = a.bfloat16().float(); b = b.bfloat16().float() if cb else None
+    perm = torch.randperm(ca + cb, generator=torch.Generator().manual_seed(ca + co0)).tolist()
+    ent = [(-1 if k % 11 == 3 else k) for k in (perm * 2)[:co0 + co1]]
+    enc = lambda ks: torch.tensor([(-1 if k < 0 else ((0 << 16) | k if k < ca else (1 << 16) | (k - ca))) for k in ks], dtype=torch.int32, device='cuda')
+    t0, t1 = enc(ent[:co0]), (enc(ent[co0:]) if co1 else None)
+    cat = torch.cat([a, b], 1) if cb else a
+
+    def ref(src, ks):
+        idx = torch.tensor([max(k, 0) for k in ks], device='cuda')
+        out = src[:, idx]
+        out[:, torch.tensor([k < 0 for k in ks], device='cuda')] = 0
+        return out
+    bits = lambda x: x.bfloat16().view(torch.int16)
+    dt = dict(dtype=torch.int16 if s16 else torch.float32, device='cuda')
+    arg = (lambda x: None if x is None else bits(x)) if s16 else (lambda x: x)
+    sfx = '_s16' if s16 else ''
+    o0 = torch.empty(rows, co0, **dt); o1 = torch.empty(rows, co1, **dt) if co1 else None
+    _lib.call('fte_channel_gather' + sfx, arg(a), arg(b), o0, t0, rows, ca, cb, co0, stream())
+    want = ref(cat, ent[:co0])
+    assert torch.equal(o0, bits(want) if s16 else want)
+    _lib.call('fte_channel_gather_affine' + sfx, arg(a), arg(b), o0, t0, co0, o1, t1, co1, rows, ca, cb, None, None, 0, None, None, 0, stream())
+    assert torch.equal(o0, bits(want) if s16 else want)
+    if co1:
+        w1 = ref(cat, ent[co0:])
+        assert torch.equal(o1, bits(w1) if s16 else w1)
+    sca = torch.rand(ca, device='cuda', generator=g) + 0.5; sfa = torch.randn(ca, device='cuda', generator=g) * 0.2
+    scb = torch.rand(max(cb, 1), device='cuda', generator=g) + 0.5; sfb = torch.randn(max(cb, 1), device='cuda', generator=g) * 0.2
+    _lib.call('fte_channel_gather_affine' + sfx, arg(a), arg(b), o0, t0, co0, o1, t1, co1, rows, ca, cb, sca, sfa, 1,
+              scb if cb else None, sfb if cb else None, 0, stream())
+    ya = torch.relu(a.double() * sca.double() + sfa.double())
+    ycat = torch.cat([ya, b.double() * scb.double() + sfb.double()], 1) if cb else ya
+    for o, ks in ((o0, ent[:co0]), (o1, ent[co0:])):
+        if o is None:
+            continue
+        got = o.view(torch.bfloat16).double() if s16 else o.double()
+        err = (got - ref(ycat, ks)).abs().max().item()
+        assert err <= (2e-2 if s16 else 2e-6), err
+
+
 @pytest.mark.parametrize('rows,c', [(3 * 14 * 14, 128), (512 * 7 * 7, 256), (40, 64)])
 def test_bn_folded_into_the_gather_is_the_unfused_sequence_bit_for_bit(rows, c):
     """fte_bn_train_stats + fte_channel_gather_affine == fte_bn_train_fwd + fte_channel_gather, and the backward pass with

@@ -2750,6 +2750,84 @@ __global__ __launch_bounds__(256) void channel_gather_affine_kernel(const float*
     }
 }
 
+
+// The same gather through LDS, for rows of a power-of-two number of 16-byte quads (ShuffleNet-v2's padded halves: 128 / 256 / 512
+// channels per source).  The kernels above fetch every element with its own 4-byte (2-byte) load -- 64 addresses per instruction,
+// 3.0 TB/s however the loop around them is arranged (fixed quad per thread, four rows in flight: 20.3 vs 20.9 us).  Here a block
+// moves GROUPS of rows: whole source rows come in as 16-byte (8-byte) pieces, four per thread in flight, get the batch-norm
+// affine of their source on the way (the same fma / max as above: bit-identical results) and land in LDS as [row][a | b]; the
+// permutation is applied by the LDS reads (4-byte reads at the table's positions, 2-way conflicts for the shuffle) and the
+// outputs leave as 16-byte pieces.  Every per-thread quantity (source, channel quad, coefficients, table entries, LDS
+// positions) is fixed for the whole walk.
+template <bool H = false>
+__global__ __launch_bounds__(256) void channel_gather_lds_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 float* __restrict__ out0, const int* __restrict__ table0, int co0,
+                                                                 float* __restrict__ out1, const int* __restrict__ table1, int co1,
+                                                                 long rows, int ca, int cb,
+                                                                 const float* __restrict__ sca, const float* __restrict__ sfa, int relu_a,
+                                                                 const float* __restrict__ scb, const float* __restrict__ sfb, int relu_b,
+                                                                 int qin, int qout, int rg) {
+    extern __shared__ __attribute__((aligned(16))) float gsh[];          // [rg][4 * qin]
+    const int tid = threadIdx.x, W = 4 * qin;
+    // load side: this thread's source quad
+    const int iq = tid & (qin - 1), ri = tid / qin, rin = 256 / qin, qa = ca >> 2;
+    const bool fb = iq >= qa;
+    const int chi = 4 * (fb ? iq - qa : iq);
+    const float* const srcp = fb ? b : a;
+    const long ldi = fb ? cb : ca;
+    const float* const scp = fb ? scb : sca;
+    const float* const sfp = fb ? sfb : sfa;
+    const bool aff = scp != nullptr, relu = fb ? relu_b != 0 : relu_a != 0;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    if (aff) { sc = *reinterpret_cast<const f32x4*>(scp + chi); sf = *reinterpret_cast<const f32x4*>(sfp + chi); }
+    // store side: this thread's output quad and where its four elements sit in a staged row
+    const int oq = tid & (qout - 1), ro = tid / qout, rout = 256 / qout, q0 = co0 >> 2;
+    const bool second = oq >= q0;
+    const int k4 = second ? oq - q0 : oq;
+    const int4 t = *reinterpret_cast<const int4*>((second ? table1 : table0) + 4 * k4);
+    const int tt[4] = {t.x, t.y, t.z, t.w};
+    int pos[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pos[e] = tt[e] < 0 ? -1 : ((tt[e] >> 16) ? ca : 0) + (tt[e] & 0xffff);
+    float* const outp = second ? out1 : out0;
+    const long ldo = second ? co1 : co0;
+    const int nin = rg / rin, nout = rg / rout;
+    for (long g0 = (long)blockIdx.x * rg; g0 < rows; g0 += (long)gridDim.x * rg) {
+        for (int s0 = 0; s0 < nin; s0 += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long r = g0 + (long)(s0 + u) * rin + ri;
+                v[u] = (s0 + u < nin && r < rows) ? ldq<H>(srcp, r * ldi + chi) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (s0 + u >= nin) continue;
+                f32x4 x = v[u];
+                if (aff) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = __builtin_fmaf(x[e], sc[e], sf[e]);
+                        if (relu) x[e] = fmaxf(x[e], 0.f);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(gsh + ((s0 + u) * rin + ri) * W + 4 * iq) = x;
+            }
+        }
+        __syncthreads();
+        for (int s = 0; s < nout; ++s) {
+            const int rl = s * rout + ro;
+            const long r = g0 + rl;
+            if (r >= rows) break;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pos[e] < 0 ? 0.f : gsh[rl * W + pos[e]];
+            stq<H>(outp, r * ldo + 4 * k4, o);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 hipError_t l_dwconv_fwd(const float* x, const float* w, float* y, int n, int h, int wd, int c, int ho, int wo, int stride, int pt, int pl, hipStream_t st, int h16) {
@@ -2803,9 +2881,29 @@ hipError_t l_dwconv_wgrad(const float* x, const float* dy, float* part, int n, i
 #undef FTE_DWW
     return hipGetLastError();
 }
+// the LDS form when a row is a power-of-two number of quads on both sides (<= 256) and holds at most 16 KB of staging per 4 load steps
+static bool gather_lds(const float* a, const float* b, float* out0, const int* table0, int co0, float* out1, const int* table1, int co1,
+                       long rows, int ca, int cb, const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b,
+                       hipStream_t st, int h16) {
+    static const bool off = getenv("FTE_GATHER_LDS") && atoi(getenv("FTE_GATHER_LDS")) == 0;      // A/B hook: the element-gather kernels
+    if (off || (ca & 3) || (cb & 3) || (co0 & 3) || (co1 & 3) || (cb && !b) || (co1 && !out1)) return false;
+    const int qin = (ca + cb) / 4, qout = (co0 + co1) / 4;
+    if (qin < 1 || qin > 256 || (qin & (qin - 1)) || qout < 1 || qout > 256 || (qout & (qout - 1))) return false;
+    static const int U = getenv("FTE_GATHER_U") ? atoi(getenv("FTE_GATHER_U")) : 4;
+    static const long cap = getenv("FTE_GATHER_BLOCKS") ? atol(getenv("FTE_GATHER_BLOCKS")) : 2048;
+    const int rin = 256 / qin, rout = 256 / qout, rg = U * (rin > rout ? rin : rout);
+    const size_t lds = (size_t)rg * qin * 16;
+    if (lds > 65536) return false;
+    const long groups = (rows + rg - 1) / rg;
+    const dim3 grid((unsigned)(groups > cap ? cap : (groups < 1 ? 1 : groups)));
+    if (h16) hipLaunchKernelGGL(channel_gather_lds_kernel<true>, grid, dim3(256), lds, st, a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b, qin, qout, rg);
+    else hipLaunchKernelGGL(channel_gather_lds_kernel<false>, grid, dim3(256), lds, st, a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b, qin, qout, rg);
+    return true;
+}
 hipError_t l_channel_gather_affine(const float* a, const float* b, float* out0, const int* table0, int co0,
                                    float* out1, const int* table1, int co1, long rows, int ca, int cb,
                                    const float* sca, const float* sfa, int relu_a, const float* scb, const float* sfb, int relu_b, hipStream_t st, int h16) {
+    if (gather_lds(a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b, st, h16)) return hipGetLastError();
     const long total = rows * ((co0 + co1) / 4);
     const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
     if (h16) hipLaunchKernelGGL(channel_gather_affine_kernel<true>, grid, dim3(256), 0, st, a, b, out0, table0, co0, out1, table1, co1, rows, ca, cb, sca, sfa, relu_a, scb, sfb, relu_b);
@@ -2813,6 +2911,7 @@ hipError_t l_channel_gather_affine(const float* a, const float* b, float* out0, 
     return hipGetLastError();
 }
 hipError_t l_channel_gather(const float* a, const float* b, float* out, const int* table, long rows, int ca, int cb, int co, hipStream_t st, int h16) {
+    if (gather_lds(a, b, out, table, co, nullptr, nullptr, 0, rows, ca, cb, nullptr, nullptr, 0, nullptr, nullptr, 0, st, h16)) return hipGetLastError();
     const long total = rows * (co / 4);
     const dim3 grid((unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256));
     if (h16) hipLaunchKernelGGL(channel_gather_kernel<true>, grid, dim3(256), 0, st, a, b, out, table, rows, ca, cb, co);
