@@ -152,7 +152,7 @@ def test_dense_nn_nt_tn(m, n, k):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
-@pytest.mark.parametrize('m,n,k', [(128, 128, 256), (128, 256, 128), (37, 64, 128), (128, 1024, 2048), (5, 32, 384), (256, 2048, 1024)])
+@pytest.mark.parametrize('m,n,k', [(128, 128, 256), (128, 256, 128), (37, 64, 128), (128, 1024, 2048), (5, 32, 384), (256, 2048, 1024), (128, 128, 2048), (128, 64, 1024), (64, 128, 512), (128, 96, 1536)])
 def test_dense_small_one_launch_layers(m, n, k, mode):
     """fte_dense_small: the squeeze-excitation gate's dense layers (nets/shufflenet_v2.py:79-85) in one launch -- forward with bias and
     ReLU / sigmoid, the gradient w.r.t. the input through w^T with the ReLU mask; ragged m (37, 5 rows: part of a 32-row tile); fp32

@@ -1041,7 +1041,7 @@ typedef __bf16 bf16x8d __attribute__((ext_vector_type(8)));
 template <bool BF, bool TW, int NW>
 __global__ __launch_bounds__(64 * NW) void dense_small_kernel(const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
                                                           const float* __restrict__ mask, float* __restrict__ out, int m, int n, int k, int act) {
-    __shared__ float part[NW][32][33];
+    __shared__ float part[NW][32][32];                        // (16 waves: the whole 64 KB)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
     const int col0 = blockIdx.x * 32, row0 = blockIdx.y * 32;
     const int kw = k / NW, kb = wv * kw;                       // this wave's K range (whole 64-deep trips: the launcher checks)
@@ -1115,10 +1115,14 @@ hipError_t k_dense_small(const float* a, const float* w, const float* bias, cons
                          bool trans_w, int act, bool bf16, hipStream_t st) {
     if (m <= 0 || n <= 0 || n % 32 || k <= 0 || k % 128) return hipErrorInvalidValue;
     const dim3 grid(n / 32, (m + 31) / 32);
-    // waves per tile: each takes k / NW in whole 64-deep trips (bf16) / 32-deep (fp32); eight from K = 1024 on (a wave's loop is a
-    // chain of ~1-us trips: 128 x 1024 <- 2048 ran 21 us with four waves)
-    const int nw = (k % 512 == 0 && k >= 1024) ? 8 : (k % 256 == 0 ? 4 : 2);
-#define FTE_DS(BF_, TW_) do { if (nw == 8) hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 8>), grid, dim3(512), 0, st, a, w, bias, mask, out, m, n, k, act); \
+    // waves per tile: each takes k / NW in whole 64-deep trips (bf16) / 32-deep (fp32).  A wave's loop is a chain of ~1.5-us trips
+    // (every trip's loads depend on nothing but are issued after the previous trip's MFMAs), and these launches are 16-64 blocks on
+    // 256 CUs -- the chain IS the kernel: 128 x 128 <- 2048 ran 21 us with four waves (8 trips), 17 with eight (4), and runs one or
+    // two trips with sixteen.  As many waves as give whole trips, up to 16.
+    static const int max_nw = getenv("FTE_DENSE_SMALL_NW") ? atoi(getenv("FTE_DENSE_SMALL_NW")) : 16;      // tuning hook
+    const int nw = (k % 1024 == 0 && max_nw >= 16) ? 16 : (k % 512 == 0 && max_nw >= 8) ? 8 : (k % 256 == 0 ? 4 : 2);
+#define FTE_DS(BF_, TW_) do { if (nw == 16) hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 16>), grid, dim3(1024), 0, st, a, w, bias, mask, out, m, n, k, act); \
+                              else if (nw == 8) hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 8>), grid, dim3(512), 0, st, a, w, bias, mask, out, m, n, k, act); \
                               else if (nw == 4) hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 4>), grid, dim3(256), 0, st, a, w, bias, mask, out, m, n, k, act); \
                               else hipLaunchKernelGGL((dense_small_kernel<BF_, TW_, 2>), grid, dim3(128), 0, st, a, w, bias, mask, out, m, n, k, act); } while (0)
     if (bf16) { if (trans_w) FTE_DS(true, true); else FTE_DS(true, false); }
