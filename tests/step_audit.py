@@ -672,7 +672,7 @@ ENTRY_KERNELS = {
     'fte_gap_fwd': ['gap_fwd_kernel'], 'fte_gap_fwd_s16': ['gap_fwd_kernel'], 'fte_gap_bwd': ['gap_bwd_kernel'], 'fte_gap_bwd_s16': ['gap_bwd_kernel'],
     'fte_im2col_first': ['im2col_first_kernel', 'im2col_first_rows_kernel'], 'fte_im2col_first_s16': ['im2col_first_kernel', 'im2col_first_rows_kernel'],
     'fte_dropout_fwd': ['dropout_fwd_kernel'], 'fte_dropout_bwd': ['scale_mask_kernel'],
-    'fte_pack_weights_bf16_table': ['pack_weights_table_kernel'], 'fte_gconv3x3_pack_bf16': ['gconv_pack16_kernel'],
+    'fte_pack_weights_bf16_table': ['pack_weights_table_kernel', 'pack_weights_tiles_kernel'], 'fte_gconv3x3_pack_bf16': ['gconv_pack16_kernel'],
     'fte_batch_hard_triplet_fwd_bwd': ['triplet_dist_kernel', 'triplet_mine_kernel', 'triplet_grad_kernel'],
     'fte_softmax_ce_fwd_bwd': ['softmax_ce_reg_kernel', 'softmax_ce_kernel'],
 }

@@ -385,7 +385,8 @@ def test_filter_packs_table_equals_per_conv_packs():
     bit-identical packs, for 3x3 and 1x1 filters of different shapes scattered through an arena, in chunks of up to 64 rows."""
     from tf_face_toolbox_amd.nets._packs import FilterPacks
     g = torch.Generator(device='cuda').manual_seed(3)
-    shapes = [(3, 64, 64), (1, 256, 64), (3, 128, 256), (1, 64, 2048), (3, 32, 32)] * 15          # 75 convs: two table launches
+    shapes = [(3, 64, 64), (1, 256, 64), (3, 128, 256), (1, 64, 2048), (3, 32, 32), (1, 160, 64), (3, 96, 96), (1, 4, 8), (3, 244, 36)] * 8 \
+        + [(1, 2048, 512), (3, 512, 512), (1, 72, 200)]          # 75 convs: two table launches; tiles that end inside a 64 x 64 tile on either side
     entries, off = [], 12                                                                           # 16-byte aligned, not at 0
     for i, (k, cin, cout) in enumerate(shapes):
         entries.append(('c%d' % i, off, k, cin, cout))

@@ -959,9 +959,62 @@ __global__ __launch_bounds__(256) void pack_weights_table_kernel(const float* __
         *reinterpret_cast<uint2*>(w16t + d[1] + j) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
     }
 }
+// The [tap][cout][cin] pack by 64 x 64 tiles through LDS (round 5).  The kernel above gathers its four source elements down a
+// column of the HWIO filter (stride cout floats): every 4-byte read is a cache line of its own, the lines come back 16-32 times
+// through L2 and the launch moves 4x its algorithmic bytes (290 MB for ResNet-50's 23.5 M filter elements, 61 us beside the stem;
+// profiles/r5_resnet50_*).  Here a block reads a tile's 64 source rows as whole 256-byte pieces, rounds, transposes in LDS and writes
+// 128-byte destination row pieces.  Same table; a block finds its (conv, tap, tile) by walking the <= 64 rows.
+__global__ __launch_bounds__(256) void pack_weights_tiles_kernel(const float* __restrict__ params, unsigned short* __restrict__ w16t,
+                                                                 const int* __restrict__ table, int nconv) {
+    __shared__ int tb[64 * 6];
+    __shared__ unsigned short tile[64][68];              // [co][ci], rows 136 bytes apart (34 words: the transposing 2-byte stores spread over the banks)
+    for (int i = threadIdx.x; i < nconv * 6; i += 256) tb[i] = table[i];
+    __syncthreads();
+    const int tid = threadIdx.x;
+    for (long t = blockIdx.x;; t += gridDim.x) {
+        long acc = 0;
+        int c = -1, nci = 0, nco = 0;
+        for (int q = 0; q < nconv; ++q) {
+            nci = (tb[q * 6 + 3] + 63) >> 6; nco = (tb[q * 6 + 4] + 63) >> 6;
+            const long nt = (long)tb[q * 6 + 2] * nci * nco;
+            if (t < acc + nt) { c = q; break; }
+            acc += nt;
+        }
+        if (c < 0) break;                                 // (uniform: every thread of the block walks the same t)
+        const int* d = tb + c * 6;
+        const int cin = d[3], cout = d[4];
+        const int local = (int)(t - acc), tap = local / (nci * nco), r2 = local - tap * (nci * nco);
+        const int ci0 = (r2 / nco) << 6, co0 = (r2 % nco) << 6;
+        const float* src = params + d[0] + (long)tap * cin * cout;
+        f32x4k v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ci = ci0 + (tid >> 4) + 16 * u, co = co0 + 4 * (tid & 15);
+            v[u] = (ci < cin && co < cout) ? *reinterpret_cast<const f32x4k*>(src + (long)ci * cout + co) : f32x4k{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[4 * (tid & 15) + e][(tid >> 4) + 16 * u] = __builtin_bit_cast(unsigned short, (__bf16)v[u][e]);
+        __syncthreads();
+        unsigned short* dst = w16t + d[1] + (long)tap * cout * cin;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = (tid >> 4) + 16 * u, co = co0 + rr, ci = ci0 + 4 * (tid & 15);
+            if (co < cout && ci < cin) *reinterpret_cast<uint2*>(dst + (long)co * cin + ci) = *reinterpret_cast<const uint2*>(&tile[rr][4 * (tid & 15)]);
+        }
+        __syncthreads();
+    }
+}
 }  // namespace
 hipError_t k_pack_weights_table(const float* params, unsigned short* w16t, const int* table, int nconv, long total, int transposed, hipStream_t st) {
     const long t4 = total / 4;
+    static const bool tiles_off = getenv("FTE_PACK_TILES") && atoi(getenv("FTE_PACK_TILES")) == 0;      // A/B hook: the element gather
+    if (transposed && !tiles_off && nconv <= 64) {
+        const long tiles = total / 4096 + 9L * nconv;     // upper bound on the tile count is all a grid-stride walk needs
+        hipLaunchKernelGGL(pack_weights_tiles_kernel, dim3((unsigned)(tiles > 4096 ? 4096 : (tiles < 1 ? 1 : tiles))), dim3(256), 0, st, params, w16t, table, nconv);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pack_weights_table_kernel, dim3((unsigned)((t4 + 255) / 256 > 8192 ? 8192 : (t4 + 255) / 256)), dim3(256), 0, st,
                        params, w16t, table, nconv, t4, transposed);
     return hipGetLastError();
