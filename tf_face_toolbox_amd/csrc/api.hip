@@ -1224,7 +1224,7 @@ int fte_conv2d_bn_fwd(const void* x, const void* w, void* z, const float* gamma,
         const int hr = igemm_prof_begin(sig, (int)M, cout, cin, 2.0 * M * cout * (double)cin, 2.0 * M * (cin + cout) + 2.0 * cin * cout, (hipStream_t)stream);
         hipError_t he = pw16_launch(pw, in_scale ? PW_PRO_FWD : PW_PRO_NONE, PW_EPI_STATS, (hipStream_t)stream);
         char sym[64];
-        snprintf(sym, sizeof(sym), "pw16_kernel<%d,%d,%d,%d,%d>", cin, cout / pw.nct, cin == 256 ? 4 : 8, in_scale ? PW_PRO_FWD : PW_PRO_NONE, PW_EPI_STATS);
+        snprintf(sym, sizeof(sym), "pw16_kernel<%d,%d,%d,%d,%d>", cin, cout / pw.nct, pw16_waves(pw, in_scale ? PW_PRO_FWD : PW_PRO_NONE, PW_EPI_STATS), in_scale ? PW_PRO_FWD : PW_PRO_NONE, PW_EPI_STATS);
         igemm_prof_end(hr, sym, (hipStream_t)stream);
         if (he != hipSuccess) return (int)he;
         return rc(l_bn_finalize((const float*)ws, pw.nrb, gamma, beta, cout, eps, decay, mean, rstd, scale, shift, moving_mean, moving_var,

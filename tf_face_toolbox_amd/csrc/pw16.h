@@ -25,3 +25,4 @@ enum { PW_EPI_PLAIN = 0, PW_EPI_STATS = 1, PW_EPI_BN = 2 };
 // true (and nrb / nct filled) when the kernel takes the shape: K in {64, 128, 256}, N a multiple of the column tile
 bool pw16_plan(long M, int K, int N, int epi, Pw16Params* p);
 hipError_t pw16_launch(const Pw16Params& p, int pro, int epi, hipStream_t st);
+int pw16_waves(const Pw16Params& p, int pro, int epi);

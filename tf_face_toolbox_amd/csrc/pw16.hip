@@ -441,9 +441,15 @@ inline int nb_for(int K, int N, int epi) {
 bool pw16_plan(long M, int K, int N, int epi, Pw16Params* p) {
     static const bool off = getenv("FTE_PW16") && atoi(getenv("FTE_PW16")) == 0;      // A/B hook
     if (off || (K != 64 && K != 128 && K != 256) || N < 64 || N % 64 || M < 32 || M * (long)(K > N ? K : N) * 2 >= ((long)1 << 31)) return false;
-    const int nb = nb_for(K, N, epi);
+    // K = 256: the 128-column slice (64 KB) leaves room for four 16 KB wave stages -- ONE wave per SIMD, every phase of a tile exposed.  A
+    // 64-column slice admits eight (32 + 128 KB): 28x28 256->128 at 128 images 34.4 -> 27.9 us, 256->256 44.0 -> 38.0 (the rows are read by
+    // two column tiles of one XCD instead of one).  The BN-backward forms keep four waves: with eight they spill.  FTE_PW16_K256=0: as before.
+    static const bool k256_wide = getenv("FTE_PW16_K256") && atoi(getenv("FTE_PW16_K256")) == 0;
+    int nb = nb_for(K, N, epi);
+    const bool eight256 = K == 256 && !k256_wide && epi != PW_EPI_BN;
+    if (eight256) nb = 64;
     if (N % nb) return false;
-    const int nw = K == 256 ? 4 : 8;
+    const int nw = (K == 256 && !eight256) ? 4 : 8;
     p->nct = N / nb;
     const long tiles = (M + 31) / 32;
     long nrb = (tiles + nw - 1) / nw;                 // at least one tile per wave ...
@@ -459,6 +465,13 @@ bool pw16_plan(long M, int K, int N, int epi, Pw16Params* p) {
     return true;
 }
 
+// waves per block of the instantiation pw16_launch picks (the launch records spell the symbol with it)
+int pw16_waves(const Pw16Params& p, int pro, int epi) {
+    if (p.K != 256) return 8;
+    static const bool k256_wide = getenv("FTE_PW16_K256") && atoi(getenv("FTE_PW16_K256")) == 0;
+    return (p.N / p.nct == 64 && !k256_wide && pro != PW_PRO_BWD && epi != PW_EPI_BN) ? 8 : 4;
+}
+
 hipError_t pw16_launch(const Pw16Params& p, int pro, int epi, hipStream_t st) {
     const int nb = p.N / p.nct;
     if (p.K == 64) {
@@ -472,7 +485,9 @@ hipError_t pw16_launch(const Pw16Params& p, int pro, int epi, hipStream_t st) {
         return launch_modes<128, 64, 8>(p, pro, epi, st);
     }
     if (p.K == 256) {
+        static const bool k256_wide = getenv("FTE_PW16_K256") && atoi(getenv("FTE_PW16_K256")) == 0;
         if (nb == 128) return launch_modes<256, 128, 4>(p, pro, epi, st);
+        if (!k256_wide && pro != PW_PRO_BWD && epi != PW_EPI_BN) return launch_modes<256, 64, 8>(p, pro, epi, st);
         return launch_modes<256, 64, 4>(p, pro, epi, st);
     }
     return hipErrorInvalidValue;
