@@ -2887,6 +2887,8 @@ static bool gather_lds(const float* a, const float* b, float* out0, const int* t
                        hipStream_t st, int h16) {
     static const bool off = getenv("FTE_GATHER_LDS") && atoi(getenv("FTE_GATHER_LDS")) == 0;      // A/B hook: the element-gather kernels
     if (off || (ca & 3) || (cb & 3) || (co0 & 3) || (co1 & 3) || (cb && !b) || (co1 && !out1)) return false;
+    const uintptr_t ptrs = (uintptr_t)a | (uintptr_t)b | (uintptr_t)out0 | (uintptr_t)out1 | (uintptr_t)sca | (uintptr_t)sfa | (uintptr_t)scb | (uintptr_t)sfb;
+    if (ptrs & 15) return false;                          // whole 16-byte pieces on both sides (the element kernels take any 4-byte alignment of the sources)
     const int qin = (ca + cb) / 4, qout = (co0 + co1) / 4;
     if (qin < 1 || qin > 256 || (qin & (qin - 1)) || qout < 1 || qout > 256 || (qout & (qout - 1))) return false;
     static const int U = getenv("FTE_GATHER_U") ? atoi(getenv("FTE_GATHER_U")) : 4;
