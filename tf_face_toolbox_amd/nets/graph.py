@@ -737,6 +737,16 @@ class GraphNet(Network):
         h16 = self.h16
         pack_ev = None
         side_packs = None
+        self._reg_ev = None
+        if is_training and self.side is not None and os.environ.get('FTE_REG_SIDE', '1') != '0':
+            # Network._regularize's sum over the decayed weights (one pass over the arena: 25-40 us) depends on nothing the walk computes:
+            # it runs on the side stream under the first layers instead of between the loss head's launches; loss_function waits for it
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            nreg = self.arena_size - self.small_end
+            call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
+                 self.loss_slots[1:2], self.ws_side, self.ws_bytes, self.side.cuda_stream)
+            self._reg_ev = self.side.record_event()
         if s16:
             # every filter's bf16 packs, refreshed once per step.  The walk's first layers need only THEIR forward packs: those are
             # made here; the rest -- the other layers' forward packs, every HWIO pack (read by the backward pass only) and the
@@ -1157,16 +1167,20 @@ class GraphNet(Network):
                 call('fte_sum', self.loss_rows, n, self.tower_scale / (n * d), slots[2:3], self.ws, self.ws_bytes, st)
                 self._dfeat = self.dfeat
                 losses.append(slots[2]); names.append('center_loss')
-        nreg = self.arena_size - self.small_end
-        call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
-             slots[1:2], self.ws, self.ws_bytes, st)
+        if getattr(self, '_reg_ev', None) is not None:           # taken on the side stream at the start of this forward pass
+            torch.cuda.current_stream().wait_event(self._reg_ev)
+            self._reg_ev = None
+        else:
+            nreg = self.arena_size - self.small_end
+            call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
+                 slots[1:2], self.ws, self.ws_bytes, st)
         losses.append(slots[1]); names.append('reg_loss')
         return losses, names, OrderedDict()
 
     # ---- backward ---------------------------------------------------------------------------------------
     def backward(self):
         if self.has_classifier:
-            self.backward_head()
+            self.backward_head(join=False)               # (backward_body joins the side stream when it returns)
         self.backward_body()
 
     def backward_stages(self):
@@ -1228,16 +1242,26 @@ class GraphNet(Network):
         self._segs = segs
         return segs
 
-    def backward_head(self):
-        """Classifier gradient (first all-reduce bucket) and the gradient wrt its input."""
+    def backward_head(self, join=True):
+        """Classifier gradient (first all-reduce bucket) and the gradient wrt its input.  The filter gradient goes to the side stream
+        like every other one (nothing but the optimizer / the bucket's all-reduce reads it); `join`: the main stream waits for it before
+        this returns (backward_stages: the bucket is reduced next)."""
         n = self._act_n
         st = _stream()
         op = self.plan[-1]
         k = self.shapes[op[2]][0]
         self._grad = {}
         gin = torch.empty(n, k, dtype=torch.float32, device=self.device)
-        _lib.call('fte_gemm_tn', self.t[op[2]], self.G, self.view(op[3], self.grads), n, self.cpad, k, self.ws, self.ws_bytes, st)
+        side = self.side if os.environ.get('FTE_HEAD_SIDE', '1') != '0' else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_event(main.record_event())         # G (the loss head's gradient) and the features are complete
+            _lib.call('fte_gemm_tn', self.t[op[2]], self.G, self.view(op[3], self.grads), n, self.cpad, k, self.ws_side, self.ws_bytes, side.cuda_stream)
+        else:
+            _lib.call('fte_gemm_tn', self.t[op[2]], self.G, self.view(op[3], self.grads), n, self.cpad, k, self.ws, self.ws_bytes, st)
         _lib.call('fte_gemm_nt', self.G, self.view(op[3]), None, None, 0, None, gin, None, n, self.cpad, k, self.ws, self.ws_bytes, st)
+        if side is not None and join:
+            torch.cuda.current_stream().wait_stream(side)
         self._grad[op[2]] = gin
 
     def _new(self, name):
