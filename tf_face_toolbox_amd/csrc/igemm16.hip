@@ -2357,7 +2357,11 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
         // loop keeps in flight: one K-step per block on the two-stage ring = 24-32 KB per block, 1.5 us per step.  A three-stage ring
         // (two steps in flight, still two blocks per CU) runs them in 0.6x the time.  FTE_BN16_NST=2 restores the two-stage ring.
         static const int nst_env = getenv("FTE_BN16_NST") ? atoi(getenv("FTE_BN16_NST")) : 3;
-        static const int nst_tiles = getenv("FTE_BN16_NST_TILES") ? atoi(getenv("FTE_BN16_NST_TILES")) : 768;
+        // ... while the launch has at most ONE tile per CU.  From 257 to 768 tiles the two-stage ring puts every tile on the chip in one
+        // round (up to four blocks per CU) where the 96 KB of the three-stage ring admit one block per CU and need two or three: conv +
+        // statistics at 128 images, us, three / two stages: 14x14 1024->256 (392 tiles) 37.0 / 31.4, 7x7 2048->1024 (392) 52.9 / 44.3,
+        // 7x7 2048->512 (196) 29.4 / 35.2; ResNeXt-50 step 6.55 -> 6.47 ms (round 5; the threshold was 768: profiles/r5_notes.md 12)
+        static const int nst_tiles = getenv("FTE_BN16_NST_TILES") ? atoi(getenv("FTE_BN16_NST_TILES")) : 256;
         const long ntl = (long)((p.M - p.m_base + 127) / 128) * (p.N / (tile == TILE_128x128 ? 128 : 64)) * (p.ncls > 1 ? p.ncls : 1);
         const bool deep = nst_env >= 3 && ntl <= nst_tiles && p.K / BK16 >= 6;
         if (tile == TILE_128x128) {
@@ -2437,7 +2441,7 @@ hipError_t igemm16_launch(const IgemmParams& p, int epi, int tile, int splits, h
     // shard): the three-stage ring, as for the conv -> BN launches above.  FTE_IGEMM16_DEEP=0 turns it off.
     {
         static const int deep_env = getenv("FTE_IGEMM16_DEEP") ? atoi(getenv("FTE_IGEMM16_DEEP")) : 1;
-        static const int deep_tiles = getenv("FTE_IGEMM16_DEEP_TILES") ? atoi(getenv("FTE_IGEMM16_DEEP_TILES")) : 768;
+        static const int deep_tiles = getenv("FTE_IGEMM16_DEEP_TILES") ? atoi(getenv("FTE_IGEMM16_DEEP_TILES")) : 256;      // (one tile per CU at most: see the conv -> BN launches above)
         const long ntl = (long)((p.M - p.m_base + 127) / 128) * (p.N / (tile == TILE_128x128 ? 128 : 64)) * (p.ncls > 1 ? p.ncls : 1);
         if (deep_env && splits == 1 && !p.PW && p.a_NT == 1 && ntl <= deep_tiles && p.kchunk >= p.K && p.K / BK16 >= 6) {
             if (tile == TILE_128x128) {
