@@ -65,6 +65,7 @@ def kernel_src_sha():
     for f in sorted(os.listdir(d)):
         if f.endswith(('.hip', '.h')):
             h.update(open(os.path.join(d, f), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 'fte.h'), 'rb').read())      # the ABI header is part of the build (csrc/build.sh)
     return h.hexdigest()[:16]
 
 

@@ -58,6 +58,22 @@ const char* fte_version(void);
 int fte_set_mfma_dtype(int dtype);
 int fte_get_mfma_dtype(void);
 
+/* ---------------------------------------------------------------------------
+ * Convolution algorithm of the stride-1 3x3 layers in the fp32, BN-free entry points (fte_conv3x3_* / fte_conv2d_*): the reference
+ * runs them on cuDNN's Winograd algorithm (train.py:260 sets TF_ENABLE_WINOGRAD_NONFUSED=1 for every run; the layers are
+ * nets/sphere.py:41-42).  Process-wide; initialised from the environment variable FTE_CONV_ALGO = direct | winograd | auto.
+ *   FTE_CONV_DIRECT   implicit GEMM over the nine taps (csrc/igemm.hip)
+ *   FTE_CONV_WINOGRAD F(2x2,3x3) -- and F(3x3,2x2) for the filter gradient -- wherever the kernels exist (channels % 64 == 0)
+ *   FTE_CONV_AUTO     (default) Winograd for the layers where it measured faster (>= 256 channels), direct elsewhere
+ * Winograd needs the workspace fte_*_ws_bytes reports UNDER THE CURRENT SETTING (transformed tiles: 64 bytes per tile and channel);
+ * with less the call runs the direct algorithm.  Same results to fp32 rounding (tests/test_gpu_wino.py: <= 2e-5 of max|ref|).
+ * ------------------------------------------------------------------------- */
+#define FTE_CONV_DIRECT 0
+#define FTE_CONV_WINOGRAD 1
+#define FTE_CONV_AUTO 2
+int fte_set_conv_algo(int algo);
+int fte_get_conv_algo(void);
+
 /* Measurement hook (bench.py's roofline leg; no reference counterpart).  While enabled, every
  * launch of the MFMA kernel family is bracketed by a HIP event pair ON THE LAUNCH STREAM and its
  * algorithmic FLOPs (2*rows*N*K of that launch) are recorded.  fte_prof_enable(1) clears and starts,

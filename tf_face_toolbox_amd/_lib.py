@@ -111,6 +111,8 @@ _SIGS = {
     'fte_gconv3x3_dgrad_bn_bf16_s16': (c_int, [_P] * 12 + [c_int] * 5 + [_P, c_size_t, _P]),
     'fte_set_mfma_dtype': (c_int, [c_int]),
     'fte_get_mfma_dtype': (c_int, []),
+    'fte_set_conv_algo': (c_int, [c_int]),
+    'fte_get_conv_algo': (c_int, []),
     'fte_dwconv3x3_fwd': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_dgrad': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_wgrad': (c_int, [_P] * 3 + [c_int] * 5 + [_P, c_size_t, _P]),

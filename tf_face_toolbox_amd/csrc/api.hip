@@ -13,6 +13,7 @@
 #include "pw16.h"
 #include "kernels.h"
 #include "layers.h"
+#include "wino.h"
 
 namespace {
 
@@ -321,6 +322,54 @@ size_t both_modes(F f) {
     }
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
+
+// ---- Winograd F(2x2, 3x3) plan (wino.hip) ---------------------------------------------------------------------------------------
+// The stride-1 3x3 layers of the BN-free fp32 path (nets/sphere.py:41-42) may run as 16 products of 1/2.25 of the MACs.  FTE_CONV_ALGO /
+// fte_set_conv_algo: direct = never, winograd = wherever the kernels exist (channels % 64, fp32 operands), auto = the measured rule:
+// layers of >= FTE_WINO_MIN_C channels (default: see wino_min_c) -- below that the transform traffic (16 floats per tile and channel, in
+// and out of HBM) outweighs the saved MFMA time.
+inline int wino_min_c() {
+    static const int v = getenv("FTE_WINO_MIN_C") ? atoi(getenv("FTE_WINO_MIN_C")) : 256;
+    return v;
+}
+inline bool wino_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+    if (ksize != 3 || stride != 1 || cin % 64 || cout % 64 || n <= 0 || h < 2 || wd < 2) return false;
+    const size_t lim = (size_t)1 << 31;
+    return (size_t)n * h * wd * cin * 4 < lim && (size_t)n * h * wd * cout * 4 < lim;
+}
+// op: 0 forward, 1 data gradient, 2 filter gradient.  wino_sized: the current switch would pick the algorithm for this layer in the
+// fp32 mode (what the workspace queries size for); wino_wanted: ... and this launch is an fp32, BN-free one
+inline bool wino_sized(int n, int h, int wd, int cin, int cout, int ksize, int stride, int op) {
+    const int algo = wino_get_algo();
+    if (algo == 0 || !wino_shape_ok(n, h, wd, cin, cout, ksize, stride)) return false;
+    if (op == 2 && !wino_wgrad_splits(cin, cout)) return false;
+    if (algo == 1) return true;
+    static const int ops = getenv("FTE_WINO_OPS") ? atoi(getenv("FTE_WINO_OPS")) : 7;      // A/B hook: bit per op
+    if (!(ops & (1 << op))) return false;
+    return cin >= wino_min_c() && cout >= wino_min_c();
+}
+inline bool wino_wanted(int n, int h, int wd, int cin, int cout, int ksize, int stride, int op) {
+    return !plan_bf16() && !g_plan_bn && wino_sized(n, h, wd, cin, cout, ksize, stride, op);
+}
+struct WinoWs { size_t v_off, u_off, slab_off, total; };
+// workspace layout behind `head` bytes the caller keeps for itself: [V pack | U pack (| slabs)]
+inline WinoWs wino_ws(int n, int h, int wd, int cin, int cout, int op, size_t head) {
+    const WinoGeom g = wino_geom(n, h, wd);
+    WinoWs w;
+    w.v_off = align_up(head);
+    if (op == 0) {            // V(x): cin channels; U: filters
+        w.u_off = w.v_off + align_up(wino_pack_floats(g.M, cin) * 4);
+        w.slab_off = w.total = w.u_off + align_up((size_t)16 * cin * cout * 4);
+    } else if (op == 1) {     // V(dz): cout channels; U: rotated filters
+        w.u_off = w.v_off + align_up(wino_pack_floats(g.M, cout) * 4);
+        w.slab_off = w.total = w.u_off + align_up((size_t)16 * cin * cout * 4);
+    } else {                  // V(x), U'(dz), slabs
+        w.u_off = w.v_off + align_up(wino_pack_floats(g.M, cin) * 4);
+        w.slab_off = w.u_off + align_up(wino_pack_floats(g.M, cout) * 4);
+        w.total = w.slab_off + align_up((size_t)wino_wgrad_splits(cin, cout) * 16 * cin * cout * 4);
+    }
+    return w;
+}
 }  // namespace
 
 extern "C" {
@@ -352,6 +401,13 @@ int fte_set_mfma_dtype(int dtype) {
 }
 int fte_get_mfma_dtype(void) { return igemm_get_bf16() ? FTE_MFMA_BF16 : FTE_MFMA_F32; }
 
+int fte_set_conv_algo(int algo) {
+    if (algo < FTE_CONV_DIRECT || algo > FTE_CONV_AUTO) return FTE_EINVAL;
+    wino_set_algo(algo);
+    return FTE_OK;
+}
+int fte_get_conv_algo(void) { return wino_get_algo(); }
+
 int fte_prof_enable(int on) { igemm_prof_enable(on != 0, on == 1); return FTE_OK; }
 int fte_prof_count(void) { return igemm_prof_count(); }
 int fte_prof_get_shape(int i, int* mnk, double* bytes) {
@@ -371,7 +427,12 @@ int fte_prof_get(int i, int* sig, double* flops, float* ms) {
 size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     if (n <= 0 || cin <= 0 || cin % 32 || cout <= 0 || cout % 64) return 0;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
-    return both_modes([&] { return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true, false, EPI_FWD).pw_bytes; });
+    size_t need = both_modes([&] { return plan_rows((long)n * ph.out * pw.out, cout, (long)ksize * ksize * cin, true, false, EPI_FWD).pw_bytes; });
+    if (wino_sized(n, h, wd, cin, cout, ksize, stride, 0)) {
+        const size_t wn = wino_ws(n, h, wd, cin, cout, 0, 0).total;
+        if (wn > need) need = wn;
+    }
+    return need;
 }
 
 // x / w are bf16 copies (x16 [n,h,wd,cin]; w16t [k*k][cout][cin], fte_pack_weights_bf16) when `src16`
@@ -402,6 +463,22 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
         p.b_ld = cout;
     }
     if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
+    if (!src16 && !stat_part && y && wino_wanted(n, h, wd, cin, cout, ksize, stride, 0)) {
+        const WinoWs wl = wino_ws(n, h, wd, cin, cout, 0, 0);
+        if (ws && ws_bytes >= wl.total) {          // Winograd F(2x2,3x3): filter transform, tile transform, 16 products + output transform + epilogue
+            float* V = (float*)((char*)ws + wl.v_off);
+            float* U = (float*)((char*)ws + wl.u_off);
+            hipError_t e = wino_transform_filter((const float*)w, U, cin, cout, 0, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            e = wino_transform_tiles((const float*)x, V, n, h, wd, cin, 0, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            WinoMMParams q;
+            memset(&q, 0, sizeof(q));
+            q.V = V; q.U = U; q.K = cin; q.N = cout; q.g = wino_geom(n, h, wd);
+            q.Y = y; q.Z = z; q.R = res; q.bias = bias; q.alpha = alpha;
+            return rc(wino_mm(q, EPI_FWD, (hipStream_t)stream));
+        }
+    }
     RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr, false, EPI_FWD);
     if (rp.tail_mode >= 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
     if (stat_part) {                                 // "BN fusion": one statistics partial row per tile row of the launch(es)
@@ -517,7 +594,7 @@ int dgrad_merged_plan(const DgradClass* cls, int nc, int n, int cin, int* order)
 
 size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     if (n <= 0 || cin <= 0 || cin % 64 || cout % 32) return 0;      // shapes fte_conv2d_dgrad rejects need no workspace
-    return both_modes([&] {
+    size_t need = both_modes([&] {
         DgradClass cls[4];
         const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
         long rows = 0;
@@ -529,6 +606,12 @@ size_t fte_conv2d_dgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
         // sized for the larger of the two modes in each part
         return 2 * align_up((size_t)rows * cin * sizeof(float)) + SCRATCH_BYTES + pw;
     });
+    if (wino_sized(n, h, wd, cin, cout, ksize, stride, 1)) {
+        const WinoGeom g = wino_geom(n, h, wd);
+        const size_t wn = wino_ws(n, h, wd, cin, cout, 1, 2 * align_up((size_t)g.MB * cin * sizeof(float)) + SCRATCH_BYTES).total;
+        if (wn > need) need = wn;
+    }
+    return need;
 }
 
 // the BN layer a "BN fusion" data gradient lands on (fte_conv2d_dgrad_bn): see igemm.h
@@ -558,6 +641,35 @@ static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const fl
     if (!dz || !w || (!dzprev && !(src16 && dzprev16)) || n <= 0 || cout % 32 || cin % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
     if (zprev && !alpha_prev) return FTE_EINVAL;
     const Pads pho = same_pads(h, ksize, stride), pwo = same_pads(wd, ksize, stride);
+    if (!src16 && !bn && dzprev && !dzprev16 && !addin16 && !zprev16 && !raw16 && wino_wanted(n, h, wd, cin, cout, ksize, stride, 1)) {
+        // Winograd: the forward algorithm on dz with the rotated, channel-swapped filters; one partial row of dalpha / dbias per row block
+        const WinoGeom g = wino_geom(n, h, wd);
+        const size_t half_w = align_up((size_t)g.MB * cin * sizeof(float));
+        const WinoWs wl = wino_ws(n, h, wd, cin, cout, 1, 2 * half_w + SCRATCH_BYTES);
+        if (ws && ws_bytes >= wl.total) {
+            const bool part = zprev && (dalpha_prev || dbias_prev);
+            float* V = (float*)((char*)ws + wl.v_off);
+            float* U = (float*)((char*)ws + wl.u_off);
+            hipError_t e = wino_transform_filter((const float*)w, U, cin, cout, 1, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            e = wino_transform_tiles((const float*)dz, V, n, h, wd, cout, 0, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            WinoMMParams q;
+            memset(&q, 0, sizeof(q));
+            q.V = V; q.U = U; q.K = cout; q.N = cin; q.g = g;
+            q.ADD = addin; q.RAW = raw; q.Zin = zprev; q.alpha = alpha_prev; q.amod = cin; q.DZ = dzprev;
+            q.PA = part ? (float*)ws : nullptr; q.PB = part ? (float*)((char*)ws + half_w) : nullptr;
+            e = wino_mm(q, EPI_DGRAD, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            if (part) {
+                float* scratch = (float*)((char*)ws + 2 * half_w);
+                if (dalpha_prev && dbias_prev) return rc(k_reduce_rows2(q.PA, dalpha_prev, q.PB, dbias_prev, nullptr, 1, g.MB, cin, 1, 1.f, scratch, (hipStream_t)stream));
+                if (dalpha_prev) return rc(k_reduce_rows(q.PA, dalpha_prev, nullptr, 1, g.MB, cin, 1, 1.f, scratch, (hipStream_t)stream));
+                return rc(k_reduce_rows(q.PB, dbias_prev, nullptr, 1, g.MB, cin, 1, 1.f, scratch, (hipStream_t)stream));
+            }
+            return FTE_OK;
+        }
+    }
     DgradClass cls[4];
     const int nc = dgrad_classes(n, h, wd, cin, cout, ksize, stride, cls);
     const bool merged = dgrad_mergeable(cls, nc, n, cin);
@@ -736,6 +848,10 @@ size_t fte_conv2d_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int ks
             if (gneed > need) need = gneed;
         }
     }
+    if (wino_sized(n, h, wd, cin, cout, ksize, stride, 2)) {
+        const size_t wn = wino_ws(n, h, wd, cin, cout, 2, 0).total;
+        if (wn > need) need = wn;
+    }
     return need + SCRATCH_BYTES;
 }
 size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride) {
@@ -749,6 +865,20 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
     int tile, splits, kchunk, K;
     wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
+    if (!src16 && wino_wanted(n, h, wd, cin, cout, ksize, stride, 2)) {
+        // Winograd F(3x3, 2x2): V = B^T d B of x, U' = G' e G'^T of dz, 16 products over the tiles, A'^T . A' of the summed planes
+        const WinoWs wl = wino_ws(n, h, wd, cin, cout, 2, 0);
+        if (ws && ws_bytes >= wl.total) {
+            float* V = (float*)((char*)ws + wl.v_off);
+            float* Up = (float*)((char*)ws + wl.u_off);
+            float* slabs = (float*)((char*)ws + wl.slab_off);
+            hipError_t e = wino_transform_tiles((const float*)x, V, n, h, wd, cin, 0, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            e = wino_transform_tiles((const float*)dz, Up, n, h, wd, cout, 1, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            return rc(wino_wgrad(V, Up, slabs, dw, wino_geom(n, h, wd), cin, cout, (hipStream_t)stream));
+        }
+    }
     if (src16 && ksize == 3 && stride == 1) {       // the resident kernel (wgrad16.hip): all nine taps per block, LDS-DMA, slot-range splits
         Wgrad16Params g;
         int cfg = 0;

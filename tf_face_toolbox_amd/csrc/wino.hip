@@ -1,0 +1,523 @@
+// wino.hip -- Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions, fp32, gfx950 (MI355X).
+//
+// The reference enables cuDNN's Winograd algorithm for every run (train.py:260, TF_ENABLE_WINOGRAD_NONFUSED=1); 16 of
+// SphereNet-20's 20 convs are stride-1 3x3 resBlock layers (nets/sphere.py:38-45,58-70) = 90.5 % of the MACs.  On a chip whose fp32
+// matrix rate is 1/16 of its bf16 rate (157 TFLOP/s, `v_mfma_f32_32x32x2_f32`) and whose 3x3 layers sit 5-40x above the fp32 ridge,
+// 2.25x fewer multiplies for a few hundred MB of transform traffic is the MI355X-first trade.
+//
+//   forward        y  = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A      d = 4x4 input patch of a 2x2 output tile, g = 3x3 filter
+//   data gradient  the same with d = dz patches and the filters rotated by 180 degrees, channels swapped
+//   filter gradient dw = A'^T [ sum_tiles (G' e G'^T) (.) (B^T d B) ] A'   F(3x3, 2x2): e = 2x2 tile of dz, the SAME B^T d B of x
+//
+// Pieces (all fp32, exact transforms: the matrices hold 0, +-1, +-1/2 only):
+//   wino_tiles_kernel<0/1>   HBM-bound: x (or dz) -> V = B^T d B per tile, or dz -> U' = G' e G'^T, written in the "pack" layout
+//                            (wino.h): one contiguous 32 KiB slab per (64 tiles, 8 channels) = the LDS image of one K-step
+//   wino_filter_kernel       G g G^T of every filter, same pack layout with rows = output channels (4 MB for 256 x 256)
+//   wino_mm_kernel           the 16 products [tiles x K] x [K x N] of ONE 64-tile x 64-channel block in one workgroup: 8 waves, each
+//                            8 of the 16 t-planes of a 32 x 32 sub-tile (128 accumulator registers), operands global -> LDS by
+//                            LDS-DMA (no VGPR staging, no address arithmetic: slabs are contiguous), two 64 KiB stages, one barrier per
+//                            K-step of 8 channels; the OUTPUT TRANSFORM runs on the accumulators (rows i of A^T M A split between
+//                            the two t-half waves, two floats per position exchanged through LDS) and feeds the same fused
+//                            epilogues as igemm_dev.h (bias / PReLU / shortcut; PReLU gradient + dalpha / dbias partial rows)
+//   wino_wgrad_kernel        16 products [cin x tiles] x [tiles x cout]: one resident workgroup per CU (64 x 64 x 16 t block of the
+//                            result, an equal share of the tiles), partial slabs -> wino_wgrad_finish_kernel (ordered sum over the
+//                            shares + A'^T . A')
+// Everything is deterministic: fixed summation orders, no atomics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "igemm.h"
+#include "igemm_dev.h"
+#include "wino.h"
+
+namespace {
+
+using namespace igemm_dev;
+
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds, 16, voff, soff, 0, 0);
+}
+
+constexpr unsigned OOB = 0x80000000u;
+constexpr int SLAB_F = 16 * 64 * 8;            // floats per (row block, K-step) slab
+constexpr int SLAB_B = SLAB_F * 4;             // 32 KiB
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// tile transforms (HBM-bound).  Thread = (tile r of the block's 64, 16-byte half of the 8-channel step); a wave stores 1 KiB
+// contiguous per t; a block walks four K-steps (one 128-byte line of every pixel it touches).
+template <int MODE>
+__global__ __launch_bounds__(256) void wino_tiles_kernel(const float* __restrict__ x, float* __restrict__ pack, int H, int W, int C,
+                                                         int TH, int TW, long M, unsigned x_bytes) {
+    constexpr int P = MODE == 0 ? 4 : 2;
+    const int tid = threadIdx.x;
+    const int half = tid & 1, r = (tid >> 1) & 63, sub = tid >> 7;
+    const int mb = blockIdx.x, KS = C >> 3;
+    const long m = (long)mb * 64 + r;
+    const int tpi = TH * TW;
+    int n = 0, ty = 0, tx = 0;
+    const bool mv = m < M;
+    if (mv) { n = (int)(m / tpi); const int rem = (int)(m - (long)n * tpi); ty = rem / TW; tx = rem - ty * TW; }
+    const int y0 = 2 * ty - (MODE == 0 ? 1 : 0), x0 = 2 * tx - (MODE == 0 ? 1 : 0);
+    unsigned off[P][P];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int yy = y0 + i, xx = x0 + j;
+            const bool ok = mv && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            off[i][j] = ok ? (unsigned)(((n * H + yy) * W + xx) * C) * 4u : OOB;
+        }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const int sw = (r >> 4) & 1;
+    for (int it = 0; it < 2; ++it) {
+        const int ks = blockIdx.y * 4 + 2 * it + sub;
+        const unsigned choff = (unsigned)(ks * 8 + half * 4) * 4u;
+        f32x4 d[P][P];
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[i][j] == OOB ? OOB : off[i][j] + choff, 0, 0));
+        f32x4 v[4][4];
+        if constexpr (MODE == 0) {
+            f32x4 w[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w[0][j] = d[0][j] - d[2][j];
+                w[1][j] = d[1][j] + d[2][j];
+                w[2][j] = d[2][j] - d[1][j];
+                w[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i][0] = w[i][0] - w[i][2];
+                v[i][1] = w[i][1] + w[i][2];
+                v[i][2] = w[i][2] - w[i][1];
+                v[i][3] = w[i][1] - w[i][3];
+            }
+        } else {
+            f32x4 u[4][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u[0][j] = d[0][j];
+                u[1][j] = 0.5f * (d[0][j] + d[1][j]);
+                u[2][j] = 0.5f * (d[0][j] - d[1][j]);
+                u[3][j] = d[1][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i][0] = u[i][0];
+                v[i][1] = 0.5f * (u[i][0] + u[i][1]);
+                v[i][2] = 0.5f * (u[i][0] - u[i][1]);
+                v[i][3] = u[i][1];
+            }
+        }
+        float* o = pack + (((size_t)mb * KS + ks) * 16 * 64 + r) * 8 + ((half ^ sw) << 2);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(o + (size_t)t * 512) = v[t >> 2][t & 3];
+    }
+}
+
+// filter transform: one thread per (k, row) pair.  dgrad = 0: g[kh][kw] = w[kh][kw][k][row]; dgrad = 1: g[kh][kw] = w[2-kh][2-kw][row][k]
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ pack, int cin, int cout, int dgrad) {
+    const int K = dgrad ? cout : cin, NR = dgrad ? cin : cout;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= K * NR) return;
+    int k, row;
+    if (dgrad) { k = idx % K; row = idx / K; }
+    else { row = idx % NR; k = idx / NR; }
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            g[a][b] = dgrad ? w[(((2 - a) * 3 + (2 - b)) * (size_t)cin + row) * cout + k] : w[((a * 3 + b) * (size_t)cin + k) * cout + row];
+    float p[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        p[0][b] = g[0][b];
+        p[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        p[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        p[3][b] = g[2][b];
+    }
+    const int KS = K >> 3, rb = row >> 6, r = row & 63, c8 = k & 7;
+    float* o = pack + ((((size_t)rb * KS + (k >> 3)) * 16) * 64 + r) * 8 + (((c8 >> 2) ^ ((r >> 4) & 1)) << 2) + (c8 & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[(size_t)(4 * i + 0) * 512] = p[i][0];
+        o[(size_t)(4 * i + 1) * 512] = 0.5f * (p[i][0] + p[i][1] + p[i][2]);
+        o[(size_t)(4 * i + 2) * 512] = 0.5f * (p[i][0] - p[i][1] + p[i][2]);
+        o[(size_t)(4 * i + 3) * 512] = p[i][2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// wino_mm_kernel: block = 64 tiles x 64 output channels x 16 t.  Wave (q, mi, ni) = wid bits 0, 1, 2: t-planes [8q, 8q+8) of tile rows
+// [32 mi, +32) x channels [32 ni, +32).  MFMA operand map (32x32x2): a = V[t][tile li][k], b = U[t][channel li][k] with k = 4 lh + j for
+// the j-th MFMA of a K-step (one ds_read_b128 per operand and t feeds four MFMAs); C rows (registers) = tiles, lanes = channels.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, int NBX, int GRP) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wid & 1, mi = (wid >> 1) & 1, ni = wid >> 2;
+    const int li = lane & 31, lh = lane >> 5;
+    const int KS = p.K >> 3, NB = p.N >> 6;
+    // ---- block -> (mb, nb): consecutive ids go round the 8 XCDs; an XCD keeps NBX column blocks (their filter slabs stay in its L2)
+    // and walks its own class of row blocks, the NBX column blocks of a row block side by side (they share the A slabs in L2)
+    int mb, nb;
+    if (GRP > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int grp = xcd % GRP, cls = xcd / GRP, C = 8 / GRP;
+        mb = (slot / NBX) * C + cls;
+        nb = grp * NBX + slot % NBX;
+    } else {
+        mb = blockIdx.x / NB; nb = blockIdx.x - mb * NB;
+    }
+    if (mb >= p.g.MB) return;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V + (size_t)mb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U + (size_t)nb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
+    const unsigned voff = (unsigned)lane * 16u;
+    auto issue = [&](int s, int stage) {
+        char* base = wsm + stage * (2 * SLAB_B);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wid + 8 * i;
+            dma16(rsA, base + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+            dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+        }
+    };
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int a_off = ((8 * q) * 64 + 32 * mi + li) * 32 + ((lh ^ ((li >> 4) & 1)) << 4);      // bytes
+    const int b_off = ((8 * q) * 64 + 32 * ni + li) * 32 + ((lh ^ ((li >> 4) & 1)) << 4);
+
+    issue(0, 0);
+    for (int s = 0; s < KS; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < KS) issue(s + 1, (s + 1) & 1);
+        const char* As = wsm + (s & 1) * (2 * SLAB_B);
+        const char* Bs = As + SLAB_B;
+        f32x4 fa[8], fb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            fa[t] = *reinterpret_cast<const f32x4*>(As + a_off + t * 2048);
+            fb[t] = *reinterpret_cast<const f32x4*>(Bs + b_off + t * 2048);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[t][j], acc[t], 0, 0, 0);
+    }
+    __syncthreads();           // the epilogue reuses the LDS
+
+    // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = plane t = 4 i + j.  This wave holds rows i = 2q, 2q+1.
+    // P[i][b] = (M A)[i][b];  Y[0][b] = (P0 + P1) + P2,  Y[1][b] = P1 + (-P2 - P3): the q = 0 wave finishes output row 0 and receives P2,
+    // the q = 1 wave finishes output row 1 and receives P1 (two floats per position through LDS).
+    float* xb = reinterpret_cast<float*>(wsm);                        // [8 waves][32][64 lanes]
+    int* rowpix = reinterpret_cast<int*>(wsm + 8 * 32 * 64 * 4);      // [64] pixel index of output (n, 2 ty, 2 tx), or -1
+    int* rowflag = rowpix + 64;                                       // bit 0: row 2 ty + 1 inside, bit 1: column 2 tx + 1 inside
+    if (tid < 64) {
+        const long m = (long)mb * 64 + tid;
+        int pix = -1, fl = 0;
+        if (m < p.g.M) {
+            const int tpi = p.g.th * p.g.tw;
+            const int n = (int)(m / tpi), rem = (int)(m - (long)n * tpi);
+            const int ty = rem / p.g.tw, tx = rem - ty * p.g.tw;
+            pix = (n * p.g.h + 2 * ty) * p.g.w + 2 * tx;
+            fl = ((2 * ty + 1 < p.g.h) ? 1 : 0) | ((2 * tx + 1 < p.g.w) ? 2 : 0);
+        }
+        rowpix[tid] = pix; rowflag[tid] = fl;
+    }
+    float keep[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p00 = acc[0][r] + acc[1][r] + acc[2][r], p01 = acc[1][r] - acc[2][r] - acc[3][r];
+        const float p10 = acc[4][r] + acc[5][r] + acc[6][r], p11 = acc[5][r] - acc[6][r] - acc[7][r];
+        float s0, s1;
+        if (q == 0) { keep[r][0] = p00 + p10; keep[r][1] = p01 + p11; s0 = p10; s1 = p11; }
+        else { keep[r][0] = -p00 - p10; keep[r][1] = -p01 - p11; s0 = p00; s1 = p01; }
+        xb[(wid * 32 + 2 * r) * 64 + lane] = s0;
+        xb[(wid * 32 + 2 * r + 1) * 64 + lane] = s1;
+    }
+    __syncthreads();
+    const int ch = nb * 64 + 32 * ni + li;
+    float bias = 0.f, al = 1.f;
+    bool act = false;
+    if constexpr (EPI == EPI_FWD) {
+        if (p.bias) bias = p.bias[ch];
+        act = p.alpha != nullptr;
+        if (act) al = p.alpha[ch];
+    } else {
+        act = p.Zin != nullptr;
+        if (act) al = p.alpha[ch % p.amod];
+    }
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int pix = rowpix[rr], fl = rowflag[rr];
+        const bool rowok = pix >= 0 && (q == 0 || (fl & 1));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float other = xb[((wid ^ 1) * 32 + 2 * r + b) * 64 + lane];
+            float v = q == 0 ? keep[r][b] + other : other + keep[r][b];
+            if (!(rowok && (b == 0 || (fl & 2)))) continue;
+            const size_t o = (size_t)(pix + q * p.g.w + b) * p.N + ch;
+            if constexpr (EPI == EPI_FWD) {
+                v += bias;
+                if (p.Z) p.Z[o] = v;
+                if (act) v = v > 0.f ? v : al * v;
+                if (p.R) v += p.R[o];
+                p.Y[o] = v;
+            } else {
+                if (p.ADD) v += p.ADD[o];
+                if (p.RAW) p.RAW[o] = v;
+                if (act) {
+                    const float z = p.Zin[o];
+                    sa += v * fminf(z, 0.f);
+                    v *= prelu_slope(z, al);
+                    sb += v;
+                }
+                p.DZ[o] = v;
+            }
+        }
+    }
+    if constexpr (EPI == EPI_DGRAD) {
+        if (p.PA) {
+            // column partials of the block: lanes of a wave = 32 channels x 2 row halves; the four (q, mi) waves of a channel half in wave order
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(wsm);              // [2][8 waves][32]
+            sa += __shfl_xor(sa, 32); sb += __shfl_xor(sb, 32);
+            if (lh == 0) { red[wid * 32 + li] = sa; red[(8 + wid) * 32 + li] = sb; }
+            __syncthreads();
+            if (tid < 64) {
+                const int n2 = tid >> 5, l2 = tid & 31;
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a += red[(4 * n2 + k) * 32 + l2]; b += red[(8 + 4 * n2 + k) * 32 + l2]; }
+                const size_t o = (size_t)mb * p.N + nb * 64 + tid;
+                p.PA[o] = a;
+                if (p.PB) p.PB[o] = b;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// wino_wgrad_kernel: 256 resident blocks.  Block = (share s of the tiles, 64 cin x 64 cout block of the 16 planes); wave (q, mi, ni):
+// planes [8q, 8q+8), cin rows [32 mi, +32), cout columns [32 ni, +32).  K-step = 8 tiles (one octet o of a 64-tile row block): of both
+// packs the block needs the 8 K-steps of ITS channel block, 256 contiguous bytes per (channel step, plane): LDS image
+// [8 channel steps][16 planes][8 tiles][8 channels], channel steps 4128 bytes apart (+32: the strided ds_read_b32 fragments --
+// a = V[t][tile 4 lh + j][cin li] -- then hit 32 different banks).
+constexpr int WG_KSTRIDE = 4096 + 32;
+constexpr int WG_OP = 8 * WG_KSTRIDE;          // bytes per operand image
+__global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(const float* __restrict__ V, const float* __restrict__ Up, float* __restrict__ slabs,
+                                                            int cin, int cout, int MB, int S) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wid & 1, mi = (wid >> 1) & 1, ni = wid >> 2;
+    const int li = lane & 31, lh = lane >> 5;
+    const int KSa = cin >> 3, KSb = cout >> 3, CB = cin >> 6, NB2 = cout >> 6, P = CB * NB2;
+    // the blocks of one share sit on one XCD (ids 8 apart): its 64-tile slabs leave HBM once and are shared through that L2
+    const int L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int split = L / P, pair = L - split * P;
+    const int cb = pair / NB2, nb = pair - cb * NB2;
+    const int mb0 = (int)((long)split * MB / S), mb1 = (int)((long)(split + 1) * MB / S);
+    const int nsteps = (mb1 - mb0) * 8;
+    const unsigned voff = (unsigned)((lane >> 4) * 2048 + (lane & 15) * 16);
+    auto issue = [&](int s, int stage) {
+        const int mb = mb0 + (s >> 3), o = s & 7;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V + (size_t)mb * KSa * SLAB_F), 0, (unsigned)KSa * SLAB_B, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Up + (size_t)mb * KSb * SLAB_F), 0, (unsigned)KSb * SLAB_B, 0x00020000);
+        char* base = wsm + stage * (2 * WG_OP);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wid + 8 * i, ks = piece >> 2, t4 = piece & 3;
+            dma16(rsA, base + ks * WG_KSTRIDE + t4 * 1024, voff, (unsigned)(((8 * cb + ks) * 16 + 4 * t4) * 2048 + o * 256));
+            dma16(rsB, base + WG_OP + ks * WG_KSTRIDE + t4 * 1024, voff, (unsigned)(((8 * nb + ks) * 16 + 4 * t4) * 2048 + o * 256));
+        }
+    };
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // fragment base addresses (bytes) for the two swizzle phases of a K-step (rows 16-31 / 48-63 of a row block hold their halves swapped)
+    const unsigned lbase = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)wsm;
+    unsigned a_b[2], b_b[2];
+#pragma unroll
+    for (int sw = 0; sw < 2; ++sw) {
+        a_b[sw] = lbase + (unsigned)((4 * mi + (li >> 3)) * WG_KSTRIDE + (8 * q) * 256 + lh * 128 + (((li & 7) ^ (4 * sw)) << 2));
+        b_b[sw] = lbase + (unsigned)(WG_OP + (4 * ni + (li >> 3)) * WG_KSTRIDE + (8 * q) * 256 + lh * 128 + (((li & 7) ^ (4 * sw)) << 2));
+    }
+    if (nsteps > 0) issue(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
+        const int sw = ((s & 7) >> 1) & 1;
+        const unsigned ab = (sw ? a_b[1] : a_b[0]) + (unsigned)((s & 1) * (2 * WG_OP));
+        const unsigned bb = (sw ? b_b[1] : b_b[0]) + (unsigned)((s & 1) * (2 * WG_OP));
+        float fa[8][4], fb[8][4];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fa[t][j] = *(const __attribute__((address_space(3))) float*)(unsigned long long)(ab + (unsigned)(t * 256 + j * 32));
+                fb[t][j] = *(const __attribute__((address_space(3))) float*)(unsigned long long)(bb + (unsigned)(t * 256 + j * 32));
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[t][j], acc[t], 0, 0, 0);
+    }
+    // raw partial planes -> slabs[split][t][cin][cout]
+    const size_t plane = (size_t)cin * cout;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        float* o = slabs + ((size_t)split * 16 + 8 * q + t) * plane + (size_t)(cb * 64 + 32 * mi + 4 * lh) * cout + nb * 64 + 32 * ni + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * cout] = acc[t][r];
+    }
+}
+
+// dw[kh][kw][ci][co] = A'^T (sum over shares, in share order) A',  A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int S, long plane) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= plane) return;
+    float m[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) m[t] = 0.f;
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) m[t] += slabs[((size_t)s * 16 + t) * plane + idx];
+    float pr[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pr[0][j] = m[0 + j] + m[4 + j] + m[8 + j];
+        pr[1][j] = m[4 + j] - m[8 + j];
+        pr[2][j] = m[4 + j] + m[8 + j] - m[12 + j];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        dw[(size_t)(a * 3 + 0) * plane + idx] = pr[a][0] + pr[a][1] + pr[a][2];
+        dw[(size_t)(a * 3 + 1) * plane + idx] = pr[a][1] - pr[a][2];
+        dw[(size_t)(a * 3 + 2) * plane + idx] = pr[a][1] + pr[a][2] - pr[a][3];
+    }
+}
+
+int g_algo = -1;
+
+}  // namespace
+
+WinoGeom wino_geom(int n, int h, int w) {
+    WinoGeom g;
+    g.n = n; g.h = h; g.w = w; g.th = (h + 1) / 2; g.tw = (w + 1) / 2;
+    g.M = (long)n * g.th * g.tw;
+    g.MB = (int)((g.M + 63) / 64);
+    return g;
+}
+
+hipError_t wino_transform_tiles(const float* x, float* pack, int n, int h, int w, int c, int mode, hipStream_t st) {
+    if (c % 32) return hipErrorInvalidValue;
+    const WinoGeom g = wino_geom(n, h, w);
+    const size_t xb = (size_t)n * h * w * c * 4;
+    if (xb >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    const dim3 grid(g.MB, c / 32);
+    if (mode == 0) hipLaunchKernelGGL(wino_tiles_kernel<0>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, (unsigned)xb);
+    else hipLaunchKernelGGL(wino_tiles_kernel<1>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, (unsigned)xb);
+    return hipGetLastError();
+}
+
+hipError_t wino_transform_filter(const float* w, float* pack, int cin, int cout, int dgrad, hipStream_t st) {
+    if (cin % 64 || cout % 64) return hipErrorInvalidValue;
+    const int total = cin * cout;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, pack, cin, cout, dgrad);
+    return hipGetLastError();
+}
+
+hipError_t wino_mm(const WinoMMParams& p, int epi, hipStream_t st) {
+    if (p.K % 64 || p.N % 64 || p.g.MB <= 0) return hipErrorInvalidValue;
+    if ((size_t)p.g.n * p.g.h * p.g.w * p.N >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    const int NB = p.N / 64;
+    int NBX = NB < 2 ? NB : 2, GRP = NB / NBX;
+    static const int plain = getenv("FTE_WINO_PLAIN_ORDER") ? atoi(getenv("FTE_WINO_PLAIN_ORDER")) : 0;      // A/B hook: no XCD-aware block order
+    int grid;
+    if (plain || NB % NBX || 8 % GRP) { GRP = 0; grid = p.g.MB * NB; }
+    else { const int C = 8 / GRP; grid = 8 * ((p.g.MB + C - 1) / C) * NBX; }
+    const size_t lds = 4 * (size_t)SLAB_B;
+    static bool attr[2] = {false, false};
+    const void* fn = epi == EPI_FWD ? reinterpret_cast<const void*>(wino_mm_kernel<EPI_FWD>) : reinterpret_cast<const void*>(wino_mm_kernel<EPI_DGRAD>);
+    if (!attr[epi == EPI_FWD ? 0 : 1]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr[epi == EPI_FWD ? 0 : 1] = true;
+    }
+    const int sig[5] = {AL_MK, BL_NK, epi, 8, 1};                    // tile id 8: the Winograd product (bench.py TILES)
+    const double flops = 2.0 * 16.0 * (double)p.g.MB * 64.0 * p.N * p.K;      // MFMA FLOPs the launch EXECUTES (padded row blocks included)
+    const double bytes = (double)wino_pack_floats(p.g.M, p.K) * 4.0 + 16.0 * p.N * p.K * 4.0 + (double)p.g.n * p.g.h * p.g.w * p.N * 4.0 *
+                         (epi == EPI_FWD ? (1 + (p.Z ? 1 : 0) + (p.R ? 1 : 0)) : (1 + (p.ADD ? 1 : 0) + (p.RAW ? 1 : 0) + (p.Zin ? 1 : 0)));
+    const int h = igemm_prof_begin(sig, (int)(p.g.MB * 64), p.N, 16 * p.K, flops, bytes, st);
+    if (epi == EPI_FWD) hipLaunchKernelGGL(wino_mm_kernel<EPI_FWD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP);
+    else hipLaunchKernelGGL(wino_mm_kernel<EPI_DGRAD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP);
+    igemm_prof_end(h, epi == EPI_FWD ? "wino_mm_kernel<0>" : "wino_mm_kernel<1>", st);
+    return hipGetLastError();
+}
+
+int wino_wgrad_splits(int cin, int cout) {
+    if (cin % 64 || cout % 64) return 0;
+    const int P = (cin / 64) * (cout / 64);
+    if (P > 256 || 256 % P) return 0;
+    return 256 / P;
+}
+
+hipError_t wino_wgrad(const float* V, const float* Up, float* slabs, float* dw, const WinoGeom& g, int cin, int cout, hipStream_t st) {
+    const int S = wino_wgrad_splits(cin, cout);
+    if (!S) return hipErrorInvalidValue;
+    const size_t lds = 4 * (size_t)WG_OP;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const int sig[5] = {AL_KM, BL_KN, EPI_FWD, 8, S};
+    const double flops = 2.0 * 16.0 * (double)g.MB * 64.0 * cin * cout;
+    const double bytes = ((double)wino_pack_floats(g.M, cin) + (double)wino_pack_floats(g.M, cout)) * 4.0 + (double)S * 16.0 * cin * cout * 4.0;
+    const int h = igemm_prof_begin(sig, 16 * cin, cout, (int)(g.MB * 64), flops, bytes, st);
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(256), dim3(512), lds, st, V, Up, slabs, cin, cout, g.MB, S);
+    igemm_prof_end(h, "wino_wgrad_kernel", st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long plane = (long)cin * cout;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, slabs, dw, S, plane);
+    return hipGetLastError();
+}
+
+void wino_set_algo(int a) { g_algo = a; }
+int wino_get_algo() {
+    if (g_algo < 0) {
+        const char* e = getenv("FTE_CONV_ALGO");
+        g_algo = 2;
+        if (e) {
+            if (!strcmp(e, "direct")) g_algo = 0;
+            else if (!strcmp(e, "winograd")) g_algo = 1;
+            else if (!strcmp(e, "auto")) g_algo = 2;
+        }
+    }
+    return g_algo;
+}
