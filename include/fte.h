@@ -73,6 +73,12 @@ int fte_get_mfma_dtype(void);
 #define FTE_CONV_AUTO 2
 int fte_set_conv_algo(int algo);
 int fte_get_conv_algo(void);
+/* The algorithm the CURRENT switch selects for a 3x3 layer in the fp32 mode, op = 0 forward, 1 data gradient, 2 filter gradient:
+ * FTE_CONV_DIRECT or FTE_CONV_WINOGRAD (given the workspace of the matching *_ws_bytes query). */
+int fte_conv3x3_algo(int n, int h, int wd, int cin, int cout, int stride, int op);
+/* Bytes of the transformed-tile pack V = B^T d B of an [n, h, wd, c] tensor (16 floats per 2x2 tile and channel, row blocks of 64
+ * tiles); 0 for shapes the Winograd kernels do not take. */
+size_t fte_wino_pack_bytes(int n, int h, int wd, int c);
 
 /* Measurement hook (bench.py's roofline leg; no reference counterpart).  While enabled, every
  * launch of the MFMA kernel family is bracketed by a HIP event pair ON THE LAUNCH STREAM and its
@@ -110,6 +116,14 @@ int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const flo
 /* ws is optional (NULL/0 allowed): with it, leftover or too-few output tiles run as split-K big tiles
  * plus a fused fix-up instead of small tiles (faster tails and small per-GPU shards). */
 size_t fte_conv3x3_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int stride);
+/* fte_conv3x3_fwd that LEAVES the transformed input tiles in `vpack` (caller-owned, fte_wino_pack_bytes(n, h, wd, cin) bytes) for the
+ * filter gradient of the same layer: the forward pass and Conv2DBackpropFilter read the same B^T d B of x (one transform instead of
+ * two).  Only for layers fte_conv3x3_algo reports FTE_CONV_WINOGRAD for (op 0 and op 2); with vpack != NULL the call either runs the
+ * Winograd algorithm or fails (FTE_EWORKSPACE) -- it never falls back silently.  vpack = NULL: exactly fte_conv3x3_fwd. */
+int fte_conv3x3_fwd_keep(const float* x, const float* w, const float* bias, const float* alpha,
+                         const float* res, float* z, float* y,
+                         int n, int h, int wd, int cin, int cout, int stride, float* vpack,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* Replaces Conv2DBackpropInput fused with the PReLU gradient of the PRODUCING
  * layer (tf.gradients, data_parallel.py:33):
@@ -132,6 +146,12 @@ int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw,
                       int n, int h, int wd, int cin, int cout, int stride,
                       void* ws, size_t ws_bytes, void* stream);
 size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int stride);
+/* fte_conv3x3_wgrad reading the V pack fte_conv3x3_fwd_keep left for this layer instead of transforming x again (x is still the
+ * layer's input and must be valid).  With vpack != NULL the call runs the Winograd algorithm or fails; vpack = NULL: exactly
+ * fte_conv3x3_wgrad. */
+int fte_conv3x3_wgrad_kept(const float* x, const float* dz, float* dw,
+                           int n, int h, int wd, int cin, int cout, int stride, const float* vpack,
+                           void* ws, size_t ws_bytes, void* stream);
 
 
 /* ---------------------------------------------------------------------------

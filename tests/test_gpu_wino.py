@@ -146,3 +146,31 @@ def test_switch_off_runs_the_direct_kernels():
         assert query('fte_set_conv_algo', 3) != 0
     finally:
         call('fte_set_conv_algo', prev)
+
+
+def test_kept_v_pack_feeds_the_filter_gradient(winograd):
+    """fte_conv3x3_fwd_keep leaves V = B^T d B of x; fte_conv3x3_wgrad_kept reads it: bit-identical to the self-contained calls; a kept
+    pack on a layer the switch does not select is an error, never a silent fallback."""
+    n, h, w, cin, cout = 6, 14, 14, 128, 256
+    r = np.random.default_rng(25)
+    x = dev(r.standard_normal((n, h, w, cin))); wt = dev(r.standard_normal((3, 3, cin, cout)) * 0.05)
+    dz = dev(r.standard_normal((n, h, w, cout)))
+    assert query('fte_conv3x3_algo', n, h, w, cin, cout, 1, 0) == WINOGRAD and query('fte_conv3x3_algo', n, h, w, cin, cout, 1, 2) == WINOGRAD
+    vb = query('fte_wino_pack_bytes', n, h, w, cin)
+    assert vb == 16 * 4 * ((n * 49 + 63) // 64 * 64) * cin
+    vpack = torch.empty(vb // 4, device='cuda')
+    wsb, nb = ws(max(query('fte_conv3x3_fwd_ws_bytes', n, h, w, cin, cout, 1), query('fte_conv3x3_wgrad_ws_bytes', n, h, w, cin, cout, 1)))
+    y1 = torch.empty(n, h, w, cout, device='cuda'); y2 = torch.empty_like(y1)
+    call('fte_conv3x3_fwd', x, wt, None, None, None, None, y1, n, h, w, cin, cout, 1, wsb, nb, stream())
+    call('fte_conv3x3_fwd_keep', x, wt, None, None, None, None, y2, n, h, w, cin, cout, 1, vpack, wsb, nb, stream())
+    assert torch.equal(y1, y2)
+    dw1 = torch.empty(3, 3, cin, cout, device='cuda'); dw2 = torch.empty_like(dw1)
+    call('fte_conv3x3_wgrad', x, dz, dw1, n, h, w, cin, cout, 1, wsb, nb, stream())
+    call('fte_conv3x3_wgrad_kept', x, dz, dw2, n, h, w, cin, cout, 1, vpack, wsb, nb, stream())
+    assert torch.equal(dw1, dw2)
+    call('fte_set_conv_algo', DIRECT)
+    assert query('fte_conv3x3_algo', n, h, w, cin, cout, 1, 0) == DIRECT
+    assert query('fte_conv3x3_fwd_keep', x.data_ptr(), wt.data_ptr(), 0, 0, 0, 0, y2.data_ptr(), n, h, w, cin, cout, 1, vpack.data_ptr(),
+                 wsb.data_ptr(), nb, 0) == -2
+    assert query('fte_conv3x3_wgrad_kept', x.data_ptr(), dz.data_ptr(), dw2.data_ptr(), n, h, w, cin, cout, 1, vpack.data_ptr(),
+                 wsb.data_ptr(), nb, 0) == -2

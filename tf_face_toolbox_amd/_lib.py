@@ -112,6 +112,10 @@ _SIGS = {
     'fte_set_mfma_dtype': (c_int, [c_int]),
     'fte_get_mfma_dtype': (c_int, []),
     'fte_set_conv_algo': (c_int, [c_int]),
+    'fte_conv3x3_algo': (c_int, [c_int] * 7),
+    'fte_wino_pack_bytes': (c_size_t, [c_int] * 4),
+    'fte_conv3x3_fwd_keep': (c_int, [_P] * 7 + [c_int] * 6 + [_P, _P, c_size_t, _P]),
+    'fte_conv3x3_wgrad_kept': (c_int, [_P] * 3 + [c_int] * 6 + [_P, _P, c_size_t, _P]),
     'fte_get_conv_algo': (c_int, []),
     'fte_dwconv3x3_fwd': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),
     'fte_dwconv3x3_dgrad': (c_int, [_P] * 3 + [c_int] * 5 + [_P]),

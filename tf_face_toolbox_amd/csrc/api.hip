@@ -326,10 +326,10 @@ size_t both_modes(F f) {
 // ---- Winograd F(2x2, 3x3) plan (wino.hip) ---------------------------------------------------------------------------------------
 // The stride-1 3x3 layers of the BN-free fp32 path (nets/sphere.py:41-42) may run as 16 products of 1/2.25 of the MACs.  FTE_CONV_ALGO /
 // fte_set_conv_algo: direct = never, winograd = wherever the kernels exist (channels % 64, fp32 operands), auto = the measured rule:
-// layers of >= FTE_WINO_MIN_C channels (default: see wino_min_c) -- below that the transform traffic (16 floats per tile and channel, in
+// layers of >= FTE_WINO_MIN_C channels (default 128: SphereNet's stages 2-4; the 64-channel stage stays direct) -- below that the transform traffic (16 floats per tile and channel, in
 // and out of HBM) outweighs the saved MFMA time.
 inline int wino_min_c() {
-    static const int v = getenv("FTE_WINO_MIN_C") ? atoi(getenv("FTE_WINO_MIN_C")) : 256;
+    static const int v = getenv("FTE_WINO_MIN_C") ? atoi(getenv("FTE_WINO_MIN_C")) : 128;
     return v;
 }
 inline bool wino_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
@@ -439,7 +439,7 @@ size_t fte_conv2d_fwd_ws_bytes(int n, int h, int wd, int cin, int cout, int ksiz
 static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float* bias, const float* alpha, const float* res,
                            float* z, float* y, uint16_t* y16, int n, int h, int wd, int cin, int cout, int ksize, int stride,
                            void* ws, size_t ws_bytes, void* stream, const uint16_t* res16 = nullptr, uint16_t* z16 = nullptr,
-                           float* stat_part = nullptr, int* stat_rows = nullptr) {
+                           float* stat_part = nullptr, int* stat_rows = nullptr, float* vpack = nullptr) {
     if (!x || !w || (!y && !(src16 && y16)) || n <= 0 || cin % 32 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3))
         return FTE_EINVAL;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
@@ -464,9 +464,10 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
     }
     if (!set_bytes(&p, (size_t)n * h * wd * cin, (size_t)ksize * ksize * cin * cout, src16 ? 2 : 4)) return FTE_EINVAL;
     if (!src16 && !stat_part && y && wino_wanted(n, h, wd, cin, cout, ksize, stride, 0)) {
-        const WinoWs wl = wino_ws(n, h, wd, cin, cout, 0, 0);
+        WinoWs wl = wino_ws(n, h, wd, cin, cout, 0, 0);
+        if (vpack) { wl.u_off = 0; wl.total = align_up((size_t)16 * cin * cout * 4); }      // the caller keeps V (fte_conv3x3_fwd_keep): ws holds the filters only
         if (ws && ws_bytes >= wl.total) {          // Winograd F(2x2,3x3): filter transform, tile transform, 16 products + output transform + epilogue
-            float* V = (float*)((char*)ws + wl.v_off);
+            float* V = vpack ? vpack : (float*)((char*)ws + wl.v_off);
             float* U = (float*)((char*)ws + wl.u_off);
             hipError_t e = wino_transform_filter((const float*)w, U, cin, cout, 0, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
@@ -479,6 +480,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
             return rc(wino_mm(q, EPI_FWD, (hipStream_t)stream));
         }
     }
+    if (vpack) return FTE_EWORKSPACE;              // a kept V was asked for and the Winograd path did not run: never silently
     RowPlan rp = plan_rows(p.M, p.N, p.K, ws != nullptr, false, EPI_FWD);
     if (rp.tail_mode >= 2 && ws_bytes < rp.pw_bytes) rp = plan_rows(p.M, p.N, p.K, false);   // no room: small-tile tail
     if (stat_part) {                                 // "BN fusion": one statistics partial row per tile row of the launch(es)
@@ -516,6 +518,21 @@ int fte_conv3x3_fwd(const float* x, const float* w, const float* bias, const flo
                     float* z, float* y, int n, int h, int wd, int cin, int cout, int stride,
                     void* ws, size_t ws_bytes, void* stream) {
     return fte_conv2d_fwd(x, w, bias, alpha, res, z, y, n, h, wd, cin, cout, 3, stride, ws, ws_bytes, stream);
+}
+int fte_conv3x3_fwd_keep(const float* x, const float* w, const float* bias, const float* alpha, const float* res,
+                         float* z, float* y, int n, int h, int wd, int cin, int cout, int stride, float* vpack,
+                         void* ws, size_t ws_bytes, void* stream) {
+    if (vpack && ((uintptr_t)vpack & 15)) return FTE_EINVAL;
+    return conv2d_fwd_impl(x, w, false, bias, alpha, res, z, y, nullptr, n, h, wd, cin, cout, 3, stride, ws, ws_bytes, stream,
+                           nullptr, nullptr, nullptr, nullptr, vpack);
+}
+int fte_conv3x3_algo(int n, int h, int wd, int cin, int cout, int stride, int op) {
+    if (op < 0 || op > 2) return FTE_EINVAL;
+    return (!igemm_get_bf16() && wino_sized(n, h, wd, cin, cout, 3, stride, op)) ? FTE_CONV_WINOGRAD : FTE_CONV_DIRECT;
+}
+size_t fte_wino_pack_bytes(int n, int h, int wd, int c) {
+    if (n <= 0 || h < 2 || wd < 2 || c <= 0 || c % 64) return 0;
+    return wino_pack_floats(wino_geom(n, h, wd).M, c) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -859,7 +876,7 @@ size_t fte_conv3x3_wgrad_ws_bytes(int n, int h, int wd, int cin, int cout, int s
 }
 
 static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* dw, int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                             void* ws, size_t ws_bytes, void* stream) {
+                             void* ws, size_t ws_bytes, void* stream, const float* vpack = nullptr) {
     if (src16 && (cin % 8 || cout % 8)) return FTE_EINVAL;
     if (!x || !dz || !dw || n <= 0 || cin % 4 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
@@ -867,18 +884,24 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
     wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
     if (!src16 && wino_wanted(n, h, wd, cin, cout, ksize, stride, 2)) {
         // Winograd F(3x3, 2x2): V = B^T d B of x, U' = G' e G'^T of dz, 16 products over the tiles, A'^T . A' of the summed planes
-        const WinoWs wl = wino_ws(n, h, wd, cin, cout, 2, 0);
+        WinoWs wl = wino_ws(n, h, wd, cin, cout, 2, 0);
+        if (vpack) {                               // V = B^T d B of x kept by the forward pass (fte_conv3x3_fwd_keep): ws holds U' and the slabs
+            const size_t vsz = wl.u_off - wl.v_off;
+            wl.u_off -= vsz; wl.slab_off -= vsz; wl.total -= vsz;
+        }
         if (ws && ws_bytes >= wl.total) {
-            float* V = (float*)((char*)ws + wl.v_off);
+            const float* V = vpack ? vpack : (float*)((char*)ws + wl.v_off);
             float* Up = (float*)((char*)ws + wl.u_off);
             float* slabs = (float*)((char*)ws + wl.slab_off);
-            hipError_t e = wino_transform_tiles((const float*)x, V, n, h, wd, cin, 0, (hipStream_t)stream);
+            hipError_t e = hipSuccess;
+            if (!vpack) e = wino_transform_tiles((const float*)x, (float*)((char*)ws + wl.v_off), n, h, wd, cin, 0, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
             e = wino_transform_tiles((const float*)dz, Up, n, h, wd, cout, 1, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
             return rc(wino_wgrad(V, Up, slabs, dw, wino_geom(n, h, wd), cin, cout, (hipStream_t)stream));
         }
     }
+    if (vpack) return FTE_EWORKSPACE;              // a kept V was handed over and the Winograd path did not run: never silently
     if (src16 && ksize == 3 && stride == 1) {       // the resident kernel (wgrad16.hip): all nine taps per block, LDS-DMA, slot-range splits
         Wgrad16Params g;
         int cfg = 0;
@@ -958,6 +981,11 @@ int fte_conv2d_wgrad16(const uint16_t* x16, const uint16_t* dz16, float* dw, int
 int fte_conv3x3_wgrad(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
                       void* ws, size_t ws_bytes, void* stream) {
     return fte_conv2d_wgrad(x, dz, dw, n, h, wd, cin, cout, 3, stride, ws, ws_bytes, stream);
+}
+int fte_conv3x3_wgrad_kept(const float* x, const float* dz, float* dw, int n, int h, int wd, int cin, int cout, int stride,
+                           const float* vpack, void* ws, size_t ws_bytes, void* stream) {
+    if (vpack && ((uintptr_t)vpack & 15)) return FTE_EINVAL;
+    return conv2d_wgrad_impl(x, dz, false, dw, n, h, wd, cin, cout, 3, stride, ws, ws_bytes, stream, vpack);
 }
 
 // ------------------------------------------------------------------------------------------------

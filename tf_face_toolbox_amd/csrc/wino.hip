@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
 // [32 mi, +32) x channels [32 ni, +32).  MFMA operand map (32x32x2): a = V[t][tile li][k], b = U[t][channel li][k] with k = 4 lh + j for
 // the j-th MFMA of a K-step (one ds_read_b128 per operand and t feeds four MFMAs); C rows (registers) = tiles, lanes = channels.
 template <int EPI>
-__global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, int NBX, int GRP) {
+__global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, int NBX, int GRP, int nvirt) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -168,22 +168,29 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
     const int q = wid & 1, mi = (wid >> 1) & 1, ni = wid >> 2;
     const int li = lane & 31, lh = lane >> 5;
     const int KS = p.K >> 3, NB = p.N >> 6;
-    // ---- block -> (mb, nb): consecutive ids go round the 8 XCDs; an XCD keeps NBX column blocks (their filter slabs stay in its L2)
-    // and walks its own class of row blocks, the NBX column blocks of a row block side by side (they share the A slabs in L2)
-    int mb, nb;
-    if (GRP > 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int grp = xcd % GRP, cls = xcd / GRP, C = 8 / GRP;
-        mb = (slot / NBX) * C + cls;
-        nb = grp * NBX + slot % NBX;
-    } else {
-        mb = blockIdx.x / NB; nb = blockIdx.x - mb * NB;
-    }
-    if (mb >= p.g.MB) return;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V + (size_t)mb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U + (size_t)nb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
+    // ---- virtual block id -> (mb, nb): consecutive ids go round the 8 XCDs; an XCD keeps NBX column blocks (their filter slabs stay in
+    // its L2) and walks its own class of row blocks, the NBX column blocks of a row block side by side (they share the A slabs in L2).
+    // The launch is ONE resident block per CU; block b takes the virtual ids b, b + grid, ... (grid % 8 == 0: same XCD every round).
+    auto decode = [&](int vid, int& mb, int& nb) -> bool {
+        if (GRP > 0) {
+            const int xcd = vid & 7, slot = vid >> 3;
+            const int grp = xcd % GRP, cls = xcd / GRP, C = 8 / GRP;
+            mb = (slot / NBX) * C + cls;
+            nb = grp * NBX + slot % NBX;
+        } else {
+            mb = vid / NB; nb = vid - mb * NB;
+        }
+        return mb < p.g.MB;
+    };
+    auto next_valid = [&](int vid, int& mb, int& nb) -> int {      // first valid id >= vid of this block's sequence, or nvirt
+        for (; vid < nvirt; vid += (int)gridDim.x)
+            if (decode(vid, mb, nb)) return vid;
+        return nvirt;
+    };
     const unsigned voff = (unsigned)lane * 16u;
-    auto issue = [&](int s, int stage) {
+    auto issue = [&](int mb, int nb, int s, int stage) {
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V + (size_t)mb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U + (size_t)nb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
         char* base = wsm + stage * (2 * SLAB_B);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -192,125 +199,168 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
             dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
         }
     };
-    f32x16 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int a_off = ((8 * q) * 64 + 32 * mi + li) * 32 + ((lh ^ ((li >> 4) & 1)) << 4);      // bytes
     const int b_off = ((8 * q) * 64 + 32 * ni + li) * 32 + ((lh ^ ((li >> 4) & 1)) << 4);
-
-    issue(0, 0);
-    for (int s = 0; s < KS; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < KS) issue(s + 1, (s + 1) & 1);
-        const char* As = wsm + (s & 1) * (2 * SLAB_B);
-        const char* Bs = As + SLAB_B;
-        f32x4 fa[8], fb[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            fa[t] = *reinterpret_cast<const f32x4*>(As + a_off + t * 2048);
-            fb[t] = *reinterpret_cast<const f32x4*>(Bs + b_off + t * 2048);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[t][j], acc[t], 0, 0, 0);
-    }
-    __syncthreads();           // the epilogue reuses the LDS
-
-    // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = plane t = 4 i + j.  This wave holds rows i = 2q, 2q+1.
-    // P[i][b] = (M A)[i][b];  Y[0][b] = (P0 + P1) + P2,  Y[1][b] = P1 + (-P2 - P3): the q = 0 wave finishes output row 0 and receives P2,
-    // the q = 1 wave finishes output row 1 and receives P1 (two floats per position through LDS).
-    float* xb = reinterpret_cast<float*>(wsm);                        // [8 waves][32][64 lanes]
-    int* rowpix = reinterpret_cast<int*>(wsm + 8 * 32 * 64 * 4);      // [64] pixel index of output (n, 2 ty, 2 tx), or -1
+    float* xb = reinterpret_cast<float*>(wsm + 2 * SLAB_B);           // stage 1, free after the last K-step: [8 waves][32][64 lanes]
+    int* rowpix = reinterpret_cast<int*>(wsm + 4 * SLAB_B);           // [64] pixel index of output (n, 2 ty, 2 tx), or -1
     int* rowflag = rowpix + 64;                                       // bit 0: row 2 ty + 1 inside, bit 1: column 2 tx + 1 inside
-    if (tid < 64) {
-        const long m = (long)mb * 64 + tid;
-        int pix = -1, fl = 0;
-        if (m < p.g.M) {
-            const int tpi = p.g.th * p.g.tw;
-            const int n = (int)(m / tpi), rem = (int)(m - (long)n * tpi);
-            const int ty = rem / p.g.tw, tx = rem - ty * p.g.tw;
-            pix = (n * p.g.h + 2 * ty) * p.g.w + 2 * tx;
-            fl = ((2 * ty + 1 < p.g.h) ? 1 : 0) | ((2 * tx + 1 < p.g.w) ? 2 : 0);
-        }
-        rowpix[tid] = pix; rowflag[tid] = fl;
-    }
-    float keep[16][2];
+    float* red = reinterpret_cast<float*>(rowflag + 64);              // [2][8 waves][32] column partials of the data-gradient epilogue
+
+    int mb = 0, nb = 0;
+    int vid = next_valid((int)blockIdx.x, mb, nb);
+    if (vid < nvirt) issue(mb, nb, 0, 0);
+    bool first = true;
+    while (vid < nvirt) {
+        int mb2 = 0, nb2 = 0;
+        const int vid2 = next_valid(vid + (int)gridDim.x, mb2, nb2);
+        f32x16 acc[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float p00 = acc[0][r] + acc[1][r] + acc[2][r], p01 = acc[1][r] - acc[2][r] - acc[3][r];
-        const float p10 = acc[4][r] + acc[5][r] + acc[6][r], p11 = acc[5][r] - acc[6][r] - acc[7][r];
-        float s0, s1;
-        if (q == 0) { keep[r][0] = p00 + p10; keep[r][1] = p01 + p11; s0 = p10; s1 = p11; }
-        else { keep[r][0] = -p00 - p10; keep[r][1] = -p01 - p11; s0 = p00; s1 = p01; }
-        xb[(wid * 32 + 2 * r) * 64 + lane] = s0;
-        xb[(wid * 32 + 2 * r + 1) * 64 + lane] = s1;
-    }
-    __syncthreads();
-    const int ch = nb * 64 + 32 * ni + li;
-    float bias = 0.f, al = 1.f;
-    bool act = false;
-    if constexpr (EPI == EPI_FWD) {
-        if (p.bias) bias = p.bias[ch];
-        act = p.alpha != nullptr;
-        if (act) al = p.alpha[ch];
-    } else {
-        act = p.Zin != nullptr;
-        if (act) al = p.alpha[ch % p.amod];
-    }
-    float sa = 0.f, sb = 0.f;
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rr = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int pix = rowpix[rr], fl = rowflag[rr];
-        const bool rowok = pix >= 0 && (q == 0 || (fl & 1));
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float other = xb[((wid ^ 1) * 32 + 2 * r + b) * 64 + lane];
-            float v = q == 0 ? keep[r][b] + other : other + keep[r][b];
-            if (!(rowok && (b == 0 || (fl & 2)))) continue;
-            const size_t o = (size_t)(pix + q * p.g.w + b) * p.N + ch;
-            if constexpr (EPI == EPI_FWD) {
-                v += bias;
-                if (p.Z) p.Z[o] = v;
-                if (act) v = v > 0.f ? v : al * v;
-                if (p.R) v += p.R[o];
-                p.Y[o] = v;
-            } else {
-                if (p.ADD) v += p.ADD[o];
-                if (p.RAW) p.RAW[o] = v;
-                if (act) {
-                    const float z = p.Zin[o];
-                    sa += v * fminf(z, 0.f);
-                    v *= prelu_slope(z, al);
-                    sb += v;
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int s = 0; s < KS; ++s) {
+            // this wave's DMA pieces of step s have landed.  Behind an epilogue no wait is needed (and none is wanted: vmcnt(0) would also
+            // wait for the epilogue's 64 stores to drain): step 0 of this tile was requested BEFORE the epilogue's loads, whose data
+            // the wave has consumed, and vector-memory operations return in issue order.
+            if (s > 0 || first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // the other stage is free (every wave is past the step that read it): next K-step of this tile, or -- behind the last
+            // step -- the FIRST K-step of the block's next tile, so that the epilogue below runs with that DMA in flight
+            if (s + 1 < KS) issue(mb, nb, s + 1, (s + 1) & 1);
+            else if (vid2 < nvirt) issue(mb2, nb2, 0, 0);
+            if (s == 0 && tid < 64) {          // (every wave has left the previous tile's epilogue: the row table may change)
+                const long m = (long)mb * 64 + tid;
+                int pix = -1, fl = 0;
+                if (m < p.g.M) {
+                    const int tpi = p.g.th * p.g.tw;
+                    const int n = (int)(m / tpi), rem = (int)(m - (long)n * tpi);
+                    const int ty = rem / p.g.tw, tx = rem - ty * p.g.tw;
+                    pix = (n * p.g.h + 2 * ty) * p.g.w + 2 * tx;
+                    fl = ((2 * ty + 1 < p.g.h) ? 1 : 0) | ((2 * tx + 1 < p.g.w) ? 2 : 0);
                 }
-                p.DZ[o] = v;
+                rowpix[tid] = pix; rowflag[tid] = fl;
             }
-        }
-    }
-    if constexpr (EPI == EPI_DGRAD) {
-        if (p.PA) {
-            // column partials of the block: lanes of a wave = 32 channels x 2 row halves; the four (q, mi) waves of a channel half in wave order
-            __syncthreads();
-            float* red = reinterpret_cast<float*>(wsm);              // [2][8 waves][32]
-            sa += __shfl_xor(sa, 32); sb += __shfl_xor(sb, 32);
-            if (lh == 0) { red[wid * 32 + li] = sa; red[(8 + wid) * 32 + li] = sb; }
-            __syncthreads();
-            if (tid < 64) {
-                const int n2 = tid >> 5, l2 = tid & 31;
-                float a = 0.f, b = 0.f;
+            const char* As = wsm + (s & 1) * (2 * SLAB_B);
+            const char* Bs = As + SLAB_B;
+            f32x4 fa[8], fb[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { a += red[(4 * n2 + k) * 32 + l2]; b += red[(8 + 4 * n2 + k) * 32 + l2]; }
-                const size_t o = (size_t)mb * p.N + nb * 64 + tid;
-                p.PA[o] = a;
-                if (p.PB) p.PB[o] = b;
+            for (int t = 0; t < 8; ++t) {
+                fa[t] = *reinterpret_cast<const f32x4*>(As + a_off + t * 2048);
+                fb[t] = *reinterpret_cast<const f32x4*>(Bs + b_off + t * 2048);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[t][j], acc[t], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // stage 1 (the last K-step's) is free: the epilogue's exchange buffer
+
+        // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = plane t = 4 i + j.  This wave holds rows i = 2q, 2q+1.
+        // P[i][b] = (M A)[i][b];  Y[0][b] = (P0 + P1) + P2,  Y[1][b] = P1 + (-P2 - P3): the q = 0 wave finishes output row 0 and receives
+        // P2, the q = 1 wave finishes output row 1 and receives P1 (two floats per position through LDS).
+        float keep[16][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p00 = acc[0][r] + acc[1][r] + acc[2][r], p01 = acc[1][r] - acc[2][r] - acc[3][r];
+            const float p10 = acc[4][r] + acc[5][r] + acc[6][r], p11 = acc[5][r] - acc[6][r] - acc[7][r];
+            float s0, s1;
+            if (q == 0) { keep[r][0] = p00 + p10; keep[r][1] = p01 + p11; s0 = p10; s1 = p11; }
+            else { keep[r][0] = -p00 - p10; keep[r][1] = -p01 - p11; s0 = p00; s1 = p01; }
+            xb[(wid * 32 + 2 * r) * 64 + lane] = s0;
+            xb[(wid * 32 + 2 * r + 1) * 64 + lane] = s1;
+        }
+        __builtin_amdgcn_sched_barrier(0);       // the accumulators are dead from here on: the loads below must not be hoisted above
+        // ---- the epilogue's global inputs, ALL requested before anything waits for one (a store between two loads of possibly aliasing
+        // tensors serialises them: 32 exposed round trips per wave, 25 us per tile when first measured).  Raw buffer accesses: an output
+        // outside the image (odd sizes, rows beyond M) or an absent tensor (descriptor of zero records) is an out-of-range offset -- loads
+        // return 0, stores are dropped -- so the whole epilogue is one basic block.
+        const int ch = nb * 64 + 32 * ni + li;
+        const unsigned bstep = (unsigned)p.N * 4u;     // the output's right neighbour (b = 1), bytes
+        unsigned off[16][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int pix = rowpix[rr], fl = rowflag[rr];
+            const bool rowok = pix >= 0 && (q == 0 || (fl & 1));
+            const unsigned o = (unsigned)((pix + q * p.g.w) * p.N + ch) * 4u;
+            off[r][0] = rowok ? o : OOB;
+            off[r][1] = (rowok && (fl & 2)) ? o + bstep : OOB;
+        }
+        const unsigned tbytes = (unsigned)((size_t)p.g.n * p.g.h * p.g.w * p.N * 4);
+        auto rsrc_of = [&](const float* q_) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q_), 0, q_ ? tbytes : 0u, 0x00020000); };
+        float in0[16][2], in1[16][2];
+        float bias = 0.f, al = 1.f;
+        bool act = false;
+        if constexpr (EPI == EPI_FWD) {
+            const __amdgpu_buffer_rsrc_t rsR = rsrc_of(p.R);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) in0[r][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[r][b], 0, 0));
+            if (p.bias) bias = p.bias[ch];
+            act = p.alpha != nullptr;
+            if (act) al = p.alpha[ch];
+        } else {
+            const __amdgpu_buffer_rsrc_t rsA = rsrc_of(p.ADD), rsZ = rsrc_of(p.Zin);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    in0[r][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, off[r][b], 0, 0));
+                    in1[r][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, off[r][b], 0, 0));
+                }
+            act = p.Zin != nullptr;
+            if (act) al = p.alpha[ch % p.amod];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float sa = 0.f, sb = 0.f;
+        if constexpr (EPI == EPI_FWD) {
+            const __amdgpu_buffer_rsrc_t rsZo = rsrc_of(p.Z), rsY = rsrc_of(p.Y);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float v = keep[r][b] + xb[((wid ^ 1) * 32 + 2 * r + b) * 64 + lane] + bias;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsZo, off[r][b], 0, 0);
+                    v = (v > 0.f ? v : al * v) + in0[r][b];          // (no activation: al = 1)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, off[r][b], 0, 0);
+                }
+        } else {
+            const __amdgpu_buffer_rsrc_t rsRaw = rsrc_of(p.RAW), rsD = rsrc_of(p.DZ);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float v = keep[r][b] + xb[((wid ^ 1) * 32 + 2 * r + b) * 64 + lane] + in0[r][b];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsRaw, off[r][b], 0, 0);
+                    const float z = act ? in1[r][b] : 1.f;            // (no PReLU below: slope 1, no dalpha term)
+                    const bool in = off[r][b] != OOB;
+                    sa += in ? v * fminf(z, 0.f) : 0.f;
+                    v *= prelu_slope(z, al);
+                    sb += in ? v : 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, off[r][b], 0, 0);
+                }
+        }
+        if constexpr (EPI == EPI_DGRAD) {
+            if (p.PA) {
+                // column partials of the block: lanes of a wave = 32 channels x 2 row halves; the four (q, mi) waves of a channel half in wave order
+                sa += __shfl_xor(sa, 32); sb += __shfl_xor(sb, 32);
+                if (lh == 0) { red[wid * 32 + li] = sa; red[(8 + wid) * 32 + li] = sb; }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (tid < 64) {
+                    const int n2 = tid >> 5, l2 = tid & 31;
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { a += red[(4 * n2 + k) * 32 + l2]; b += red[(8 + 4 * n2 + k) * 32 + l2]; }
+                    const size_t o = (size_t)mb * p.N + nb * 64 + tid;
+                    p.PA[o] = a;
+                    if (p.PB) p.PB[o] = b;
+                }
             }
         }
+        vid = vid2; mb = mb2; nb = nb2;
+        first = false;
     }
 }
 
@@ -456,10 +506,18 @@ hipError_t wino_mm(const WinoMMParams& p, int epi, hipStream_t st) {
     const int NB = p.N / 64;
     int NBX = NB < 2 ? NB : 2, GRP = NB / NBX;
     static const int plain = getenv("FTE_WINO_PLAIN_ORDER") ? atoi(getenv("FTE_WINO_PLAIN_ORDER")) : 0;      // A/B hook: no XCD-aware block order
-    int grid;
-    if (plain || NB % NBX || 8 % GRP) { GRP = 0; grid = p.g.MB * NB; }
-    else { const int C = 8 / GRP; grid = 8 * ((p.g.MB + C - 1) / C) * NBX; }
-    const size_t lds = 4 * (size_t)SLAB_B;
+    int nvirt;
+    if (plain || NB % NBX || 8 % GRP) { GRP = 0; nvirt = p.g.MB * NB; }
+    else { const int C = 8 / GRP; nvirt = 8 * ((p.g.MB + C - 1) / C) * NBX; }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+        cus = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+    }
+    const int grid = nvirt < cus ? (nvirt + 7) / 8 * 8 : cus;      // one resident block per CU (a multiple of 8: a block keeps its XCD)
+    const size_t lds = 4 * (size_t)SLAB_B + 2 * 64 * 4 + 2 * 8 * 32 * 4;
     static bool attr[2] = {false, false};
     const void* fn = epi == EPI_FWD ? reinterpret_cast<const void*>(wino_mm_kernel<EPI_FWD>) : reinterpret_cast<const void*>(wino_mm_kernel<EPI_DGRAD>);
     if (!attr[epi == EPI_FWD ? 0 : 1]) {
@@ -472,8 +530,8 @@ hipError_t wino_mm(const WinoMMParams& p, int epi, hipStream_t st) {
     const double bytes = (double)wino_pack_floats(p.g.M, p.K) * 4.0 + 16.0 * p.N * p.K * 4.0 + (double)p.g.n * p.g.h * p.g.w * p.N * 4.0 *
                          (epi == EPI_FWD ? (1 + (p.Z ? 1 : 0) + (p.R ? 1 : 0)) : (1 + (p.ADD ? 1 : 0) + (p.RAW ? 1 : 0) + (p.Zin ? 1 : 0)));
     const int h = igemm_prof_begin(sig, (int)(p.g.MB * 64), p.N, 16 * p.K, flops, bytes, st);
-    if (epi == EPI_FWD) hipLaunchKernelGGL(wino_mm_kernel<EPI_FWD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP);
-    else hipLaunchKernelGGL(wino_mm_kernel<EPI_DGRAD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP);
+    if (epi == EPI_FWD) hipLaunchKernelGGL(wino_mm_kernel<EPI_FWD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP, nvirt);
+    else hipLaunchKernelGGL(wino_mm_kernel<EPI_DGRAD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP, nvirt);
     igemm_prof_end(h, epi == EPI_FWD ? "wino_mm_kernel<0>" : "wino_mm_kernel<1>", st);
     return hipGetLastError();
 }

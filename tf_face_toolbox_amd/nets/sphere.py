@@ -194,8 +194,10 @@ class SphereNet(Network):
 
     def _alloc_acts(self, n):
         s16 = self._storage16()
-        if self._act_n == n and getattr(self, '_act_s16', False) == s16:
+        key = (s16, _lib.get_mfma_dtype(), _lib.query('fte_get_conv_algo'))      # what the workspace / V-pack sizes depend on
+        if self._act_n == n and getattr(self, '_act_key', None) == key:
             return
+        self._act_key = key
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         i16 = dict(dtype=torch.int16, device=dev)
@@ -233,6 +235,14 @@ class SphereNet(Network):
                                     raw=[torch.empty(shp, **f32), torch.empty(shp, **f32)], dzi=0, rawi=0)
         need = 4096
         q = _lib.query
+        # Winograd layers (fte.h FTE_CONV_*; the reference's train.py:260): the forward pass leaves V = B^T d B of its input for the
+        # layer's filter gradient (fte_conv3x3_fwd_keep / fte_conv3x3_wgrad_kept) -- one tile transform instead of two
+        self.vpack = [None] * len(self.convs)
+        if not s16 and os.environ.get('FTE_WINO_KEEP', '1') != '0':
+            for l, c in enumerate(self.convs):
+                if l > 0 and c.stride == 1 and q('fte_conv3x3_algo', n, c.hin, c.win, c.cin, c.cout, 1, 0) == 1 \
+                        and q('fte_conv3x3_algo', n, c.hin, c.win, c.cin, c.cout, 1, 2) == 1:
+                    self.vpack[l] = torch.empty(q('fte_wino_pack_bytes', n, c.hin, c.win, c.cin) // 4, **f32)
         for c in self.convs[1:]:
             need = max(need, q('fte_conv3x3_fwd_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride),
                        q('fte_conv3x3_wgrad_ws_bytes', n, c.hin, c.win, c.cin, c.cout, c.stride),
@@ -299,6 +309,7 @@ class SphereNet(Network):
         copies = self._use_copies() or s16
         self._copies_live = copies and keep              # backward of THIS forward may use the bf16 copies
         self._s16_live = s16 and keep
+        self._vpack_live = keep and not copies           # ... or the V packs the Winograd layers keep
         if copies:
             self._alloc_copies()
             self._pack_weights(st)
@@ -324,6 +335,9 @@ class SphereNet(Network):
                 if copies:
                     call('fte_conv2d_fwd16', self.y16[l - 1], self.w16t[c.name], bv, av, res, zz, self.y[l], self.y16[l],
                          n, c.hin, c.win, c.cin, c.cout, 3, c.stride, self.ws, self.ws_bytes, st)
+                elif keep and self.vpack[l] is not None:
+                    call('fte_conv3x3_fwd_keep', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
+                         n, c.hin, c.win, c.cin, c.cout, c.stride, self.vpack[l], self.ws, self.ws_bytes, st)
                 else:
                     call('fte_conv3x3_fwd', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
                          n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
@@ -496,6 +510,9 @@ class SphereNet(Network):
             if copies:
                 call('fte_conv2d_wgrad16', self.y16[l - 1], dz16_cur, gw, n, c.hin, c.win, c.cin, c.cout, 3, c.stride,
                      wws, self.ws_bytes, wst)
+            elif getattr(self, '_vpack_live', False) and self.vpack[l] is not None:
+                call('fte_conv3x3_wgrad_kept', self.y[l - 1], dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
+                     self.vpack[l], wws, self.ws_bytes, wst)
             else:
                 call('fte_conv3x3_wgrad', self.y[l - 1], dz_cur, gw, n, c.hin, c.win, c.cin, c.cout, c.stride,
                      wws, self.ws_bytes, wst)
