@@ -33,6 +33,15 @@
 #include "igemm_dev.h"
 #include "wino.h"
 
+#ifdef FTE_WINO_STAMP
+// DIAGNOSTIC BUILD ONLY (scripts/dev/build_wino_stamp.sh -> variants/libfte_wstamp.so; never the product library): every resident block of
+// wino_mm_kernel stamps s_memtime (shader clock) / s_memrealtime (100 MHz) at its tile boundaries into a buffer nothing else reads.
+__device__ unsigned long long* g_wino_stamp = nullptr;
+extern "C" int fte_debug_set_wino_stamp(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wino_stamp), &buf, sizeof(buf));
+}
+#endif
+
 namespace {
 
 using namespace igemm_dev;
@@ -206,59 +215,107 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
     int* rowflag = rowpix + 64;                                       // bit 0: row 2 ty + 1 inside, bit 1: column 2 tx + 1 inside
     float* red = reinterpret_cast<float*>(rowflag + 64);              // [2][8 waves][32] column partials of the data-gradient epilogue
 
+    // ---- software pipeline of the K loop (a K-step = 8 channels = 32 MFMAs per wave, in two halves of four t-planes) ---------------
+    //   half 0: MFMAs on fragment set X (planes 0-3 of step g) | payload: fragment reads of planes 4-7 of step g -> set Y
+    //   wait for Y and for this wave's DMA pieces of step g + 1, ONE barrier: every wave has its last fragments of step g's stage in
+    //           registers (the stage is free) and step g + 1 is complete in the other stage
+    //   half 1: MFMAs on Y | payload: fragment reads of planes 0-3 of step g + 1 -> X, then the 8 DMA pieces of step g + 2 into the
+    //           stage just freed
+    // so the MFMAs behind the barrier have their operands in registers already and the LDS-DMA issue (~60 cycles a piece) and the
+    // fragment round trips sit in MFMA shadows (first form: barrier, 8 DMA issues, 16 reads, then 32 MFMAs -- 15 % of every K-step
+    // was the matrix pipe waiting for that head).  The pipeline runs ACROSS tiles: behind a tile's last step come the next tile's
+    // steps 0 and 1, so the epilogue runs with step 0's first fragments in registers and its stage untouched; step 1's DMA is held back
+    // until the epilogue's exchange buffer (stage 1) has been read.
     int mb = 0, nb = 0;
     int vid = next_valid((int)blockIdx.x, mb, nb);
-    if (vid < nvirt) issue(mb, nb, 0, 0);
+    if (vid >= nvirt) return;
+    f32x4 xa[4], xb4[4], ya[4], yb[4];
+    auto read_frags = [&](int stage, int half, f32x4 (&fa)[4], f32x4 (&fb)[4], int t) {
+        const char* As = wsm + stage * (2 * SLAB_B);
+        fa[t] = *reinterpret_cast<const f32x4*>(As + a_off + (4 * half + t) * 2048);
+        fb[t] = *reinterpret_cast<const f32x4*>(As + SLAB_B + b_off + (4 * half + t) * 2048);
+    };
+    auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int s, int stage, int i) {
+        char* base = wsm + stage * (2 * SLAB_B);
+        const int piece = wid + 8 * (i >> 1);
+        if (i & 1) dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+        else dma16(rsA, base + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+    };
+    issue(mb, nb, 0, 0);
+    issue(mb, nb, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t) read_frags(0, 0, xa, xb4, t);
     bool first = true;
     while (vid < nvirt) {
         int mb2 = 0, nb2 = 0;
         const int vid2 = next_valid(vid + (int)gridDim.x, mb2, nb2);
+        const bool has_next = vid2 < nvirt;
+#ifdef FTE_WINO_STAMP
+        unsigned long long st0 = 0, sr0 = 0, st1 = 0;
+        if (g_wino_stamp) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+#endif
         f32x16 acc[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         for (int s = 0; s < KS; ++s) {
-            // this wave's DMA pieces of step s have landed.  Behind an epilogue no wait is needed (and none is wanted: vmcnt(0) would also
-            // wait for the epilogue's 64 stores to drain): step 0 of this tile was requested BEFORE the epilogue's loads, whose data
-            // the wave has consumed, and vector-memory operations return in issue order.
-            if (s > 0 || first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // the other stage is free (every wave is past the step that read it): next K-step of this tile, or -- behind the last
-            // step -- the FIRST K-step of the block's next tile, so that the epilogue below runs with that DMA in flight
-            if (s + 1 < KS) issue(mb, nb, s + 1, (s + 1) & 1);
-            else if (vid2 < nvirt) issue(mb2, nb2, 0, 0);
+            const int st = s & 1;
+            // ---- half 0 ----
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 16>([&](auto ic) {
+                constexpr int idx = decltype(ic)::value, j = idx >> 2, t = idx & 3;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], xb4[t][j], acc[t], 0, 0, 0);
+                if constexpr (idx < 4) read_frags(st, 1, ya, yb, idx);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // this wave's pieces of step g + 1 have landed.  In a tile's first step behind an epilogue they are OLDER than the epilogue's
+            // 16 stores (vector-memory operations retire in issue order): vmcnt(16) leaves the stores draining under the MFMAs
+            if (s == 0 && !first) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // ---- half 1 ----
+            // step g + 2: of this tile, or step 0 / 1 of the block's next tile (step 1 of the next tile waits for the epilogue)
+            const bool same = s + 2 < KS;
+            const bool dma = same || (has_next && s + 2 == KS);
+            const int dmb = same ? mb : mb2, dnb = same ? nb : nb2, ds = same ? s + 2 : 0;
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V + (size_t)dmb * KS * SLAB_F), 0, dma ? (unsigned)KS * SLAB_B : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U + (size_t)dnb * KS * SLAB_F), 0, dma ? (unsigned)KS * SLAB_B : 0u, 0x00020000);
             if (s == 0 && tid < 64) {          // (every wave has left the previous tile's epilogue: the row table may change)
-                const long m = (long)mb * 64 + tid;
+                const int m = mb * 64 + tid;               // (tiles < 2^31: the output tensor is below 2 GiB)
                 int pix = -1, fl = 0;
-                if (m < p.g.M) {
+                if (m < (int)p.g.M) {
                     const int tpi = p.g.th * p.g.tw;
-                    const int n = (int)(m / tpi), rem = (int)(m - (long)n * tpi);
+                    const int n = m / tpi, rem = m - n * tpi;
                     const int ty = rem / p.g.tw, tx = rem - ty * p.g.tw;
                     pix = (n * p.g.h + 2 * ty) * p.g.w + 2 * tx;
                     fl = ((2 * ty + 1 < p.g.h) ? 1 : 0) | ((2 * tx + 1 < p.g.w) ? 2 : 0);
                 }
                 rowpix[tid] = pix; rowflag[tid] = fl;
             }
-            const char* As = wsm + (s & 1) * (2 * SLAB_B);
-            const char* Bs = As + SLAB_B;
-            f32x4 fa[8], fb[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                fa[t] = *reinterpret_cast<const f32x4*>(As + a_off + t * 2048);
-                fb[t] = *reinterpret_cast<const f32x4*>(Bs + b_off + t * 2048);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[t][j], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 16>([&](auto ic) {
+                constexpr int idx = decltype(ic)::value, j = idx >> 2, t = idx & 3;
+                acc[4 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[t][j], yb[t][j], acc[4 + t], 0, 0, 0);
+                // (the fragments of the step after the block's very last one are read from a stage nobody refills: unused)
+                if constexpr (idx < 4) read_frags(st ^ 1, 0, xa, xb4, idx);
+                if constexpr (idx >= 4 && idx < 12) dma_piece(rsA, rsB, ds, st, idx - 4);      // (no step g + 2: descriptors of zero records)
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
+#ifdef FTE_WINO_STAMP
+        if (g_wino_stamp) { st1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // stage 1 (the last K-step's) is free: the epilogue's exchange buffer
 
         // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = plane t = 4 i + j.  This wave holds rows i = 2q, 2q+1.
         // P[i][b] = (M A)[i][b];  Y[0][b] = (P0 + P1) + P2,  Y[1][b] = P1 + (-P2 - P3): the q = 0 wave finishes output row 0 and receives
         // P2, the q = 1 wave finishes output row 1 and receives P1 (two floats per position through LDS).
+        // (everything the epilogue derives from the lane id is recomputed per tile from an opaque copy: hoisted out of the tile loop it
+        // stayed live across the K loop -- 40 spilled registers)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 31, lh_e = lane_e >> 5;
         float keep[16][2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -267,86 +324,116 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
             float s0, s1;
             if (q == 0) { keep[r][0] = p00 + p10; keep[r][1] = p01 + p11; s0 = p10; s1 = p11; }
             else { keep[r][0] = -p00 - p10; keep[r][1] = -p01 - p11; s0 = p00; s1 = p01; }
-            xb[(wid * 32 + 2 * r) * 64 + lane] = s0;
-            xb[(wid * 32 + 2 * r + 1) * 64 + lane] = s1;
+            xb[(wid * 32 + 2 * r) * 64 + lane_e] = s0;
+            xb[(wid * 32 + 2 * r + 1) * 64 + lane_e] = s1;
         }
         __builtin_amdgcn_sched_barrier(0);       // the accumulators are dead from here on: the loads below must not be hoisted above
-        // ---- the epilogue's global inputs, ALL requested before anything waits for one (a store between two loads of possibly aliasing
-        // tensors serialises them: 32 exposed round trips per wave, 25 us per tile when first measured).  Raw buffer accesses: an output
-        // outside the image (odd sizes, rows beyond M) or an absent tensor (descriptor of zero records) is an out-of-range offset -- loads
-        // return 0, stores are dropped -- so the whole epilogue is one basic block.
-        const int ch = nb * 64 + 32 * ni + li;
-        const unsigned bstep = (unsigned)p.N * 4u;     // the output's right neighbour (b = 1), bytes
-        unsigned off[16][2];
+        // ---- the epilogue's global traffic moves 16 bytes per lane in a TRANSPOSED lane map (lane = (row prw of 8, channel quad pc4): 8
+        // rows x 128 B per wave instruction; the accumulator map, lane = channel, gives 4-byte accesses -- 96 of them per lane, store-issue
+        // bound: 27 k cycles per tile when measured).  Its inputs are ALL requested here, before anything waits for one.  Raw buffer
+        // accesses: an output outside the image (odd sizes, rows beyond M) or an absent tensor (descriptor of zero records) is an
+        // out-of-range offset -- loads return 0, stores are dropped -- so the epilogue has no branches.
+        // pass (b, h2, j): output column b, tile row 32 mi + 16 h2 + prw + 8 j
+        const int prw = lane_e >> 3, pc4 = lane_e & 7;
+        const int ch0 = nb * 64 + 32 * ni + 4 * pc4;
+        unsigned off[2][2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int pix = rowpix[rr], fl = rowflag[rr];
-            const bool rowok = pix >= 0 && (q == 0 || (fl & 1));
-            const unsigned o = (unsigned)((pix + q * p.g.w) * p.N + ch) * 4u;
-            off[r][0] = rowok ? o : OOB;
-            off[r][1] = (rowok && (fl & 2)) ? o + bstep : OOB;
-        }
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rr = 32 * mi + 16 * h2 + prw + 8 * j;
+                const int pix = rowpix[rr], fl = rowflag[rr];
+                const bool rowok = pix >= 0 && (q == 0 || (fl & 1));
+                const unsigned o = (unsigned)((pix + q * p.g.w) * p.N + ch0) * 4u;
+                off[0][h2][j] = rowok ? o : OOB;
+                off[1][h2][j] = (rowok && (fl & 2)) ? o + (unsigned)p.N * 4u : OOB;
+            }
         const unsigned tbytes = (unsigned)((size_t)p.g.n * p.g.h * p.g.w * p.N * 4);
         auto rsrc_of = [&](const float* q_) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q_), 0, q_ ? tbytes : 0u, 0x00020000); };
-        float in0[16][2], in1[16][2];
-        float bias = 0.f, al = 1.f;
+        auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r_, unsigned o) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_, o, 0, 0)); };
+        auto st4 = [&](const __amdgpu_buffer_rsrc_t& r_, unsigned o, const f32x4& v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_, o, 0, 0); };
+        f32x4 in0[2][2][2], in1[2][2][2];
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, al4 = {1.f, 1.f, 1.f, 1.f};
         bool act = false;
         if constexpr (EPI == EPI_FWD) {
             const __amdgpu_buffer_rsrc_t rsR = rsrc_of(p.R);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) in0[r][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, off[r][b], 0, 0));
-            if (p.bias) bias = p.bias[ch];
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) in0[b][h2][j] = ld4(rsR, off[b][h2][j]);
+            if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ch0);
             act = p.alpha != nullptr;
-            if (act) al = p.alpha[ch];
+            if (act) al4 = *reinterpret_cast<const f32x4*>(p.alpha + ch0);
         } else {
             const __amdgpu_buffer_rsrc_t rsA = rsrc_of(p.ADD), rsZ = rsrc_of(p.Zin);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    in0[r][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, off[r][b], 0, 0));
-                    in1[r][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsZ, off[r][b], 0, 0));
-                }
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { in0[b][h2][j] = ld4(rsA, off[b][h2][j]); in1[b][h2][j] = ld4(rsZ, off[b][h2][j]); }
             act = p.Zin != nullptr;
-            if (act) al = p.alpha[ch % p.amod];
+            if (act) al4 = *reinterpret_cast<const f32x4*>(p.alpha + ch0 % p.amod);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float sa = 0.f, sb = 0.f;
-        if constexpr (EPI == EPI_FWD) {
-            const __amdgpu_buffer_rsrc_t rsZo = rsrc_of(p.Z), rsY = rsrc_of(p.Y);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float v = keep[r][b] + xb[((wid ^ 1) * 32 + 2 * r + b) * 64 + lane] + bias;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsZo, off[r][b], 0, 0);
-                    v = (v > 0.f ? v : al * v) + in0[r][b];          // (no activation: al = 1)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, off[r][b], 0, 0);
+            for (int b = 0; b < 2; ++b) keep[r][b] += xb[((wid ^ 1) * 32 + 2 * r + b) * 64 + lane_e];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // every wave has its partner's values: stage 1 may be refilled
+        if (has_next) issue(mb2, nb2, 1, 1);
+        // ---- accumulator map -> transposed map through a wave-private 16 x 36 float patch, four passes ----
+        float* patch = reinterpret_cast<float*>(wsm + 4 * SLAB_B + 2560) + wid * (16 * 36);
+        f32x4 sa4 = {0.f, 0.f, 0.f, 0.f}, sb4 = {0.f, 0.f, 0.f, 0.f};
+        const __amdgpu_buffer_rsrc_t rsO0 = rsrc_of(EPI == EPI_FWD ? p.Z : p.RAW), rsO1 = rsrc_of(EPI == EPI_FWD ? p.Y : p.DZ);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) patch[((r8 & 3) + 8 * (r8 >> 2) + 4 * lh_e) * 36 + li_e] = keep[8 * h2 + r8][b];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + (prw + 8 * j) * 36 + 4 * pc4);
+                    const unsigned o = off[b][h2][j];
+                    if constexpr (EPI == EPI_FWD) {
+                        v += bias4;
+                        st4(rsO0, o, v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : al4[e] * v[e];          // (no activation: al = 1)
+                        v += in0[b][h2][j];
+                        st4(rsO1, o, v);
+                    } else {
+                        v += in0[b][h2][j];
+                        st4(rsO0, o, v);
+                        const bool in = o != OOB;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = act ? in1[b][h2][j][e] : 1.f;        // (no PReLU below: slope 1, no dalpha term)
+                            sa4[e] += in ? v[e] * fminf(z, 0.f) : 0.f;
+                            v[e] *= prelu_slope(z, al4[e]);
+                            sb4[e] += in ? v[e] : 0.f;
+                        }
+                        st4(rsO1, o, v);
+                    }
                 }
-        } else {
-            const __amdgpu_buffer_rsrc_t rsRaw = rsrc_of(p.RAW), rsD = rsrc_of(p.DZ);
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float v = keep[r][b] + xb[((wid ^ 1) * 32 + 2 * r + b) * 64 + lane] + in0[r][b];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsRaw, off[r][b], 0, 0);
-                    const float z = act ? in1[r][b] : 1.f;            // (no PReLU below: slope 1, no dalpha term)
-                    const bool in = off[r][b] != OOB;
-                    sa += in ? v * fminf(z, 0.f) : 0.f;
-                    v *= prelu_slope(z, al);
-                    sb += in ? v : 0.f;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsD, off[r][b], 0, 0);
-                }
-        }
+            }
         if constexpr (EPI == EPI_DGRAD) {
             if (p.PA) {
-                // column partials of the block: lanes of a wave = 32 channels x 2 row halves; the four (q, mi) waves of a channel half in wave order
-                sa += __shfl_xor(sa, 32); sb += __shfl_xor(sb, 32);
-                if (lh == 0) { red[wid * 32 + li] = sa; red[(8 + wid) * 32 + li] = sb; }
+                // column partials of the block: a wave's lanes = 8 rows x 8 channel quads; the four (q, mi) waves of a channel half in wave order
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a_ = sa4[e], b_ = sb4[e];
+                    a_ += __shfl_xor(a_, 8); b_ += __shfl_xor(b_, 8);
+                    a_ += __shfl_xor(a_, 16); b_ += __shfl_xor(b_, 16);
+                    a_ += __shfl_xor(a_, 32); b_ += __shfl_xor(b_, 32);
+                    if (prw == 0) { red[wid * 32 + 4 * pc4 + e] = a_; red[(8 + wid) * 32 + 4 * pc4 + e] = b_; }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (tid < 64) {
                     const int n2 = tid >> 5, l2 = tid & 31;
@@ -358,6 +445,19 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
                     if (p.PB) p.PB[o] = b;
                 }
             }
+        }
+#ifdef FTE_WINO_STAMP
+        if (g_wino_stamp && tid == 0) {
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* o = g_wino_stamp + 8 * (size_t)vid;
+            o[0] = st1 - st0; o[1] = t2 - st1; o[2] = t2 - st0; o[3] = r2 - sr0; o[4] = sr0; o[5] = (unsigned long long)KS; o[6] = blockIdx.x; o[7] = r2;
+        }
+#endif
+        // planes 0-3 of the next tile's first step (its stage landed before the epilogue; read again here rather than carried through the
+        // epilogue in 32 registers)
+        if (has_next) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) read_frags(0, 0, xa, xb4, t);
         }
         vid = vid2; mb = mb2; nb = nb2;
         first = false;
@@ -517,7 +617,7 @@ hipError_t wino_mm(const WinoMMParams& p, int epi, hipStream_t st) {
         cus = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
     }
     const int grid = nvirt < cus ? (nvirt + 7) / 8 * 8 : cus;      // one resident block per CU (a multiple of 8: a block keeps its XCD)
-    const size_t lds = 4 * (size_t)SLAB_B + 2 * 64 * 4 + 2 * 8 * 32 * 4;
+    const size_t lds = 4 * (size_t)SLAB_B + 2560 + 8 * 16 * 36 * 4;      // two stages, row table + column partials, the epilogue's transpose patches
     static bool attr[2] = {false, false};
     const void* fn = epi == EPI_FWD ? reinterpret_cast<const void*>(wino_mm_kernel<EPI_FWD>) : reinterpret_cast<const void*>(wino_mm_kernel<EPI_DGRAD>);
     if (!attr[epi == EPI_FWD ? 0 : 1]) {
