@@ -363,9 +363,9 @@ inline WinoWs wino_ws(int n, int h, int wd, int cin, int cout, int op, size_t he
     } else if (op == 1) {     // V(dz): cout channels; U: rotated filters
         w.u_off = w.v_off + align_up(wino_pack_floats(g.M, cout) * 4);
         w.slab_off = w.total = w.u_off + align_up((size_t)16 * cin * cout * 4);
-    } else {                  // V(x), U'(dz), slabs
+    } else {                  // V(x), slabs (U' of dz is computed inside the kernel)
         w.u_off = w.v_off + align_up(wino_pack_floats(g.M, cin) * 4);
-        w.slab_off = w.u_off + align_up(wino_pack_floats(g.M, cout) * 4);
+        w.slab_off = w.u_off;
         w.total = w.slab_off + align_up((size_t)wino_wgrad_splits(cin, cout) * 16 * cin * cout * 4);
     }
     return w;
@@ -883,7 +883,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
     int tile, splits, kchunk, K;
     wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
     if (!src16 && wino_wanted(n, h, wd, cin, cout, ksize, stride, 2)) {
-        // Winograd F(3x3, 2x2): V = B^T d B of x, U' = G' e G'^T of dz, 16 products over the tiles, A'^T . A' of the summed planes
+        // Winograd F(3x3, 2x2): V = B^T d B of x, 16 products over the tiles with U' = G' e G'^T of dz formed in the kernel, A'^T . A' of the sums
         WinoWs wl = wino_ws(n, h, wd, cin, cout, 2, 0);
         if (vpack) {                               // V = B^T d B of x kept by the forward pass (fte_conv3x3_fwd_keep): ws holds U' and the slabs
             const size_t vsz = wl.u_off - wl.v_off;
@@ -891,14 +891,11 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
         }
         if (ws && ws_bytes >= wl.total) {
             const float* V = vpack ? vpack : (float*)((char*)ws + wl.v_off);
-            float* Up = (float*)((char*)ws + wl.u_off);
             float* slabs = (float*)((char*)ws + wl.slab_off);
             hipError_t e = hipSuccess;
             if (!vpack) e = wino_transform_tiles((const float*)x, (float*)((char*)ws + wl.v_off), n, h, wd, cin, 0, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
-            e = wino_transform_tiles((const float*)dz, Up, n, h, wd, cout, 1, (hipStream_t)stream);
-            if (e != hipSuccess) return (int)e;
-            return rc(wino_wgrad(V, Up, slabs, dw, wino_geom(n, h, wd), cin, cout, (hipStream_t)stream));
+            return rc(wino_wgrad(V, (const float*)dz, slabs, dw, wino_geom(n, h, wd), cin, cout, (hipStream_t)stream));
         }
     }
     if (vpack) return FTE_EWORKSPACE;              // a kept V was handed over and the Winograd path did not run: never silently

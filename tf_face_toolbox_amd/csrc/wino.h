@@ -41,10 +41,11 @@ struct WinoMMParams {
 };
 hipError_t wino_mm(const WinoMMParams& p, int epi, hipStream_t st);
 
-// filter gradient: slabs[s][t][cin][cout] = sum over the tiles of split s of V_t[tile][cin] * U'_t[tile][cout]; then
+// filter gradient: slabs[s][t][cin][cout] = sum over the tiles of split s of V_t[tile][cin] * U'_t[tile][cout] with U' = G' e G'^T of
+// the 2x2 tiles of dz computed inside the kernel (dz: [n, h, w, cout] NHWC); then
 // dw[3][3][cin][cout] = A'^T (sum_s slabs) A' with A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
 int wino_wgrad_splits(int cin, int cout);      // 0: shape not supported
-hipError_t wino_wgrad(const float* V, const float* Up, float* slabs, float* dw, const WinoGeom& g, int cin, int cout, hipStream_t st);
+hipError_t wino_wgrad(const float* V, const float* dz, float* slabs, float* dw, const WinoGeom& g, int cin, int cout, hipStream_t st);
 
 // conv algorithm switch (api.hip): 0 = direct implicit GEMM, 1 = Winograd wherever it applies, 2 = auto (the planner's rule)
 void wino_set_algo(int a);

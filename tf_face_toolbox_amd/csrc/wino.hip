@@ -60,11 +60,14 @@ constexpr int SLAB_B = SLAB_F * 4;             // 32 KiB
 // contiguous per t; a block walks four K-steps (one 128-byte line of every pixel it touches).
 template <int MODE>
 __global__ __launch_bounds__(256) void wino_tiles_kernel(const float* __restrict__ x, float* __restrict__ pack, int H, int W, int C,
-                                                         int TH, int TW, long M, unsigned x_bytes) {
+                                                         int TH, int TW, long M, int MB, unsigned x_bytes) {
     constexpr int P = MODE == 0 ? 4 : 2;
     const int tid = threadIdx.x;
     const int half = tid & 1, r = (tid >> 1) & 63, sub = tid >> 7;
-    const int mb = blockIdx.x, KS = C >> 3;
+    // consecutive block ids go round the 8 XCDs: an XCD takes a CONTIGUOUS range of row blocks (neighbours share halo rows in its L2)
+    const int per = (MB + 7) >> 3;
+    const int mb = (blockIdx.x & 7) * per + (blockIdx.x >> 3), KS = C >> 3;
+    if (mb >= MB) return;
     const long m = (long)mb * 64 + r;
     const int tpi = TH * TW;
     int n = 0, ty = 0, tx = 0;
@@ -465,22 +468,28 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// wino_wgrad_kernel: 256 resident blocks.  Block = (share s of the tiles, 64 cin x 64 cout block of the 16 planes); wave (q, mi, ni):
-// planes [8q, 8q+8), cin rows [32 mi, +32), cout columns [32 ni, +32).  K-step = 8 tiles (one octet o of a 64-tile row block): of both
-// packs the block needs the 8 K-steps of ITS channel block, 256 contiguous bytes per (channel step, plane): LDS image
-// [8 channel steps][16 planes][8 tiles][8 channels], channel steps 4128 bytes apart (+32: the strided ds_read_b32 fragments --
-// a = V[t][tile 4 lh + j][cin li] -- then hit 32 different banks).
+// wino_wgrad_kernel: 256 resident blocks.  Block = (share s of the tiles, 64 cin x 64 cout block of the 16 planes); wave w: planes 2w,
+// 2w + 1 of the whole block.  K-step = 8 tiles (one octet o of a 64-tile row block).
+//   A = V (the forward pass's B^T d B pack of x): the 8 channel steps of the block's cin block, 256 contiguous bytes per (channel step,
+//       plane), by LDS-DMA;
+//   B = U' = G' e G'^T of the 2x2 dz tiles, G' = [[1,0],[.5,.5],[.5,-.5],[0,1]]: computed HERE from dz (tiles do not overlap: 8 KB of dz
+//       per K-step instead of 32 KB of a U' pack that a separate pass would first write to HBM) by waves 0-3, one (tile, channel pair)
+//       per lane and K-step: 4 eight-byte loads one step ahead, ~50 vector instructions, 16 ds_write_b64.
+// LDS image of both: [8 channel steps][16 planes][8 tiles][8 channels], channel steps 4128 bytes apart (+32: the strided ds_read_b32
+// fragments -- a = V[t][tile 4 lh + j][cin li] -- then hit 32 different banks).
+#ifndef WG_ABL
+#define WG_ABL 0      // diagnostic builds only (scripts/dev/build_wino_stamp.sh with EXTRA=-DWG_ABL=n): 1 = no DMA, 2 = no U' work, 4 = no fragment reads
+#endif
 constexpr int WG_KSTRIDE = 4096 + 32;
 constexpr int WG_OP = 8 * WG_KSTRIDE;          // bytes per operand image
-__global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(const float* __restrict__ V, const float* __restrict__ Up, float* __restrict__ slabs,
-                                                            int cin, int cout, int MB, int S) {
+__global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(const float* __restrict__ V, const float* __restrict__ dz, float* __restrict__ slabs,
+                                                            int cin, int cout, WinoGeom g, int S, unsigned dz_bytes) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = wid & 1, mi = (wid >> 1) & 1, ni = wid >> 2;
     const int li = lane & 31, lh = lane >> 5;
-    const int KSa = cin >> 3, KSb = cout >> 3, CB = cin >> 6, NB2 = cout >> 6, P = CB * NB2;
+    const int KSa = cin >> 3, CB = cin >> 6, NB2 = cout >> 6, P = CB * NB2, MB = g.MB;
     // the blocks of one share sit on one XCD (ids 8 apart): its 64-tile slabs leave HBM once and are shared through that L2
     const int L = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int split = L / P, pair = L - split * P;
@@ -488,61 +497,139 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(const float* __restr
     const int mb0 = (int)((long)split * MB / S), mb1 = (int)((long)(split + 1) * MB / S);
     const int nsteps = (mb1 - mb0) * 8;
     const unsigned voff = (unsigned)((lane >> 4) * 2048 + (lane & 15) * 16);
-    auto issue = [&](int s, int stage) {
-        const int mb = mb0 + (s >> 3), o = s & 7;
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V + (size_t)mb * KSa * SLAB_F), 0, (unsigned)KSa * SLAB_B, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Up + (size_t)mb * KSb * SLAB_F), 0, (unsigned)KSb * SLAB_B, 0x00020000);
-        char* base = wsm + stage * (2 * WG_OP);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wid + 8 * i, ks = piece >> 2, t4 = piece & 3;
-            dma16(rsA, base + ks * WG_KSTRIDE + t4 * 1024, voff, (unsigned)(((8 * cb + ks) * 16 + 4 * t4) * 2048 + o * 256));
-            dma16(rsB, base + WG_OP + ks * WG_KSTRIDE + t4 * 1024, voff, (unsigned)(((8 * nb + ks) * 16 + 4 * t4) * 2048 + o * 256));
-        }
-    };
-    f32x16 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // fragment base addresses (bytes) for the two swizzle phases of a K-step (rows 16-31 / 48-63 of a row block hold their halves swapped)
-    const unsigned lbase = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)wsm;
-    unsigned a_b[2], b_b[2];
-#pragma unroll
-    for (int sw = 0; sw < 2; ++sw) {
-        a_b[sw] = lbase + (unsigned)((4 * mi + (li >> 3)) * WG_KSTRIDE + (8 * q) * 256 + lh * 128 + (((li & 7) ^ (4 * sw)) << 2));
-        b_b[sw] = lbase + (unsigned)(WG_OP + (4 * ni + (li >> 3)) * WG_KSTRIDE + (8 * q) * 256 + lh * 128 + (((li & 7) ^ (4 * sw)) << 2));
+    // ---- the dz side: wave w forms U' of tile w of every K-step's 8, lane = channel of the block's 64.  The tile's pixel coordinates
+    // are wave-uniform (scalar registers, advanced by 8 tiles per step: no division, no vector instruction); per lane and step 4 dword
+    // loads one step ahead, 12 adds (the 1/2 factors of G' are folded into the finish kernel: exact, powers of two), 16 ds_write_b32.
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
+    const int q8 = 8 / g.tw, r8 = 8 - q8 * g.tw;
+    int pn, pty, ptx;                           // tile of the NEXT load_dz call
+    {
+        const int m = mb0 * 64 + wid, tpi = g.th * g.tw;
+        pn = m / tpi;
+        const int rem = m - pn * tpi;
+        pty = rem / g.tw; ptx = rem - pty * g.tw;
     }
-    if (nsteps > 0) issue(0, 0);
-    for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
-        const int sw = ((s & 7) >> 1) & 1;
-        const unsigned ab = (sw ? a_b[1] : a_b[0]) + (unsigned)((s & 1) * (2 * WG_OP));
-        const unsigned bb = (sw ? b_b[1] : b_b[0]) + (unsigned)((s & 1) * (2 * WG_OP));
-        float fa[8][4], fb[8][4];
+    int ps = 0;                                 // its K-step
+    float e[2][2];
+    auto load_dz = [&]() {                      // the 2x2 tile (zeros outside the image / beyond the share), then advance by one K-step
+        const bool mv = ps < nsteps && pn < g.n;
+        const int base = ((pn * g.h + 2 * pty) * g.w + 2 * ptx) * cout + nb * 64;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                fa[t][j] = *(const __attribute__((address_space(3))) float*)(unsigned long long)(ab + (unsigned)(t * 256 + j * 32));
-                fb[t][j] = *(const __attribute__((address_space(3))) float*)(unsigned long long)(bb + (unsigned)(t * 256 + j * 32));
+            for (int b_ = 0; b_ < 2; ++b_) {
+                const bool ok = mv && 2 * pty + a_ < g.h && 2 * ptx + b_ < g.w;
+                // (the range check covers the VECTOR offset only: an absent pixel is an out-of-range vector offset, the wave-uniform pixel
+                // offset rides in the scalar one)
+                const unsigned so = ok ? (unsigned)(base + (a_ * g.w + b_) * cout) * 4u : 0u;
+                e[a_][b_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, ok ? (unsigned)lane * 4u : OOB, so, 0));
             }
+        ++ps;
+        ptx += r8; pty += q8;
+        if (ptx >= g.tw) { ptx -= g.tw; ++pty; }
+        while (pty >= g.th) { pty -= g.th; ++pn; }
+    };
+    const unsigned up_base = (unsigned)(WG_OP + (lane >> 3) * WG_KSTRIDE + wid * 32 + (lane & 7) * 4);
+    auto store_up_row = [&](int stage, int i) {      // planes 4 i .. 4 i + 3 of the (unscaled) U' of the tile in `e` -> the stage's B image
+        const float c0 = i == 0 ? e[0][0] : i == 1 ? e[0][0] + e[1][0] : i == 2 ? e[0][0] - e[1][0] : e[1][0];
+        const float c1 = i == 0 ? e[0][1] : i == 1 ? e[0][1] + e[1][1] : i == 2 ? e[0][1] - e[1][1] : e[1][1];
+        char* base = wsm + stage * (2 * WG_OP) + up_base + (4 * i) * 256;
+        *reinterpret_cast<float*>(base) = c0;
+        *reinterpret_cast<float*>(base + 256) = c0 + c1;
+        *reinterpret_cast<float*>(base + 512) = c0 - c1;
+        *reinterpret_cast<float*>(base + 768) = c1;
+    };
+    auto store_up = [&](int stage) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) store_up_row(stage, i);
+    };
+    // wave w = planes 2w, 2w + 1 of the WHOLE 64 x 64 block (2 x 2 MFMA blocks per plane): every fragment feeds two MFMAs -- half the
+    // ds_read_b32 traffic of a (8 planes, 32 x 32) wave tile, which ran the loop LDS-bound (6100 cycles per K-step for 4096 of MFMA)
+    f32x16 acc[2][2][2];                       // [plane][ci block][co block]
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[t][j], acc[t], 0, 0, 0);
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+    // fragment base addresses (bytes).  A: the pack holds the 16-byte halves of a row swapped for rows 16-31 / 48-63 of a row block
+    // (two phases of K-steps); B: written here, plain
+    const unsigned lbase = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)wsm;
+    // (four plain registers, selected by wave-uniform conditions: as an indexed array the bases went to scratch memory and every K-step
+    // began with a scratch load and a vmcnt(0))
+    const unsigned a_lo = lbase + (unsigned)((li >> 3) * WG_KSTRIDE + (2 * wid) * 256 + lh * 128 + ((li & 7) << 2));
+    const unsigned a_hi = lbase + (unsigned)((li >> 3) * WG_KSTRIDE + (2 * wid) * 256 + lh * 128 + (((li & 7) ^ 4) << 2));
+    const unsigned b_b = lbase + (unsigned)(WG_OP + (li >> 3) * WG_KSTRIDE + (2 * wid) * 256 + lh * 128 + ((li & 7) << 2));
+    // ---- software pipeline (as wino_mm_kernel): a K-step = 32 MFMAs per wave in two halves (k pairs j = 0, 1 | j = 2, 3) ----
+    //   half 0: MFMAs on fragment set X (j = 0, 1 of step g) | payload: reads of set Y (j = 2, 3 of step g)
+    //   wait for Y, for this wave's pieces of step g + 1 and its U' writes, ONE barrier (step g's stage is free, step g + 1 complete)
+    //   half 1: MFMAs on Y | payload: reads of X of step g + 1, the 4 DMA pieces of step g + 2 into the freed stage, U' of this
+    //           wave's tile of step g + 2 (its dz loads were requested a step ago), then the loads of step g + 3
+    float xa[2][2][2], xb[2][2][2], ya[2][2][2], yb[2][2][2];      // [plane][block][j in the half]
+    auto read_frag = [&](unsigned abase, unsigned bbase, int half, float (&fa)[2][2][2], float (&fb)[2][2][2], int idx) {      // idx 0..7: (t, i, jj)
+        const int t = idx >> 2, i = (idx >> 1) & 1, jj = idx & 1;
+        const unsigned so = (unsigned)(i * 4 * WG_KSTRIDE + t * 256 + (2 * half + jj) * 32);       // (an immediate of the read)
+        fa[t][i][jj] = *(const __attribute__((address_space(3))) float*)(unsigned long long)(abase + so);
+        fb[t][i][jj] = *(const __attribute__((address_space(3))) float*)(unsigned long long)(bbase + so);
+    };
+    auto a_base = [&](int s_) { return ((((s_ & 7) >> 1) & 1) ? a_hi : a_lo) + (unsigned)((s_ & 1) * (2 * WG_OP)); };
+    auto b_base = [&](int s_) { return b_b + (unsigned)((s_ & 1) * (2 * WG_OP)); };
+    auto dma_piece = [&](int s_, int i) {         // piece i (0..3) of this wave for step s_ (a descriptor of zero records beyond the share)
+        const int mb = mb0 + (s_ >> 3), o = s_ & 7;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V + (size_t)(s_ < nsteps ? mb : mb0) * KSa * SLAB_F), 0,
+                                                                             s_ < nsteps ? (unsigned)KSa * SLAB_B : 0u, 0x00020000);
+        const int piece = wid + 8 * i, ks = piece >> 2, t4 = piece & 3;
+        dma16(rsA, wsm + (s_ & 1) * (2 * WG_OP) + ks * WG_KSTRIDE + t4 * 1024, voff, (unsigned)(((8 * cb + ks) * 16 + 4 * t4) * 2048 + o * 256));
+    };
+    if (nsteps > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dma_piece(0, i); dma_piece(1, i); }
+        load_dz(); store_up(0);
+        load_dz(); store_up(1);
+        load_dz();                     // step 2
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (the 4 loads of step 2 stay in flight)
+        const unsigned pa = a_base(0), pb = b_base(0);
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) read_frag(pa, pb, 0, xa, xb, idx);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const unsigned ca = a_base(s), cbb = b_base(s), na = a_base(s + 1), nbb = b_base(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 16>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value, jj = idx >> 3, t = (idx >> 2) & 1, i = (idx >> 1) & 1, k = idx & 1;
+            acc[t][i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][i][jj], xb[t][k][jj], acc[t][i][k], 0, 0, 0);
+            if constexpr (idx < 8 && !(WG_ABL & 4)) read_frag(ca, cbb, 1, ya, yb, idx);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // this wave's pieces of step s + 1 landed (the 4 dz loads of step s + 2 behind them stay in flight), its U' writes are done
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 16>([&](auto ic) {
+            constexpr int idx = decltype(ic)::value, jj = idx >> 3, t = (idx >> 2) & 1, i = (idx >> 1) & 1, k = idx & 1;
+            acc[t][i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[t][i][jj], yb[t][k][jj], acc[t][i][k], 0, 0, 0);
+            if constexpr (idx < 8 && !(WG_ABL & 4)) read_frag(na, nbb, 0, xa, xb, idx);
+            if constexpr (idx >= 8 && idx < 12 && !(WG_ABL & 1)) dma_piece(s + 2, idx - 8);
+            if constexpr (idx >= 12 && !(WG_ABL & 2)) {                                    // U' of step s + 2 (a row of planes per slot), dz of step s + 3
+                store_up_row(s & 1, idx - 12);
+                if constexpr (idx == 15) load_dz();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
     // raw partial planes -> slabs[split][t][cin][cout]
     const size_t plane = (size_t)cin * cout;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        float* o = slabs + ((size_t)split * 16 + 8 * q + t) * plane + (size_t)(cb * 64 + 32 * mi + 4 * lh) * cout + nb * 64 + 32 * ni + li;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * cout] = acc[t][r];
-    }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float* o = slabs + ((size_t)split * 16 + 2 * wid + t) * plane + (size_t)(cb * 64 + 32 * i + 4 * lh) * cout + nb * 64 + 32 * k + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2)) * cout] = acc[t][i][k][r];
+            }
 }
 
 // dw[kh][kw][ci][co] = A'^T (sum over shares, in share order) A',  A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]]
@@ -555,6 +642,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
     for (int s = 0; s < S; ++s)
 #pragma unroll
         for (int t = 0; t < 16; ++t) m[t] += slabs[((size_t)s * 16 + t) * plane + idx];
+    // the 1/2 factors of G' = diag(1, 1/2, 1/2, 1) [[1,0],[1,1],[1,-1],[0,1]], left out of the kernel's U' (exact: powers of two)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const float sc = (((t >> 2) == 1 || (t >> 2) == 2) ? 0.5f : 1.f) * (((t & 3) == 1 || (t & 3) == 2) ? 0.5f : 1.f);
+        m[t] *= sc;
+    }
     float pr[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -587,9 +680,9 @@ hipError_t wino_transform_tiles(const float* x, float* pack, int n, int h, int w
     const WinoGeom g = wino_geom(n, h, w);
     const size_t xb = (size_t)n * h * w * c * 4;
     if (xb >= ((size_t)1 << 31)) return hipErrorInvalidValue;
-    const dim3 grid(g.MB, c / 32);
-    if (mode == 0) hipLaunchKernelGGL(wino_tiles_kernel<0>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, (unsigned)xb);
-    else hipLaunchKernelGGL(wino_tiles_kernel<1>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, (unsigned)xb);
+    const dim3 grid(8 * ((g.MB + 7) / 8), c / 32);
+    if (mode == 0) hipLaunchKernelGGL(wino_tiles_kernel<0>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
+    else hipLaunchKernelGGL(wino_tiles_kernel<1>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
     return hipGetLastError();
 }
 
@@ -643,9 +736,11 @@ int wino_wgrad_splits(int cin, int cout) {
     return 256 / P;
 }
 
-hipError_t wino_wgrad(const float* V, const float* Up, float* slabs, float* dw, const WinoGeom& g, int cin, int cout, hipStream_t st) {
+hipError_t wino_wgrad(const float* V, const float* dz, float* slabs, float* dw, const WinoGeom& g, int cin, int cout, hipStream_t st) {
     const int S = wino_wgrad_splits(cin, cout);
     if (!S) return hipErrorInvalidValue;
+    const size_t db = (size_t)g.n * g.h * g.w * cout * 4;
+    if (db >= ((size_t)1 << 31)) return hipErrorInvalidValue;      // buffer range
     const size_t lds = 4 * (size_t)WG_OP;
     static bool attr = false;
     if (!attr) {
@@ -655,9 +750,9 @@ hipError_t wino_wgrad(const float* V, const float* Up, float* slabs, float* dw, 
     }
     const int sig[5] = {AL_KM, BL_KN, EPI_FWD, 8, S};
     const double flops = 2.0 * 16.0 * (double)g.MB * 64.0 * cin * cout;
-    const double bytes = ((double)wino_pack_floats(g.M, cin) + (double)wino_pack_floats(g.M, cout)) * 4.0 + (double)S * 16.0 * cin * cout * 4.0;
+    const double bytes = (double)wino_pack_floats(g.M, cin) * 4.0 + (double)db + (double)S * 16.0 * cin * cout * 4.0;
     const int h = igemm_prof_begin(sig, 16 * cin, cout, (int)(g.MB * 64), flops, bytes, st);
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(256), dim3(512), lds, st, V, Up, slabs, cin, cout, g.MB, S);
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(256), dim3(512), lds, st, V, dz, slabs, cin, cout, g, S, (unsigned)db);
     igemm_prof_end(h, "wino_wgrad_kernel", st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
