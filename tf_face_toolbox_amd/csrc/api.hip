@@ -326,7 +326,7 @@ size_t both_modes(F f) {
 // ---- Winograd F(2x2, 3x3) plan (wino.hip) ---------------------------------------------------------------------------------------
 // The stride-1 3x3 layers of the BN-free fp32 path (nets/sphere.py:41-42) may run as 16 products of 1/2.25 of the MACs.  FTE_CONV_ALGO /
 // fte_set_conv_algo: direct = never, winograd = wherever the kernels exist (channels % 64, fp32 operands), auto = the measured rule:
-// layers of >= FTE_WINO_MIN_C channels (default 128: SphereNet's stages 2-4; the 64-channel stage stays direct) -- below that the transform traffic (16 floats per tile and channel, in
+// layers of >= FTE_WINO_MIN_C channels (default 128: SphereNet's stages 2-4) take it for all three products; 64-channel layers per FTE_WINO_OPS64 -- below that the transform traffic (16 floats per tile and channel, in
 // and out of HBM) outweighs the saved MFMA time.
 inline int wino_min_c() {
     static const int v = getenv("FTE_WINO_MIN_C") ? atoi(getenv("FTE_WINO_MIN_C")) : 128;
@@ -345,8 +345,13 @@ inline bool wino_sized(int n, int h, int wd, int cin, int cout, int ksize, int s
     if (op == 2 && !wino_wgrad_splits(cin, cout)) return false;
     if (algo == 1) return true;
     static const int ops = getenv("FTE_WINO_OPS") ? atoi(getenv("FTE_WINO_OPS")) : 7;      // A/B hook: bit per op
-    if (!(ops & (1 << op))) return false;
-    return cin >= wino_min_c() && cout >= wino_min_c();
+    // 64-channel layers (SphereNet's stage 1, 56x56): the tile packs are 16 floats per tile and channel -- 1.6 GB at 512 images, 0.4 ms of
+    // HBM time per transform against ~0.5 ms saved in a product.  Measured (one box, same call): forward + filter gradient (they share
+    // one transform) 35.60 -> 34.96 ms per step, the data gradient on top 34.98: it stays direct.  FTE_WINO_OPS64: bit per op for that class
+    static const int ops64 = getenv("FTE_WINO_OPS64") ? atoi(getenv("FTE_WINO_OPS64")) : 5;
+    const int cmin = cin < cout ? cin : cout;
+    if (cmin < wino_min_c()) return cmin >= 64 && (ops64 & (1 << op)) != 0;
+    return (ops & (1 << op)) != 0;
 }
 inline bool wino_wanted(int n, int h, int wd, int cin, int cout, int ksize, int stride, int op) {
     return !plan_bf16() && !g_plan_bn && wino_sized(n, h, wd, cin, cout, ksize, stride, op);

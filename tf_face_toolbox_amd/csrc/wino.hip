@@ -56,14 +56,14 @@ constexpr int SLAB_F = 16 * 64 * 8;            // floats per (row block, K-step)
 constexpr int SLAB_B = SLAB_F * 4;             // 32 KiB
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// tile transforms (HBM-bound).  Thread = (tile r of the block's 64, 16-byte half of the 8-channel step); a wave stores 1 KiB
-// contiguous per t; a block walks four K-steps (one 128-byte line of every pixel it touches).
+// tile transforms (HBM-bound).  Block = 64 tiles x 32 channels (one 128-byte line of every pixel it touches); thread = (tile r, channel
+// quad c4 of 8), a wave = 8 tiles x 8 quads: loads are whole 128-byte pixel pieces, stores 256 contiguous bytes per (K-step, plane).
 template <int MODE>
-__global__ __launch_bounds__(256) void wino_tiles_kernel(const float* __restrict__ x, float* __restrict__ pack, int H, int W, int C,
+__global__ __launch_bounds__(512) void wino_tiles_kernel(const float* __restrict__ x, float* __restrict__ pack, int H, int W, int C,
                                                          int TH, int TW, long M, int MB, unsigned x_bytes) {
     constexpr int P = MODE == 0 ? 4 : 2;
     const int tid = threadIdx.x;
-    const int half = tid & 1, r = (tid >> 1) & 63, sub = tid >> 7;
+    const int c4 = tid & 7, r = tid >> 3;
     // consecutive block ids go round the 8 XCDs: an XCD takes a CONTIGUOUS range of row blocks (neighbours share halo rows in its L2)
     const int per = (MB + 7) >> 3;
     const int mb = (blockIdx.x & 7) * per + (blockIdx.x >> 3), KS = C >> 3;
@@ -74,64 +74,55 @@ __global__ __launch_bounds__(256) void wino_tiles_kernel(const float* __restrict
     const bool mv = m < M;
     if (mv) { n = (int)(m / tpi); const int rem = (int)(m - (long)n * tpi); ty = rem / TW; tx = rem - ty * TW; }
     const int y0 = 2 * ty - (MODE == 0 ? 1 : 0), x0 = 2 * tx - (MODE == 0 ? 1 : 0);
-    unsigned off[P][P];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    const unsigned choff = (unsigned)(blockIdx.y * 32 + c4 * 4) * 4u;
+    f32x4 d[P][P];
 #pragma unroll
     for (int i = 0; i < P; ++i)
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const int yy = y0 + i, xx = x0 + j;
             const bool ok = mv && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            off[i][j] = ok ? (unsigned)(((n * H + yy) * W + xx) * C) * 4u : OOB;
+            d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(((n * H + yy) * W + xx) * C) * 4u + choff : OOB, 0, 0));
         }
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
-    const int sw = (r >> 4) & 1;
-    for (int it = 0; it < 2; ++it) {
-        const int ks = blockIdx.y * 4 + 2 * it + sub;
-        const unsigned choff = (unsigned)(ks * 8 + half * 4) * 4u;
-        f32x4 d[P][P];
+    f32x4 v[4][4];
+    if constexpr (MODE == 0) {
+        f32x4 w[4][4];
 #pragma unroll
-        for (int i = 0; i < P; ++i)
-#pragma unroll
-            for (int j = 0; j < P; ++j)
-                d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[i][j] == OOB ? OOB : off[i][j] + choff, 0, 0));
-        f32x4 v[4][4];
-        if constexpr (MODE == 0) {
-            f32x4 w[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                w[0][j] = d[0][j] - d[2][j];
-                w[1][j] = d[1][j] + d[2][j];
-                w[2][j] = d[2][j] - d[1][j];
-                w[3][j] = d[1][j] - d[3][j];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i][0] = w[i][0] - w[i][2];
-                v[i][1] = w[i][1] + w[i][2];
-                v[i][2] = w[i][2] - w[i][1];
-                v[i][3] = w[i][1] - w[i][3];
-            }
-        } else {
-            f32x4 u[4][2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                u[0][j] = d[0][j];
-                u[1][j] = 0.5f * (d[0][j] + d[1][j]);
-                u[2][j] = 0.5f * (d[0][j] - d[1][j]);
-                u[3][j] = d[1][j];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i][0] = u[i][0];
-                v[i][1] = 0.5f * (u[i][0] + u[i][1]);
-                v[i][2] = 0.5f * (u[i][0] - u[i][1]);
-                v[i][3] = u[i][1];
-            }
+        for (int j = 0; j < 4; ++j) {
+            w[0][j] = d[0][j] - d[2][j];
+            w[1][j] = d[1][j] + d[2][j];
+            w[2][j] = d[2][j] - d[1][j];
+            w[3][j] = d[1][j] - d[3][j];
         }
-        float* o = pack + (((size_t)mb * KS + ks) * 16 * 64 + r) * 8 + ((half ^ sw) << 2);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(o + (size_t)t * 512) = v[t >> 2][t & 3];
+        for (int i = 0; i < 4; ++i) {
+            v[i][0] = w[i][0] - w[i][2];
+            v[i][1] = w[i][1] + w[i][2];
+            v[i][2] = w[i][2] - w[i][1];
+            v[i][3] = w[i][1] - w[i][3];
+        }
+    } else {
+        f32x4 u[4][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u[0][j] = d[0][j];
+            u[1][j] = 0.5f * (d[0][j] + d[1][j]);
+            u[2][j] = 0.5f * (d[0][j] - d[1][j]);
+            u[3][j] = d[1][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i][0] = u[i][0];
+            v[i][1] = 0.5f * (u[i][0] + u[i][1]);
+            v[i][2] = 0.5f * (u[i][0] - u[i][1]);
+            v[i][3] = u[i][1];
+        }
     }
+    const int ks = blockIdx.y * 4 + (c4 >> 1), sw = (r >> 4) & 1;
+    float* o = pack + (((size_t)mb * KS + ks) * 16 * 64 + r) * 8 + (((c4 & 1) ^ sw) << 2);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(o + (size_t)t * 512) = v[t >> 2][t & 3];
 }
 
 // filter transform: one thread per (k, row) pair.  dgrad = 0: g[kh][kw] = w[kh][kw][k][row]; dgrad = 1: g[kh][kw] = w[2-kh][2-kw][row][k]
@@ -681,8 +672,8 @@ hipError_t wino_transform_tiles(const float* x, float* pack, int n, int h, int w
     const size_t xb = (size_t)n * h * w * c * 4;
     if (xb >= ((size_t)1 << 31)) return hipErrorInvalidValue;
     const dim3 grid(8 * ((g.MB + 7) / 8), c / 32);
-    if (mode == 0) hipLaunchKernelGGL(wino_tiles_kernel<0>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
-    else hipLaunchKernelGGL(wino_tiles_kernel<1>, grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
+    if (mode == 0) hipLaunchKernelGGL(wino_tiles_kernel<0>, grid, dim3(512), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
+    else hipLaunchKernelGGL(wino_tiles_kernel<1>, grid, dim3(512), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
     return hipGetLastError();
 }
 
