@@ -55,7 +55,13 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0                   # same table, "Peak BF16/FP16 M
 HBM_PEAK_GBPS = 8000.0                           # same table, HBM3E peak (spec)
 LR = 1e-4
 TILES = {0: '128,128', 1: '256,64', 2: '128,64', 3: '64,64', 4: '192,64', 5: '64,64 (1 wave)', 6: '64,64 (2 waves)',   # igemm.h's TILE_* enum
-         7: 'resident filter gradient (wgrad16.hip): 9 taps x 32|64 cin x 256|128 cout, or a 1x1 channel tile'}
+         7: 'resident filter gradient (wgrad16.hip): 9 taps x 32|64 cin x 256|128 cout, or a 1x1 channel tile',
+         8: 'Winograd F(2x2,3x3) / F(3x3,2x2) (wino.hip): 64 x 64 x 16 planes per resident block'}
+CONV_ALGOS = {0: 'direct', 1: 'winograd', 2: 'auto'}
+# (name, MFMA dtype, images) of the other BASELINE.json configs' per-GPU shards and of SphereNet's 2 / 4 / 8-GPU shards: timed after the
+# headline region and the CPU baseline, reported under `other_configs` (the LAST key of the line)
+OTHER_CONFIGS = [('ResNeXt-50-center', 'bf16s', 128), ('SENet-50-triplet', 'bf16s', 128), ('ShuffleNet-v2-small', 'f32', 256),
+                 ('SphereNet-ASoftmax', 'f32', 256), ('SphereNet-ASoftmax', 'f32', 128), ('SphereNet-ASoftmax', 'f32', 64)]
 
 
 def kernel_src_sha():
@@ -218,6 +224,10 @@ def latest_traffic_file(dtype='f32'):
 
 
 def op_kind(key, sym=''):
+    if sym.startswith('wino_mm_kernel'):
+        return 'dgrad' if sym.endswith('<1>') else 'fwd'
+    if sym.startswith('wino_wgrad'):
+        return 'wgrad'
     al, bl, epi = key[:3]
     if al == 1:
         return 'wgrad'                           # A = x^T (k = pixel): filter gradient / dense tn
@@ -226,12 +236,52 @@ def op_kind(key, sym=''):
     return 'dgrad' if epi == 1 or bl == 1 else 'fwd'
 
 
+def time_other_configs(dev, steps=10, warmup=3):
+    """One GPU, synthetic inputs, whole training steps (forward + loss + backward + optimizer) of the other BASELINE.json configs at their
+    per-GPU shards and of SphereNet at the 2 / 4 / 8-GPU shards: device time over `steps` steps after `warmup`, by events on the stream."""
+    import torch
+    from tf_face_toolbox_amd import net_select, Singular, _lib
+    out = []
+    prev = _lib.precision_mode()
+    for name, mode, b in OTHER_CONFIGS:
+        try:
+            _lib.set_mfma_dtype(mode)
+            g = torch.Generator().manual_seed(7)
+            x = (torch.rand(b, H, W, CH, generator=g) * 2 - 1).to(dev)
+            y = torch.randint(0, NUM_CLASSES, (b,), generator=g, dtype=torch.int32).to(dev)
+            net = net_select(name, 'NCHW', 5e-4)
+            step, losses, names, _ = Singular(net, 1e-4, 'Momentum')({'images': x, 'labels': y, 'num_classes': NUM_CLASSES, 'num_examples': b,
+                                                                     'batch_size': b})
+            for _ in range(warmup):
+                step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / steps
+            dev_ms = e0.elapsed_time(e1) / steps
+            vals = [float(l) for l in losses]
+            out.append({'net': name, 'dtype': mode, 'images': b, 'ms_per_step': round(1e3 * wall, 3), 'device_ms_per_step': round(dev_ms, 3),
+                        'images_per_sec': round(b / wall, 1), 'steps': steps, 'finite': all(v == v and abs(v) < 1e30 for v in vals)})
+            del step, net, x, y, losses
+            torch.cuda.empty_cache()
+        except Exception as e:                     # a config that fails is reported, never silently dropped
+            out.append({'net': name, 'dtype': mode, 'images': b, 'error': '%s: %s' % (type(e).__name__, e)})
+    _lib.set_mfma_dtype(prev)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)      # SURVEY.md 8d: mean over >= 50 timed steps after >= 10 warm-up
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` leg (N = 1 only, ~15 s)')
     ap.add_argument('--global-batch', type=int, default=GLOBAL_BATCH,
                     help='exploration only (e.g. the per-rank shard sizes of N=2/4/8 on one GPU); the metric is quoted at 512')
     ap.add_argument('--mfma-dtype', choices=['f32', 'bf16', 'bf16s'], default='f32',
@@ -443,10 +493,23 @@ def main():
             'config': {'workload': 'SphereFaceNet-20 + A-softmax training step, 112x112x3, global batch %d, 10575 classes, Momentum, %s' % (gb, {'f32': 'fp32', 'bf16': 'bf16 MFMA operands / fp32 accumulate + storage', 'bf16s': 'bf16 MFMA operands + bf16 storage of activations and inter-layer gradients / fp32 accumulate, sums, master weights'}[args.mfma_dtype]),
                        'global_batch': gb, 'per_gpu_batch': shard, 'lr': LR, 'parallelism': 'dp%d' % world,
                        'train_gflop_per_image': 12.2698},
+            # the algorithm of the stride-1 3x3 layers (fte.h FTE_CONV_*; the reference runs Winograd: train.py:260) and how many launches of
+            # a recorded step took it
+            'conv_algo': {'setting': CONV_ALGOS.get(_lib.query('fte_get_conv_algo'), '?'),
+                          'winograd_launches_per_step': round(sum(v[0] for k, v in table.items() if k.startswith('wino_')) / sampled, 2),
+                          'direct_mfma_launches_per_step': round(sum(v[0] for k, v in table.items() if not k.startswith('wino_')) / sampled, 2),
+                          'note': 'Winograd F(2x2,3x3) forward / data gradient and F(3x3,2x2) filter gradient on the stride-1 3x3 layers of '
+                                  '>= 128 channels, forward + filter gradient of the 64-channel stage; direct implicit GEMM elsewhere'},
+            # step_mfma_frac: DIRECT-CONVOLUTION-EQUIVALENT FLOPs of the step (12.27 GFLOP per image) / time / peak -- the
+            # metric's own FLOP count; under Winograd the kernels execute fewer FLOPs, so this figure is not bounded by 1.
+            # step_mfma_frac_executed: the FLOPs the MFMA launches of a recorded step actually execute / the step time / peak (<= 1)
             'step_mfma_frac': round(gb * args.steps / elapsed * 12.2698e9 / (peak * 1e12) / world, 4),
+            'step_mfma_frac_basis': 'direct-convolution-equivalent FLOPs (12.27 GFLOP per image)',
+            'step_mfma_frac_executed': round(all_flops / sampled / (elapsed / args.steps) / (peak * 1e12), 4),
             'losses': dict(zip(losses_name, [round(v, 6) for v in loss_vals])),
             'roofline': {'bound': 'mfma',
-                         'kernel': '%s = %s (MFMA implicit GEMM)' % (DOM, {'fwd': 'conv3x3 forward + bias/PReLU/residual', 'dgrad': 'conv3x3 data gradient + PReLU gradient', 'wgrad': 'conv3x3 filter gradient'}[kinds[DOM]]),
+                         'kernel': '%s = %s (%s)' % (DOM, {'fwd': 'conv3x3 forward + bias/PReLU/residual', 'dgrad': 'conv3x3 data gradient + PReLU gradient', 'wgrad': 'conv3x3 filter gradient'}[kinds[DOM]],
+                                                       'Winograd: 16 plane products on the fp32 MFMA; FLOPs = those the launch EXECUTES' if DOM.startswith('wino_') else 'MFMA implicit GEMM'),
                          'achieved': round(achieved, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'launches_timed': cnt, 'avg_launch_ms': round(avg_ms, 4),
@@ -473,6 +536,11 @@ def main():
             out['cpu_baseline'], out['parity'] = cpu_baseline_and_parity(dev, args.mfma_dtype)
         else:
             out['cpu_baseline'] = None
+        if world == 1 and not args.no_other_configs and gb == GLOBAL_BATCH and args.mfma_dtype == 'f32':
+            train_ops = model = None
+            del net, images, labels, inputs
+            torch.cuda.empty_cache()
+            out['other_configs'] = time_other_configs(dev)       # LAST key: it lands in the tail of the line
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -51,3 +51,22 @@ def test_library_carries_the_hash_of_the_kernel_sources():
     assert _lib.version().endswith('src:' + bench.kernel_src_sha()), (_lib.version(), bench.kernel_src_sha())
     assert bench.library_src_sha() == bench.kernel_src_sha()
     assert bench.check_library_stamp() == bench.kernel_src_sha()
+
+
+def test_other_configs_is_the_last_key_of_the_line():
+    """the other BASELINE.json configs (and SphereNet's 2 / 4 / 8-GPU shards) are timed on the driver's clock and
+    reported under `other_configs`, the LAST key of the N = 1 line (the driver keeps the tail).  Checked on the source: the last
+    assignment into `out` before the print, and the list itself."""
+    sys.path.insert(0, ROOT)
+    import bench
+    names = [(n, d, b) for n, d, b in bench.OTHER_CONFIGS]
+    assert ('ResNeXt-50-center', 'bf16s', 128) in names and ('SENet-50-triplet', 'bf16s', 128) in names
+    assert ('ShuffleNet-v2-small', 'f32', 256) in names
+    assert [b for n, d, b in names if n == 'SphereNet-ASoftmax' and d == 'f32'] == [256, 128, 64]
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    head, _ = src.rsplit('print(json.dumps(out))', 1)
+    assigns = [ln.strip() for ln in head.splitlines() if ln.strip().startswith("out['")]
+    assert assigns[-1].startswith("out['other_configs'] = time_other_configs("), assigns[-3:]
+    from tf_face_toolbox_amd.nets.net_base import net_select      # every name is a factory name
+    for n, _, _ in names:
+        assert net_select(n, 'NCHW', 5e-4) is not None

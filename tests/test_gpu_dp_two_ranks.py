@@ -71,6 +71,88 @@ def test_two_ranks_equal_the_oracle_two_tower_step(tmp_path, name, head):
         assert np.sqrt(((a - b) ** 2).sum()) <= 2e-5 * max(np.sqrt((b * b).sum()), 1e-30), k
 
 
+@pytest.mark.parametrize('world', [4, 8])
+def test_n_ranks_equal_the_oracle_n_tower_step(tmp_path, world):
+    """The same pins at the world sizes the driver's scaling run uses (BASELINE.json: 1 / 2 / 4 / 8 GPUs; data_parallel.py:203-256,
+    train.py:98,101-120): 4 and 8 ranks, two images each, replicas started different, equal after every step and equal to the
+    oracle's `world`-tower step.  One GPU per rank over RCCL when the box has them, else all ranks on the GPUs there are over gloo."""
+    n, h, w, ch, ncls, steps = 2 * world, 32, 32, 3, 20, 2
+    p = osn.perturb_params(osn.init_params(81, ch, ncls, h, w), 82)
+    rng = np.random.default_rng(83)
+    x = rng.uniform(-1, 1, (n, h, w, ch)); y = rng.integers(0, ncls, n)
+    fix = str(tmp_path / 'fix.npz')
+    np.savez(fix, x=x, y=y, ncls=ncls, **{'p:' + k: v for k, v in p.items()})
+    out = str(tmp_path / 'out')
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='2')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+                        '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                        os.path.join(ROOT, 'tests', 'dp_worker.py'), fix, out, 'SphereNet-ASoftmax', str(steps)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:]
+    res = [np.load(out + '.rank%d.npz' % k) for k in range(world)]
+    rccl = torch.cuda.device_count() >= world and os.environ.get('FTE_TEST_FORCE_GLOO') != '1'
+    for k, rk in enumerate(res):
+        assert str(rk['backend']) == ('nccl' if rccl else 'gloo')
+        if rccl:
+            assert int(rk['device']) == k
+        for key in res[0].files:                               # replicas bit-identical (weights AND displayed losses)
+            if key not in ('backend', 'device'):
+                np.testing.assert_array_equal(res[0][key], rk[key], err_msg='rank %d %s' % (k, key))
+    from oracle import ops
+    ref = dict(p)
+    slots = {k: np.zeros_like(v) for k, v in p.items()}
+    ref_losses = []
+    for t in range(steps):
+        ref, slots, ls = osn.train_step(ref, slots, x, y, 0.05, num_towers=world, weight_decay=5e-4, data_format='NCHW', head='asoftmax',
+                                        lam=ops.asoftmax_lambda(t))
+        ref_losses.append(ls)
+    np.testing.assert_allclose(res[0]['losses'], np.array(ref_losses), rtol=2e-5)
+    for k in p:
+        a, b = res[0]['w:' + k].astype(np.float64), ref[k]
+        assert np.sqrt(((a - b) ** 2).sum()) <= 2e-5 * max(np.sqrt((b * b).sum()), 1e-30), k
+
+
+def test_bench_py_runs_with_eight_ranks(tmp_path):
+    """`python bench.py --gpus 8` as the driver's scaling run starts it (its own ranks), at 8 images per rank: ONE JSON line, the five
+    gradient buckets summing to the arena, finite losses.  (On the one-GPU test box the eight ranks share it over gloo.)"""
+    import json
+    shared = torch.cuda.device_count() < 8
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='2')
+    if shared:
+        env['FTE_BENCH_SHARED_GPU'] = '1'
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--global-batch', '64'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['steps'] == 2 and out['scaling'] == 'strong'
+    assert out['config']['global_batch'] == 64 and out['config']['per_gpu_batch'] == 8 and out['config']['parallelism'] == 'dp8'
+    assert out['value'] > 0 and all(np.isfinite(v) for v in out['losses'].values())
+    ar = out['allreduce']
+    assert ar['rccl_ranks'] == (0 if shared else 8)
+    assert len(ar['bucket_bytes']) == 5 and sum(ar['bucket_bytes']) == 4 * (out_arena(out) + 4)
+    assert 'other_configs' not in out and out['cpu_baseline'] is None
+
+
+def test_train_py_launches_eight_ranks(tmp_path):
+    """`python train.py --num_gpus 8` as the reference is invoked (train.py:98,178-184): the script starts its eight ranks itself; three
+    steps on a resident synthetic batch, the log lines of rank 0 only, exit status 0."""
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS='2')
+    if torch.cuda.device_count() < 8:
+        env['FTE_BENCH_SHARED_GPU'] = '1'
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '--net_name', 'SphereNet-ASoftmax', '--model_name', 'n8', '--synthetic', '1',
+                        '--synthetic_classes', '32', '--input_height', '32', '--input_width', '32', '--batch_size', '16', '--num_gpus', '8',
+                        '--init_lr', '0.01', '--lr_decay_epoch', '2', '--max_epoches', '3', '--display_interval', '1', '--save_interval', '1000',
+                        '--max_steps', '3'], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert r.stdout.count('Loss #0: cross_entropy') == 3 and 'throughput =' in r.stdout
+
+
 @pytest.mark.parametrize('launcher', ['self', 'torchrun'])
 def test_bench_py_runs_with_two_ranks(tmp_path, launcher):
     """bench.py for N = 2, both ways the driver may start it: plain `python bench.py --gpus 2` (the script launches its own

@@ -26,6 +26,7 @@ def _run(cases, env=None, timeout=900):
     e = dict(os.environ)
     for k in ('FTE_WGRAD_TILE', 'FTE_NARROW_TILE', 'FTE_WIDE_TILE', 'FTE_WGRAD_SPLIT_MAJOR', 'FTE_SPLIT_MINK', 'FTE_SK', 'FTE_SK_TILE', 'FTE_SK_WS_FLAGS'):
         e.pop(k, None)
+    e['FTE_CONV_ALGO'] = 'direct'          # this module pins the tile instantiations of the DIRECT family; the Winograd symbols have their own test below
     e.update(env or {})
     r = subprocess.run([sys.executable, os.path.join(HERE, 'tile_worker.py'), json.dumps(cases)], env=e, cwd=ROOT,
                        capture_output=True, text=True, timeout=timeout)
@@ -228,6 +229,21 @@ def test_stream_k_flag_words_in_the_workspace():
     cs = _run([['fwd', 64, 14, 14, 256, 256, 1], ['dgrad', 64, 14, 14, 256, 256, 1]], {'FTE_SK_WS_FLAGS': '1'})
     _has(cs[0], 'igemm_sk_kernel<64,64,2,2,0,0,0>')
     _has(cs[1], 'igemm_sk_kernel<128,64,2,2,0,1,1>')
+
+
+def test_winograd_symbols_run_naturally_at_the_headline_shapes():
+    """FTE_CONV_ALGO=auto (the default): the stride-1 3x3 layers of >= 128 channels take the Winograd kernels for all three products,
+    the 64-channel stage for forward and filter gradient (csrc/api.hip wino_sized); each symbol at a shard of the headline shape that
+    gives every resident block several tiles and a ragged last row block, block by block against the float64 oracle."""
+    cs = _run([['fwd', 72, 14, 14, 256, 256, 1], ['dgrad', 72, 14, 14, 256, 256, 1], ['wgrad', 72, 14, 14, 256, 256, 1],
+               ['fwd', 24, 28, 28, 128, 128, 1], ['dgrad', 24, 28, 28, 128, 128, 1], ['wgrad', 24, 28, 28, 128, 128, 1],
+               ['fwd', 136, 7, 7, 512, 512, 1], ['dgrad', 136, 7, 7, 512, 512, 1], ['wgrad', 136, 7, 7, 512, 512, 1],
+               ['fwd', 8, 56, 56, 64, 64, 1], ['wgrad', 8, 56, 56, 64, 64, 1]], env={'FTE_CONV_ALGO': 'auto'})
+    for c in cs:
+        want = {'fwd': 'wino_mm_kernel<0>', 'dgrad': 'wino_mm_kernel<1>', 'wgrad': 'wino_wgrad_kernel'}[c['case'][0]]
+        assert c['symbols'] == [want], c
+    d = _run([['dgrad', 8, 56, 56, 64, 64, 1]], env={'FTE_CONV_ALGO': 'auto'})[0]      # the 64-channel data gradient stays direct
+    assert all(s_.startswith('igemm') for s_ in d['symbols']), d
 
 
 def test_every_conv_symbol_of_the_headline_run_was_checked():

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <initializer_list>
+
 #include "../../include/fte.h"
 #include "igemm.h"
 #include "wgrad16.h"
@@ -79,7 +81,7 @@ struct RowPlan {
     int tail_mode, tail_tile; long tail_mtiles; int tail_splits, tail_kchunk; size_t pw_bytes;
     int sk_workers;
 };
-constexpr long NUM_CU = 256;
+#define NUM_CU ((long)igemm_num_cus())      // (was a constant 256: the planner now follows the device)
 // ... and a storage-only launch (bf16 tensors in the epilogue, no fp32 outputs): the persistent kernels of igemm16.hip take it
 thread_local bool g_plan_s16 = false;
 struct PlanS16 { bool prev; explicit PlanS16(bool on) : prev(g_plan_s16) { g_plan_s16 = on; } ~PlanS16() { g_plan_s16 = prev; } };
@@ -356,6 +358,12 @@ inline bool wino_sized(int n, int h, int wd, int cin, int cout, int ksize, int s
 inline bool wino_wanted(int n, int h, int wd, int cin, int cout, int ksize, int stride, int op) {
     return !plan_bf16() && !g_plan_bn && wino_sized(n, h, wd, cin, cout, ksize, stride, op);
 }
+// every tensor the Winograd kernels touch moves 16 bytes per lane, like the direct path's (igemm_launch): 16-byte aligned or an error code
+inline bool aligned16(std::initializer_list<const void*> ptrs) {
+    uintptr_t v = 0;
+    for (const void* q : ptrs) v |= (uintptr_t)q;
+    return (v & 15) == 0;
+}
 struct WinoWs { size_t v_off, u_off, slab_off, total; };
 // workspace layout behind `head` bytes the caller keeps for itself: [V pack | U pack (| slabs)]
 inline WinoWs wino_ws(int n, int h, int wd, int cin, int cout, int op, size_t head) {
@@ -472,6 +480,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
         WinoWs wl = wino_ws(n, h, wd, cin, cout, 0, 0);
         if (vpack) { wl.u_off = 0; wl.total = align_up((size_t)16 * cin * cout * 4); }      // the caller keeps V (fte_conv3x3_fwd_keep): ws holds the filters only
         if (ws && ws_bytes >= wl.total) {          // Winograd F(2x2,3x3): filter transform, tile transform, 16 products + output transform + epilogue
+            if (!aligned16({x, w, bias, alpha, res, z, y, ws, vpack})) return FTE_EINVAL;
             float* V = vpack ? vpack : (float*)((char*)ws + wl.v_off);
             float* U = (float*)((char*)ws + wl.u_off);
             hipError_t e = wino_transform_filter((const float*)w, U, cin, cout, 0, (hipStream_t)stream);
@@ -669,6 +678,7 @@ static int conv2d_dgrad_impl(const void* dz, const void* w, bool src16, const fl
         const size_t half_w = align_up((size_t)g.MB * cin * sizeof(float));
         const WinoWs wl = wino_ws(n, h, wd, cin, cout, 1, 2 * half_w + SCRATCH_BYTES);
         if (ws && ws_bytes >= wl.total) {
+            if (!aligned16({dz, w, addin, zprev, alpha_prev, raw, dzprev, ws})) return FTE_EINVAL;
             const bool part = zprev && (dalpha_prev || dbias_prev);
             float* V = (float*)((char*)ws + wl.v_off);
             float* U = (float*)((char*)ws + wl.u_off);
@@ -895,6 +905,7 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
             wl.u_off -= vsz; wl.slab_off -= vsz; wl.total -= vsz;
         }
         if (ws && ws_bytes >= wl.total) {
+            if (!aligned16({x, dz, dw, ws, vpack})) return FTE_EINVAL;
             const float* V = vpack ? vpack : (float*)((char*)ws + wl.v_off);
             float* slabs = (float*)((char*)ws + wl.slab_off);
             hipError_t e = hipSuccess;

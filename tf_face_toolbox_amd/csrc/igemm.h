@@ -88,7 +88,8 @@ hipError_t igemm_fixup(const IgemmParams& p, int epi, int tile, int splits, hipS
 void igemm_tile_dims(int tile, int* bm, int* bn);
 // stream-K: resident blocks per CU the planner assumes for a tile shape (0: no stream-K instantiation of that shape), and the
 // workspace (slabs + flag words) a launch of `workers` blocks needs
-int igemm_sk_blocks_per_cu(int tile, int epi);
+int igemm_sk_blocks_per_cu(int tile, int epi);      // min(compiled figure, the runtime's occupancy of that symbol on this device)
+int igemm_num_cus();                                   // compute units of the current device (256 without one)
 size_t igemm_sk_ws_bytes(int tile, int workers);
 
 // igemm16.hip: the bf16 LDS-DMA kernel (k-contiguous bf16 A and B: conv forward / dgrad on the bf16 operand copies).  igemm_launch

@@ -1483,16 +1483,53 @@ hipError_t igemm_prof_get(int i, int* sig, double* flops, float* ms) {
     return hipEventElapsedTime(ms, r.e0, r.e1);
 }
 
+namespace {
+// resident blocks per CU the RUNTIME reports for a stream-K symbol (registers, LDS, wave slots of THIS device and compiler), queried once
+// per symbol; -1: no device / query failed (the compiled figure is used)
+template <int BM, int BN, int EPI>
+int sk_runtime_occupancy() {
+    static const int v = [] {
+        int nb = 0;
+        constexpr int AL = AL_MK, BL = EPI == EPI_FWD ? BL_KN : BL_NK;
+        const size_t epi_b = (size_t)(BM + 4 * 32 * 36 + 2 * 2 * BN) * sizeof(float);
+        const size_t loop_b = (FTE_SINGLE ? 1 : 2) * (size_t)(BM + BN) * igemm_dev::BK * sizeof(float);
+        const size_t lds = epi_b > loop_b ? epi_b : loop_b;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(igemm_sk_kernel<BM, BN, 2, 2, AL, BL, EPI>), 256, lds);
+        if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+        return nb;
+    }();
+    return v;
+}
+}  // namespace
+
+int igemm_num_cus() {
+    static const int v = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+            (void)hipGetLastError();
+            return 256;                            // MI355X; a host without a device only sizes workspaces
+        }
+        return prop.multiProcessorCount;
+    }();
+    return v;
+}
+
 int igemm_sk_blocks_per_cu(int tile, int epi) {
-    // co-resident blocks per CU the stream-K symbols are compiled for (SK_MINB; FTE_SK_DEBUG=1 prints what the runtime reports)
+    // Workers per CU of a stream-K launch = min(the figure the symbol is compiled for (SK_MINB), what the runtime reports as resident).
+    // A finisher spins on flags of higher-numbered workers: planning more workers than are resident (a register count that moved
+    // with the compiler -- round 5: six planned, five fit -- another part's CU / register file) serialises the launch into rounds
+    // of spinning blocks, so the plan follows the device; 0 resident -> no stream-K for that shape (the one-block-per-tile plan).
     static const int env = getenv("FTE_SK_BPC") ? atoi(getenv("FTE_SK_BPC")) : 0;      // tuning hook: fewer workers per CU
-    int v = 0;
+    int v = 0, rt = -1;
+    const bool fwd = epi == EPI_FWD;
     switch (tile) {
-        case TILE_64x64:   v = SK_MINB(64, 64, epi); break;
-        case TILE_128x64:  v = SK_MINB(128, 64, epi); break;
-        case TILE_128x128: v = SK_MINB(128, 128, epi); break;
+        case TILE_64x64:   v = SK_MINB(64, 64, epi);   rt = fwd ? sk_runtime_occupancy<64, 64, EPI_FWD>() : sk_runtime_occupancy<64, 64, EPI_DGRAD>(); break;
+        case TILE_128x64:  v = SK_MINB(128, 64, epi);  rt = fwd ? sk_runtime_occupancy<128, 64, EPI_FWD>() : sk_runtime_occupancy<128, 64, EPI_DGRAD>(); break;
+        case TILE_128x128: v = SK_MINB(128, 128, epi); rt = fwd ? sk_runtime_occupancy<128, 128, EPI_FWD>() : sk_runtime_occupancy<128, 128, EPI_DGRAD>(); break;
         default: return 0;
     }
+    if (rt >= 0 && rt < v) v = rt;
     return env > 0 && env < v ? env : v;
 }
 size_t igemm_sk_ws_bytes(int tile, int workers) {

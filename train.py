@@ -143,11 +143,19 @@ def train(FLAGS):
         raise SystemExit('--num_gpus %d but WORLD_SIZE is %d: one process per GPU (python -m torch.distributed.run --nproc-per-node %d '
                          '--master-addr 127.0.0.1 train.py ..., or plain `python train.py --num_gpus %d`, which launches them)'
                          % (FLAGS.num_gpus, world, FLAGS.num_gpus, FLAGS.num_gpus))
+    # FTE_BENCH_SHARED_GPU=1 (tests only, as in bench.py): all ranks on the GPUs that exist, gloo as the transport -- RCCL refuses two
+    # ranks on one device and the test boxes have one GPU; everything else of the N > 1 path is what a multi-GPU node runs
+    shared = os.environ.get('FTE_BENCH_SHARED_GPU') == '1'
+    if shared:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if shared:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
     from tf_face_toolbox_amd import _lib
     _lib.set_mfma_dtype(FLAGS.mfma_dtype)
 
