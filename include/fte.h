@@ -568,6 +568,11 @@ int fte_asoftmax_colcoef(const float* G, const float* s, const float* wn, float*
 int fte_row_norms(const float* a, float* out, int rows, int cols, int ld, void* stream);
 /* out[j] = sqrt(sum_i a[i,j]^2) over columns */
 int fte_col_norms(const float* a, float* out, int rows, int cols, int ld, void* stream);
+/* The flip-averaged inference path (nets/sphere.py:97-101, evaluate.py:62-63): y[n,h,w',c] = x[n,h,wd-1-w',c] replaces
+ * tf.reverse(images, axis=[2]) (x != y; 16-byte aligned when c % 4 == 0) and out = a*x + b*y the mean of the two embeddings
+ * (a = b = 0.5; out may alias x or y). */
+int fte_flip_width(const float* x, float* y, int n, int h, int wd, int c, void* stream);
+int fte_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream);
 /* a[i,j] += rc[i] * b[i,j]   (rc NULL -> skip) ;  a[i,j] += cc[j] * b[i,j]  (cc NULL -> skip) */
 int fte_add_scaled_rows_cols(float* a, const float* b, const float* rc, const float* cc,
                              int rows, int cols, int ld, void* stream);

@@ -314,3 +314,28 @@ def test_unaligned_pointers_are_rejected_not_executed():
     with pytest.raises(FteError):
         call('fte_conv3x3_fwd', x, wt, None, None, None, None, y[1:], n, h, w, cin, cout, 1, buf, nb, stream())
     torch.cuda.synchronize()
+
+
+def test_two_gib_tensors_are_rejected():
+    """fte.h conventions: every tensor is smaller than 2 GiB (32-bit buffer offsets, 0x80000000 = the out-of-range marker); a larger
+    shape is FTE_EINVAL before anything is launched, in the direct and the Winograd plan alike (csrc/api.hip set_bytes / wino_shape_ok).
+    9000 x 56 x 56 x 64 floats = 7.2 GB: the pointers are never dereferenced."""
+    y = torch.empty(64, device='cuda')
+    for algo in (0, 1, 2):
+        call('fte_set_conv_algo', algo)
+        try:
+            assert query('fte_conv3x3_fwd', y.data_ptr(), y.data_ptr(), 0, 0, 0, 0, y.data_ptr(), 9000, 56, 56, 64, 64, 1, 0, 0, 0) == -1
+            assert query('fte_conv3x3_wgrad', y.data_ptr(), y.data_ptr(), y.data_ptr(), 9000, 56, 56, 64, 64, 1, y.data_ptr(), 256, 0) == -1
+        finally:
+            call('fte_set_conv_algo', 2)
+    # the eval path's helpers (fte_flip_width, fte_axpby) against numpy
+    r = _rng(31)
+    x = r.standard_normal((3, 5, 7, 3)).astype(np.float32); x4 = r.standard_normal((2, 4, 6, 8)).astype(np.float32)
+    for a in (x, x4):
+        o = torch.empty(a.shape, device='cuda')
+        call('fte_flip_width', dev(a), o, a.shape[0], a.shape[1], a.shape[2], a.shape[3], stream())
+        np.testing.assert_array_equal(o.cpu().numpy(), a[:, :, ::-1, :])
+    u, v = r.standard_normal(1000).astype(np.float32), r.standard_normal(1000).astype(np.float32)
+    o = torch.empty(1000, device='cuda')
+    call('fte_axpby', 0.5, dev(u), 0.5, dev(v), o, 1000, stream())
+    np.testing.assert_array_equal(o.cpu().numpy(), np.float32(0.5) * u + np.float32(0.5) * v)

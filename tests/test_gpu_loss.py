@@ -41,8 +41,10 @@ def test_center_loss_and_triplet_functions():
         rows, dft = L.batch_hard_triplet_loss(dev(f), dev(labels, torch.int32), margin)
         check_maxabs(host(rows), per, 2e-5, 'per-sample triplet loss')
         check_rell2(host(dft), dfe / n, 2e-5, 'd(mean)/dfeatures')
-    with pytest.raises(NotImplementedError):
-        L.batch_hard_triplet_loss(dev(f), dev(labels, torch.int32), metric='cityblock')
+    # `metric` is ignored exactly as the reference ignores it (loss.py:65 never forwards it to cdist): euclidean whatever is passed
+    per, dfe = ops.batch_hard_triplet(f, labels, 0.3)
+    rows, dft = L.batch_hard_triplet_loss(dev(f), dev(labels, torch.int32), 0.3, metric='cityblock')
+    check_maxabs(host(rows), per, 2e-5, 'per-sample triplet loss, metric argument ignored')
 
 
 def test_focal_head_on_a_graph_net():

@@ -138,6 +138,8 @@ _SIGS = {
     'fte_row_norms': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
     'fte_col_norms': (c_int, [_P] * 2 + [c_int] * 3 + [_P]),
     'fte_add_scaled_rows_cols': (c_int, [_P] * 4 + [c_int] * 3 + [_P]),
+    'fte_flip_width': (c_int, [_P] * 2 + [c_int] * 4 + [_P]),
+    'fte_axpby': (c_int, [c_float, _P, c_float, _P, _P, c_long, _P]),
     'fte_center_loss_fwd_bwd_update': (c_int, [_P] * 5 + [c_int] * 3 + [c_float] * 2 + [_P, c_size_t, _P]),
     'fte_center_scatter_update': (c_int, [_P] * 3 + [c_int] * 3 + [c_float, _P]),
     'fte_batch_hard_triplet_fwd_bwd': (c_int, [_P] * 2 + [c_float, c_int, c_float] + [_P] * 2 + [c_int] * 2 + [_P, c_size_t, _P]),

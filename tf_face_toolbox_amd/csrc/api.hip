@@ -895,6 +895,10 @@ static int conv2d_wgrad_impl(const void* x, const void* dz, bool src16, float* d
     if (src16 && (cin % 8 || cout % 8)) return FTE_EINVAL;
     if (!x || !dz || !dw || n <= 0 || cin % 4 || cout % 64 || (stride != 1 && stride != 2) || (ksize != 1 && ksize != 3)) return FTE_EINVAL;
     const Pads ph = same_pads(h, ksize, stride), pw = same_pads(wd, ksize, stride);
+    {       // tensors of 2 GiB or more (32-bit buffer offsets): an argument error, reported before any workspace question
+        const size_t lim = (size_t)1 << 31, es = src16 ? 2 : 4;
+        if ((size_t)n * h * wd * cin * es >= lim || (size_t)n * ph.out * pw.out * cout * es >= lim) return FTE_EINVAL;
+    }
     int tile, splits, kchunk, K;
     wgrad_plan(n, h, wd, cin, cout, ksize, stride, &tile, &splits, &kchunk, &K);
     if (!src16 && wino_wanted(n, h, wd, cin, cout, ksize, stride, 2)) {
@@ -1205,6 +1209,15 @@ int fte_row_norms(const float* a, float* out, int rows, int cols, int ld, void* 
 int fte_col_norms(const float* a, float* out, int rows, int cols, int ld, void* stream) {
     if (!a || !out || rows <= 0) return FTE_EINVAL;
     return rc(k_col_norms(a, out, rows, cols, ld, (hipStream_t)stream));
+}
+int fte_flip_width(const float* x, float* y, int n, int h, int wd, int c, void* stream) {
+    if (!x || !y || x == y || n <= 0 || h <= 0 || wd <= 0 || c <= 0) return FTE_EINVAL;
+    if ((c % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) & 15)) return FTE_EINVAL;
+    return rc(k_flip_w(x, y, (long)n * h, wd, c, (hipStream_t)stream));
+}
+int fte_axpby(float a, const float* x, float b, const float* y, float* out, long n, void* stream) {
+    if (!x || !y || !out || n <= 0) return FTE_EINVAL;
+    return rc(k_axpby(a, x, b, y, out, n, (hipStream_t)stream));
 }
 int fte_add_scaled_rows_cols(float* a, const float* b, const float* rcf, const float* cc, int rows, int cols, int ld, void* stream) {
     if (!a || !b || rows <= 0) return FTE_EINVAL;

@@ -27,6 +27,8 @@ hipError_t k_asoftmax_colcoef(const float* G, const float* s, const float* wn, f
 hipError_t k_row_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st);
 hipError_t k_col_norms(const float* a, float* out, int rows, int cols, int ld, hipStream_t st);
 hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* cc, int rows, int cols, int ld, hipStream_t st);
+hipError_t k_flip_w(const float* x, float* y, long rows, int w, int c, hipStream_t st);                    // rows = n * h
+hipError_t k_axpby(float a, const float* x, float b, const float* y, float* out, long n, hipStream_t st);
 hipError_t k_center_loss(const float* feat, const int32_t* labels, float* centers, float* loss_rows, float* dfeat,
                          int n, int d, int num_classes, float alpha, float gs, float* ws, hipStream_t st);
 hipError_t k_center_update(const float* diff, const int32_t* labels, float* centers, int n, int d, int num_classes, float alpha, hipStream_t st);

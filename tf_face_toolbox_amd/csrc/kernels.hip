@@ -1051,6 +1051,45 @@ hipError_t k_col_norms(const float* a, float* out, int rows, int cols, int ld, h
     hipLaunchKernelGGL(col_norms_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, a, out, rows, cols, ld);
     return hipGetLastError();
 }
+namespace {
+// y[n][h][w'][c] = x[n][h][w - 1 - w'][c]: tf.reverse(images, axis=[2]) of the eval path (nets/sphere.py:97-101), 16 bytes per lane
+__global__ __launch_bounds__(256) void flip_w_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int w, int c4) {
+    const long total = rows * w * c4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pix = i / c4;
+        const int q = (int)(i - pix * c4);
+        const long row = pix / w;
+        const int xo = (int)(pix - row * w);
+        *reinterpret_cast<f32x4*>(y + i * 4) = *reinterpret_cast<const f32x4*>(x + ((row * w + (w - 1 - xo)) * c4 + q) * 4);
+    }
+}
+__global__ __launch_bounds__(256) void flip_w1_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int w, int c) {
+    const long total = rows * w * c;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pix = i / c;
+        const int q = (int)(i - pix * c);
+        const long row = pix / w;
+        const int xo = (int)(pix - row * w);
+        y[i] = x[(row * w + (w - 1 - xo)) * c + q];
+    }
+}
+// out = a * x + b * y  (the mean of the two embeddings of the eval path: a = b = 1/2)
+__global__ __launch_bounds__(256) void axpby_kernel(float a, const float* __restrict__ x, float b, const float* __restrict__ y, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a * x[i] + b * y[i];
+}
+}  // namespace
+hipError_t k_flip_w(const float* x, float* y, long rows, int w, int c, hipStream_t st) {
+    const long total = rows * w * c;
+    const int nb = (int)((total / ((c % 4) ? 1 : 4) + 255) / 256 > 4096 ? 4096 : (total / ((c % 4) ? 1 : 4) + 255) / 256);
+    if (c % 4 == 0) hipLaunchKernelGGL(flip_w_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, x, y, rows, w, c / 4);
+    else hipLaunchKernelGGL(flip_w1_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, x, y, rows, w, c);
+    return hipGetLastError();
+}
+hipError_t k_axpby(float a, const float* x, float b, const float* y, float* out, long n, hipStream_t st) {
+    const int nb = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(axpby_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, st, a, x, b, y, out, n);
+    return hipGetLastError();
+}
 hipError_t k_add_scaled(float* a, const float* b, const float* rc, const float* cc, int rows, int cols, int ld, hipStream_t st) {
     const long tot = (long)rows * cols;
     hipLaunchKernelGGL(add_scaled_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, b, rc, cc, rows, cols, ld);

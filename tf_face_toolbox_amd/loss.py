@@ -58,9 +58,9 @@ def center_loss(features, labels, num_classes, alpha=0.99, weight=1.0, centers=N
 
 def batch_hard_triplet_loss(features, labels, margin=None, metric='euclidean'):
     """loss.py:47-78: per-sample batch-hard triplet loss (UNREDUCED, as the reference returns it): softplus(pos - neg)
-    for margin None, else max(0, pos - neg + margin).  -> (diff [N], dfeatures of mean(diff))."""
-    if metric != 'euclidean':
-        raise NotImplementedError('The following metric is not implemented by `cdist` yet: {}'.format(metric))
+    for margin None, else max(0, pos - neg + margin).  -> (diff [N], dfeatures of mean(diff)).
+    `metric` is accepted and IGNORED, as in the reference: loss.py:65 calls `cdist(features, features)` without forwarding it, so
+    every value gives the euclidean distance sqrt(sum d^2 + 1e-12) of loss.py:57."""
     features, labels = _check(features, torch.float32, 'features'), _check(labels, torch.int32, 'labels')
     n, d = features.shape
     rows = torch.empty(n, dtype=torch.float32, device=features.device)

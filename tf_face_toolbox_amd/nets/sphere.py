@@ -368,9 +368,18 @@ class SphereNet(Network):
 
     def _eval_features(self, images):
         # nets/sphere.py:97-101: mean of the embeddings of x and of its horizontal flip (axis 2 of NHWC)
-        f1 = self.backbone(images, is_training=False).clone()
-        f2 = self.backbone(torch.flip(images, dims=[2]), is_training=False)
-        return (f1 + f2) / 2
+        # (flip and mean run in libfte.so like everything else of the path: fte_flip_width, fte_axpby)
+        images = self._check_images(images)
+        n, h, w, ch = images.shape
+        st = _stream()
+        out = torch.empty(n, EMBED, dtype=torch.float32, device=images.device)
+        f1 = self.backbone(images, is_training=False)
+        _lib.call('fte_axpby', 0.5, f1, 0.0, f1, out, n * EMBED, st)
+        flipped = torch.empty_like(images)
+        _lib.call('fte_flip_width', images, flipped, n, h, w, ch, st)
+        f2 = self.backbone(flipped, is_training=False)
+        _lib.call('fte_axpby', 1.0, out, 0.5, f2, out, n * EMBED, st)
+        return out
 
     # ------------------------------------------------------------------ loss
     def _grad_scale(self, n):
