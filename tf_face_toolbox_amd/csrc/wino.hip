@@ -56,18 +56,22 @@ constexpr int SLAB_F = 16 * 64 * 8;            // floats per (row block, K-step)
 constexpr int SLAB_B = SLAB_F * 4;             // 32 KiB
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// tile transforms (HBM-bound).  Block = 64 tiles x 32 channels (one 128-byte line of every pixel it touches); thread = (tile r, channel
-// quad c4 of 8), a wave = 8 tiles x 8 quads: loads are whole 128-byte pixel pieces, stores 256 contiguous bytes per (K-step, plane).
+// tile transforms (HBM-bound).  Block = 64 tiles x 32 channels (one 128-byte line of every pixel it touches), 512 threads; thread =
+// (tile, channel quad of 8), a wave = 8 tiles x 8 quads: loads are whole 128-byte pixel pieces, stores 256 contiguous bytes per (K-step,
+// plane).  Planes are formed and stored a row at a time: 68 registers, so that a block (2 waves per SIMD) fits on a CU BESIDE a resident
+// block of the filter-gradient kernel (2 waves x 176 registers per SIMD) -- which is how the data-gradient side's transforms run
+// under the MFMA-bound kernel of the other stream (nets/sphere.py _body_walk: one stream 34.85 ms per step, two 33.9-34.1).
 template <int MODE>
 __global__ __launch_bounds__(512) void wino_tiles_kernel(const float* __restrict__ x, float* __restrict__ pack, int H, int W, int C,
                                                          int TH, int TW, long M, int MB, unsigned x_bytes) {
     constexpr int P = MODE == 0 ? 4 : 2;
     const int tid = threadIdx.x;
-    const int c4 = tid & 7, r = tid >> 3;
+    const int c4 = tid & 7;
     // consecutive block ids go round the 8 XCDs: an XCD takes a CONTIGUOUS range of row blocks (neighbours share halo rows in its L2)
     const int per = (MB + 7) >> 3;
     const int mb = (blockIdx.x & 7) * per + (blockIdx.x >> 3), KS = C >> 3;
     if (mb >= MB) return;
+    const int r = tid >> 3;
     const long m = (long)mb * 64 + r;
     const int tpi = TH * TW;
     int n = 0, ty = 0, tx = 0;
@@ -85,44 +89,33 @@ __global__ __launch_bounds__(512) void wino_tiles_kernel(const float* __restrict
             const bool ok = mv && yy >= 0 && yy < H && xx >= 0 && xx < W;
             d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(((n * H + yy) * W + xx) * C) * 4u + choff : OOB, 0, 0));
         }
-    f32x4 v[4][4];
-    if constexpr (MODE == 0) {
-        f32x4 w[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            w[0][j] = d[0][j] - d[2][j];
-            w[1][j] = d[1][j] + d[2][j];
-            w[2][j] = d[2][j] - d[1][j];
-            w[3][j] = d[1][j] - d[3][j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i][0] = w[i][0] - w[i][2];
-            v[i][1] = w[i][1] + w[i][2];
-            v[i][2] = w[i][2] - w[i][1];
-            v[i][3] = w[i][1] - w[i][3];
-        }
-    } else {
-        f32x4 u[4][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            u[0][j] = d[0][j];
-            u[1][j] = 0.5f * (d[0][j] + d[1][j]);
-            u[2][j] = 0.5f * (d[0][j] - d[1][j]);
-            u[3][j] = d[1][j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i][0] = u[i][0];
-            v[i][1] = 0.5f * (u[i][0] + u[i][1]);
-            v[i][2] = 0.5f * (u[i][0] - u[i][1]);
-            v[i][3] = u[i][1];
-        }
-    }
     const int ks = blockIdx.y * 4 + (c4 >> 1), sw = (r >> 4) & 1;
     float* o = pack + (((size_t)mb * KS + ks) * 16 * 64 + r) * 8 + (((c4 & 1) ^ sw) << 2);
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(o + (size_t)t * 512) = v[t >> 2][t & 3];
+        for (int i = 0; i < 4; ++i) {          // row i of B^T d, then (B^T d) B: planes 4 i .. 4 i + 3
+            f32x4 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = i == 0 ? d[0][j] - d[2][j] : i == 1 ? d[1][j] + d[2][j] : i == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 0) * 512) = w[0] - w[2];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 1) * 512) = w[1] + w[2];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 2) * 512) = w[2] - w[1];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 3) * 512) = w[1] - w[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 u[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                u[j] = i == 0 ? d[0][j] : i == 1 ? 0.5f * (d[0][j] + d[1][j]) : i == 2 ? 0.5f * (d[0][j] - d[1][j]) : d[1][j];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 0) * 512) = u[0];
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 1) * 512) = 0.5f * (u[0] + u[1]);
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 2) * 512) = 0.5f * (u[0] - u[1]);
+            *reinterpret_cast<f32x4*>(o + (size_t)(4 * i + 3) * 512) = u[1];
+        }
+    }
 }
 
 // filter transform: one thread per (k, row) pair.  dgrad = 0: g[kh][kw] = w[kh][kw][k][row]; dgrad = 1: g[kh][kw] = w[2-kh][2-kw][row][k]
