@@ -38,8 +38,10 @@ def avg_by_kernel(rows, counter):
 
 def short(kernel_name):
     """'void (anonymous namespace)::igemm_kernel<64, 64, 2, 2, 0, 0, 0, 0>(IgemmParams)' -> bench.py's 'igemm_kernel<64,64,2,2,0,0,0,0>'."""
-    m = re.search(r'((?:igemm(?:16(?:rw|w|p|r)?)?|wgrad16p?)_kernel)<([^>]*)>', kernel_name)
-    return '%s<%s>' % (m.group(1), m.group(2).replace(' ', '')) if m else None
+    m = re.search(r'((?:igemm(?:16(?:rw|w|p|r)?)?|wgrad16p?|wino_mm)_kernel)<([^>]*)>', kernel_name)
+    if m:
+        return '%s<%s>' % (m.group(1), m.group(2).replace(' ', ''))
+    return 'wino_wgrad_kernel' if 'wino_wgrad_kernel(' in kernel_name else None
 
 
 bline = json.loads([l for l in open(bench_json) if l.startswith('{')][-1])
