@@ -60,11 +60,13 @@ def test_full_size_step_properties():
     z_full = [z[:B // 2].clone() for z in net.z]                                      # pre-activations of the first half inside the 512-batch
     l_a, g_a, _ = _step(net, x[:B // 2], y[:B // 2], 0.5)
     flips, total, worst_band = 0, 0, 0.0
+    layer_flips = []                                                                  # per conv layer, in net.convs order
     for zf, za in zip(z_full, net.z):
         za = za[:B // 2]
         d = (zf > 0) != (za > 0)
         k = int(d.sum())
         total += zf.numel()
+        layer_flips.append(k)
         if k:
             flips += k
             rms = float(zf.float().pow(2).mean().sqrt())
@@ -80,8 +82,13 @@ def test_full_size_step_properties():
         # PReLU kinks: the few z whose sign differs between the two K orders must be AT the kink (inside the band the oracle
         # comparisons use) and few -- each changes one element of one dz by a factor <= 4
         assert flips <= 2e-6 * total and worst_band <= 1e-5, (flips, total, worst_band)
-    tol = 2e-5 if (strict or flips == 0) else 5e-3
+    # A flipped PReLU slope at layer k changes dz of layers <= k only (the gradient flows from the loss down): a variable of conv layer
+    # l keeps the strict 2e-5 unless some layer >= l has a flipped element; the dense layers above the conv stack always keep it.
+    first_flipped = max([i for i, k in enumerate(layer_flips) if k] or [-1])
+    conv_of = {c.name: i for i, c in enumerate(net.convs)}
     for name, v in net.variables.items():                                           # tower-split additivity, per variable
+        layer = conv_of.get(name.rsplit('/', 1)[0], len(net.convs))
+        tol = 2e-5 if (strict or layer > first_flipped) else 5e-3
         a, b = gs[v.offset:v.offset + v.size], gf[v.offset:v.offset + v.size]
         check_rell2(a, b, tol, 'split-sum gradient of ' + name)
     _, _, e_small = _step(net, x[:4], y[:4], 1.0)                                    # batch independence

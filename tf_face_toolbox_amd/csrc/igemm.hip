@@ -35,6 +35,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -1198,7 +1199,9 @@ hipError_t fixup_tile(const IgemmParams& p, int tile, int splits, hipStream_t st
 // caller's workspace is a fill kernel of ~6 us in front of EVERY stream-K launch (measured: 31 per SphereNet step at 64 images).
 // Instead the library owns one row of words per STREAM (launches of one stream never overlap, so a row has one user at a time) and
 // tags them with a per-row launch counter: a word equals the current epoch only after this launch's producer has stored it.  Rows are
-// handed out to stream handles first come, first served; a 17th concurrent stream falls back to words in the workspace + a memset.
+// handed out to stream handles first come, first served; a 17th concurrent stream falls back to words in the workspace + a memset
+// (a row is never taken from its stream: a launch of that stream may still be polling its words -- the price of cycling through more
+// than 16 stream handles is the ~6 us fill in front of their stream-K launches, never a wrong flag).
 constexpr int SK_ROWS = 16, SK_ROW_WORDS = 2048;
 __device__ unsigned g_sk_words[SK_ROWS][SK_ROW_WORDS];
 struct SkRow { hipStream_t st; int dev; unsigned epoch; bool used; };
@@ -1257,11 +1260,16 @@ hipError_t launch_cfg_p(const IgemmParams& p, int splits, hipStream_t st) {
             auto sk = igemm_sk_kernel<BM, BN, WM, WN, AL, BL, EPI>;
             if (bnm) sk = igemm_bn_sk_kernel<BM, BN, WM, WN, AL, BL, EPI>;
             if (igemm_prof_on()) { const int ta[7] = {BM, BN, WM, WN, AL, BL, EPI}; igemm_note_symbol(bnm ? "igemm_bn_sk_kernel" : "igemm_sk_kernel", ta, 7); }
-            static bool sk_attr[2] = {false, false};
-            if (!sk_attr[bnm]) {
+            // (per device and symbol, set-once with an atomic mask: two host threads driving two devices of one process both get their
+            // attribute; setting it twice is harmless)
+            static std::atomic<unsigned> sk_attr[2] = {{0u}, {0u}};
+            int adev = 0;
+            (void)hipGetDevice(&adev);
+            const unsigned abit = 1u << (adev & 31);
+            if (!(sk_attr[bnm].load(std::memory_order_acquire) & abit)) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + 65536));
                 if (e != hipSuccess) return e;
-                sk_attr[bnm] = true;
+                sk_attr[bnm].fetch_or(abit, std::memory_order_release);
             }
             static const bool sk_dbg = getenv("FTE_SK_DEBUG") != nullptr;
             if (sk_dbg) {

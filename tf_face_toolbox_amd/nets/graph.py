@@ -744,8 +744,14 @@ class GraphNet(Network):
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)
             nreg = self.arena_size - self.small_end
-            call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
-                 self.loss_slots[1:2], self.ws_side, self.ws_bytes, self.side.cuda_stream)
+            # (into a scratch scalar of its own, not the displayed slot: the previous step's reg_loss stays readable until this step's
+            # loss_function copies the new value in; the scale used is remembered -- a tower_scale / weight_decay changed between
+            # forward() and loss_function() makes loss_function recompute)
+            if getattr(self, '_reg_scratch', None) is None:
+                self._reg_scratch = torch.zeros(4, dtype=torch.float32, device=self.params.device)
+            self._reg_scale = 0.5 * self.weight_decay * self.tower_scale
+            call('fte_sumsq', self.params[self.small_end:], nreg, self._reg_scale,
+                 self._reg_scratch[0:1], self.ws_side, self.ws_bytes, self.side.cuda_stream)
             self._reg_ev = self.side.record_event()
         if s16:
             # every filter's bf16 packs, refreshed once per step.  The walk's first layers need only THEIR forward packs: those are
@@ -1167,10 +1173,12 @@ class GraphNet(Network):
                 call('fte_sum', self.loss_rows, n, self.tower_scale / (n * d), slots[2:3], self.ws, self.ws_bytes, st)
                 self._dfeat = self.dfeat
                 losses.append(slots[2]); names.append('center_loss')
-        if getattr(self, '_reg_ev', None) is not None:           # taken on the side stream at the start of this forward pass
-            torch.cuda.current_stream().wait_event(self._reg_ev)
+        if getattr(self, '_reg_ev', None) is not None and self._reg_scale == 0.5 * self.weight_decay * self.tower_scale:
+            torch.cuda.current_stream().wait_event(self._reg_ev)           # taken on the side stream at the start of this forward pass
             self._reg_ev = None
+            call('fte_axpby', 1.0, self._reg_scratch[0:1], 0.0, self._reg_scratch[0:1], slots[1:2], 1, st)
         else:
+            self._reg_ev = None
             nreg = self.arena_size - self.small_end
             call('fte_sumsq', self.params[self.small_end:], nreg, 0.5 * self.weight_decay * self.tower_scale,
                  slots[1:2], self.ws, self.ws_bytes, st)
