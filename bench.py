@@ -224,8 +224,8 @@ def latest_traffic_file(dtype='f32'):
 
 
 def op_kind(key, sym=''):
-    if sym.startswith('wino_mm_kernel'):
-        return 'dgrad' if sym.endswith('<1>') else 'fwd'
+    if sym.startswith('wino_mm_kernel'):          # wino_mm_kernel<EPI, channel halves per block>
+        return 'dgrad' if sym.startswith('wino_mm_kernel<1') else 'fwd'
     if sym.startswith('wino_wgrad'):
         return 'wgrad'
     al, bl, epi = key[:3]

@@ -240,8 +240,17 @@ def test_winograd_symbols_run_naturally_at_the_headline_shapes():
                ['fwd', 136, 7, 7, 512, 512, 1], ['dgrad', 136, 7, 7, 512, 512, 1], ['wgrad', 136, 7, 7, 512, 512, 1],
                ['fwd', 8, 56, 56, 64, 64, 1], ['wgrad', 8, 56, 56, 64, 64, 1]], env={'FTE_CONV_ALGO': 'auto'})
     for c in cs:
-        want = {'fwd': 'wino_mm_kernel<0>', 'dgrad': 'wino_mm_kernel<1>', 'wgrad': 'wino_wgrad_kernel'}[c['case'][0]]
-        assert c['symbols'] == [want], c
+        want = {'fwd': 'wino_mm_kernel<0,', 'dgrad': 'wino_mm_kernel<1,', 'wgrad': 'wino_wgrad_kernel'}[c['case'][0]]
+        assert c['symbols'] and all(s_.startswith(want) for s_ in c['symbols']), c
+    # 72 x 14x14 x 256 = 224 tiles: one round of whole tiles; 136 x 7x7 x 512 = 272 tiles: two rounds of whole tiles
+    assert cs[0]['symbols'] == ['wino_mm_kernel<0,2>'] and cs[6]['symbols'] == ['wino_mm_kernel<0,2>'], (cs[0], cs[6])
+    # the 8-GPU shard of stage 4 (64 images: 128 tiles, half a round): half tiles only, both products
+    hs = _run([['fwd', 64, 7, 7, 512, 512, 1], ['dgrad', 64, 7, 7, 512, 512, 1]], env={'FTE_CONV_ALGO': 'auto'})
+    assert hs[0]['symbols'] == ['wino_mm_kernel<0,1>'] and hs[1]['symbols'] == ['wino_mm_kernel<1,1>'], hs
+    # the A/B hook: the last, partly filled round of a two-round launch as a half-tile launch of its own behind the whole tiles
+    ab = _run([['fwd', 136, 7, 7, 512, 512, 1], ['dgrad', 84, 14, 14, 256, 256, 1]], env={'FTE_CONV_ALGO': 'auto', 'FTE_WINO_HALF_TILES': '2'})
+    assert sorted(ab[0]['symbols']) == ['wino_mm_kernel<0,1>', 'wino_mm_kernel<0,2>'], ab[0]
+    assert sorted(ab[1]['symbols']) == ['wino_mm_kernel<1,1>', 'wino_mm_kernel<1,2>'], ab[1]
     d = _run([['dgrad', 8, 56, 56, 64, 64, 1]], env={'FTE_CONV_ALGO': 'auto'})[0]      # the 64-channel data gradient stays direct
     assert all(s_.startswith('igemm') for s_ in d['symbols']), d
 

@@ -24,7 +24,8 @@ CASES = [
     (1, 28, 28, 128, 128),       # stage 2
     (2, 56, 56, 64, 64),         # stage 1: one column block
     (40, 14, 14, 256, 256),      # 31 row blocks: every XCD class, several tiles per filter-gradient share
-    (64, 7, 7, 512, 512),        # the 8-GPU shard of stage 4
+    (64, 7, 7, 512, 512),        # the 8-GPU shard of stage 4: 128 tiles = 256 half tiles, no whole round
+    (84, 14, 14, 256, 256),      # 260 tiles: a whole round + a second round of 4 tiles (resident blocks with 2 and with 1 tile)
 ]
 
 
@@ -57,7 +58,7 @@ def test_wino_fwd(winograd, n, h, w, cin, cout):
     wsb, nb = ws(query('fte_conv3x3_fwd_ws_bytes', n, h, w, cin, cout, 1))
     args = (dev(x), dev(wt), dev(b), dev(al), dev(res), z, y, n, h, w, cin, cout, 1, wsb, nb, stream())
     syms = _symbols(lambda: call('fte_conv3x3_fwd', *args))
-    assert syms == ['wino_mm_kernel<0>'], syms
+    assert syms and all(s_.startswith('wino_mm_kernel<0,') for s_ in syms), syms
     check_maxabs(host(z), z_ref, what='z'); check_maxabs(host(y), y_ref, what='y')
     y2 = torch.full(z_ref.shape, 7.0, device='cuda')
     call('fte_conv3x3_fwd', dev(x), dev(wt), None, None, None, None, y2, n, h, w, cin, cout, 1, wsb, nb, stream())
@@ -84,7 +85,7 @@ def test_wino_dgrad_with_prelu_backward(winograd, n, h, w, cin, cout):
     wsb, nb = ws(query('fte_conv3x3_dgrad_ws_bytes', n, h, w, cin, cout, 1))
     args = (dev(dz), dev(wt), dev(addin), dev(zprev), dev(alp), raw, dzp, da, db, n, h, w, cin, cout, 1, wsb, nb, stream())
     syms = _symbols(lambda: call('fte_conv3x3_dgrad', *args))
-    assert syms == ['wino_mm_kernel<1>'], syms
+    assert syms and all(s_.startswith('wino_mm_kernel<1,') for s_ in syms), syms
     check_maxabs(host(raw), g_ref, what='raw'); check_maxabs(host(dzp), dzprev_ref, what='dzprev')
     check_rell2(host(da), dalpha_ref, what='dalpha'); check_rell2(host(db), dbias_ref, what='dbias')
     dzp2 = torch.full(x.shape, 7.0, device='cuda')
@@ -132,7 +133,7 @@ def test_switch_off_runs_the_direct_kernels():
         assert torch.equal(y, y_direct)
         wsb2, nb2 = ws(big)
         syms = _symbols(lambda: call('fte_conv3x3_fwd', x, wt, None, None, None, None, y, n, h, w, c, c, 1, wsb2, nb2, stream()))
-        assert syms == ['wino_mm_kernel<0>'], syms
+        assert syms and all(s_.startswith('wino_mm_kernel<0,') for s_ in syms), syms
         check_maxabs(host(y), host(y_direct), tol=4e-5, what='winograd vs direct')
         y2 = torch.empty(n, 7, 7, c, device='cuda')
         syms = _symbols(lambda: call('fte_conv3x3_fwd', x, wt, None, None, None, None, y2, n, h, w, c, c, 2, wsb2, nb2, stream()))

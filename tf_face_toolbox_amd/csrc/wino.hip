@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "igemm.h"
 #include "igemm_dev.h"
 #include "wino.h"
@@ -155,13 +157,23 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
 // wino_mm_kernel: block = 64 tiles x 64 output channels x 16 t.  Wave (q, mi, ni) = wid bits 0, 1, 2: t-planes [8q, 8q+8) of tile rows
 // [32 mi, +32) x channels [32 ni, +32).  MFMA operand map (32x32x2): a = V[t][tile li][k], b = U[t][channel li][k] with k = 4 lh + j for
 // the j-th MFMA of a K-step (one ds_read_b128 per operand and t feeds four MFMAs); C rows (registers) = tiles, lanes = channels.
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, int NBX, int GRP, int nvirt) {
+// NWN = channel halves of the block: 2 = the 64 x 64 block on 8 waves; 1 = HALF tiles, 64 tiles x 32 channels on 4 waves, one per SIMD
+// (a lone wave issues its 64-cycle MFMAs back to back: ~2600 cycles per K-step, a half tile takes 0.55 of a tile's loop) -- for launches
+// that are less than half a round of whole tiles (the 7x7x512 layers at a 64-image shard: 128 tiles on 256 CUs -> 256 half tiles, 0.126
+// -> 0.087 ms).  Measured and NOT used for the last, partly filled round of a many-round launch: a launch of its own costs ~11 us of
+// ramp and epilogue beside its loop, as much as the resident blocks' last round saves (14x14x256 at 512 images: 0.482 -> 0.479 ms);
+// four extra loader waves in the half-tile block changed nothing (r6_notes.md 7).
+template <int EPI, int NWN>
+__global__ __launch_bounds__(256 * NWN, 1) void wino_mm_kernel(const WinoMMParams p, int NBX, int GRP, int vid0, int nvirt) {
+    constexpr int NW = 4 * NWN;                    // waves per block
+    constexpr int BSTG = NWN * (SLAB_B / 2);       // bytes of a stage's filter image (NWN = 1: the block's 32 rows of the 64-row slab)
+    constexpr int STG = SLAB_B + BSTG;             // bytes per stage
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = wid & 1, mi = (wid >> 1) & 1, ni = wid >> 2;
+    const int q = wid & 1, mi = (wid >> 1) & 1, ni = NWN == 2 ? wid >> 2 : 0;
+    const int hb = NWN == 2 ? 0 : (int)(blockIdx.x & 1);      // NWN = 1: which channel half of the column block
     const int li = lane & 31, lh = lane >> 5;
     const int KS = p.K >> 3, NB = p.N >> 6;
     // ---- virtual block id -> (mb, nb): consecutive ids go round the 8 XCDs; an XCD keeps NBX column blocks (their filter slabs stay in
@@ -178,29 +190,44 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
         }
         return mb < p.g.MB;
     };
+    // the block's tiles: NWN = 2: the valid ids vid0 + b, + grid, ... below nvirt; NWN = 1: ONE tile, the (b >> 1)-th valid id of [vid0, nvirt)
     auto next_valid = [&](int vid, int& mb, int& nb) -> int {      // first valid id >= vid of this block's sequence, or nvirt
-        for (; vid < nvirt; vid += (int)gridDim.x)
-            if (decode(vid, mb, nb)) return vid;
+        if constexpr (NWN == 2) {
+            for (; vid < nvirt; vid += (int)gridDim.x)
+                if (decode(vid, mb, nb)) return vid;
+        } else if (vid == vid0) {
+            int c = 0;
+            for (int v = vid0; v < nvirt; ++v)
+                if (decode(v, mb, nb)) {
+                    if (c == (int)(blockIdx.x >> 1)) return v;
+                    ++c;
+                }
+        }
         return nvirt;
     };
     const unsigned voff = (unsigned)lane * 16u;
     auto issue = [&](int mb, int nb, int s, int stage) {
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V + (size_t)mb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U + (size_t)nb * KS * SLAB_F), 0, (unsigned)KS * SLAB_B, 0x00020000);
-        char* base = wsm + stage * (2 * SLAB_B);
+        char* base = wsm + stage * STG;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wid + 8 * i;
+        for (int i = 0; i < 32 / NW; ++i) {
+            const int piece = wid + NW * i;
             dma16(rsA, base + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
-            dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {             // the filter image: 32 pieces, or the 16 of this block's channel half (plane t: piece 2 t + hb)
+            const int piece = wid + NW * i;
+            dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + (NWN == 2 ? piece : 2 * piece + hb) * 1024));
         }
     };
+    constexpr int BPL = NWN * 1024;               // bytes per plane of the filter image
     const int a_off = ((8 * q) * 64 + 32 * mi + li) * 32 + ((lh ^ ((li >> 4) & 1)) << 4);      // bytes
-    const int b_off = ((8 * q) * 64 + 32 * ni + li) * 32 + ((lh ^ ((li >> 4) & 1)) << 4);
-    float* xb = reinterpret_cast<float*>(wsm + 2 * SLAB_B);           // stage 1, free after the last K-step: [8 waves][32][64 lanes]
-    int* rowpix = reinterpret_cast<int*>(wsm + 4 * SLAB_B);           // [64] pixel index of output (n, 2 ty, 2 tx), or -1
+    const int b_off = (8 * q) * BPL + (32 * ni + li) * 32 + ((lh ^ ((li >> 4) & 1)) << 4);
+    float* xb = reinterpret_cast<float*>(wsm + STG);                  // stage 1, free after the last K-step: [NW waves][32][64 lanes]
+    int* rowpix = reinterpret_cast<int*>(wsm + 2 * STG);              // [64] pixel index of output (n, 2 ty, 2 tx), or -1
     int* rowflag = rowpix + 64;                                       // bit 0: row 2 ty + 1 inside, bit 1: column 2 tx + 1 inside
-    float* red = reinterpret_cast<float*>(rowflag + 64);              // [2][8 waves][32] column partials of the data-gradient epilogue
+    float* red = reinterpret_cast<float*>(rowflag + 64);              // [2][NW waves][32] column partials of the data-gradient epilogue
 
     // ---- software pipeline of the K loop (a K-step = 8 channels = 32 MFMAs per wave, in two halves of four t-planes) ---------------
     //   half 0: MFMAs on fragment set X (planes 0-3 of step g) | payload: fragment reads of planes 4-7 of step g -> set Y
@@ -214,20 +241,28 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
     // steps 0 and 1, so the epilogue runs with step 0's first fragments in registers and its stage untouched; step 1's DMA is held back
     // until the epilogue's exchange buffer (stage 1) has been read.
     int mb = 0, nb = 0;
-    int vid = next_valid((int)blockIdx.x, mb, nb);
+    int vid = next_valid(NWN == 2 ? vid0 + (int)blockIdx.x : vid0, mb, nb);
     if (vid >= nvirt) return;
     f32x4 xa[4], xb4[4], ya[4], yb[4];
     auto read_frags = [&](int stage, int half, f32x4 (&fa)[4], f32x4 (&fb)[4], int t) {
-        const char* As = wsm + stage * (2 * SLAB_B);
+        const char* As = wsm + stage * STG;
         fa[t] = *reinterpret_cast<const f32x4*>(As + a_off + (4 * half + t) * 2048);
-        fb[t] = *reinterpret_cast<const f32x4*>(As + SLAB_B + b_off + (4 * half + t) * 2048);
+        fb[t] = *reinterpret_cast<const f32x4*>(As + SLAB_B + b_off + (4 * half + t) * BPL);
     };
     auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int s, int stage, int i) {
-        char* base = wsm + stage * (2 * SLAB_B);
-        const int piece = wid + 8 * (i >> 1);
-        if (i & 1) dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
-        else dma16(rsA, base + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+        // piece i of this wave's list for one K-step: NWN = 2: 8 (A and filter pieces alternating); NWN = 1: 12 (8 of A, then 4 filter pieces)
+        char* base = wsm + stage * STG;
+        if constexpr (NWN == 2) {
+            const int piece = wid + 8 * (i >> 1);
+            if (i & 1) dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+            else dma16(rsA, base + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+        } else {
+            const int piece = wid + 4 * (i & 7);
+            if (i >= 8) dma16(rsB, base + SLAB_B + piece * 1024, voff, (unsigned)(s * SLAB_B + (2 * piece + hb) * 1024));
+            else dma16(rsA, base + piece * 1024, voff, (unsigned)(s * SLAB_B + piece * 1024));
+        }
     };
+    constexpr int NDMA = NWN == 2 ? 8 : 12;       // DMA pieces per wave and K-step
     issue(mb, nb, 0, 0);
     issue(mb, nb, 1, 1);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -236,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
     bool first = true;
     while (vid < nvirt) {
         int mb2 = 0, nb2 = 0;
-        const int vid2 = next_valid(vid + (int)gridDim.x, mb2, nb2);
+        const int vid2 = NWN == 2 ? next_valid(vid + (int)gridDim.x, mb2, nb2) : nvirt;
         const bool has_next = vid2 < nvirt;
 #ifdef FTE_WINO_STAMP
         unsigned long long st0 = 0, sr0 = 0, st1 = 0;
@@ -286,7 +321,7 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
                 acc[4 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[t][j], yb[t][j], acc[4 + t], 0, 0, 0);
                 // (the fragments of the step after the block's very last one are read from a stage nobody refills: unused)
                 if constexpr (idx < 4) read_frags(st ^ 1, 0, xa, xb4, idx);
-                if constexpr (idx >= 4 && idx < 12) dma_piece(rsA, rsB, ds, st, idx - 4);      // (no step g + 2: descriptors of zero records)
+                if constexpr (idx >= 4 && idx < 4 + NDMA) dma_piece(rsA, rsB, ds, st, idx - 4);      // (no step g + 2: descriptors of zero records)
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -322,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
         // out-of-range offset -- loads return 0, stores are dropped -- so the epilogue has no branches.
         // pass (b, h2, j): output column b, tile row 32 mi + 16 h2 + prw + 8 j
         const int prw = lane_e >> 3, pc4 = lane_e & 7;
-        const int ch0 = nb * 64 + 32 * ni + 4 * pc4;
+        const int ch0 = nb * 64 + 32 * (NWN == 2 ? ni : hb) + 4 * pc4;
         unsigned off[2][2][2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
@@ -372,7 +407,7 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // every wave has its partner's values: stage 1 may be refilled
         if (has_next) issue(mb2, nb2, 1, 1);
         // ---- accumulator map -> transposed map through a wave-private 16 x 36 float patch, four passes ----
-        float* patch = reinterpret_cast<float*>(wsm + 4 * SLAB_B + 2560) + wid * (16 * 36);
+        float* patch = reinterpret_cast<float*>(wsm + 2 * STG + 2560) + wid * (16 * 36);
         f32x4 sa4 = {0.f, 0.f, 0.f, 0.f}, sb4 = {0.f, 0.f, 0.f, 0.f};
         const __amdgpu_buffer_rsrc_t rsO0 = rsrc_of(EPI == EPI_FWD ? p.Z : p.RAW), rsO1 = rsrc_of(EPI == EPI_FWD ? p.Y : p.DZ);
 #pragma unroll
@@ -419,15 +454,15 @@ __global__ __launch_bounds__(512, 1) void wino_mm_kernel(const WinoMMParams p, i
                     a_ += __shfl_xor(a_, 8); b_ += __shfl_xor(b_, 8);
                     a_ += __shfl_xor(a_, 16); b_ += __shfl_xor(b_, 16);
                     a_ += __shfl_xor(a_, 32); b_ += __shfl_xor(b_, 32);
-                    if (prw == 0) { red[wid * 32 + 4 * pc4 + e] = a_; red[(8 + wid) * 32 + 4 * pc4 + e] = b_; }
+                    if (prw == 0) { red[wid * 32 + 4 * pc4 + e] = a_; red[(NW + wid) * 32 + 4 * pc4 + e] = b_; }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tid < 64) {
+                if (tid < 32 * NWN) {
                     const int n2 = tid >> 5, l2 = tid & 31;
                     float a = 0.f, b = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { a += red[(4 * n2 + k) * 32 + l2]; b += red[(8 + 4 * n2 + k) * 32 + l2]; }
-                    const size_t o = (size_t)mb * p.N + nb * 64 + tid;
+                    for (int k = 0; k < 4; ++k) { a += red[(4 * n2 + k) * 32 + l2]; b += red[(NW + 4 * n2 + k) * 32 + l2]; }
+                    const size_t o = (size_t)mb * p.N + nb * 64 + (NWN == 2 ? tid : 32 * hb + tid);
                     p.PA[o] = a;
                     if (p.PB) p.PB[o] = b;
                 }
@@ -677,6 +712,32 @@ hipError_t wino_transform_filter(const float* w, float* pack, int cin, int cout,
     return hipGetLastError();
 }
 
+namespace {
+template <int EPI, int NWN>
+hipError_t wino_mm_launch(const WinoMMParams& p, int NBX, int GRP, int vid0, int vid1, int grid, int tiles, hipStream_t st) {
+    constexpr int NW = 4 * NWN;
+    const size_t lds = 2 * ((size_t)SLAB_B + NWN * (SLAB_B / 2)) + 2560 + (size_t)NW * 16 * 36 * 4;      // two stages, row table + column partials, transpose patches
+    static std::atomic<unsigned> attr{0u};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (!(attr.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_mm_kernel<EPI, NWN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr.fetch_or(bit, std::memory_order_release);
+    }
+    const int sig[5] = {AL_MK, BL_NK, EPI, 8, 1};                    // tile id 8: the Winograd product (bench.py TILES)
+    const double frac = (double)tiles / ((double)p.g.MB * (p.N / 64));
+    const double flops = 2.0 * 16.0 * (double)tiles * 64.0 * 64.0 * p.K;      // MFMA FLOPs the launch EXECUTES (padded row blocks included)
+    const double bytes = frac * ((double)wino_pack_floats(p.g.M, p.K) * 4.0 + 16.0 * p.N * p.K * 4.0 + (double)p.g.n * p.g.h * p.g.w * p.N * 4.0 *
+                                 (EPI == EPI_FWD ? (1 + (p.Z ? 1 : 0) + (p.R ? 1 : 0)) : (1 + (p.ADD ? 1 : 0) + (p.RAW ? 1 : 0) + (p.Zin ? 1 : 0))));
+    const int h = igemm_prof_begin(sig, (int)((long)tiles * 64 / (p.N / 64)), p.N, 16 * p.K, flops, bytes, st);      // rows = tiles of the launch
+    hipLaunchKernelGGL((wino_mm_kernel<EPI, NWN>), dim3(grid), dim3(256 * NWN), lds, st, p, NBX, GRP, vid0, vid1);
+    igemm_prof_end(h, EPI == EPI_FWD ? (NWN == 2 ? "wino_mm_kernel<0,2>" : "wino_mm_kernel<0,1>") : (NWN == 2 ? "wino_mm_kernel<1,2>" : "wino_mm_kernel<1,1>"), st);
+    return hipGetLastError();
+}
+}  // namespace
+
 hipError_t wino_mm(const WinoMMParams& p, int epi, hipStream_t st) {
     if (p.K % 64 || p.N % 64 || p.g.MB <= 0) return hipErrorInvalidValue;
     if ((size_t)p.g.n * p.g.h * p.g.w * p.N >= ((size_t)1 << 31)) return hipErrorInvalidValue;
@@ -694,23 +755,30 @@ hipError_t wino_mm(const WinoMMParams& p, int epi, hipStream_t st) {
         cus = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
     }
     const int grid = nvirt < cus ? (nvirt + 7) / 8 * 8 : cus;      // one resident block per CU (a multiple of 8: a block keeps its XCD)
-    const size_t lds = 4 * (size_t)SLAB_B + 2560 + 8 * 16 * 36 * 4;      // two stages, row table + column partials, the epilogue's transpose patches
-    static bool attr[2] = {false, false};
-    const void* fn = epi == EPI_FWD ? reinterpret_cast<const void*>(wino_mm_kernel<EPI_FWD>) : reinterpret_cast<const void*>(wino_mm_kernel<EPI_DGRAD>);
-    if (!attr[epi == EPI_FWD ? 0 : 1]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // A launch of at most half a round of whole tiles runs as HALF tiles (wino_mm_kernel<EPI, 1>): 7x7x512 at 64 images: 256 half tiles
+    // instead of 128 tiles.  FTE_WINO_HALF_TILES=2 (A/B hook) also sends the last, partly filled round of a many-round launch there as a
+    // launch of its own (measured: no gain, see the kernel).  (the same id -> tile map as the kernel's decode)
+    static const int halves = getenv("FTE_WINO_HALF_TILES") ? atoi(getenv("FTE_WINO_HALF_TILES")) : 1;      // A/B hook
+    auto valid = [&](int vid) {
+        if (GRP > 0) { const int xcd = vid & 7, slot = vid >> 3, cls = xcd / GRP, C = 8 / GRP; return (slot / NBX) * C + cls < p.g.MB; }
+        return vid / NB < p.g.MB;
+    };
+    const int rounds = (nvirt + grid - 1) / grid, last = grid * (rounds - 1);
+    int L = 0;
+    for (int v = last; v < nvirt; ++v) L += valid(v) ? 1 : 0;
+    const int total = p.g.MB * NB;
+    int tail_base = nvirt;
+    if (halves && L > 0 && 2 * L <= cus && (rounds == 1 || halves == 2)) tail_base = last;
+    hipError_t e = hipSuccess;
+    if (tail_base > 0) {
+        e = epi == EPI_FWD ? wino_mm_launch<EPI_FWD, 2>(p, NBX, GRP, 0, tail_base, grid, total - (tail_base < nvirt ? L : 0), st)
+                           : wino_mm_launch<EPI_DGRAD, 2>(p, NBX, GRP, 0, tail_base, grid, total - (tail_base < nvirt ? L : 0), st);
         if (e != hipSuccess) return e;
-        attr[epi == EPI_FWD ? 0 : 1] = true;
     }
-    const int sig[5] = {AL_MK, BL_NK, epi, 8, 1};                    // tile id 8: the Winograd product (bench.py TILES)
-    const double flops = 2.0 * 16.0 * (double)p.g.MB * 64.0 * p.N * p.K;      // MFMA FLOPs the launch EXECUTES (padded row blocks included)
-    const double bytes = (double)wino_pack_floats(p.g.M, p.K) * 4.0 + 16.0 * p.N * p.K * 4.0 + (double)p.g.n * p.g.h * p.g.w * p.N * 4.0 *
-                         (epi == EPI_FWD ? (1 + (p.Z ? 1 : 0) + (p.R ? 1 : 0)) : (1 + (p.ADD ? 1 : 0) + (p.RAW ? 1 : 0) + (p.Zin ? 1 : 0)));
-    const int h = igemm_prof_begin(sig, (int)(p.g.MB * 64), p.N, 16 * p.K, flops, bytes, st);
-    if (epi == EPI_FWD) hipLaunchKernelGGL(wino_mm_kernel<EPI_FWD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP, nvirt);
-    else hipLaunchKernelGGL(wino_mm_kernel<EPI_DGRAD>, dim3(grid), dim3(512), lds, st, p, NBX, GRP, nvirt);
-    igemm_prof_end(h, epi == EPI_FWD ? "wino_mm_kernel<0>" : "wino_mm_kernel<1>", st);
-    return hipGetLastError();
+    if (tail_base < nvirt)
+        e = epi == EPI_FWD ? wino_mm_launch<EPI_FWD, 1>(p, NBX, GRP, tail_base, nvirt, 2 * L, L, st)
+                           : wino_mm_launch<EPI_DGRAD, 1>(p, NBX, GRP, tail_base, nvirt, 2 * L, L, st);
+    return e;
 }
 
 int wino_wgrad_splits(int cin, int cout) {
