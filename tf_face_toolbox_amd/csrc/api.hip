@@ -334,6 +334,13 @@ inline int wino_min_c() {
     static const int v = getenv("FTE_WINO_MIN_C") ? atoi(getenv("FTE_WINO_MIN_C")) : 128;
     return v;
 }
+// forward-side tile transforms in 256-thread blocks (wino.h; the default: 72 registers per SIMD fit beside a resident block of the forward
+// product, so one half shard's transform runs under the other's product -- nets/sphere.py backbone; alone 34.72 -> 34.58 ms per step at 512
+// images, with the half shards 34.36 -> 34.21).  FTE_WINO_FWD_TPB=512: the 512-thread blocks of the data-gradient side.
+inline bool wino_fwd_small_tiles() {
+    static const int tpb = getenv("FTE_WINO_FWD_TPB") ? atoi(getenv("FTE_WINO_FWD_TPB")) : 256;
+    return tpb != 512;
+}
 inline bool wino_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
     if (ksize != 3 || stride != 1 || cin % 64 || cout % 64 || n <= 0 || h < 2 || wd < 2) return false;
     const size_t lim = (size_t)1 << 31;
@@ -485,7 +492,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, bool src16, const float
             float* U = (float*)((char*)ws + wl.u_off);
             hipError_t e = wino_transform_filter((const float*)w, U, cin, cout, 0, (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
-            e = wino_transform_tiles((const float*)x, V, n, h, wd, cin, 0, (hipStream_t)stream);
+            e = wino_transform_tiles((const float*)x, V, n, h, wd, cin, 0, (hipStream_t)stream, wino_fwd_small_tiles());
             if (e != hipSuccess) return (int)e;
             WinoMMParams q;
             memset(&q, 0, sizeof(q));

@@ -22,7 +22,8 @@ inline size_t wino_pack_floats(long rows, int c) { return (size_t)((rows + 63) /
 
 // mode 0: V = B^T d B of the 4x4 input patch of every tile (forward: d = x; data gradient: d = dz)
 // mode 1: U' = G' d G'^T of the 2x2 tile itself (filter gradient: d = dz), G' = [[1,0],[.5,.5],[.5,-.5],[0,1]]
-hipError_t wino_transform_tiles(const float* x, float* pack, int n, int h, int w, int c, int mode, hipStream_t st);
+// small: 256-thread blocks of half a row block each (mode 0; fits on a CU beside a resident block of the forward product)
+hipError_t wino_transform_tiles(const float* x, float* pack, int n, int h, int w, int c, int mode, hipStream_t st, bool small = false);
 // U = G g G^T of every 3x3 filter, packed with rows = the product's output channels.  w is HWIO [3][3][cin][cout];
 // dgrad = 0: rows = cout, k = cin (forward);  dgrad = 1: rows = cin, k = cout, taps rotated by 180 degrees (data gradient)
 hipError_t wino_transform_filter(const float* w, float* pack, int cin, int cout, int dgrad, hipStream_t st);

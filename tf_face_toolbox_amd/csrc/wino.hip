@@ -63,17 +63,21 @@ constexpr int SLAB_B = SLAB_F * 4;             // 32 KiB
 // plane).  Planes are formed and stored a row at a time: 68 registers, so that a block (2 waves per SIMD) fits on a CU BESIDE a resident
 // block of the filter-gradient kernel (2 waves x 176 registers per SIMD) -- which is how the data-gradient side's transforms run
 // under the MFMA-bound kernel of the other stream (nets/sphere.py _body_walk: one stream 34.85 ms per step, two 33.9-34.1).
-template <int MODE>
-__global__ __launch_bounds__(512) void wino_tiles_kernel(const float* __restrict__ x, float* __restrict__ pack, int H, int W, int C,
+// TPB = 256: half a row block (32 tiles) per block, one wave per SIMD -- 72 registers per SIMD, what is left beside a resident block of
+// the FORWARD product (2 x 216): the forward walk's two half shards (nets/sphere.py backbone) run one half's transform under the other's product.
+template <int MODE, int TPB>
+__global__ __launch_bounds__(TPB) void wino_tiles_kernel(const float* __restrict__ x, float* __restrict__ pack, int H, int W, int C,
                                                          int TH, int TW, long M, int MB, unsigned x_bytes) {
     constexpr int P = MODE == 0 ? 4 : 2;
+    constexpr int SUB = 512 / TPB;             // blocks per row block
     const int tid = threadIdx.x;
     const int c4 = tid & 7;
     // consecutive block ids go round the 8 XCDs: an XCD takes a CONTIGUOUS range of row blocks (neighbours share halo rows in its L2)
     const int per = (MB + 7) >> 3;
-    const int mb = (blockIdx.x & 7) * per + (blockIdx.x >> 3), KS = C >> 3;
+    const int slot = blockIdx.x >> 3;
+    const int mb = (blockIdx.x & 7) * per + slot / SUB, KS = C >> 3;
     if (mb >= MB) return;
-    const int r = tid >> 3;
+    const int r = (slot % SUB) * (64 / SUB) + (tid >> 3);
     const long m = (long)mb * 64 + r;
     const int tpi = TH * TW;
     int n = 0, ty = 0, tx = 0;
@@ -694,14 +698,15 @@ WinoGeom wino_geom(int n, int h, int w) {
     return g;
 }
 
-hipError_t wino_transform_tiles(const float* x, float* pack, int n, int h, int w, int c, int mode, hipStream_t st) {
+hipError_t wino_transform_tiles(const float* x, float* pack, int n, int h, int w, int c, int mode, hipStream_t st, bool small) {
     if (c % 32) return hipErrorInvalidValue;
     const WinoGeom g = wino_geom(n, h, w);
     const size_t xb = (size_t)n * h * w * c * 4;
     if (xb >= ((size_t)1 << 31)) return hipErrorInvalidValue;
-    const dim3 grid(8 * ((g.MB + 7) / 8), c / 32);
-    if (mode == 0) hipLaunchKernelGGL(wino_tiles_kernel<0>, grid, dim3(512), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
-    else hipLaunchKernelGGL(wino_tiles_kernel<1>, grid, dim3(512), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
+    const dim3 grid(8 * ((g.MB + 7) / 8) * (small ? 2 : 1), c / 32);
+    if (mode == 0 && small) hipLaunchKernelGGL((wino_tiles_kernel<0, 256>), grid, dim3(256), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
+    else if (mode == 0) hipLaunchKernelGGL((wino_tiles_kernel<0, 512>), grid, dim3(512), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
+    else hipLaunchKernelGGL((wino_tiles_kernel<1, 512>), grid, dim3(512), 0, st, x, pack, h, w, c, g.th, g.tw, g.M, g.MB, (unsigned)xb);
     return hipGetLastError();
 }
 

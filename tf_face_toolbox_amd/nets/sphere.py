@@ -293,6 +293,31 @@ class SphereNet(Network):
             images = images.contiguous()
         return images
 
+    def _fwd_halves(self, n, copies):
+        """Forward walk as two half shards on two streams?  fp32 Winograd plan only (the direct kernels fill the chip by themselves and
+        have no HBM-bound companion), even shards whose halves end on whole 64-tile row blocks of every kept V pack and plan the same
+        algorithm per layer.  FTE_FWD_HALVES=0 / 1 forces it off / on where it is possible."""
+        env = os.environ.get('FTE_FWD_HALVES', 'auto')
+        if env == '0' or copies or self.side is None or n % 2 or n < 2:
+            return False
+        key = (n, getattr(self, '_act_key', None))
+        if getattr(self, '_halves_key', None) != key:
+            q = _lib.query
+            ok, any_w = True, False
+            for l, c in enumerate(self.convs):
+                if l == 0 or c.stride != 1:
+                    continue
+                a_full, a_half = (q('fte_conv3x3_algo', m, c.hin, c.win, c.cin, c.cout, 1, 0) for m in (n, n // 2))
+                any_w = any_w or a_full == 1
+                if a_full != a_half:
+                    ok = False
+                if self.vpack[l] is not None and ((n // 2) * ((c.hin + 1) // 2) * ((c.win + 1) // 2)) % 64:
+                    ok = False
+            self._halves_key, self._halves_ok = key, ok and any_w
+        if not self._halves_ok:
+            return False
+        return env == '1' or n >= int(os.environ.get('FTE_FWD_HALVES_MIN', '128'))
+
     def backbone(self, inputs, is_training=False, reuse=None):
         """nets/sphere.py:47-76: [N,H,W,C] NHWC -> embedding [N,512] (a view of an internal buffer)."""
         x = self._check_images(inputs)
@@ -313,34 +338,54 @@ class SphereNet(Network):
         if copies:
             self._alloc_copies()
             self._pack_weights(st)
-        for l, c in enumerate(self.convs):
+        def layer(l, c, lo, hi, ws, st):
+            """layer l over images [lo, hi) on stream st (every forward kernel is per image: no statistics, nets/sphere.py:38-45)"""
+            m = hi - lo
             wv = self.view(c.name + '/weights')
             bv = self.view(c.name + '/biases') if c.has_bias else None
             av = self.view(c.name + '/alpha')
-            zz = self.z[l] if keep else None
+            zz = self.z[l][lo:hi] if keep else None
             if s16:
                 # bf16 storage: every layer writes bf16 z / y only (+ the unrounded fp32 pair for the last layer: the dense layer reads it)
-                z16 = self.z16[l] if keep else None
+                z16 = self.z16[l][lo:hi] if keep else None
                 if l == 0:
-                    call('fte_conv3x3_first_fwd_s16', x, wv, bv, av, z16, self.y16[0], n, c.hin, c.win, c.cin, c.cout, c.stride, st)
+                    call('fte_conv3x3_first_fwd_s16', x[lo:hi], wv, bv, av, z16, self.y16[0][lo:hi], m, c.hin, c.win, c.cin, c.cout, c.stride, st)
                 else:
-                    call('fte_conv2d_fwd_s16', self.y16[l - 1], self.w16t[c.name], bv, av, self.y16[l - 2] if c.second == 1 else None,
-                         z16, self.y16[l], zz, self.y[l], n, c.hin, c.win, c.cin, c.cout, 3, c.stride, self.ws, self.ws_bytes, st)
+                    call('fte_conv2d_fwd_s16', self.y16[l - 1][lo:hi], self.w16t[c.name], bv, av, self.y16[l - 2][lo:hi] if c.second == 1 else None,
+                         z16, self.y16[l][lo:hi], zz, self.y[l][lo:hi] if self.y[l] is not None else None, m, c.hin, c.win, c.cin, c.cout, 3, c.stride,
+                         ws, self.ws_bytes, st)
             elif l == 0:
-                call('fte_conv3x3_first_fwd', x, wv, bv, av, zz, self.y[0], n, c.hin, c.win, c.cin, c.cout, c.stride, st)
+                call('fte_conv3x3_first_fwd', x[lo:hi], wv, bv, av, zz, self.y[0][lo:hi], m, c.hin, c.win, c.cin, c.cout, c.stride, st)
                 if copies:
-                    call('fte_to_bf16', self.y[0], self.y16[0], self.y[0].numel(), st)
+                    call('fte_to_bf16', self.y[0][lo:hi], self.y16[0][lo:hi], self.y[0][lo:hi].numel(), st)
             else:
-                res = self.y[l - 2] if c.second == 1 else None
+                res = self.y[l - 2][lo:hi] if c.second == 1 else None
                 if copies:
-                    call('fte_conv2d_fwd16', self.y16[l - 1], self.w16t[c.name], bv, av, res, zz, self.y[l], self.y16[l],
-                         n, c.hin, c.win, c.cin, c.cout, 3, c.stride, self.ws, self.ws_bytes, st)
+                    call('fte_conv2d_fwd16', self.y16[l - 1][lo:hi], self.w16t[c.name], bv, av, res, zz, self.y[l][lo:hi], self.y16[l][lo:hi],
+                         m, c.hin, c.win, c.cin, c.cout, 3, c.stride, ws, self.ws_bytes, st)
                 elif keep and self.vpack[l] is not None:
-                    call('fte_conv3x3_fwd_keep', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
-                         n, c.hin, c.win, c.cin, c.cout, c.stride, self.vpack[l], self.ws, self.ws_bytes, st)
+                    vp = self.vpack[l]
+                    if m != n:                               # a half shard's V pack is its half of the shard's (whole row blocks: _fwd_halves)
+                        vp = vp[(lo // m) * (vp.numel() // 2):(lo // m + 1) * (vp.numel() // 2)]
+                    call('fte_conv3x3_fwd_keep', self.y[l - 1][lo:hi], wv, bv, av, res, zz, self.y[l][lo:hi],
+                         m, c.hin, c.win, c.cin, c.cout, c.stride, vp, ws, self.ws_bytes, st)
                 else:
-                    call('fte_conv3x3_fwd', self.y[l - 1], wv, bv, av, res, zz, self.y[l],
-                         n, c.hin, c.win, c.cin, c.cout, c.stride, self.ws, self.ws_bytes, st)
+                    call('fte_conv3x3_fwd', self.y[l - 1][lo:hi], wv, bv, av, res, zz, self.y[l][lo:hi],
+                         m, c.hin, c.win, c.cin, c.cout, c.stride, ws, self.ws_bytes, st)
+
+        if self._fwd_halves(n, copies):
+            # Two half shards, one per stream: layer l of one half runs beside the tile transform of the other (an HBM-bound kernel of
+            # 68 registers under an MFMA-bound resident one), and the CUs a launch's last, partly filled round leaves idle go to the
+            # other half's launch.  Exact: no forward kernel of this net looks across images.
+            main, side = torch.cuda.current_stream(), self.side
+            side.wait_stream(main)
+            for l, c in enumerate(self.convs):
+                layer(l, c, 0, n // 2, self.ws, st)
+                layer(l, c, n // 2, n, self.ws_side, side.cuda_stream)
+            main.wait_stream(side)
+        else:
+            for l, c in enumerate(self.convs):
+                layer(l, c, 0, n, self.ws, st)
         call('fte_gemm_nn', self.y[-1], self.view(self.name + '/fully_connected/weights'),
              self.view(self.name + '/fully_connected/biases'), self.emb, n, EMBED, self.fin, self.ws, self.ws_bytes, st)
         return self.emb
