@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256 * NWN, 1) void wino_mm_kernel(const WinoMMParam
 #ifdef FTE_WINO_STAMP
         if (g_wino_stamp) { st1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); }
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           // stage 1 (the last K-step's) is free: the epilogue's exchange buffer
+        // stage 1 (the last K-step's) becomes the epilogue's exchange buffer.  vmcnt(0): the last K-step's DMA slots ran on descriptors of
+        // zero records, and an out-of-range LDS-DMA load still WRITES its zeros -- into stage 1, possibly after the exchange values (seen
+        // as a rare wrong output of the half-tile kernel, whose last DMA slot is the loop's last instruction)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
         // ---- output transform Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]], M[i][j] = plane t = 4 i + j.  This wave holds rows i = 2q, 2q+1.
         // P[i][b] = (M A)[i][b];  Y[0][b] = (P0 + P1) + P2,  Y[1][b] = P1 + (-P2 - P3): the q = 0 wave finishes output row 0 and receives
@@ -641,6 +644,9 @@ __global__ __launch_bounds__(512, 1) void wino_wgrad_kernel(const float* __restr
             __builtin_amdgcn_sched_barrier(0);
         });
     }
+    // (the last two steps' DMA slots ran on descriptors of zero records: such a load still writes zeros to LDS -- let them land before
+    // the block can end and its LDS go to another block)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // raw partial planes -> slabs[split][t][cin][cout]
     const size_t plane = (size_t)cin * cout;
 #pragma unroll
