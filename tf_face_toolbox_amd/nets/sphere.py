@@ -344,7 +344,7 @@ class SphereNet(Network):
             wv = self.view(c.name + '/weights')
             bv = self.view(c.name + '/biases') if c.has_bias else None
             av = self.view(c.name + '/alpha')
-            zz = self.z[l][lo:hi] if keep else None
+            zz = self.z[l][lo:hi] if keep and self.z[l] is not None else None      # (bf16 storage keeps fp32 z / y for the last layer only)
             if s16:
                 # bf16 storage: every layer writes bf16 z / y only (+ the unrounded fp32 pair for the last layer: the dense layer reads it)
                 z16 = self.z16[l][lo:hi] if keep else None
