@@ -282,6 +282,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` leg (N = 1 only, ~15 s)')
+    ap.add_argument('--one-stream', action='store_true',
+                    help='profiling only: EVERY step runs as the launch-record steps do (one chain of kernels, no second stream), so that '
+                         'rocprofv3 kernel durations and PMC bytes are each launch\'s own (scripts/collect_profiles.sh); the value printed is '
+                         'then not the metric')
     ap.add_argument('--global-batch', type=int, default=GLOBAL_BATCH,
                     help='exploration only (e.g. the per-rank shard sizes of N=2/4/8 on one GPU); the metric is quoted at 512')
     ap.add_argument('--mfma-dtype', choices=['f32', 'bf16', 'bf16s'], default='f32',
@@ -345,6 +349,7 @@ def main():
         torch.cuda.synchronize()
 
     peak = FP32_MFMA_PEAK_TFLOPS if args.mfma_dtype == 'f32' else BF16_MFMA_PEAK_TFLOPS
+    net.one_stream = args.one_stream
     for _ in range(args.warmup):
         train_ops()
     barrier()
@@ -359,6 +364,7 @@ def main():
         PROF_EVERY = max(4, (args.steps + 1) // 2)
     prof = os.environ.get('FTE_BENCH_NO_PROF') != '1'
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step device times (no host sync)
+    net.one_stream = args.one_stream
     first = True
     t0 = time.perf_counter()
     marks[0].record()
@@ -371,7 +377,7 @@ def main():
         train_ops()
         if prof and i % PROF_EVERY == 0:
             _lib.query('fte_prof_enable', 0)
-            net.one_stream = False
+            net.one_stream = args.one_stream
         marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -499,7 +505,11 @@ def main():
                           'winograd_launches_per_step': round(sum(v[0] for k, v in table.items() if k.startswith('wino_')) / sampled, 2),
                           'direct_mfma_launches_per_step': round(sum(v[0] for k, v in table.items() if not k.startswith('wino_')) / sampled, 2),
                           'note': 'Winograd F(2x2,3x3) forward / data gradient and F(3x3,2x2) filter gradient on the stride-1 3x3 layers of '
-                                  '>= 128 channels, forward + filter gradient of the 64-channel stage; direct implicit GEMM elsewhere'},
+                                  '>= 128 channels, forward + filter gradient of the 64-channel stage; direct implicit GEMM elsewhere',
+                          # how the timed steps walk the net (the launch-record steps behind `roofline` run one chain of kernels instead)
+                          'forward_walk': ('two half shards on two streams' if getattr(net, '_fwd_halves', None) is not None and not args.one_stream
+                                           and net._fwd_halves(shard, _lib.get_mfma_dtype() == 'bf16') else 'one chain'),
+                          'backward_walk': 'filter gradients on a second stream' if two_streams and not args.one_stream else 'one chain'},
             # step_mfma_frac: DIRECT-CONVOLUTION-EQUIVALENT FLOPs of the step (12.27 GFLOP per image) / time / peak -- the
             # metric's own FLOP count; under Winograd the kernels execute fewer FLOPs, so this figure is not bounded by 1.
             # step_mfma_frac_executed: the FLOPs the MFMA launches of a recorded step actually execute / the step time / peak (<= 1)

@@ -293,30 +293,35 @@ class SphereNet(Network):
             images = images.contiguous()
         return images
 
-    def _fwd_halves(self, n, copies):
-        """Forward walk as two half shards on two streams?  fp32 Winograd plan only (the direct kernels fill the chip by themselves and
-        have no HBM-bound companion), even shards whose halves end on whole 64-tile row blocks of every kept V pack and plan the same
-        algorithm per layer.  FTE_FWD_HALVES=0 / 1 forces it off / on where it is possible."""
+    def _fwd_split(self, n, copies):
+        """Forward walk as two part shards on two streams: the size of the first part, or 0 (one chain).  fp32 Winograd plan only (the
+        direct kernels fill the chip by themselves and have no HBM-bound companion); both parts must end on whole 64-tile row blocks of
+        every kept V pack and plan the same algorithm per layer as the whole shard.  FTE_FWD_HALVES=0 / 1 forces it off / on where it is
+        possible; FTE_FWD_SPLIT=<images> moves the split point off the middle (exploration)."""
         env = os.environ.get('FTE_FWD_HALVES', 'auto')
-        if env == '0' or copies or self.side is None or n % 2 or n < 2:
-            return False
+        if env == '0' or copies or self.side is None or n < 2 or getattr(self, 'one_stream', False):      # (one_stream: bench.py's launch-record steps)
+            return 0
         key = (n, getattr(self, '_act_key', None))
-        if getattr(self, '_halves_key', None) != key:
+        if getattr(self, '_split_key', None) != key:
             q = _lib.query
-            ok, any_w = True, False
+            a = int(os.environ.get('FTE_FWD_SPLIT', n // 2))
+            ok, any_w = 0 < a < n, False
             for l, c in enumerate(self.convs):
-                if l == 0 or c.stride != 1:
+                if l == 0 or c.stride != 1 or not ok:
                     continue
-                a_full, a_half = (q('fte_conv3x3_algo', m, c.hin, c.win, c.cin, c.cout, 1, 0) for m in (n, n // 2))
-                any_w = any_w or a_full == 1
-                if a_full != a_half:
+                algo = [q('fte_conv3x3_algo', m, c.hin, c.win, c.cin, c.cout, 1, 0) for m in (n, a, n - a)]
+                any_w = any_w or algo[0] == 1
+                if algo[1] != algo[0] or algo[2] != algo[0]:
                     ok = False
-                if self.vpack[l] is not None and ((n // 2) * ((c.hin + 1) // 2) * ((c.win + 1) // 2)) % 64:
+                if self.vpack[l] is not None and (a * ((c.hin + 1) // 2) * ((c.win + 1) // 2)) % 64:
                     ok = False
-            self._halves_key, self._halves_ok = key, ok and any_w
-        if not self._halves_ok:
-            return False
-        return env == '1' or n >= int(os.environ.get('FTE_FWD_HALVES_MIN', '128'))
+            self._split_key, self._split = key, (a if ok and any_w else 0)
+        if not self._split:
+            return 0
+        return self._split if env == '1' or n >= int(os.environ.get('FTE_FWD_HALVES_MIN', '128')) else 0
+
+    def _fwd_halves(self, n, copies):
+        return self._fwd_split(n, copies) > 0
 
     def backbone(self, inputs, is_training=False, reuse=None):
         """nets/sphere.py:47-76: [N,H,W,C] NHWC -> embedding [N,512] (a view of an internal buffer)."""
@@ -365,23 +370,25 @@ class SphereNet(Network):
                          m, c.hin, c.win, c.cin, c.cout, 3, c.stride, ws, self.ws_bytes, st)
                 elif keep and self.vpack[l] is not None:
                     vp = self.vpack[l]
-                    if m != n:                               # a half shard's V pack is its half of the shard's (whole row blocks: _fwd_halves)
-                        vp = vp[(lo // m) * (vp.numel() // 2):(lo // m + 1) * (vp.numel() // 2)]
+                    if m != n:                               # a part shard's V pack is its part of the shard's (whole row blocks: _fwd_split)
+                        per = ((c.hin + 1) // 2) * ((c.win + 1) // 2) * c.cin * 16      # floats per image
+                        vp = vp[lo * per:hi * per]
                     call('fte_conv3x3_fwd_keep', self.y[l - 1][lo:hi], wv, bv, av, res, zz, self.y[l][lo:hi],
                          m, c.hin, c.win, c.cin, c.cout, c.stride, vp, ws, self.ws_bytes, st)
                 else:
                     call('fte_conv3x3_fwd', self.y[l - 1][lo:hi], wv, bv, av, res, zz, self.y[l][lo:hi],
                          m, c.hin, c.win, c.cin, c.cout, c.stride, ws, self.ws_bytes, st)
 
-        if self._fwd_halves(n, copies):
-            # Two half shards, one per stream: layer l of one half runs beside the tile transform of the other (an HBM-bound kernel of
-            # 68 registers under an MFMA-bound resident one), and the CUs a launch's last, partly filled round leaves idle go to the
-            # other half's launch.  Exact: no forward kernel of this net looks across images.
+        split = self._fwd_split(n, copies)
+        if split:
+            # Two part shards (halves), one per stream: layer l of one part runs beside the tile transform of the other (an HBM-bound
+            # kernel of 68 registers under an MFMA-bound resident one), and the CUs a launch's last, partly filled round leaves idle go
+            # to the other part's launch.  Exact: no forward kernel of this net looks across images.
             main, side = torch.cuda.current_stream(), self.side
             side.wait_stream(main)
             for l, c in enumerate(self.convs):
-                layer(l, c, 0, n // 2, self.ws, st)
-                layer(l, c, n // 2, n, self.ws_side, side.cuda_stream)
+                layer(l, c, 0, split, self.ws, st)
+                layer(l, c, split, n, self.ws_side, side.cuda_stream)
             main.wait_stream(side)
         else:
             for l, c in enumerate(self.convs):
