@@ -236,9 +236,10 @@ def op_kind(key, sym=''):
     return 'dgrad' if epi == 1 or bl == 1 else 'fwd'
 
 
-def time_other_configs(dev, steps=10, warmup=3):
+def time_other_configs(dev, steps0=10, warmup0=3):
     """One GPU, synthetic inputs, whole training steps (forward + loss + backward + optimizer) of the other BASELINE.json configs at their
-    per-GPU shards and of SphereNet at the 2 / 4 / 8-GPU shards: device time over `steps` steps after `warmup`, by events on the stream."""
+    per-GPU shards and of SphereNet at the 2 / 4 / 8-GPU shards: device time over `steps0` steps after `warmup0` (four times as many for
+    shards of <= 128 images), by events on the stream."""
     import torch
     from tf_face_toolbox_amd import net_select, Singular, _lib
     out = []
@@ -252,6 +253,9 @@ def time_other_configs(dev, steps=10, warmup=3):
             net = net_select(name, 'NCHW', 5e-4)
             step, losses, names, _ = Singular(net, 1e-4, 'Momentum')({'images': x, 'labels': y, 'num_classes': NUM_CLASSES, 'num_examples': b,
                                                                      'batch_size': b})
+            # (the short steps get more of them: 13 steps of 6 ms end before the clocks have settled -- 64 images read 6.56 ms here
+            # against 5.97 ms in a 120-step run of the same shard)
+            steps, warmup = (steps0, warmup0) if b > 128 else (4 * steps0, 4 * warmup0)
             for _ in range(warmup):
                 step()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
