@@ -283,5 +283,5 @@ def test_profile_tables_regenerate_from_the_committed_profiles(capsys):
     assert out.count('bn_bwd_apply_kernel') >= 3 and 'at::native' not in out.split('### config 3')[1]
     for name, key in (('headline_symbols.json', 'conv_symbols'), ('symbols_resnext50_bf16s_b128.json', None)):
         d = json.load(open(os.path.join(root, 'tests', 'golden', name)))
-        assert 'r5_' in d['source'], name
+        assert ('r6_' if name.startswith('headline') else 'r5_') in d['source'], name      # SphereNet: round 6's profiles; the BN nets': round 5's
         assert (d[key] if key else [v for k, v in d.items() if isinstance(v, list)][0])
