@@ -34,6 +34,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  time with the all-reduce switched off (what the collective costs after overlap).
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -272,7 +273,8 @@ def time_other_configs(dev, steps0=10, warmup0=3):
             out.append({'net': name, 'dtype': mode, 'images': b, 'ms_per_step': round(1e3 * wall, 3), 'device_ms_per_step': round(dev_ms, 3),
                         'images_per_sec': round(b / wall, 1), 'steps': steps, 'finite': all(v == v and abs(v) < 1e30 for v in vals)})
             del step, net, x, y, losses
-            torch.cuda.empty_cache()
+            gc.collect()                           # (the net and its step closure are a reference cycle: left to the collector, its buffers are
+            torch.cuda.empty_cache()               # freed -- device-synchronising hipFree calls -- inside the NEXT config's timed steps)
         except Exception as e:                     # a config that fails is reported, never silently dropped
             out.append({'net': name, 'dtype': mode, 'images': b, 'error': '%s: %s' % (type(e).__name__, e)})
     _lib.set_mfma_dtype(prev)

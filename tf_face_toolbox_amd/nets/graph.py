@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 
 from .. import _lib
-from .net_base import Network
+from .net_base import Network, side_stream
 from .sphere import Variable, same_pads
 
 BN_EPS = 1e-3          # nets/resnet.py:97-99 via layers.batch_norm defaults
@@ -713,7 +713,7 @@ class GraphNet(Network):
         self.ws = torch.empty((need + 3) // 4 + 1024, **f32)
         self.ws_bytes = self.ws.numel() * 4
         # filter gradients run on a second HIP stream beside the data-gradient chain (backward_body): their own workspace
-        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('FTE_SIDE_PRIO', '0'))) if os.environ.get('FTE_SIDE_STREAM', '1') != '0' else None
+        self.side = side_stream(dev, int(os.environ.get('FTE_SIDE_PRIO', '0'))) if os.environ.get('FTE_SIDE_STREAM', '1') != '0' else None
         self.ws_side = torch.empty_like(self.ws) if self.side is not None else self.ws
         self.side_batch = int(os.environ.get('FTE_SIDE_BATCH', '3'))
         self._act_n = n

@@ -90,3 +90,21 @@ class Network(abc.ABC):
 
     def mult_lr_list(self, scope=None):
         return [1.0 for _ in self.param_list(is_training=True, trainable=True, scope=scope)]
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, priority=0):
+    """The process's second stream on `device` (filter gradients beside the data-gradient chain, the forward walk's second half shard, the
+    BN nets' side work): ONE per (device, priority), shared by every net of the process.  A stream per net made the walk's overlap a
+    matter of luck: the runtime maps streams onto a few hardware queues round-robin, and the n-th stream created can share its queue
+    with the current stream -- the 64-image SphereNet step then read 6.5 ms instead of 5.9 in bench.py's `other_configs` leg, depending
+    on which nets had been built before it."""
+    import torch
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(priority))
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev, priority=int(priority))
+    return s

@@ -22,7 +22,7 @@ from collections import OrderedDict
 import torch
 
 from .. import _lib
-from .net_base import Network
+from .net_base import Network, side_stream
 
 NUM_BLOCKS = (1, 2, 4, 1)     # nets/sphere.py:58,62,66,70
 EMBED = 512                   # nets/sphere.py:73
@@ -254,7 +254,7 @@ class SphereNet(Network):
         self.ws_bytes = self.ws.numel() * 4
         # filter gradients run on a second stream beside the data gradient of the same layer (_body_walk); their split-K slabs
         # need a workspace of their own
-        self.side = torch.cuda.Stream(device=self.device) if os.environ.get('FTE_SIDE_STREAM', '1') != '0' else None
+        self.side = side_stream(self.device) if os.environ.get('FTE_SIDE_STREAM', '1') != '0' else None
         self.ws_side = torch.empty_like(self.ws) if self.side is not None else self.ws
         self._act_n = n
         self.y16 = None                                   # allocated on first use (_alloc_copies)
