@@ -41,9 +41,9 @@ def _pass(net, x, y, ncls, noise):
 
 
 @pytest.mark.parametrize('name,mode,n,hw', [
-    ('SphereNet-ASoftmax', 'f32', 64, (112, 96)),        # the 8-GPU shard: half-tile Winograd products, stream-K, two-stream backward walk
-    ('SphereNet-ASoftmax', 'f32', 136, (112, 96)),       # forward walk as two half shards, whole-tile products of several rounds
-    ('SphereNet-ASoftmax', 'f32', 6, (112, 96)),         # every Winograd launch a fraction of a round
+    ('SphereNet-ASoftmax', 'f32', 64, (112, 112)),       # the 8-GPU shard: half-tile Winograd products, stream-K, two-stream backward walk
+    ('SphereNet-ASoftmax', 'f32', 136, (112, 112)),      # forward walk as two part shards (64 + 72 images), whole-tile products of several rounds
+    ('SphereNet-ASoftmax', 'f32', 6, (112, 96)),         # every Winograd launch a fraction of a round (112 x 96: 7 x 6 tiles at 14 x 12)
     ('SphereNet-ASoftmax', 'bf16s', 64, (112, 96)),      # LDS-DMA bf16 kernels, bf16 storage
     ('ResNeXt-50-center', 'bf16s', 32, (112, 112)),      # the BN nets' fused kernels (pw16, igemm16_bn, grouped 3x3), two streams
     ('SENet-50-triplet', 'bf16s', 32, (112, 112)),
@@ -86,3 +86,39 @@ def test_training_pass_is_bit_stable_under_memory_noise(name, mode, n, hw):
         assert not bad, 'passes that differ from the quiet first one: %s' % bad[:4]
     finally:
         _lib.set_mfma_dtype(prev)
+
+
+@pytest.mark.parametrize('n', [136, 512])
+def test_part_shard_forward_walk_is_the_net_on_each_part(n):
+    """SphereNet fp32 at the BASELINE geometry: the forward walk as two part shards on two streams (nets/sphere.py backbone) leaves, for
+    each part, EXACTLY what the net computes for those images as a shard of their own (bit for bit: the same calls on the same data --
+    no forward kernel of this net looks across images, nets/sphere.py:38-45 has no batch statistics), repeats itself bit for bit, and
+    agrees with the one-chain walk over the whole shard within the forward tolerance (not bit for bit: the direct kernels of the
+    stride-2 layers split their K sums by the size of the launch)."""
+    from util_gpu import check_maxabs, host
+    ncls = 10575
+    g = torch.Generator().manual_seed(23)
+    x = (torch.rand(n, 112, 112, 3, generator=g) * 2 - 1).cuda()
+    y = torch.randint(0, ncls, (n,), generator=g, dtype=torch.int32).cuda()
+    net = net_select('SphereNet-ASoftmax', 'NCHW', 5e-4)
+    net.seed = 4
+    net.build(112, 112, 3, ncls, 'cuda')
+    a = n // 2 // 64 * 64
+    net.one_stream = False
+    l0, g0 = _pass(net, x, y, ncls, lambda: None)
+    assert net._fwd_split(n, False) == a, 'the part-shard walk is not on at %d images' % n
+    emb0, logits0, y0 = net.emb.clone(), net.s_raw.clone(), net.y[-1].clone()      # (y[-1]: the last conv layer's output, the dense layer's input)
+    l1, g1 = _pass(net, x, y, ncls, lambda: None)
+    assert l1 == l0 and torch.equal(g1, g0) and torch.equal(net.emb, emb0)
+    assert float(g0.abs().max()) > 0
+    net.one_stream = True                                    # ONE chain over the whole shard (what bench.py's launch-record steps run)
+    l2, _ = _pass(net, x, y, ncls, lambda: None)
+    assert net._fwd_split(n, False) == 0
+    check_maxabs(host(net.emb), host(emb0), 2e-5, 'embeddings: part shards vs one chain')
+    check_maxabs(host(net.s_raw), host(logits0), 2e-5, 'logits: part shards vs one chain')
+    assert abs(l2[0] - l0[0]) <= 1e-5 * abs(l0[0])
+    for lo, hi in ((0, a), (a, n)):                          # each part as a shard of its own, one chain
+        net.forward(x[lo:hi].contiguous(), y[lo:hi].contiguous(), num_classes=ncls, is_training=True)
+        torch.cuda.synchronize()
+        assert torch.equal(net.y[-1], y0[lo:hi]), 'part [%d, %d) differs from the net on those images alone' % (lo, hi)
+    net.one_stream = False

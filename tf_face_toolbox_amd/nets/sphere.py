@@ -16,6 +16,7 @@ MI355X-first layout decisions (engine-internal; the boundary keeps the reference
   * every conv keeps z (pre-activation) and y = PReLU(z) (+shortcut): backward needs sign(z)
     and min(z,0) exactly, for any alpha.
 """
+import math
 import os
 from collections import OrderedDict
 
@@ -295,16 +296,22 @@ class SphereNet(Network):
 
     def _fwd_split(self, n, copies):
         """Forward walk as two part shards on two streams: the size of the first part, or 0 (one chain).  fp32 Winograd plan only (the
-        direct kernels fill the chip by themselves and have no HBM-bound companion); both parts must end on whole 64-tile row blocks of
-        every kept V pack and plan the same algorithm per layer as the whole shard.  FTE_FWD_HALVES=0 / 1 forces it off / on where it is
-        possible; FTE_FWD_SPLIT=<images> moves the split point off the middle (exploration)."""
+        direct kernels fill the chip by themselves and have no HBM-bound companion).  The first part must end on a whole 64-tile row
+        block of every kept V pack (the second part's pack is the rest of the shard's): the split point is the multiple of that
+        granule nearest below the middle (112 x 112: 64 images), and both parts must plan the same algorithm per layer as the whole
+        shard.  FTE_FWD_HALVES=0 / 1 forces it off / on where it is possible; FTE_FWD_SPLIT=<images> moves the split point (exploration)."""
         env = os.environ.get('FTE_FWD_HALVES', 'auto')
         if env == '0' or copies or self.side is None or n < 2 or getattr(self, 'one_stream', False):      # (one_stream: bench.py's launch-record steps)
             return 0
         key = (n, getattr(self, '_act_key', None))
         if getattr(self, '_split_key', None) != key:
             q = _lib.query
-            a = int(os.environ.get('FTE_FWD_SPLIT', n // 2))
+            gran = 1
+            for l, c in enumerate(self.convs):
+                if self.vpack[l] is not None:
+                    tpi = ((c.hin + 1) // 2) * ((c.win + 1) // 2)
+                    gran = max(gran, 64 // math.gcd(64, tpi))      # (powers of two: the largest is their common multiple)
+            a = int(os.environ.get('FTE_FWD_SPLIT', (n // 2) // gran * gran))
             ok, any_w = 0 < a < n, False
             for l, c in enumerate(self.convs):
                 if l == 0 or c.stride != 1 or not ok:
@@ -372,7 +379,7 @@ class SphereNet(Network):
                     vp = self.vpack[l]
                     if m != n:                               # a part shard's V pack is its part of the shard's (whole row blocks: _fwd_split)
                         per = ((c.hin + 1) // 2) * ((c.win + 1) // 2) * c.cin * 16      # floats per image
-                        vp = vp[lo * per:hi * per]
+                        vp = vp[lo * per:hi * per] if hi < n else vp[lo * per:]        # (the last part keeps the shard's padding rows)
                     call('fte_conv3x3_fwd_keep', self.y[l - 1][lo:hi], wv, bv, av, res, zz, self.y[l][lo:hi],
                          m, c.hin, c.win, c.cin, c.cout, c.stride, vp, ws, self.ws_bytes, st)
                 else:
@@ -383,7 +390,9 @@ class SphereNet(Network):
         if split:
             # Two part shards (halves), one per stream: layer l of one part runs beside the tile transform of the other (an HBM-bound
             # kernel of 68 registers under an MFMA-bound resident one), and the CUs a launch's last, partly filled round leaves idle go
-            # to the other part's launch.  Exact: no forward kernel of this net looks across images.
+            # to the other part's launch.  No forward kernel of this net looks across images: each part comes out bit for bit as the
+            # net computes it for those images as a shard of their own (against ONE launch over the whole shard the direct kernels of
+            # the stride-2 layers may split their K sums differently: ~1e-7 relative; tests/test_gpu_stress.py).
             main, side = torch.cuda.current_stream(), self.side
             side.wait_stream(main)
             for l, c in enumerate(self.convs):
