@@ -54,6 +54,9 @@ __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, char* lds
 }
 
 constexpr unsigned OOB = 0x80000000u;
+#ifndef WMM_ABL
+#define WMM_ABL 0      // diagnostic builds only (scripts/dev/build_wino_stamp.sh, EXTRA=-DWMM_ABL=n): 1 = no DMA in the K loop, 2 = no fragment reads, 4 = no mid-step barrier (wrong results, right timing)
+#endif
 constexpr int SLAB_F = 16 * 64 * 8;            // floats per (row block, K-step) slab
 constexpr int SLAB_B = SLAB_F * 4;             // 32 KiB
 
@@ -293,12 +296,13 @@ __global__ __launch_bounds__(256 * NWN, 1) void wino_mm_kernel(const WinoMMParam
             static_for<0, 16>([&](auto ic) {
                 constexpr int idx = decltype(ic)::value, j = idx >> 2, t = idx & 3;
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[t][j], xb4[t][j], acc[t], 0, 0, 0);
-                if constexpr (idx < 4) read_frags(st, 1, ya, yb, idx);
+                if constexpr (idx < 4 && !(WMM_ABL & 2)) read_frags(st, 1, ya, yb, idx);
                 __builtin_amdgcn_sched_barrier(0);
             });
             // this wave's pieces of step g + 1 have landed.  In a tile's first step behind an epilogue they are OLDER than the epilogue's
             // 16 stores (vector-memory operations retire in issue order): vmcnt(16) leaves the stores draining under the MFMAs
-            if (s == 0 && !first) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (WMM_ABL & 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (s == 0 && !first) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             // ---- half 1 ----
             // step g + 2: of this tile, or step 0 / 1 of the block's next tile (step 1 of the next tile waits for the epilogue)
@@ -324,8 +328,8 @@ __global__ __launch_bounds__(256 * NWN, 1) void wino_mm_kernel(const WinoMMParam
                 constexpr int idx = decltype(ic)::value, j = idx >> 2, t = idx & 3;
                 acc[4 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[t][j], yb[t][j], acc[4 + t], 0, 0, 0);
                 // (the fragments of the step after the block's very last one are read from a stage nobody refills: unused)
-                if constexpr (idx < 4) read_frags(st ^ 1, 0, xa, xb4, idx);
-                if constexpr (idx >= 4 && idx < 4 + NDMA) dma_piece(rsA, rsB, ds, st, idx - 4);      // (no step g + 2: descriptors of zero records)
+                if constexpr (idx < 4 && !(WMM_ABL & 2)) read_frags(st ^ 1, 0, xa, xb4, idx);
+                if constexpr (idx >= 4 && idx < 4 + NDMA && !(WMM_ABL & 1)) dma_piece(rsA, rsB, ds, st, idx - 4);      // (no step g + 2: descriptors of zero records)
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
