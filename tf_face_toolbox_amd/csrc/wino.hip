@@ -809,11 +809,14 @@ hipError_t wino_wgrad(const float* V, const float* dz, float* slabs, float* dw, 
     const size_t db = (size_t)g.n * g.h * g.w * cout * 4;
     if (db >= ((size_t)1 << 31)) return hipErrorInvalidValue;      // buffer range
     const size_t lds = 4 * (size_t)WG_OP;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<unsigned> attr{0u};               // per device (bit), as wino_mm_launch's
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (!(attr.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr.fetch_or(bit, std::memory_order_release);
     }
     const int sig[5] = {AL_KM, BL_KN, EPI_FWD, 8, S};
     const double flops = 2.0 * 16.0 * (double)g.MB * 64.0 * cin * cout;
