@@ -18,12 +18,14 @@ gradient all-reduce + optimizer (one `sess.run(train_ops)` of train.py:228) on s
 already resident in HBM.  Strong scaling: rank r works on rows [r*512/N, (r+1)*512/N).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel symbol (most device time among the MFMA launches; for this workload the fp32-MFMA
-                 implicit-GEMM conv3x3 forward igemm_kernel<64,64,2,2,MK,KN,FWD>).  Its launches inside every 4th timed step
-                 are bracketed by a HIP event pair on the launch stream (fte_prof_*, include/fte.h); achieved = sum of the
-                 launches' algorithmic FLOPs (2*rows*N*K each) / sum of their durations, against the 157.3 TFLOP/s fp32
-                 matrix peak.  avg_launch_ms is directly comparable with the AverageNs of the same symbol in
-                 profiles/*kernel_stats.csv.  `per_shape` lists every (op, GEMM shape) of the step: fwd / dgrad / wgrad of
+  roofline     : the dominant kernel symbol (most device time among the MFMA launches; since round 6 the Winograd product of the
+                 conv3x3 forward pass, wino_mm_kernel<0,2>; with FTE_CONV_ALGO=direct an igemm_kernel<...> instantiation).  Its
+                 launches inside the recorded steps (two of the timed steps at 512 images, every 4th where the net walks one
+                 stream anyway) are bracketed by a HIP event pair on the launch stream (fte_prof_*, include/fte.h); a recorded
+                 step runs ONE chain of kernels (no second stream, no half shards) so that a launch's duration is its own;
+                 achieved = sum of the FLOPs the launches EXECUTE (Winograd: 2*16*tiles*N*K; direct: 2*rows*N*K) / sum of
+                 their durations, against the 157.3 TFLOP/s fp32 matrix peak.  avg_launch_ms is directly comparable with the
+                 AverageNs of the same symbol in profiles/*kernel_stats.csv (collected with --one-stream: every step that way).  `per_shape` lists every (op, GEMM shape) of the step: fwd / dgrad / wgrad of
                  the four stages, the stride-2 entries, FC and classifier -- ms, TFLOP/s, fraction of peak, and the
                  algorithmic bytes / s of that launch (every operand and result tensor once);
   cpu_baseline : BASELINE.md section 3: the float32 torch-CPU restatement of the reference graph (oracle/torch_ref.py,
