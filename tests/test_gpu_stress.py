@@ -123,4 +123,12 @@ def test_part_shard_forward_walk_is_the_net_on_each_part(n):
         net.forward(x[lo:hi].contiguous(), y[lo:hi].contiguous(), num_classes=ncls, is_training=True)
         torch.cuda.synchronize()
         assert torch.equal(net.y[-1], y0[lo:hi]), 'part [%d, %d) differs from the net on those images alone' % (lo, hi)
+    # the flip-averaged evaluation features (nets/sphere.py:97-101) take the same walk: two streams against one chain
+    net.one_stream = False
+    f2 = net.forward(x, None, num_classes=ncls, is_training=False).clone()
+    net.one_stream = True
+    f1 = net.forward(x, None, num_classes=ncls, is_training=False).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(f2).all() and float(f2.abs().max()) > 0
+    check_maxabs(host(f2), host(f1), 2e-5, 'evaluation features: part shards vs one chain')
     net.one_stream = False
